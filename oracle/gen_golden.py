@@ -1,0 +1,342 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE itself (build container only).
+
+    python oracle/gen_golden.py            # writes tests/golden/*.npz
+
+TEST INFRASTRUCTURE.  Imports /root/reference with the stub packages in
+oracle/ref_shims (omegaconf / hydra / bitarray are absent in the image) and the two
+compat preludes from SURVEY.md Appendix C; builds ``S2STTransformerModel`` +
+``Tacotron2Criterion`` through the reference's own constructors, loads name-keyed
+synthetic weights (oracle/synth_weights.py), runs forward / backward / optimizer steps
+on seeded synthetic batches and stores inputs-by-seed + expected outputs.  Nothing from
+the reference is copied: the fixtures are numbers.  /root/reference does not exist on
+the GPU box; the committed .npz files are what travels.
+"""
+import argparse
+import os
+import sys
+import importlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+sys.path.insert(0, os.path.join(HERE, "ref_shims"))
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+for _n, _t in dict(float=float, int=int, bool=bool, object=object, complex=complex, str=str).items():
+    if not hasattr(np, _n):
+        setattr(np, _n, _t)
+torch._C.has_cudnn = False
+
+import fairseq  # noqa: E402
+from fairseq.data import Dictionary  # noqa: E402
+from examples.s2s_trans.models.s2st_transformer import (  # noqa: E402
+    S2STTransformerModel, base_architecture)
+from examples.s2s_trans.criterions.s2st_loss import Tacotron2Criterion  # noqa: E402
+from fairseq.optim.adam import Adam as RefAdam  # noqa: E402
+from fairseq.utils import clip_grad_norm_ as ref_clip  # noqa: E402
+
+from configs import CONFIGS  # noqa: E402
+from synth_weights import load_synth  # noqa: E402
+import s2st_oracle as O  # noqa: E402
+
+import s2st_amd  # noqa: E402,F401
+D = importlib.import_module("speech-to-speech-translation_amd.data")
+
+
+def make_dict(n):
+    d = Dictionary()
+    for i in range(n - 4):
+        d.add_symbol(f"s{i}")
+    assert len(d) == n
+    return d
+
+
+def build_reference(cfg):
+    a = O.make_args(**cfg)  # same flag values the oracle sees
+    ns = argparse.Namespace(**vars(a))
+    base_architecture(ns)
+    src_d, tgt_d = make_dict(a.src_vocab_size), make_dict(a.tgt_vocab_size)
+
+    class FakeTask:
+        source_dictionary = src_d
+        target_dictionary = tgt_d
+        src_dict = src_d
+        tgt_dict = tgt_d
+        args = ns
+
+        @staticmethod
+        def get_speaker_embeddings(args, dim):
+            return None
+
+    ns.speaker_to_id = None
+    ns.speaker_emb_path = None
+    model = S2STTransformerModel.build_model(ns, FakeTask)
+    crit = Tacotron2Criterion(
+        FakeTask, sentence_avg=False, n_frames_per_step=a.n_frames_per_step,
+        use_guided_attention_loss=a.use_guided_attention_loss,
+        guided_attention_loss_sigma=a.guided_attention_loss_sigma,
+        bce_pos_weight=a.bce_pos_weight, ctc_weight=a.ctc_weight,
+        asr_ce_weight=a.asr_ce_weight, st_ce_weight=a.st_ce_weight,
+        l1_loss_weight=a.l1_loss_weight, mse_loss_weight=a.mse_loss_weight,
+        eos_loss_weight=a.eos_loss_weight, attn_loss_weight=a.attn_loss_weight,
+        label_smoothing=a.label_smoothing, report_accuracy=True)
+    return a, model, crit
+
+
+FULL_GRADS_TINY = [
+    "decoder.pos_emb_alpha", "encoder.subsample.conv_layers.0.bias",
+    "encoder.subsample.conv_layers.1.weight",
+    "encoder.transformer_layers.0.self_attn.q_proj.weight",
+    "encoder.transformer_layers.0.self_attn.k_proj.bias",
+    "encoder.transformer_layers.1.fc1.weight", "encoder.layer_norm.weight",
+    "decoder.prenet.0.layers.0.0.weight", "decoder.prenet.1.bias",
+    "decoder.transformer_layers.1.encoder_attn.v_proj.weight",
+    "decoder.transformer_layers.0.self_attn.out_proj.weight",
+    "decoder.transformer_layers.1.final_layer_norm.bias",
+    "decoder.feat_proj.bias", "decoder.eos_proj.weight",
+    "decoder.postnet.convolutions.0.0.weight", "decoder.postnet.convolutions.2.1.weight",
+    "decoder.postnet.convolutions.4.1.bias", "decoder.ctc_proj.weight",
+    "aux_asr_decoder.embed_tokens.weight", "aux_asr_decoder.project_in_dim.weight",
+    "aux_asr_decoder.layers.0.encoder_attn.k_proj.weight",
+    "aux_st_decoder.output_projection.weight", "aux_st_decoder.project_out_dim.weight",
+    "encoder.aux_asr_norm.weight",
+]
+
+
+from configs import golden_sample as sample_for  # noqa: E402
+
+
+def to_np(t):
+    return t.detach().cpu().numpy()
+
+
+SUB_STRIDE = 61
+
+
+def sub(x):
+    """Tensors above 40k elements are stored as a strided subsample of the flat view
+    (tests apply the same rule: flat[::61])."""
+    return x if x.size <= 40000 else x.reshape(-1)[::SUB_STRIDE].copy()
+
+
+def run_config(name, out_dir, full=True, n_updates=3):
+    cfg = CONFIGS[name]
+    torch.manual_seed(0)
+    a, model, crit = build_reference(cfg)
+    load_synth(model, seed=0)
+    model.train()
+    sample = sample_for(name, 0)
+    out = {}
+    # ---- forward / backward on batch 0 ------------------------------------------------
+    loss, sample_size, log = crit(model, sample)
+    for k, v in log.items():
+        out[f"log.{k}"] = np.asarray(float(v))
+    loss.backward()
+    # second forward to capture tensors (BN running stats get a second update; captured
+    # after the FIRST call below via a fresh model instead)
+    gn = {n: float(p.grad.norm()) for n, p in model.named_parameters() if p.grad is not None}
+    out["grad_norm_names"] = np.array(sorted(gn.keys()))
+    out["grad_norms"] = np.array([gn[k] for k in sorted(gn.keys())], dtype=np.float64)
+    none_grads = [n for n, p in model.named_parameters() if p.grad is None]
+    out["grad_none_names"] = np.array(none_grads)
+    named = dict(model.named_parameters())
+    for n in FULL_GRADS_TINY:
+        if n in named and named[n].grad is not None:
+            out[f"grad.{n}"] = sub(to_np(named[n].grad))
+    sd = model.state_dict()
+    for k, v in sd.items():
+        if "running_" in k or "num_batches" in k:
+            out[f"buf.{k}"] = to_np(v)
+    # state-dict contract (Appendix A): names and shapes
+    out["sd_names"] = np.array(list(sd.keys()))
+    out["sd_shapes"] = np.array([",".join(str(int(s)) for s in v.shape) for v in sd.values()])
+
+    # ---- tensors of the same forward (fresh model so BN stats are single-step) ---------
+    a2, model2, crit2 = build_reference(cfg)
+    load_synth(model2, seed=0)
+    model2.train()
+    ni = sample["net_input"]
+    net = model2(
+        src_tokens=ni["src_speech"], src_lengths=ni["src_speech_lens"], collated_audios=None,
+        padding_mask=None, prev_output_tokens=ni["prev_output_tokens"],
+        prev_src_text_tokens=ni["prev_src_text_tokens"] if a.asr_ce_weight > 0 else None,
+        prev_tgt_text_tokens=ni["prev_tgt_text_tokens"] if a.st_ce_weight > 0 else None,
+        incremental_state=None, target_lengths=sample["target_lengths"], speaker=None)
+    (post, eos, extra), asr, st = net
+    enc = model2.encoder(ni["src_speech"], ni["src_speech_lens"], None, None)
+    tens = {"post_feat_out": post, "eos_out": eos, "feature_out": extra["feature_out"],
+            "attn": extra["attn"], "encoder_out": enc["encoder_out"][0]}
+    for i, t in enumerate(extra["out_middle_layers"]):
+        tens[f"tap{i}"] = t
+    if asr is not None:
+        tens["asr_logits"] = asr[0]
+    if st is not None:
+        tens["st_logits"] = st[0]
+    if a.ctc_weight > 0:
+        lp = model2.decoder.get_normalized_probs((post, eos, extra), True, None).transpose(0, 1)
+        tens["ctc_lprobs"] = lp
+        ilens = O.ctc_input_lengths(ni["src_speech_lens"], [5, 5])
+        out["int.ctc_greedy"] = to_np(O.ctc_greedy_path(lp, ilens))
+        out["int.ctc_input_lens"] = to_np(ilens)
+    out["int.stop_idx"] = to_np(O.stop_indices(eos))
+    out["int.encoder_lens"] = to_np(model2.encoder.subsample.get_out_seq_lens_tensor(ni["src_speech_lens"]))
+    for k, t in tens.items():
+        if t is None:
+            continue
+        t = to_np(t).astype(np.float32)
+        if full:
+            out[f"out.{k}"] = t
+        else:
+            out[f"sum.{k}"] = np.array([t.astype(np.float64).sum(), np.abs(t.astype(np.float64)).sum(),
+                                        float(np.sqrt((t.astype(np.float64) ** 2).sum()))])
+            out[f"head.{k}"] = t.reshape(-1)[:256].copy()
+
+    # ---- n optimizer updates with the reference's Adam / clip (trainer.py:838-873) -----
+    a3, model3, crit3 = build_reference(cfg)
+    load_synth(model3, seed=0)
+    model3.train()
+    params = [p for p in model3.parameters() if p.requires_grad]
+    opt = RefAdam(params, lr=0.0, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    LR, WARM, CLIP = 1e-3, 2, 0.02
+    losses, gnorms, lrs = [], [], []
+    for u in range(n_updates):
+        s = sample_for(name, u % 2)
+        opt.zero_grad()
+        for p in params:
+            p.grad = None
+        loss, ss, log = crit3(model3, s)
+        loss.backward()
+        for p in params:
+            if p.grad is not None:
+                p.grad.mul_(1.0 / float(ss))
+        gnorm = ref_clip(params, CLIP)
+        lr = O.inverse_sqrt_lr(u, LR, WARM)  # restated; checked vs the reference class below
+        for g in opt.param_groups:
+            g["lr"] = lr
+        opt.step()
+        losses.append(float(loss))
+        gnorms.append(float(gnorm))
+        lrs.append(lr)
+    out["train.loss"] = np.array(losses)
+    out["train.gnorm"] = np.array(gnorms)
+    out["train.lr"] = np.array(lrs)
+    out["train.hparams"] = np.array([LR, WARM, CLIP, n_updates])
+    pn = {n: float(p.detach().norm()) for n, p in model3.named_parameters()}
+    out["train.param_norm_names"] = np.array(sorted(pn.keys()))
+    out["train.param_norms"] = np.array([pn[k] for k in sorted(pn.keys())], dtype=np.float64)
+    named3 = dict(model3.named_parameters())
+    for n in FULL_GRADS_TINY[:8]:
+        if n in named3:
+            out[f"train.param.{n}"] = sub(to_np(named3[n]))
+    path = os.path.join(out_dir, f"s2st_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path)/1e6:.2f} MB, loss={losses}, gnorm={gnorms}")
+
+
+def lr_schedule_golden(out_dir):
+    """LR sequence from the reference's InverseSquareRootSchedule class."""
+    from fairseq.optim.lr_scheduler.inverse_square_root_schedule import InverseSquareRootSchedule
+    from fairseq.optim import FairseqOptimizer
+
+    class _Opt(FairseqOptimizer):
+        def __init__(self):
+            self._lr = 0.0
+
+        def set_lr(self, lr):
+            self._lr = lr
+
+        def get_lr(self):
+            return self._lr
+
+    res = {}
+    for lr, warm in [(1.5e-3, 4000), (1e-3, 2), (5e-4, 10)]:
+        cfg = argparse.Namespace(lr=[lr], warmup_updates=warm, warmup_init_lr=-1.0)
+        sch = InverseSquareRootSchedule(cfg, _Opt())
+        steps = [0, 1, 2, 3, 5, 9, 10, 11, 100, 3999, 4000, 4001, 10000, 100000]
+        res[f"lr_{lr}_{warm}"] = np.array([[n, sch.step_update(n)] for n in steps])
+    np.savez(os.path.join(out_dir, "lr_schedule.npz"), **res)
+
+
+def batch_by_size_golden(out_dir):
+    """Compile the reference's Cython batch packer into /tmp and record its batches."""
+    import subprocess
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    src = os.path.join(REF, "fairseq/data/data_utils_fast.pyx")
+    setup = f"""
+from setuptools import setup, Extension
+from Cython.Build import cythonize
+import numpy
+setup(ext_modules=cythonize([Extension("data_utils_fast", [r"{src}"], language="c++",
+      include_dirs=[numpy.get_include()])], build_dir=r"{tmp}/b"), script_args=["build_ext", "--build-lib", r"{tmp}", "--build-temp", r"{tmp}/t"])
+"""
+    open(os.path.join(tmp, "setup_tmp.py"), "w").write(setup)
+    subprocess.check_call([sys.executable, os.path.join(tmp, "setup_tmp.py")], cwd=tmp,
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    sys.path.insert(0, tmp)
+    import data_utils_fast as duf
+    res = {}
+    cases = [("fisher4096", D.SyntheticFisherCorpus(4096, 1234), 20000, 0, 8),
+             ("fisher512_mt60000", D.SyntheticFisherCorpus(512, 5), 60000, 0, 8),
+             ("small_ms", D.SyntheticFisherCorpus(100, 3, max_src=200), 2000, 6, 4),
+             ("mult1", D.SyntheticFisherCorpus(77, 9, max_src=500), 3000, 0, 1)]
+    for nm, c, mt, ms, mult in cases:
+        idx = c.ordered_indices().astype(np.int64)
+        ntok = c.src_n_frames[idx].astype(np.int64)
+        b = duf.batch_by_size_vec(idx, ntok, mt, ms if ms > 0 else -1, mult)
+        res[f"{nm}.params"] = np.array([len(c), c.seed, mt, ms, mult])
+        res[f"{nm}.sizes"] = np.array([len(x) for x in b])
+        res[f"{nm}.first"] = np.array([int(x[0]) for x in b])
+    # unsorted random-length case
+    rs = np.random.RandomState(0)
+    ntok = rs.randint(1, 400, size=300).astype(np.int64)
+    b = duf.batch_by_size_vec(np.arange(300, dtype=np.int64), ntok, 1500, -1, 8)
+    res["random.ntok"] = ntok
+    res["random.sizes"] = np.array([len(x) for x in b])
+    np.savez(os.path.join(out_dir, "batch_by_size.npz"), **res)
+    print("batch_by_size goldens ok")
+
+
+def kat_golden(out_dir):
+    """Known-answer data of the reference's own unit tests that touch building blocks
+    (tests/test_label_smoothing.py:18-57): 3x7 probability table, targets, eps."""
+    from fairseq.criterions.label_smoothed_cross_entropy import label_smoothed_nll_loss as ref_ls
+    from examples.s2s_trans.criterions.s2st_loss import label_smoothed_nll_loss as ref_ls2
+    probs = torch.FloatTensor(
+        # pad   eos  unk   w1   w2   w3   w4
+        [[0.05, 0.05, 0.1, 0.05, 0.3, 0.4, 0.05],
+         [0.05, 0.10, 0.2, 0.05, 0.2, 0.3, 0.10],
+         [0.05, 0.15, 0.3, 0.05, 0.1, 0.2, 0.15]])
+    lp = probs.log()
+    tgt = torch.tensor([4, 5, 1])  # includes a pad target (pad idx = 1 here: column 'eos')
+    res = {"probs": probs.numpy(), "target": tgt.numpy()}
+    for eps in (0.0, 0.1, 0.3):
+        l, n = ref_ls2(lp, tgt, eps, ignore_index=1, reduce=True)
+        l_f, n_f = ref_ls(lp, tgt, eps, ignore_index=1, reduce=True)
+        assert abs(float(l) - float(l_f)) < 1e-6
+        res[f"eps{eps}"] = np.array([float(l), float(n)])
+    np.savez(os.path.join(out_dir, "label_smoothing_kat.npz"), **res)
+
+
+if __name__ == "__main__":
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+    which = sys.argv[1:] or ["tiny", "tiny_postln", "base", "lr", "bbs", "kat"]
+    if "tiny" in which:
+        run_config("tiny", out_dir, full=True)
+    if "tiny_postln" in which:
+        run_config("tiny_postln", out_dir, full=True)
+    if "base" in which:
+        run_config("base", out_dir, full=False, n_updates=2)
+    if "lr" in which:
+        lr_schedule_golden(out_dir)
+    if "bbs" in which:
+        batch_by_size_golden(out_dir)
+    if "kat" in which:
+        kat_golden(out_dir)
