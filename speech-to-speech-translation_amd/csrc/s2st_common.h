@@ -1,0 +1,73 @@
+// Device-side helpers shared by the s2st HIP kernels (gfx950 / CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "s2st_hip.h"
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16v4 __attribute__((ext_vector_type(4)));
+typedef float f32v4 __attribute__((ext_vector_type(4)));
+
+#define S2ST_WAVE 64
+
+// 4 x f32 -> 4 x bf16 (round-to-nearest-even), packed in 8 bytes.
+// Lowers to two v_cvt_pk_bf16_f32 on gfx950.
+__device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d) {
+  f32v4 f = {a, b, c, d};
+  bf16v4 h = __builtin_convertvector(f, bf16v4);
+  union { bf16v4 v; uint2 u; } cv;
+  cv.v = h;
+  return cv.u;
+}
+
+// hi/lo split: x ~= hi + lo with both bf16 (error ~2^-17 |x|): the "bf16x3" precise mode.
+__device__ __forceinline__ void split_bf16x4(float a, float b, float c, float d, uint2& hi, uint2& lo) {
+  f32v4 f = {a, b, c, d};
+  bf16v4 h = __builtin_convertvector(f, bf16v4);
+  f32v4 hf = __builtin_convertvector(h, f32v4);
+  f32v4 r = f - hf;
+  bf16v4 l = __builtin_convertvector(r, bf16v4);
+  union { bf16v4 v; uint2 u; } c1, c2;
+  c1.v = h;
+  c2.v = l;
+  hi = c1.u;
+  lo = c2.u;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+  return v;
+}
+
+// Counter-based dropout RNG: keep(element) is a pure function of (seed, element index), so
+// the backward pass regenerates the forward mask without storing it.
+__device__ __forceinline__ uint32_t mix64(uint64_t x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return (uint32_t)x;
+}
+__device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
+  // returns 0 (dropped) or 1/(1-p) (kept)
+  uint32_t h = mix64(seed + idx * 0x9E3779B97F4A7C15ULL);
+  float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+  return u >= p ? inv_keep : 0.0f;
+}
+
+// "slow index" -> element offset with an optional split (used for [B][T(+halo)][C]
+// buffers addressed by a flat row id): off(i) = (i / per) * bs + (i % per) * ld
+typedef s2st_split Split;
+__device__ __forceinline__ long split_off(const Split& s, int i) {
+  if (s.per <= 0) return (long)i * s.ld;
+  int q = i / s.per;
+  return (long)q * s.bs + (long)(i - q * s.per) * s.ld;
+}

@@ -1,0 +1,125 @@
+"""ctypes binding of libs2st_hip.so (C ABI declared in include/s2st_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There is no
+CPU fallback: if the shared object is missing or no HIP device is visible, the first
+compute call raises.  ``load_library(path)`` with an explicit path exists so the test-suite
+can load the host build made against the wave64 emulator (tests/hipemu) -- the product
+never does that.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "csrc", "libs2st_hip.so")
+
+_lib: Optional[C.CDLL] = None
+_lib_is_emulator = False
+
+
+class Split(C.Structure):
+    _fields_ = [("ld", C.c_int64), ("bs", C.c_int64), ("per", C.c_int32), ("_pad", C.c_int32)]
+
+
+class GemmOperand(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("kmajor", C.c_int32), ("_pad", C.c_int32), ("sp", Split),
+                ("zo", C.c_int64), ("zi", C.c_int64)]
+
+
+class GemmOut(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("sp", Split), ("zo", C.c_int64), ("zi", C.c_int64)]
+
+
+class GemmEpilogue(C.Structure):
+    _fields_ = [("alpha", C.c_float), ("act", C.c_int32), ("bias", C.c_void_p),
+                ("drop_p", C.c_float), ("accumulate", C.c_int32), ("seed", C.c_uint64),
+                ("resid", C.c_void_p)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", GemmOperand), ("B", GemmOperand), ("C", GemmOut), ("ep", GemmEpilogue),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("batch", C.c_int32),
+                ("zdiv", C.c_int32), ("precise", C.c_int32), ("splitk", C.c_int32),
+                ("kchunk", C.c_int32), ("avec", C.c_int32), ("bvec", C.c_int32)]
+
+
+class S2STHipError(RuntimeError):
+    pass
+
+
+def load_library(path: Optional[str] = None, emulator: bool = False) -> C.CDLL:
+    """Load the kernel library.  ``emulator=True`` is for tests only."""
+    global _lib, _lib_is_emulator
+    path = path or os.environ.get("S2ST_HIP_LIB") or DEFAULT_LIB
+    if not os.path.exists(path):
+        raise S2STHipError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+            " (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    _lib = C.CDLL(path)
+    _lib_is_emulator = emulator
+    _lib.s2st_version.restype = C.c_int
+    _lib.s2st_device_count.restype = C.c_int
+    return _lib
+
+
+def lib() -> C.CDLL:
+    if _lib is None:
+        load_library()
+    return _lib
+
+
+def is_emulator() -> bool:
+    return _lib_is_emulator
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise S2STHipError(f"{what} failed with code {rc}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream_ptr() -> Optional[int]:
+    """Current torch HIP stream as a raw hipStream_t (None = default stream / emulator)."""
+    if _lib_is_emulator or not torch.cuda.is_available():
+        return None
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(t: torch.Tensor):
+    if not _lib_is_emulator and not t.is_cuda:
+        raise S2STHipError("s2st HIP ops need device (cuda/HIP) tensors; there is no CPU path")
+
+
+def make_split(ld: int, per: int = 0, bs: int = 0) -> Split:
+    return Split(ld, bs, per, 0)
+
+
+def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K: int, *,
+         a_kmajor=True, a_ld=None, a_per=0, a_bs=0, a_zo=0, a_zi=0,
+         b_kmajor=True, b_ld=None, b_per=0, b_bs=0, b_zo=0, b_zi=0,
+         c_ld=None, c_per=0, c_bs=0, c_zo=0, c_zi=0,
+         batch=1, zdiv=1, alpha=1.0, bias=None, act=0, drop_p=0.0, seed=0, resid=None,
+         accumulate=False, precise=False, a_off=0, b_off=0, c_off=0):
+    """Raw GEMM entry (s2st_gemm_f32). Offsets are in elements."""
+    require_device(A)
+    g = GemmArgs()
+    g.A = GemmOperand(A.data_ptr() + 4 * a_off, 1 if a_kmajor else 0, 0,
+                      make_split(a_ld if a_ld is not None else (K if a_kmajor else M), a_per, a_bs),
+                      a_zo, a_zi)
+    g.B = GemmOperand(B.data_ptr() + 4 * b_off, 1 if b_kmajor else 0, 0,
+                      make_split(b_ld if b_ld is not None else (K if b_kmajor else N), b_per, b_bs),
+                      b_zo, b_zi)
+    g.C = GemmOut(Cout.data_ptr() + 4 * c_off, make_split(c_ld if c_ld is not None else N, c_per, c_bs),
+                  c_zo, c_zi)
+    g.ep = GemmEpilogue(alpha, act, ptr(bias), drop_p, 1 if accumulate else 0, seed, ptr(resid))
+    g.M, g.N, g.K, g.batch, g.zdiv, g.precise = M, N, K, batch, zdiv, 1 if precise else 0
+    check(lib().s2st_gemm_f32(C.byref(g), C.c_void_p(stream_ptr())), "s2st_gemm_f32")

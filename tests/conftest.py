@@ -1,4 +1,6 @@
+import importlib
 import os
+import subprocess
 import sys
 
 import pytest
@@ -9,6 +11,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+EMU_LIB = os.path.join(ROOT, "tests", "hipemu", "_build", "libs2st_emu.so")
 
 
 def pytest_configure(config):
@@ -18,3 +21,48 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+class Backend:
+    """Which build of the kernels a test drives.
+
+    * ``hip``: the product library (hipcc, gfx950) on cuda:0 -- the parity tests proper.
+    * ``emu``: the SAME sources compiled for the host against the wave64 emulator in
+      tests/hipemu; CPU-only logic check of kernels and schedule on tiny shapes.  Test
+      infrastructure, never a product path.
+    """
+
+    def __init__(self, kind):
+        import torch
+        self.kind = kind
+        self.bd = importlib.import_module("speech-to-speech-translation_amd.runtime.binding")
+        if kind == "emu":
+            subprocess.check_call([os.path.join(ROOT, "tests", "hipemu", "build_emu.sh")],
+                                  stdout=subprocess.DEVNULL)
+            self.bd.load_library(EMU_LIB, emulator=True)
+            self.device = torch.device("cpu")
+        else:
+            assert torch.cuda.is_available(), "gpu-marked test needs a HIP device"
+            self.bd.load_library(self.bd.DEFAULT_LIB, emulator=False)
+            assert self.bd.lib().s2st_device_count() >= 1
+            self.device = torch.device("cuda:0")
+
+    def sync(self):
+        import torch
+        if self.kind == "hip":
+            torch.cuda.synchronize()
+
+
+_backends = {}
+
+
+@pytest.fixture(params=[pytest.param("emu"), pytest.param("hip", marks=pytest.mark.gpu)])
+def backend(request):
+    k = request.param
+    if k not in _backends:
+        _backends[k] = Backend(k)
+    b = _backends[k]
+    # re-bind (the binding module holds one library at a time)
+    if b.bd.is_emulator() != (k == "emu"):
+        b.bd.load_library(EMU_LIB if k == "emu" else b.bd.DEFAULT_LIB, emulator=(k == "emu"))
+    return b

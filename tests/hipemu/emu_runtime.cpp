@@ -1,0 +1,180 @@
+// Fiber scheduler of the wave64 emulator (test infrastructure, see hip/hip_runtime.h).
+#include "hip/hip_runtime.h"
+#include <ucontext.h>
+#include <atomic>
+#include <thread>
+#include <vector>
+
+thread_local emu_uint3 threadIdx, blockIdx;
+thread_local dim3 blockDim, gridDim;
+
+namespace {
+constexpr size_t kStack = 96 * 1024;
+
+struct Fiber {
+  ucontext_t ctx;
+  char* stack = nullptr;
+  bool done = true;
+  const volatile unsigned* wait_ptr = nullptr;  // runnable when *wait_ptr != wait_val
+  unsigned wait_val = 0;
+  emu_uint3 tid;
+};
+
+struct Wave {
+  volatile unsigned gen = 0;
+  int arrived = 0;
+  int nlanes = 64;
+  unsigned ops = 0;
+  alignas(16) char buf[2][64][64];
+};
+
+struct Worker {
+  std::vector<Fiber> fibers;
+  std::vector<Wave> waves;
+  ucontext_t sched;
+  int cur = -1;
+  int nthreads = 0;
+  int active = 0;
+  volatile unsigned bar_gen = 0;
+  int bar_arrived = 0;
+  void (*tramp)(void*) = nullptr;
+  void* args = nullptr;
+};
+thread_local Worker* W = nullptr;
+
+void fiber_main() {
+  Worker* w = W;
+  w->tramp(w->args);
+  Fiber& f = w->fibers[w->cur];
+  f.done = true;
+  w->active--;
+  // a thread that exits counts as arrived for any pending workgroup barrier
+  if (w->bar_arrived > 0 && w->bar_arrived >= w->active) { w->bar_arrived = 0; w->bar_gen++; }
+  swapcontext(&f.ctx, &w->sched);
+}
+
+void yield_wait(const volatile unsigned* p, unsigned v) {
+  Worker* w = W;
+  Fiber& f = w->fibers[w->cur];
+  f.wait_ptr = p;
+  f.wait_val = v;
+  swapcontext(&f.ctx, &w->sched);
+}
+
+void run_block(Worker* w, dim3 block) {
+  int n = block.x * block.y * block.z;
+  if ((int)w->fibers.size() < n) {
+    size_t old = w->fibers.size();
+    w->fibers.resize(n);
+    for (size_t i = old; i < (size_t)n; ++i) w->fibers[i].stack = (char*)malloc(kStack);
+  }
+  int nw = (n + 63) / 64;
+  w->waves.assign(nw, Wave());
+  for (int i = 0; i < nw; ++i) w->waves[i].nlanes = std::min(64, n - 64 * i);
+  w->nthreads = n;
+  w->active = n;
+  w->bar_gen = 0;
+  w->bar_arrived = 0;
+  for (int i = 0; i < n; ++i) {
+    Fiber& f = w->fibers[i];
+    f.done = false;
+    f.wait_ptr = nullptr;
+    f.tid.x = i % block.x;
+    f.tid.y = (i / block.x) % block.y;
+    f.tid.z = i / (block.x * block.y);
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack;
+    f.ctx.uc_stack.ss_size = kStack;
+    f.ctx.uc_link = nullptr;
+    makecontext(&f.ctx, fiber_main, 0);
+  }
+  int remaining = n;
+  while (remaining > 0) {
+    bool progressed = false;
+    remaining = 0;
+    for (int i = 0; i < n; ++i) {
+      Fiber& f = w->fibers[i];
+      if (f.done) continue;
+      remaining++;
+      if (f.wait_ptr && *f.wait_ptr == f.wait_val) continue;
+      f.wait_ptr = nullptr;
+      w->cur = i;
+      threadIdx = f.tid;
+      swapcontext(&w->sched, &f.ctx);
+      progressed = true;
+    }
+    if (!progressed && remaining > 0) {
+      fprintf(stderr, "hipemu: deadlock (divergent barrier / collective) in block (%u,%u,%u)\n",
+              blockIdx.x, blockIdx.y, blockIdx.z);
+      abort();
+    }
+  }
+}
+}  // namespace
+
+int emu_lane() { return W->cur & 63; }
+
+void emu_syncthreads() {
+  Worker* w = W;
+  unsigned g = w->bar_gen;
+  w->bar_arrived++;
+  if (w->bar_arrived >= w->active) {
+    w->bar_arrived = 0;
+    w->bar_gen = g + 1;
+    return;
+  }
+  yield_wait(&w->bar_gen, g);
+}
+
+void emu_wave_exchange(const void* in, void* all_out, int bytes) {
+  Worker* w = W;
+  if (bytes > 64) { fprintf(stderr, "hipemu: exchange too wide\n"); abort(); }
+  Wave& wv = w->waves[w->cur >> 6];
+  int lane = w->cur & 63;
+  // every lane runs the same op sequence; its own count picks the double buffer
+  static thread_local std::vector<unsigned> lane_ops;
+  if (lane_ops.size() < (size_t)w->nthreads) lane_ops.resize(w->nthreads);
+  (void)lane_ops;
+  unsigned g = wv.gen;
+  int b = g & 1;
+  memcpy(wv.buf[b][lane], in, bytes);
+  wv.arrived++;
+  if (wv.arrived >= wv.nlanes) {
+    wv.arrived = 0;
+    wv.gen = g + 1;
+  } else {
+    yield_wait(&wv.gen, g);
+  }
+  char* o = (char*)all_out;
+  for (int i = 0; i < 64; ++i) memcpy(o + (size_t)i * bytes, wv.buf[b][i], bytes);
+}
+
+void emu_launch_impl(void (*tramp)(void*), void* args, dim3 grid, dim3 block) {
+  size_t nblocks = (size_t)grid.x * grid.y * grid.z;
+  if (nblocks == 0) return;
+  unsigned hw = std::thread::hardware_concurrency();
+  const char* env = getenv("HIPEMU_THREADS");
+  unsigned nthr = env ? (unsigned)atoi(env) : (hw ? hw : 4);
+  nthr = (unsigned)std::min<size_t>(nthr, nblocks);
+  std::atomic<size_t> next{0};
+  auto work = [&]() {
+    static thread_local Worker worker;
+    W = &worker;
+    worker.tramp = tramp;
+    worker.args = args;
+    blockDim = block;
+    gridDim = grid;
+    for (;;) {
+      size_t b = next.fetch_add(1);
+      if (b >= nblocks) break;
+      blockIdx.x = b % grid.x;
+      blockIdx.y = (b / grid.x) % grid.y;
+      blockIdx.z = b / ((size_t)grid.x * grid.y);
+      run_block(&worker, block);
+    }
+  };
+  if (nthr <= 1) { work(); return; }
+  std::vector<std::thread> ts;
+  for (unsigned i = 0; i < nthr; ++i) ts.emplace_back(work);
+  for (auto& t : ts) t.join();
+}

@@ -1,0 +1,152 @@
+"""s2st_gemm_f32 against torch fp32 matmul: every operand layout, both precisions,
+ragged sizes, split rows (halo buffers), batching, fused epilogues."""
+import numpy as np
+import pytest
+import torch
+
+
+def _ref(A, B):
+    return A.double() @ B.double().t()
+
+
+def _relerr(C, R):
+    return ((C.double().cpu() - R).abs().max() / R.abs().max()).item()
+
+
+SHAPES = [(100, 72, 96), (130, 74, 44), (67, 130, 50), (257, 192, 320)]
+
+
+@pytest.mark.parametrize("akm", [True, False])
+@pytest.mark.parametrize("bkm", [True, False])
+@pytest.mark.parametrize("precise", [False, True])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_layouts(backend, akm, bkm, precise, shape):
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g)
+    Am = (A if akm else A.t().contiguous()).to(backend.device)
+    Bm = (B if bkm else B.t().contiguous()).to(backend.device)
+    C = torch.full((M, N), 7.0, device=backend.device)
+    backend.bd.gemm(Am, Bm, C, M, N, K, a_kmajor=akm, b_kmajor=bkm, precise=precise)
+    backend.sync()
+    # tolerance: bf16 inputs (8-bit mantissa) vs bf16x3 split (~fp32)
+    assert _relerr(C, _ref(A, B)) < (2e-5 if precise else 1.5e-2)
+
+
+def test_big_tile_and_splitk(backend):
+    if backend.kind == "emu":
+        M, N, K = 256, 256, 64
+    else:
+        M, N, K = 4096, 1024, 512
+    g = torch.Generator().manual_seed(1)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g)
+    C = torch.zeros(M, N, device=backend.device)
+    backend.bd.gemm(A.to(backend.device), B.to(backend.device), C, M, N, K)
+    backend.sync()
+    assert _relerr(C, _ref(A, B)) < 1.5e-2
+    # weight-gradient form: dW[N,K] += dY[M,N]^T X[M,K], reduction over M, accumulate (split-K)
+    Mred = 1024 if backend.kind == "emu" else 8192
+    dY = torch.randn(Mred, 64, generator=g)
+    X = torch.randn(Mred, 96, generator=g)
+    dW0 = torch.randn(64, 96, generator=g)
+    dW = dW0.clone().to(backend.device)
+    backend.bd.gemm(dY.to(backend.device), X.to(backend.device), dW, 64, 96, Mred,
+                    a_kmajor=False, a_ld=64, b_kmajor=False, b_ld=96, accumulate=True, precise=True)
+    backend.sync()
+    R = dW0.double() + dY.double().t() @ X.double()
+    assert _relerr(dW, R) < 3e-5
+
+
+def test_epilogue_bias_relu_resid_alpha(backend):
+    M, N, K = 90, 70, 64
+    g = torch.Generator().manual_seed(2)
+    A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    d = backend.device
+    C = torch.zeros(M, N, device=d)
+    backend.bd.gemm(A.to(d), B.to(d), C, M, N, K, alpha=0.5, bias=bias.to(d), act=1,
+                    resid=res.to(d), precise=True)
+    backend.sync()
+    R = torch.relu(0.5 * _ref(A, B) + bias.double()) + res.double()
+    assert _relerr(C, R) < 2e-5
+    # accumulate without split
+    C2 = res.clone().to(d)
+    backend.bd.gemm(A.to(d), B.to(d), C2, M, N, K, accumulate=True, precise=True)
+    backend.sync()
+    assert _relerr(C2, res.double() + _ref(A, B)) < 2e-5
+
+
+def test_conv_as_gemm_halo(backend):
+    """Conv1d(k=5, stride s, pad 2) == GEMM over a halo-padded [B][T+4][C] buffer whose
+    im2col rows are overlapping windows (s2st_transformer.py:135-139)."""
+    Bn, T, Cin, Cout, Kw = 3, 37, 8, 24, 5
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(Bn, T, Cin, generator=g)
+    w = torch.randn(Cout, Cin, Kw, generator=g)
+    b = torch.randn(Cout, generator=g)
+    d = backend.device
+    for stride in (1, 2):
+        ref = torch.nn.functional.conv1d(x.transpose(1, 2), w, b, stride=stride, padding=2).transpose(1, 2)
+        Tout = ref.shape[1]
+        xp = torch.zeros(Bn, T + 4, Cin)
+        xp[:, 2:T + 2] = x
+        wf = w.permute(0, 2, 1).contiguous()  # [O][Kw][I]
+        y = torch.zeros(Bn, Tout, Cout, device=d)
+        backend.bd.gemm(xp.to(d), wf.to(d), y, Bn * Tout, Cout, Kw * Cin,
+                        a_ld=stride * Cin, a_per=Tout, a_bs=(T + 4) * Cin, b_ld=Kw * Cin,
+                        bias=b.to(d), precise=True)
+        backend.sync()
+        assert _relerr(y, ref.double()) < 2e-5
+
+
+def test_batched_attention_forms(backend):
+    """Q K^T and P V with (b, h) batching over [B*T, C] projections
+    (multihead_attention.py:332, 367)."""
+    Bn, H, T, S, Dh = 2, 4, 19, 23, 16
+    Cm = H * Dh
+    g = torch.Generator().manual_seed(4)
+    q = torch.randn(Bn, T, Cm, generator=g)
+    k = torch.randn(Bn, S, Cm, generator=g)
+    v = torch.randn(Bn, S, Cm, generator=g)
+    d = backend.device
+    ld = 24  # padded score rows
+    sc = torch.zeros(Bn, H, T, ld, device=d)
+    backend.bd.gemm(q.to(d), k.to(d), sc, T, S, Dh, a_ld=Cm, a_zo=T * Cm, a_zi=Dh,
+                    b_ld=Cm, b_zo=S * Cm, b_zi=Dh, c_ld=ld, c_zo=H * T * ld, c_zi=T * ld,
+                    batch=Bn * H, zdiv=H, alpha=0.25, precise=True)
+    backend.sync()
+    qh = q.view(Bn, T, H, Dh).permute(0, 2, 1, 3).double()
+    kh = k.view(Bn, S, H, Dh).permute(0, 2, 1, 3).double()
+    vh = v.view(Bn, S, H, Dh).permute(0, 2, 1, 3).double()
+    R = 0.25 * qh @ kh.transpose(-1, -2)
+    assert _relerr(sc[..., :S], R) < 2e-5
+    p = torch.softmax(R, -1).float()
+    pp = torch.zeros(Bn, H, T, ld)
+    pp[..., :S] = p
+    o = torch.zeros(Bn, T, Cm, device=d)
+    backend.bd.gemm(pp.to(d), v.to(d), o, T, Dh, S, a_ld=ld, a_zo=H * T * ld, a_zi=T * ld,
+                    b_kmajor=False, b_ld=Cm, b_zo=S * Cm, b_zi=Dh,
+                    c_ld=Cm, c_zo=T * Cm, c_zi=Dh, batch=Bn * H, zdiv=H, precise=True)
+    backend.sync()
+    Ro = (p.double() @ vh).permute(0, 2, 1, 3).reshape(Bn, T, Cm)
+    assert _relerr(o, Ro) < 2e-5
+
+
+def test_dropout_epilogue_statistics(backend):
+    M, N, K = 128, 128, 32
+    d = backend.device
+    A = torch.ones(M, K, device=d)
+    B = torch.ones(N, K, device=d) / K
+    C = torch.zeros(M, N, device=d)
+    backend.bd.gemm(A, B, C, M, N, K, drop_p=0.25, seed=1234, precise=True)
+    backend.sync()
+    C = C.cpu()
+    kept = (C != 0)
+    assert abs(kept.float().mean().item() - 0.75) < 0.02
+    np.testing.assert_allclose(C[kept].numpy(), 1.0 / 0.75, rtol=1e-5)
+    C2 = torch.zeros(M, N, device=d)
+    backend.bd.gemm(A, B, C2, M, N, K, drop_p=0.25, seed=1234, precise=True)
+    backend.sync()
+    assert torch.equal(C, C2.cpu())  # same seed -> same mask
