@@ -63,6 +63,84 @@ typedef struct {
  * examples/s2s_trans/models/s2st_transformer.py:135-139,452-455, tacotron2.py:95-126. */
 int s2st_gemm_f32(const s2st_gemm_args* args, void* stream);
 
+/* fairseq/modules/layer_norm.py:11-35 (LayerNorm / FusedLayerNorm), forward; saves mean, rstd */
+int s2st_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int32_t rows, int32_t cols, float eps, void* stream);
+
+/* backward of the above: dx (=|+=), dgamma += , dbeta += */
+int s2st_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx, int32_t dx_accumulate, float* dgamma, float* dbeta, int32_t rows, int32_t cols, void* stream);
+
+/* multihead_attention.py:343-366: key-padding / causal -inf masks, fp32 softmax, dropout. scores [B,H,T,ld] */
+int s2st_softmax_fwd_f32(const float* s, float* p, float* pd, const int32_t* klen, int32_t B, int32_t H, int32_t T, int32_t S, int32_t ld, int32_t causal, float drop_p, uint64_t seed, void* stream);
+
+/* ds = p * (dp' - sum dp' p), dp' = dropmask * dpd */
+int s2st_softmax_bwd_f32(const float* p, const float* dpd, float* ds, int32_t B, int32_t H, int32_t T, int32_t S, int32_t ld, float drop_p, uint64_t seed, void* stream);
+
+/* bias gradients: out[c] (+)= sum_r x[r][c] */
+int s2st_colsum_f32(const float* x, int64_t ld, int32_t rows, int32_t cols, float* out, int32_t accumulate, void* stream);
+
+/* s2st_transformer.py:424-427: mean over heads, [B,H,T,S] -> [B,S,T] */
+int s2st_attn_headmean_f32(const float* p, float* out, int32_t B, int32_t H, int32_t T, int32_t S, int32_t ld, void* stream);
+
+/* row copy between split-addressed buffers (halo padding for the convs) */
+int s2st_copy_rows_f32(const float* x, s2st_split xsp, float* y, s2st_split ysp, int32_t rows, int32_t C, void* stream);
+
+/* s2st_transformer.py:137 F.glu(dim=channels): a [rows][2C] -> y rows via split */
+int s2st_glu_fwd_f32(const float* a, float* y, s2st_split ysp, int32_t rows, int32_t C, void* stream);
+
+/* backward of GLU */
+int s2st_glu_bwd_f32(const float* a, const float* dy, s2st_split dysp, float* da, s2st_split dasp, int32_t rows, int32_t C, void* stream);
+
+/* s2st_transformer.py:197-208, 385-387: y = dropout(scale*x + alpha*PE[pos]) */
+int s2st_add_pe_f32(const float* x, float* y, const int32_t* pos, const float* table, int32_t rows, int32_t C, float scale, const float* alpha_ptr, float drop_p, uint64_t seed, void* stream);
+
+/* gradient of decoder.pos_emb_alpha */
+int s2st_pe_alpha_bwd_f32(const float* dy, const int32_t* pos, const float* table, int32_t rows, int32_t C, float drop_p, uint64_t seed, float* dalpha, void* stream);
+
+/* transformer_decoder.py:303: embed_scale * embed_tokens(tokens) */
+int s2st_embed_fwd_f32(const int64_t* tokens, const float* table, float* y, int32_t rows, int32_t C, float scale, void* stream);
+
+/* embedding gradient (pad row receives none) */
+int s2st_embed_bwd_f32(const int64_t* tokens, const float* dy, float* dtable, int32_t rows, int32_t C, float scale, int64_t pad, void* stream);
+
+/* fairseq_dropout.py:16-27: y (+)= a * x * mask(seed) */
+int s2st_dropout_f32(const float* x, float* y, int64_t n, float a, float p, uint64_t seed, int32_t accumulate, void* stream);
+
+/* backward of dropout(relu(z)) from its output */
+int s2st_relu_drop_bwd_f32(const float* dy, const float* y, float* dz, int64_t n, float p, void* stream);
+
+/* Conv1d weight [O][I][Kw] -> GEMM layouts [O][Kw][I] and flipped [I][Kw][O] */
+int s2st_conv_w_permute_f32(const float* w, float* wf, float* wd, int32_t O, int32_t I, int32_t Kw, void* stream);
+
+/* dW[O][I][Kw] += dWf[O][Kw][I] */
+int s2st_conv_w_unpermute_acc_f32(const float* dwf, float* dw, int32_t O, int32_t I, int32_t Kw, void* stream);
+
+/* tacotron2.py:112,125 BatchNorm1d(train): batch mean/var over all rows + running stats; tmp 2C floats */
+int s2st_bn_stats_f32(const float* x, int32_t rows, int32_t C, float* mean, float* var, float* run_mean, float* run_var, float momentum, float* tmp, void* stream);
+
+/* y = dropout([tanh](gamma*xhat+beta)) (+resid) */
+int s2st_bn_apply_f32(const float* x, const float* mean, const float* var, const float* gamma, const float* beta, float* y, s2st_split ysp, const float* resid, int32_t rows, int32_t C, float eps, int32_t tanh_, float drop_p, uint64_t seed, void* stream);
+
+/* backward of bn_apply (train-mode statistics) */
+int s2st_bn_bwd_f32(const float* dy, s2st_split dysp, const float* x, const float* mean, const float* var, const float* gamma, const float* beta, float* dx, s2st_split dxsp, float* dgamma, float* dbeta, float* tmp, int32_t rows, int32_t C, float eps, int32_t tanh_, float drop_p, uint64_t seed, void* stream);
+
+/* s2st_loss.py:294-315 compute_loss: masked L1+MSE (pre/post-net) + BCE(pos_weight) sums and gradients */
+int s2st_mel_loss_f32(const float* feat, const float* post, const float* eos, const float* tgt, const int32_t* lens, int32_t B, int32_t D, int32_t F, float pos_weight, float* stats, float c_l1, float c_mse, float c_eos, float* dfeat, float* dpost, float* deos, void* stream);
+
+/* s2st_loss.py:33-50, 330-348: log_softmax + label-smoothed NLL + accuracy, and d/dlogits */
+int s2st_ls_ce_f32(const float* logits, const int64_t* target, int32_t rows, int32_t V, int64_t pad, float eps, float* stats, float* dlogits, float gscale, void* stream);
+
+/* s2st_loss.py:229-243 + s2st_transformer.py:458-463: log_softmax + CTCLoss(mean, zero_infinity); ws from s2st_ctc_workspace_floats */
+int s2st_ctc_f32(const float* logits, const int64_t* targets, int32_t Lmax, const int32_t* in_lens, const int32_t* tgt_lens, int32_t B, int32_t E, int32_t V, float* lprobs, float* loss_per_utt, float* dlogits, float gscale, float* ws, void* stream);
+
+/* fairseq/utils.py:345-385 gradient L2 norm (sum of squares, out +=) */
+int s2st_sumsq_f32(const float* x, int64_t n, float* out, void* stream);
+
+/* trainer.py:838-873 + adam.py:163-239: grad scale, clip-by-norm, fairseq Adam on a flat arena */
+int s2st_adam_f32(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float gmul, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int32_t step, float* gnorm_out, void* stream);
+
+/* floats of workspace s2st_ctc_f32 needs */
+int64_t s2st_ctc_workspace(int32_t B, int32_t E, int32_t Lmax);
+
 int s2st_version(void);
 /* number of HIP devices visible (0 = none: every compute entry point then fails) */
 int s2st_device_count(void);

@@ -16,4 +16,106 @@ int s2st_gemm_f32(const s2st_gemm_args* a, void* stream) {
   return s2st_gemm(*a, (hipStream_t)stream);
 }
 
+int s2st_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int32_t rows, int32_t cols, float eps, void* stream) {
+  return s2st_layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, cols, eps, (hipStream_t)stream);
+}
+
+int s2st_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx, int32_t dx_accumulate, float* dgamma, float* dbeta, int32_t rows, int32_t cols, void* stream) {
+  return s2st_layernorm_bwd(dy, x, gamma, mean, rstd, dx, dx_accumulate, dgamma, dbeta, rows, cols, (hipStream_t)stream);
+}
+
+int s2st_softmax_fwd_f32(const float* s, float* p, float* pd, const int32_t* klen, int32_t B, int32_t H, int32_t T, int32_t S, int32_t ld, int32_t causal, float drop_p, uint64_t seed, void* stream) {
+  return s2st_softmax_fwd(s, p, pd, klen, B, H, T, S, ld, causal, drop_p, seed, (hipStream_t)stream);
+}
+
+int s2st_softmax_bwd_f32(const float* p, const float* dpd, float* ds, int32_t B, int32_t H, int32_t T, int32_t S, int32_t ld, float drop_p, uint64_t seed, void* stream) {
+  return s2st_softmax_bwd(p, dpd, ds, B, H, T, S, ld, drop_p, seed, (hipStream_t)stream);
+}
+
+int s2st_colsum_f32(const float* x, int64_t ld, int32_t rows, int32_t cols, float* out, int32_t accumulate, void* stream) {
+  return s2st_colsum(x, ld, rows, cols, out, accumulate, (hipStream_t)stream);
+}
+
+int s2st_attn_headmean_f32(const float* p, float* out, int32_t B, int32_t H, int32_t T, int32_t S, int32_t ld, void* stream) {
+  return s2st_attn_headmean(p, out, B, H, T, S, ld, (hipStream_t)stream);
+}
+
+int s2st_copy_rows_f32(const float* x, s2st_split xsp, float* y, s2st_split ysp, int32_t rows, int32_t C, void* stream) {
+  return s2st_copy_rows(x, xsp, y, ysp, rows, C, (hipStream_t)stream);
+}
+
+int s2st_glu_fwd_f32(const float* a, float* y, s2st_split ysp, int32_t rows, int32_t C, void* stream) {
+  return s2st_glu_fwd(a, y, ysp, rows, C, (hipStream_t)stream);
+}
+
+int s2st_glu_bwd_f32(const float* a, const float* dy, s2st_split dysp, float* da, s2st_split dasp, int32_t rows, int32_t C, void* stream) {
+  return s2st_glu_bwd(a, dy, dysp, da, dasp, rows, C, (hipStream_t)stream);
+}
+
+int s2st_add_pe_f32(const float* x, float* y, const int32_t* pos, const float* table, int32_t rows, int32_t C, float scale, const float* alpha_ptr, float drop_p, uint64_t seed, void* stream) {
+  return s2st_add_pe(x, y, pos, table, rows, C, scale, alpha_ptr, drop_p, seed, (hipStream_t)stream);
+}
+
+int s2st_pe_alpha_bwd_f32(const float* dy, const int32_t* pos, const float* table, int32_t rows, int32_t C, float drop_p, uint64_t seed, float* dalpha, void* stream) {
+  return s2st_pe_alpha_bwd(dy, pos, table, rows, C, drop_p, seed, dalpha, (hipStream_t)stream);
+}
+
+int s2st_embed_fwd_f32(const int64_t* tokens, const float* table, float* y, int32_t rows, int32_t C, float scale, void* stream) {
+  return s2st_embed_fwd((const long*)tokens, table, y, rows, C, scale, (hipStream_t)stream);
+}
+
+int s2st_embed_bwd_f32(const int64_t* tokens, const float* dy, float* dtable, int32_t rows, int32_t C, float scale, int64_t pad, void* stream) {
+  return s2st_embed_bwd((const long*)tokens, dy, dtable, rows, C, scale, pad, (hipStream_t)stream);
+}
+
+int s2st_dropout_f32(const float* x, float* y, int64_t n, float a, float p, uint64_t seed, int32_t accumulate, void* stream) {
+  return s2st_dropout(x, y, n, a, p, seed, accumulate, (hipStream_t)stream);
+}
+
+int s2st_relu_drop_bwd_f32(const float* dy, const float* y, float* dz, int64_t n, float p, void* stream) {
+  return s2st_relu_drop_bwd(dy, y, dz, n, p, (hipStream_t)stream);
+}
+
+int s2st_conv_w_permute_f32(const float* w, float* wf, float* wd, int32_t O, int32_t I, int32_t Kw, void* stream) {
+  return s2st_conv_w_permute(w, wf, wd, O, I, Kw, (hipStream_t)stream);
+}
+
+int s2st_conv_w_unpermute_acc_f32(const float* dwf, float* dw, int32_t O, int32_t I, int32_t Kw, void* stream) {
+  return s2st_conv_w_unpermute_acc(dwf, dw, O, I, Kw, (hipStream_t)stream);
+}
+
+int s2st_bn_stats_f32(const float* x, int32_t rows, int32_t C, float* mean, float* var, float* run_mean, float* run_var, float momentum, float* tmp, void* stream) {
+  return s2st_bn_stats(x, rows, C, mean, var, run_mean, run_var, momentum, tmp, (hipStream_t)stream);
+}
+
+int s2st_bn_apply_f32(const float* x, const float* mean, const float* var, const float* gamma, const float* beta, float* y, s2st_split ysp, const float* resid, int32_t rows, int32_t C, float eps, int32_t tanh_, float drop_p, uint64_t seed, void* stream) {
+  return s2st_bn_apply(x, mean, var, gamma, beta, y, ysp, resid, rows, C, eps, tanh_, drop_p, seed, (hipStream_t)stream);
+}
+
+int s2st_bn_bwd_f32(const float* dy, s2st_split dysp, const float* x, const float* mean, const float* var, const float* gamma, const float* beta, float* dx, s2st_split dxsp, float* dgamma, float* dbeta, float* tmp, int32_t rows, int32_t C, float eps, int32_t tanh_, float drop_p, uint64_t seed, void* stream) {
+  return s2st_bn_bwd(dy, dysp, x, mean, var, gamma, beta, dx, dxsp, dgamma, dbeta, tmp, rows, C, eps, tanh_, drop_p, seed, (hipStream_t)stream);
+}
+
+int s2st_mel_loss_f32(const float* feat, const float* post, const float* eos, const float* tgt, const int32_t* lens, int32_t B, int32_t D, int32_t F, float pos_weight, float* stats, float c_l1, float c_mse, float c_eos, float* dfeat, float* dpost, float* deos, void* stream) {
+  return s2st_mel_loss(feat, post, eos, tgt, lens, B, D, F, pos_weight, stats, c_l1, c_mse, c_eos, dfeat, dpost, deos, (hipStream_t)stream);
+}
+
+int s2st_ls_ce_f32(const float* logits, const int64_t* target, int32_t rows, int32_t V, int64_t pad, float eps, float* stats, float* dlogits, float gscale, void* stream) {
+  return s2st_ls_ce(logits, (const long*)target, rows, V, pad, eps, stats, dlogits, gscale, (hipStream_t)stream);
+}
+
+int s2st_ctc_f32(const float* logits, const int64_t* targets, int32_t Lmax, const int32_t* in_lens, const int32_t* tgt_lens, int32_t B, int32_t E, int32_t V, float* lprobs, float* loss_per_utt, float* dlogits, float gscale, float* ws, void* stream) {
+  return s2st_ctc(logits, (const long*)targets, Lmax, in_lens, tgt_lens, B, E, V, lprobs, loss_per_utt, dlogits, gscale, ws, (hipStream_t)stream);
+}
+
+int s2st_sumsq_f32(const float* x, int64_t n, float* out, void* stream) {
+  return s2st_sumsq(x, n, out, (hipStream_t)stream);
+}
+
+int s2st_adam_f32(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float gmul, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int32_t step, float* gnorm_out, void* stream) {
+  return s2st_adam(p, g, m, v, n, sumsq, gmul, max_norm, lr, beta1, beta2, eps, wd, step, gnorm_out, (hipStream_t)stream);
+}
+
+int64_t s2st_ctc_workspace(int32_t B, int32_t E, int32_t Lmax) { return s2st_ctc_workspace_floats(B, E, Lmax); }
+
 }  // extern "C"

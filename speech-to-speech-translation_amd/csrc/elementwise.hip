@@ -1,0 +1,449 @@
+// Element-wise / per-channel kernels of the s2st hot path (HBM-bound): GLU, positional
+// embedding add, embedding gather/scatter, dropout, BatchNorm1d (batch statistics over all
+// B*T rows, tanh, dropout), conv-weight re-layout, row copies into halo-padded buffers.
+//
+// Reference call sites replaced: s2st_transformer.py:135-139 (F.glu), :197-208, :385-387
+// (scale + sinusoidal positions + dropout), fairseq/models/text_to_speech/tacotron2.py:101-126
+// (BatchNorm1d + tanh + dropout in the post-net), transformer_decoder.py:303-320 (token
+// embedding), fairseq/modules/fairseq_dropout.py:16-27.
+#include "s2st_ops.h"
+
+namespace {
+
+constexpr int EW_BLOCK = 256;
+
+inline unsigned ew_grid(long n, int per_thread = 1) {
+  long b = (n + (long)EW_BLOCK * per_thread - 1) / ((long)EW_BLOCK * per_thread);
+  return (unsigned)(b < 1 ? 1 : b);
+}
+
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ x, Split xsp,
+                                                        float* __restrict__ y, Split ysp, int rows,
+                                                        int C4) {
+  long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  long n = (long)rows * C4;
+  if (i >= n) return;
+  int r = (int)(i / C4), c = (int)(i - (long)r * C4);
+  reinterpret_cast<float4*>(y + split_off(ysp, r))[c] =
+      reinterpret_cast<const float4*>(x + split_off(xsp, r))[c];
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+__global__ __launch_bounds__(256) void glu_fwd_kernel(const float* __restrict__ a,
+                                                      float* __restrict__ y, Split ysp, int rows,
+                                                      int C) {
+  long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  long n = (long)rows * C;
+  if (i >= n) return;
+  int r = (int)(i / C), c = (int)(i - (long)r * C);
+  const float* ar = a + (long)r * 2 * C;
+  y[split_off(ysp, r) + c] = ar[c] * sigmoidf_(ar[c + C]);
+}
+
+__global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ a,
+                                                      const float* __restrict__ dy, Split dysp,
+                                                      float* __restrict__ da, Split dasp, int rows,
+                                                      int C) {
+  long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  long n = (long)rows * C;
+  if (i >= n) return;
+  int r = (int)(i / C), c = (int)(i - (long)r * C);
+  const float* ar = a + (long)r * 2 * C;
+  float g = dy[split_off(dysp, r) + c];
+  float s = sigmoidf_(ar[c + C]);
+  float* dr = da + split_off(dasp, r);
+  dr[c] = g * s;
+  dr[c + C] = g * ar[c] * s * (1.f - s);
+}
+
+__global__ __launch_bounds__(256) void add_pe_kernel(const float* __restrict__ x,
+                                                     float* __restrict__ y,
+                                                     const int* __restrict__ pos,
+                                                     const float* __restrict__ table, int rows,
+                                                     int C, float scale,
+                                                     const float* __restrict__ alpha_ptr,
+                                                     float drop_p, uint64_t seed) {
+  long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  long n = (long)rows * C;
+  if (i >= n) return;
+  int r = (int)(i / C), c = (int)(i - (long)r * C);
+  float alpha = alpha_ptr ? alpha_ptr[0] : 1.f;
+  float v = scale * x[i] + alpha * table[(long)pos[r] * C + c];
+  if (drop_p > 0.f) v *= drop_scale(seed, (uint64_t)i, drop_p, 1.f / (1.f - drop_p));
+  y[i] = v;
+}
+
+// dalpha += sum_i dy[i] * mask(i) * PE[pos(row)][c]
+__global__ __launch_bounds__(256) void pe_alpha_bwd_kernel(const float* __restrict__ dy,
+                                                           const int* __restrict__ pos,
+                                                           const float* __restrict__ table,
+                                                           int rows, int C, float drop_p,
+                                                           uint64_t seed,
+                                                           float* __restrict__ dalpha) {
+  __shared__ float red[4];
+  long n = (long)rows * C;
+  float a = 0.f;
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  for (long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * EW_BLOCK) {
+    int r = (int)(i / C), c = (int)(i - (long)r * C);
+    float g = dy[i];
+    if (drop_p > 0.f) g *= drop_scale(seed, (uint64_t)i, drop_p, inv_keep);
+    a += g * table[(long)pos[r] * C + c];
+  }
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(dalpha, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const long* __restrict__ tok,
+                                                        const float* __restrict__ table,
+                                                        float* __restrict__ y, int rows, int C,
+                                                        float scale) {
+  long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  long n = (long)rows * C;
+  if (i >= n) return;
+  int r = (int)(i / C), c = (int)(i - (long)r * C);
+  y[i] = scale * table[tok[r] * C + c];
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const long* __restrict__ tok,
+                                                        const float* __restrict__ dy,
+                                                        float* __restrict__ dtable, int rows, int C,
+                                                        float scale, long pad) {
+  long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  long n = (long)rows * C;
+  if (i >= n) return;
+  int r = (int)(i / C), c = (int)(i - (long)r * C);
+  long t = tok[r];
+  if (t == pad) return;  // nn.Embedding(padding_idx): no gradient for the pad row
+  atomicAdd(&dtable[t * C + c], scale * dy[i]);
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x,
+                                                      float* __restrict__ y, long n, float a,
+                                                      float p, uint64_t seed, int accumulate) {
+  long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  float v = a * x[i];
+  if (p > 0.f) v *= drop_scale(seed, (uint64_t)i, p, 1.f / (1.f - p));
+  y[i] = accumulate ? y[i] + v : v;
+}
+
+__global__ __launch_bounds__(256) void relu_drop_bwd_kernel(const float* __restrict__ dy,
+                                                            const float* __restrict__ yout,
+                                                            float* __restrict__ dz, long n,
+                                                            float inv_keep) {
+  long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  dz[i] = yout[i] != 0.f ? dy[i] * inv_keep : 0.f;
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ x,
+                                                   float* __restrict__ y, long n, float a) {
+  long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  if (i < n) y[i] += a * x[i];
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long n, float a) {
+  long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  if (i < n) x[i] *= a;
+}
+
+// W[O][I][Kw] -> Wf[O][Kw][I] ; Wd[I][Kw-1-j][O]
+__global__ __launch_bounds__(256) void conv_w_permute_kernel(const float* __restrict__ w,
+                                                             float* __restrict__ wf,
+                                                             float* __restrict__ wd, int O, int I,
+                                                             int Kw) {
+  long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  long n = (long)O * I * Kw;
+  if (i >= n) return;
+  int j = (int)(i % Kw);
+  int c = (int)((i / Kw) % I);
+  int o = (int)(i / ((long)Kw * I));
+  float v = w[i];
+  if (wf) wf[((long)o * Kw + j) * I + c] = v;
+  if (wd) wd[((long)c * Kw + (Kw - 1 - j)) * O + o] = v;
+}
+
+__global__ __launch_bounds__(256) void conv_w_unpermute_acc_kernel(const float* __restrict__ dwf,
+                                                                   float* __restrict__ dw, int O,
+                                                                   int I, int Kw) {
+  long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  long n = (long)O * I * Kw;
+  if (i >= n) return;
+  int j = (int)(i % Kw);
+  int c = (int)((i / Kw) % I);
+  int o = (int)(i / ((long)Kw * I));
+  dw[i] += dwf[((long)o * Kw + j) * I + c];
+}
+
+// ---- column reductions with a per-element functor returning two values ------------------
+template <class F>
+__global__ __launch_bounds__(256) void colreduce2_kernel(F f, int rows, int cols,
+                                                         float* __restrict__ out0,
+                                                         float* __restrict__ out1,
+                                                         int rows_per_block) {
+  __shared__ float red[2][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  float a0 = 0.f, a1 = 0.f;
+  if (c < cols)
+    for (int r = r0 + ty; r < r1; r += 4) {
+      float2 v = f(r, c);
+      a0 += v.x;
+      a1 += v.y;
+    }
+  red[0][ty][tx] = a0;
+  red[1][ty][tx] = a1;
+  __syncthreads();
+  if (ty == 0 && c < cols) {
+    atomicAdd(&out0[c], red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx]);
+    if (out1) atomicAdd(&out1[c], red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx]);
+  }
+}
+
+template <class F>
+int colreduce2(F f, int rows, int cols, float* out0, float* out1, hipStream_t st) {
+  int cb = (cols + 63) / 64;
+  int slabs = (512 + cb - 1) / cb;
+  int rpb = (rows + slabs - 1) / slabs;
+  if (rpb < 16) rpb = 16;
+  slabs = (rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL((colreduce2_kernel<F>), dim3(cb, slabs), dim3(256), 0, st, f, rows, cols, out0,
+                     out1, rpb);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+
+struct SumF {
+  const float* x; int C;
+  __device__ float2 operator()(int r, int c) const { return make_float2(x[(long)r * C + c], 0.f); }
+};
+struct SqDevF {
+  const float* x; const float* sum; int C; float inv_rows;
+  __device__ float2 operator()(int r, int c) const {
+    float d = x[(long)r * C + c] - sum[c] * inv_rows;
+    return make_float2(d * d, 0.f);
+  }
+};
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sum,
+                                                          const float* __restrict__ sq,
+                                                          float* __restrict__ mean,
+                                                          float* __restrict__ var,
+                                                          float* __restrict__ run_mean,
+                                                          float* __restrict__ run_var, int C,
+                                                          int rows, float momentum) {
+  int c = blockIdx.x * EW_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  float m = sum[c] / rows;
+  float v = sq[c] / rows;
+  mean[c] = m;
+  var[c] = v;
+  if (run_mean) {
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * m;
+    float unb = rows > 1 ? v * ((float)rows / (float)(rows - 1)) : v;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * unb;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(
+    const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ var,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
+    Split ysp, const float* __restrict__ resid, int rows, int C, float eps, int tanh_, float drop_p,
+    uint64_t seed) {
+  long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  long n = (long)rows * C;
+  if (i >= n) return;
+  int r = (int)(i / C), c = (int)(i - (long)r * C);
+  float u = gamma[c] * (x[i] - mean[c]) * rsqrtf(var[c] + eps) + beta[c];
+  if (tanh_) u = tanhf(u);
+  if (drop_p > 0.f) u *= drop_scale(seed, (uint64_t)i, drop_p, 1.f / (1.f - drop_p));
+  if (resid) u += resid[i];
+  y[split_off(ysp, r) + c] = u;
+}
+
+// du = dy * dropmask * (1 - tanh^2)   (recomputed from x);  returns {du, du * xhat}
+struct BnBwdF {
+  const float* dy; Split dysp; const float* x; const float* mean; const float* var;
+  const float* gamma; const float* beta; int C; float eps; int tanh_; float drop_p; uint64_t seed;
+  __device__ float2 operator()(int r, int c) const {
+    long i = (long)r * C + c;
+    float xh = (x[i] - mean[c]) * rsqrtf(var[c] + eps);
+    float g = dy[split_off(dysp, r) + c];
+    if (drop_p > 0.f) g *= drop_scale(seed, (uint64_t)i, drop_p, 1.f / (1.f - drop_p));
+    if (tanh_) {
+      float t = tanhf(gamma[c] * xh + beta[c]);
+      g *= (1.f - t * t);
+    }
+    return make_float2(g, g * xh);
+  }
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(BnBwdF f, const float* __restrict__ sums,
+                                                        float* __restrict__ dx, Split dxsp,
+                                                        int rows, int C) {
+  long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  long n = (long)rows * C;
+  if (i >= n) return;
+  int r = (int)(i / C), c = (int)(i - (long)r * C);
+  float2 v = f(r, c);  // {du, du*xhat}
+  float rstd = rsqrtf(f.var[c] + f.eps);
+  float xh = (f.x[i] - f.mean[c]) * rstd;
+  float inv = 1.f / rows;
+  dx[split_off(dxsp, r) + c] = f.gamma[c] * rstd * (v.x - sums[c] * inv - xh * sums[C + c] * inv);
+}
+
+__global__ __launch_bounds__(256) void add_vec_kernel(const float* __restrict__ a,
+                                                      float* __restrict__ b, int n) {
+  int i = blockIdx.x * EW_BLOCK + threadIdx.x;
+  if (i < n) b[i] += a[i];
+}
+
+}  // namespace
+
+#define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH)
+
+int s2st_copy_rows(const float* x, Split xsp, float* y, Split ysp, int rows, int C,
+                   hipStream_t st) {
+  if (rows <= 0) return 0;
+  if (C % 4) return S2ST_ERR_SHAPE;
+  long n = (long)rows * (C / 4);
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, xsp, y, ysp, rows, C / 4);
+  return LAUNCH_OK();
+}
+
+int s2st_glu_fwd(const float* a, float* y, Split ysp, int rows, int C, hipStream_t st) {
+  long n = (long)rows * C;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(glu_fwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, a, y, ysp, rows, C);
+  return LAUNCH_OK();
+}
+
+int s2st_glu_bwd(const float* a, const float* dy, Split dysp, float* da, Split dasp, int rows,
+                 int C, hipStream_t st) {
+  long n = (long)rows * C;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(glu_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, a, dy, dysp, da, dasp, rows, C);
+  return LAUNCH_OK();
+}
+
+int s2st_add_pe(const float* x, float* y, const int* pos, const float* table, int rows, int C,
+                float scale, const float* alpha_ptr, float drop_p, uint64_t seed, hipStream_t st) {
+  long n = (long)rows * C;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(add_pe_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, y, pos, table, rows, C,
+                     scale, alpha_ptr, drop_p, seed);
+  return LAUNCH_OK();
+}
+
+int s2st_pe_alpha_bwd(const float* dy, const int* pos, const float* table, int rows, int C,
+                      float drop_p, uint64_t seed, float* dalpha, hipStream_t st) {
+  long n = (long)rows * C;
+  if (n <= 0) return 0;
+  unsigned g = ew_grid(n, 8);
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(pe_alpha_bwd_kernel, dim3(g), dim3(EW_BLOCK), 0, st, dy, pos, table, rows, C,
+                     drop_p, seed, dalpha);
+  return LAUNCH_OK();
+}
+
+int s2st_embed_fwd(const long* tokens, const float* table, float* y, int rows, int C, float scale,
+                   hipStream_t st) {
+  long n = (long)rows * C;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, tokens, table, y, rows, C, scale);
+  return LAUNCH_OK();
+}
+
+int s2st_embed_bwd(const long* tokens, const float* dy, float* dtable, int rows, int C, float scale,
+                   long pad, hipStream_t st) {
+  long n = (long)rows * C;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, tokens, dy, dtable, rows, C, scale, pad);
+  return LAUNCH_OK();
+}
+
+int s2st_dropout(const float* x, float* y, long n, float a, float p, uint64_t seed, int accumulate,
+                 hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, y, n, a, p, seed, accumulate);
+  return LAUNCH_OK();
+}
+
+int s2st_relu_drop_bwd(const float* dy, const float* y, float* dz, long n, float p, hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, dy, y, dz, n,
+                     p > 0.f ? 1.f / (1.f - p) : 1.f);
+  return LAUNCH_OK();
+}
+
+int s2st_axpy(const float* x, float* y, long n, float a, hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(axpy_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, y, n, a);
+  return LAUNCH_OK();
+}
+
+int s2st_scale(float* x, long n, float a, hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(scale_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, n, a);
+  return LAUNCH_OK();
+}
+
+int s2st_conv_w_permute(const float* w, float* wf, float* wd, int O, int I, int Kw, hipStream_t st) {
+  long n = (long)O * I * Kw;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(conv_w_permute_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, w, wf, wd, O, I, Kw);
+  return LAUNCH_OK();
+}
+
+int s2st_conv_w_unpermute_acc(const float* dwf, float* dw, int O, int I, int Kw, hipStream_t st) {
+  long n = (long)O * I * Kw;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(conv_w_unpermute_acc_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, dwf, dw, O, I, Kw);
+  return LAUNCH_OK();
+}
+
+// tmp: 2*C floats of scratch
+int s2st_bn_stats(const float* x, int rows, int C, float* mean, float* var, float* run_mean,
+                  float* run_var, float momentum, float* tmp, hipStream_t st) {
+  if (rows <= 0 || C <= 0) return 0;
+  hipMemsetAsync(tmp, 0, sizeof(float) * 2 * C, st);
+  int rc = colreduce2(SumF{x, C}, rows, C, tmp, nullptr, st);
+  if (rc) return rc;
+  rc = colreduce2(SqDevF{x, tmp, C, 1.f / rows}, rows, C, tmp + C, nullptr, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + EW_BLOCK - 1) / EW_BLOCK), dim3(EW_BLOCK), 0, st,
+                     tmp, tmp + C, mean, var, run_mean, run_var, C, rows, momentum);
+  return LAUNCH_OK();
+}
+
+int s2st_bn_apply(const float* x, const float* mean, const float* var, const float* gamma,
+                  const float* beta, float* y, Split ysp, const float* resid, int rows, int C,
+                  float eps, int tanh_, float drop_p, uint64_t seed, hipStream_t st) {
+  long n = (long)rows * C;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, mean, var, gamma,
+                     beta, y, ysp, resid, rows, C, eps, tanh_, drop_p, seed);
+  return LAUNCH_OK();
+}
+
+int s2st_bn_bwd(const float* dy, Split dysp, const float* x, const float* mean, const float* var,
+                const float* gamma, const float* beta, float* dx, Split dxsp, float* dgamma,
+                float* dbeta, float* tmp, int rows, int C, float eps, int tanh_, float drop_p,
+                uint64_t seed, hipStream_t st) {
+  long n = (long)rows * C;
+  if (n <= 0) return 0;
+  BnBwdF f{dy, dysp, x, mean, var, gamma, beta, C, eps, tanh_, drop_p, seed};
+  hipMemsetAsync(tmp, 0, sizeof(float) * 2 * C, st);
+  int rc = colreduce2(f, rows, C, tmp, tmp + C, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, f, tmp, dx, dxsp, rows, C);
+  unsigned g = (C + EW_BLOCK - 1) / EW_BLOCK;
+  hipLaunchKernelGGL(add_vec_kernel, dim3(g), dim3(EW_BLOCK), 0, st, (const float*)tmp, dbeta, C);
+  hipLaunchKernelGGL(add_vec_kernel, dim3(g), dim3(EW_BLOCK), 0, st, (const float*)(tmp + C), dgamma, C);
+  return LAUNCH_OK();
+}

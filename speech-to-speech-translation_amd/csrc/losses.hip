@@ -1,0 +1,292 @@
+// s2st_loss kernels: masked L1 + MSE (pre/post-net) + BCE-with-logits stop loss,
+// label-smoothed cross entropy fused with log-softmax and accuracy, CTC (log-softmax,
+// alpha/beta recursions in LDS, gradient w.r.t. the logits).
+//
+// Reference call sites replaced: examples/s2s_trans/criterions/s2st_loss.py:294-315
+// (compute_loss), :33-50 + :330-348 (label_smoothed_nll_loss, accuracy), :229-243 with
+// s2st_transformer.py:458-463 (log_softmax + torch.nn.CTCLoss(mean, zero_infinity)).
+#include "s2st_ops.h"
+
+namespace {
+
+__device__ __forceinline__ float softplusf_(float x) {  // log(1 + exp(x)), stable
+  return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
+}
+
+// One thread per (row, f) element for the mel terms; thread f == 0 of each row also does the
+// stop-token term.  stats: [0] sum |fo-t| + |fp-t|, [1] sum (fo-t)^2 + (fp-t)^2, [2] sum bce
+__global__ __launch_bounds__(256) void mel_loss_kernel(
+    const float* __restrict__ feat, const float* __restrict__ post, const float* __restrict__ eos,
+    const float* __restrict__ tgt, const int* __restrict__ lens, int B, int D, int F,
+    float pos_weight, float* __restrict__ stats, float c_l1, float c_mse, float c_eos,
+    float* __restrict__ dfeat, float* __restrict__ dpost, float* __restrict__ deos) {
+  __shared__ float red[3][4];
+  const long n = (long)B * D * F;
+  float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    long row = i / F;
+    int f = (int)(i - row * F);
+    int b = (int)(row / D), t = (int)(row - (long)b * D);
+    int len = lens[b];
+    bool valid = t < len;
+    float gt = tgt[i];
+    float e1 = feat[i] - gt, e2 = post[i] - gt;
+    if (valid) {
+      a1 += fabsf(e1) + fabsf(e2);
+      a2 += e1 * e1 + e2 * e2;
+    }
+    if (dfeat) {
+      float s1 = e1 > 0.f ? 1.f : (e1 < 0.f ? -1.f : 0.f);
+      float s2 = e2 > 0.f ? 1.f : (e2 < 0.f ? -1.f : 0.f);
+      dfeat[i] = valid ? c_l1 * s1 + c_mse * 2.f * e1 : 0.f;
+      dpost[i] = valid ? c_l1 * s2 + c_mse * 2.f * e2 : 0.f;
+    }
+    if (f == 0) {
+      float x = eos[row];
+      float y = (t == len - 1) ? 1.f : 0.f;
+      if (valid) a3 += pos_weight * y * softplusf_(-x) + (1.f - y) * softplusf_(x);
+      if (deos) {
+        float sg = 1.f / (1.f + expf(-x));
+        deos[row] = valid ? c_eos * (-pos_weight * y * (1.f - sg) + (1.f - y) * sg) : 0.f;
+      }
+    }
+  }
+  if (stats) {
+    a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = a1; red[1][w] = a2; red[2][w] = a3; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+      int k = threadIdx.x;
+      atomicAdd(&stats[k], red[k][0] + red[k][1] + red[k][2] + red[k][3]);
+    }
+  }
+}
+
+// one wave per row
+__global__ __launch_bounds__(256) void ls_ce_kernel(const float* __restrict__ logits,
+                                                    const long* __restrict__ target, int rows,
+                                                    int V, long pad, float eps,
+                                                    float* __restrict__ stats,
+                                                    float* __restrict__ dlogits, float gscale) {
+  __shared__ float red[4][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float nll_a = 0.f, sm_a = 0.f, cor_a = 0.f, tot_a = 0.f;
+  const float eps_i = eps / (float)(V - 1);
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const float* x = logits + (long)row * V;
+    const long tg = target[row];
+    float mx = -INFINITY;
+    int am = 0;
+    for (int c = lane; c < V; c += 64) {
+      float v = x[c];
+      if (v > mx) { mx = v; am = c; }
+    }
+    // wave arg-max: larger value wins, ties -> smaller index (torch.argmax: first maximum)
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      float ov = __shfl_xor(mx, m);
+      int oi = __shfl_xor(am, m);
+      if (ov > mx || (ov == mx && oi < am)) { mx = ov; am = oi; }
+    }
+    float se = 0.f, sx = 0.f;
+    for (int c = lane; c < V; c += 64) {
+      se += expf(x[c] - mx);
+      sx += x[c];
+    }
+    se = wave_sum(se);
+    sx = wave_sum(sx);
+    const float lse = logf(se) + mx;
+    const bool valid = tg != pad;
+    if (valid) {
+      nll_a += lse - x[tg];          // every lane holds the same value; lane 0 is used below
+      sm_a += (float)V * lse - sx;   // -sum_c lprob_c
+      cor_a += (am == (int)tg) ? 1.f : 0.f;
+      tot_a += 1.f;
+    }
+    if (dlogits) {
+      float* d = dlogits + (long)row * V;
+      for (int c = lane; c < V; c += 64) {
+        float p = expf(x[c] - lse);
+        float g = (1.f - eps - eps_i) * (p - (c == (int)tg ? 1.f : 0.f)) + eps_i * ((float)V * p - 1.f);
+        d[c] = valid ? gscale * g : 0.f;
+      }
+    }
+  }
+  if (stats) {
+    if (lane == 0) { red[0][wave] = nll_a; red[1][wave] = sm_a; red[2][wave] = cor_a; red[3][wave] = tot_a; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      int k = threadIdx.x;
+      atomicAdd(&stats[k], red[k][0] + red[k][1] + red[k][2] + red[k][3]);
+    }
+  }
+}
+
+constexpr float CTC_NEG = -1.0e30f;
+constexpr int CTC_MAXS = 2048;  // 2 * Lmax + 1 <= CTC_MAXS
+constexpr int CTC_MAXV = 512;
+
+__device__ __forceinline__ float lse3(float a, float b, float c) {
+  float m = fmaxf(a, fmaxf(b, c));
+  if (m < -1.0e29f) return CTC_NEG;
+  return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+}
+
+// One workgroup per utterance.  logits [B][E][V]; lp (log-softmax) [B][E][V];
+// alpha workspace [B][E][S_stride].
+__global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logits,
+                                                  const long* __restrict__ targets, int Lmax,
+                                                  const int* __restrict__ in_lens,
+                                                  const int* __restrict__ tgt_lens, int E, int V,
+                                                  float* __restrict__ lp_all,
+                                                  float* __restrict__ alpha_all, int s_stride,
+                                                  float* __restrict__ loss_out,
+                                                  float* __restrict__ dlogits, float gscale) {
+  __shared__ float prev[2][CTC_MAXS];
+  __shared__ float occ[CTC_MAXV];
+  __shared__ int ext[CTC_MAXS];
+  __shared__ float llsh;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = tgt_lens[b];
+  const int Tb = min(in_lens[b], E);
+  const int S = 2 * L + 1;
+  const float* x = logits + (long)b * E * V;
+  float* lp = lp_all + (long)b * E * V;
+  float* alpha = alpha_all + (long)b * E * s_stride;
+  float* dl = dlogits ? dlogits + (long)b * E * V : nullptr;
+
+  // 1) log-softmax of every frame (also the get_normalized_probs output)
+  for (int t = wave; t < E; t += 4) {
+    const float* xr = x + (long)t * V;
+    float mx = -INFINITY;
+    for (int c = lane; c < V; c += 64) mx = fmaxf(mx, xr[c]);
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int c = lane; c < V; c += 64) se += expf(xr[c] - mx);
+    se = wave_sum(se);
+    float lse = logf(se) + mx;
+    for (int c = lane; c < V; c += 64) lp[(long)t * V + c] = xr[c] - lse;
+  }
+  for (int s = tid; s < S; s += 256) ext[s] = (s & 1) ? (int)targets[(long)b * Lmax + (s >> 1)] : 0;
+  for (int v = tid; v < V; v += 256) occ[v] = 0.f;
+  __syncthreads();
+
+  // 2) alpha recursion (previous row in LDS, every row also kept in HBM for step 4)
+  if (Tb > 0) {
+    for (int s = tid; s < S; s += 256) {
+      float a = s < 2 ? lp[ext[s]] : CTC_NEG;
+      prev[0][s] = a;
+      alpha[s] = a;
+    }
+  }
+  __syncthreads();
+  for (int t = 1; t < Tb; ++t) {
+    const float* pr = prev[(t - 1) & 1];
+    float* cu = prev[t & 1];
+    const float* lpt = lp + (long)t * V;
+    for (int s = tid; s < S; s += 256) {
+      float a0 = pr[s];
+      float a1 = s >= 1 ? pr[s - 1] : CTC_NEG;
+      float a2 = (s >= 2 && (s & 1) && ext[s] != ext[s - 2]) ? pr[s - 2] : CTC_NEG;
+      float a = lse3(a0, a1, a2);
+      a = a < -1.0e29f ? CTC_NEG : a + lpt[ext[s]];
+      cu[s] = a;
+      alpha[(long)t * s_stride + s] = a;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float ll = CTC_NEG;
+    if (Tb > 0) {
+      const float* last = prev[(Tb - 1) & 1];
+      ll = lse3(last[S - 1], S >= 2 ? last[S - 2] : CTC_NEG, CTC_NEG);
+    }
+    llsh = ll;
+    float per = (ll < -1.0e29f) ? 0.f : -ll / (float)max(L, 1);  // zero_infinity
+    loss_out[b] = per;
+  }
+  __syncthreads();
+  const float ll = llsh;
+  if (!dl) return;
+  const bool feasible = ll > -1.0e29f;
+  const float sc = gscale / (float)max(L, 1);
+  // frames past the utterance's input length (and infeasible utterances) get zero gradient
+  for (long i = tid; i < (long)E * V; i += 256) {
+    int t = (int)(i / V);
+    if (t >= Tb || !feasible) dl[i] = 0.f;
+  }
+  if (!feasible || Tb <= 0) return;
+
+  // 3+4) beta recursion fused with the occupancy accumulation and the gradient
+  for (int t = Tb - 1; t >= 0; --t) {
+    float* cu = prev[t & 1];
+    const float* nx = prev[(t + 1) & 1];
+    const float* lpt = lp + (long)t * V;
+    for (int s = tid; s < S; s += 256) {
+      float bt;
+      if (t == Tb - 1) {
+        bt = (s >= S - 2) ? lpt[ext[s]] : CTC_NEG;
+      } else {
+        float b0 = nx[s];
+        float b1 = s + 1 < S ? nx[s + 1] : CTC_NEG;
+        float b2 = (s + 2 < S && ((s + 2) & 1) && ext[s + 2] != ext[s]) ? nx[s + 2] : CTC_NEG;
+        bt = lse3(b0, b1, b2);
+        bt = bt < -1.0e29f ? CTC_NEG : bt + lpt[ext[s]];
+      }
+      cu[s] = bt;
+      float al = alpha[(long)t * s_stride + s];
+      if (al > -1.0e29f && bt > -1.0e29f) atomicAdd(&occ[ext[s]], expf(al + bt - lpt[ext[s]] - ll));
+    }
+    __syncthreads();
+    for (int v = tid; v < V; v += 256) {
+      dl[(long)t * V + v] = sc * (expf(lpt[v]) - occ[v]);
+      occ[v] = 0.f;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+#define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH)
+
+int s2st_mel_loss(const float* feat, const float* post, const float* eos, const float* tgt,
+                  const int* lens, int B, int D, int F, float pos_weight, float* stats, float c_l1,
+                  float c_mse, float c_eos, float* dfeat, float* dpost, float* deos,
+                  hipStream_t st) {
+  long n = (long)B * D * F;
+  if (n <= 0) return 0;
+  long blocks = (n + 256 * 4 - 1) / (256 * 4);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(mel_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, st, feat, post, eos, tgt,
+                     lens, B, D, F, pos_weight, stats, c_l1, c_mse, c_eos, dfeat, dpost, deos);
+  return LAUNCH_OK();
+}
+
+int s2st_ls_ce(const float* logits, const long* target, int rows, int V, long pad, float eps,
+               float* stats, float* dlogits, float gscale, hipStream_t st) {
+  if (rows <= 0) return 0;
+  int blocks = (rows + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(ls_ce_kernel, dim3(blocks), dim3(256), 0, st, logits, target, rows, V, pad, eps,
+                     stats, dlogits, gscale);
+  return LAUNCH_OK();
+}
+
+long s2st_ctc_workspace_floats(int B, int E, int Lmax) {
+  long ss = ((2L * Lmax + 1 + 3) / 4) * 4;
+  return (long)B * E * ss;
+}
+
+int s2st_ctc(const float* logits, const long* targets, int Lmax, const int* in_lens,
+             const int* tgt_lens, int B, int E, int V, float* lprobs, float* loss_per_utt,
+             float* dlogits, float gscale, float* ws, hipStream_t st) {
+  if (B <= 0) return 0;
+  if (2 * Lmax + 1 > CTC_MAXS || V > CTC_MAXV) return S2ST_ERR_SHAPE;
+  int ss = ((2 * Lmax + 1 + 3) / 4) * 4;
+  hipLaunchKernelGGL(ctc_kernel, dim3(B), dim3(256), 0, st, logits, targets, Lmax, in_lens, tgt_lens,
+                     E, V, lprobs, ws, ss, loss_per_utt, dlogits, gscale);
+  return LAUNCH_OK();
+}

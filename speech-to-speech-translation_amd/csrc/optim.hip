@@ -1,0 +1,78 @@
+// Optimizer step over the flat parameter arena: gradient L2 norm, then one fused kernel for
+// grad scaling (world / sample_size), clip-by-global-norm and the fairseq flavour of Adam.
+//
+// Reference call sites replaced: fairseq/trainer.py:838-873 (multiply_grads, clip_grad_norm,
+// optimizer.step), fairseq/utils.py:345-395 (clip_grad_norm_; apex multi_tensor_l2norm),
+// fairseq/optim/adam.py:163-239 (Adam.step; apex FusedAdam), fused_adam.py:11-37.
+#include "s2st_ops.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n,
+                                                    float* __restrict__ out) {
+  __shared__ float red[4];
+  float a = 0.f;
+  long n4 = n >> 2;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 v = x4[i];
+    a += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    a += x[i] * x[i];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// gnorm = sqrt(sumsq) * gmul ; coef = max_norm > 0 ? min(1, max_norm / (gnorm + 1e-6)) : 1
+// g' = g * gmul * coef ; m = b1 m + (1-b1) g' ; v = b2 v + (1-b2) g'^2
+// p -= lr*wd*p ; p -= lr * sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   long n, const float* __restrict__ sumsq,
+                                                   float gmul, float max_norm, float lr, float b1,
+                                                   float b2, float eps, float wd, float step_size,
+                                                   float* __restrict__ gnorm_out) {
+  const float gn = sqrtf(sumsq[0]) * gmul;
+  if (gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) gnorm_out[0] = gn;
+  if (!(gn < INFINITY)) return;  // inf / nan gradients: skip the update (trainer.py:860-867)
+  float coef = gmul;
+  if (max_norm > 0.f) coef *= fminf(1.f, max_norm / (gn + 1e-6f));
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float gi = g[i] * coef;
+    g[i] = gi;
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float pi = p[i];
+    if (wd != 0.f) pi -= wd * lr * pi;
+    p[i] = pi - step_size * mi / (sqrtf(vi) + eps);
+  }
+}
+
+}  // namespace
+
+int s2st_sumsq(const float* x, long n, float* out, hipStream_t st) {
+  if (n <= 0) return 0;
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, out);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+
+int s2st_adam(float* p, float* g, float* m, float* v, long n, const float* sumsq, float gmul,
+              float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step,
+              float* gnorm_out, hipStream_t st) {
+  if (n <= 0) return 0;
+  double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  float step_size = (float)((double)lr * sqrt(bc2) / bc1);
+  long blocks = (n + 256 * 4 - 1) / (256 * 4);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, n, sumsq, gmul,
+                     max_norm, lr, beta1, beta2, eps, wd, step_size, gnorm_out);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}

@@ -1,0 +1,317 @@
+// Row-wise kernels: LayerNorm fwd/bwd, attention softmax fwd/bwd (masks + dropout),
+// column sums, head-mean of attention maps.  One wave64 per row, reductions by wave
+// shuffles (no LDS on the row path), 16-byte loads when the row length allows.
+//
+// Reference call sites replaced: fairseq/modules/layer_norm.py:11-35 (F.layer_norm /
+// apex FusedLayerNorm), fairseq/modules/multihead_attention.py:343-366 (mask fill,
+// fp32 softmax, dropout) and the softmax inside F.multi_head_attention_forward (:170-192).
+#include "s2st_ops.h"
+
+namespace {
+
+constexpr int LN_MAXV = 4;  // float4 per lane cached in registers (cols <= 1024)
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            float* __restrict__ y,
+                                                            float* __restrict__ mean_out,
+                                                            float* __restrict__ rstd_out,
+                                                            int rows, int cols, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;  // whole wave exits together (row is wave-uniform)
+  const float* xr = x + (long)row * cols;
+  float* yr = y + (long)row * cols;
+  const int nv = cols >> 2;  // launcher guarantees cols % 4 == 0
+  float4 v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    int c4 = lane + 64 * i;
+    if (c4 < nv) {
+      v[i] = reinterpret_cast<const float4*>(xr)[c4];
+      s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+  }
+  const float mean = wave_sum(s) / cols;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    int c4 = lane + 64 * i;
+    if (c4 < nv) {
+      float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      q += a * a + b * b + c * c + d * d;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / cols + eps);
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    int c4 = lane + 64 * i;
+    if (c4 < nv) {
+      float4 g = reinterpret_cast<const float4*>(gamma)[c4];
+      float4 b = reinterpret_cast<const float4*>(beta)[c4];
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + b.x;
+      o.y = (v[i].y - mean) * rstd * g.y + b.y;
+      o.z = (v[i].z - mean) * rstd * g.z + b.z;
+      o.w = (v[i].w - mean) * rstd * g.w + b.w;
+      reinterpret_cast<float4*>(yr)[c4] = o;
+    }
+  }
+  if (lane == 0) {
+    mean_out[row] = mean;
+    rstd_out[row] = rstd;
+  }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
+    int dx_accumulate, float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int cols) {
+  __shared__ float red[2][4][LN_MAXV * 64];  // [dgamma|dbeta][wave][float4 slot]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = cols >> 2;
+  const float invc = 1.f / cols;
+  float4 ag[LN_MAXV], ab[LN_MAXV];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const float* xr = x + (long)row * cols;
+    const float* dyr = dy + (long)row * cols;
+    float* dxr = dx + (long)row * cols;
+    const float mu = mean[row], rs = rstd[row];
+    float4 xh[LN_MAXV], g[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      int c4 = lane + 64 * i;
+      if (c4 < nv) {
+        float4 xv = reinterpret_cast<const float4*>(xr)[c4];
+        float4 dv = reinterpret_cast<const float4*>(dyr)[c4];
+        float4 gm = reinterpret_cast<const float4*>(gamma)[c4];
+        xh[i].x = (xv.x - mu) * rs; xh[i].y = (xv.y - mu) * rs;
+        xh[i].z = (xv.z - mu) * rs; xh[i].w = (xv.w - mu) * rs;
+        g[i].x = dv.x * gm.x; g[i].y = dv.y * gm.y; g[i].z = dv.z * gm.z; g[i].w = dv.w * gm.w;
+        s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+        s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
+        ag[i].x += dv.x * xh[i].x; ag[i].y += dv.y * xh[i].y;
+        ag[i].z += dv.z * xh[i].z; ag[i].w += dv.w * xh[i].w;
+        ab[i].x += dv.x; ab[i].y += dv.y; ab[i].z += dv.z; ab[i].w += dv.w;
+      }
+    }
+    s1 = wave_sum(s1) * invc;
+    s2 = wave_sum(s2) * invc;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      int c4 = lane + 64 * i;
+      if (c4 < nv) {
+        float4 o;
+        o.x = rs * (g[i].x - s1 - xh[i].x * s2);
+        o.y = rs * (g[i].y - s1 - xh[i].y * s2);
+        o.z = rs * (g[i].z - s1 - xh[i].z * s2);
+        o.w = rs * (g[i].w - s1 - xh[i].w * s2);
+        if (dx_accumulate) {
+          float4 p = reinterpret_cast<float4*>(dxr)[c4];
+          o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+        }
+        reinterpret_cast<float4*>(dxr)[c4] = o;
+      }
+    }
+  }
+  // cross-wave reduction of the parameter gradients, then one atomic per column per block
+  float* rg = &red[0][0][0];
+  float* rb = &red[1][0][0];
+  constexpr int WSTRIDE = LN_MAXV * 64;  // one float4 component per pass
+  for (int comp = 0; comp < 4; ++comp) {
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      int c4 = lane + 64 * i;
+      float gv = comp == 0 ? ag[i].x : comp == 1 ? ag[i].y : comp == 2 ? ag[i].z : ag[i].w;
+      float bv = comp == 0 ? ab[i].x : comp == 1 ? ab[i].y : comp == 2 ? ab[i].z : ab[i].w;
+      rg[wave * WSTRIDE + c4] = gv;
+      rb[wave * WSTRIDE + c4] = bv;
+    }
+    __syncthreads();
+    for (int c4 = threadIdx.x; c4 < nv; c4 += 256) {
+      float gsum = rg[c4] + rg[WSTRIDE + c4] + rg[2 * WSTRIDE + c4] + rg[3 * WSTRIDE + c4];
+      float bsum = rb[c4] + rb[WSTRIDE + c4] + rb[2 * WSTRIDE + c4] + rb[3 * WSTRIDE + c4];
+      atomicAdd(&dgamma[c4 * 4 + comp], gsum);
+      atomicAdd(&dbeta[c4 * 4 + comp], bsum);
+    }
+    __syncthreads();
+  }
+}
+
+constexpr int SM_MAXE = 16;  // elements per lane cached (S <= 1024)
+
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ s,
+                                                          float* __restrict__ p,
+                                                          float* __restrict__ pd,
+                                                          const int* __restrict__ klen, int B,
+                                                          int H, int T, int S, int ld, int causal,
+                                                          float drop_p, uint64_t seed) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long rows = (long)B * H * T;
+  if (row >= rows) return;
+  const int b = (int)(row / ((long)H * T));
+  const int t = (int)(row % T);
+  int lim = klen ? min(klen[b], S) : S;
+  if (causal) lim = min(lim, t + 1);
+  const float* sr = s + row * ld;
+  float* pr = p + row * ld;
+  float v[SM_MAXE];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < SM_MAXE; ++i) {
+    int c = lane + 64 * i;
+    v[i] = (c < lim) ? sr[c] : -INFINITY;
+    mx = fmaxf(mx, v[i]);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < SM_MAXE; ++i) {
+    int c = lane + 64 * i;
+    v[i] = (c < lim) ? expf(v[i] - mx) : 0.f;
+    sum += v[i];
+  }
+  const float inv = 1.f / wave_sum(sum);
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+#pragma unroll
+  for (int i = 0; i < SM_MAXE; ++i) {
+    int c = lane + 64 * i;
+    if (c < S) {
+      float q = v[i] * inv;
+      pr[c] = q;
+      if (pd) pd[row * ld + c] = q * drop_scale(seed, (uint64_t)row * ld + c, drop_p, inv_keep);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ p,
+                                                          const float* __restrict__ dpd,
+                                                          float* __restrict__ ds, long rows, int S,
+                                                          int ld, float drop_p, uint64_t seed) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  float pv[SM_MAXE], dv[SM_MAXE];
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < SM_MAXE; ++i) {
+    int c = lane + 64 * i;
+    pv[i] = dv[i] = 0.f;
+    if (c < S) {
+      pv[i] = p[row * ld + c];
+      dv[i] = dpd[row * ld + c];
+      if (drop_p > 0.f) dv[i] *= drop_scale(seed, (uint64_t)row * ld + c, drop_p, inv_keep);
+      dot += pv[i] * dv[i];
+    }
+  }
+  dot = wave_sum(dot);
+#pragma unroll
+  for (int i = 0; i < SM_MAXE; ++i) {
+    int c = lane + 64 * i;
+    if (c < S) ds[row * ld + c] = pv[i] * (dv[i] - dot);
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long ld, int rows,
+                                                     int cols, float* __restrict__ out,
+                                                     int rows_per_block) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  float a = 0.f;
+  if (c < cols)
+    for (int r = r0 + ty; r < r1; r += 4) a += x[(long)r * ld + c];
+  red[ty][tx] = a;
+  __syncthreads();
+  if (ty == 0 && c < cols) atomicAdd(&out[c], red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
+}
+
+__global__ __launch_bounds__(256) void headmean_kernel(const float* __restrict__ p,
+                                                       float* __restrict__ out, int B, int H, int T,
+                                                       int S, int ld) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  long n = (long)B * T * S;
+  if (i >= n) return;
+  int s = (int)(i % S);
+  int t = (int)((i / S) % T);
+  int b = (int)(i / ((long)S * T));
+  float a = 0.f;
+  for (int h = 0; h < H; ++h) a += p[(((long)b * H + h) * T + t) * ld + s];
+  out[((long)b * S + s) * T + t] = a / H;
+}
+
+}  // namespace
+
+int s2st_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                       float* mean, float* rstd, int rows, int cols, float eps, hipStream_t st) {
+  if (rows <= 0) return 0;
+  if (cols % 4 != 0 || cols > LN_MAXV * 256) return S2ST_ERR_SHAPE;
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, gamma, beta,
+                     y, mean, rstd, rows, cols, eps);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+
+int s2st_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                       const float* rstd, float* dx, int dx_accumulate, float* dgamma,
+                       float* dbeta, int rows, int cols, hipStream_t st) {
+  if (rows <= 0) return 0;
+  if (cols % 4 != 0 || cols > LN_MAXV * 256) return S2ST_ERR_SHAPE;
+  int blocks = (rows + 3) / 4;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, x, gamma, mean,
+                     rstd, dx, dx_accumulate, dgamma, dbeta, rows, cols);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+
+int s2st_softmax_fwd(const float* s, float* p, float* pd, const int* klen, int B, int H, int T,
+                     int S, int ld, int causal, float drop_p, uint64_t seed, hipStream_t st) {
+  long rows = (long)B * H * T;
+  if (rows <= 0) return 0;
+  if (S > SM_MAXE * 64) return S2ST_ERR_SHAPE;
+  if (drop_p <= 0.f) pd = nullptr;
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, s, p,
+                     pd, klen, B, H, T, S, ld, causal, drop_p, seed);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+
+int s2st_softmax_bwd(const float* p, const float* dpd, float* ds, int B, int H, int T, int S,
+                     int ld, float drop_p, uint64_t seed, hipStream_t st) {
+  long rows = (long)B * H * T;
+  if (rows <= 0) return 0;
+  if (S > SM_MAXE * 64) return S2ST_ERR_SHAPE;
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p,
+                     dpd, ds, rows, S, ld, drop_p, seed);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+
+int s2st_colsum(const float* x, long ld, int rows, int cols, float* out, int accumulate,
+                hipStream_t st) {
+  if (cols <= 0) return 0;
+  if (!accumulate) hipMemsetAsync(out, 0, sizeof(float) * cols, st);
+  if (rows <= 0) return 0;
+  int cb = (cols + 63) / 64;
+  int slabs = (512 + cb - 1) / cb;
+  int rpb = (rows + slabs - 1) / slabs;
+  if (rpb < 16) rpb = 16;
+  slabs = (rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL(colsum_kernel, dim3(cb, slabs), dim3(256), 0, st, x, ld, rows, cols, out, rpb);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+
+int s2st_attn_headmean(const float* p, float* out, int B, int H, int T, int S, int ld,
+                       hipStream_t st) {
+  long n = (long)B * T * S;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(headmean_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, out,
+                     B, H, T, S, ld);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}

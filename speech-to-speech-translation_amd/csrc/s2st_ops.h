@@ -70,79 +70,79 @@ int s2st_attn_headmean(const float* p, float* out, int B, int H, int T, int S, i
 // ---------------------------------------------------------------------------------------
 // elementwise (elementwise.hip)
 // ---------------------------------------------------------------------------------------
-// y[r][c] = a[r][c] * sigmoid(a[r][c + C])   a: [rows][2C] ; y rows addressed via split
+// copy [rows][C] between split-addressed buffers (halo padding, zero-stuffing); C % 4 == 0
+int s2st_copy_rows(const float* x, Split xsp, float* y, Split ysp, int rows, int C,
+                   hipStream_t st);
+// y[r][c] = a[r][c] * sigmoid(a[r][c + C])   a: [rows][2C] plain ; y rows via split
 int s2st_glu_fwd(const float* a, float* y, Split ysp, int rows, int C, hipStream_t st);
-int s2st_glu_bwd(const float* a, const float* dy, Split dysp, float* da, int rows, int C,
-                 hipStream_t st);
-// y[b][t][:] = scale * x[b][t][:] + alpha * PE(pos(b, t))  ; pos = t + 2 if t < len[b] else pad
-// alpha read from device pointer if alpha_ptr != null (decoder pos_emb_alpha)
-int s2st_add_pe(const float* x, float* y, const int* lens, int B, int T, int C, float scale,
-                const float* alpha_ptr, float drop_p, uint64_t seed, hipStream_t st);
-// text decoder variant: positions from token ids (pad = 1)
-int s2st_embed_fwd(const long* tokens, const float* table, float* y, int B, int L, int Cin,
-                   float scale, hipStream_t st);
-int s2st_embed_bwd(const long* tokens, const float* dy, float* dtable, int B, int L, int Cin,
-                   float scale, hipStream_t st);
-int s2st_add_pe_tokens(const float* x, float* y, const long* tokens, int B, int L, int C,
-                       float drop_p, uint64_t seed, hipStream_t st);
-// dalpha += sum dy * PE ; used for decoder.pos_emb_alpha
-int s2st_pe_alpha_bwd(const float* dy, const int* lens, int B, int T, int C, float* dalpha,
-                      hipStream_t st);
-// generic: y = x * dropmask (or y = x if p == 0), optional accumulate; flat n elements
-int s2st_dropout(const float* x, float* y, long n, float p, uint64_t seed, int accumulate,
+int s2st_glu_bwd(const float* a, const float* dy, Split dysp, float* da, Split dasp, int rows,
+                 int C, hipStream_t st);
+// y[r][:] = dropout(scale * x[r][:] + alpha * table[pos[r]][:])   (alpha = *alpha_ptr or 1)
+int s2st_add_pe(const float* x, float* y, const int* pos, const float* table, int rows, int C,
+                float scale, const float* alpha_ptr, float drop_p, uint64_t seed, hipStream_t st);
+// dalpha += sum dropmask * dy * table[pos]
+int s2st_pe_alpha_bwd(const float* dy, const int* pos, const float* table, int rows, int C,
+                      float drop_p, uint64_t seed, float* dalpha, hipStream_t st);
+int s2st_embed_fwd(const long* tokens, const float* table, float* y, int rows, int C, float scale,
+                   hipStream_t st);
+int s2st_embed_bwd(const long* tokens, const float* dy, float* dtable, int rows, int C, float scale,
+                   long pad, hipStream_t st);
+// y (+)= a * x * dropmask(p, seed)   (p == 0: plain scaled copy / accumulate)
+int s2st_dropout(const float* x, float* y, long n, float a, float p, uint64_t seed, int accumulate,
                  hipStream_t st);
 // dz = dy * (y != 0 ? 1/(1-p) : 0)   (backward of dropout(relu(z)) given its OUTPUT y)
 int s2st_relu_drop_bwd(const float* dy, const float* y, float* dz, long n, float p,
                        hipStream_t st);
 int s2st_axpy(const float* x, float* y, long n, float a, hipStream_t st);  // y += a * x
 int s2st_scale(float* x, long n, float a, hipStream_t st);
-// copy rows [B][T][C] into a halo-padded buffer [B][T + 2*halo][C] (halo rows untouched)
-int s2st_copy_rows(const float* x, Split xsp, float* y, Split ysp, int rows, int C,
-                   hipStream_t st);
 // conv weight W[O][I][Kw] -> Wf[O][Kw][I] (forward GEMM layout) and, if wd != null,
-// Wd[I][Kw'][O] with Kw' = Kw-1-j (flipped; dgrad GEMM layout)
+// Wd[I][Kw-1-j][O] (flipped; data-gradient GEMM layout)
 int s2st_conv_w_permute(const float* w, float* wf, float* wd, int O, int I, int Kw,
                         hipStream_t st);
 // dW[O][I][Kw] += dWf[O][Kw][I]
 int s2st_conv_w_unpermute_acc(const float* dwf, float* dw, int O, int I, int Kw, hipStream_t st);
-// zero-stuff: up[b][2t][c] = x[b][t][c], odd rows zero (stride-2 conv dgrad)
-// BatchNorm over rows (training): statistics, apply (+tanh)(+dropout), backward
+// BatchNorm1d in training mode over [rows][C] (rows = ALL B*T positions, padded included,
+// tacotron2.py:122-126): two-pass statistics + running-stat update; tmp = 2*C floats
 int s2st_bn_stats(const float* x, int rows, int C, float* mean, float* var, float* run_mean,
-                  float* run_var, float momentum, hipStream_t st);
+                  float* run_var, float momentum, float* tmp, hipStream_t st);
+// y = dropout([tanh](gamma * xhat + beta)) (+ resid)
 int s2st_bn_apply(const float* x, const float* mean, const float* var, const float* gamma,
-                  const float* beta, float* y, Split ysp, int rows, int C, float eps, int tanh_,
-                  float drop_p, uint64_t seed, hipStream_t st);
-int s2st_bn_bwd(const float* dy, Split dysp, const float* x, const float* y, Split ysp,
-                const float* mean, const float* var, const float* gamma, float* dx,
-                float* dgamma, float* dbeta, float* tmp2C, int rows, int C, float eps, int tanh_,
-                float drop_p, uint64_t seed, hipStream_t st);
+                  const float* beta, float* y, Split ysp, const float* resid, int rows, int C,
+                  float eps, int tanh_, float drop_p, uint64_t seed, hipStream_t st);
+// dx (via dxsp) = BN/tanh/dropout backward; dgamma/dbeta += ; tmp = 2*C floats
+int s2st_bn_bwd(const float* dy, Split dysp, const float* x, const float* mean, const float* var,
+                const float* gamma, const float* beta, float* dx, Split dxsp, float* dgamma,
+                float* dbeta, float* tmp, int rows, int C, float eps, int tanh_, float drop_p,
+                uint64_t seed, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------
 // losses (losses.hip)
 // ---------------------------------------------------------------------------------------
-// stats[0..4] += {sum|fo-t|, sum|fp-t|, sum(fo-t)^2, sum(fp-t)^2, sum bce}; valid rows only
-// grads (if non-null) are d(total)/d(.) for total = wl1*(L1o+L1p)/Nf + wmse*(..)/Nf + weos*bce/Nr
+// stats (optional) += {sum|fo-t| + sum|fp-t|, sum(fo-t)^2 + sum(fp-t)^2, sum bce} over valid
+// steps t < lens[b]; stop target = 1 at t == lens[b]-1.  Gradients (optional):
+//   dfeat/dpost = c_l1 * sign(e) + c_mse * 2e ; deos = c_eos * dBCE/dx ; zero on padded steps
 int s2st_mel_loss(const float* feat, const float* post, const float* eos, const float* tgt,
-                  const int* lens, int B, int D, int F, float pos_weight, float* stats,
+                  const int* lens, int B, int D, int F, float pos_weight, float* stats, float c_l1,
+                  float c_mse, float c_eos, float* dfeat, float* dpost, float* deos,
                   hipStream_t st);
-int s2st_mel_loss_bwd(const float* feat, const float* post, const float* eos, const float* tgt,
-                      const int* lens, int B, int D, int F, float pos_weight, float w_l1,
-                      float w_mse, float w_eos, float gscale, float* dfeat, float* dpost,
-                      float* deos, hipStream_t st);
-// label-smoothed CE over logits [rows][V]; stats += {nll_sum, smooth_sum, n_correct, total}
-// dlogits = gscale * d(loss_sum)/dlogits with loss = (1-eps-eps_i)*nll + eps_i*smooth
-int s2st_ls_ce(const float* logits, const long* target, int rows, int V, int pad, float eps,
+// label-smoothed CE over logits [rows][V]; stats (optional) += {nll_sum, smooth_sum,
+// n_correct, total}; dlogits (optional) = gscale * d/dlogits[(1-eps-eps_i) nll + eps_i smooth]
+int s2st_ls_ce(const float* logits, const long* target, int rows, int V, long pad, float eps,
                float* stats, float* dlogits, float gscale, hipStream_t st);
-// log_softmax + CTC (blank 0).  logits [B][E][V].  ws: workspace >= B*E*(2L+1) floats * 2
-int s2st_ctc(const float* logits, const long* targets /*[B][Lmax]*/, const int* in_lens,
-             const int* tgt_lens, int B, int E, int V, int Lmax, float* lprobs_out,
-             float* loss_per_utt, float* dlogits, float gscale_over_B, float* ws, hipStream_t st);
+// log_softmax + CTC (blank 0, zero_infinity).  logits [B][E][V]; targets [B][Lmax];
+// lprobs [B][E][V] (required, also an output); loss_per_utt[b] = nll_b / max(L_b, 1);
+// dlogits (optional) = gscale / max(L_b,1) * (softmax - occupancy), 0 for t >= in_lens[b]
+long s2st_ctc_workspace_floats(int B, int E, int Lmax);
+int s2st_ctc(const float* logits, const long* targets, int Lmax, const int* in_lens,
+             const int* tgt_lens, int B, int E, int V, float* lprobs, float* loss_per_utt,
+             float* dlogits, float gscale, float* ws, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------
 // optimizer (optim.hip)
 // ---------------------------------------------------------------------------------------
 int s2st_sumsq(const float* x, long n, float* out /* += */, hipStream_t st);
-// g *= gmul * clip ; clip = min(1, max_norm / (sqrt(sumsq)*gmul + 1e-6)) ; fairseq Adam
+// g *= gmul * clip ; clip = min(1, max_norm / (sqrt(sumsq)*gmul + 1e-6)) ; fairseq Adam.
+// step >= 1 is the Adam step count; gnorm_out (optional) receives sqrt(sumsq)*gmul.
 int s2st_adam(float* p, float* g, float* m, float* v, long n, const float* sumsq, float gmul,
               float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step,
-              hipStream_t st);
+              float* gnorm_out, hipStream_t st);

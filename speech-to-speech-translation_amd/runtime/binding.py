@@ -123,3 +123,66 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
     g.ep = GemmEpilogue(alpha, act, ptr(bias), drop_p, 1 if accumulate else 0, seed, ptr(resid))
     g.M, g.N, g.K, g.batch, g.zdiv, g.precise = M, N, K, batch, zdiv, 1 if precise else 0
     check(lib().s2st_gemm_f32(C.byref(g), C.c_void_p(stream_ptr())), "s2st_gemm_f32")
+
+
+# ---------------------------------------------------------------------------------------------
+# generic call path: argtypes are derived from include/s2st_hip.h so the binding cannot drift
+# from the declared C ABI
+# ---------------------------------------------------------------------------------------------
+import re
+
+HEADER = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "s2st_hip.h")
+_CT = {"int32_t": C.c_int32, "int64_t": C.c_int64, "uint64_t": C.c_uint64, "float": C.c_float,
+       "int": C.c_int, "s2st_split": Split}
+_protos = None
+
+
+def header_prototypes():
+    """{name: (restype, [(ctype, argname), ...])} parsed from the C header."""
+    global _protos
+    if _protos is not None:
+        return _protos
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(int|int64_t)\s+(s2st_\w+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        alist = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                if "*" in a:
+                    alist.append((C.c_void_p, a.split("*")[-1].strip()))
+                else:
+                    ty, nm = a.rsplit(" ", 1)
+                    alist.append((_CT[ty.replace("const ", "").strip()], nm))
+        out[name] = (C.c_int64 if ret == "int64_t" else C.c_int, alist)
+    _protos = out
+    return out
+
+
+def _bind(name):
+    fn = getattr(lib(), name)
+    if getattr(fn, "_s2st_bound", False):
+        return fn
+    ret, alist = header_prototypes()[name]
+    fn.restype = ret
+    fn.argtypes = [t for t, _ in alist]
+    fn._s2st_bound = True
+    return fn
+
+
+def call(name: str, *args):
+    """Call a C-ABI entry point; torch tensors become device pointers, the trailing `stream`
+    argument is filled with the current torch stream."""
+    fn = _bind(name)
+    conv = []
+    for a in args:
+        if isinstance(a, torch.Tensor):
+            require_device(a)
+            conv.append(a.data_ptr())
+        else:
+            conv.append(a)
+    conv.append(stream_ptr())
+    rc = fn(*conv)
+    check(rc, name)
