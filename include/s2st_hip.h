@@ -141,6 +141,113 @@ int s2st_adam_f32(float* p, float* g, float* m, float* v, int64_t n, const float
 /* floats of workspace s2st_ctc_f32 needs */
 int64_t s2st_ctc_workspace(int32_t B, int32_t E, int32_t Lmax);
 
+/* ======================================================================================
+ * Training engine: the whole s2st_transformer forward (+ s2st_loss) and backward as one
+ * stream-ordered schedule of the kernels above, over flat parameter / gradient arenas.
+ * Replaces, for the hot path, S2STTransformerModel.forward
+ * (examples/s2s_trans/models/s2st_transformer.py:752-786, with encoder :195-237, decoder
+ * :369-456, aux decoders :483-578 over fairseq/models/transformer/transformer_decoder.py:253-378)
+ * and Tacotron2Criterion.forward (criterions/s2st_loss.py:179-292) plus autograd's backward.
+ * ====================================================================================== */
+typedef struct {
+  int32_t enc_layers, dec_layers, enc_dim, dec_dim, enc_ffn, dec_ffn, enc_heads, dec_heads;
+  int32_t enc_pre_ln, dec_pre_ln;
+  int32_t in_dim, conv_channels, conv_k; /* two conv layers, stride 2 (conv_kernel_sizes "k,k") */
+  int32_t out_dim;                        /* output_frame_dim * n_frames_per_step */
+  int32_t prenet_layers, prenet_dim, postnet_layers, postnet_dim, postnet_k;
+  int32_t tap_asr, tap_st;                /* --middle-layers ids (0-based, after the layer); -1 none */
+  int32_t has_asr, has_st, has_ctc;
+  int32_t asr_layers, asr_dim, st_layers, st_dim, src_vocab, tgt_vocab;
+  int32_t no_scale_embedding;
+  int32_t precise;                        /* 1: bf16x3 GEMMs (parity mode) */
+  float dropout, attn_dropout, act_dropout, prenet_dropout, postnet_dropout;
+  float ctc_weight, asr_weight, st_weight, w_l1, w_mse, w_eos, bce_pos_weight, label_smoothing;
+} s2st_model_config;
+
+typedef struct {
+  char name[120];
+  int64_t offset; /* element offset in the flat arena (params: fp32 trainable; buffers: BN stats) */
+  int64_t numel;
+  int32_t ndim;
+  int32_t shape[4];
+  int32_t is_buffer; /* 0: parameter arena, 1: buffer arena */
+} s2st_param_info;
+
+typedef struct {
+  int32_t B, S, D, Ls, Lt;        /* batch, max src frames, max decoder steps, max text lens */
+  int32_t E;                      /* encoder positions = conv-subsampled S (host computes) */
+  const float* src;               /* [B,S,in_dim] */
+  const int32_t* enc_lens;        /* [B] valid encoder positions */
+  const int32_t* enc_pos;         /* [B*E] positional-table rows (make_positions on the pad mask) */
+  const int32_t* ctc_in_lens;     /* [B] (s2st_loss.py:231-232) */
+  const float* prev;              /* [B,D,out_dim] prev_output_tokens */
+  const float* tgt;               /* [B,D,out_dim] tgt_speech */
+  const int32_t* tgt_lens;        /* [B] */
+  const int32_t* dec_pos;         /* [B*D] */
+  const int64_t* prev_src_txt;    /* [B,Ls] */
+  const int64_t* src_txt;         /* [B,Ls] */
+  const int32_t* src_txt_lens;    /* [B] */
+  const int32_t* src_txt_pos;     /* [B*Ls] */
+  const int64_t* prev_tgt_txt;    /* [B,Lt] */
+  const int64_t* tgt_txt;         /* [B,Lt] */
+  const int32_t* tgt_txt_lens;    /* [B] */
+  const int32_t* tgt_txt_pos;     /* [B*Lt] */
+  /* sinusoidal tables [>= T+2][dim] (row 1 = padding row = zeros), built once by the host */
+  const float* pe_enc;            /* dim enc_dim, rows >= E + 2 */
+  const float* pe_dec;            /* dim dec_dim, rows >= D + 2 */
+  const float* pe_asr;            /* dim asr_dim, rows >= Ls + 2 */
+  const float* pe_st;             /* dim st_dim,  rows >= Lt + 2 */
+  int32_t ntokens, src_txt_ntokens, tgt_txt_ntokens; /* host-side sums */
+  int32_t training;               /* BatchNorm batch stats + dropout */
+  int32_t want_attn;              /* also produce the head-averaged alignment [B,E,D] */
+  uint64_t seed;                  /* dropout seed of this step */
+} s2st_batch;
+
+typedef struct { /* caller-owned device outputs; any pointer may be NULL (kept internal) */
+  float* post_feat;   /* [B,D,out_dim] */
+  float* feat;        /* [B,D,out_dim] feature_out */
+  float* eos;         /* [B,D] */
+  float* attn;        /* [B,E,D] */
+  float* enc_out;     /* [B,E,C] (reference layout is [E,B,C]: transpose the view) */
+  float* tap0;        /* [B,E,C] */
+  float* tap1;        /* [B,E,C] */
+  float* asr_logits;  /* [B,Ls,src_vocab] */
+  float* st_logits;   /* [B,Lt,tgt_vocab] */
+  float* ctc_lprobs;  /* [B,E,src_vocab] */
+  float* stats;       /* [32]: see S2ST_STAT_* */
+} s2st_outputs;
+
+enum {
+  S2ST_STAT_L1_SUM = 0, S2ST_STAT_MSE_SUM = 1, S2ST_STAT_BCE_SUM = 2,
+  S2ST_STAT_ASR_NLL = 3, S2ST_STAT_ASR_SMOOTH = 4, S2ST_STAT_ASR_CORRECT = 5, S2ST_STAT_ASR_TOTAL = 6,
+  S2ST_STAT_ST_NLL = 7, S2ST_STAT_ST_SMOOTH = 8, S2ST_STAT_ST_CORRECT = 9, S2ST_STAT_ST_TOTAL = 10,
+  S2ST_STAT_LOSS = 16, S2ST_STAT_L1 = 17, S2ST_STAT_MSE = 18, S2ST_STAT_EOS = 19,
+  S2ST_STAT_CTC = 20, S2ST_STAT_ASR = 21, S2ST_STAT_ST = 22, S2ST_STAT_GNORM = 24
+};
+
+typedef struct s2st_engine s2st_engine;
+
+int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out);
+void s2st_engine_destroy(s2st_engine* e);
+int32_t s2st_engine_num_params(const s2st_engine* e);
+int s2st_engine_param_info(const s2st_engine* e, int32_t i, s2st_param_info* out);
+int64_t s2st_engine_param_floats(const s2st_engine* e);  /* size of the parameter arena */
+int64_t s2st_engine_buffer_floats(const s2st_engine* e); /* size of the buffer arena */
+/* bind caller-owned device arenas: params/grads [param_floats], buffers [buffer_floats] */
+int s2st_engine_bind(s2st_engine* e, float* params, float* grads, float* buffers);
+/* workspace (floats) one forward+backward of this batch geometry needs */
+int64_t s2st_engine_workspace_floats(s2st_engine* e, const s2st_batch* geometry);
+/* forward (+ losses if tgt != NULL).  Activations live in `workspace` until the next call. */
+int s2st_engine_forward(s2st_engine* e, const s2st_batch* b, const s2st_outputs* out,
+                        float* workspace, int64_t workspace_floats, void* stream);
+/* backward of the last forward: grads += gscale * dLoss/dparams. `upto` = -1 runs the whole
+ * tape; otherwise runs tape segments [from previous call, upto) so the caller can interleave
+ * gradient all-reduce of finished arena ranges (see s2st_engine_num_segments). */
+int s2st_engine_backward(s2st_engine* e, float gscale, int32_t segment, void* stream);
+int32_t s2st_engine_num_segments(const s2st_engine* e);
+/* after segment i has run, gradients in arena range [lo, hi) are final */
+int s2st_engine_segment_range(const s2st_engine* e, int32_t i, int64_t* lo, int64_t* hi);
+
 int s2st_version(void);
 /* number of HIP devices visible (0 = none: every compute entry point then fails) */
 int s2st_device_count(void);

@@ -1,0 +1,943 @@
+// s2st training engine: forward + loss + backward of the s2st_transformer as one stream-ordered
+// schedule of HIP kernels over flat parameter / gradient arenas and a bump-allocated
+// activation workspace.  No tracing compiler, no autograd graph: the forward pushes one
+// backward closure per op on a tape; the backward pops them.  Parameters are laid out in
+// forward-use order so the backward finishes gradient ranges back-to-front, which lets the
+// host overlap RCCL all-reduce of finished ranges with the rest of the backward.
+//
+// Reference behaviour reproduced (file:line under /root/reference):
+//   encoder   examples/s2s_trans/models/s2st_transformer.py:94-140, 195-237
+//   decoder   s2st_transformer.py:369-456 ; Prenet/Postnet fairseq/models/text_to_speech/tacotron2.py:85-126
+//   layers    fairseq/modules/transformer_layer.py:107-165, 301-446 ; MHA multihead_attention.py:160-385
+//   aux text decoders  s2st_transformer.py:483-578 ; transformer_decoder.py:253-378
+//   criterion examples/s2s_trans/criterions/s2st_loss.py:179-315
+// Layout: activations are [B][T][C] row-major (the reference is [T][B][C]); padded rows are
+// computed exactly as the reference computes them.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "s2st_ops.h"
+
+namespace {
+
+struct PInfo {
+  std::string name;
+  long off, numel;
+  int ndim;
+  int shape[4];
+  int is_buffer;
+};
+
+struct Ten {  // plain [rows][cols] fp32 activation
+  float* d = nullptr;
+  float* g = nullptr;
+  int rows = 0, cols = 0;
+  bool needs_grad = true;
+  long n() const { return (long)rows * cols; }
+};
+
+struct LinP { long w, b; int N, K; };           // offsets into the param arena (b < 0: no bias)
+struct LNP { long g, b; int C; };
+struct AttnP { long kvq_w, kvq_b, out_w, out_b; };                 // self: [3C][C] k,v,q rows
+struct XAttnP { long kv_w, kv_b, q_w, q_b, out_w, out_b; };         // cross: kv [2C][Cenc]
+struct EncLayerP { AttnP sa; LNP ln1; LinP fc1, fc2; LNP ln2; };
+struct DecLayerP { AttnP sa; LNP ln1; XAttnP xa; LNP ln2; LinP fc1, fc2; LNP ln3; };
+struct ConvP { long w, b; int O, I, Kw; };
+struct BNP { long g, b, rm, rv; int C; };
+struct AuxP {
+  long embed; int V, in_dim, d, layers;
+  long proj_in;  // -1 if none
+  std::vector<DecLayerP> L;
+  LNP ln; bool has_ln;
+  long proj_out; // -1 if none
+  long out_proj;
+};
+
+}  // namespace
+
+struct s2st_engine {
+  s2st_model_config c;
+  std::vector<PInfo> infos;
+  long n_params = 0, n_buffers = 0;
+  float *P = nullptr, *G = nullptr, *BUF = nullptr;
+
+  // parameter handles
+  ConvP sub[2];
+  std::vector<EncLayerP> enc;
+  LNP enc_ln; bool has_enc_ln = false;
+  LNP asr_norm, st_norm;
+  long pos_alpha = 0;
+  std::vector<LinP> prenet;   // prenet_layers + 1
+  std::vector<DecLayerP> dec;
+  LNP dec_ln; bool has_dec_ln = false;
+  LinP feat_proj, eos_proj;
+  std::vector<ConvP> post_conv;
+  std::vector<BNP> post_bn;
+  LinP ctc_proj;
+  AuxP asr, st;
+
+  // per-call state
+  float* ws = nullptr;
+  long ws_cap = 0, ws_top = 0, ws_peak = 0;
+  bool dry = false, oom = false;
+  int err = 0;
+  hipStream_t st_ = nullptr;
+  std::vector<std::function<void()>> tape;
+  std::vector<Ten*> tens;
+  struct Mark { size_t tape_idx; long param_off; };
+  std::vector<Mark> marks;
+  long param_watermark = 0;
+  int next_segment = 0;
+  uint64_t seed = 0, site = 0;
+  float gscale = 1.f;
+  s2st_batch bt;
+  s2st_outputs outs;
+
+  // ------------------------------------------------------------------------------------
+  long add(const std::string& name, std::vector<int> shape, int is_buffer = 0) {
+    PInfo p;
+    p.name = name;
+    p.ndim = (int)shape.size();
+    p.numel = 1;
+    for (int i = 0; i < 4; ++i) p.shape[i] = i < p.ndim ? shape[i] : 1;
+    for (int s : shape) p.numel *= s;
+    long& top = is_buffer ? n_buffers : n_params;
+    p.off = top;
+    top += (p.numel + 3) / 4 * 4;  // keep every tensor 16-byte aligned in the arena
+    p.is_buffer = is_buffer;
+    infos.push_back(p);
+    return p.off;
+  }
+  LinP add_lin(const std::string& pre, int N, int K, bool bias = true) {
+    LinP l;
+    l.N = N; l.K = K;
+    l.w = add(pre + ".weight", {N, K});
+    l.b = bias ? add(pre + ".bias", {N}) : -1;
+    return l;
+  }
+  LNP add_ln(const std::string& pre, int C) {
+    LNP l;
+    l.C = C;
+    l.g = add(pre + ".weight", {C});
+    l.b = add(pre + ".bias", {C});
+    return l;
+  }
+  AttnP add_self_attn(const std::string& pre, int C) {
+    AttnP a;
+    a.kvq_w = add(pre + ".k_proj.weight", {C, C});
+    add(pre + ".v_proj.weight", {C, C});
+    add(pre + ".q_proj.weight", {C, C});
+    a.kvq_b = add(pre + ".k_proj.bias", {C});
+    add(pre + ".v_proj.bias", {C});
+    add(pre + ".q_proj.bias", {C});
+    a.out_w = add(pre + ".out_proj.weight", {C, C});
+    a.out_b = add(pre + ".out_proj.bias", {C});
+    return a;
+  }
+  XAttnP add_cross_attn(const std::string& pre, int C, int Cenc) {
+    XAttnP a;
+    a.kv_w = add(pre + ".k_proj.weight", {C, Cenc});
+    add(pre + ".v_proj.weight", {C, Cenc});
+    a.kv_b = add(pre + ".k_proj.bias", {C});
+    add(pre + ".v_proj.bias", {C});
+    a.q_w = add(pre + ".q_proj.weight", {C, C});
+    a.q_b = add(pre + ".q_proj.bias", {C});
+    a.out_w = add(pre + ".out_proj.weight", {C, C});
+    a.out_b = add(pre + ".out_proj.bias", {C});
+    return a;
+  }
+  DecLayerP add_dec_layer(const std::string& pre, int C, int ffn, int Cenc) {
+    DecLayerP l;
+    l.sa = add_self_attn(pre + ".self_attn", C);
+    l.ln1 = add_ln(pre + ".self_attn_layer_norm", C);
+    l.xa = add_cross_attn(pre + ".encoder_attn", C, Cenc);
+    l.ln2 = add_ln(pre + ".encoder_attn_layer_norm", C);
+    l.fc1 = add_lin(pre + ".fc1", ffn, C);
+    l.fc2 = add_lin(pre + ".fc2", C, ffn);
+    l.ln3 = add_ln(pre + ".final_layer_norm", C);
+    return l;
+  }
+  AuxP add_aux(const std::string& pre, int V, int in_dim, int d, int layers) {
+    AuxP a;
+    a.V = V; a.in_dim = in_dim; a.d = d; a.layers = layers;
+    a.embed = add(pre + ".embed_tokens.weight", {V, in_dim});
+    a.proj_in = d != in_dim ? add(pre + ".project_in_dim.weight", {d, in_dim}) : -1;
+    for (int i = 0; i < layers; ++i)
+      a.L.push_back(add_dec_layer(pre + ".layers." + std::to_string(i), d, c.dec_ffn, c.enc_dim));
+    a.has_ln = c.dec_pre_ln != 0;
+    if (a.has_ln) a.ln = add_ln(pre + ".layer_norm", d);
+    a.proj_out = d != 512 ? add(pre + ".project_out_dim.weight", {512, d}) : -1;
+    a.out_proj = add(pre + ".output_projection.weight", {V, 512});
+    return a;
+  }
+
+  void build_params() {
+    const int C = c.enc_dim, Cd = c.dec_dim;
+    // forward-use order == arena order (see file header)
+    sub[0] = ConvP{add("encoder.subsample.conv_layers.0.weight", {c.conv_channels, c.in_dim, c.conv_k}),
+                   add("encoder.subsample.conv_layers.0.bias", {c.conv_channels}), c.conv_channels,
+                   c.in_dim, c.conv_k};
+    sub[1] = ConvP{add("encoder.subsample.conv_layers.1.weight", {2 * C, c.conv_channels / 2, c.conv_k}),
+                   add("encoder.subsample.conv_layers.1.bias", {2 * C}), 2 * C, c.conv_channels / 2,
+                   c.conv_k};
+    for (int i = 0; i < c.enc_layers; ++i) {
+      std::string pre = "encoder.transformer_layers." + std::to_string(i);
+      EncLayerP l;
+      l.sa = add_self_attn(pre + ".self_attn", C);
+      l.ln1 = add_ln(pre + ".self_attn_layer_norm", C);
+      l.fc1 = add_lin(pre + ".fc1", c.enc_ffn, C);
+      l.fc2 = add_lin(pre + ".fc2", C, c.enc_ffn);
+      l.ln2 = add_ln(pre + ".final_layer_norm", C);
+      enc.push_back(l);
+    }
+    has_enc_ln = c.enc_pre_ln != 0;
+    if (has_enc_ln) enc_ln = add_ln("encoder.layer_norm", C);
+    if (c.has_asr) asr_norm = add_ln("encoder.aux_asr_norm", C);
+    if (c.has_st) st_norm = add_ln("encoder.aux_st_norm", C);
+    pos_alpha = add("decoder.pos_emb_alpha", {1});
+    for (int i = 0; i < c.prenet_layers; ++i)
+      prenet.push_back(add_lin("decoder.prenet.0.layers." + std::to_string(i) + ".0",
+                               c.prenet_dim, i == 0 ? c.out_dim : c.prenet_dim));
+    prenet.push_back(add_lin("decoder.prenet.1", Cd, c.prenet_dim));
+    for (int i = 0; i < c.dec_layers; ++i)
+      dec.push_back(add_dec_layer("decoder.transformer_layers." + std::to_string(i), Cd, c.dec_ffn, C));
+    has_dec_ln = c.dec_pre_ln != 0;
+    if (has_dec_ln) dec_ln = add_ln("decoder.layer_norm", Cd);
+    feat_proj = add_lin("decoder.feat_proj", c.out_dim, Cd);
+    eos_proj = add_lin("decoder.eos_proj", 1, Cd);
+    for (int i = 0; i < c.postnet_layers; ++i) {
+      int ci = i == 0 ? c.out_dim : c.postnet_dim;
+      int co = i == c.postnet_layers - 1 ? c.out_dim : c.postnet_dim;
+      std::string pre = "decoder.postnet.convolutions." + std::to_string(i);
+      ConvP cv{add(pre + ".0.weight", {co, ci, c.postnet_k}), add(pre + ".0.bias", {co}), co, ci, c.postnet_k};
+      post_conv.push_back(cv);
+      BNP bn;
+      bn.C = co;
+      bn.g = add(pre + ".1.weight", {co});
+      bn.b = add(pre + ".1.bias", {co});
+      bn.rm = add(pre + ".1.running_mean", {co}, 1);
+      bn.rv = add(pre + ".1.running_var", {co}, 1);
+      post_bn.push_back(bn);
+    }
+    if (c.has_ctc) ctc_proj = add_lin("decoder.ctc_proj", c.src_vocab, C);
+    // aux decoders: embedding dims follow the reference's in-place args mutation
+    // (s2st_transformer.py:492-493, 541-542, 669-678)
+    int cur = Cd;
+    if (c.has_asr) {
+      asr = add_aux("aux_asr_decoder", c.src_vocab, cur, c.asr_dim, c.asr_layers);
+      cur = c.asr_dim;
+    }
+    if (c.has_st) st = add_aux("aux_st_decoder", c.tgt_vocab, cur, c.st_dim, c.st_layers);
+  }
+
+  // ------------------------------------------------------------------------------------
+  // arena
+  float* alloc(long n, bool zero = false) {
+    n = (n + 63) / 64 * 64;
+    float* p = nullptr;
+    if (ws_top + n > ws_cap) {
+      if (!dry) { oom = true; err = S2ST_ERR_WORKSPACE; }
+    } else {
+      p = ws + ws_top;
+    }
+    ws_top += n;
+    if (ws_top > ws_peak) ws_peak = ws_top;
+    if (p && zero && !dry) hipMemsetAsync(p, 0, sizeof(float) * n, st_);
+    return p;
+  }
+  Ten* newT(int rows, int cols, float* ext = nullptr) {
+    Ten* t = new Ten();
+    t->rows = rows; t->cols = cols;
+    t->d = ext ? ext : alloc(t->n());
+    tens.push_back(t);
+    return t;
+  }
+  // gradient buffer of t: first request allocates it (acc = false: caller must overwrite),
+  // later requests accumulate
+  float* gradbuf(Ten* t, bool& acc) {
+    if (t->g) { acc = true; return t->g; }
+    t->g = alloc(t->n());
+    acc = false;
+    return t->g;
+  }
+  bool live() const { return !dry && !oom && err == 0; }
+  void chk(int rc) { if (rc && !err) err = rc; }
+  uint64_t next_seed() { return seed * 0x100000001B3ULL + (++site) * 0x9E3779B97F4A7C15ULL; }
+  void mark() { marks.push_back(Mark{tape.size(), param_watermark}); }
+  void touch(long off_end) { if (off_end > param_watermark) param_watermark = off_end; }
+
+  // ------------------------------------------------------------------------------------
+  // op: y = [resid +] dropout(act(x W^T + b))
+  Ten* linear(Ten* x, long w, long b, int N, int K, int act = 0, float drop_p = 0.f,
+              Ten* resid = nullptr, float* ext_out = nullptr) {
+    const int M = x->rows;
+    Ten* y = newT(M, N, ext_out);
+    touch(w + (long)N * K);
+    if (b >= 0) touch(b + N);
+    const uint64_t sd = drop_p > 0.f ? next_seed() : 0;
+    if (live()) {
+      GemmArgs g{};
+      g.A = gemm_rowmajor(x->d, x->cols);
+      g.B = gemm_rowmajor(P + w, K);
+      g.C = gemm_out(y->d, N);
+      g.ep = gemm_epi_default();
+      g.ep.bias = b >= 0 ? P + b : nullptr;
+      g.ep.act = act;
+      g.ep.drop_p = drop_p;
+      g.ep.seed = sd;
+      g.ep.resid = resid ? resid->d : nullptr;
+      g.M = M; g.N = N; g.K = K; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
+      chk(s2st_gemm(g, st_));
+    }
+    tape.push_back([=]() {
+      if (!y->g) return;  // nothing flowed back
+      float* dy = y->g;
+      if (resid && resid->needs_grad) {
+        if (!resid->g) resid->g = dy;  // alias: every reader of dy runs before resid's producers
+        else if (live()) chk(s2st_axpy(dy, resid->g, y->n(), 1.f, st_));
+      }
+      float* dpre = dy;
+      if (act == 1) {
+        dpre = alloc(y->n());
+        if (live()) chk(s2st_relu_drop_bwd(dy, y->d, dpre, y->n(), drop_p, st_));
+      } else if (drop_p > 0.f) {
+        dpre = alloc(y->n());
+        if (live()) chk(s2st_dropout(dy, dpre, y->n(), 1.f, drop_p, sd, 0, st_));
+      }
+      if (live()) {
+        GemmArgs g{};  // dW[N][K] += dpre^T x
+        g.A = gemm_colmajor(dpre, N);
+        g.B = gemm_colmajor(x->d, x->cols);
+        g.C = gemm_out(G + w, K);
+        g.ep = gemm_epi_default();
+        g.ep.accumulate = 1;
+        g.M = N; g.N = K; g.K = M; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
+        chk(s2st_gemm(g, st_));
+        if (b >= 0) chk(s2st_colsum(dpre, N, M, N, G + b, 1, st_));
+      }
+      if (x->needs_grad) {
+        bool acc;
+        float* dx = gradbuf(x, acc);
+        if (live()) {
+          GemmArgs g{};  // dx[M][K] (+)= dpre W
+          g.A = gemm_rowmajor(dpre, N);
+          g.B = gemm_colmajor(P + w, K);
+          g.C = gemm_out(dx, x->cols);
+          g.ep = gemm_epi_default();
+          g.ep.accumulate = acc ? 1 : 0;
+          g.M = M; g.N = K; g.K = N; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
+          chk(s2st_gemm(g, st_));
+        }
+      }
+    });
+    return y;
+  }
+
+  Ten* layernorm(Ten* x, const LNP& p, float* ext_out = nullptr) {
+    Ten* y = newT(x->rows, x->cols, ext_out);
+    float* mean = alloc(x->rows);
+    float* rstd = alloc(x->rows);
+    touch(p.b + p.C);
+    if (live()) chk(s2st_layernorm_fwd(x->d, P + p.g, P + p.b, y->d, mean, rstd, x->rows, x->cols, 1e-5f, st_));
+    LNP pp = p;
+    tape.push_back([=]() {
+      if (!y->g) return;
+      bool acc;
+      float* dx = gradbuf(x, acc);
+      if (live())
+        chk(s2st_layernorm_bwd(y->g, x->d, P + pp.g, mean, rstd, dx, acc ? 1 : 0, G + pp.g, G + pp.b,
+                               x->rows, x->cols, st_));
+    });
+    return y;
+  }
+
+  // attention core.  q: [B*T] rows at qp (+ h*dh), ld ldq ; k/v rows [B*S] ; out [B*T][C]
+  struct AttnIO {
+    Ten* qt; int qoff, ldq;     // tensor holding q, column offset, row stride
+    Ten* kt; int koff, ldk;
+    Ten* vt; int voff, ldv;
+  };
+  Ten* attention(const AttnIO& io, int B, int T, int S, int H, int dh, const int* klen, int causal,
+                 float drop_p, float* attn_mean_out /* [B][S][T] or null */) {
+    const int C = H * dh;
+    const int ld = (S + 3) / 4 * 4;
+    Ten* o = newT(B * T, C);
+    float* p = alloc((long)B * H * T * ld);
+    float* pd = drop_p > 0.f ? alloc((long)B * H * T * ld) : p;
+    const uint64_t sd = drop_p > 0.f ? next_seed() : 0;
+    const float scaling = 1.0f / sqrtf((float)dh);
+    const int prec = c.precise;
+    auto bgemm = [=](const float* A, int akm, long ald, long azo, const float* Bp, int bkm, long bld,
+                     long bzo, float* Cp, long cld, long czo, long czi, long azi, long bzi, int M, int N,
+                     int K, float alpha) {
+      GemmArgs g{};
+      g.A = akm ? gemm_rowmajor(A, ald) : gemm_colmajor(A, ald);
+      g.A.zo = azo; g.A.zi = azi;
+      g.B = bkm ? gemm_rowmajor(Bp, bld) : gemm_colmajor(Bp, bld);
+      g.B.zo = bzo; g.B.zi = bzi;
+      g.C = gemm_out(Cp, cld);
+      g.C.zo = czo; g.C.zi = czi;
+      g.ep = gemm_epi_default();
+      g.ep.alpha = alpha;
+      g.M = M; g.N = N; g.K = K; g.batch = B * H; g.zdiv = H; g.precise = prec;
+      chk(s2st_gemm(g, st_));
+    };
+    const long pzo = (long)H * T * ld, pzi = (long)T * ld;
+    if (live()) {
+      // scores = (q * dh^-0.5) k^T      (multihead_attention.py:224, 332)
+      bgemm(io.qt->d + io.qoff, 1, io.ldq, (long)T * io.ldq, io.kt->d + io.koff, 1, io.ldk,
+            (long)S * io.ldk, p, ld, pzo, pzi, dh, dh, T, S, dh, scaling);
+      chk(s2st_softmax_fwd(p, p, drop_p > 0.f ? pd : nullptr, klen, B, H, T, S, ld, causal, drop_p, sd, st_));
+      // o = dropout(p) v                 (:367)
+      bgemm(pd, 1, ld, pzo, io.vt->d + io.voff, 0, io.ldv, (long)S * io.ldv, o->d, C, (long)T * C, dh,
+            pzi, dh, T, dh, S, 1.f);
+      if (attn_mean_out) chk(s2st_attn_headmean(p, attn_mean_out, B, H, T, S, ld, st_));
+    }
+    AttnIO io2 = io;
+    tape.push_back([=]() {
+      if (!o->g) return;
+      // q/k/v gradients are written into column blocks of their holders' gradient buffers
+      bool aq, ak, av;
+      float* gq = gradbuf(io2.qt, aq);
+      float* gk = gradbuf(io2.kt, ak);
+      float* gv = gradbuf(io2.vt, av);
+      (void)aq; (void)ak; (void)av;  // column blocks are disjoint and written exactly once
+      float* dp = alloc((long)B * H * T * ld);
+      if (!live()) return;
+      // dPd = dO V^T
+      bgemm(o->g, 1, C, (long)T * C, io2.vt->d + io2.voff, 1, io2.ldv, (long)S * io2.ldv, dp, ld, pzo,
+            pzi, dh, dh, T, S, dh, 1.f);
+      // dV = Pd^T dO
+      bgemm(pd, 0, ld, pzo, o->g, 0, C, (long)T * C, gv + io2.voff, io2.ldv, (long)S * io2.ldv, dh, pzi,
+            dh, S, dh, T, 1.f);
+      chk(s2st_softmax_bwd(p, dp, dp, B, H, T, S, ld, drop_p, sd, st_));
+      // dQ = scaling * dS K ; dK = scaling * dS^T Q
+      bgemm(dp, 1, ld, pzo, io2.kt->d + io2.koff, 0, io2.ldk, (long)S * io2.ldk, gq + io2.qoff, io2.ldq,
+            (long)T * io2.ldq, dh, pzi, dh, T, dh, S, scaling);
+      bgemm(dp, 0, ld, pzo, io2.qt->d + io2.qoff, 0, io2.ldq, (long)T * io2.ldq, gk + io2.koff, io2.ldk,
+            (long)S * io2.ldk, dh, pzi, dh, S, dh, T, scaling);
+    });
+    return o;
+  }
+
+  Ten* self_attn_block(Ten* x, const AttnP& a, int B, int T, int H, const int* klen, int causal,
+                       Ten* resid) {
+    const int C = x->cols;
+    Ten* kvq = linear(x, a.kvq_w, a.kvq_b, 3 * C, C);
+    AttnIO io{kvq, 2 * C, 3 * C, kvq, 0, 3 * C, kvq, C, 3 * C};
+    Ten* o = attention(io, B, T, T, H, C / H, klen, causal, bt.training ? c.attn_dropout : 0.f, nullptr);
+    return linear(o, a.out_w, a.out_b, C, C, 0, bt.training ? c.dropout : 0.f, resid);
+  }
+  Ten* cross_attn_block(Ten* x, Ten* encx, const XAttnP& a, int B, int T, int S, int H,
+                        const int* klen, Ten* resid, float* attn_mean_out) {
+    const int C = x->cols;
+    Ten* q = linear(x, a.q_w, a.q_b, C, C);
+    Ten* kv = linear(encx, a.kv_w, a.kv_b, 2 * C, encx->cols);
+    AttnIO io{q, 0, C, kv, 0, 2 * C, kv, C, 2 * C};
+    Ten* o = attention(io, B, T, S, H, C / H, klen, 0, bt.training ? c.attn_dropout : 0.f, attn_mean_out);
+    return linear(o, a.out_w, a.out_b, C, C, 0, bt.training ? c.dropout : 0.f, resid);
+  }
+  Ten* ffn_block(Ten* x, const LinP& fc1, const LinP& fc2, Ten* resid) {
+    Ten* h = linear(x, fc1.w, fc1.b, fc1.N, fc1.K, 1, bt.training ? c.act_dropout : 0.f);
+    return linear(h, fc2.w, fc2.b, fc2.N, fc2.K, 0, bt.training ? c.dropout : 0.f, resid);
+  }
+  Ten* enc_layer(Ten* x, const EncLayerP& l, int B, int T) {
+    const int H = c.enc_heads;
+    if (c.enc_pre_ln) {
+      x = self_attn_block(layernorm(x, l.ln1), l.sa, B, T, H, bt.enc_lens, 0, x);
+      return ffn_block(layernorm(x, l.ln2), l.fc1, l.fc2, x);
+    }
+    x = layernorm(self_attn_block(x, l.sa, B, T, H, bt.enc_lens, 0, x), l.ln1);
+    return layernorm(ffn_block(x, l.fc1, l.fc2, x), l.ln2);
+  }
+  Ten* dec_layer(Ten* x, Ten* encx, const DecLayerP& l, int B, int T, int S, int H, bool pre_ln,
+                 const int* self_klen, float* attn_mean_out) {
+    if (pre_ln) {
+      x = self_attn_block(layernorm(x, l.ln1), l.sa, B, T, H, self_klen, 1, x);
+      x = cross_attn_block(layernorm(x, l.ln2), encx, l.xa, B, T, S, H, bt.enc_lens, x, attn_mean_out);
+      return ffn_block(layernorm(x, l.ln3), l.fc1, l.fc2, x);
+    }
+    x = layernorm(self_attn_block(x, l.sa, B, T, H, self_klen, 1, x), l.ln1);
+    x = layernorm(cross_attn_block(x, encx, l.xa, B, T, S, H, bt.enc_lens, x, attn_mean_out), l.ln2);
+    return layernorm(ffn_block(x, l.fc1, l.fc2, x), l.ln3);
+  }
+
+  // conv over a halo-padded input.  xh: [B][Tin + 2*pad][I] (zeros in the halo); returns z [B*Tout][O].
+  // The backward needs dz both plain (weight gradient / bias) and as a halo-padded, for
+  // stride 2 zero-stuffed, image (data gradient as a stride-1 correlation with flipped taps).
+  struct ConvIn { float* xh; Ten* src; int Tin; };  // src: plain tensor whose grad we produce (or null)
+  Ten* conv(const ConvIn& in, const ConvP& p, int B, int stride, float* wf, float* wd, float* dwf) {
+    const int pad = p.Kw / 2;
+    const int Tin = in.Tin, Tout = (Tin + 2 * pad - p.Kw) / stride + 1;
+    const int Th = Tin + 2 * pad;
+    Ten* z = newT(B * Tout, p.O);
+    touch(p.w + (long)p.O * p.I * p.Kw);
+    touch(p.b + p.O);
+    if (live()) {
+      GemmArgs g{};
+      g.A = gemm_rowmajor(in.xh, (long)stride * p.I);
+      g.A.sp.per = Tout; g.A.sp.bs = (long)Th * p.I;
+      g.B = gemm_rowmajor(wf, (long)p.Kw * p.I);
+      g.C = gemm_out(z->d, p.O);
+      g.ep = gemm_epi_default();
+      g.ep.bias = P + p.b;
+      g.M = B * Tout; g.N = p.O; g.K = p.Kw * p.I; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
+      chk(s2st_gemm(g, st_));
+    }
+    ConvP pp = p;
+    ConvIn in2 = in;
+    tape.push_back([=]() {
+      if (!z->g) return;
+      const int M = B * Tout;
+      if (live()) {
+        GemmArgs g{};  // dWf[O][(j,c)] += sum_(b,t) dz[(b,t)][o] * xh[b][t*stride + j][c]
+        g.A = gemm_colmajor(z->g, pp.O);
+        g.B = gemm_colmajor(in2.xh, (long)stride * pp.I);
+        g.B.sp.per = Tout; g.B.sp.bs = (long)Th * pp.I;
+        g.C = gemm_out(dwf, (long)pp.Kw * pp.I);
+        g.ep = gemm_epi_default();
+        g.ep.accumulate = 1;
+        g.M = pp.O; g.N = pp.Kw * pp.I; g.K = M; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
+        chk(s2st_gemm(g, st_));
+        chk(s2st_colsum(z->g, pp.O, M, pp.O, G + pp.b, 1, st_));
+        chk(s2st_conv_w_unpermute_acc(dwf, G + pp.w, pp.O, pp.I, pp.Kw, st_));
+      }
+      if (in2.src && in2.src->needs_grad) {
+        // dz placed at rows pad + stride*t of a zeroed [B][Tin + 2 pad][O] image
+        float* up = alloc((long)B * Th * pp.O, true);
+        bool acc;
+        float* dx = gradbuf(in2.src, acc);
+        if (live()) {
+          Split xs{(long)pp.O, 0, 0, 0};
+          Split ys{(long)stride * pp.O, (long)Th * pp.O, Tout, 0};
+          chk(s2st_copy_rows(z->g, xs, up + (long)pad * pp.O, ys, M, pp.O, st_));
+          GemmArgs g{};  // dx[(b,u)][c] = sum_(j',o) up[b][u + j'][o] * Wd[c][j'][o]
+          g.A = gemm_rowmajor(up, pp.O);
+          g.A.sp.per = Tin; g.A.sp.bs = (long)Th * pp.O;
+          g.B = gemm_rowmajor(wd, (long)pp.Kw * pp.O);
+          g.C = gemm_out(dx, pp.I);
+          g.ep = gemm_epi_default();
+          g.ep.accumulate = acc ? 1 : 0;
+          g.M = B * Tin; g.N = pp.I; g.K = pp.Kw * pp.O; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
+          chk(s2st_gemm(g, st_));
+        }
+      }
+    });
+    return z;
+  }
+
+  // GLU of z [rows][2C] into a halo-padded image [B][T + 2 pad][C]; returns the plain-gradient
+  // holder for the image (its grad is [rows][C] plain)
+  Ten* glu_to(Ten* z, float* y, Split ysp, int Cc) {
+    Ten* holder = newT(z->rows, Cc, y);  // d points at the (possibly halo) image; only g is used plainly
+    if (live()) chk(s2st_glu_fwd(z->d, y, ysp, z->rows, Cc, st_));
+    tape.push_back([=]() {
+      if (!holder->g) return;
+      bool acc;
+      float* dz = gradbuf(z, acc);
+      (void)acc;  // single consumer
+      Split ds{(long)Cc, 0, 0, 0}, das{(long)2 * Cc, 0, 0, 0};
+      if (live()) chk(s2st_glu_bwd(z->d, holder->g, ds, dz, das, z->rows, Cc, st_));
+    });
+    return holder;
+  }
+
+  Ten* add_pe(Ten* x, const int* pos, const float* table, float scale, long alpha_off, float drop_p) {
+    Ten* y = newT(x->rows, x->cols);
+    const uint64_t sd = drop_p > 0.f ? next_seed() : 0;
+    if (alpha_off >= 0) touch(alpha_off + 1);
+    if (live())
+      chk(s2st_add_pe(x->d, y->d, pos, table, x->rows, x->cols, scale, alpha_off >= 0 ? P + alpha_off : nullptr,
+                      drop_p, sd, st_));
+    tape.push_back([=]() {
+      if (!y->g) return;
+      if (alpha_off >= 0 && live())
+        chk(s2st_pe_alpha_bwd(y->g, pos, table, x->rows, x->cols, drop_p, sd, G + alpha_off, st_));
+      if (x->needs_grad) {
+        bool acc;
+        float* dx = gradbuf(x, acc);
+        if (live()) chk(s2st_dropout(y->g, dx, x->n(), scale, drop_p, sd, acc ? 1 : 0, st_));
+      }
+    });
+    return y;
+  }
+
+  Ten* aux_decoder(const AuxP& a, Ten* tap, const long* prev_tok, const int* pos, const int* lens, int B,
+                   int L, const float* pe, float* logits_out) {
+    const int E = bt.E;
+    Ten* emb = newT(B * L, a.in_dim);
+    const float scale = c.no_scale_embedding ? 1.f : sqrtf((float)a.d);
+    touch(a.embed + (long)a.V * a.in_dim);
+    if (live()) chk(s2st_embed_fwd(prev_tok, P + a.embed, emb->d, B * L, a.in_dim, scale, st_));
+    long embed_off = a.embed;
+    int in_dim = a.in_dim;
+    tape.push_back([=]() {
+      if (!emb->g) return;
+      if (live()) chk(s2st_embed_bwd(prev_tok, emb->g, G + embed_off, B * L, in_dim, scale, 1, st_));
+    });
+    Ten* x = emb;
+    if (a.proj_in >= 0) x = linear(x, a.proj_in, -1, a.d, a.in_dim);
+    x = add_pe(x, pos, pe, 1.f, -1, bt.training ? c.dropout : 0.f);
+    for (int i = 0; i < a.layers; ++i)
+      x = dec_layer(x, tap, a.L[i], B, L, E, c.dec_heads, c.dec_pre_ln != 0, lens, nullptr);
+    if (a.has_ln) x = layernorm(x, a.ln);
+    if (a.proj_out >= 0) x = linear(x, a.proj_out, -1, 512, a.d);
+    return linear(x, a.out_proj, -1, a.V, 512, 0, 0.f, nullptr, logits_out);
+  }
+
+  // ------------------------------------------------------------------------------------
+  void reset_call() {
+    for (Ten* t : tens) delete t;
+    tens.clear();
+    tape.clear();
+    marks.clear();
+    ws_top = 0;
+    ws_peak = 0;
+    oom = false;
+    err = 0;
+    site = 0;
+    param_watermark = 0;
+    next_segment = 0;
+  }
+
+  int forward() {
+    const int B = bt.B, S = bt.S, D = bt.D, C = c.enc_dim, Cd = c.dec_dim;
+    const int pad = c.conv_k / 2;
+    const int T1 = (S + 2 * pad - c.conv_k) / 2 + 1;
+    const int T2 = (T1 + 2 * pad - c.conv_k) / 2 + 1;
+    if (T2 != bt.E) return S2ST_ERR_SHAPE;
+    const int E = T2;
+    const bool tr = bt.training != 0;
+    const bool with_loss = bt.tgt != nullptr;
+    seed = bt.seed;
+
+    // sinusoidal tables come from the host side (cached per dim); conv weight layouts are
+    // scratch at the bottom of the workspace
+    const float *pe_enc = bt.pe_enc, *pe_dec = bt.pe_dec, *pe_asr = bt.pe_asr, *pe_st = bt.pe_st;
+    struct ConvScratch { float *wf, *wd, *dwf; };
+    auto conv_scratch = [&](const ConvP& p, bool need_wd) {
+      ConvScratch s;
+      long n = (long)p.O * p.I * p.Kw;
+      s.wf = alloc(n);
+      s.wd = need_wd ? alloc(n) : nullptr;
+      s.dwf = alloc(n, tr);
+      if (live()) chk(s2st_conv_w_permute(P + p.w, s.wf, s.wd, p.O, p.I, p.Kw, st_));
+      return s;
+    };
+    ConvScratch cs0 = conv_scratch(sub[0], false), cs1 = conv_scratch(sub[1], true);
+    std::vector<ConvScratch> csp;
+    for (auto& pc : post_conv) csp.push_back(conv_scratch(pc, true));
+
+    mark();
+    // ---- encoder front: 2 x (conv k s2 -> GLU), sqrt(C) scale + positions + dropout -------------
+    float* xh0 = alloc((long)B * (S + 2 * pad) * c.in_dim, true);
+    if (live()) {
+      Split xs{(long)c.in_dim, 0, 0, 0};
+      Split ys{(long)c.in_dim, (long)(S + 2 * pad) * c.in_dim, S, 0};
+      chk(s2st_copy_rows(bt.src, xs, xh0 + (long)pad * c.in_dim, ys, B * S, c.in_dim, st_));
+    }
+    Ten* z1 = conv(ConvIn{xh0, nullptr, S}, sub[0], B, 2, cs0.wf, cs0.wd, cs0.dwf);
+    const int C1 = c.conv_channels / 2;
+    float* g1h = alloc((long)B * (T1 + 2 * pad) * C1, true);
+    Ten* g1 = glu_to(z1, g1h + (long)pad * C1, Split{(long)C1, (long)(T1 + 2 * pad) * C1, T1, 0}, C1);
+    Ten* z2 = conv(ConvIn{g1h, g1, T1}, sub[1], B, 2, cs1.wf, cs1.wd, cs1.dwf);
+    float* x0d = alloc((long)B * E * C);
+    Ten* x0 = glu_to(z2, x0d, Split{(long)C, 0, 0, 0}, C);
+    Ten* x = add_pe(x0, bt.enc_pos, pe_enc, c.no_scale_embedding ? 1.f : sqrtf((float)C), -1,
+                    tr ? c.dropout : 0.f);
+    mark();
+    // ---- encoder layers, taps -----------------------------------------------------------------
+    Ten *tap_asr = nullptr, *tap_st = nullptr;
+    for (int i = 0; i < c.enc_layers; ++i) {
+      x = enc_layer(x, enc[i], B, E);
+      if (i == c.tap_asr) tap_asr = x;
+      if (i == c.tap_st) tap_st = x;
+      if (i % 3 == 2) mark();
+    }
+    Ten* enc_out = has_enc_ln ? layernorm(x, enc_ln, outs.enc_out) : x;
+    if (c.has_asr && tap_asr) tap_asr = layernorm(tap_asr, asr_norm, outs.tap0);
+    if (c.has_st && tap_st) tap_st = layernorm(tap_st, st_norm, outs.tap1);
+    mark();
+    // ---- decoder: prenet (dropout always on), alpha * positions, layers ---------------------------
+    Ten* prev = newT(B * D, c.out_dim, const_cast<float*>(bt.prev));
+    prev->needs_grad = false;
+    Ten* h = prev;
+    for (int i = 0; i < c.prenet_layers; ++i)
+      h = linear(h, prenet[i].w, prenet[i].b, prenet[i].N, prenet[i].K, 1, c.prenet_dropout);
+    h = linear(h, prenet.back().w, prenet.back().b, Cd, c.prenet_dim);
+    Ten* y = add_pe(h, bt.dec_pos, pe_dec, 1.f, pos_alpha, tr ? c.dropout : 0.f);
+    mark();
+    float* attn_out = nullptr;
+    for (int i = 0; i < c.dec_layers; ++i) {
+      float* am = (i == c.dec_layers - 1 && bt.want_attn) ? outs.attn : nullptr;
+      y = dec_layer(y, enc_out, dec[i], B, D, E, c.dec_heads, c.dec_pre_ln != 0, bt.tgt_lens, am);
+      if (i % 2 == 1) mark();
+    }
+    (void)attn_out;
+    if (has_dec_ln) y = layernorm(y, dec_ln);
+    Ten* feat = linear(y, feat_proj.w, feat_proj.b, c.out_dim, Cd, 0, 0.f, nullptr, outs.feat);
+    Ten* eos = linear(y, eos_proj.w, eos_proj.b, 1, Cd, 0, 0.f, nullptr, outs.eos);
+    // ---- post-net: 5 x (conv k5 -> BatchNorm(batch stats over ALL B*D rows) -> tanh -> dropout) ----
+    Ten* cur = feat;  // plain holder of the current layer input
+    const int pp = c.postnet_k / 2;
+    float* curh = alloc((long)B * (D + 2 * pp) * c.out_dim, true);
+    if (live()) {
+      Split xs{(long)c.out_dim, 0, 0, 0};
+      Split ys{(long)c.out_dim, (long)(D + 2 * pp) * c.out_dim, D, 0};
+      chk(s2st_copy_rows(feat->d, xs, curh + (long)pp * c.out_dim, ys, B * D, c.out_dim, st_));
+    }
+    Ten* post = nullptr;
+    float* bn_tmp = alloc(2 * (long)(c.postnet_dim > c.out_dim ? c.postnet_dim : c.out_dim));
+    for (int i = 0; i < c.postnet_layers; ++i) {
+      const ConvP& pc = post_conv[i];
+      const BNP& bn = post_bn[i];
+      const bool last = i == c.postnet_layers - 1;
+      Ten* z = conv(ConvIn{curh, cur, D}, pc, B, 1, csp[i].wf, csp[i].wd, csp[i].dwf);
+      float* mean = alloc(bn.C);
+      float* var = alloc(bn.C);
+      touch(bn.b + bn.C);
+      const float pdrop = tr ? c.postnet_dropout : 0.f;
+      const uint64_t sd = pdrop > 0.f ? next_seed() : 0;
+      float* nexth = nullptr;
+      Ten* out;
+      Split osp;
+      if (last) {
+        out = newT(B * D, bn.C, outs.post_feat);
+        osp = Split{(long)bn.C, 0, 0, 0};
+      } else {
+        nexth = alloc((long)B * (D + 2 * pp) * bn.C, true);
+        out = newT(B * D, bn.C, nexth + (long)pp * bn.C);
+        osp = Split{(long)bn.C, (long)(D + 2 * pp) * bn.C, D, 0};
+      }
+      if (live()) {
+        const float *m = BUF + bn.rm, *v = BUF + bn.rv;
+        if (tr) {
+          chk(s2st_bn_stats(z->d, B * D, bn.C, mean, var, BUF + bn.rm, BUF + bn.rv, 0.1f, bn_tmp, st_));
+          m = mean; v = var;
+        }
+        chk(s2st_bn_apply(z->d, m, v, P + bn.g, P + bn.b, out->d, osp, last ? feat->d : nullptr, B * D,
+                          bn.C, 1e-5f, last ? 0 : 1, pdrop, sd, st_));
+      }
+      BNP bnp = bn;
+      tape.push_back([=]() {
+        if (!out->g) return;
+        if (last) {  // post = feat + postnet(feat): the residual branch
+          bool acc;
+          float* df = gradbuf(feat, acc);
+          if (live()) chk(s2st_dropout(out->g, df, feat->n(), 1.f, 0.f, 0, acc ? 1 : 0, st_));
+        }
+        bool acc;
+        float* dz = gradbuf(z, acc);
+        (void)acc;
+        Split ps{(long)bnp.C, 0, 0, 0};
+        if (live())
+          chk(s2st_bn_bwd(out->g, ps, z->d, mean, var, P + bnp.g, P + bnp.b, dz, ps, G + bnp.g, G + bnp.b,
+                          bn_tmp, B * D, bnp.C, 1e-5f, last ? 0 : 1, pdrop, sd, st_));
+      });
+      cur = out;
+      curh = nexth;
+      if (last) post = out;
+    }
+    mark();
+    // ---- CTC head on tap 0 (ctc_proj lives on the decoder, fed the encoder tap; :458-463) ----------
+    Ten* ctc_logits = nullptr;
+    if (c.has_ctc && tap_asr) ctc_logits = linear(tap_asr, ctc_proj.w, ctc_proj.b, c.src_vocab, C);
+    // ---- aux text decoders ---------------------------------------------------------------------------
+    Ten *asr_logits = nullptr, *st_logits = nullptr;
+    if (c.has_asr && tap_asr && bt.prev_src_txt)
+      asr_logits = aux_decoder(asr, tap_asr, (const long*)bt.prev_src_txt, bt.src_txt_pos, bt.src_txt_lens, B,
+                               bt.Ls, pe_asr, outs.asr_logits);
+    if (c.has_st && tap_st && bt.prev_tgt_txt)
+      st_logits = aux_decoder(st, tap_st, (const long*)bt.prev_tgt_txt, bt.tgt_txt_pos, bt.tgt_txt_lens, B,
+                              bt.Lt, pe_st, outs.st_logits);
+    mark();
+    // ---- losses (s2st_loss.py:219-257) -----------------------------------------------------------------
+    if (with_loss) {
+      float* stats = outs.stats;
+      float* ctc_per = c.has_ctc ? alloc(B) : nullptr;
+      float* ctc_lp = nullptr;
+      float* ctc_ws = nullptr;
+      if (c.has_ctc && ctc_logits) {
+        ctc_lp = outs.ctc_lprobs ? outs.ctc_lprobs : alloc((long)B * E * c.src_vocab);
+        ctc_ws = alloc(s2st_ctc_workspace_floats(B, E, bt.Ls));
+      }
+      const float nr = (float)bt.ntokens, nf = nr * c.out_dim;
+      if (live()) {
+        hipMemsetAsync(stats, 0, sizeof(float) * 32, st_);
+        chk(s2st_mel_loss(feat->d, post->d, eos->d, bt.tgt, bt.tgt_lens, B, D, c.out_dim, c.bce_pos_weight,
+                          stats + S2ST_STAT_L1_SUM, 0, 0, 0, nullptr, nullptr, nullptr, st_));
+        if (ctc_logits)
+          chk(s2st_ctc(ctc_logits->d, (const long*)bt.src_txt, bt.Ls, bt.ctc_in_lens, bt.src_txt_lens, B, E,
+                       c.src_vocab, ctc_lp, ctc_per, nullptr, 0.f, ctc_ws, st_));
+        if (asr_logits)
+          chk(s2st_ls_ce(asr_logits->d, (const long*)bt.src_txt, B * bt.Ls, c.src_vocab, 1, c.label_smoothing,
+                         stats + S2ST_STAT_ASR_NLL, nullptr, 0.f, st_));
+        if (st_logits)
+          chk(s2st_ls_ce(st_logits->d, (const long*)bt.tgt_txt, B * bt.Lt, c.tgt_vocab, 1, c.label_smoothing,
+                         stats + S2ST_STAT_ST_NLL, nullptr, 0.f, st_));
+        chk(s2st_loss_finalize(stats, ctc_per, B, nf, nr, c.w_l1, c.w_mse, c.w_eos, c.ctc_weight,
+                               c.asr_weight, c.st_weight, c.label_smoothing, c.src_vocab, c.tgt_vocab,
+                               (float)bt.src_txt_ntokens, (float)bt.tgt_txt_ntokens, st_));
+      }
+      tape.push_back([=]() {
+        // roots of the backward: d loss / d {feat, post, eos, logits}
+        const float gs = gscale;
+        bool a1, a2, a3;
+        float* dfeat = gradbuf(feat, a1);
+        float* dpost = gradbuf(post, a2);
+        float* deos = gradbuf(eos, a3);
+        if (live())
+          chk(s2st_mel_loss(feat->d, post->d, eos->d, bt.tgt, bt.tgt_lens, B, D, c.out_dim, c.bce_pos_weight,
+                            nullptr, gs * c.w_l1 / nf, gs * c.w_mse / nf, gs * c.w_eos / nr, dfeat, dpost, deos,
+                            st_));
+        if (ctc_logits) {
+          bool a;
+          float* dl = gradbuf(ctc_logits, a);
+          if (live())
+            chk(s2st_ctc(ctc_logits->d, (const long*)bt.src_txt, bt.Ls, bt.ctc_in_lens, bt.src_txt_lens, B, E,
+                         c.src_vocab, ctc_lp, ctc_per, dl, gs * c.ctc_weight / B, ctc_ws, st_));
+        }
+        if (asr_logits) {
+          bool a;
+          float* dl = gradbuf(asr_logits, a);
+          if (live())
+            chk(s2st_ls_ce(asr_logits->d, (const long*)bt.src_txt, B * bt.Ls, c.src_vocab, 1, c.label_smoothing,
+                           nullptr, dl, gs * c.asr_weight / (float)bt.src_txt_ntokens, st_));
+        }
+        if (st_logits) {
+          bool a;
+          float* dl = gradbuf(st_logits, a);
+          if (live())
+            chk(s2st_ls_ce(st_logits->d, (const long*)bt.tgt_txt, B * bt.Lt, c.tgt_vocab, 1, c.label_smoothing,
+                           nullptr, dl, gs * c.st_weight / (float)bt.tgt_txt_ntokens, st_));
+        }
+      });
+    }
+    mark();
+    return err;
+  }
+
+  int n_segments() const { return marks.empty() ? 0 : (int)marks.size() - 1; }
+
+  // run tape closures of segment `seg` (0 = last part of the forward)
+  int backward_segment(int seg) {
+    int ns = n_segments();
+    if (seg < 0 || seg >= ns) return S2ST_ERR_ARG;
+    size_t hi = marks[ns - seg].tape_idx, lo = marks[ns - seg - 1].tape_idx;
+    for (size_t i = hi; i-- > lo;) {
+      tape[i]();
+      if (err) return err;
+    }
+    return err;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
+  if (!cfg || !out) return S2ST_ERR_ARG;
+  if (cfg->enc_dim % cfg->enc_heads || cfg->dec_dim % cfg->dec_heads || cfg->enc_dim % 4 ||
+      cfg->dec_dim % 4 || cfg->in_dim % 4 || cfg->out_dim % 4 || cfg->conv_channels % 8)
+    return S2ST_ERR_SHAPE;
+  s2st_engine* e = new s2st_engine();
+  e->c = *cfg;
+  e->build_params();
+  *out = e;
+  return 0;
+}
+
+void s2st_engine_destroy(s2st_engine* e) {
+  if (!e) return;
+  e->reset_call();
+  delete e;
+}
+
+int32_t s2st_engine_num_params(const s2st_engine* e) { return (int32_t)e->infos.size(); }
+
+int s2st_engine_param_info(const s2st_engine* e, int32_t i, s2st_param_info* out) {
+  if (i < 0 || i >= (int)e->infos.size()) return S2ST_ERR_ARG;
+  const PInfo& p = e->infos[i];
+  memset(out, 0, sizeof(*out));
+  strncpy(out->name, p.name.c_str(), sizeof(out->name) - 1);
+  out->offset = p.off;
+  out->numel = p.numel;
+  out->ndim = p.ndim;
+  for (int k = 0; k < 4; ++k) out->shape[k] = p.shape[k];
+  out->is_buffer = p.is_buffer;
+  return 0;
+}
+
+int64_t s2st_engine_param_floats(const s2st_engine* e) { return e->n_params; }
+int64_t s2st_engine_buffer_floats(const s2st_engine* e) { return e->n_buffers; }
+
+int s2st_engine_bind(s2st_engine* e, float* params, float* grads, float* buffers) {
+  e->P = params;
+  e->G = grads;
+  e->BUF = buffers;
+  return 0;
+}
+
+int64_t s2st_engine_workspace_floats(s2st_engine* e, const s2st_batch* b) {
+  e->reset_call();
+  e->bt = *b;
+  memset(&e->outs, 0, sizeof(e->outs));
+  e->dry = true;
+  e->ws = reinterpret_cast<float*>(0x10000);  // never dereferenced: dry mode launches nothing
+  e->ws_cap = (long)1 << 50;
+  e->st_ = nullptr;
+  // outputs the caller may keep internal are counted as workspace
+  int rc = e->forward();
+  if (rc == 0) {
+    e->gscale = 1.f;
+    for (int s = 0; s < e->n_segments(); ++s) e->backward_segment(s);
+  }
+  long peak = e->ws_peak;
+  e->reset_call();
+  e->dry = false;
+  return rc ? (int64_t)rc : (int64_t)peak + 1024;
+}
+
+int s2st_engine_forward(s2st_engine* e, const s2st_batch* b, const s2st_outputs* out, float* workspace,
+                        int64_t workspace_floats, void* stream) {
+  if (!e->P || !e->BUF) return S2ST_ERR_ARG;
+  e->reset_call();
+  e->bt = *b;
+  e->outs = *out;
+  e->dry = false;
+  e->ws = workspace;
+  e->ws_cap = workspace_floats;
+  e->st_ = (hipStream_t)stream;
+  if (!e->outs.stats && b->tgt) return S2ST_ERR_ARG;
+  return e->forward();
+}
+
+int s2st_engine_backward(s2st_engine* e, float gscale, int32_t segment, void* stream) {
+  if (!e->G) return S2ST_ERR_ARG;
+  e->st_ = (hipStream_t)stream;
+  e->gscale = gscale;
+  if (segment < 0) {
+    for (int s = 0; s < e->n_segments(); ++s) {
+      int rc = e->backward_segment(s);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  return e->backward_segment(segment);
+}
+
+int32_t s2st_engine_num_segments(const s2st_engine* e) { return e->n_segments(); }
+
+int s2st_engine_segment_range(const s2st_engine* e, int32_t i, int64_t* lo, int64_t* hi) {
+  int ns = e->n_segments();
+  if (i < 0 || i >= ns) return S2ST_ERR_ARG;
+  *lo = e->marks[ns - i - 1].param_off;
+  *hi = e->marks[ns - i].param_off;
+  return 0;
+}
+
+}  // extern "C"

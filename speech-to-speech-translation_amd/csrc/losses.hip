@@ -248,6 +248,38 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
   }
 }
 
+// stats[16..22] = {loss, l1, mse, eos, ctc, asr, st} from the raw sums (s2st_loss.py:245-257)
+__global__ void loss_finalize_kernel(float* __restrict__ stats, const float* __restrict__ ctc_per, int B,
+                                     float nf, float nr, float w_l1, float w_mse, float w_eos,
+                                     float w_ctc, float w_asr, float w_st, float eps, int Vs, int Vt,
+                                     float src_ntok, float tgt_ntok) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float l1 = w_l1 * stats[S2ST_STAT_L1_SUM] / nf;
+  float mse = w_mse * stats[S2ST_STAT_MSE_SUM] / nf;
+  float eos = w_eos * stats[S2ST_STAT_BCE_SUM] / nr;
+  float ctc = 0.f;
+  if (ctc_per) {
+    for (int b = 0; b < B; ++b) ctc += ctc_per[b];
+    ctc = w_ctc * ctc / (float)B;
+  }
+  float asr = 0.f, st = 0.f;
+  if (w_asr > 0.f && src_ntok > 0.f) {
+    float ei = eps / (float)(Vs - 1);
+    asr = w_asr * ((1.f - eps - ei) * stats[S2ST_STAT_ASR_NLL] + ei * stats[S2ST_STAT_ASR_SMOOTH]) / src_ntok;
+  }
+  if (w_st > 0.f && tgt_ntok > 0.f) {
+    float ei = eps / (float)(Vt - 1);
+    st = w_st * ((1.f - eps - ei) * stats[S2ST_STAT_ST_NLL] + ei * stats[S2ST_STAT_ST_SMOOTH]) / tgt_ntok;
+  }
+  stats[S2ST_STAT_L1] = l1;
+  stats[S2ST_STAT_MSE] = mse;
+  stats[S2ST_STAT_EOS] = eos;
+  stats[S2ST_STAT_CTC] = ctc;
+  stats[S2ST_STAT_ASR] = asr;
+  stats[S2ST_STAT_ST] = st;
+  stats[S2ST_STAT_LOSS] = l1 + mse + eos + ctc + asr + st;
+}
+
 }  // namespace
 
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH)
@@ -288,5 +320,13 @@ int s2st_ctc(const float* logits, const long* targets, int Lmax, const int* in_l
   int ss = ((2 * Lmax + 1 + 3) / 4) * 4;
   hipLaunchKernelGGL(ctc_kernel, dim3(B), dim3(256), 0, st, logits, targets, Lmax, in_lens, tgt_lens,
                      E, V, lprobs, ws, ss, loss_per_utt, dlogits, gscale);
+  return LAUNCH_OK();
+}
+
+int s2st_loss_finalize(float* stats, const float* ctc_per, int B, float nf, float nr, float w_l1,
+                       float w_mse, float w_eos, float w_ctc, float w_asr, float w_st, float eps, int Vs,
+                       int Vt, float src_ntok, float tgt_ntok, hipStream_t st) {
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, stats, ctc_per, B, nf, nr, w_l1, w_mse,
+                     w_eos, w_ctc, w_asr, w_st, eps, Vs, Vt, src_ntok, tgt_ntok);
   return LAUNCH_OK();
 }

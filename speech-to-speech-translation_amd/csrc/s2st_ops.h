@@ -137,6 +137,10 @@ int s2st_ctc(const float* logits, const long* targets, int Lmax, const int* in_l
              const int* tgt_lens, int B, int E, int V, float* lprobs, float* loss_per_utt,
              float* dlogits, float gscale, float* ws, hipStream_t st);
 
+int s2st_loss_finalize(float* stats, const float* ctc_per, int B, float nf, float nr, float w_l1,
+                       float w_mse, float w_eos, float w_ctc, float w_asr, float w_st, float eps, int Vs,
+                       int Vt, float src_ntok, float tgt_ntok, hipStream_t st);
+
 // ---------------------------------------------------------------------------------------
 // optimizer (optim.hip)
 // ---------------------------------------------------------------------------------------

@@ -145,7 +145,7 @@ def header_prototypes():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(int|int64_t)\s+(s2st_\w+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(int|int32_t|int64_t|void)\s+(s2st_\w+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         alist = []
         if args and args != "void":
@@ -156,7 +156,7 @@ def header_prototypes():
                 else:
                     ty, nm = a.rsplit(" ", 1)
                     alist.append((_CT[ty.replace("const ", "").strip()], nm))
-        out[name] = (C.c_int64 if ret == "int64_t" else C.c_int, alist)
+        out[name] = ({"int64_t": C.c_int64, "void": None}.get(ret, C.c_int), alist)
     _protos = out
     return out
 

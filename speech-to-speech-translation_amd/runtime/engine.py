@@ -1,0 +1,339 @@
+"""Host side of the HIP training engine (C ABI: include/s2st_hip.h, `s2st_engine_*`).
+
+PyTorch is used for device memory (flat parameter / gradient / buffer arenas, the
+activation workspace, caller-owned outputs) and streams; all arithmetic runs in the HIP
+kernels.  The sample dict consumed here has the schema of ``S2STDataset.collater``
+(reference: examples/s2s_trans/data/s2st_dataset.py:427-455).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from . import binding as bd
+
+PAD = 1
+
+
+class ModelConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "enc_layers", "dec_layers", "enc_dim", "dec_dim", "enc_ffn", "dec_ffn", "enc_heads",
+        "dec_heads", "enc_pre_ln", "dec_pre_ln", "in_dim", "conv_channels", "conv_k", "out_dim",
+        "prenet_layers", "prenet_dim", "postnet_layers", "postnet_dim", "postnet_k", "tap_asr",
+        "tap_st", "has_asr", "has_st", "has_ctc", "asr_layers", "asr_dim", "st_layers", "st_dim",
+        "src_vocab", "tgt_vocab", "no_scale_embedding", "precise")] + [(n, C.c_float) for n in (
+        "dropout", "attn_dropout", "act_dropout", "prenet_dropout", "postnet_dropout", "ctc_weight",
+        "asr_weight", "st_weight", "w_l1", "w_mse", "w_eos", "bce_pos_weight", "label_smoothing")]
+
+
+class ParamInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 120), ("offset", C.c_int64), ("numel", C.c_int64),
+                ("ndim", C.c_int32), ("shape", C.c_int32 * 4), ("is_buffer", C.c_int32)]
+
+
+_P = C.c_void_p
+
+
+class Batch(C.Structure):
+    _fields_ = [("B", C.c_int32), ("S", C.c_int32), ("D", C.c_int32), ("Ls", C.c_int32),
+                ("Lt", C.c_int32), ("E", C.c_int32),
+                ("src", _P), ("enc_lens", _P), ("enc_pos", _P), ("ctc_in_lens", _P),
+                ("prev", _P), ("tgt", _P), ("tgt_lens", _P), ("dec_pos", _P),
+                ("prev_src_txt", _P), ("src_txt", _P), ("src_txt_lens", _P), ("src_txt_pos", _P),
+                ("prev_tgt_txt", _P), ("tgt_txt", _P), ("tgt_txt_lens", _P), ("tgt_txt_pos", _P),
+                ("pe_enc", _P), ("pe_dec", _P), ("pe_asr", _P), ("pe_st", _P),
+                ("ntokens", C.c_int32), ("src_txt_ntokens", C.c_int32),
+                ("tgt_txt_ntokens", C.c_int32), ("training", C.c_int32), ("want_attn", C.c_int32),
+                ("seed", C.c_uint64)]
+
+
+class Outputs(C.Structure):
+    _fields_ = [(n, _P) for n in ("post_feat", "feat", "eos", "attn", "enc_out", "tap0", "tap1",
+                                  "asr_logits", "st_logits", "ctc_lprobs", "stats")]
+
+
+STAT = dict(L1_SUM=0, MSE_SUM=1, BCE_SUM=2, ASR_NLL=3, ASR_SMOOTH=4, ASR_CORRECT=5, ASR_TOTAL=6,
+            ST_NLL=7, ST_SMOOTH=8, ST_CORRECT=9, ST_TOTAL=10, LOSS=16, L1=17, MSE=18, EOS=19,
+            CTC=20, ASR=21, ST=22, GNORM=24)
+
+
+def config_from_args(a, precise: bool = False) -> ModelConfig:
+    """Map the reference's flags (s2st_transformer.py:586-664, 792-830; s2st_loss.py:52-103)
+    onto the engine config."""
+    ks = [int(k) for k in str(a.conv_kernel_sizes).split(",")]
+    if len(ks) != 2 or ks[0] != ks[1]:
+        raise ValueError("engine supports two equal conv kernel sizes (reference default '5,5')")
+    mids = [int(k) for k in str(a.middle_layers).split(",")]
+    has_asr, has_st, has_ctc = a.asr_ce_weight > 0, a.st_ce_weight > 0, a.ctc_weight > 0
+    c = ModelConfig()
+    c.enc_layers, c.dec_layers = a.encoder_transformer_layers, a.decoder_transformer_layers
+    c.enc_dim, c.dec_dim = a.encoder_embed_dim, a.decoder_embed_dim
+    c.enc_ffn, c.dec_ffn = a.encoder_ffn_embed_dim, a.decoder_ffn_embed_dim
+    c.enc_heads, c.dec_heads = a.encoder_attention_heads, a.decoder_attention_heads
+    c.enc_pre_ln, c.dec_pre_ln = int(a.encoder_normalize_before), int(a.decoder_normalize_before)
+    c.in_dim = a.input_feat_per_channel * a.input_channels
+    c.conv_channels, c.conv_k = 1024, ks[0]  # --conv-channels is ignored by the reference (:802)
+    c.out_dim = a.output_frame_dim * a.n_frames_per_step
+    c.prenet_layers, c.prenet_dim = a.prenet_layers, a.prenet_dim
+    c.postnet_layers, c.postnet_dim, c.postnet_k = a.postnet_layers, a.postnet_conv_dim, a.postnet_conv_kernel_size
+    c.tap_asr = mids[0] if (has_asr or has_ctc) else -1
+    c.tap_st = mids[1] if has_st and len(mids) > 1 else -1
+    c.has_asr, c.has_st, c.has_ctc = int(has_asr), int(has_st), int(has_ctc)
+    c.asr_layers, c.asr_dim = a.asr_decoder_layers, a.asr_decoder_embed_dim
+    c.st_layers, c.st_dim = a.st_decoder_layers, a.st_decoder_embed_dim
+    c.src_vocab, c.tgt_vocab = a.src_vocab_size, a.tgt_vocab_size
+    c.no_scale_embedding = int(bool(a.no_scale_embedding))
+    c.precise = int(precise)
+    c.dropout, c.attn_dropout, c.act_dropout = a.dropout, a.attention_dropout, a.activation_dropout
+    c.prenet_dropout, c.postnet_dropout = a.prenet_dropout, a.postnet_dropout
+    c.ctc_weight, c.asr_weight, c.st_weight = a.ctc_weight, a.asr_ce_weight, a.st_ce_weight
+    c.w_l1, c.w_mse, c.w_eos = a.l1_loss_weight, a.mse_loss_weight, a.eos_loss_weight
+    c.bce_pos_weight, c.label_smoothing = a.bce_pos_weight, a.label_smoothing
+    return c
+
+
+def sinusoidal_table(num: int, dim: int, padding_idx: int = PAD) -> torch.Tensor:
+    """[sin | cos] table, exponent log(1e4)/(half-1), zero padding row
+    (fairseq/modules/sinusoidal_positional_embedding.py:35-58)."""
+    half = dim // 2
+    e = math.log(10000) / (half - 1)
+    e = torch.exp(torch.arange(half, dtype=torch.float) * -e)
+    e = torch.arange(num, dtype=torch.float).unsqueeze(1) * e.unsqueeze(0)
+    t = torch.cat([torch.sin(e), torch.cos(e)], dim=1).view(num, -1)
+    if dim % 2 == 1:
+        t = torch.cat([t, torch.zeros(num, 1)], dim=1)
+    t[padding_idx, :] = 0
+    return t
+
+
+def conv_out_len(n: int, k: int, stride: int = 2) -> int:
+    return (n + 2 * (k // 2) - k) // stride + 1
+
+
+class Engine:
+    """Owns the arenas and the native engine handle."""
+
+    def __init__(self, args, device: torch.device, precise: bool = False):
+        self.args = args
+        self.device = device
+        self.lib = bd.lib()
+        self.cfg = config_from_args(args, precise)
+        self.lib.s2st_engine_create.argtypes = [C.POINTER(ModelConfig), C.POINTER(C.c_void_p)]
+        self.lib.s2st_engine_destroy.argtypes = [C.c_void_p]
+        self.lib.s2st_engine_destroy.restype = None
+        self.lib.s2st_engine_num_params.argtypes = [C.c_void_p]
+        self.lib.s2st_engine_param_info.argtypes = [C.c_void_p, C.c_int32, C.POINTER(ParamInfo)]
+        self.lib.s2st_engine_param_floats.argtypes = [C.c_void_p]
+        self.lib.s2st_engine_param_floats.restype = C.c_int64
+        self.lib.s2st_engine_buffer_floats.argtypes = [C.c_void_p]
+        self.lib.s2st_engine_buffer_floats.restype = C.c_int64
+        self.lib.s2st_engine_bind.argtypes = [C.c_void_p] * 4
+        self.lib.s2st_engine_workspace_floats.argtypes = [C.c_void_p, C.POINTER(Batch)]
+        self.lib.s2st_engine_workspace_floats.restype = C.c_int64
+        self.lib.s2st_engine_forward.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(Outputs),
+                                                 C.c_void_p, C.c_int64, C.c_void_p]
+        self.lib.s2st_engine_backward.argtypes = [C.c_void_p, C.c_float, C.c_int32, C.c_void_p]
+        self.lib.s2st_engine_num_segments.argtypes = [C.c_void_p]
+        self.lib.s2st_engine_segment_range.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64),
+                                                       C.POINTER(C.c_int64)]
+        h = C.c_void_p()
+        bd.check(self.lib.s2st_engine_create(C.byref(self.cfg), C.byref(h)), "s2st_engine_create")
+        self.h = h
+        self.n_params = int(self.lib.s2st_engine_param_floats(h))
+        self.n_buffers = int(self.lib.s2st_engine_buffer_floats(h))
+        self.infos: List[Tuple[str, int, int, Tuple[int, ...], bool]] = []
+        for i in range(self.lib.s2st_engine_num_params(h)):
+            pi = ParamInfo()
+            bd.check(self.lib.s2st_engine_param_info(h, i, C.byref(pi)), "param_info")
+            self.infos.append((pi.name.decode(), int(pi.offset), int(pi.numel),
+                               tuple(pi.shape[:pi.ndim]), bool(pi.is_buffer)))
+        self.params = torch.zeros(self.n_params, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(self.n_params, dtype=torch.float32, device=device)
+        self.buffers = torch.zeros(max(self.n_buffers, 4), dtype=torch.float32, device=device)
+        self.lib.s2st_engine_bind(h, self.params.data_ptr(), self.grads.data_ptr(), self.buffers.data_ptr())
+        self.workspace: Optional[torch.Tensor] = None
+        self._pe: Dict[int, torch.Tensor] = {}
+        self._keep = None
+        self.step_seed = 1
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.s2st_engine_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # -- named views ---------------------------------------------------------------------------
+    def named_views(self):
+        """[(name, param_view, grad_view | None, is_buffer)] in arena order."""
+        out = []
+        for name, off, n, shape, is_buf in self.infos:
+            if is_buf:
+                out.append((name, self.buffers[off:off + n].view(shape), None, True))
+            else:
+                out.append((name, self.params[off:off + n].view(shape), self.grads[off:off + n].view(shape), False))
+        return out
+
+    def pe(self, dim: int, rows: int) -> torch.Tensor:
+        t = self._pe.get(dim)
+        if t is None or t.shape[0] < rows:
+            n = max(rows, 64)
+            n = 1 << (n - 1).bit_length()
+            t = sinusoidal_table(n + 2, dim).to(self.device)
+            self._pe[dim] = t
+        return t
+
+    # -- batch preparation (host logic: lengths, positions; mirrors lengths_to_padding_mask +
+    #    make_positions, fairseq/utils.py:254-264) ---------------------------------------------
+    def prepare(self, sample: Dict, training: bool = True, want_attn: bool = False,
+                with_loss: bool = True, seed: Optional[int] = None):
+        a, dev = self.args, self.device
+        ni = sample["net_input"]
+        src = ni["src_speech"].to(dev, torch.float32).contiguous()
+        B, S, _ = src.shape
+        src_lens = ni["src_speech_lens"].cpu().long()
+        k = self.cfg.conv_k
+        E = conv_out_len(conv_out_len(S, k), k)
+        # encoder lengths: floor((len - 1) / 2 + 1) twice (s2st_transformer.py:126-130)
+        enc_lens = src_lens.clone()
+        ctc_lens = src_lens.clone()
+        for _ in range(2):
+            enc_lens = ((enc_lens.float() - 1) / 2 + 1).floor().long()
+            ctc_lens = (ctc_lens - k + 2 * (k // 2)) // 2 + 1  # s2st_loss.py:231-232
+        prev = ni["prev_output_tokens"].to(dev, torch.float32).contiguous()
+        D = prev.shape[1]
+        tgt_lens = sample["target_lengths"].cpu().long()
+
+        def speech_pos(lens, T):
+            t = torch.arange(T).unsqueeze(0)
+            valid = t < lens.unsqueeze(1)
+            return torch.where(valid, t + PAD + 1, torch.full_like(t, PAD)).to(torch.int32)
+
+        def token_pos(tok):
+            m = tok.ne(PAD).int()
+            return ((torch.cumsum(m, dim=1) * m) + PAD).to(torch.int32)
+
+        keep = {"src": src, "prev": prev}
+        keep["enc_lens"] = enc_lens.to(torch.int32).to(dev)
+        keep["ctc_lens"] = ctc_lens.to(torch.int32).to(dev)
+        keep["enc_pos"] = speech_pos(enc_lens, E).contiguous().to(dev)
+        keep["tgt_lens"] = tgt_lens.to(torch.int32).to(dev)
+        keep["dec_pos"] = speech_pos(tgt_lens, D).contiguous().to(dev)
+        b = Batch()
+        b.B, b.S, b.D, b.E = B, S, D, E
+        b.src, b.prev = src.data_ptr(), prev.data_ptr()
+        b.enc_lens, b.enc_pos = keep["enc_lens"].data_ptr(), keep["enc_pos"].data_ptr()
+        b.ctc_in_lens = keep["ctc_lens"].data_ptr()
+        b.tgt_lens, b.dec_pos = keep["tgt_lens"].data_ptr(), keep["dec_pos"].data_ptr()
+        b.pe_enc = self.pe(self.cfg.enc_dim, E + 2).data_ptr()
+        b.pe_dec = self.pe(self.cfg.dec_dim, D + 2).data_ptr()
+        if with_loss:
+            keep["tgt"] = sample["tgt_speech"].to(dev, torch.float32).contiguous()
+            b.tgt = keep["tgt"].data_ptr()
+        Ls = Lt = 0
+        if self.cfg.has_asr or self.cfg.has_ctc:
+            st = sample["src_text"].cpu().long().contiguous()
+            Ls = st.shape[1]
+            keep["src_txt"] = st.to(dev)
+            keep["src_txt_lens"] = sample["src_text_len"].to(torch.int32).to(dev)
+            b.src_txt, b.src_txt_lens = keep["src_txt"].data_ptr(), keep["src_txt_lens"].data_ptr()
+        if self.cfg.has_asr:
+            pt = ni["prev_src_text_tokens"].cpu().long().contiguous()
+            keep["prev_src_txt"] = pt.to(dev)
+            keep["src_txt_pos"] = token_pos(pt).contiguous().to(dev)
+            b.prev_src_txt, b.src_txt_pos = keep["prev_src_txt"].data_ptr(), keep["src_txt_pos"].data_ptr()
+            b.pe_asr = self.pe(self.cfg.asr_dim, Ls + 2).data_ptr()
+        if self.cfg.has_st:
+            tt = sample["tgt_text"].cpu().long().contiguous()
+            Lt = tt.shape[1]
+            pt = ni["prev_tgt_text_tokens"].cpu().long().contiguous()
+            keep["tgt_txt"], keep["prev_tgt_txt"] = tt.to(dev), pt.to(dev)
+            keep["tgt_txt_lens"] = sample["tgt_text_len"].to(torch.int32).to(dev)
+            keep["tgt_txt_pos"] = token_pos(pt).contiguous().to(dev)
+            b.tgt_txt, b.prev_tgt_txt = keep["tgt_txt"].data_ptr(), keep["prev_tgt_txt"].data_ptr()
+            b.tgt_txt_lens, b.tgt_txt_pos = keep["tgt_txt_lens"].data_ptr(), keep["tgt_txt_pos"].data_ptr()
+            b.pe_st = self.pe(self.cfg.st_dim, Lt + 2).data_ptr()
+        b.Ls, b.Lt = Ls, Lt
+        b.ntokens = int(sample["ntokens"])
+        b.src_txt_ntokens = int(sample.get("src_txt_ntokens", 0))
+        b.tgt_txt_ntokens = int(sample.get("tgt_txt_ntokens", 0))
+        b.training, b.want_attn = int(training), int(want_attn)
+        if seed is None:
+            seed = self.step_seed
+            self.step_seed += 1
+        b.seed = seed
+        return b, keep
+
+    def forward(self, sample: Dict, training: bool = True, want_attn: bool = False,
+                with_loss: bool = True, seed: Optional[int] = None) -> Dict[str, torch.Tensor]:
+        b, keep = self.prepare(sample, training, want_attn, with_loss, seed)
+        need = int(self.lib.s2st_engine_workspace_floats(self.h, C.byref(b)))
+        if need < 0:
+            raise bd.S2STHipError(f"workspace planning failed ({need})")
+        if self.workspace is None or self.workspace.numel() < need:
+            self.workspace = None
+            self.workspace = torch.empty(int(need * 1.05) + 4096, dtype=torch.float32, device=self.device)
+        dev, c = self.device, self.cfg
+        B, D, E = b.B, b.D, b.E
+
+        def buf(*shape):
+            return torch.empty(shape, dtype=torch.float32, device=dev)
+
+        o = {"post_feat_out": buf(B, D, c.out_dim), "feature_out": buf(B, D, c.out_dim),
+             "eos_out": buf(B, D, 1), "encoder_out": buf(B, E, c.enc_dim), "stats": buf(32)}
+        out = Outputs()
+        out.post_feat, out.feat, out.eos = o["post_feat_out"].data_ptr(), o["feature_out"].data_ptr(), o["eos_out"].data_ptr()
+        out.enc_out, out.stats = o["encoder_out"].data_ptr(), o["stats"].data_ptr()
+        if want_attn:
+            o["attn"] = buf(B, E, D)
+            out.attn = o["attn"].data_ptr()
+        if c.has_asr or c.has_ctc:
+            o["tap0"] = buf(B, E, c.enc_dim)
+            out.tap0 = o["tap0"].data_ptr()
+        if c.has_st:
+            o["tap1"] = buf(B, E, c.enc_dim)
+            out.tap1 = o["tap1"].data_ptr()
+        if c.has_asr:
+            o["asr_logits"] = buf(B, b.Ls, c.src_vocab)
+            out.asr_logits = o["asr_logits"].data_ptr()
+        if c.has_st:
+            o["st_logits"] = buf(B, b.Lt, c.tgt_vocab)
+            out.st_logits = o["st_logits"].data_ptr()
+        if c.has_ctc and with_loss:
+            o["ctc_lprobs"] = buf(B, E, c.src_vocab)
+            out.ctc_lprobs = o["ctc_lprobs"].data_ptr()
+        rc = self.lib.s2st_engine_forward(self.h, C.byref(b), C.byref(out), self.workspace.data_ptr(),
+                                          self.workspace.numel(), bd.stream_ptr())
+        bd.check(rc, "s2st_engine_forward")
+        self._keep = (b, keep, o)  # inputs/outputs must outlive the backward
+        o["encoder_lens"] = keep["enc_lens"]
+        return o
+
+    def num_segments(self) -> int:
+        return int(self.lib.s2st_engine_num_segments(self.h))
+
+    def segment_range(self, i: int) -> Tuple[int, int]:
+        lo, hi = C.c_int64(), C.c_int64()
+        bd.check(self.lib.s2st_engine_segment_range(self.h, i, C.byref(lo), C.byref(hi)), "segment_range")
+        return int(lo.value), int(hi.value)
+
+    def backward(self, gscale: float = 1.0,
+                 on_segment: Optional[Callable[[int, int, int], None]] = None):
+        """grads += gscale * dLoss/dparams.  ``on_segment(i, lo, hi)`` is called after tape
+        segment i has been enqueued: gradients in arena range [lo, hi) are then final (used to
+        overlap the gradient all-reduce with the rest of the backward)."""
+        if on_segment is None:
+            bd.check(self.lib.s2st_engine_backward(self.h, gscale, -1, bd.stream_ptr()), "s2st_engine_backward")
+            return
+        for i in range(self.num_segments()):
+            bd.check(self.lib.s2st_engine_backward(self.h, gscale, i, bd.stream_ptr()), "s2st_engine_backward")
+            lo, hi = self.segment_range(i)
+            if hi > lo:
+                on_segment(i, lo, hi)
+
+    def zero_grad(self):
+        self.grads.zero_()
