@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Headline benchmark: mel-frames/sec of the s2st_transformer training step (fwd + bwd +
+gradient all-reduce + clip + Adam) on synthetic Fisher-shaped fbank80 -> mel80 batches.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): base 12 enc / 6 dec, d=512, n-frames-per-step 4, recipe
+flags of run_baseline.sh (pre-LN, 1-layer d=64 aux ASR/ST decoders, dropout .1/.1/.01,
+pre/post-net .5) plus CTC; batches packed by the reference's batch_by_size rule at
+max-tokens=20000.  One "step" = one optimizer update on one batch per rank (update-freq 1);
+rank r takes batches r, r+W, ... (weak scaling: per-GPU work fixed).  Inputs are resident in
+HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+PKG = "speech-to-speech-translation_amd"
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def algorithmic_macs(sample, a):
+    """Forward MACs of the GEMM-shaped work on VALID (un-padded) tokens: the per-utterance
+    formula of SURVEY.md section 8(d) (subsample, encoder layers + scores, prenet, decoder
+    layers + cross K/V + scores (causal half), heads, post-net, CTC proj, aux decoders)."""
+    ni = sample["net_input"]
+    S = ni["src_speech_lens"].double()
+    E = (((S - 1) / 2 + 1).floor() - 1).div(2).add(1).floor()
+    D = sample["target_lengths"].double()
+    C, F, Cd, Fd = a.encoder_embed_dim, a.encoder_ffn_embed_dim, a.decoder_embed_dim, a.decoder_ffn_embed_dim
+    P, out = a.prenet_dim, a.output_frame_dim * a.n_frames_per_step
+    k = 5
+    m = (S / 2 * (a.input_feat_per_channel * k * 1024) + S / 4 * (512 * k * 2 * C)).sum()
+    m += (E * a.encoder_transformer_layers * (4 * C * C + 2 * C * F) + a.encoder_transformer_layers * 2 * E * E * C).sum()
+    m += (D * (out * P + (a.prenet_layers - 1) * P * P + P * Cd)).sum()
+    L = a.decoder_transformer_layers
+    m += (D * L * (4 * Cd * Cd + 2 * Cd * Cd + 2 * Cd * Fd) + E * L * 2 * C * Cd + L * 2 * Cd * (D * D / 2 + D * E)).sum()
+    m += (D * Cd * (out + 1)).sum()
+    pc = a.postnet_conv_dim
+    m += (D * k * (out * pc + (a.postnet_layers - 2) * pc * pc + pc * out)).sum()
+    if a.ctc_weight > 0:
+        m += (E * C * a.src_vocab_size).sum()
+    for on, d, nl, lens, V, first in ((a.asr_ce_weight > 0, a.asr_decoder_embed_dim, a.asr_decoder_layers,
+                                       sample.get("src_text_len"), a.src_vocab_size, True),
+                                      (a.st_ce_weight > 0, a.st_decoder_embed_dim, a.st_decoder_layers,
+                                       sample.get("tgt_text_len"), a.tgt_vocab_size, False)):
+        if on:
+            Lt = lens.double()
+            m += (nl * (Lt * (4 * d * d + 2 * d * d + 2 * d * Fd) + E * 2 * C * d + 2 * d * (Lt * Lt / 2 + Lt * E))).sum()
+            m += (Lt * ((512 * d if first else 0) + d * 512 + 512 * V)).sum()
+    return float(m)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="base_recipe")
+    ap.add_argument("--max-tokens", type=int, default=20000)
+    ap.add_argument("--n-utts", type=int, default=4096)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-baseline leg (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        print(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}: launch N>1 with torch.distributed.run", file=sys.stderr)
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+
+    import s2st_amd  # noqa: F401
+    import s2st_oracle as O
+    from configs import CONFIGS
+    tasks = importlib.import_module(PKG + ".tasks")
+    trainer_mod = importlib.import_module(PKG + ".trainer")
+    bd = importlib.import_module(PKG + ".runtime.binding")
+
+    a = O.make_args(**CONFIGS[args.config])
+    a.lr, a.warmup_updates, a.clip_norm, a.seed = 1.5e-3, 4000, 1.0, 1
+    task = tasks.S2ST_TranslationTask.setup_task(a, device=dev)
+    torch.manual_seed(1)
+    model = task.build_model(a)
+    criterion = task.build_criterion(a)
+    trainer = trainer_mod.Trainer(a, task, model, criterion)
+    eng = model.engine
+
+    corpus = task.load_dataset("train", n_utts=args.n_utts, seed=1234)
+    batches = corpus.batches(max_tokens=args.max_tokens, bsz_mult=8)
+    # deterministic shuffle of the (length-sorted) batches, then deal round-robin to ranks
+    import numpy as np
+    order = np.random.RandomState(7).permutation(len(batches))
+    need = (args.steps + args.warmup)
+    mine = [batches[order[(i * world + rank) % len(batches)]] for i in range(need)]
+    samples = [corpus.collate_batch(ix) for ix in mine]
+    prepared = [eng.prepare(s, training=True) for s in samples]  # device-resident inputs
+    frames = [a.n_frames_per_step * s["ntokens"] for s in samples]
+    macs = [algorithmic_macs(s, a) for s in samples]
+
+    def step(i):
+        return trainer.train_step([_Prepared(prepared[i], samples[i])])
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    my_frames = float(sum(frames[args.warmup:]))
+    my_flops = 3.0 * 2.0 * sum(macs[args.warmup:])  # fwd + bwd = 3 x fwd, 2 FLOP per MAC
+    stat = torch.tensor([dt, my_frames, my_flops], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stat[:1].clone()
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        tot = stat[1:].clone()
+        torch.distributed.all_reduce(tot, op=torch.distributed.ReduceOp.SUM)
+        dt, total_frames, total_flops = float(tmax[0]), float(tot[0]), float(tot[1])
+    else:
+        total_frames, total_flops = my_frames, my_flops
+    last_loss = float(trainer.criterion.last_outputs["stats"][16])
+
+    # ---- roofline leg: replay the timed steps with per-launch HIP events around every GEMM -------
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        import ctypes as C
+        lib = bd.lib()
+        n_replay = min(args.steps, 5)
+        lib.s2st_profile_gemm(1)
+        for i in range(args.warmup, args.warmup + n_replay):
+            step(i)
+        torch.cuda.synchronize()
+        lib.s2st_profile_gemm(0)
+        fl, ms, nl = C.c_double(), C.c_double(), C.c_int64()
+        lib.s2st_profile_gemm_read(C.byref(fl), C.byref(ms), C.byref(nl))
+        alg = 3.0 * 2.0 * sum(macs[args.warmup:args.warmup + n_replay])
+        achieved = alg / (ms.value * 1e-3) / 1e12
+        roofline = {
+            "bound": "mfma", "kernel": "gemm_kernel<BM,BN,layouts> (all GEMM launches of the step)",
+            "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 5), "traffic": None,
+            "launches_per_step": nl.value // n_replay,
+            "avg_launch_us": round(ms.value * 1e3 / max(nl.value, 1), 2),
+            "gemm_ms_per_step": round(ms.value / n_replay, 3),
+            "as_launched_tflops": round(fl.value / (ms.value * 1e-3) / 1e12, 2),
+            "algorithmic_gflop_per_step": round(alg / n_replay / 1e9, 1),
+        }
+
+    # ---- CPU baseline leg: the oracle (torch fp32, all host cores) on a bounded sample ------------
+    cpu = None
+    if args.cpu_seconds > 0 and rank == 0 and world == 1:
+        from configs import CONFIGS as _C
+        torch.set_num_threads(os.cpu_count() or 1)
+        ca = O.make_args(**_C[args.config])
+        m = O.S2STModel(ca)
+        m.train()
+        opt = O.FairseqAdam(m.parameters())
+        sub = corpus.collate_batch(mine[args.warmup][:16])
+        O.train_step(m, opt, sub, 0, 1.5e-3, 4000, 1.0)  # warm-up
+        tcpu, n = 0.0, 0
+        while tcpu < args.cpu_seconds and n < 3:
+            t1 = time.perf_counter()
+            O.train_step(m, opt, sub, n + 1, 1.5e-3, 4000, 1.0)
+            tcpu += time.perf_counter() - t1
+            n += 1
+        cpu = {"value": round(ca.n_frames_per_step * sub["ntokens"] * n / tcpu, 1), "unit": "mel-frames/s",
+               "cores": os.cpu_count(), "kind": "port",
+               "sample": f"oracle (torch CPU fp32) fwd+bwd+clip+Adam on the first 16 utterances of timed batch 0 "
+                         f"({ca.n_frames_per_step * sub['ntokens']} mel frames), 1 warm-up + {n} timed steps"}
+
+    if rank == 0:
+        value = total_frames / dt
+        line = {
+            "metric": "mel-frames/sec (fwd+bwd+opt) on Fisher-shaped fbank80->mel80", "value": round(value, 1),
+            "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "s2st_transformer base 12enc/6dec d512 nfps4 + aux ASR/ST(1x64) + CTC, "
+                                   "recipe dropouts, max-tokens=20000 Fisher-shaped batches, update-freq 1",
+                       "global_batch_mel_frames": round(total_frames / args.steps, 1),
+                       "parallelism": f"dp{world}", "gemm": "bf16 MFMA, fp32 accumulate, fp32 storage",
+                       "final_loss": round(last_loss, 4),
+                       "model_tflops": round(total_flops / dt / 1e12, 2)},
+        }
+        if roofline:
+            line["roofline"] = roofline
+        if cpu:
+            line["cpu_baseline"] = cpu
+            line["config"]["x_over_cpu"] = round(value / cpu["value"], 1)
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+class _Prepared(tuple):
+    """(Batch, keep) pair that also answers the few dict lookups the trainer makes."""
+
+    def __new__(cls, prepared, sample):
+        o = super().__new__(cls, prepared)
+        o.sample = sample
+        return o
+
+    def __getitem__(self, k):
+        if isinstance(k, str):
+            return self.sample[k]
+        return tuple.__getitem__(self, k)
+
+
+if __name__ == "__main__":
+    main()

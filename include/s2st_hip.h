@@ -135,8 +135,8 @@ int s2st_ctc_f32(const float* logits, const int64_t* targets, int32_t Lmax, cons
 /* fairseq/utils.py:345-385 gradient L2 norm (sum of squares, out +=) */
 int s2st_sumsq_f32(const float* x, int64_t n, float* out, void* stream);
 
-/* trainer.py:838-873 + adam.py:163-239: grad scale, clip-by-norm, fairseq Adam on a flat arena */
-int s2st_adam_f32(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float gmul, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int32_t step, float* gnorm_out, void* stream);
+/* trainer.py:838-873 + adam.py:163-239: grad scale (gmul * *gmul_dev), clip-by-norm, fairseq Adam on a flat arena */
+int s2st_adam_f32(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float gmul, const float* gmul_dev, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int32_t step, float* gnorm_out, void* stream);
 
 /* floats of workspace s2st_ctc_f32 needs */
 int64_t s2st_ctc_workspace(int32_t B, int32_t E, int32_t Lmax);
@@ -247,6 +247,12 @@ int s2st_engine_backward(s2st_engine* e, float gscale, int32_t segment, void* st
 int32_t s2st_engine_num_segments(const s2st_engine* e);
 /* after segment i has run, gradients in arena range [lo, hi) are final */
 int s2st_engine_segment_range(const s2st_engine* e, int32_t i, int64_t* lo, int64_t* hi);
+
+/* Measurement aid (bench.py roofline leg): bracket every GEMM launch with HIP events on its
+ * own stream; read returns the sum of as-launched FLOPs (2*M*N*K*batch), the sum of kernel
+ * durations in ms and the launch count since enable, then clears. */
+int s2st_profile_gemm(int32_t enable);
+int s2st_profile_gemm_read(double* flops, double* ms, int64_t* launches);
 
 int s2st_version(void);
 /* number of HIP devices visible (0 = none: every compute entry point then fails) */

@@ -1,0 +1,1 @@
+from .s2st_loss import Tacotron2Criterion, label_smoothed_nll_loss  # noqa: F401

@@ -112,10 +112,18 @@ int s2st_sumsq_f32(const float* x, int64_t n, float* out, void* stream) {
   return s2st_sumsq(x, n, out, (hipStream_t)stream);
 }
 
-int s2st_adam_f32(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float gmul, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int32_t step, float* gnorm_out, void* stream) {
-  return s2st_adam(p, g, m, v, n, sumsq, gmul, max_norm, lr, beta1, beta2, eps, wd, step, gnorm_out, (hipStream_t)stream);
+int s2st_adam_f32(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float gmul, const float* gmul_dev, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int32_t step, float* gnorm_out, void* stream) {
+  return s2st_adam(p, g, m, v, n, sumsq, gmul, gmul_dev, max_norm, lr, beta1, beta2, eps, wd, step, gnorm_out, (hipStream_t)stream);
 }
 
 int64_t s2st_ctc_workspace(int32_t B, int32_t E, int32_t Lmax) { return s2st_ctc_workspace_floats(B, E, Lmax); }
+
+int s2st_profile_gemm(int32_t enable) { s2st_gemm_profile_enable(enable); return 0; }
+int s2st_profile_gemm_read(double* flops, double* ms, int64_t* launches) {
+  long n = 0;
+  int rc = s2st_gemm_profile_read(flops, ms, &n);
+  *launches = n;
+  return rc;
+}
 
 }  // extern "C"

@@ -14,6 +14,8 @@
 // v_mfma_f32_16x16x32_bf16; global loads of tile t+1 are in flight during the MFMAs of
 // tile t (one barrier per K-step).  Epilogue fuses alpha, bias, ReLU, dropout, residual,
 // accumulate / split-K atomics.
+#include <vector>
+
 #include "s2st_ops.h"
 
 namespace {
@@ -255,8 +257,42 @@ bool vec_ok(const GemmOperand& o) {
 
 }  // namespace
 
+// ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream ----
+namespace {
+struct ProfRec { hipEvent_t a, b; double flops; };
+std::vector<ProfRec> g_prof;
+bool g_prof_on = false;
+}  // namespace
+
+void s2st_gemm_profile_enable(int on) { g_prof_on = on != 0; }
+
+int s2st_gemm_profile_read(double* flops, double* ms, long* launches) {
+  double f = 0, t = 0;
+  for (auto& r : g_prof) {
+    hipEventSynchronize(r.b);
+    float e = 0.f;
+    hipEventElapsedTime(&e, r.a, r.b);
+    t += e;
+    f += r.flops;
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  *flops = f;
+  *ms = t;
+  *launches = (long)g_prof.size();
+  g_prof.clear();
+  return 0;
+}
+
 int s2st_gemm(GemmArgs g, hipStream_t st) {
   if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return 0;
+  ProfRec rec{};
+  if (g_prof_on) {
+    hipEventCreate(&rec.a);
+    hipEventCreate(&rec.b);
+    rec.flops = 2.0 * g.M * g.N * (double)g.K * g.batch;
+    hipEventRecord(rec.a, st);
+  }
   if (g.zdiv <= 0) g.zdiv = 1;
   g.avec = vec_ok(g.A) ? 1 : 0;
   g.bvec = vec_ok(g.B) ? 1 : 0;
@@ -288,6 +324,10 @@ int s2st_gemm(GemmArgs g, hipStream_t st) {
     launch_layouts<128, 128, false>(g, grid, st);
   } else {
     launch_layouts<64, 64, false>(g, grid, st);
+  }
+  if (g_prof_on) {
+    hipEventRecord(rec.b, st);
+    g_prof.push_back(rec);
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -32,9 +32,11 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    long n, const float* __restrict__ sumsq,
-                                                   float gmul, float max_norm, float lr, float b1,
-                                                   float b2, float eps, float wd, float step_size,
+                                                   float gmul, const float* __restrict__ gmul_dev,
+                                                   float max_norm, float lr, float b1, float b2, float eps,
+                                                   float wd, float step_size,
                                                    float* __restrict__ gnorm_out) {
+  if (gmul_dev) gmul *= gmul_dev[0];
   const float gn = sqrtf(sumsq[0]) * gmul;
   if (gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) gnorm_out[0] = gn;
   if (!(gn < INFINITY)) return;  // inf / nan gradients: skip the update (trainer.py:860-867)
@@ -65,7 +67,7 @@ int s2st_sumsq(const float* x, long n, float* out, hipStream_t st) {
 }
 
 int s2st_adam(float* p, float* g, float* m, float* v, long n, const float* sumsq, float gmul,
-              float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step,
+              const float* gmul_dev, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step,
               float* gnorm_out, hipStream_t st) {
   if (n <= 0) return 0;
   double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
@@ -73,6 +75,6 @@ int s2st_adam(float* p, float* g, float* m, float* v, long n, const float* sumsq
   long blocks = (n + 256 * 4 - 1) / (256 * 4);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, n, sumsq, gmul,
-                     max_norm, lr, beta1, beta2, eps, wd, step_size, gnorm_out);
+                     gmul_dev, max_norm, lr, beta1, beta2, eps, wd, step_size, gnorm_out);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }

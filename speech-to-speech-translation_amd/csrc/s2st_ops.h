@@ -40,6 +40,8 @@ inline GemmEpilogue gemm_epi_default() {
 }
 
 int s2st_gemm(GemmArgs g, hipStream_t st);
+void s2st_gemm_profile_enable(int on);
+int s2st_gemm_profile_read(double* flops, double* ms, long* launches);
 
 // ---------------------------------------------------------------------------------------
 // row ops (rowops.hip)
@@ -147,6 +149,7 @@ int s2st_loss_finalize(float* stats, const float* ctc_per, int B, float nf, floa
 int s2st_sumsq(const float* x, long n, float* out /* += */, hipStream_t st);
 // g *= gmul * clip ; clip = min(1, max_norm / (sqrt(sumsq)*gmul + 1e-6)) ; fairseq Adam.
 // step >= 1 is the Adam step count; gnorm_out (optional) receives sqrt(sumsq)*gmul.
+// effective gradient multiplier = gmul * (gmul_dev ? *gmul_dev : 1)
 int s2st_adam(float* p, float* g, float* m, float* v, long n, const float* sumsq, float gmul,
-              float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step,
+              const float* gmul_dev, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step,
               float* gnorm_out, hipStream_t st);

@@ -1,0 +1,267 @@
+"""``--arch s2st_transformer`` on the MI355X engine.
+
+Host-side mirror of examples/s2s_trans/models/s2st_transformer.py:580-830 (names, flags,
+state_dict keys, forward signature and return structure).  The module owns no arithmetic:
+its parameters are views into the engine's flat fp32 arena, and ``forward`` runs the HIP
+schedule behind include/s2st_hip.h.  Training goes through the fused criterion
+(criterions/s2st_loss.py), which hands loss + gradients back through one autograd node.
+"""
+from __future__ import annotations
+
+import argparse
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from ..registry import register_model, register_model_architecture
+from ..runtime.engine import Engine
+
+
+class _Holder(nn.Module):
+    """Anonymous container so parameters appear under the reference's dotted names."""
+
+
+def _register(root: nn.Module, dotted: str, tensor: torch.Tensor, is_buffer: bool):
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, _Holder())
+        mod = mod._modules[p]
+    if is_buffer:
+        mod.register_buffer(parts[-1], tensor)
+    else:
+        mod.register_parameter(parts[-1], tensor)
+
+
+@register_model("s2st_transformer")
+class S2STTransformerModel(nn.Module):
+    @staticmethod
+    def add_args(parser):
+        """Same flags as the reference (s2st_transformer.py:586-664)."""
+        a = parser.add_argument
+        a("--dropout", type=float)
+        a("--output-frame-dim", type=int)
+        a("--speaker-embed-dim", type=int)
+        a("--speaker-embed-dim-dec", type=int)
+        a("--middle-layers", default="6", type=str)
+        a("--hubert-hidden", type=int, default=768)
+        a("--conv_kernel-sizes", default="5,5", type=str)
+        a("--conv-channels", default=1024, type=int)
+        a("--input-feat-per-channel", default=80, type=int)
+        a("--input_channels", default=1, type=int)
+        a("--encoder-transformer-layers", type=int)
+        a("--encoder-embed-dim", type=int)
+        a("--encoder-ffn-embed-dim", type=int)
+        a("--encoder-normalize-before", action="store_true")
+        a("--encoder-attention-heads", type=int)
+        a("--attention-dropout", type=float)
+        a("--activation-dropout", "--relu-dropout", type=float)
+        a("--activation-fn", type=str, default="relu")
+        a("--no_scale_embedding", default=False)
+        a("--prenet-dropout", type=float)
+        a("--prenet-layers", type=int)
+        a("--prenet-dim", type=int)
+        a("--postnet-dropout", type=float)
+        a("--postnet-layers", type=int)
+        a("--postnet-conv-dim", type=int)
+        a("--postnet-conv-kernel-size", type=int)
+        a("--decoder-transformer-layers", type=int)
+        a("--asr-decoder-layers", type=int)
+        a("--st-decoder-layers", type=int)
+        a("--decoder-embed-dim", type=int)
+        a("--asr-decoder-embed-dim", type=int)
+        a("--st-decoder-embed-dim", type=int)
+        a("--decoder-ffn-embed-dim", type=int)
+        a("--decoder-normalize-before", action="store_true")
+        a("--decoder-attention-heads", type=int)
+        a("--load-pretrained-encoder-from", type=str)
+        a("--load-pretrained-hubert-from", type=str)
+        a("--load-pretrained-decoder-from", type=str)
+
+    @classmethod
+    def build_model(cls, args, task):
+        base_architecture(args)
+        if getattr(args, "activation_fn", "relu") != "relu":
+            raise NotImplementedError("the HIP path implements the reference default activation (relu)")
+        if str(getattr(args, "use_hubert", "false")) == "true":
+            raise NotImplementedError("frozen-HuBERT front end (config 4) is not built yet on the HIP path")
+        if not hasattr(args, "src_vocab_size"):
+            args.src_vocab_size = len(task.source_dictionary)
+            args.tgt_vocab_size = len(task.target_dictionary)
+        device = getattr(task, "device", None) or torch.device("cuda", torch.cuda.current_device())
+        return cls(args, device=device, precise=bool(getattr(args, "precise_gemm", False)))
+
+    def __init__(self, args, device: torch.device, precise: bool = False):
+        super().__init__()
+        self.args = args
+        self.engine = Engine(args, device, precise=precise)
+        self._views = {}
+        for name, pv, gv, is_buf in self.engine.named_views():
+            if is_buf:
+                _register(self, name, pv, True)
+            else:
+                p = nn.Parameter(pv)
+                p.grad = gv  # gradients are written in place by the engine
+                _register(self, name, p, False)
+            self._views[name] = pv
+        # bookkeeping buffers the reference's state_dict carries
+        for holder in ["encoder", "decoder"] + [k for k in ("aux_asr_decoder", "aux_st_decoder") if k in self._modules]:
+            _register(self, holder + ".embed_positions._float_tensor", torch.zeros(1, device=device), True)
+        for k in ("aux_asr_decoder", "aux_st_decoder"):
+            if k in self._modules:
+                _register(self, k + ".version", torch.tensor([3.0], device=device), True)
+        for i in range(args.postnet_layers):
+            _register(self, f"decoder.postnet.convolutions.{i}.1.num_batches_tracked",
+                      torch.zeros((), dtype=torch.long, device=device), True)
+        self._num_updates = 0
+        self.reset_parameters()
+
+    # -- initialisation: the reference's schemes ("Init") -----------------
+    @torch.no_grad()
+    def reset_parameters(self):
+        for name, p in self.named_parameters():
+            if name.endswith("pos_emb_alpha"):
+                p.fill_(1.0)
+            elif p.dim() == 1:
+                if name.endswith(".weight"):
+                    p.fill_(1.0)  # LayerNorm / BatchNorm gain
+                elif "norm" in name or name.endswith(".1.bias") or name.endswith("out_proj.bias"):
+                    p.zero_()  # norm shifts; MHA out_proj bias (multihead_attention.py:107-108)
+                else:
+                    fan_in = self._fan_in(name)
+                    bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
+                    p.uniform_(-bound, bound)  # nn.Linear / nn.Conv1d default
+            elif "embed_tokens" in name:
+                nn.init.normal_(p, mean=0, std=p.shape[1] ** -0.5)
+                p[1].zero_()  # padding_idx
+            elif "output_projection" in name:
+                nn.init.normal_(p, mean=0, std=p.shape[1] ** -0.5)
+            elif any(k in name for k in (".k_proj.", ".v_proj.", ".q_proj.")):
+                nn.init.xavier_uniform_(p, gain=1 / math.sqrt(2))  # multihead_attention.py:94-112
+            elif ".out_proj." in name or "project_in_dim" in name or "project_out_dim" in name:
+                nn.init.xavier_uniform_(p)
+            elif p.dim() == 3 and name.startswith("decoder."):
+                nn.init.xavier_uniform_(p, nn.init.calculate_gain("tanh"))  # decoder_init (:314-316)
+            else:
+                nn.init.kaiming_uniform_(p, a=math.sqrt(5))  # nn.Linear / nn.Conv1d default
+        for name, b in self.named_buffers():
+            if name.endswith("running_var"):
+                b.fill_(1.0)
+            elif name.endswith("running_mean"):
+                b.zero_()
+
+    def _fan_in(self, bias_name: str) -> int:
+        w = self._views.get(bias_name[: -len("bias")] + "weight")
+        return int(w[0].numel()) if w is not None else 0
+
+    # -- reference API --------------------------------------------------------------------------
+    def set_num_updates(self, num_updates):
+        self._num_updates = num_updates
+
+    def max_positions(self):
+        return (self.args.max_source_positions, self.args.max_target_positions)
+
+    def get_targets(self, sample, test_type, net_output):
+        return sample["src_text"] if test_type == "asr" else sample["tgt_text"]
+
+    def _run(self, src_tokens, src_lengths, prev_output_tokens, target_lengths,
+             prev_src_text_tokens=None, prev_tgt_text_tokens=None, want_attn=True):
+        B, D, _ = prev_output_tokens.shape
+        sample = {
+            "net_input": {"src_speech": src_tokens, "src_speech_lens": src_lengths,
+                          "prev_output_tokens": prev_output_tokens,
+                          "prev_src_text_tokens": prev_src_text_tokens,
+                          "prev_tgt_text_tokens": prev_tgt_text_tokens},
+            "target_lengths": target_lengths, "ntokens": int(target_lengths.sum()),
+        }
+        # text targets are only needed by the loss; the aux decoders need the shifted inputs
+        if prev_src_text_tokens is not None:
+            sample["src_text"] = prev_src_text_tokens
+            sample["src_text_len"] = prev_src_text_tokens.ne(1).sum(1)
+        if prev_tgt_text_tokens is not None:
+            sample["tgt_text"] = prev_tgt_text_tokens
+            sample["tgt_text_len"] = prev_tgt_text_tokens.ne(1).sum(1)
+        return self.engine.forward(sample, training=self.training, want_attn=want_attn, with_loss=False)
+
+    def forward(self, src_tokens, src_lengths, collated_audios, padding_mask, prev_output_tokens,
+                **kwargs):
+        """Returns ``[(post_feat_out, eos_out, extra), (asr_logits, None) | None,
+        (st_logits, None) | None]`` as s2st_transformer.py:752-786."""
+        o = self._run(src_tokens, src_lengths, prev_output_tokens, kwargs["target_lengths"],
+                      kwargs.get("prev_src_text_tokens"), kwargs.get("prev_tgt_text_tokens"))
+        taps = [o[k].transpose(0, 1) for k in ("tap0", "tap1") if k in o]
+        extra = {"attn": o.get("attn"), "feature_out": o["feature_out"], "out_middle_layers": taps}
+        asr = (o["asr_logits"], None) if "asr_logits" in o else None
+        st = (o["st_logits"], None) if "st_logits" in o else None
+        return [(o["post_feat_out"], o["eos_out"], extra), asr, st]
+
+    def forward_encoder(self, src_tokens, src_lengths, collated_audios=None, padding_mask=None,
+                        speaker=None, **kwargs):
+        B = src_tokens.shape[0]
+        dummy = torch.zeros(B, 1, self.engine.cfg.out_dim)
+        o = self._run(src_tokens, src_lengths, dummy, torch.ones(B, dtype=torch.long), want_attn=False)
+        lens = o["encoder_lens"].long()
+        E = o["encoder_out"].shape[1]
+        pad = torch.arange(E, device=lens.device).unsqueeze(0) >= lens.unsqueeze(1)
+        return {"encoder_out": [o["encoder_out"].transpose(0, 1)],
+                "encoder_padding_mask": [pad] if bool(pad.any()) else [],
+                "encoder_embedding": [], "encoder_states": [],
+                "out_middle_layers": [o[k].transpose(0, 1) for k in ("tap0", "tap1") if k in o],
+                "src_tokens": [], "src_lengths": []}
+
+    def get_normalized_probs(self, net_output, log_probs, sample=None):
+        """CTC head over tap 0 (s2st_transformer.py:458-463); uses the engine's fused
+        log-softmax output when available."""
+        raise NotImplementedError("use criterion outputs['ctc_lprobs'] (fused log-softmax + CTC)")
+
+
+@register_model_architecture("s2st_transformer", "s2st_transformer")
+def base_architecture(args):
+    """Defaults of s2st_transformer.py:792-830 (including the `conv_chaFnnels` typo that pins
+    conv_channels to 1024)."""
+    def g(k, v):
+        if getattr(args, k, None) is None:
+            setattr(args, k, v)
+
+    g("dropout", 0.1)
+    g("output_frame_dim", 80)
+    g("middle_layers", "6")
+    g("conv_kernel_sizes", "5,5")
+    args.conv_channels = 1024
+    g("encoder_transformer_layers", 12)
+    g("encoder_embed_dim", 512)
+    g("encoder_ffn_embed_dim", 4 * args.encoder_embed_dim)
+    if not hasattr(args, "encoder_normalize_before"):
+        args.encoder_normalize_before = True
+    g("encoder_attention_heads", 4)
+    g("attention_dropout", args.dropout)
+    g("activation_dropout", args.dropout)
+    g("activation_fn", "relu")
+    g("prenet_dropout", 0.5)
+    g("prenet_layers", 2)
+    g("prenet_dim", 256)
+    g("postnet_dropout", 0.5)
+    g("postnet_layers", 5)
+    g("postnet_conv_dim", 512)
+    g("postnet_conv_kernel_size", 5)
+    g("asr_decoder_layers", 6)
+    g("st_decoder_layers", 6)
+    g("asr_decoder_embed_dim", 256)
+    g("st_decoder_embed_dim", 256)
+    g("decoder_transformer_layers", 6)
+    g("decoder_embed_dim", 512)
+    g("decoder_ffn_embed_dim", 4 * args.decoder_embed_dim)
+    if not hasattr(args, "decoder_normalize_before"):
+        args.decoder_normalize_before = False
+    g("decoder_attention_heads", 4)
+    # task / criterion flags the constructors read
+    for k, v in dict(n_frames_per_step=4, input_feat_per_channel=80, input_channels=1,
+                     max_source_positions=3000, max_target_positions=2400, no_scale_embedding=False,
+                     ctc_weight=0.0, asr_ce_weight=0.0, st_ce_weight=0.0, bce_pos_weight=1.0,
+                     label_smoothing=0.0, l1_loss_weight=1.0, mse_loss_weight=1.0, eos_loss_weight=1.0,
+                     use_hubert="false").items():
+        g(k, v)
+    return args

@@ -153,6 +153,8 @@ def header_prototypes():
                 a = " ".join(a.split())
                 if "*" in a:
                     alist.append((C.c_void_p, a.split("*")[-1].strip()))
+                elif a == "void":
+                    continue
                 else:
                     ty, nm = a.rsplit(" ", 1)
                     alist.append((_CT[ty.replace("const ", "").strip()], nm))

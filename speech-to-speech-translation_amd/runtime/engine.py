@@ -156,6 +156,7 @@ class Engine:
         self.lib.s2st_engine_bind(h, self.params.data_ptr(), self.grads.data_ptr(), self.buffers.data_ptr())
         self.workspace: Optional[torch.Tensor] = None
         self._pe: Dict[int, torch.Tensor] = {}
+        self._plan: Dict[tuple, int] = {}
         self._keep = None
         self.step_seed = 1
 
@@ -268,10 +269,25 @@ class Engine:
         b.seed = seed
         return b, keep
 
-    def forward(self, sample: Dict, training: bool = True, want_attn: bool = False,
+    def forward(self, sample, training: bool = True, want_attn: bool = False,
                 with_loss: bool = True, seed: Optional[int] = None) -> Dict[str, torch.Tensor]:
-        b, keep = self.prepare(sample, training, want_attn, with_loss, seed)
-        need = int(self.lib.s2st_engine_workspace_floats(self.h, C.byref(b)))
+        """``sample`` is a collater dict, or the ``(Batch, keep)`` pair returned by ``prepare``
+        (device-resident inputs, reused across steps by the data loader / bench)."""
+        if isinstance(sample, tuple):
+            b, keep = sample
+            b.training, b.want_attn = int(training), int(want_attn)
+            if seed is None:
+                seed = self.step_seed
+                self.step_seed += 1
+            b.seed = seed
+            with_loss = with_loss and bool(b.tgt)
+        else:
+            b, keep = self.prepare(sample, training, want_attn, with_loss, seed)
+        geo = (b.B, b.S, b.D, b.Ls, b.Lt, bool(b.tgt), b.training)
+        need = self._plan.get(geo)
+        if need is None:
+            need = int(self.lib.s2st_engine_workspace_floats(self.h, C.byref(b)))
+            self._plan[geo] = need
         if need < 0:
             raise bd.S2STHipError(f"workspace planning failed ({need})")
         if self.workspace is None or self.workspace.numel() < need:

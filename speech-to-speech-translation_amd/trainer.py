@@ -1,0 +1,120 @@
+"""Train-step driver: the counterpart of ``Trainer.train_step`` (fairseq/trainer.py:709-1010)
+for the MI355X engine.
+
+Per update: seed = seed + num_updates (:1254-1258); zero grads; for each micro-batch
+forward + backward (gradients accumulate in the flat arena); SUM all-reduce of gradients
+(overlapped with backward) and of the sample sizes; ``grads *= world / sum(sample_size)``
+(:838-843), clip by global norm (:850, fairseq/utils.py:345-395), fairseq-Adam
+(fairseq/optim/adam.py:163-239) with lr = inverse_sqrt(num_updates)
+(inverse_square_root_schedule.py:52-85) -- scale, clip and Adam are one HIP kernel over the
+arena.  Non-finite gradient norm skips the update (:860-867) without a host sync.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from .runtime import binding as bd
+from .runtime.distributed import GradReducer, all_reduce_scalars, is_dist, world_size
+from .runtime.engine import STAT
+
+
+def inverse_sqrt_lr(num_updates: int, lr: float, warmup_updates: int, warmup_init_lr: float = -1.0) -> float:
+    if warmup_init_lr < 0:
+        warmup_init_lr = 0.0 if warmup_updates > 0 else lr
+    if num_updates < warmup_updates:
+        return warmup_init_lr + num_updates * (lr - warmup_init_lr) / warmup_updates
+    return lr * warmup_updates ** 0.5 * num_updates ** -0.5
+
+
+class Trainer:
+    def __init__(self, args, task, model, criterion):
+        self.args, self.task, self.model, self.criterion = args, task, model, criterion
+        self.engine = model.engine
+        dev = self.engine.device
+        n = self.engine.n_params
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.gmul_dev = torch.ones(1, dtype=torch.float32, device=dev)
+        self.num_updates = 0
+        self.lr = getattr(args, "lr", 1.5e-3)
+        self.lr = self.lr[0] if isinstance(self.lr, (list, tuple)) else self.lr
+        self.warmup = getattr(args, "warmup_updates", 4000)
+        self.clip_norm = getattr(args, "clip_norm", 0.0)
+        self.betas = tuple(getattr(args, "adam_betas", (0.9, 0.999)))
+        self.eps = getattr(args, "adam_eps", 1e-8)
+        self.wd = getattr(args, "weight_decay", 0.0)
+        self.seed = getattr(args, "seed", 1)
+        self.reducer = GradReducer(self.engine.grads) if is_dist() else None
+        if is_dist():
+            # DDP's constructor broadcast of parameters and buffers from rank 0
+            torch.distributed.broadcast(self.engine.params, 0)
+            torch.distributed.broadcast(self.engine.buffers, 0)
+
+    def get_lr(self) -> float:
+        return inverse_sqrt_lr(self.num_updates, self.lr, self.warmup)
+
+    def train_step(self, samples: List[Dict], fast: bool = True):
+        """One optimizer update over ``samples`` (the update_freq micro-batches of this rank).
+        ``fast`` bypasses autograd (engine.backward is called directly); ``fast=False`` goes
+        through ``task.train_step`` / ``loss.backward()`` exactly like fairseq would."""
+        eng = self.engine
+        self.model.train()
+        eng.step_seed = (self.seed + self.num_updates) * 1000003
+        eng.zero_grad()
+        sample_size = 0
+        logs = []
+        hooks = self.reducer.on_segment if self.reducer is not None else None
+        for i, sample in enumerate(samples):
+            last = i == len(samples) - 1
+            seg_hooks = hooks if last else None  # like no_sync(): reduce once, on the last micro-batch
+            if fast:
+                loss, ss, log = self._fast_micro_step(sample, seg_hooks)
+            else:
+                self.criterion.grad_hooks = seg_hooks
+                loss, ss, log = self.task.train_step(sample, self.model, self.criterion, None, self.num_updates)
+            sample_size += ss
+            logs.append(log)
+        self._bump_bn_counters(len(samples))
+        gmul_dev = None
+        world = world_size()
+        if self.reducer is not None:
+            self.reducer.finish()
+            self.gmul_dev.fill_(float(sample_size))
+            all_reduce_scalars(self.gmul_dev)           # sum of sample sizes over ranks
+            self.gmul_dev.reciprocal_().mul_(float(world))  # world / sum(sample_size)
+            gmul_dev, gmul = self.gmul_dev, 1.0
+        else:
+            gmul = 1.0 / float(sample_size)
+        self.sumsq.zero_()
+        bd.call("s2st_sumsq_f32", eng.grads, eng.n_params, self.sumsq)
+        lr = self.get_lr()
+        bd.call("s2st_adam_f32", eng.params, eng.grads, self.exp_avg, self.exp_avg_sq, eng.n_params,
+                self.sumsq, gmul, gmul_dev, float(self.clip_norm), lr, self.betas[0], self.betas[1],
+                self.eps, self.wd, self.num_updates + 1, self.gnorm)
+        self.num_updates += 1
+        self.model.set_num_updates(self.num_updates)
+        return {"logs": logs, "sample_size": sample_size, "lr": lr, "gnorm": self.gnorm}
+
+    def _fast_micro_step(self, sample, hooks):
+        eng = self.engine
+        out = eng.forward(sample, training=True, want_attn=False, with_loss=True)
+        self.criterion.last_outputs = out
+        eng.backward(1.0, on_segment=hooks)
+        from .criterions.s2st_loss import LazyLog
+        c = eng.cfg
+        log = LazyLog(out["stats"], {"ntokens": sample["ntokens"], "nsentences": sample["nsentences"],
+                                     "sample_size": sample["ntokens"]},
+                      getattr(self.criterion, "report_accuracy", False), bool(c.has_asr), bool(c.has_st))
+        return out["stats"][STAT["LOSS"]], sample["ntokens"], log
+
+    def _bump_bn_counters(self, n):
+        for name, b in self.model.named_buffers():
+            if name.endswith("num_batches_tracked"):
+                b += n
+
+    def valid_step(self, sample):
+        return self.task.valid_step(sample, self.model, self.criterion)

@@ -345,6 +345,7 @@ def test_sumsq_adam(backend):
     opt = O.FairseqAdam([pr], weight_decay=0.01)
     pd, gd = dev(backend, p0.clone(), g0.clone())
     m, v = torch.zeros(n, device=backend.device), torch.zeros(n, device=backend.device)
+    half = torch.full((1,), 0.5, device=backend.device)  # device-side part of the multiplier
     for step in range(1, 4):
         gcur = g0 * step
         pr.grad = gcur.clone() * 0.01  # multiply_grads(1/sample_size)
@@ -354,7 +355,7 @@ def test_sumsq_adam(backend):
         ss = torch.zeros(1, device=backend.device)
         gno = torch.zeros(1, device=backend.device)
         backend.bd.call("s2st_sumsq_f32", gd, n, ss)
-        backend.bd.call("s2st_adam_f32", pd, gd, m, v, n, ss, 0.01, 0.5, 1e-2, 0.9, 0.999, 1e-8, 0.01,
+        backend.bd.call("s2st_adam_f32", pd, gd, m, v, n, ss, 0.02, half, 0.5, 1e-2, 0.9, 0.999, 1e-8, 0.01,
                         step, gno)
         backend.sync()
         close(gno, gn_ref.view(1), 1e-5, 1e-6)
