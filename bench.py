@@ -62,6 +62,56 @@ def algorithmic_macs(sample, a):
     return float(m)
 
 
+_T0 = time.perf_counter()
+
+
+def vlog(*a):
+    if os.environ.get("S2ST_BENCH_VERBOSE"):
+        print(f"[bench +{time.perf_counter() - _T0:7.2f}s]", *a, file=sys.stderr, flush=True)
+
+
+def effective_cores():
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_leg(args):
+    """Child process: oracle (torch CPU fp32) fwd+bwd+clip+Adam on the given utterances."""
+    import s2st_amd  # noqa: F401
+    import s2st_oracle as O
+    from configs import CONFIGS
+    D = importlib.import_module(PKG + ".data")
+    ncores = effective_cores()
+    torch.set_num_threads(ncores)
+    O.USE_TORCH_CTC = True  # the reference calls torch.nn.CTCLoss (s2st_loss.py:173-176)
+    ca = O.make_args(**CONFIGS[args.config])
+    corpus = D.SyntheticFisherCorpus(n_utts=args.n_utts, seed=1234)
+    sub = corpus.collate_batch([int(i) for i in args.cpu_leg.split(",")])
+    torch.manual_seed(1)
+    m = O.S2STModel(ca)
+    m.train()
+    opt = O.FairseqAdam(m.parameters())
+    O.train_step(m, opt, sub, 0, 1.5e-3, 4000, 1.0)  # warm-up
+    tcpu, n = 0.0, 0
+    while tcpu < args.cpu_seconds and n < 5:
+        t1 = time.perf_counter()
+        O.train_step(m, opt, sub, n + 1, 1.5e-3, 4000, 1.0)
+        tcpu += time.perf_counter() - t1
+        n += 1
+    fr = ca.n_frames_per_step * sub["ntokens"]
+    print(json.dumps({"value": round(fr * n / tcpu, 1), "unit": "mel-frames/s", "cores": ncores, "kind": "port",
+                      "sample": f"oracle (torch CPU fp32, {ncores} threads) fwd+bwd+clip+Adam on the first 8 utterances "
+                                f"of timed batch 0 ({fr} mel frames, src up to {int(sub['net_input']['src_speech'].shape[1])} "
+                                f"frames), 1 warm-up + {n} timed steps"}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,7 +122,10 @@ def main():
     ap.add_argument("--n-utts", type=int, default=4096)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-baseline leg (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_leg:
+        return cpu_leg(args)
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -103,6 +156,7 @@ def main():
     criterion = task.build_criterion(a)
     trainer = trainer_mod.Trainer(a, task, model, criterion)
     eng = model.engine
+    vlog('model built', eng.n_params, 'params')
 
     corpus = task.load_dataset("train", n_utts=args.n_utts, seed=1234)
     batches = corpus.batches(max_tokens=args.max_tokens, bsz_mult=8)
@@ -115,12 +169,16 @@ def main():
     prepared = [eng.prepare(s, training=True) for s in samples]  # device-resident inputs
     frames = [a.n_frames_per_step * s["ntokens"] for s in samples]
     macs = [algorithmic_macs(s, a) for s in samples]
+    vlog('batches prepared', [(len(ix), int(corpus.src_n_frames[ix].max())) for ix in mine])
 
     def step(i):
         return trainer.train_step([_Prepared(prepared[i], samples[i])])
 
     for i in range(args.warmup):
         step(i)
+        if os.environ.get('S2ST_BENCH_VERBOSE'):
+            torch.cuda.synchronize()
+            vlog('warmup step', i, 'done')
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -133,6 +191,7 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    vlog('timed region', dt)
     my_frames = float(sum(frames[args.warmup:]))
     my_flops = 3.0 * 2.0 * sum(macs[args.warmup:])  # fwd + bwd = 3 x fwd, 2 FLOP per MAC
     stat = torch.tensor([dt, my_frames, my_flops], dtype=torch.float64, device=dev)
@@ -159,6 +218,7 @@ def main():
         lib.s2st_profile_gemm(0)
         fl, ms, nl = C.c_double(), C.c_double(), C.c_int64()
         lib.s2st_profile_gemm_read(C.byref(fl), C.byref(ms), C.byref(nl))
+        vlog('roofline leg done', nl.value, 'gemm launches')
         alg = 3.0 * 2.0 * sum(macs[args.warmup:args.warmup + n_replay])
         achieved = alg / (ms.value * 1e-3) / 1e12
         roofline = {
@@ -172,27 +232,23 @@ def main():
             "algorithmic_gflop_per_step": round(alg / n_replay / 1e9, 1),
         }
 
-    # ---- CPU baseline leg: the oracle (torch fp32, all host cores) on a bounded sample ------------
+    # ---- CPU baseline leg: the oracle (torch fp32, all usable host cores) on a bounded sample, in a
+    #      child process with a hard time limit so a slow host can never stall the bench -----------
     cpu = None
     if args.cpu_seconds > 0 and rank == 0 and world == 1:
-        from configs import CONFIGS as _C
-        torch.set_num_threads(os.cpu_count() or 1)
-        ca = O.make_args(**_C[args.config])
-        m = O.S2STModel(ca)
-        m.train()
-        opt = O.FairseqAdam(m.parameters())
-        sub = corpus.collate_batch(mine[args.warmup][:16])
-        O.train_step(m, opt, sub, 0, 1.5e-3, 4000, 1.0)  # warm-up
-        tcpu, n = 0.0, 0
-        while tcpu < args.cpu_seconds and n < 3:
-            t1 = time.perf_counter()
-            O.train_step(m, opt, sub, n + 1, 1.5e-3, 4000, 1.0)
-            tcpu += time.perf_counter() - t1
-            n += 1
-        cpu = {"value": round(ca.n_frames_per_step * sub["ntokens"] * n / tcpu, 1), "unit": "mel-frames/s",
-               "cores": os.cpu_count(), "kind": "port",
-               "sample": f"oracle (torch CPU fp32) fwd+bwd+clip+Adam on the first 16 utterances of timed batch 0 "
-                         f"({ca.n_frames_per_step * sub['ntokens']} mel frames), 1 warm-up + {n} timed steps"}
+        import subprocess
+        idx = ",".join(str(int(i)) for i in mine[args.warmup][:8])
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-leg", idx, "--config", args.config,
+                                "--n-utts", str(args.n_utts), "--cpu-seconds", str(args.cpu_seconds)],
+                               capture_output=True, text=True, timeout=6 * args.cpu_seconds + 90)
+            for ln in r.stdout.splitlines():
+                if ln.startswith("{"):
+                    cpu = json.loads(ln)
+            if cpu is None:
+                vlog("cpu leg produced no result:", r.stderr[-400:])
+        except subprocess.TimeoutExpired:
+            vlog("cpu leg timed out")
 
     if rank == 0:
         value = total_frames / dt

@@ -66,8 +66,9 @@ int s2st_gemm_f32(const s2st_gemm_args* args, void* stream);
 /* fairseq/modules/layer_norm.py:11-35 (LayerNorm / FusedLayerNorm), forward; saves mean, rstd */
 int s2st_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int32_t rows, int32_t cols, float eps, void* stream);
 
-/* backward of the above: dx (=|+=), dgamma += , dbeta += */
-int s2st_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx, int32_t dx_accumulate, float* dgamma, float* dbeta, int32_t rows, int32_t cols, void* stream);
+/* backward of the above: dx (=|+=), dgamma += , dbeta += ; scratch: s2st_layernorm_bwd_scratch floats */
+int s2st_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx, int32_t dx_accumulate, float* dgamma, float* dbeta, float* scratch, int32_t rows, int32_t cols, void* stream);
+int64_t s2st_layernorm_bwd_scratch(int32_t rows, int32_t cols);
 
 /* multihead_attention.py:343-366: key-padding / causal -inf masks, fp32 softmax, dropout. scores [B,H,T,ld] */
 int s2st_softmax_fwd_f32(const float* s, float* p, float* pd, const int32_t* klen, int32_t B, int32_t H, int32_t T, int32_t S, int32_t ld, int32_t causal, float drop_p, uint64_t seed, void* stream);

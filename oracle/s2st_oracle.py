@@ -524,11 +524,17 @@ class S2STModel(nn.Module):
 # ----------------------------------------------------------------------------------------
 # criterion (examples/s2s_trans/criterions/s2st_loss.py)
 # ----------------------------------------------------------------------------------------
+USE_TORCH_CTC = False  # bench.py's CPU-baseline leg flips this: same numbers, ATen's C++ loop
+
+
 def ctc_loss_mean(lprobs, targets_flat, input_lens, target_lens, blank=0):
     """CTC negative log-likelihood, alpha recursion in log space, reduction='mean'
     (per-utterance loss / clamp(target_len, 1), then batch mean) and zero_infinity=True --
     the semantics of ``torch.nn.CTCLoss(reduction="mean", zero_infinity=True)`` as used at
     s2st_loss.py:173-176, 242-243.  Graves et al. 2006.  lprobs [T, B, V]."""
+    if USE_TORCH_CTC:
+        return F.ctc_loss(lprobs, targets_flat, input_lens, target_lens, blank=blank,
+                          reduction="mean", zero_infinity=True)
     T, B, V = lprobs.shape
     losses = []
     off = 0

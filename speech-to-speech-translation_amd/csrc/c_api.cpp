@@ -20,8 +20,8 @@ int s2st_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta
   return s2st_layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, cols, eps, (hipStream_t)stream);
 }
 
-int s2st_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx, int32_t dx_accumulate, float* dgamma, float* dbeta, int32_t rows, int32_t cols, void* stream) {
-  return s2st_layernorm_bwd(dy, x, gamma, mean, rstd, dx, dx_accumulate, dgamma, dbeta, rows, cols, (hipStream_t)stream);
+int s2st_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx, int32_t dx_accumulate, float* dgamma, float* dbeta, float* scratch, int32_t rows, int32_t cols, void* stream) {
+  return s2st_layernorm_bwd(dy, x, gamma, mean, rstd, dx, dx_accumulate, dgamma, dbeta, scratch, rows, cols, (hipStream_t)stream);
 }
 
 int s2st_softmax_fwd_f32(const float* s, float* p, float* pd, const int32_t* klen, int32_t B, int32_t H, int32_t T, int32_t S, int32_t ld, int32_t causal, float drop_p, uint64_t seed, void* stream) {
@@ -116,6 +116,7 @@ int s2st_adam_f32(float* p, float* g, float* m, float* v, int64_t n, const float
   return s2st_adam(p, g, m, v, n, sumsq, gmul, gmul_dev, max_norm, lr, beta1, beta2, eps, wd, step, gnorm_out, (hipStream_t)stream);
 }
 
+int64_t s2st_layernorm_bwd_scratch(int32_t rows, int32_t cols) { return (int64_t)s2st_layernorm_bwd_blocks(rows) * 2 * cols; }
 int64_t s2st_ctc_workspace(int32_t B, int32_t E, int32_t Lmax) { return s2st_ctc_workspace_floats(B, E, Lmax); }
 
 int s2st_profile_gemm(int32_t enable) { s2st_gemm_profile_enable(enable); return 0; }

@@ -348,9 +348,10 @@ struct s2st_engine {
       if (!y->g) return;
       bool acc;
       float* dx = gradbuf(x, acc);
+      float* scratch = alloc((long)s2st_layernorm_bwd_blocks(x->rows) * 2 * x->cols);
       if (live())
         chk(s2st_layernorm_bwd(y->g, x->d, P + pp.g, mean, rstd, dx, acc ? 1 : 0, G + pp.g, G + pp.b,
-                               x->rows, x->cols, st_));
+                               scratch, x->rows, x->cols, st_));
     });
     return y;
   }

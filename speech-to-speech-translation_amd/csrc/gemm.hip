@@ -23,14 +23,30 @@ namespace {
 constexpr int BK = 32;
 constexpr int LDS_ROW = 80;  // bytes per tile row: 32 bf16 (64 B) + 16 B pad
 
-template <bool KM, int ROWS>
+// LDS images (bf16):
+//   K-contiguous operand  : [row][32 k], pitch LDS_ROW (80 B); fragments by ds_read_b128.
+//   rows-contiguous operand: natural [k slot][rows], pitch 2*ROWS + 32 B, k rows stored at slot
+//     s(k) = k with bits 2 and 3 swapped so that the 8 k rows one 32-lane half reads with
+//     ds_read_b64_tr_b16 ({0-3, 8-11} + 4h) are adjacent 32-B chunks: conflict-free reads, and
+//     the stores (consecutive lanes = consecutive row quads of one k) are contiguous.
+__device__ __forceinline__ constexpr int kslot(int k) {
+  return (k & 19) | ((k & 4) << 1) | ((k & 8) >> 1);
+}
+
+template <bool KM, int ROWS, bool VEC>
 struct TileLoader {
-  // KM  : slot i -> f = tid + 256 i ; row = f >> 3 ; kq = f & 7      (ROWS*8/256 slots)
-  // !KM : rq = tid % (ROWS/4), kq = tid / (ROWS/4) (active if kq < 8) ; slot i -> k = 4 kq + i
-  static constexpr int NLD = KM ? (ROWS * 8 / 256) : 4;
+  // KM  : slot i -> f = tid + 256 i ; row = f >> 3 ; kq = f & 7 (= tid & 7)
+  // !KM : slot i -> f = tid + 256 i ; rq = f % (ROWS/4) ; kk = f / (ROWS/4)
+  // VEC : every access is an aligned float4 and the loop body is branch-free: out-of-range
+  //       rows are CLAMPED (their products land in accumulator rows/cols the epilogue never
+  //       stores), the K tail is clamped and zeroed by a select.  !VEC: guarded scalar loads.
+  static constexpr int NLD = ROWS * 8 / 256;
+  static constexpr int RQ = ROWS / 4;
+  static constexpr int PITCH = KM ? LDS_ROW : (2 * ROWS + 32);
+  static constexpr int BYTES = KM ? ROWS * LDS_ROW : BK * (2 * ROWS + 32);
   float r[NLD][4];
-  long off[NLD];   // KM: per-slot row offset (-1 = row out of range)
-  int tid;
+  long off[NLD];  // KM: row offset (VEC: clamped row; !VEC: -1 = out of range)
+  int tid, row0;  // !KM: first of this thread's 4 rows (VEC: clamped)
 
   __device__ __forceinline__ void init(const GemmOperand& X, int r0, int R, int tid_) {
     tid = tid_;
@@ -38,46 +54,48 @@ struct TileLoader {
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
         int row = r0 + ((tid + 256 * i) >> 3);
-        off[i] = row < R ? split_off(X.sp, row) : -1;
+        if (VEC) off[i] = split_off(X.sp, min(row, R - 1));
+        else off[i] = row < R ? split_off(X.sp, row) : -1;
       }
+    } else {
+      row0 = r0 + 4 * (tid % RQ);
+      if (VEC) row0 = min(row0, R - 4);
     }
   }
 
-  __device__ __forceinline__ void load(const GemmOperand& X, const float* base, int r0, int R,
-                                       int kt, int kend, int vec) {
+  __device__ __forceinline__ void load(const GemmOperand& X, const float* base, int R, int kt, int kend) {
     if (KM) {
+      const int k = kt + (tid & 7) * 4;
+      if (VEC) {
+        const bool ok = k < kend;
+        const int kc = min(k, kend - 4);
 #pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        int k = kt + ((tid + 256 * i) & 7) * 4;
-        r[i][0] = r[i][1] = r[i][2] = r[i][3] = 0.f;
-        if (off[i] >= 0 && k < kend) {
-          const float* p = base + off[i] + k;
-          if (vec && k + 3 < kend) {
-            float4 v = *reinterpret_cast<const float4*>(p);
-            r[i][0] = v.x; r[i][1] = v.y; r[i][2] = v.z; r[i][3] = v.w;
-          } else {
+        for (int i = 0; i < NLD; ++i) {
+          float4 v = *reinterpret_cast<const float4*>(base + off[i] + kc);
+          r[i][0] = ok ? v.x : 0.f; r[i][1] = ok ? v.y : 0.f;
+          r[i][2] = ok ? v.z : 0.f; r[i][3] = ok ? v.w : 0.f;
+        }
+      } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (k + e < kend) r[i][e] = p[e];
-          }
+        for (int i = 0; i < NLD; ++i) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            r[i][e] = (off[i] >= 0 && k + e < kend) ? base[off[i] + k + e] : 0.f;
         }
       }
     } else {
-      constexpr int RQ = ROWS / 4;
-      int rq = tid % RQ, kq = tid / RQ;
-      int row = r0 + 4 * rq;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        r[i][0] = r[i][1] = r[i][2] = r[i][3] = 0.f;
-        int k = kt + 4 * kq + i;
-        if (kq < 8 && k < kend && row < R) {
-          const float* p = base + split_off(X.sp, k) + row;
-          if (vec && row + 3 < R) {
-            float4 v = *reinterpret_cast<const float4*>(p);
-            r[i][0] = v.x; r[i][1] = v.y; r[i][2] = v.z; r[i][3] = v.w;
-          } else {
+      for (int i = 0; i < NLD; ++i) {
+        const int k = kt + (tid + 256 * i) / RQ;
+        const bool ok = k < kend;
+        const long o = split_off(X.sp, min(k, kend - 1));
+        if (VEC) {
+          float4 v = *reinterpret_cast<const float4*>(base + o + row0);
+          r[i][0] = ok ? v.x : 0.f; r[i][1] = ok ? v.y : 0.f;
+          r[i][2] = ok ? v.z : 0.f; r[i][3] = ok ? v.w : 0.f;
+        } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (row + e < R) r[i][e] = p[e];
-          }
+          for (int e = 0; e < 4; ++e) r[i][e] = (ok && row0 + e < R) ? base[o + row0 + e] : 0.f;
         }
       }
     }
@@ -85,45 +103,44 @@ struct TileLoader {
 
   template <bool PRECISE>
   __device__ __forceinline__ void store(unsigned char* hi_img, unsigned char* lo_img) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int f = tid + 256 * i;
+      const int o = KM ? (f >> 3) * LDS_ROW + (f & 7) * 8 : kslot(f / RQ) * PITCH + (f % RQ) * 8;
+      if (PRECISE) {
+        uint2 h, l;
+        split_bf16x4(r[i][0], r[i][1], r[i][2], r[i][3], h, l);
+        *reinterpret_cast<uint2*>(hi_img + o) = h;
+        *reinterpret_cast<uint2*>(lo_img + o) = l;
+      } else {
+        *reinterpret_cast<uint2*>(hi_img + o) = pack_bf16x4(r[i][0], r[i][1], r[i][2], r[i][3]);
+      }
+    }
+  }
+
+  // MFMA 16x16x32 operand fragment for tile rows [rt, rt + 16): lane l holds k = 8 (l>>4) + j
+  __device__ static __forceinline__ bf16x8 frag(const unsigned char* img, int rt, int lane) {
     if (KM) {
-#pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        int f = tid + 256 * i;
-        int o = (f >> 3) * LDS_ROW + (f & 7) * 8;
-        if (PRECISE) {
-          uint2 h, l;
-          split_bf16x4(r[i][0], r[i][1], r[i][2], r[i][3], h, l);
-          *reinterpret_cast<uint2*>(hi_img + o) = h;
-          *reinterpret_cast<uint2*>(lo_img + o) = l;
-        } else {
-          *reinterpret_cast<uint2*>(hi_img + o) = pack_bf16x4(r[i][0], r[i][1], r[i][2], r[i][3]);
-        }
-      }
+      return *reinterpret_cast<const bf16x8*>(img + (rt + (lane & 15)) * LDS_ROW + (lane >> 4) * 16);
     } else {
-      constexpr int RQ = ROWS / 4;
-      int rq = tid % RQ, kq = tid / RQ;
-      if (kq < 8) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          int o = (4 * rq + j) * LDS_ROW + kq * 8;
-          if (PRECISE) {
-            uint2 h, l;
-            split_bf16x4(r[0][j], r[1][j], r[2][j], r[3][j], h, l);
-            *reinterpret_cast<uint2*>(hi_img + o) = h;
-            *reinterpret_cast<uint2*>(lo_img + o) = l;
-          } else {
-            *reinterpret_cast<uint2*>(hi_img + o) = pack_bf16x4(r[0][j], r[1][j], r[2][j], r[3][j]);
-          }
-        }
-      }
+      const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+      const unsigned char* a = img + kslot(8 * g + q) * PITCH + (rt + 4 * p) * 2;
+      s16x4 lo = lds_read_tr16(a);
+      s16x4 hi = lds_read_tr16(a + (kslot(4) - kslot(0)) * PITCH);  // k rows +4 -> slot +8
+      bf16x8 f;
+      f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+      f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+      return f;
     }
   }
 };
 
-template <int BM, int BN, bool AKM, bool BKM, bool PRECISE>
+template <int BM, int BN, bool AKM, bool BKM, bool PRECISE, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
-  constexpr int A_BYTES = BM * LDS_ROW, B_BYTES = BN * LDS_ROW;
+  typedef TileLoader<AKM, BM, VEC> LA;
+  typedef TileLoader<BKM, BN, VEC> LB;
+  constexpr int A_BYTES = LA::BYTES, B_BYTES = LB::BYTES;
   constexpr int IMG = PRECISE ? 2 : 1;
   constexpr int STAGE = (A_BYTES + B_BYTES) * IMG;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
@@ -140,8 +157,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int kend = min(g.K, kbeg + g.kchunk);
   const int nt = (kend - kbeg + BK - 1) / BK;
 
-  TileLoader<AKM, BM> la;
-  TileLoader<BKM, BN> lb;
+  LA la;
+  LB lb;
   la.init(g.A, m0, g.M, tid);
   lb.init(g.B, n0, g.N, tid);
 
@@ -151,38 +168,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // stage layout: [A hi][B hi]([A lo][B lo])
   if (nt > 0) {
-    la.load(g.A, abase, m0, g.M, kbeg, kend, g.avec);
-    lb.load(g.B, bbase, n0, g.N, kbeg, kend, g.bvec);
+    la.load(g.A, abase, g.M, kbeg, kend);
+    lb.load(g.B, bbase, g.N, kbeg, kend);
     la.template store<PRECISE>(smem, smem + A_BYTES + B_BYTES);
     lb.template store<PRECISE>(smem + A_BYTES, smem + A_BYTES + B_BYTES + A_BYTES);
   }
   __syncthreads();
 
-  const int frag_off = (lane & 15) * LDS_ROW + (lane >> 4) * 16;
   for (int t = 0; t < nt; ++t) {
     unsigned char* cur = smem + (t & 1) * STAGE;
     unsigned char* nxt = smem + ((t + 1) & 1) * STAGE;
     const bool more = t + 1 < nt;
     if (more) {
-      la.load(g.A, abase, m0, g.M, kbeg + (t + 1) * BK, kend, g.avec);
-      lb.load(g.B, bbase, n0, g.N, kbeg + (t + 1) * BK, kend, g.bvec);
+      la.load(g.A, abase, g.M, kbeg + (t + 1) * BK, kend);
+      lb.load(g.B, bbase, g.N, kbeg + (t + 1) * BK, kend);
     }
     bf16x8 af[TM], bf[TN];
-    const unsigned char* As = cur + wm * WM * LDS_ROW + frag_off;
-    const unsigned char* Bs = cur + A_BYTES + wn * WN * LDS_ROW + frag_off;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + i * 16 * LDS_ROW);
+    for (int i = 0; i < TM; ++i) af[i] = LA::frag(cur, wm * WM + i * 16, lane);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 16 * LDS_ROW);
+    for (int j = 0; j < TN; ++j) bf[j] = LB::frag(cur + A_BYTES, wn * WN + j * 16, lane);
     if (PRECISE) {
       bf16x8 al[TM], bl[TN];
-      const unsigned char* Al = As + A_BYTES + B_BYTES;
-      const unsigned char* Bl = Bs + A_BYTES + B_BYTES;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) al[i] = *reinterpret_cast<const bf16x8*>(Al + i * 16 * LDS_ROW);
+      for (int i = 0; i < TM; ++i) al[i] = LA::frag(cur + A_BYTES + B_BYTES, wm * WM + i * 16, lane);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bl[j] = *reinterpret_cast<const bf16x8*>(Bl + j * 16 * LDS_ROW);
+      for (int j = 0; j < TN; ++j) bl[j] = LB::frag(cur + A_BYTES + B_BYTES + A_BYTES, wn * WN + j * 16, lane);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -238,21 +251,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
 }
 
-template <int BM, int BN, bool PRECISE>
+template <int BM, int BN, bool PRECISE, bool VEC>
 void launch_layouts(const GemmArgs& g, dim3 grid, hipStream_t st) {
   if (g.A.kmajor && g.B.kmajor)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, PRECISE>), grid, dim3(256), 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, PRECISE, VEC>), grid, dim3(256), 0, st, g);
   else if (g.A.kmajor && !g.B.kmajor)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false, PRECISE>), grid, dim3(256), 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false, PRECISE, VEC>), grid, dim3(256), 0, st, g);
   else if (!g.A.kmajor && g.B.kmajor)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true, PRECISE>), grid, dim3(256), 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true, PRECISE, VEC>), grid, dim3(256), 0, st, g);
   else
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false, PRECISE>), grid, dim3(256), 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false, PRECISE, VEC>), grid, dim3(256), 0, st, g);
 }
 
-bool vec_ok(const GemmOperand& o) {
-  return ((uintptr_t)o.p % 16 == 0) && (o.sp.ld % 4 == 0) && (o.sp.bs % 4 == 0) &&
-         (o.zo % 4 == 0) && (o.zi % 4 == 0);
+// aligned-float4 fast path: pointer/strides 16-byte aligned and the contiguous extent a multiple of 4
+bool vec_ok(const GemmOperand& o, int R, int K) {
+  bool base = ((uintptr_t)o.p % 16 == 0) && (o.sp.ld % 4 == 0) && (o.sp.bs % 4 == 0) &&
+              (o.zo % 4 == 0) && (o.zi % 4 == 0) && K >= 4;
+  return base && (o.kmajor ? (K % 4 == 0) : (R % 4 == 0 && R >= 4));
 }
 
 }  // namespace
@@ -294,18 +309,20 @@ int s2st_gemm(GemmArgs g, hipStream_t st) {
     hipEventRecord(rec.a, st);
   }
   if (g.zdiv <= 0) g.zdiv = 1;
-  g.avec = vec_ok(g.A) ? 1 : 0;
-  g.bvec = vec_ok(g.B) ? 1 : 0;
+  g.avec = vec_ok(g.A, g.M, g.K) ? 1 : 0;
+  g.bvec = vec_ok(g.B, g.N, g.K) ? 1 : 0;
+  const bool vec = g.avec && g.bvec;
   auto tiles = [&](int bm, int bn) {
     return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * g.batch;
   };
-  bool big = !g.precise && tiles(128, 128) >= 192;
+  bool linear_epi = !g.ep.act && g.ep.drop_p == 0.f;
+  bool wgrad_like = g.ep.accumulate && linear_epi && g.K >= 16 * BK;
+  bool big = vec && !g.precise && (tiles(128, 128) >= 192 || (wgrad_like && g.M >= 128 && g.N >= 128));
   int bm = big ? 128 : 64, bn = bm;
   long nt = tiles(bm, bn);
   // split-K only for accumulating outputs (weight gradients): partial sums are added with
   // fp32 atomics, the epilogue must then be linear.
   g.splitk = 1;
-  bool linear_epi = !g.ep.act && g.ep.drop_p == 0.f;
   if (g.ep.accumulate && linear_epi && nt < 256 && g.K >= 8 * BK) {
     int want = (int)((512 + nt - 1) / nt);
     int maxs = g.K / (4 * BK);
@@ -313,17 +330,19 @@ int s2st_gemm(GemmArgs g, hipStream_t st) {
     if (g.splitk < 1) g.splitk = 1;
   }
   int kt = (g.K + BK - 1) / BK;
-  g.kchunk = ((kt + g.splitk - 1) / g.splitk) * BK;
+  g.kchunk = ((kt + g.splitk - 1) / g.splitk) * BK;  // multiple of 32: split chunks keep K % 4
   g.splitk = (g.K + g.kchunk - 1) / g.kchunk;
   if (g.splitk < 1) g.splitk = 1;
   dim3 grid((g.N + bn - 1) / bn, (g.M + bm - 1) / bm, g.batch * g.splitk);
   if (grid.y > 65535 || grid.z > 65535) return -2;
   if (g.precise) {
-    launch_layouts<64, 64, true>(g, grid, st);
+    if (vec) launch_layouts<64, 64, true, true>(g, grid, st);
+    else launch_layouts<64, 64, true, false>(g, grid, st);
   } else if (big) {
-    launch_layouts<128, 128, false>(g, grid, st);
+    launch_layouts<128, 128, false, true>(g, grid, st);
   } else {
-    launch_layouts<64, 64, false>(g, grid, st);
+    if (vec) launch_layouts<64, 64, false, true>(g, grid, st);
+    else launch_layouts<64, 64, false, false>(g, grid, st);
   }
   if (g_prof_on) {
     hipEventRecord(rec.b, st);

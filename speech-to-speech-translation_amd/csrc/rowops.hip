@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
-    int dx_accumulate, float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int cols) {
+    int dx_accumulate, float* __restrict__ part, int rows, int cols) {
   __shared__ float red[2][4][LN_MAXV * 64];  // [dgamma|dbeta][wave][float4 slot]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = cols >> 2;
@@ -136,10 +136,31 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     for (int c4 = threadIdx.x; c4 < nv; c4 += 256) {
       float gsum = rg[c4] + rg[WSTRIDE + c4] + rg[2 * WSTRIDE + c4] + rg[3 * WSTRIDE + c4];
       float bsum = rb[c4] + rb[WSTRIDE + c4] + rb[2 * WSTRIDE + c4] + rb[3 * WSTRIDE + c4];
-      atomicAdd(&dgamma[c4 * 4 + comp], gsum);
-      atomicAdd(&dbeta[c4 * 4 + comp], bsum);
+      // per-block partials: [block][2][cols]
+      part[((long)blockIdx.x * 2 + 0) * cols + c4 * 4 + comp] = gsum;
+      part[((long)blockIdx.x * 2 + 1) * cols + c4 * 4 + comp] = bsum;
     }
     __syncthreads();
+  }
+}
+
+// out[c] += sum_b part[b][c] over the [nblocks][2*cols] partials (out = [dgamma | dbeta] halves)
+__global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ part,
+                                                                   int nblocks, int cols,
+                                                                   float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;  // over 2 * cols
+  float a = 0.f;
+  if (c < 2 * cols)
+    for (int b = ty; b < nblocks; b += 4) a += part[(long)b * 2 * cols + c];
+  red[ty][tx] = a;
+  __syncthreads();
+  if (ty == 0 && c < 2 * cols) {
+    float v = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+    if (c < cols) dgamma[c] += v;
+    else dbeta[c - cols] += v;
   }
 }
 
@@ -260,15 +281,22 @@ int s2st_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
+int s2st_layernorm_bwd_blocks(int rows) {
+  int blocks = (rows + 3) / 4;
+  return blocks > 256 ? 256 : blocks;
+}
+
+// scratch: s2st_layernorm_bwd_blocks(rows) * 2 * cols floats
 int s2st_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                        const float* rstd, float* dx, int dx_accumulate, float* dgamma,
-                       float* dbeta, int rows, int cols, hipStream_t st) {
+                       float* dbeta, float* scratch, int rows, int cols, hipStream_t st) {
   if (rows <= 0) return 0;
   if (cols % 4 != 0 || cols > LN_MAXV * 256) return S2ST_ERR_SHAPE;
-  int blocks = (rows + 3) / 4;
-  if (blocks > 512) blocks = 512;
+  int blocks = s2st_layernorm_bwd_blocks(rows);
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, x, gamma, mean,
-                     rstd, dx, dx_accumulate, dgamma, dbeta, rows, cols);
+                     rstd, dx, dx_accumulate, scratch, rows, cols);
+  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * cols + 63) / 64), dim3(256), 0, st,
+                     (const float*)scratch, blocks, cols, dgamma, dbeta);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 

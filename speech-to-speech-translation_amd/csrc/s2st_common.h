@@ -11,6 +11,15 @@ typedef float f32v4 __attribute__((ext_vector_type(4)));
 
 #define S2ST_WAVE 64
 
+// ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies the address of row q, columns
+// 4p..4p+3 of a 4 x 16 block of 16-bit elements; lane i receives column i, row q in element q
+// (cdna_hip_programming.md T10).  Used to read K-strided ("rows-contiguous") GEMM operands
+// from an LDS image kept in its natural [k][rows] layout.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 lds_read_tr16(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
 // 4 x f32 -> 4 x bf16 (round-to-nearest-even), packed in 8 bytes.
 // Lowers to two v_cvt_pk_bf16_f32 on gfx950.
 __device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d) {

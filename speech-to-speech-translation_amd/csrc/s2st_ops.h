@@ -48,10 +48,11 @@ int s2st_gemm_profile_read(double* flops, double* ms, long* launches);
 // ---------------------------------------------------------------------------------------
 int s2st_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                        float* mean, float* rstd, int rows, int cols, float eps, hipStream_t st);
-// dx (+)= ...; dgamma/dbeta accumulated with atomics (caller zeroes or owns accumulation)
+// dx (=|+=) ...; dgamma += , dbeta += (per-block partials in `scratch`, then a reduce kernel)
+int s2st_layernorm_bwd_blocks(int rows);  // scratch floats = blocks * 2 * cols
 int s2st_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                        const float* rstd, float* dx, int dx_accumulate, float* dgamma,
-                       float* dbeta, int rows, int cols, hipStream_t st);
+                       float* dbeta, float* scratch, int rows, int cols, hipStream_t st);
 
 // attention probabilities: p = softmax(s + masks) rows of [B, H, T, S(ld)]
 //   key mask: col >= klen[b] -> -inf ; causal: col > row -> -inf

@@ -88,10 +88,12 @@ class S2ST_TranslationTask:
         return self.datasets[split]
 
     def build_model(self, args):
+        from .. import models  # noqa: F401  (registers the architecture)
         args.n_frames_per_step = self.args.n_frames_per_step
         return MODELS["s2st_transformer"].build_model(args, self)
 
     def build_criterion(self, args):
+        from .. import criterions  # noqa: F401
         return CRITERIA["s2st_loss"].build_criterion(args, self)
 
     def train_step(self, sample, model, criterion, optimizer, update_num, ignore_grad=False):

@@ -139,6 +139,22 @@ static inline emu_f32x4 emu_mfma_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f
   return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 emu_mfma_16x16x32_bf16
+// ds_read_b64_tr_b16 (see cdna_hip_programming.md T10)
+typedef short emu_s16x4 __attribute__((ext_vector_type(4)));
+static inline emu_s16x4 emu_ds_read_tr16(const void* p) {
+  const unsigned char* mine = (const unsigned char*)p;
+  const unsigned char* all[64];
+  emu_wave_exchange(&mine, all, sizeof(mine));
+  int l = emu_lane(), g = l & ~15, i = l & 15;
+  emu_s16x4 r;
+  for (int q = 0; q < 4; ++q) {
+    const unsigned char* a = all[g + 4 * q + (i >> 2)] + 2 * (i & 3);
+    short v; memcpy(&v, a, 2);
+    r[q] = v;
+  }
+  return r;
+}
+#define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu_ds_read_tr16((const void*)(p))
 #define __builtin_amdgcn_readfirstlane(x) (emu_shfl_idx((x), 0))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)

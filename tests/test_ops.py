@@ -38,7 +38,8 @@ def test_layernorm(backend, rows, cols):
     dx = torch.ones_like(xd)
     dg = torch.zeros(cols, device=backend.device)
     db = torch.zeros(cols, device=backend.device)
-    backend.bd.call("s2st_layernorm_bwd_f32", dyd, xd, gd, mean, rstd, dx, 1, dg, db, rows, cols)
+    scratch = torch.zeros(backend.bd._bind("s2st_layernorm_bwd_scratch")(rows, cols), device=backend.device)
+    backend.bd.call("s2st_layernorm_bwd_f32", dyd, xd, gd, mean, rstd, dx, 1, dg, db, scratch, rows, cols)
     backend.sync()
     close(dx, xr.grad + 1.0, 1e-4, 1e-5)
     close(dg, gr.grad, 1e-4, 1e-4)
