@@ -84,8 +84,10 @@ class Trainer:
         if self.reducer is not None:
             self.reducer.finish()
             self.gmul_dev.fill_(float(sample_size))
-            all_reduce_scalars(self.gmul_dev)           # sum of sample sizes over ranks
-            self.gmul_dev.reciprocal_().mul_(float(world))  # world / sum(sample_size)
+            all_reduce_scalars(self.gmul_dev)  # sum of sample sizes over ranks
+            # DDP averages gradients and the trainer multiplies by world / sum(sample_size); the
+            # arena holds the SUM over ranks, so the net factor is 1 / sum(sample_size)
+            self.gmul_dev.reciprocal_()
             gmul_dev, gmul = self.gmul_dev, 1.0
         else:
             gmul = 1.0 / float(sample_size)

@@ -33,6 +33,19 @@ MICRO = dict(
 MICRO_POSTLN = dict(MICRO, decoder_normalize_before=False, ctc_weight=0.0, asr_ce_weight=0.0,
                     st_ce_weight=0.0, middle_layers="0")
 
+# smallest geometry that still exercises every op (host / distributed tests on the emulator)
+NANO = dict(MICRO, encoder_transformer_layers=2, decoder_transformer_layers=1, encoder_embed_dim=32,
+            decoder_embed_dim=32, encoder_ffn_embed_dim=64, decoder_ffn_embed_dim=64,
+            encoder_attention_heads=2, decoder_attention_heads=2, prenet_dim=16, postnet_conv_dim=32,
+            middle_layers="0,1", asr_decoder_embed_dim=16, st_decoder_embed_dim=16, postnet_layers=2)
+
+
+def nano_batches():
+    D = importlib.import_module(DATA)
+    c = D.SyntheticFisherCorpus(n_utts=4, seed=3, max_src=44, median_src=40, min_src=30)
+    return [c.collate_batch(range(2)), c.collate_batch(range(2, 4))]
+
+
 LOSS_KEYS = [("loss", 16), ("l1_loss", 17), ("mse_loss", 18), ("eos_loss", 19), ("ctc_loss", 20),
              ("aux_asr_loss", 21), ("aux_st_loss", 22)]
 SUB = 61
