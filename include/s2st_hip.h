@@ -25,17 +25,21 @@ extern "C" {
 typedef struct { int64_t ld; int64_t bs; int32_t per; int32_t _pad; } s2st_split;
 
 typedef struct {
-  const float* p;
+  const void* p;  /* fp32 (dtype 0) or bf16 (dtype 1, raw uint16) elements */
   int32_t kmajor; /* 1: X(r,k) at p + split(r) + k ; 0: X(r,k) at p + split(k) + r */
-  int32_t _pad;
+  int32_t dtype;  /* S2ST_F32 / S2ST_BF16; all strides below are in ELEMENTS of this type */
   s2st_split sp;
   int64_t zo, zi; /* batch strides: z -> (z / zdiv) * zo + (z % zdiv) * zi */
 } s2st_gemm_operand;
 
+#define S2ST_F32 0
+#define S2ST_BF16 1
+
 typedef struct {
-  float* p;
+  float* p;      /* fp32 result, or NULL when only the bf16 copy is wanted */
   s2st_split sp; /* C(m,n) at p + split(m) + n */
   int64_t zo, zi;
+  uint16_t* h;   /* optional bf16 (round-to-nearest-even) copy of the result, addressed like p */
 } s2st_gemm_out;
 
 typedef struct {
@@ -54,11 +58,22 @@ typedef struct {
   s2st_gemm_epilogue ep;
   int32_t M, N, K;
   int32_t batch, zdiv;
-  int32_t precise; /* 0: bf16 MFMA; 1: bf16x3 split (~fp32 accuracy, parity tests) */
-  int32_t splitk, kchunk, avec, bvec; /* filled by the launcher */
+  int32_t precise; /* 0: bf16 MFMA; 1: bf16x3 split (~fp32 accuracy, parity tests; fp32 operands only) */
+  int32_t splitk, kchunk, avec, bvec, cvec, tiles_n; /* filled by the launcher */
+  /* optional caller-owned scratch for split-K partial sums (bf16-operand path): accumulating
+   * GEMMs with few output tiles (weight gradients) split K over workgroups, write fp32 partial
+   * slabs here and combine them with a second kernel.  NULL: fp32 atomics into C instead. */
+  float* ws;
+  int64_t ws_floats;
+  float* slab; /* filled by the launcher */
 } s2st_gemm_args;
 
-/* C(m,n) = epi(alpha * sum_k A(m,k) B(n,k)).  Replaces F.linear / F.conv1d / torch.bmm at
+/* C(m,n) = epi(alpha * sum_k A(m,k) B(n,k)).  Operands are both fp32 (converted to bf16 on the
+ * way into LDS) or both bf16 (the fast path: producers keep bf16 copies of every GEMM operand so
+ * the rounding is the same as the fp32 path's, at half the bytes).  bf16 operands must have
+ * 16-byte aligned bases, ld % 8 == 0 and rows readable up to the next multiple of 8 elements of
+ * their contiguous extent (padding content is ignored); otherwise a guarded scalar path runs.
+ * Replaces F.linear / F.conv1d / torch.bmm at
  * fairseq/modules/multihead_attention.py:170-192,332,367, transformer_layer.py:158-162,
  * examples/s2s_trans/models/s2st_transformer.py:135-139,452-455, tacotron2.py:95-126. */
 int s2st_gemm_f32(const s2st_gemm_args* args, void* stream);
@@ -236,6 +251,9 @@ int64_t s2st_engine_param_floats(const s2st_engine* e);  /* size of the paramete
 int64_t s2st_engine_buffer_floats(const s2st_engine* e); /* size of the buffer arena */
 /* bind caller-owned device arenas: params/grads [param_floats], buffers [buffer_floats] */
 int s2st_engine_bind(s2st_engine* e, float* params, float* grads, float* buffers);
+/* fast (precise == 0) mode only: caller-owned bf16 arena of param_floats elements; the engine
+ * refreshes it from `params` at the start of every forward and feeds the GEMMs from it */
+int s2st_engine_bind_bf16(s2st_engine* e, uint16_t* params_bf16);
 /* workspace (floats) one forward+backward of this batch geometry needs */
 int64_t s2st_engine_workspace_floats(s2st_engine* e, const s2st_batch* geometry);
 /* forward (+ losses if tgt != NULL).  Activations live in `workspace` until the next call. */

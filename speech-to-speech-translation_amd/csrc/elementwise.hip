@@ -28,6 +28,28 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict_
       reinterpret_cast<const float4*>(x + split_off(xsp, r))[c];
 }
 
+// fp32 [rows][cols] (row stride ldx) -> bf16 [rows][ldy], columns [cols, ldy) zero-filled.
+// One thread per 4 output columns (ldy % 4 == 0); 16-byte loads when the source row allows.
+__global__ __launch_bounds__(256) void cast_bf16_rows_kernel(const float* __restrict__ x, long ldx,
+                                                             uint16_t* __restrict__ y, long ldy, long rows,
+                                                             int cols, int vec) {
+  const long q = ldy >> 2;
+  long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  if (i >= rows * q) return;
+  const long r = i / q;
+  const int c = (int)(i - r * q) * 4;
+  const float* xr = x + r * ldx;
+  float v[4];
+  if (vec && c + 3 < cols) {
+    float4 f = *reinterpret_cast<const float4*>(xr + c);
+    v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = c + e < cols ? xr[c + e] : 0.f;
+  }
+  *reinterpret_cast<uint2*>(y + r * ldy + c) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+}
+
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
 __global__ __launch_bounds__(256) void glu_fwd_kernel(const float* __restrict__ a,
@@ -138,6 +160,49 @@ __global__ __launch_bounds__(256) void relu_drop_bwd_kernel(const float* __restr
   long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
   if (i >= n) return;
   dz[i] = yout[i] != 0.f ? dy[i] * inv_keep : 0.f;
+}
+
+// Backward prologue of y = dropout(act(x W^T + b)): dpre = f(dy) written as the bf16 GEMM operand
+// (row stride ldp, pad columns zeroed) and, fused, the bias gradient db += colsum(dpre).
+//   MODE 0: dpre = dy ; 1: ReLU + dropout from the OUTPUT y (y != 0 ? dy/(1-p) : 0) ;
+//   2: dropout mask regenerated from (seed, element index)
+// 256 threads = 4 waves; a wave owns every 4th row of the block's row slab, a lane 4 columns.
+template <int MODE>
+__global__ __launch_bounds__(256) void dpre_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                   uint16_t* __restrict__ dph, long ldp, float* __restrict__ dpre,
+                                                   float* __restrict__ dbias, int M, int N, int rows_per_block,
+                                                   float p, float inv_keep, uint64_t seed) {
+  __shared__ float red[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < N) {
+    for (int r = r0 + wave; r < r1; r += 4) {
+      const long o = (long)r * N + c;
+      float4 d = *reinterpret_cast<const float4*>(dy + o);
+      if (MODE == 1) {
+        const float4 yv = *reinterpret_cast<const float4*>(y + o);
+        d.x = yv.x != 0.f ? d.x * inv_keep : 0.f; d.y = yv.y != 0.f ? d.y * inv_keep : 0.f;
+        d.z = yv.z != 0.f ? d.z * inv_keep : 0.f; d.w = yv.w != 0.f ? d.w * inv_keep : 0.f;
+      } else if (MODE == 2) {
+        d.x *= drop_scale(seed, (uint64_t)o, p, inv_keep); d.y *= drop_scale(seed, (uint64_t)o + 1, p, inv_keep);
+        d.z *= drop_scale(seed, (uint64_t)o + 2, p, inv_keep); d.w *= drop_scale(seed, (uint64_t)o + 3, p, inv_keep);
+      }
+      *reinterpret_cast<uint2*>(dph + (long)r * ldp + c) = pack_bf16x4(d.x, d.y, d.z, d.w);
+      if (dpre) *reinterpret_cast<float4*>(dpre + o) = d;
+      a0 += d.x; a1 += d.y; a2 += d.z; a3 += d.w;
+    }
+  } else if (c < ldp) {
+    for (int r = r0 + wave; r < r1; r += 4) *reinterpret_cast<uint2*>(dph + (long)r * ldp + c) = make_uint2(0, 0);
+  }
+  if (!dbias) return;
+  red[wave][lane * 4 + 0] = a0; red[wave][lane * 4 + 1] = a1;
+  red[wave][lane * 4 + 2] = a2; red[wave][lane * 4 + 3] = a3;
+  __syncthreads();
+  const int cc = blockIdx.x * 256 + threadIdx.x;
+  if (cc < N)
+    atomicAdd(dbias + cc, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 __global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ x,
@@ -316,6 +381,15 @@ int s2st_copy_rows(const float* x, Split xsp, float* y, Split ysp, int rows, int
   return LAUNCH_OK();
 }
 
+int s2st_cast_bf16_rows(const float* x, long ldx, uint16_t* y, long ldy, long rows, int cols, hipStream_t st) {
+  if (rows <= 0 || cols <= 0) return 0;
+  if (ldy % 4 != 0 || ldy < cols) return S2ST_ERR_SHAPE;
+  const int vec = ((uintptr_t)x % 16 == 0) && (ldx % 4 == 0);
+  long n = rows * (ldy >> 2);
+  hipLaunchKernelGGL(cast_bf16_rows_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, ldx, y, ldy, rows, cols, vec);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+
 int s2st_glu_fwd(const float* a, float* y, Split ysp, int rows, int C, hipStream_t st) {
   long n = (long)rows * C;
   if (n <= 0) return 0;
@@ -378,6 +452,24 @@ int s2st_relu_drop_bwd(const float* dy, const float* y, float* dz, long n, float
   if (n <= 0) return 0;
   hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, dy, y, dz, n,
                      p > 0.f ? 1.f / (1.f - p) : 1.f);
+  return LAUNCH_OK();
+}
+
+int s2st_linear_bwd_prep(const float* dy, const float* y, int mode, float p, uint64_t seed, uint16_t* dph,
+                         long ldp, float* dpre, float* dbias, int M, int N, hipStream_t st) {
+  if (M <= 0 || N <= 0) return 0;
+  if (N % 4 != 0 || ldp % 4 != 0 || ldp < N || ((uintptr_t)dy % 16) || (mode == 1 && ((uintptr_t)y % 16)))
+    return S2ST_ERR_SHAPE;
+  const int cb = (int)((ldp + 255) / 256);
+  int slabs = (1024 + cb - 1) / cb;
+  int rpb = (M + slabs - 1) / slabs;
+  if (rpb < 16) rpb = 16;
+  slabs = (M + rpb - 1) / rpb;
+  const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  dim3 grid(cb, slabs);
+  if (mode == 0) hipLaunchKernelGGL(dpre_kernel<0>, grid, dim3(256), 0, st, dy, y, dph, ldp, dpre, dbias, M, N, rpb, p, ik, seed);
+  else if (mode == 1) hipLaunchKernelGGL(dpre_kernel<1>, grid, dim3(256), 0, st, dy, y, dph, ldp, dpre, dbias, M, N, rpb, p, ik, seed);
+  else hipLaunchKernelGGL(dpre_kernel<2>, grid, dim3(256), 0, st, dy, y, dph, ldp, dpre, dbias, M, N, rpb, p, ik, seed);
   return LAUNCH_OK();
 }
 

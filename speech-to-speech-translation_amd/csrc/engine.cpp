@@ -15,6 +15,7 @@
 // computed exactly as the reference computes them.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <string>
@@ -35,9 +36,15 @@ struct PInfo {
 struct Ten {  // plain [rows][cols] fp32 activation
   float* d = nullptr;
   float* g = nullptr;
+  // fast (bf16-operand) mode: bf16 copies of d / g with row stride hld(), made by the producer
+  // kernel when it can, else by a cast kernel at the first GEMM that reads them
+  bf16raw* h = nullptr;
+  bf16raw* gh = nullptr;
   int rows = 0, cols = 0;
   bool needs_grad = true;
+  bool want_gh = false;  // the gradient is consumed as a GEMM operand: its producer writes gh too
   long n() const { return (long)rows * cols; }
+  int hld() const { return (cols + 7) & ~7; }
 };
 
 struct LinP { long w, b; int N, K; };           // offsets into the param arena (b < 0: no bias)
@@ -64,6 +71,11 @@ struct s2st_engine {
   std::vector<PInfo> infos;
   long n_params = 0, n_buffers = 0;
   float *P = nullptr, *G = nullptr, *BUF = nullptr;
+  float* skws = nullptr;  // split-K partial-sum scratch of the weight-gradient GEMMs (per call)
+  long skws_n = 0;
+  bf16raw* PH = nullptr;  // bf16 copy of the parameter arena (same offsets), refreshed every forward
+  bool f32_operands = false;  // debug A/B switch S2ST_F32_OPERANDS=1: bf16 MFMA on fp32-stored operands
+  bool fast() const { return c.precise == 0 && !f32_operands; }
 
   // parameter handles
   ConvP sub[2];
@@ -107,7 +119,7 @@ struct s2st_engine {
     for (int s : shape) p.numel *= s;
     long& top = is_buffer ? n_buffers : n_params;
     p.off = top;
-    top += (p.numel + 3) / 4 * 4;  // keep every tensor 16-byte aligned in the arena
+    top += (p.numel + 7) / 8 * 8;  // every tensor 32-byte aligned (16 bytes in the bf16 copy)
     p.is_buffer = is_buffer;
     infos.push_back(p);
     return p.off;
@@ -264,7 +276,28 @@ struct s2st_engine {
     acc = false;
     return t->g;
   }
+  bf16raw* alloc_h(long n) { return reinterpret_cast<bf16raw*>(alloc((n + 1) / 2)); }
   bool live() const { return !dry && !oom && err == 0; }
+  // bf16 copy of an activation / of its gradient (cast on first use unless the producer made it)
+  bf16raw* half_of(Ten* t) {
+    if (!t->h) {
+      t->h = alloc_h((long)t->rows * t->hld());
+      if (live()) chk(s2st_cast_bf16_rows(t->d, t->cols, t->h, t->hld(), t->rows, t->cols, st_));
+    }
+    return t->h;
+  }
+  bf16raw* ghalf_of(Ten* t) {
+    if (!t->gh) {
+      t->gh = alloc_h((long)t->rows * t->hld());
+      if (live()) chk(s2st_cast_bf16_rows(t->g, t->cols, t->gh, t->hld(), t->rows, t->cols, st_));
+    }
+    return t->gh;
+  }
+  bf16raw* cast_buf(const float* x, long n) {  // whole-buffer twin (halo images, conv weights)
+    bf16raw* y = alloc_h((n + 7) / 8 * 8);
+    if (live()) chk(s2st_cast_bf16_rows(x, n, y, (n + 7) / 8 * 8, 1, (int)n, st_));
+    return y;
+  }
   void chk(int rc) { if (rc && !err) err = rc; }
   uint64_t next_seed() { return seed * 0x100000001B3ULL + (++site) * 0x9E3779B97F4A7C15ULL; }
   void mark() { marks.push_back(Mark{tape.size(), param_watermark}); }
@@ -279,11 +312,15 @@ struct s2st_engine {
     touch(w + (long)N * K);
     if (b >= 0) touch(b + N);
     const uint64_t sd = drop_p > 0.f ? next_seed() : 0;
+    const bool fm = fast();
+    const bf16raw* xh = fm ? half_of(x) : nullptr;
+    if (fm && N % 8 == 0) y->h = alloc_h(y->n());
     if (live()) {
       GemmArgs g{};
-      g.A = gemm_rowmajor(x->d, x->cols);
-      g.B = gemm_rowmajor(P + w, K);
+      g.A = fm ? gemm_rowmajor(xh, x->hld()) : gemm_rowmajor(x->d, x->cols);
+      g.B = fm ? gemm_rowmajor(PH + w, K) : gemm_rowmajor(P + w, K);
       g.C = gemm_out(y->d, N);
+      g.C.h = y->h;
       g.ep = gemm_epi_default();
       g.ep.bias = b >= 0 ? P + b : nullptr;
       g.ep.act = act;
@@ -301,34 +338,56 @@ struct s2st_engine {
         else if (live()) chk(s2st_axpy(dy, resid->g, y->n(), 1.f, st_));
       }
       float* dpre = dy;
-      if (act == 1) {
-        dpre = alloc(y->n());
-        if (live()) chk(s2st_relu_drop_bwd(dy, y->d, dpre, y->n(), drop_p, st_));
-      } else if (drop_p > 0.f) {
-        dpre = alloc(y->n());
-        if (live()) chk(s2st_dropout(dy, dpre, y->n(), 1.f, drop_p, sd, 0, st_));
+      const int ldp = (N + 7) & ~7;
+      const bf16raw* dph = nullptr;
+      bool bias_done = false;
+      if (fm && N % 4 == 0) {
+        // one pass: bf16 GEMM operand of f(dy) + bias gradient (no fp32 dpre is materialised)
+        bf16raw* t = alloc_h((long)M * ldp);
+        const int mode = act == 1 ? 1 : (drop_p > 0.f ? 2 : 0);
+        if (live())
+          chk(s2st_linear_bwd_prep(dy, y->d, mode, drop_p, sd, t, ldp, nullptr, b >= 0 ? G + b : nullptr, M, N, st_));
+        dph = t;
+        bias_done = true;
+      } else {
+        if (act == 1) {
+          dpre = alloc(y->n());
+          if (live()) chk(s2st_relu_drop_bwd(dy, y->d, dpre, y->n(), drop_p, st_));
+        } else if (drop_p > 0.f) {
+          dpre = alloc(y->n());
+          if (live()) chk(s2st_dropout(dy, dpre, y->n(), 1.f, drop_p, sd, 0, st_));
+        }
+        if (fm) {
+          bf16raw* t = alloc_h((long)M * ldp);
+          if (live()) chk(s2st_cast_bf16_rows(dpre, N, t, ldp, M, N, st_));
+          dph = t;
+        }
       }
       if (live()) {
         GemmArgs g{};  // dW[N][K] += dpre^T x
-        g.A = gemm_colmajor(dpre, N);
-        g.B = gemm_colmajor(x->d, x->cols);
+        g.A = fm ? gemm_colmajor(dph, ldp) : gemm_colmajor(dpre, N);
+        g.B = fm ? gemm_colmajor(xh, x->hld()) : gemm_colmajor(x->d, x->cols);
         g.C = gemm_out(G + w, K);
         g.ep = gemm_epi_default();
         g.ep.accumulate = 1;
+        g.ws = skws; g.ws_floats = skws_n;
         g.M = N; g.N = K; g.K = M; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
         chk(s2st_gemm(g, st_));
-        if (b >= 0) chk(s2st_colsum(dpre, N, M, N, G + b, 1, st_));
+        if (b >= 0 && !bias_done) chk(s2st_colsum(dpre, N, M, N, G + b, 1, st_));
       }
       if (x->needs_grad) {
         bool acc;
         float* dx = gradbuf(x, acc);
+        if (fm && !acc && x->want_gh && x->hld() == x->cols) x->gh = alloc_h(x->n());
         if (live()) {
           GemmArgs g{};  // dx[M][K] (+)= dpre W
-          g.A = gemm_rowmajor(dpre, N);
-          g.B = gemm_colmajor(P + w, K);
+          g.A = fm ? gemm_rowmajor(dph, ldp) : gemm_rowmajor(dpre, N);
+          g.B = fm ? gemm_colmajor(PH + w, K) : gemm_colmajor(P + w, K);
           g.C = gemm_out(dx, x->cols);
+          if (fm && !acc) g.C.h = x->gh;  // the consumer (attention backward) reads dO as a GEMM operand
           g.ep = gemm_epi_default();
           g.ep.accumulate = acc ? 1 : 0;
+          g.ws = skws; g.ws_floats = skws_n;
           g.M = M; g.N = K; g.K = N; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
           chk(s2st_gemm(g, st_));
         }
@@ -342,7 +401,9 @@ struct s2st_engine {
     float* mean = alloc(x->rows);
     float* rstd = alloc(x->rows);
     touch(p.b + p.C);
-    if (live()) chk(s2st_layernorm_fwd(x->d, P + p.g, P + p.b, y->d, mean, rstd, x->rows, x->cols, 1e-5f, st_));
+    if (fast() && x->cols % 8 == 0) y->h = alloc_h(y->n());
+    if (live())
+      chk(s2st_layernorm_fwd(x->d, P + p.g, P + p.b, y->d, mean, rstd, x->rows, x->cols, 1e-5f, st_, y->h));
     LNP pp = p;
     tape.push_back([=]() {
       if (!y->g) return;
@@ -365,37 +426,55 @@ struct s2st_engine {
   Ten* attention(const AttnIO& io, int B, int T, int S, int H, int dh, const int* klen, int causal,
                  float drop_p, float* attn_mean_out /* [B][S][T] or null */) {
     const int C = H * dh;
-    const int ld = (S + 3) / 4 * 4;
+    const int ld = (S + 7) / 8 * 8;
+    const bool fm = fast();
     Ten* o = newT(B * T, C);
+    o->want_gh = true;
+    if (fm && C % 8 == 0) o->h = alloc_h(o->n());
     float* p = alloc((long)B * H * T * ld);
     float* pd = drop_p > 0.f ? alloc((long)B * H * T * ld) : p;
+    bf16raw* pdh = fm ? alloc_h((long)B * H * T * ld) : nullptr;  // bf16 dropout(p): the P*V / dV operand
     const uint64_t sd = drop_p > 0.f ? next_seed() : 0;
     const float scaling = 1.0f / sqrtf((float)dh);
     const int prec = c.precise;
-    auto bgemm = [=](const float* A, int akm, long ald, long azo, const float* Bp, int bkm, long bld,
-                     long bzo, float* Cp, long cld, long czo, long czi, long azi, long bzi, int M, int N,
-                     int K, float alpha) {
+    // operand views: (fp32 base, bf16 base) + element offset; strides are the same in both
+    struct View { const float* f; const bf16raw* h; };
+    auto bgemm = [=](View A, int akm, long ald, long azo, View Bv, int bkm, long bld, long bzo, float* Cp,
+                     long cld, long czo, long czi, long azi, long bzi, int M, int N, int K, float alpha,
+                     bf16raw* Ch = nullptr) {
       GemmArgs g{};
-      g.A = akm ? gemm_rowmajor(A, ald) : gemm_colmajor(A, ald);
+      if (fm) {
+        g.A = akm ? gemm_rowmajor(A.h, ald) : gemm_colmajor(A.h, ald);
+        g.B = bkm ? gemm_rowmajor(Bv.h, bld) : gemm_colmajor(Bv.h, bld);
+      } else {
+        g.A = akm ? gemm_rowmajor(A.f, ald) : gemm_colmajor(A.f, ald);
+        g.B = bkm ? gemm_rowmajor(Bv.f, bld) : gemm_colmajor(Bv.f, bld);
+      }
       g.A.zo = azo; g.A.zi = azi;
-      g.B = bkm ? gemm_rowmajor(Bp, bld) : gemm_colmajor(Bp, bld);
       g.B.zo = bzo; g.B.zi = bzi;
       g.C = gemm_out(Cp, cld);
       g.C.zo = czo; g.C.zi = czi;
+      g.C.h = Ch;
       g.ep = gemm_epi_default();
       g.ep.alpha = alpha;
       g.M = M; g.N = N; g.K = K; g.batch = B * H; g.zdiv = H; g.precise = prec;
       chk(s2st_gemm(g, st_));
     };
     const long pzo = (long)H * T * ld, pzi = (long)T * ld;
+    // q / k / v column blocks of their holders (row stride == hld: every projection width is % 8)
+    const bf16raw *qh = nullptr, *kh = nullptr, *vh = nullptr;
+    if (fm) { qh = half_of(io.qt); kh = half_of(io.kt); vh = half_of(io.vt); }
+    const View Vq{io.qt->d + io.qoff, fm ? qh + io.qoff : nullptr};
+    const View Vk{io.kt->d + io.koff, fm ? kh + io.koff : nullptr};
+    const View Vv{io.vt->d + io.voff, fm ? vh + io.voff : nullptr};
     if (live()) {
       // scores = (q * dh^-0.5) k^T      (multihead_attention.py:224, 332)
-      bgemm(io.qt->d + io.qoff, 1, io.ldq, (long)T * io.ldq, io.kt->d + io.koff, 1, io.ldk,
-            (long)S * io.ldk, p, ld, pzo, pzi, dh, dh, T, S, dh, scaling);
-      chk(s2st_softmax_fwd(p, p, drop_p > 0.f ? pd : nullptr, klen, B, H, T, S, ld, causal, drop_p, sd, st_));
+      bgemm(Vq, 1, io.ldq, (long)T * io.ldq, Vk, 1, io.ldk, (long)S * io.ldk, p, ld, pzo, pzi, dh, dh, T, S, dh,
+            scaling);
+      chk(s2st_softmax_fwd(p, p, drop_p > 0.f ? pd : nullptr, klen, B, H, T, S, ld, causal, drop_p, sd, st_, pdh));
       // o = dropout(p) v                 (:367)
-      bgemm(pd, 1, ld, pzo, io.vt->d + io.voff, 0, io.ldv, (long)S * io.ldv, o->d, C, (long)T * C, dh,
-            pzi, dh, T, dh, S, 1.f);
+      bgemm(View{pd, pdh}, 1, ld, pzo, Vv, 0, io.ldv, (long)S * io.ldv, o->d, C, (long)T * C, dh, pzi, dh, T, dh,
+            S, 1.f, o->h);
       if (attn_mean_out) chk(s2st_attn_headmean(p, attn_mean_out, B, H, T, S, ld, st_));
     }
     AttnIO io2 = io;
@@ -408,18 +487,20 @@ struct s2st_engine {
       float* gv = gradbuf(io2.vt, av);
       (void)aq; (void)ak; (void)av;  // column blocks are disjoint and written exactly once
       float* dp = alloc((long)B * H * T * ld);
+      bf16raw* dsh = fm ? alloc_h((long)B * H * T * ld) : nullptr;
+      const bf16raw* doh = fm ? ghalf_of(o) : nullptr;
       if (!live()) return;
+      const View Vdo{o->g, doh};
       // dPd = dO V^T
-      bgemm(o->g, 1, C, (long)T * C, io2.vt->d + io2.voff, 1, io2.ldv, (long)S * io2.ldv, dp, ld, pzo,
-            pzi, dh, dh, T, S, dh, 1.f);
+      bgemm(Vdo, 1, C, (long)T * C, Vv, 1, io2.ldv, (long)S * io2.ldv, dp, ld, pzo, pzi, dh, dh, T, S, dh, 1.f);
       // dV = Pd^T dO
-      bgemm(pd, 0, ld, pzo, o->g, 0, C, (long)T * C, gv + io2.voff, io2.ldv, (long)S * io2.ldv, dh, pzi,
+      bgemm(View{pd, pdh}, 0, ld, pzo, Vdo, 0, C, (long)T * C, gv + io2.voff, io2.ldv, (long)S * io2.ldv, dh, pzi,
             dh, S, dh, T, 1.f);
-      chk(s2st_softmax_bwd(p, dp, dp, B, H, T, S, ld, drop_p, sd, st_));
+      chk(s2st_softmax_bwd(p, dp, dp, B, H, T, S, ld, drop_p, sd, st_, dsh));
       // dQ = scaling * dS K ; dK = scaling * dS^T Q
-      bgemm(dp, 1, ld, pzo, io2.kt->d + io2.koff, 0, io2.ldk, (long)S * io2.ldk, gq + io2.qoff, io2.ldq,
+      bgemm(View{dp, dsh}, 1, ld, pzo, Vk, 0, io2.ldk, (long)S * io2.ldk, gq + io2.qoff, io2.ldq,
             (long)T * io2.ldq, dh, pzi, dh, T, dh, S, scaling);
-      bgemm(dp, 0, ld, pzo, io2.qt->d + io2.qoff, 0, io2.ldq, (long)T * io2.ldq, gk + io2.koff, io2.ldk,
+      bgemm(View{dp, dsh}, 0, ld, pzo, Vq, 0, io2.ldq, (long)T * io2.ldq, gk + io2.koff, io2.ldk,
             (long)S * io2.ldk, dh, pzi, dh, S, dh, T, scaling);
     });
     return o;
@@ -470,8 +551,12 @@ struct s2st_engine {
   // conv over a halo-padded input.  xh: [B][Tin + 2*pad][I] (zeros in the halo); returns z [B*Tout][O].
   // The backward needs dz both plain (weight gradient / bias) and as a halo-padded, for
   // stride 2 zero-stuffed, image (data gradient as a stride-1 correlation with flipped taps).
-  struct ConvIn { float* xh; Ten* src; int Tin; };  // src: plain tensor whose grad we produce (or null)
-  Ten* conv(const ConvIn& in, const ConvP& p, int B, int stride, float* wf, float* wd, float* dwf) {
+  struct ConvIn { float* xh; Ten* src; int Tin; const bf16raw* xhh; };  // src: plain tensor whose grad we produce (or null); xhh: bf16 twin of xh
+  struct ConvW { float *wf, *wd, *dwf; const bf16raw *wfh, *wdh; };
+  Ten* conv(const ConvIn& in, const ConvP& p, int B, int stride, const ConvW& cw) {
+    float *wf = cw.wf, *wd = cw.wd, *dwf = cw.dwf;
+    const bf16raw *wfh = cw.wfh, *wdh = cw.wdh;
+    const bool fm = fast();
     const int pad = p.Kw / 2;
     const int Tin = in.Tin, Tout = (Tin + 2 * pad - p.Kw) / stride + 1;
     const int Th = Tin + 2 * pad;
@@ -480,9 +565,9 @@ struct s2st_engine {
     touch(p.b + p.O);
     if (live()) {
       GemmArgs g{};
-      g.A = gemm_rowmajor(in.xh, (long)stride * p.I);
+      g.A = fm ? gemm_rowmajor(in.xhh, (long)stride * p.I) : gemm_rowmajor(in.xh, (long)stride * p.I);
       g.A.sp.per = Tout; g.A.sp.bs = (long)Th * p.I;
-      g.B = gemm_rowmajor(wf, (long)p.Kw * p.I);
+      g.B = fm ? gemm_rowmajor(wfh, (long)p.Kw * p.I) : gemm_rowmajor(wf, (long)p.Kw * p.I);
       g.C = gemm_out(z->d, p.O);
       g.ep = gemm_epi_default();
       g.ep.bias = P + p.b;
@@ -494,14 +579,16 @@ struct s2st_engine {
     tape.push_back([=]() {
       if (!z->g) return;
       const int M = B * Tout;
+      const bf16raw* dzh = fm ? ghalf_of(z) : nullptr;
       if (live()) {
         GemmArgs g{};  // dWf[O][(j,c)] += sum_(b,t) dz[(b,t)][o] * xh[b][t*stride + j][c]
-        g.A = gemm_colmajor(z->g, pp.O);
-        g.B = gemm_colmajor(in2.xh, (long)stride * pp.I);
+        g.A = fm ? gemm_colmajor(dzh, z->hld()) : gemm_colmajor(z->g, pp.O);
+        g.B = fm ? gemm_colmajor(in2.xhh, (long)stride * pp.I) : gemm_colmajor(in2.xh, (long)stride * pp.I);
         g.B.sp.per = Tout; g.B.sp.bs = (long)Th * pp.I;
         g.C = gemm_out(dwf, (long)pp.Kw * pp.I);
         g.ep = gemm_epi_default();
         g.ep.accumulate = 1;
+        g.ws = skws; g.ws_floats = skws_n;
         g.M = pp.O; g.N = pp.Kw * pp.I; g.K = M; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
         chk(s2st_gemm(g, st_));
         chk(s2st_colsum(z->g, pp.O, M, pp.O, G + pp.b, 1, st_));
@@ -516,10 +603,13 @@ struct s2st_engine {
           Split xs{(long)pp.O, 0, 0, 0};
           Split ys{(long)stride * pp.O, (long)Th * pp.O, Tout, 0};
           chk(s2st_copy_rows(z->g, xs, up + (long)pad * pp.O, ys, M, pp.O, st_));
+        }
+        const bf16raw* uph = fm ? cast_buf(up, (long)B * Th * pp.O) : nullptr;
+        if (live()) {
           GemmArgs g{};  // dx[(b,u)][c] = sum_(j',o) up[b][u + j'][o] * Wd[c][j'][o]
-          g.A = gemm_rowmajor(up, pp.O);
+          g.A = fm ? gemm_rowmajor(uph, pp.O) : gemm_rowmajor(up, pp.O);
           g.A.sp.per = Tin; g.A.sp.bs = (long)Th * pp.O;
-          g.B = gemm_rowmajor(wd, (long)pp.Kw * pp.O);
+          g.B = fm ? gemm_rowmajor(wdh, (long)pp.Kw * pp.O) : gemm_rowmajor(wd, (long)pp.Kw * pp.O);
           g.C = gemm_out(dx, pp.I);
           g.ep = gemm_epi_default();
           g.ep.accumulate = acc ? 1 : 0;
@@ -619,7 +709,13 @@ struct s2st_engine {
     // sinusoidal tables come from the host side (cached per dim); conv weight layouts are
     // scratch at the bottom of the workspace
     const float *pe_enc = bt.pe_enc, *pe_dec = bt.pe_dec, *pe_asr = bt.pe_asr, *pe_st = bt.pe_st;
-    struct ConvScratch { float *wf, *wd, *dwf; };
+    const bool fm = fast();
+    if (fm && !PH && !dry) return S2ST_ERR_ARG;
+    // bf16 copy of the whole parameter arena (292 MB read + 146 MB written: ~0.08 ms)
+    if (fm && live()) chk(s2st_cast_bf16_rows(P, n_params, PH, n_params, 1, (int)n_params, st_));
+    skws_n = fm ? (long)16 << 20 : 0;
+    skws = fm ? alloc(skws_n) : nullptr;
+    typedef ConvW ConvScratch;
     auto conv_scratch = [&](const ConvP& p, bool need_wd) {
       ConvScratch s;
       long n = (long)p.O * p.I * p.Kw;
@@ -627,6 +723,8 @@ struct s2st_engine {
       s.wd = need_wd ? alloc(n) : nullptr;
       s.dwf = alloc(n, tr);
       if (live()) chk(s2st_conv_w_permute(P + p.w, s.wf, s.wd, p.O, p.I, p.Kw, st_));
+      s.wfh = fm ? cast_buf(s.wf, n) : nullptr;
+      s.wdh = fm && need_wd ? cast_buf(s.wd, n) : nullptr;
       return s;
     };
     ConvScratch cs0 = conv_scratch(sub[0], false), cs1 = conv_scratch(sub[1], true);
@@ -641,11 +739,13 @@ struct s2st_engine {
       Split ys{(long)c.in_dim, (long)(S + 2 * pad) * c.in_dim, S, 0};
       chk(s2st_copy_rows(bt.src, xs, xh0 + (long)pad * c.in_dim, ys, B * S, c.in_dim, st_));
     }
-    Ten* z1 = conv(ConvIn{xh0, nullptr, S}, sub[0], B, 2, cs0.wf, cs0.wd, cs0.dwf);
+    const bf16raw* xh0h = fm ? cast_buf(xh0, (long)B * (S + 2 * pad) * c.in_dim) : nullptr;
+    Ten* z1 = conv(ConvIn{xh0, nullptr, S, xh0h}, sub[0], B, 2, cs0);
     const int C1 = c.conv_channels / 2;
     float* g1h = alloc((long)B * (T1 + 2 * pad) * C1, true);
     Ten* g1 = glu_to(z1, g1h + (long)pad * C1, Split{(long)C1, (long)(T1 + 2 * pad) * C1, T1, 0}, C1);
-    Ten* z2 = conv(ConvIn{g1h, g1, T1}, sub[1], B, 2, cs1.wf, cs1.wd, cs1.dwf);
+    const bf16raw* g1hh = fm ? cast_buf(g1h, (long)B * (T1 + 2 * pad) * C1) : nullptr;
+    Ten* z2 = conv(ConvIn{g1h, g1, T1, g1hh}, sub[1], B, 2, cs1);
     float* x0d = alloc((long)B * E * C);
     Ten* x0 = glu_to(z2, x0d, Split{(long)C, 0, 0, 0}, C);
     Ten* x = add_pe(x0, bt.enc_pos, pe_enc, c.no_scale_embedding ? 1.f : sqrtf((float)C), -1,
@@ -697,7 +797,8 @@ struct s2st_engine {
       const ConvP& pc = post_conv[i];
       const BNP& bn = post_bn[i];
       const bool last = i == c.postnet_layers - 1;
-      Ten* z = conv(ConvIn{curh, cur, D}, pc, B, 1, csp[i].wf, csp[i].wd, csp[i].dwf);
+      const bf16raw* curhh = fm ? cast_buf(curh, (long)B * (D + 2 * pp) * pc.I) : nullptr;
+      Ten* z = conv(ConvIn{curh, cur, D, curhh}, pc, B, 1, csp[i]);
       float* mean = alloc(bn.C);
       float* var = alloc(bn.C);
       touch(bn.b + bn.C);
@@ -845,8 +946,15 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   if (cfg->enc_dim % cfg->enc_heads || cfg->dec_dim % cfg->dec_heads || cfg->enc_dim % 4 ||
       cfg->dec_dim % 4 || cfg->in_dim % 4 || cfg->out_dim % 4 || cfg->conv_channels % 8)
     return S2ST_ERR_SHAPE;
+  // bf16-operand mode reads 16-byte chunks of 8 elements: every projection width must be % 8
+  if (!cfg->precise && (cfg->enc_dim % 8 || cfg->dec_dim % 8 || cfg->in_dim % 8 || cfg->out_dim % 8 ||
+                        cfg->prenet_dim % 8 || cfg->postnet_dim % 8 || cfg->enc_ffn % 8 || cfg->dec_ffn % 8 ||
+                        cfg->conv_channels % 16 || (cfg->has_asr && cfg->asr_dim % 8) ||
+                        (cfg->has_st && cfg->st_dim % 8)))
+    return S2ST_ERR_SHAPE;
   s2st_engine* e = new s2st_engine();
   e->c = *cfg;
+  e->f32_operands = getenv("S2ST_F32_OPERANDS") && atoi(getenv("S2ST_F32_OPERANDS")) != 0;
   e->build_params();
   *out = e;
   return 0;
@@ -880,6 +988,11 @@ int s2st_engine_bind(s2st_engine* e, float* params, float* grads, float* buffers
   e->P = params;
   e->G = grads;
   e->BUF = buffers;
+  return 0;
+}
+
+int s2st_engine_bind_bf16(s2st_engine* e, uint16_t* params_bf16) {
+  e->PH = params_bf16;
   return 0;
 }
 

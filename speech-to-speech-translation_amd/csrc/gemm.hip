@@ -14,6 +14,8 @@
 // v_mfma_f32_16x16x32_bf16; global loads of tile t+1 are in flight during the MFMAs of
 // tile t (one barrier per K-step).  Epilogue fuses alpha, bias, ReLU, dropout, residual,
 // accumulate / split-K atomics.
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "s2st_ops.h"
@@ -151,8 +153,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int zb = blockIdx.z / g.splitk, ks = blockIdx.z - zb * g.splitk;
   const int zq = zb / g.zdiv, zr = zb - zq * g.zdiv;
-  const float* abase = g.A.p + zq * g.A.zo + zr * g.A.zi;
-  const float* bbase = g.B.p + zq * g.B.zo + zr * g.B.zi;
+  const float* abase = reinterpret_cast<const float*>(g.A.p) + zq * g.A.zo + zr * g.A.zi;
+  const float* bbase = reinterpret_cast<const float*>(g.B.p) + zq * g.B.zo + zr * g.B.zi;
   const int kbeg = ks * g.kchunk;
   const int kend = min(g.K, kbeg + g.kchunk);
   const int nt = (kend - kbeg + BK - 1) / BK;
@@ -274,7 +276,7 @@ bool vec_ok(const GemmOperand& o, int R, int K) {
 
 // ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream ----
 namespace {
-struct ProfRec { hipEvent_t a, b; double flops; };
+struct ProfRec { hipEvent_t a, b; double flops; int M, N, K, batch, akm, bkm, acc, bm, splitk; };
 std::vector<ProfRec> g_prof;
 bool g_prof_on = false;
 }  // namespace
@@ -283,15 +285,22 @@ void s2st_gemm_profile_enable(int on) { g_prof_on = on != 0; }
 
 int s2st_gemm_profile_read(double* flops, double* ms, long* launches) {
   double f = 0, t = 0;
+  // tuning aid: S2ST_GEMM_PROFILE_DUMP=<path> appends one line per launch (shape, layout, tile, us)
+  const char* dump = getenv("S2ST_GEMM_PROFILE_DUMP");
+  FILE* df = dump ? fopen(dump, "a") : nullptr;
   for (auto& r : g_prof) {
     hipEventSynchronize(r.b);
     float e = 0.f;
     hipEventElapsedTime(&e, r.a, r.b);
     t += e;
     f += r.flops;
+    if (df)
+      fprintf(df, "%d,%d,%d,%d,%c%c,%d,%d,%d,%.2f\n", r.M, r.N, r.K, r.batch, r.akm ? 'K' : 'R',
+              r.bkm ? 'K' : 'R', r.acc, r.bm, r.splitk, e * 1e3);
     hipEventDestroy(r.a);
     hipEventDestroy(r.b);
   }
+  if (df) fclose(df);
   *flops = f;
   *ms = t;
   *launches = (long)g_prof.size();
@@ -301,6 +310,10 @@ int s2st_gemm_profile_read(double* flops, double* ms, long* launches) {
 
 int s2st_gemm(GemmArgs g, hipStream_t st) {
   if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return 0;
+  if (g.A.dtype != g.B.dtype) return S2ST_ERR_ARG;
+  const bool bf16_in = g.A.dtype == S2ST_BF16;
+  if (bf16_in && g.precise) return S2ST_ERR_ARG;       // bf16x3 needs the fp32 values
+  if (!bf16_in && (g.C.h || !g.C.p)) return S2ST_ERR_ARG;  // bf16 copy: fast path only
   ProfRec rec{};
   if (g_prof_on) {
     hipEventCreate(&rec.a);
@@ -309,6 +322,17 @@ int s2st_gemm(GemmArgs g, hipStream_t st) {
     hipEventRecord(rec.a, st);
   }
   if (g.zdiv <= 0) g.zdiv = 1;
+  if (bf16_in) {
+    int tile = 0;
+    int rc = s2st_gemm_bf16(g, st, &tile);
+    if (g_prof_on) {
+      rec.M = g.M; rec.N = g.N; rec.K = g.K; rec.batch = g.batch; rec.akm = g.A.kmajor; rec.bkm = g.B.kmajor;
+      rec.acc = g.ep.accumulate; rec.bm = tile; rec.splitk = 0;
+      hipEventRecord(rec.b, st);
+      g_prof.push_back(rec);
+    }
+    return rc;
+  }
   g.avec = vec_ok(g.A, g.M, g.K) ? 1 : 0;
   g.bvec = vec_ok(g.B, g.N, g.K) ? 1 : 0;
   const bool vec = g.avec && g.bvec;
@@ -345,6 +369,8 @@ int s2st_gemm(GemmArgs g, hipStream_t st) {
     else launch_layouts<64, 64, false, false>(g, grid, st);
   }
   if (g_prof_on) {
+    rec.M = g.M; rec.N = g.N; rec.K = g.K; rec.batch = g.batch; rec.akm = g.A.kmajor; rec.bkm = g.B.kmajor;
+    rec.acc = g.ep.accumulate; rec.bm = bm; rec.splitk = g.splitk;
     hipEventRecord(rec.b, st);
     g_prof.push_back(rec);
   }

@@ -1,0 +1,440 @@
+// bf16-operand GEMM for gfx950:  C(m,n) = epi(alpha * sum_k A(m,k) * B(n,k)),  A and B bf16 in HBM,
+// fp32 accumulation on v_mfma_f32_16x16x32_bf16, fp32 and/or bf16 result.
+//
+// This is the fast path of s2st_gemm (gemm.hip keeps the fp32-operand kernel used by the bf16x3
+// "precise" mode): the training engine stores a bf16 copy of every tensor that is a GEMM operand
+// (weights, layer-norm outputs, attention probabilities, activation gradients), so the values the
+// matrix cores see are bit-identical to what the fp32 path produces by converting on the fly --
+// at half the HBM/L2 bytes and with no conversion VALU in the loop.
+//
+// Structure: 256 threads = 4 waves (2 x 2), block tile BM x BN in {128x128, 128x64, 64x64},
+// BK = 64 (two MFMA k-steps per barrier).  Tiles are staged through registers (16-byte global
+// loads of tile t+1 are in flight during the MFMAs of tile t) into a double-buffered LDS image:
+//   K-contiguous operand   [row][64 k]    128-byte rows, 16-byte chunk c stored at slot c ^ (row & 7)
+//                                         -> ds_read_b128 fragment reads are bank-conflict free;
+//   rows-contiguous operand [k][ROWS]     natural layout (weight-gradient / P*V / data-gradient
+//                                         forms), 32-byte pair c stored at c ^ f(k) so that the 8 k
+//                                         rows a half-wave reads with ds_read_b64_tr_b16 hit
+//                                         distinct banks.
+// The MFMA is issued with the operands swapped (D = B_frag x A_frag = C^T tile) so that each lane
+// ends up with 4 consecutive n of one row m: the epilogue (alpha, bias, ReLU, dropout, residual,
+// accumulate) runs on float4 and stores 16 bytes (fp32) / 8 bytes (bf16 copy) per lane.
+// Workgroup ids are remapped so that the blocks that share an XCD (id % 8) own a contiguous run
+// of tiles (same A rows -> hits in that XCD's L2).
+#include <cstdio>
+#include <cstdlib>
+
+#include "s2st_ops.h"
+
+namespace {
+
+typedef unsigned short bf16_t;
+constexpr int BK = 64;
+
+template <int ROWS>
+__device__ __forceinline__ int kperm(int kr) {
+  // XOR key (in 32-byte pairs) of k row kr of a rows-contiguous image
+  if (ROWS >= 128) return (kr & 3) | (((kr >> 3) & 1) << 2);
+  return ((kr >> 1) & 1) | (((kr >> 3) & 1) << 1);
+}
+
+__device__ __forceinline__ uint4 mask_tail(uint4 v, int nvalid) {
+  // keep the first nvalid (0..8) bf16 elements of a 16-byte chunk, zero the rest
+  unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int e = nvalid - 2 * i;
+    w[i] = e >= 2 ? w[i] : (e == 1 ? (w[i] & 0xffffu) : 0u);
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <bool KM, int ROWS, bool VEC>
+struct Stage {
+  static constexpr int NCH = ROWS * 8 / 256;  // 16-byte chunks per thread per K step
+  static constexpr int RC = ROWS / 8;         // chunks per k row (rows-contiguous image)
+  static constexpr int PITCH = KM ? 128 : ROWS * 2;
+  static constexpr int BYTES = ROWS * 128;
+  uint4 r[NCH];
+  long off[NCH];  // KM: element offset of this chunk's row (clamped) ; !KM: clamped first row
+  int tid;
+
+  __device__ __forceinline__ void init(const GemmOperand& X, int r0, int R, int tid_) {
+    tid = tid_;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int f = tid + 256 * i;
+      if (KM) {
+        const int row = r0 + (f >> 3);
+        if (VEC) off[i] = split_off(X.sp, min(row, R - 1));
+        else off[i] = row < R ? split_off(X.sp, row) : -1;
+      } else {
+        const int rr = r0 + (f % RC) * 8;
+        // VEC: rows are readable up to the next multiple of 8 (launcher contract)
+        off[i] = VEC ? min(rr, ((R + 7) & ~7) - 8) : rr;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void load(const GemmOperand& X, const bf16_t* base, int R, int kt, int kend) {
+    const bool tail = kt + BK > kend;  // wave-uniform: only the last K step of a chunk
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int f = tid + 256 * i;
+      if (KM) {
+        const int k0 = kt + (f & 7) * 8;
+        if (VEC) {
+          if (!tail) {
+            r[i] = *reinterpret_cast<const uint4*>(base + off[i] + k0);
+          } else {
+            const int nv = kend - k0;  // valid elements of this chunk
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (nv > 0) v = *reinterpret_cast<const uint4*>(base + off[i] + k0);
+            r[i] = nv >= 8 ? v : mask_tail(v, nv > 0 ? nv : 0);
+          }
+        } else {
+          unsigned short e[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) e[j] = (off[i] >= 0 && k0 + j < kend) ? base[off[i] + k0 + j] : 0;
+          r[i] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+        }
+      } else {
+        const int k = kt + f / RC;
+        const bool ok = k < kend;
+        const long o = split_off(X.sp, min(k, kend - 1));
+        if (VEC) {
+          uint4 v = *reinterpret_cast<const uint4*>(base + o + off[i]);
+          r[i] = ok ? v : make_uint4(0, 0, 0, 0);
+        } else {
+          unsigned short e[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) e[j] = (ok && off[i] + j < R) ? base[o + off[i] + j] : 0;
+          r[i] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+        }
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(unsigned char* img) const {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int f = tid + 256 * i;
+      int o;
+      if (KM) {
+        const int row = f >> 3, ch = f & 7;
+        o = row * 128 + ((ch ^ (row & 7)) << 4);
+      } else {
+        const int kr = f / RC, ch = f % RC;
+        o = kr * PITCH + (((((ch >> 1) ^ kperm<ROWS>(kr)) << 1) | (ch & 1)) << 4);
+      }
+      *reinterpret_cast<uint4*>(img + o) = r[i];
+    }
+  }
+
+  // MFMA 16x16x32 operand fragment, tile rows [rt, rt+16) (rt % 16 == 0), k step s (0/1):
+  // lane l holds k = 32 s + 8 (l >> 4) + j
+  __device__ static __forceinline__ bf16x8 frag(const unsigned char* img, int rt, int s, int lane) {
+    if (KM) {
+      const int row = rt + (lane & 15), ch = 4 * s + (lane >> 4);
+      return *reinterpret_cast<const bf16x8*>(img + row * 128 + ((ch ^ (row & 7)) << 4));
+    } else {
+      const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+      const int kr = 32 * s + 8 * g + q;
+      const unsigned char* a = img + kr * PITCH + ((((rt >> 4) ^ kperm<ROWS>(kr))) << 5) + 8 * p;
+      s16x4 lo = lds_read_tr16(a);
+      s16x4 hi = lds_read_tr16(a + 4 * PITCH);  // k rows +4: same XOR key
+      bf16x8 fr;
+      fr[0] = lo[0]; fr[1] = lo[1]; fr[2] = lo[2]; fr[3] = lo[3];
+      fr[4] = hi[0]; fr[5] = hi[1]; fr[6] = hi[2]; fr[7] = hi[3];
+      return fr;
+    }
+  }
+};
+
+template <int BM, int BN, bool AKM, bool BKM, bool VEC>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  typedef Stage<AKM, BM, VEC> LA;
+  typedef Stage<BKM, BN, VEC> LB;
+  constexpr int A_BYTES = LA::BYTES, B_BYTES = LB::BYTES, STAGE = A_BYTES + B_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware tile order: ids that share an XCD (id % 8) get a contiguous run of tiles
+  const int nwg = gridDim.x;
+  int id = blockIdx.x;
+  {
+    const int x = id & 7, q = nwg >> 3, r = nwg & 7;
+    id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+  }
+  const int tile_m = id / g.tiles_n, tile_n = id - tile_m * g.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int zb = blockIdx.y / g.splitk, ks = blockIdx.y - zb * g.splitk;
+  const int zq = zb / g.zdiv, zr = zb - zq * g.zdiv;
+  const bf16_t* abase = reinterpret_cast<const bf16_t*>(g.A.p) + zq * g.A.zo + zr * g.A.zi;
+  const bf16_t* bbase = reinterpret_cast<const bf16_t*>(g.B.p) + zq * g.B.zo + zr * g.B.zi;
+  const int kbeg = ks * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  const int nt = (kend - kbeg + BK - 1) / BK;
+
+  LA la;
+  LB lb;
+  la.init(g.A, m0, g.M, tid);
+  lb.init(g.B, n0, g.N, tid);
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nt > 0) {
+    la.load(g.A, abase, g.M, kbeg, kend);
+    lb.load(g.B, bbase, g.N, kbeg, kend);
+    la.store(smem);
+    lb.store(smem + A_BYTES);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const unsigned char* cur = smem + (t & 1) * STAGE;
+    unsigned char* nxt = smem + ((t + 1) & 1) * STAGE;
+    const bool more = t + 1 < nt;
+    if (more) {
+      la.load(g.A, abase, g.M, kbeg + (t + 1) * BK, kend);
+      lb.load(g.B, bbase, g.N, kbeg + (t + 1) * BK, kend);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = LA::frag(cur, wm * WM + i * 16, s, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = LB::frag(cur + A_BYTES, wn * WN + j * 16, s, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)  // swapped operands: D[n][m] -> lane: m = lane & 15, n = 4 (lane >> 4) + r
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      la.store(nxt);
+      lb.store(nxt + A_BYTES);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------
+  const long czoff = zq * g.C.zo + zr * g.C.zi;
+  float* cbase = g.C.p ? g.C.p + czoff : nullptr;
+  bf16_t* hbase = g.C.h ? g.C.h + czoff : nullptr;
+  const float* rbase = g.ep.resid ? g.ep.resid + czoff : nullptr;
+  const float inv_keep = g.ep.drop_p > 0.f ? 1.f / (1.f - g.ep.drop_p) : 1.f;
+  const bool lead = (ks == 0);
+  const bool cvec = g.cvec != 0;
+  if (g.slab) {
+    // split-K partial: alpha * acc into slab[blockIdx.y][M][N] (dense); splitk_reduce_kernel combines
+    float* sb = g.slab + (long)blockIdx.y * g.M * g.N;
+    const bool v4 = (g.N & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * WM + i * 16 + (lane & 15);
+      if (m >= g.M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 16 + (lane >> 4) * 4;
+        if (n >= g.N) continue;
+        float* dst = sb + (long)m * g.N + n;
+        if (v4) {
+          *reinterpret_cast<float4*>(dst) = make_float4(g.ep.alpha * acc[i][j][0], g.ep.alpha * acc[i][j][1],
+                                                        g.ep.alpha * acc[i][j][2], g.ep.alpha * acc[i][j][3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (n + r < g.N) dst[r] = g.ep.alpha * acc[i][j][r];
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * WM + i * 16 + (lane & 15);
+    if (m >= g.M) continue;
+    const long roff = split_off(g.C.sp, m);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * WN + j * 16 + (lane >> 4) * 4;
+      if (n >= g.N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = g.ep.alpha * acc[i][j][r];
+      const bool full = cvec && n + 3 < g.N;
+      if (g.ep.bias && lead) {
+        if (full) {
+          const float4 b4 = *reinterpret_cast<const float4*>(g.ep.bias + n);
+          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (n + r < g.N) v[r] += g.ep.bias[n + r];
+        }
+      }
+      if (g.ep.act == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (g.ep.drop_p > 0.f) {
+        const uint64_t e0 = ((uint64_t)zb * g.M + m) * (uint64_t)g.N + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= drop_scale(g.ep.seed, e0 + r, g.ep.drop_p, inv_keep);
+      }
+      if (full) {
+        if (rbase && lead) {
+          const float4 r4 = *reinterpret_cast<const float4*>(rbase + roff + n);
+          v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+        }
+        if (g.splitk > 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomicAdd(cbase + roff + n + r, v[r]);
+          continue;
+        }
+        if (g.ep.accumulate) {
+          const float4 c4 = *reinterpret_cast<const float4*>(cbase + roff + n);
+          v[0] += c4.x; v[1] += c4.y; v[2] += c4.z; v[3] += c4.w;
+        }
+        if (cbase) *reinterpret_cast<float4*>(cbase + roff + n) = make_float4(v[0], v[1], v[2], v[3]);
+        if (hbase) *reinterpret_cast<uint2*>(hbase + roff + n) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r >= g.N) continue;
+          float x = v[r];
+          if (rbase && lead) x += rbase[roff + n + r];
+          if (g.splitk > 1) { atomicAdd(cbase + roff + n + r, x); continue; }
+          if (g.ep.accumulate) x += cbase[roff + n + r];
+          if (cbase) cbase[roff + n + r] = x;
+          if (hbase) hbase[roff + n + r] = (bf16_t)(pack_bf16x4(x, 0.f, 0.f, 0.f).x & 0xffffu);
+        }
+      }
+    }
+  }
+}
+
+// C(m, n) (+)= sum_s slab[z][s][m][n]
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, GemmOut C, int M, int N,
+                                                            int splitk, int zdiv, int accumulate) {
+  const int nq = (N + 3) >> 2;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)M * nq) return;
+  const int m = (int)(i / nq), n = (int)(i - (long)m * nq) * 4;
+  const int z = blockIdx.y, zq = z / zdiv, zr = z - zq * zdiv;
+  const float* sp = slab + ((long)z * splitk * M + m) * N + n;
+  float* cp = C.p + zq * C.zo + zr * C.zi + split_off(C.sp, m) + n;
+  const long sstride = (long)M * N;
+  if ((N & 3) == 0 && ((uintptr_t)cp & 15) == 0) {
+    float4 a = accumulate ? *reinterpret_cast<const float4*>(cp) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < splitk; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(sp + s * sstride);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *reinterpret_cast<float4*>(cp) = a;
+  } else {
+    for (int r = 0; r < 4 && n + r < N; ++r) {
+      float a = accumulate ? cp[r] : 0.f;
+      for (int s = 0; s < splitk; ++s) a += sp[s * sstride + r];
+      cp[r] = a;
+    }
+  }
+}
+
+template <int BM, int BN, bool VEC>
+void launch_layouts(const GemmArgs& g, dim3 grid, hipStream_t st) {
+  if (g.A.kmajor && g.B.kmajor)
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, true, true, VEC>), grid, dim3(256), 0, st, g);
+  else if (g.A.kmajor && !g.B.kmajor)
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, true, false, VEC>), grid, dim3(256), 0, st, g);
+  else if (!g.A.kmajor && g.B.kmajor)
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, false, true, VEC>), grid, dim3(256), 0, st, g);
+  else
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, false, false, VEC>), grid, dim3(256), 0, st, g);
+}
+
+// 16-byte fast path: aligned base, ld and batch strides multiples of 8 elements.  (K tails are
+// masked in the kernel; rows-contiguous operands rely on the padded-row contract.)
+bool vec_ok(const GemmOperand& o) {
+  return ((uintptr_t)o.p % 16 == 0) && (o.sp.ld % 8 == 0) && (o.sp.bs % 8 == 0) && (o.zo % 8 == 0) &&
+         (o.zi % 8 == 0);
+}
+
+}  // namespace
+
+// tile choice: estimated time = rounds over the 256 CUs x per-tile work / per-tile efficiency
+int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
+  const bool vec = vec_ok(g.A) && vec_ok(g.B);
+  g.avec = g.bvec = vec ? 1 : 0;
+  g.cvec = ((!g.C.p || (uintptr_t)g.C.p % 16 == 0) && (!g.C.h || (uintptr_t)g.C.h % 8 == 0) &&
+            g.C.sp.ld % 4 == 0 && g.C.sp.bs % 4 == 0 && g.C.zo % 4 == 0 && g.C.zi % 4 == 0 &&
+            (!g.ep.resid || (uintptr_t)g.ep.resid % 16 == 0) && (!g.ep.bias || (uintptr_t)g.ep.bias % 16 == 0))
+               ? 1 : 0;
+  const bool linear_epi = !g.ep.act && g.ep.drop_p == 0.f;
+  struct Cand { int bm, bn; double eff; };
+  const Cand cands[3] = {{128, 128, 1.0}, {128, 64, 0.8}, {64, 64, 0.55}};
+  int bm = 64, bn = 64;
+  if (vec) {
+    double best = 1e300;
+    for (const Cand& c : cands) {
+      long tiles = (long)((g.M + c.bm - 1) / c.bm) * ((g.N + c.bn - 1) / c.bn) * g.batch;
+      long rounds = (tiles + 255) / 256;
+      // split-K candidates fill the chip anyway: cost by work / efficiency only
+      double cost = (double)rounds * c.bm * c.bn / c.eff;
+      if (cost < best) { best = cost; bm = c.bm; bn = c.bn; }
+    }
+  }
+  if (vec) {  // tuning aid: S2ST_GEMM_TILE=128x128|128x64|64x64 forces the tile
+    static const char* force = getenv("S2ST_GEMM_TILE");
+    if (force && sscanf(force, "%dx%d", &bm, &bn) != 2) { bm = 64; bn = 64; }
+  }
+  const bool can_split_ = g.ep.accumulate && linear_epi && g.C.p && !g.C.h && !g.ep.bias && !g.ep.resid && g.K >= 8 * BK;
+  if (vec && can_split_ && (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch < 256) { bm = 128; bn = 128; }
+  const int tm = (g.M + bm - 1) / bm, tn = (g.N + bn - 1) / bn;
+  const long nt = (long)tm * tn * g.batch;
+  // split-K only for accumulating fp32 outputs with a linear epilogue (weight gradients): K is
+  // split over workgroups; partial sums go to fp32 slabs in the caller's scratch and are combined
+  // by splitk_reduce_kernel (HBM/MALL streaming, ~5 TB/s), or -- without scratch -- are added
+  // with fp32 atomics (~1.3 TB/s chip-wide, so only a fallback).
+  g.splitk = 1;
+  g.slab = nullptr;
+  if (can_split_ && nt < 256) {
+    int want = (int)((512 + nt - 1) / nt);
+    int maxs = g.K / (4 * BK);
+    g.splitk = want < maxs ? want : maxs;
+    if (g.ws) {
+      long fit = g.ws_floats / ((long)g.M * g.N * g.batch);
+      if (fit < g.splitk) g.splitk = (int)fit;
+    }
+    if (g.splitk < 1) g.splitk = 1;
+  }
+  const int kt = (g.K + BK - 1) / BK;
+  g.kchunk = ((kt + g.splitk - 1) / g.splitk) * BK;
+  g.splitk = (g.K + g.kchunk - 1) / g.kchunk;
+  if (g.splitk < 1) g.splitk = 1;
+  g.tiles_n = tn;
+  const bool use_slab = g.splitk > 1 && g.ws != nullptr;
+  if (use_slab) g.slab = g.ws;
+  dim3 grid(tm * tn, g.batch * g.splitk, 1);
+  if (grid.y > 65535) return -2;
+  if (bm_out) *bm_out = bm * 1000 + bn;
+  if (!vec) launch_layouts<64, 64, false>(g, grid, st);
+  else if (bm == 128 && bn == 128) launch_layouts<128, 128, true>(g, grid, st);
+  else if (bm == 128) launch_layouts<128, 64, true>(g, grid, st);
+  else launch_layouts<64, 64, true>(g, grid, st);
+  if (use_slab) {
+    const long nthr = (long)g.M * ((g.N + 3) / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthr + 255) / 256), g.batch), dim3(256), 0, st,
+                       (const float*)g.slab, g.C, g.M, g.N, g.splitk, g.zdiv, g.ep.accumulate);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -17,7 +17,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             float* __restrict__ y,
                                                             float* __restrict__ mean_out,
                                                             float* __restrict__ rstd_out,
-                                                            int rows, int cols, float eps) {
+                                                            int rows, int cols, float eps,
+                                                            uint16_t* __restrict__ yh) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;  // whole wave exits together (row is wave-uniform)
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
       o.z = (v[i].z - mean) * rstd * g.z + b.z;
       o.w = (v[i].w - mean) * rstd * g.w + b.w;
       reinterpret_cast<float4*>(yr)[c4] = o;
+      if (yh) reinterpret_cast<uint2*>(yh + (long)row * cols)[c4] = pack_bf16x4(o.x, o.y, o.z, o.w);
     }
   }
   if (lane == 0) {
@@ -144,21 +146,34 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
   }
 }
 
-// out[c] += sum_b part[b][c] over the [nblocks][2*cols] partials (out = [dgamma | dbeta] halves)
+// out[c] += sum_b part[b][c] over the [nblocks][2*cols] partials (out = [dgamma | dbeta] halves).
+// 256 threads = 32 columns x 8 row groups; a thread sums every 8th partial row with 4 loads in
+// flight, the 8 groups are combined through LDS.
 __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ part,
                                                                    int nblocks, int cols,
                                                                    float* __restrict__ dgamma,
                                                                    float* __restrict__ dbeta) {
-  __shared__ float red[4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + tx;  // over 2 * cols
-  float a = 0.f;
-  if (c < 2 * cols)
-    for (int b = ty; b < nblocks; b += 4) a += part[(long)b * 2 * cols + c];
-  red[ty][tx] = a;
+  __shared__ float red[8][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + tx;  // over 2 * cols
+  const long ld = 2L * cols;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < 2 * cols) {
+    int b = ty;
+    for (; b + 24 < nblocks; b += 32) {
+      a0 += part[(long)b * ld + c];
+      a1 += part[(long)(b + 8) * ld + c];
+      a2 += part[(long)(b + 16) * ld + c];
+      a3 += part[(long)(b + 24) * ld + c];
+    }
+    for (; b < nblocks; b += 8) a0 += part[(long)b * ld + c];
+  }
+  red[ty][tx] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (ty == 0 && c < 2 * cols) {
-    float v = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v += red[i][tx];
     if (c < cols) dgamma[c] += v;
     else dbeta[c - cols] += v;
   }
@@ -171,7 +186,8 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
                                                           float* __restrict__ pd,
                                                           const int* __restrict__ klen, int B,
                                                           int H, int T, int S, int ld, int causal,
-                                                          float drop_p, uint64_t seed) {
+                                                          float drop_p, uint64_t seed,
+                                                          uint16_t* __restrict__ pdh) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long rows = (long)B * H * T;
@@ -206,7 +222,12 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
     if (c < S) {
       float q = v[i] * inv;
       pr[c] = q;
-      if (pd) pd[row * ld + c] = q * drop_scale(seed, (uint64_t)row * ld + c, drop_p, inv_keep);
+      float qd = q;
+      if (drop_p > 0.f) qd = q * drop_scale(seed, (uint64_t)row * ld + c, drop_p, inv_keep);
+      if (pd) pd[row * ld + c] = qd;
+      if (pdh) pdh[row * ld + c] = (uint16_t)(pack_bf16x4(qd, 0.f, 0.f, 0.f).x & 0xffffu);
+    } else if (c < ld && pdh) {
+      pdh[row * ld + c] = 0;
     }
   }
 }
@@ -214,7 +235,8 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ p,
                                                           const float* __restrict__ dpd,
                                                           float* __restrict__ ds, long rows, int S,
-                                                          int ld, float drop_p, uint64_t seed) {
+                                                          int ld, float drop_p, uint64_t seed,
+                                                          uint16_t* __restrict__ dsh) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -236,7 +258,13 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
 #pragma unroll
   for (int i = 0; i < SM_MAXE; ++i) {
     int c = lane + 64 * i;
-    if (c < S) ds[row * ld + c] = pv[i] * (dv[i] - dot);
+    if (c < S) {
+      const float o = pv[i] * (dv[i] - dot);
+      ds[row * ld + c] = o;
+      if (dsh) dsh[row * ld + c] = (uint16_t)(pack_bf16x4(o, 0.f, 0.f, 0.f).x & 0xffffu);
+    } else if (c < ld && dsh) {
+      dsh[row * ld + c] = 0;
+    }
   }
 }
 
@@ -273,11 +301,12 @@ __global__ __launch_bounds__(256) void headmean_kernel(const float* __restrict__
 }  // namespace
 
 int s2st_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
-                       float* mean, float* rstd, int rows, int cols, float eps, hipStream_t st) {
+                       float* mean, float* rstd, int rows, int cols, float eps, hipStream_t st,
+                       uint16_t* yh) {
   if (rows <= 0) return 0;
   if (cols % 4 != 0 || cols > LN_MAXV * 256) return S2ST_ERR_SHAPE;
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, gamma, beta,
-                     y, mean, rstd, rows, cols, eps);
+                     y, mean, rstd, rows, cols, eps, yh);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
@@ -295,29 +324,30 @@ int s2st_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
   int blocks = s2st_layernorm_bwd_blocks(rows);
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, x, gamma, mean,
                      rstd, dx, dx_accumulate, scratch, rows, cols);
-  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * cols + 63) / 64), dim3(256), 0, st,
+  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * cols + 31) / 32), dim3(256), 0, st,
                      (const float*)scratch, blocks, cols, dgamma, dbeta);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
 int s2st_softmax_fwd(const float* s, float* p, float* pd, const int* klen, int B, int H, int T,
-                     int S, int ld, int causal, float drop_p, uint64_t seed, hipStream_t st) {
+                     int S, int ld, int causal, float drop_p, uint64_t seed, hipStream_t st,
+                     uint16_t* pdh) {
   long rows = (long)B * H * T;
   if (rows <= 0) return 0;
-  if (S > SM_MAXE * 64) return S2ST_ERR_SHAPE;
+  if (S > SM_MAXE * 64 || ld > SM_MAXE * 64) return S2ST_ERR_SHAPE;
   if (drop_p <= 0.f) pd = nullptr;
   hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, s, p,
-                     pd, klen, B, H, T, S, ld, causal, drop_p, seed);
+                     pd, klen, B, H, T, S, ld, causal, drop_p, seed, pdh);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
 int s2st_softmax_bwd(const float* p, const float* dpd, float* ds, int B, int H, int T, int S,
-                     int ld, float drop_p, uint64_t seed, hipStream_t st) {
+                     int ld, float drop_p, uint64_t seed, hipStream_t st, uint16_t* dsh) {
   long rows = (long)B * H * T;
   if (rows <= 0) return 0;
-  if (S > SM_MAXE * 64) return S2ST_ERR_SHAPE;
+  if (S > SM_MAXE * 64 || ld > SM_MAXE * 64) return S2ST_ERR_SHAPE;
   hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p,
-                     dpd, ds, rows, S, ld, drop_p, seed);
+                     dpd, ds, rows, S, ld, drop_p, seed, dsh);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 

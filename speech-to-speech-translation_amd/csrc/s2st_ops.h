@@ -18,7 +18,7 @@ typedef s2st_gemm_args GemmArgs;
 
 inline GemmOperand gemm_rowmajor(const float* p, long ld) {  // X[r][k], k contiguous
   GemmOperand o;
-  o.p = p; o.kmajor = 1; o._pad = 0; o.sp.ld = ld; o.sp.bs = 0; o.sp.per = 0; o.sp._pad = 0;
+  o.p = p; o.kmajor = 1; o.dtype = S2ST_F32; o.sp.ld = ld; o.sp.bs = 0; o.sp.per = 0; o.sp._pad = 0;
   o.zo = o.zi = 0;
   return o;
 }
@@ -29,7 +29,18 @@ inline GemmOperand gemm_colmajor(const float* p, long ld) {  // X stored [k][r],
 }
 inline GemmOut gemm_out(float* p, long ld) {
   GemmOut o;
-  o.p = p; o.sp.ld = ld; o.sp.bs = 0; o.sp.per = 0; o.sp._pad = 0; o.zo = o.zi = 0;
+  o.p = p; o.sp.ld = ld; o.sp.bs = 0; o.sp.per = 0; o.sp._pad = 0; o.zo = o.zi = 0; o.h = nullptr;
+  return o;
+}
+typedef uint16_t bf16raw;
+inline GemmOperand gemm_rowmajor(const bf16raw* p, long ld) {
+  GemmOperand o = gemm_rowmajor((const float*)nullptr, ld);
+  o.p = p; o.dtype = S2ST_BF16;
+  return o;
+}
+inline GemmOperand gemm_colmajor(const bf16raw* p, long ld) {
+  GemmOperand o = gemm_rowmajor(p, ld);
+  o.kmajor = 0;
   return o;
 }
 inline GemmEpilogue gemm_epi_default() {
@@ -40,6 +51,7 @@ inline GemmEpilogue gemm_epi_default() {
 }
 
 int s2st_gemm(GemmArgs g, hipStream_t st);
+int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* tile_out);  // gemm_bf16.hip (both operands bf16)
 void s2st_gemm_profile_enable(int on);
 int s2st_gemm_profile_read(double* flops, double* ms, long* launches);
 
@@ -47,7 +59,8 @@ int s2st_gemm_profile_read(double* flops, double* ms, long* launches);
 // row ops (rowops.hip)
 // ---------------------------------------------------------------------------------------
 int s2st_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
-                       float* mean, float* rstd, int rows, int cols, float eps, hipStream_t st);
+                       float* mean, float* rstd, int rows, int cols, float eps, hipStream_t st,
+                       uint16_t* yh = nullptr /* optional bf16 copy of y */);
 // dx (=|+=) ...; dgamma += , dbeta += (per-block partials in `scratch`, then a reduce kernel)
 int s2st_layernorm_bwd_blocks(int rows);  // scratch floats = blocks * 2 * cols
 int s2st_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
@@ -58,10 +71,12 @@ int s2st_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
 //   key mask: col >= klen[b] -> -inf ; causal: col > row -> -inf
 //   pd (optional, drop_p > 0) = dropout(p)
 int s2st_softmax_fwd(const float* s, float* p, float* pd, const int* klen, int B, int H, int T,
-                     int S, int ld, int causal, float drop_p, uint64_t seed, hipStream_t st);
+                     int S, int ld, int causal, float drop_p, uint64_t seed, hipStream_t st,
+                     uint16_t* pdh = nullptr /* optional bf16 copy of dropout(p), pad cols zeroed */);
 // ds = p * (dp' - sum(dp' * p)),  dp' = dropmask * dpd ; in place allowed (ds == dpd)
 int s2st_softmax_bwd(const float* p, const float* dpd, float* ds, int B, int H, int T, int S,
-                     int ld, float drop_p, uint64_t seed, hipStream_t st);
+                     int ld, float drop_p, uint64_t seed, hipStream_t st,
+                     uint16_t* dsh = nullptr /* optional bf16 copy of ds, pad cols zeroed */);
 
 // column sums: out[c] (+)= sum_r x[r][c]   (bias gradients)
 int s2st_colsum(const float* x, long ld, int rows, int cols, float* out, int accumulate,
@@ -73,6 +88,9 @@ int s2st_attn_headmean(const float* p, float* out, int B, int H, int T, int S, i
 // ---------------------------------------------------------------------------------------
 // elementwise (elementwise.hip)
 // ---------------------------------------------------------------------------------------
+// fp32 [rows][cols] (stride ldx) -> bf16 [rows][ldy] (ldy % 4 == 0, pad columns zeroed): the
+// bf16 copies the fast GEMM path reads
+int s2st_cast_bf16_rows(const float* x, long ldx, uint16_t* y, long ldy, long rows, int cols, hipStream_t st);
 // copy [rows][C] between split-addressed buffers (halo padding, zero-stuffing); C % 4 == 0
 int s2st_copy_rows(const float* x, Split xsp, float* y, Split ysp, int rows, int C,
                    hipStream_t st);
@@ -96,6 +114,11 @@ int s2st_dropout(const float* x, float* y, long n, float a, float p, uint64_t se
 // dz = dy * (y != 0 ? 1/(1-p) : 0)   (backward of dropout(relu(z)) given its OUTPUT y)
 int s2st_relu_drop_bwd(const float* dy, const float* y, float* dz, long n, float p,
                        hipStream_t st);
+// fused backward prologue of a linear layer (fast mode): dph = bf16(f(dy)) with row stride ldp
+// (pad columns zeroed), optional fp32 copy dpre, dbias += colsum(f(dy)).  mode 0: f = id ;
+// 1: ReLU+dropout backward from the layer OUTPUT y ; 2: dropout(seed) backward.  N % 4 == 0.
+int s2st_linear_bwd_prep(const float* dy, const float* y, int mode, float p, uint64_t seed, uint16_t* dph,
+                         long ldp, float* dpre, float* dbias, int M, int N, hipStream_t st);
 int s2st_axpy(const float* x, float* y, long n, float a, hipStream_t st);  // y += a * x
 int s2st_scale(float* x, long n, float a, hipStream_t st);
 // conv weight W[O][I][Kw] -> Wf[O][Kw][I] (forward GEMM layout) and, if wd != null,

@@ -26,12 +26,12 @@ class Split(C.Structure):
 
 
 class GemmOperand(C.Structure):
-    _fields_ = [("p", C.c_void_p), ("kmajor", C.c_int32), ("_pad", C.c_int32), ("sp", Split),
+    _fields_ = [("p", C.c_void_p), ("kmajor", C.c_int32), ("dtype", C.c_int32), ("sp", Split),
                 ("zo", C.c_int64), ("zi", C.c_int64)]
 
 
 class GemmOut(C.Structure):
-    _fields_ = [("p", C.c_void_p), ("sp", Split), ("zo", C.c_int64), ("zi", C.c_int64)]
+    _fields_ = [("p", C.c_void_p), ("sp", Split), ("zo", C.c_int64), ("zi", C.c_int64), ("h", C.c_void_p)]
 
 
 class GemmEpilogue(C.Structure):
@@ -44,7 +44,8 @@ class GemmArgs(C.Structure):
     _fields_ = [("A", GemmOperand), ("B", GemmOperand), ("C", GemmOut), ("ep", GemmEpilogue),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("batch", C.c_int32),
                 ("zdiv", C.c_int32), ("precise", C.c_int32), ("splitk", C.c_int32),
-                ("kchunk", C.c_int32), ("avec", C.c_int32), ("bvec", C.c_int32)]
+                ("kchunk", C.c_int32), ("avec", C.c_int32), ("bvec", C.c_int32), ("cvec", C.c_int32),
+                ("tiles_n", C.c_int32), ("ws", C.c_void_p), ("ws_floats", C.c_int64), ("slab", C.c_void_p)]
 
 
 class S2STHipError(RuntimeError):
@@ -108,9 +109,14 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
          b_kmajor=True, b_ld=None, b_per=0, b_bs=0, b_zo=0, b_zi=0,
          c_ld=None, c_per=0, c_bs=0, c_zo=0, c_zi=0,
          batch=1, zdiv=1, alpha=1.0, bias=None, act=0, drop_p=0.0, seed=0, resid=None,
-         accumulate=False, precise=False, a_off=0, b_off=0, c_off=0):
-    """Raw GEMM entry (s2st_gemm_f32). Offsets are in elements."""
+         accumulate=False, precise=False, a_off=0, b_off=0, c_off=0, c_bf16=None, ws=None):
+    """Raw GEMM entry (s2st_gemm_f32). Offsets are in elements.  A and B are both fp32 or both
+    torch.bfloat16 tensors; ``Cout`` (fp32) may be None when only ``c_bf16`` is wanted."""
     require_device(A)
+    if A.dtype != B.dtype:
+        raise S2STHipError("gemm operands must have the same dtype")
+    if A.dtype == torch.bfloat16:
+        return _gemm_bf16(A, B, Cout, M, N, K, locals())
     g = GemmArgs()
     g.A = GemmOperand(A.data_ptr() + 4 * a_off, 1 if a_kmajor else 0, 0,
                       make_split(a_ld if a_ld is not None else (K if a_kmajor else M), a_per, a_bs),
@@ -119,9 +125,29 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
                       make_split(b_ld if b_ld is not None else (K if b_kmajor else N), b_per, b_bs),
                       b_zo, b_zi)
     g.C = GemmOut(Cout.data_ptr() + 4 * c_off, make_split(c_ld if c_ld is not None else N, c_per, c_bs),
-                  c_zo, c_zi)
+                  c_zo, c_zi, None)
     g.ep = GemmEpilogue(alpha, act, ptr(bias), drop_p, 1 if accumulate else 0, seed, ptr(resid))
     g.M, g.N, g.K, g.batch, g.zdiv, g.precise = M, N, K, batch, zdiv, 1 if precise else 0
+    check(lib().s2st_gemm_f32(C.byref(g), C.c_void_p(stream_ptr())), "s2st_gemm_f32")
+
+
+def _gemm_bf16(A, B, Cout, M, N, K, kw):
+    g = GemmArgs()
+    a_ld = kw["a_ld"] if kw["a_ld"] is not None else (K if kw["a_kmajor"] else M)
+    b_ld = kw["b_ld"] if kw["b_ld"] is not None else (K if kw["b_kmajor"] else N)
+    g.A = GemmOperand(A.data_ptr() + 2 * kw["a_off"], 1 if kw["a_kmajor"] else 0, 1,
+                      make_split(a_ld, kw["a_per"], kw["a_bs"]), kw["a_zo"], kw["a_zi"])
+    g.B = GemmOperand(B.data_ptr() + 2 * kw["b_off"], 1 if kw["b_kmajor"] else 0, 1,
+                      make_split(b_ld, kw["b_per"], kw["b_bs"]), kw["b_zo"], kw["b_zi"])
+    h = kw["c_bf16"]
+    g.C = GemmOut(Cout.data_ptr() + 4 * kw["c_off"] if Cout is not None else None,
+                  make_split(kw["c_ld"] if kw["c_ld"] is not None else N, kw["c_per"], kw["c_bs"]),
+                  kw["c_zo"], kw["c_zi"], h.data_ptr() + 2 * kw["c_off"] if h is not None else None)
+    g.ep = GemmEpilogue(kw["alpha"], kw["act"], ptr(kw["bias"]), kw["drop_p"], 1 if kw["accumulate"] else 0,
+                        kw["seed"], ptr(kw["resid"]))
+    g.M, g.N, g.K, g.batch, g.zdiv, g.precise = M, N, K, kw["batch"], kw["zdiv"], 0
+    if kw["ws"] is not None:
+        g.ws, g.ws_floats = kw["ws"].data_ptr(), kw["ws"].numel()
     check(lib().s2st_gemm_f32(C.byref(g), C.c_void_p(stream_ptr())), "s2st_gemm_f32")
 
 

@@ -154,6 +154,12 @@ class Engine:
         self.grads = torch.zeros(self.n_params, dtype=torch.float32, device=device)
         self.buffers = torch.zeros(max(self.n_buffers, 4), dtype=torch.float32, device=device)
         self.lib.s2st_engine_bind(h, self.params.data_ptr(), self.grads.data_ptr(), self.buffers.data_ptr())
+        # fast mode: bf16 copy of the parameter arena (refreshed by the engine every forward)
+        self.params_bf16 = None
+        if not precise:
+            self.params_bf16 = torch.zeros(self.n_params, dtype=torch.bfloat16, device=device)
+            self.lib.s2st_engine_bind_bf16.argtypes = [C.c_void_p, C.c_void_p]
+            self.lib.s2st_engine_bind_bf16(h, self.params_bf16.data_ptr())
         self.workspace: Optional[torch.Tensor] = None
         self._pe: Dict[int, torch.Tensor] = {}
         self._plan: Dict[tuple, int] = {}

@@ -150,3 +150,137 @@ def test_dropout_epilogue_statistics(backend):
     backend.bd.gemm(A, B, C2, M, N, K, drop_p=0.25, seed=1234, precise=True)
     backend.sync()
     assert torch.equal(C, C2.cpu())  # same seed -> same mask
+
+
+# ---- bf16-operand fast path (gemm_bf16.hip) ---------------------------------------------------
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+def _pad_cols(x, mult=8):
+    """[R][C] -> [R][round_up(C, mult)] with NaN padding: the kernel must ignore pad content."""
+    R, Cc = x.shape
+    ld = (Cc + mult - 1) // mult * mult
+    out = torch.full((R, ld), float("nan"), dtype=x.dtype)
+    out[:, :Cc] = x
+    return out, ld
+
+
+BF_SHAPES = [(100, 72, 96), (130, 74, 44), (67, 130, 50), (257, 192, 320), (191, 128, 191)]
+
+
+@pytest.mark.parametrize("akm", [True, False])
+@pytest.mark.parametrize("bkm", [True, False])
+@pytest.mark.parametrize("shape", BF_SHAPES)
+def test_bf16_layouts(backend, akm, bkm, shape):
+    """bf16 operands, every layout, ragged M/N/K; padded lds filled with NaN (contract: pad
+    content is never used); fp32 result + bf16 copy."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + 1)
+    A = _bf(torch.randn(M, K, generator=g))
+    B = _bf(torch.randn(N, K, generator=g))
+    Am, a_ld = _pad_cols(A if akm else A.t().contiguous())
+    Bm, b_ld = _pad_cols(B if bkm else B.t().contiguous())
+    d = backend.device
+    ldc = (N + 3) // 4 * 4
+    C = torch.full((M, ldc), 7.0, device=d)
+    Ch = torch.zeros(M, ldc, dtype=torch.bfloat16, device=d)
+    backend.bd.gemm(Am.to(d), Bm.to(d), C, M, N, K, a_kmajor=akm, b_kmajor=bkm, a_ld=a_ld, b_ld=b_ld,
+                    c_ld=ldc, c_bf16=Ch)
+    backend.sync()
+    R = A.double() @ B.double().t()
+    assert _relerr(C[:, :N], R) < 2e-6  # exact products of bf16 values, fp32 accumulation
+    assert torch.equal(Ch[:, :N].cpu(), C[:, :N].cpu().to(torch.bfloat16))
+
+
+def test_bf16_matches_f32_path_bitwise_inputs(backend):
+    """Same rounding as the fp32-operand kernel: feeding bf16(x) gives what feeding x gives."""
+    M, N, K = 96, 80, 128
+    g = torch.Generator().manual_seed(11)
+    A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    d = backend.device
+    C1 = torch.zeros(M, N, device=d)
+    C2 = torch.zeros(M, N, device=d)
+    backend.bd.gemm(A.to(d), B.to(d), C1, M, N, K)
+    backend.bd.gemm(_bf(A).to(d), _bf(B).to(d), C2, M, N, K)
+    backend.sync()
+    assert _relerr(C2, C1.double().cpu()) < 1e-6
+
+
+def test_bf16_epilogue_and_unaligned(backend):
+    M, N, K = 90, 70, 64
+    g = torch.Generator().manual_seed(12)
+    A, B = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g))
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    d = backend.device
+    C = torch.zeros(M, N, device=d)  # ld 70: scalar epilogue path
+    backend.bd.gemm(A.to(d), B.to(d), C, M, N, K, alpha=0.5, bias=bias.to(d), act=1, resid=res.to(d))
+    backend.sync()
+    R = torch.relu(0.5 * (A.double() @ B.double().t()) + bias.double()) + res.double()
+    assert _relerr(C, R) < 2e-6
+    C2 = res.clone().to(d)
+    backend.bd.gemm(A.to(d), B.to(d), C2, M, N, K, accumulate=True)
+    backend.sync()
+    assert _relerr(C2, res.double() + A.double() @ B.double().t()) < 2e-6
+    # unaligned ld (K = 50 -> ld 50): guarded scalar loader
+    A3, B3 = _bf(torch.randn(33, 50, generator=g)), _bf(torch.randn(21, 50, generator=g))
+    C3 = torch.zeros(33, 21, device=d)
+    backend.bd.gemm(A3.to(d), B3.to(d), C3, 33, 21, 50)
+    backend.sync()
+    assert _relerr(C3, A3.double() @ B3.double().t()) < 2e-6
+
+
+def test_bf16_tiles_splitk_conv_batched(backend):
+    d = backend.device
+    g = torch.Generator().manual_seed(13)
+    # large-tile selection (128x128 / 128x64) and the wgrad split-K form
+    M, N, K = (256, 256, 128) if backend.kind == "emu" else (4584, 512, 2048)
+    A, B = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g))
+    C = torch.zeros(M, N, device=d)
+    backend.bd.gemm(A.to(d), B.to(d), C, M, N, K)
+    backend.sync()
+    assert _relerr(C, A.double() @ B.double().t()) < 2e-6
+    Mred = 1024 if backend.kind == "emu" else 8192
+    dY, X = _bf(torch.randn(Mred, 64, generator=g)), _bf(torch.randn(Mred, 96, generator=g))
+    dW0 = torch.randn(64, 96, generator=g)
+    dW = dW0.clone().to(d)
+    backend.bd.gemm(dY.to(d), X.to(d), dW, 64, 96, Mred, a_kmajor=False, a_ld=64, b_kmajor=False, b_ld=96,
+                    accumulate=True)
+    backend.sync()
+    assert _relerr(dW, dW0.double() + dY.double().t() @ X.double()) < 1e-5
+    # same with caller scratch: partial slabs + combine kernel instead of atomics
+    dW2 = dW0.clone().to(d)
+    ws = torch.empty(1 << 20, device=d)
+    backend.bd.gemm(dY.to(d), X.to(d), dW2, 64, 96, Mred, a_kmajor=False, a_ld=64, b_kmajor=False, b_ld=96,
+                    accumulate=True, ws=ws)
+    backend.sync()
+    assert _relerr(dW2, dW0.double() + dY.double().t() @ X.double()) < 1e-5
+    # conv as GEMM over a halo image (stride 2), bf16
+    Bn, T, Cin, Cout, Kw = 3, 37, 8, 24, 5
+    x = _bf(torch.randn(Bn, T, Cin, generator=g))
+    w = _bf(torch.randn(Cout, Cin, Kw, generator=g))
+    ref = torch.nn.functional.conv1d(x.float().transpose(1, 2), w.float(), None, stride=2, padding=2).transpose(1, 2)
+    Tout = ref.shape[1]
+    xp = torch.zeros(Bn, T + 4, Cin, dtype=torch.bfloat16)
+    xp[:, 2:T + 2] = x
+    wf = w.permute(0, 2, 1).contiguous()
+    y = torch.zeros(Bn, Tout, Cout, device=d)
+    backend.bd.gemm(xp.to(d), wf.to(d), y, Bn * Tout, Cout, Kw * Cin, a_ld=2 * Cin, a_per=Tout,
+                    a_bs=(T + 4) * Cin, b_ld=Kw * Cin)
+    backend.sync()
+    assert _relerr(y, ref.double()) < 2e-6
+    # batched P V with rows-contiguous V (b, h batching), S not a multiple of 8
+    Bn, H, T, S, Dh = 2, 4, 19, 23, 16
+    Cm = H * Dh
+    p = _bf(torch.rand(Bn, H, T, S, generator=g))
+    v = _bf(torch.randn(Bn, S, Cm, generator=g))
+    ld = 24
+    pp = torch.full((Bn, H, T, ld), float("nan"), dtype=torch.bfloat16)
+    pp[..., :S] = p
+    o = torch.zeros(Bn, T, Cm, device=d)
+    backend.bd.gemm(pp.to(d), v.to(d), o, T, Dh, S, a_ld=ld, a_zo=H * T * ld, a_zi=T * ld, b_kmajor=False,
+                    b_ld=Cm, b_zo=S * Cm, b_zi=Dh, c_ld=Cm, c_zo=T * Cm, c_zi=Dh, batch=Bn * H, zdiv=H)
+    backend.sync()
+    vh = v.view(Bn, S, H, Dh).permute(0, 2, 1, 3).double()
+    Ro = (p.double() @ vh).permute(0, 2, 1, 3).reshape(Bn, T, Cm)
+    assert _relerr(o, Ro) < 2e-6
