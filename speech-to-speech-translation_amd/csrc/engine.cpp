@@ -956,6 +956,7 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->c = *cfg;
   e->f32_operands = getenv("S2ST_F32_OPERANDS") && atoi(getenv("S2ST_F32_OPERANDS")) != 0;
   e->build_params();
+  if (!cfg->precise && s2st_gemm_bf16_preload(nullptr) != 0) { delete e; return S2ST_ERR_LAUNCH; }
   *out = e;
   return 0;
 }

@@ -151,84 +151,11 @@ struct Stage {
   }
 };
 
-template <int BM, int BN, bool AKM, bool BKM, bool VEC>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
-  typedef Stage<AKM, BM, VEC> LA;
-  typedef Stage<BKM, BN, VEC> LB;
-  constexpr int A_BYTES = LA::BYTES, B_BYTES = LB::BYTES, STAGE = A_BYTES + B_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
-
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  // XCD-aware tile order: ids that share an XCD (id % 8) get a contiguous run of tiles
-  const int nwg = gridDim.x;
-  int id = blockIdx.x;
-  {
-    const int x = id & 7, q = nwg >> 3, r = nwg & 7;
-    id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
-  }
-  const int tile_m = id / g.tiles_n, tile_n = id - tile_m * g.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  const int zb = blockIdx.y / g.splitk, ks = blockIdx.y - zb * g.splitk;
-  const int zq = zb / g.zdiv, zr = zb - zq * g.zdiv;
-  const bf16_t* abase = reinterpret_cast<const bf16_t*>(g.A.p) + zq * g.A.zo + zr * g.A.zi;
-  const bf16_t* bbase = reinterpret_cast<const bf16_t*>(g.B.p) + zq * g.B.zo + zr * g.B.zi;
-  const int kbeg = ks * g.kchunk;
-  const int kend = min(g.K, kbeg + g.kchunk);
-  const int nt = (kend - kbeg + BK - 1) / BK;
-
-  LA la;
-  LB lb;
-  la.init(g.A, m0, g.M, tid);
-  lb.init(g.B, n0, g.N, tid);
-
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  if (nt > 0) {
-    la.load(g.A, abase, g.M, kbeg, kend);
-    lb.load(g.B, bbase, g.N, kbeg, kend);
-    la.store(smem);
-    lb.store(smem + A_BYTES);
-  }
-  __syncthreads();
-
-  for (int t = 0; t < nt; ++t) {
-    const unsigned char* cur = smem + (t & 1) * STAGE;
-    unsigned char* nxt = smem + ((t + 1) & 1) * STAGE;
-    const bool more = t + 1 < nt;
-    if (more) {
-      la.load(g.A, abase, g.M, kbeg + (t + 1) * BK, kend);
-      lb.load(g.B, bbase, g.N, kbeg + (t + 1) * BK, kend);
-    }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 af[TM], bf[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = LA::frag(cur, wm * WM + i * 16, s, lane);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = LB::frag(cur + A_BYTES, wn * WN + j * 16, s, lane);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)  // swapped operands: D[n][m] -> lane: m = lane & 15, n = 4 (lane >> 4) + r
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
-    }
-    if (more) {
-      la.store(nxt);
-      lb.store(nxt + A_BYTES);
-    }
-    __syncthreads();
-  }
-
-  // ---- epilogue -------------------------------------------------------------------------
+// Epilogue shared by the two kernels.  acc holds C^T tiles: lane -> m = lane & 15, n = 4 (lane >> 4) + r.
+template <int BM, int BN, int WGN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM / 32][BN / (16 * WGN)], int m0,
+                                              int n0, int wm, int wn, int lane, int zb, int ks, int zq, int zr) {
+  constexpr int WM = BM / 2, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
   const long czoff = zq * g.C.zo + zr * g.C.zi;
   float* cbase = g.C.p ? g.C.p + czoff : nullptr;
   bf16_t* hbase = g.C.h ? g.C.h + czoff : nullptr;
@@ -323,6 +250,277 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
   }
 }
 
+template <int BM, int BN, bool AKM, bool BKM, bool VEC>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  typedef Stage<AKM, BM, VEC> LA;
+  typedef Stage<BKM, BN, VEC> LB;
+  constexpr int A_BYTES = LA::BYTES, B_BYTES = LB::BYTES, STAGE = A_BYTES + B_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware tile order: ids that share an XCD (id % 8) get a contiguous run of tiles
+  const int nwg = gridDim.x;
+  int id = blockIdx.x;
+  {
+    const int x = id & 7, q = nwg >> 3, r = nwg & 7;
+    id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+  }
+  const int tile_m = id / g.tiles_n, tile_n = id - tile_m * g.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int zb = blockIdx.y / g.splitk, ks = blockIdx.y - zb * g.splitk;
+  const int zq = zb / g.zdiv, zr = zb - zq * g.zdiv;
+  const bf16_t* abase = reinterpret_cast<const bf16_t*>(g.A.p) + zq * g.A.zo + zr * g.A.zi;
+  const bf16_t* bbase = reinterpret_cast<const bf16_t*>(g.B.p) + zq * g.B.zo + zr * g.B.zi;
+  const int kbeg = ks * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  const int nt = (kend - kbeg + BK - 1) / BK;
+
+  LA la;
+  LB lb;
+  la.init(g.A, m0, g.M, tid);
+  lb.init(g.B, n0, g.N, tid);
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nt > 0) {
+    la.load(g.A, abase, g.M, kbeg, kend);
+    lb.load(g.B, bbase, g.N, kbeg, kend);
+    la.store(smem);
+    lb.store(smem + A_BYTES);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const unsigned char* cur = smem + (t & 1) * STAGE;
+    unsigned char* nxt = smem + ((t + 1) & 1) * STAGE;
+    const bool more = t + 1 < nt;
+    if (more) {
+      la.load(g.A, abase, g.M, kbeg + (t + 1) * BK, kend);
+      lb.load(g.B, bbase, g.N, kbeg + (t + 1) * BK, kend);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = LA::frag(cur, wm * WM + i * 16, s, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = LB::frag(cur + A_BYTES, wn * WN + j * 16, s, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)  // swapped operands: D[n][m] -> lane: m = lane & 15, n = 4 (lane >> 4) + r
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      la.store(nxt);
+      lb.store(nxt + A_BYTES);
+    }
+    __syncthreads();
+  }
+
+  gemm_epilogue<BM, BN, 2>(g, acc, m0, n0, wm, wn, lane, zb, ks, zq, zr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA ring kernel (aligned operands): the same tile math, but the tiles are moved HBM/L2 -> LDS by
+// global_load_lds_dwordx4 (no VGPR staging, no ds_write) into a ring of NS stages, NS-1 K-steps ahead
+// of the MFMAs.  A wave-instruction writes 1 KiB of LDS linearly (lane l -> base + 16 l), so the
+// swizzles of the LDS images above are applied to the per-lane SOURCE address instead:
+//   K-contiguous image : a wave-instruction covers 8 rows x 128 B; lane l = (row l>>3, slot l&7) fetches
+//                        chunk (l&7) ^ (l>>3) of its row;
+//   rows-contiguous    : a wave-instruction covers 1 KiB of k rows; slot p of k row kr fetches chunk
+//                        (((p>>1) ^ kperm(kr)) << 1) | (p&1).
+// One raw s_barrier per K-step: [counted vmcnt: stage t landed] -> barrier (everyone's stage-t DMA is
+// visible, everyone is done reading stage t-1) -> issue stage t+NS-1 into the slot of t-1 -> MFMAs of
+// stage t.  A K tail (kend - kt < 64) is loaded from clamped addresses and zeroed in LDS.
+// ------------------------------------------------------------------------------------------------
+#define S2ST_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | 0x0f70)
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <bool KM, int ROWS, int NW>
+struct Dma {
+  static constexpr int NI = ROWS / (8 * NW);  // wave-instructions per wave per stage (1 KiB each)
+  static constexpr int PITCH = KM ? 128 : ROWS * 2;
+  static constexpr int BYTES = ROWS * 128;
+  static constexpr int KR_PER_I = 1024 / PITCH;  // rows-contiguous: k rows per wave-instruction
+  const bf16_t* p[NI];  // KM: this lane's row (clamped) + chunk offset ; !KM: base + clamped first row of its chunk
+  long ld;              // !KM: element stride of one k row
+  int kr0[NI];          // !KM: k row (within the stage) this lane fetches in instruction j
+  int chunk8;           // KM: 8 * (source chunk of this lane)
+
+  __device__ __forceinline__ void init(const GemmOperand& X, const bf16_t* base, int r0, int R, int wave, int lane) {
+    if (KM) {
+      chunk8 = 8 * ((lane & 7) ^ (lane >> 3));
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int row = r0 + wave * (ROWS / NW) + j * 8 + (lane >> 3);
+        p[j] = base + split_off(X.sp, min(row, R - 1));
+      }
+    } else {
+      ld = X.sp.ld;
+      constexpr int LPR = PITCH / 16;  // lanes (16-byte slots) per k row
+      const int slot = lane % LPR;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int kr = wave * (64 / NW) + j * KR_PER_I + lane / LPR;
+        kr0[j] = kr;
+        const int ch = ((((slot >> 1) ^ kperm<ROWS>(kr)) << 1) | (slot & 1));
+        p[j] = base + min(r0 + ch * 8, ((R + 7) & ~7) - 8);
+      }
+    }
+  }
+
+  // issue the DMA of K-step starting at kt into the stage image at `img` (wave-uniform)
+  __device__ __forceinline__ void issue(unsigned char* img, int kt, int K, int wave) const {
+    if (KM) {
+      const int ko = min(kt + chunk8, ((K + 7) & ~7) - 8);  // stay inside the padded row
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        __builtin_amdgcn_global_load_lds((gptr_t)(p[j] + ko), (lptr_t)(img + (wave * (ROWS / NW) + j * 8) * 128), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const long k = min(kt + kr0[j], K - 1);
+        __builtin_amdgcn_global_load_lds((gptr_t)(p[j] + k * ld),
+                                         (lptr_t)(img + (wave * (64 / NW) + j * KR_PER_I) * PITCH), 16, 0, 0);
+      }
+    }
+  }
+
+  // zero k >= kv (valid k of this stage) in the landed image
+  __device__ static __forceinline__ void sanitize(unsigned char* img, int kv, int tid) {
+    for (int f = tid; f < ROWS * 8; f += 64 * NW) {
+      if (KM) {
+        const int row = f >> 3, slot = f & 7;
+        const int nv = kv - 8 * (slot ^ (row & 7));
+        if (nv < 8) {
+          uint4* q = reinterpret_cast<uint4*>(img + row * 128 + slot * 16);
+          *q = mask_tail(*q, nv > 0 ? nv : 0);
+        }
+      } else {
+        constexpr int RC = ROWS / 8;
+        if (f / RC >= kv) *reinterpret_cast<uint4*>(img + (long)f * 16) = make_uint4(0, 0, 0, 0);
+      }
+    }
+  }
+};
+
+template <int BM, int BN, bool AKM, bool BKM, int NS, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_kernel(GemmArgs g) {
+  constexpr int WGN = NW / 2;  // waves: 2 (M) x WGN (N)
+  constexpr int WM = BM / 2, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
+  typedef Dma<AKM, BM, NW> DA;
+  typedef Dma<BKM, BN, NW> DB;
+  typedef Stage<AKM, BM, true> LA;  // fragment readers (same images)
+  typedef Stage<BKM, BN, true> LB;
+  constexpr int A_BYTES = DA::BYTES, B_BYTES = DB::BYTES, STAGE = A_BYTES + B_BYTES;
+  constexpr int PER_STAGE = DA::NI + DB::NI;  // DMA instructions per wave per stage
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int nwg = gridDim.x;
+  int id = blockIdx.x;
+  {
+    const int x = id & 7, q = nwg >> 3, r = nwg & 7;
+    id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+  }
+  const int tile_m = id / g.tiles_n, tile_n = id - tile_m * g.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int zb = blockIdx.y / g.splitk, ks = blockIdx.y - zb * g.splitk;
+  const int zq = zb / g.zdiv, zr = zb - zq * g.zdiv;
+  const bf16_t* abase = reinterpret_cast<const bf16_t*>(g.A.p) + zq * g.A.zo + zr * g.A.zi;
+  const bf16_t* bbase = reinterpret_cast<const bf16_t*>(g.B.p) + zq * g.B.zo + zr * g.B.zi;
+  const int kbeg = ks * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  const int nt = (kend - kbeg + BK - 1) / BK;
+
+  DA da;
+  DB db;
+  da.init(g.A, abase, m0, g.M, wave, lane);
+  db.init(g.B, bbase, n0, g.N, wave, lane);
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: stages 0 .. NS-2
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nt) {
+      da.issue(smem + s * STAGE, kbeg + s * BK, g.K, wave);
+      db.issue(smem + s * STAGE + A_BYTES, kbeg + s * BK, g.K, wave);
+    }
+
+  for (int t = 0; t < nt; ++t) {
+    // my DMA of stage t has landed once at most min(NS-2, nt-1-t) later stages are outstanding
+    const int ahead = nt - 1 - t;
+    if (ahead >= NS - 2) S2ST_VMCNT((NS - 2) * PER_STAGE);
+    else if (NS > 3 && ahead == 1) S2ST_VMCNT(PER_STAGE);
+    else S2ST_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+    unsigned char* cur = smem + (t % NS) * STAGE;
+    if (t + NS - 1 < nt) {
+      unsigned char* nxt = smem + ((t + NS - 1) % NS) * STAGE;
+      da.issue(nxt, kbeg + (t + NS - 1) * BK, g.K, wave);
+      db.issue(nxt + A_BYTES, kbeg + (t + NS - 1) * BK, g.K, wave);
+    }
+    if (t == nt - 1 && kend - (kbeg + t * BK) < BK) {  // K tail: zero the invalid k of this stage
+      const int kv = kend - (kbeg + t * BK);
+      DA::sanitize(cur, kv, tid);
+      DB::sanitize(cur + A_BYTES, kv, tid);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = LA::frag(cur, wm * WM + i * 16, s, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = LB::frag(cur + A_BYTES, wn * WN + j * 16, s, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  }
+  gemm_epilogue<BM, BN, WGN>(g, acc, m0, n0, wm, wn, lane, zb, ks, zq, zr);
+}
+
+template <int BM, int BN, int NS, int NW>
+int launch_dma(const GemmArgs& g, dim3 grid, hipStream_t st) {
+  constexpr int LDS = NS * (BM + BN) * 128;
+  auto go = [&](auto kern) {
+    static bool configured = false;  // one flag per instantiation (the lambda's operator() template)
+    if (!configured) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+        return -1;
+      configured = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), LDS, st, g);
+    return 0;
+  };
+  if (g.A.kmajor && g.B.kmajor) return go(gemm_bf16_dma_kernel<BM, BN, true, true, NS, NW>);
+  if (g.A.kmajor && !g.B.kmajor) return go(gemm_bf16_dma_kernel<BM, BN, true, false, NS, NW>);
+  if (!g.A.kmajor && g.B.kmajor) return go(gemm_bf16_dma_kernel<BM, BN, false, true, NS, NW>);
+  return go(gemm_bf16_dma_kernel<BM, BN, false, false, NS, NW>);
+}
+
 // C(m, n) (+)= sum_s slab[z][s][m][n]
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, GemmOut C, int M, int N,
                                                             int splitk, int zdiv, int accumulate) {
@@ -370,6 +568,30 @@ bool vec_ok(const GemmOperand& o) {
 }
 
 }  // namespace
+
+// Launch every kernel instantiation once on an empty problem (M = N = K = 0: no loads, no stores) so
+// that code objects are resident and the > 64 KiB dynamic-LDS attribute is set before the first
+// timed step (first use of a kernel on a fresh process costs milliseconds).
+int s2st_gemm_bf16_preload(hipStream_t st) {
+  GemmArgs g{};
+  g.A.dtype = g.B.dtype = S2ST_BF16;
+  g.splitk = 1; g.zdiv = 1; g.tiles_n = 1; g.batch = 1; g.kchunk = BK;
+  dim3 grid(1, 1, 1);
+  int rc = 0;
+  for (int lay = 0; lay < 4; ++lay) {
+    g.A.kmajor = lay & 1; g.B.kmajor = (lay >> 1) & 1;
+    launch_layouts<128, 128, true>(g, grid, st);
+    launch_layouts<128, 64, true>(g, grid, st);
+    launch_layouts<64, 64, true>(g, grid, st);
+    launch_layouts<64, 64, false>(g, grid, st);
+    rc |= launch_dma<128, 128, 4, 8>(g, grid, st);
+    rc |= launch_dma<128, 128, 4, 4>(g, grid, st);
+    rc |= launch_dma<128, 64, 4, 8>(g, grid, st);
+    rc |= launch_dma<128, 64, 4, 4>(g, grid, st);
+    rc |= launch_dma<64, 64, 4, 4>(g, grid, st);
+  }
+  return rc || hipGetLastError() != hipSuccess ? -1 : 0;
+}
 
 // tile choice: estimated time = rounds over the 256 CUs x per-tile work / per-tile efficiency
 int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
@@ -427,6 +649,17 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
   dim3 grid(tm * tn, g.batch * g.splitk, 1);
   if (grid.y > 65535) return -2;
   if (bm_out) *bm_out = bm * 1000 + bn;
+  // LDS-DMA ring kernel: aligned operands; rows-contiguous operands need a plain k stride
+  static const int use_dma = getenv("S2ST_GEMM_DMA") ? atoi(getenv("S2ST_GEMM_DMA")) : 1;
+  const bool dma_ok = vec && use_dma && (g.A.kmajor || g.A.sp.per <= 0) && (g.B.kmajor || g.B.sp.per <= 0);
+  if (dma_ok) {
+    int rc;
+    static const int nw8 = getenv("S2ST_GEMM_NW8") ? atoi(getenv("S2ST_GEMM_NW8")) : 1;
+    if (bm == 128 && bn == 128) rc = nw8 ? launch_dma<128, 128, 4, 8>(g, grid, st) : launch_dma<128, 128, 4, 4>(g, grid, st);
+    else if (bm == 128) rc = nw8 ? launch_dma<128, 64, 4, 8>(g, grid, st) : launch_dma<128, 64, 4, 4>(g, grid, st);
+    else rc = launch_dma<64, 64, 4, 4>(g, grid, st);
+    if (rc) return rc;
+  } else
   if (!vec) launch_layouts<64, 64, false>(g, grid, st);
   else if (bm == 128 && bn == 128) launch_layouts<128, 128, true>(g, grid, st);
   else if (bm == 128) launch_layouts<128, 64, true>(g, grid, st);

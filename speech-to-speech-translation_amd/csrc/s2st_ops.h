@@ -51,7 +51,8 @@ inline GemmEpilogue gemm_epi_default() {
 }
 
 int s2st_gemm(GemmArgs g, hipStream_t st);
-int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* tile_out);  // gemm_bf16.hip (both operands bf16)
+int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* tile_out);
+int s2st_gemm_bf16_preload(hipStream_t st);  // load every instantiation (empty launches)  // gemm_bf16.hip (both operands bf16)
 void s2st_gemm_profile_enable(int on);
 int s2st_gemm_profile_read(double* flops, double* ms, long* launches);
 

@@ -5,6 +5,7 @@
 #include <thread>
 #include <vector>
 
+thread_local unsigned char emu_dyn_smem[160 * 1024];
 thread_local emu_uint3 threadIdx, blockIdx;
 thread_local dim3 blockDim, gridDim;
 

@@ -156,6 +156,20 @@ static inline emu_s16x4 emu_ds_read_tr16(const void* p) {
 }
 #define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu_ds_read_tr16((const void*)(p))
 #define __builtin_amdgcn_readfirstlane(x) (emu_shfl_idx((x), 0))
+// dynamic LDS: one 160 KiB buffer per workgroup thread (emu_runtime.cpp)
+extern thread_local unsigned char emu_dyn_smem[160 * 1024];
+#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(emu_dyn_smem);
+// global_load_lds_dwordx4: LDS destination = wave-uniform base (lane 0's pointer) + lane * size;
+// the global source is per lane.  Completion is immediate here (waitcnt / s_barrier are no-op / sync).
+static inline void emu_global_load_lds(const void* g, void* l, unsigned size, int offset, unsigned) {
+  void* base = emu_shfl_idx(l, 0);
+  memcpy((unsigned char*)base + offset + (size_t)emu_lane() * size, (const unsigned char*)g + offset, size);
+}
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_global_load_lds((const void*)(g), (void*)(l), size, off, aux)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_s_barrier() emu_syncthreads()
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 

@@ -19,6 +19,8 @@ def run(tag, M, N, K, akm, bkm, accumulate=False, iters=30, batch=1, dt=torch.fl
     C = torch.zeros(batch, M, r8(N), device=dev)
     kw = dict(a_kmajor=akm, b_kmajor=bkm, accumulate=accumulate, a_ld=A.shape[2], b_ld=B.shape[2], c_ld=r8(N),
               batch=batch, a_zo=A.shape[1] * A.shape[2], b_zo=B.shape[1] * B.shape[2], c_zo=M * r8(N))
+    if accumulate and dt == torch.bfloat16:
+        kw["ws"] = WS
     f = lambda: bd.gemm(A, B, C, M, N, K, **kw)
     for _ in range(3): f()
     torch.cuda.synchronize()
@@ -32,6 +34,7 @@ def run(tag, M, N, K, akm, bkm, accumulate=False, iters=30, batch=1, dt=torch.fl
           f"{t*1e6:8.1f} us  {2.0*M*N*K*batch/t/1e12:7.1f} TF/s", flush=True)
 
 
+WS = torch.empty(16 << 20, device=dev)
 Mr, Md = 4584, 3120
 cases = [
     ("fc1 fwd", Mr, 2048, 512, True, True, False, 1), ("fc2 fwd", Mr, 512, 2048, True, True, False, 1),
