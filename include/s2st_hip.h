@@ -44,7 +44,7 @@ typedef struct {
 
 typedef struct {
   float alpha;
-  int32_t act;        /* 0 none, 1 relu */
+  int32_t act;        /* 0 none, 1 relu, 2 exact (erf) gelu */
   const float* bias;  /* [N] or NULL */
   float drop_p;       /* dropout after activation, 0 = off */
   int32_t accumulate; /* C += value */
@@ -266,6 +266,26 @@ int s2st_engine_backward(s2st_engine* e, float gscale, int32_t segment, void* st
 int32_t s2st_engine_num_segments(const s2st_engine* e);
 /* after segment i has run, gradients in arena range [lo, hi) are final */
 int s2st_engine_segment_range(const s2st_engine* e, int32_t i, int64_t* lo, int64_t* hi);
+
+/* ---- frozen HuBERT front end of config 4 (--use-hubert): fairseq/models/hubert/hubert.py:412-461,
+ * 518-534 (extract_features, eval, mask=False) with wav2vec2.py:736-905.  The handle is an
+ * s2st_engine in "hubert mode": parameters are enumerated / bound with s2st_engine_param_info,
+ * s2st_engine_bind(params, NULL, NULL) and s2st_engine_bind_bf16; conv weights are stored in GEMM
+ * layout [O][k][I] and the weight-normed pos_conv as its effective weight [G][E/G][k][E/G] (the host
+ * wrapper converts from the reference state_dict).  Forward only. */
+typedef struct {
+  int32_t n_conv;
+  int32_t conv_dim[8], conv_k[8], conv_stride[8];
+  int32_t embed, layers, heads, ffn, conv_pos, conv_pos_groups;
+  int32_t precise;
+} s2st_hubert_config;
+int s2st_hubert_create(const s2st_hubert_config* cfg, s2st_engine** out);
+int32_t s2st_hubert_out_frames(const s2st_engine* e, int32_t n_samples);
+int64_t s2st_hubert_workspace_floats(s2st_engine* e, int32_t B, int32_t N);
+/* wave [B][N] fp32 (zero right-padded), frame_lens [B] = valid output frames per utterance
+ * (hubert.py:400-410 applied to the sample padding mask) -> out [B][T'][embed] fp32 */
+int s2st_hubert_forward(s2st_engine* e, const float* wave, const int32_t* frame_lens, int32_t B, int32_t N,
+                        float* out, float* workspace, int64_t workspace_floats, void* stream);
 
 /* Measurement aid (bench.py roofline leg): bracket every GEMM launch with HIP events on its
  * own stream; read returns the sum of as-launched FLOPs (2*M*N*K*batch), the sum of kernel

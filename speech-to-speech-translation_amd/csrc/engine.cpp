@@ -71,6 +71,32 @@ struct s2st_engine {
   std::vector<PInfo> infos;
   long n_params = 0, n_buffers = 0;
   float *P = nullptr, *G = nullptr, *BUF = nullptr;
+  // weight-gradient GEMMs are off the backward critical path: they run on a second stream, next
+  // to the data-gradient chain (each of these GEMMs alone fills about half of the 256 CUs)
+  hipStream_t side_ = nullptr;
+  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+  bool side_used = false;
+  float* skws_side = nullptr;
+  hipStream_t fork_side() {  // everything issued on st_ so far happens-before what follows on the returned stream
+    if (!side_) return st_;
+    hipEventRecord(ev_fork_, st_);
+    hipStreamWaitEvent(side_, ev_fork_, 0);
+    side_used = true;
+    return side_;
+  }
+  void join_side() {
+    if (!side_ || !side_used) return;
+    hipEventRecord(ev_join_, side_);
+    hipStreamWaitEvent(st_, ev_join_, 0);
+    side_used = false;
+  }
+  int ffn_act = 1;        // 1 relu (s2st layers), 2 gelu (HuBERT layers)
+  // ---- frozen HuBERT front end (config 4): same engine object in "hubert mode" -------------
+  bool is_hubert = false;
+  s2st_hubert_config hc{};
+  struct HubP {
+    long conv_w[8]; long gn_g, gn_b; LNP ln; LinP proj; long pos_w, pos_b; std::vector<EncLayerP> L; LNP enc_ln;
+  } hp;
   float* skws = nullptr;  // split-K partial-sum scratch of the weight-gradient GEMMs (per call)
   long skws_n = 0;
   bf16raw* PH = nullptr;  // bf16 copy of the parameter arena (same offsets), refreshed every forward
@@ -370,9 +396,10 @@ struct s2st_engine {
         g.C = gemm_out(G + w, K);
         g.ep = gemm_epi_default();
         g.ep.accumulate = 1;
-        g.ws = skws; g.ws_floats = skws_n;
+        hipStream_t ws_st = fm ? fork_side() : st_;
+        g.ws = ws_st == st_ ? skws : skws_side; g.ws_floats = skws_n;
         g.M = N; g.N = K; g.K = M; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
-        chk(s2st_gemm(g, st_));
+        chk(s2st_gemm(g, ws_st));
         if (b >= 0 && !bias_done) chk(s2st_colsum(dpre, N, M, N, G + b, 1, st_));
       }
       if (x->needs_grad) {
@@ -524,7 +551,7 @@ struct s2st_engine {
     return linear(o, a.out_w, a.out_b, C, C, 0, bt.training ? c.dropout : 0.f, resid);
   }
   Ten* ffn_block(Ten* x, const LinP& fc1, const LinP& fc2, Ten* resid) {
-    Ten* h = linear(x, fc1.w, fc1.b, fc1.N, fc1.K, 1, bt.training ? c.act_dropout : 0.f);
+    Ten* h = linear(x, fc1.w, fc1.b, fc1.N, fc1.K, ffn_act, bt.training ? c.act_dropout : 0.f);
     return linear(h, fc2.w, fc2.b, fc2.N, fc2.K, 0, bt.training ? c.dropout : 0.f, resid);
   }
   Ten* enc_layer(Ten* x, const EncLayerP& l, int B, int T) {
@@ -680,6 +707,126 @@ struct s2st_engine {
     return linear(x, a.out_proj, -1, a.V, 512, 0, 0.f, nullptr, logits_out);
   }
 
+
+  // ------------------------------------------------------------------------------------
+  // HuBERT (fairseq/models/hubert/hubert.py:412-461, 518-534; wav2vec2.py:736-905): parameters in
+  // GEMM-ready layouts (conv weights [O][k][I], the weight-normed pos_conv as its effective weight
+  // [G][E/G][k][E/G]); the host wrapper converts from the reference state_dict layouts.
+  void build_params_hubert() {
+    int cin = 1;
+    for (int i = 0; i < hc.n_conv; ++i) {
+      std::string pre = "feature_extractor.conv_layers." + std::to_string(i);
+      hp.conv_w[i] = add(pre + ".0.weight", {hc.conv_dim[i], hc.conv_k[i], cin});
+      if (i == 0) {
+        hp.gn_g = add(pre + ".2.weight", {hc.conv_dim[0]});
+        hp.gn_b = add(pre + ".2.bias", {hc.conv_dim[0]});
+      }
+      cin = hc.conv_dim[i];
+    }
+    hp.ln = add_ln("layer_norm", cin);
+    hp.proj = add_lin("post_extract_proj", hc.embed, cin);
+    const int Eg = hc.embed / hc.conv_pos_groups;
+    hp.pos_w = add("encoder.pos_conv.0.weight", {hc.conv_pos_groups, Eg, hc.conv_pos, Eg});
+    hp.pos_b = add("encoder.pos_conv.0.bias", {hc.embed});
+    for (int l = 0; l < hc.layers; ++l) {
+      std::string pre = "encoder.layers." + std::to_string(l);
+      EncLayerP e;
+      e.sa = add_self_attn(pre + ".self_attn", hc.embed);
+      e.ln1 = add_ln(pre + ".self_attn_layer_norm", hc.embed);
+      e.fc1 = add_lin(pre + ".fc1", hc.ffn, hc.embed);
+      e.fc2 = add_lin(pre + ".fc2", hc.embed, hc.ffn);
+      e.ln2 = add_ln(pre + ".final_layer_norm", hc.embed);
+      hp.L.push_back(e);
+    }
+    hp.enc_ln = add_ln("encoder.layer_norm", hc.embed);
+  }
+
+  int hubert_frames(int n) const {
+    for (int i = 0; i < hc.n_conv; ++i) n = n < hc.conv_k[i] ? 0 : (n - hc.conv_k[i]) / hc.conv_stride[i] + 1;
+    return n;
+  }
+
+  int forward_hubert(const float* wave, const int* frame_lens, int B, int N, float* out) {
+    const bool fm = fast();
+    if (fm && !PH && !dry) return S2ST_ERR_ARG;
+    bt = s2st_batch{};
+    bt.B = B;
+    bt.training = 0;
+    bt.enc_lens = frame_lens;
+    skws = nullptr; skws_n = 0; skws_side = nullptr;
+    // conv0 (1 -> C0) + GroupNorm(C0, C0) over ALL Tn frames of the padded batch + GELU
+    const int C0 = hc.conv_dim[0];
+    int Tin = (N - hc.conv_k[0]) / hc.conv_stride[0] + 1;
+    if (N < hc.conv_k[0] || Tin <= 0) return S2ST_ERR_SHAPE;
+    Ten* a = newT(B * Tin, C0);
+    float* mean = alloc((long)B * C0);
+    float* var = alloc((long)B * C0);
+    float* tmp = alloc(2L * C0);
+    if (fm) a->h = alloc_h(a->n());
+    if (live()) {
+      chk(s2st_hubert_conv0(wave, P + hp.conv_w[0], a->d, B, N, Tin, C0, hc.conv_k[0], hc.conv_stride[0], st_));
+      for (int b = 0; b < B; ++b)
+        chk(s2st_bn_stats(a->d + (long)b * Tin * C0, Tin, C0, mean + (long)b * C0, var + (long)b * C0, nullptr, nullptr,
+                          0.f, tmp, st_));
+      chk(s2st_gn_gelu(a->d, mean, var, P + hp.gn_g, P + hp.gn_b, a->h, B, Tin, C0, 1e-5f, st_));
+    }
+    // conv_i + GELU as GEMMs over the channel-last activations (no padding: windows never cross utterances)
+    for (int i = 1; i < hc.n_conv; ++i) {
+      const int k = hc.conv_k[i], sd = hc.conv_stride[i], I = hc.conv_dim[i - 1], O = hc.conv_dim[i];
+      const int Tout = Tin < k ? 0 : (Tin - k) / sd + 1;
+      if (Tout <= 0) return S2ST_ERR_SHAPE;
+      Ten* y = newT(B * Tout, O);
+      if (fm) y->h = alloc_h(y->n());
+      if (live()) {
+        GemmArgs g{};
+        g.A = fm ? gemm_rowmajor(a->h, (long)sd * I) : gemm_rowmajor(a->d, (long)sd * I);
+        g.A.sp.per = Tout; g.A.sp.bs = (long)Tin * I;
+        g.B = fm ? gemm_rowmajor(PH + hp.conv_w[i], (long)k * I) : gemm_rowmajor(P + hp.conv_w[i], (long)k * I);
+        g.C = gemm_out(y->d, O);
+        g.C.h = y->h;
+        g.ep = gemm_epi_default();
+        g.ep.act = 2;
+        g.M = B * Tout; g.N = O; g.K = k * I; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
+        chk(s2st_gemm(g, st_));
+      }
+      a = y;
+      Tin = Tout;
+    }
+    const int T = Tin, E = hc.embed, G = hc.conv_pos_groups, Eg = E / G, kp = hc.conv_pos;
+    Ten* x = linear(layernorm(a, hp.ln), hp.proj.w, hp.proj.b, E, hp.proj.K);
+    // padded frames -> 0 (wav2vec2.py:870-871); x += gelu(pos_conv(x)) with SamePad (:873-875)
+    const int pad = kp / 2, Tp = T + kp;
+    float* img = fm ? nullptr : alloc((long)G * B * Tp * Eg, true);
+    bf16raw* imgh = fm ? alloc_h((long)G * B * Tp * Eg) : nullptr;
+    if (fm && live()) hipMemsetAsync(imgh, 0, sizeof(bf16raw) * (size_t)G * B * Tp * Eg, st_);
+    Ten* x2 = newT(B * T, E);
+    if (live()) {
+      chk(s2st_posconv_prep(x->d, frame_lens, img, imgh, B, T, E, G, pad, Tp, st_));
+      for (int gi = 0; gi < G; ++gi) {
+        GemmArgs g{};
+        const long io = (long)gi * B * Tp * Eg, wo = hp.pos_w + (long)gi * Eg * kp * Eg;
+        g.A = fm ? gemm_rowmajor(imgh + io, Eg) : gemm_rowmajor(img + io, Eg);
+        g.A.sp.per = T; g.A.sp.bs = (long)Tp * Eg;
+        g.B = fm ? gemm_rowmajor(PH + wo, (long)kp * Eg) : gemm_rowmajor(P + wo, (long)kp * Eg);
+        g.C = gemm_out(x2->d + (long)gi * Eg, E);
+        g.ep = gemm_epi_default();
+        g.ep.bias = P + hp.pos_b + (long)gi * Eg;
+        g.ep.act = 2;
+        g.ep.resid = x->d + (long)gi * Eg;
+        g.M = B * T; g.N = Eg; g.K = kp * Eg; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
+        chk(s2st_gemm(g, st_));
+      }
+    }
+    Ten* y = layernorm(x2, hp.enc_ln);
+    for (int l = 0; l < hc.layers; ++l) {
+      const bool last = l == hc.layers - 1;
+      const EncLayerP& L = hp.L[l];
+      y = layernorm(self_attn_block(y, L.sa, B, T, hc.heads, frame_lens, 0, y), L.ln1);
+      y = layernorm(ffn_block(y, L.fc1, L.fc2, y), L.ln2, last ? out : nullptr);
+    }
+    return err;
+  }
+
   // ------------------------------------------------------------------------------------
   void reset_call() {
     for (Ten* t : tens) delete t;
@@ -715,6 +862,7 @@ struct s2st_engine {
     if (fm && live()) chk(s2st_cast_bf16_rows(P, n_params, PH, n_params, 1, (int)n_params, st_));
     skws_n = fm ? (long)16 << 20 : 0;
     skws = fm ? alloc(skws_n) : nullptr;
+    skws_side = fm && side_ ? alloc(skws_n) : skws;
     typedef ConvW ConvScratch;
     auto conv_scratch = [&](const ConvP& p, bool need_wd) {
       ConvScratch s;
@@ -932,8 +1080,9 @@ struct s2st_engine {
     size_t hi = marks[ns - seg].tape_idx, lo = marks[ns - seg - 1].tape_idx;
     for (size_t i = hi; i-- > lo;) {
       tape[i]();
-      if (err) return err;
+      if (err) break;
     }
+    join_side();  // the segment's weight gradients are complete in st_ order
     return err;
   }
 };
@@ -957,12 +1106,26 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->f32_operands = getenv("S2ST_F32_OPERANDS") && atoi(getenv("S2ST_F32_OPERANDS")) != 0;
   e->build_params();
   if (!cfg->precise && s2st_gemm_bf16_preload(nullptr) != 0) { delete e; return S2ST_ERR_LAUNCH; }
+  if (!cfg->precise && !(getenv("S2ST_NO_SIDE_STREAM") && atoi(getenv("S2ST_NO_SIDE_STREAM")))) {
+    if (hipStreamCreateWithFlags(&e->side_, hipStreamNonBlocking) != hipSuccess) e->side_ = nullptr;
+    if (e->side_ && (hipEventCreateWithFlags(&e->ev_fork_, hipEventDisableTiming) != hipSuccess ||
+                     hipEventCreateWithFlags(&e->ev_join_, hipEventDisableTiming) != hipSuccess)) {
+      hipStreamDestroy(e->side_);
+      e->side_ = nullptr;
+    }
+  }
   *out = e;
   return 0;
 }
 
 void s2st_engine_destroy(s2st_engine* e) {
   if (!e) return;
+  if (e->side_) {
+    hipStreamSynchronize(e->side_);
+    hipStreamDestroy(e->side_);
+    hipEventDestroy(e->ev_fork_);
+    hipEventDestroy(e->ev_join_);
+  }
   e->reset_call();
   delete e;
 }
@@ -1053,6 +1216,68 @@ int s2st_engine_segment_range(const s2st_engine* e, int32_t i, int64_t* lo, int6
   *lo = e->marks[ns - i - 1].param_off;
   *hi = e->marks[ns - i].param_off;
   return 0;
+}
+
+// ---- HuBERT front end ---------------------------------------------------------------------------
+int s2st_hubert_create(const s2st_hubert_config* cfg, s2st_engine** out) {
+  if (!cfg || !out || cfg->n_conv < 1 || cfg->n_conv > 8) return S2ST_ERR_ARG;
+  if (cfg->embed % cfg->heads || cfg->embed % cfg->conv_pos_groups || cfg->conv_dim[0] % 4 ||
+      (cfg->embed / cfg->conv_pos_groups) % 4 || cfg->embed % 4)
+    return S2ST_ERR_SHAPE;
+  if (!cfg->precise) {
+    for (int i = 0; i < cfg->n_conv; ++i)
+      if (cfg->conv_dim[i] % 8) return S2ST_ERR_SHAPE;
+    if (cfg->embed % 8 || cfg->ffn % 8 || (cfg->embed / cfg->conv_pos_groups) % 8) return S2ST_ERR_SHAPE;
+  }
+  s2st_engine* e = new s2st_engine();
+  e->is_hubert = true;
+  e->hc = *cfg;
+  e->c = s2st_model_config{};
+  e->c.precise = cfg->precise;
+  e->c.enc_heads = cfg->heads;
+  e->c.enc_dim = cfg->embed;
+  e->ffn_act = 2;
+  e->f32_operands = getenv("S2ST_F32_OPERANDS") && atoi(getenv("S2ST_F32_OPERANDS")) != 0;
+  e->build_params_hubert();
+  if (!cfg->precise && s2st_gemm_bf16_preload(nullptr) != 0) { delete e; return S2ST_ERR_LAUNCH; }
+  *out = e;
+  return 0;
+}
+
+int32_t s2st_hubert_out_frames(const s2st_engine* e, int32_t n_samples) { return e->hubert_frames(n_samples); }
+
+int64_t s2st_hubert_workspace_floats(s2st_engine* e, int32_t B, int32_t N) {
+  if (!e->is_hubert) return S2ST_ERR_ARG;
+  e->reset_call();
+  e->dry = true;
+  e->ws = reinterpret_cast<float*>(0x10000);
+  e->ws_cap = (long)1 << 50;
+  e->st_ = nullptr;
+  int rc = e->forward_hubert(nullptr, nullptr, B, N, nullptr);
+  long peak = e->ws_peak;
+  e->reset_call();
+  e->dry = false;
+  return rc ? (int64_t)rc : (int64_t)peak + 1024;
+}
+
+int s2st_hubert_forward(s2st_engine* e, const float* wave, const int32_t* frame_lens, int32_t B, int32_t N, float* out,
+                        float* workspace, int64_t workspace_floats, void* stream) {
+  if (!e->is_hubert || !e->P || !wave || !frame_lens || !out) return S2ST_ERR_ARG;
+  e->reset_call();
+  e->dry = false;
+  e->ws = workspace;
+  e->ws_cap = workspace_floats;
+  e->st_ = (hipStream_t)stream;
+  const bool fm = e->fast();
+  if (fm && !e->PH) return S2ST_ERR_ARG;
+  // frozen weights: the bf16 copy is refreshed every call (cheap next to the conv stack)
+  if (fm) {
+    int rc = s2st_cast_bf16_rows(e->P, e->n_params, e->PH, e->n_params, 1, (int)e->n_params, e->st_);
+    if (rc) return rc;
+  }
+  int rc = e->forward_hubert(wave, frame_lens, B, N, out);
+  e->tape.clear();  // forward only: the front end is frozen (s2st_transformer.py:245-249)
+  return rc;
 }
 
 }  // extern "C"

@@ -237,6 +237,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         float v = g.ep.alpha * acc[i][j][r];
         if (g.ep.bias && lead) v += g.ep.bias[n];
         if (g.ep.act == 1) v = fmaxf(v, 0.f);
+        else if (g.ep.act == 2) v = gelu_erf(v);
         if (g.ep.drop_p > 0.f)
           v *= drop_scale(g.ep.seed, ((uint64_t)zb * g.M + m) * (uint64_t)g.N + n, g.ep.drop_p, inv_keep);
         if (rbase && lead) v += rbase[roff + n];

@@ -212,6 +212,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
       if (g.ep.act == 1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      } else if (g.ep.act == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
       }
       if (g.ep.drop_p > 0.f) {
         const uint64_t e0 = ((uint64_t)zb * g.M + m) * (uint64_t)g.N + n;

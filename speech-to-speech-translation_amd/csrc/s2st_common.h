@@ -55,6 +55,9 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// exact GELU (nn.GELU(), fairseq utils.gelu: 0.5 x (1 + erf(x / sqrt 2)))
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
 // Counter-based dropout RNG: keep(element) is a pure function of (seed, element index), so
 // the backward pass regenerates the forward mask without storing it.
 __device__ __forceinline__ uint32_t mix64(uint64_t x) {

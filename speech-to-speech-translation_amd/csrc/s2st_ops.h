@@ -143,6 +143,16 @@ int s2st_bn_bwd(const float* dy, Split dysp, const float* x, const float* mean, 
                 uint64_t seed, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------
+// HuBERT front end (hubert.hip): waveform conv, GroupNorm(C, C) + GELU, pos-conv input re-layout
+// ---------------------------------------------------------------------------------------
+int s2st_hubert_conv0(const float* x, const float* w, float* y, int B, int N, int T, int C, int k, int stride,
+                      hipStream_t st);
+int s2st_gn_gelu(float* x, const float* mean, const float* var, const float* gamma, const float* beta, uint16_t* xh,
+                 int B, int T, int C, float eps, hipStream_t st);
+int s2st_posconv_prep(float* x, const int* lens, float* img, uint16_t* imgh, int B, int T, int E, int G, int pad,
+                      int Tp, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------
 // losses (losses.hip)
 // ---------------------------------------------------------------------------------------
 // stats (optional) += {sum|fo-t| + sum|fp-t|, sum(fo-t)^2 + sum(fp-t)^2, sum bce} over valid

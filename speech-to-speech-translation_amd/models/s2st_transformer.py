@@ -86,8 +86,6 @@ class S2STTransformerModel(nn.Module):
         base_architecture(args)
         if getattr(args, "activation_fn", "relu") != "relu":
             raise NotImplementedError("the HIP path implements the reference default activation (relu)")
-        if str(getattr(args, "use_hubert", "false")) == "true":
-            raise NotImplementedError("frozen-HuBERT front end (config 4) is not built yet on the HIP path")
         if not hasattr(args, "src_vocab_size"):
             args.src_vocab_size = len(task.source_dictionary)
             args.tgt_vocab_size = len(task.target_dictionary)
@@ -97,6 +95,21 @@ class S2STTransformerModel(nn.Module):
     def __init__(self, args, device: torch.device, precise: bool = False):
         super().__init__()
         self.args = args
+        # frozen HuBERT front end (s2st_transformer.py:685-703): hubert_base geometry unless the
+        # caller passes ``hubert_geometry`` (tests); weights from --load-pretrained-hubert-from
+        self.hubert = None
+        if str(getattr(args, "use_hubert", "false")) == "true":
+            from .hubert import HubertFrontend
+            geo = dict(getattr(args, "hubert_geometry", None) or {})
+            if not geo:
+                geo = dict(embed=getattr(args, "hubert_hidden", 768))
+            self.hubert = HubertFrontend(device, precise=precise, **geo)
+            if self.hubert.embed != getattr(args, "hubert_hidden", 768):
+                raise ValueError("--hubert-hidden must equal the HuBERT embedding width")
+            path = getattr(args, "load_pretrained_hubert_from", None)
+            if path:
+                ck = torch.load(path, map_location="cpu")
+                self.hubert.load_state_dict(ck["model"] if "model" in ck else ck, strict=True)
         self.engine = Engine(args, device, precise=precise)
         self._views = {}
         for name, pv, gv, is_buf in self.engine.named_views():
@@ -186,10 +199,20 @@ class S2STTransformerModel(nn.Module):
             sample["tgt_text_len"] = prev_tgt_text_tokens.ne(1).sum(1)
         return self.engine.forward(sample, training=self.training, want_attn=want_attn, with_loss=False)
 
+    def _front_end(self, src_tokens, src_lengths, collated_audios, padding_mask):
+        """s2st_transformer.py:245-252: with --use-hubert the encoder input is the frozen HuBERT's
+        features and the lengths are its un-padded frame counts."""
+        if self.hubert is None:
+            return src_tokens, src_lengths
+        self.hubert.eval()
+        feats, pad = self.hubert.extract_features(collated_audios, padding_mask)
+        return feats, (~pad).long().sum(-1)
+
     def forward(self, src_tokens, src_lengths, collated_audios, padding_mask, prev_output_tokens,
                 **kwargs):
         """Returns ``[(post_feat_out, eos_out, extra), (asr_logits, None) | None,
         (st_logits, None) | None]`` as s2st_transformer.py:752-786."""
+        src_tokens, src_lengths = self._front_end(src_tokens, src_lengths, collated_audios, padding_mask)
         o = self._run(src_tokens, src_lengths, prev_output_tokens, kwargs["target_lengths"],
                       kwargs.get("prev_src_text_tokens"), kwargs.get("prev_tgt_text_tokens"))
         taps = [o[k].transpose(0, 1) for k in ("tap0", "tap1") if k in o]
@@ -200,6 +223,7 @@ class S2STTransformerModel(nn.Module):
 
     def forward_encoder(self, src_tokens, src_lengths, collated_audios=None, padding_mask=None,
                         speaker=None, **kwargs):
+        src_tokens, src_lengths = self._front_end(src_tokens, src_lengths, collated_audios, padding_mask)
         B = src_tokens.shape[0]
         dummy = torch.zeros(B, 1, self.engine.cfg.out_dim)
         o = self._run(src_tokens, src_lengths, dummy, torch.ones(B, dtype=torch.long), want_attn=False)

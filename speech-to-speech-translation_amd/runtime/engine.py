@@ -74,7 +74,9 @@ def config_from_args(a, precise: bool = False) -> ModelConfig:
     c.enc_ffn, c.dec_ffn = a.encoder_ffn_embed_dim, a.decoder_ffn_embed_dim
     c.enc_heads, c.dec_heads = a.encoder_attention_heads, a.decoder_attention_heads
     c.enc_pre_ln, c.dec_pre_ln = int(a.encoder_normalize_before), int(a.decoder_normalize_before)
-    c.in_dim = a.input_feat_per_channel * a.input_channels
+    # --use-hubert: the subsampler's first conv reads HuBERT features (s2st_transformer.py:162-163)
+    c.in_dim = (a.hubert_hidden if str(getattr(a, "use_hubert", "false")) == "true"
+                else a.input_feat_per_channel * a.input_channels)
     c.conv_channels, c.conv_k = 1024, ks[0]  # --conv-channels is ignored by the reference (:802)
     c.out_dim = a.output_frame_dim * a.n_frames_per_step
     c.prenet_layers, c.prenet_dim = a.prenet_layers, a.prenet_dim

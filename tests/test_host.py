@@ -153,3 +153,34 @@ def test_tiny_golden_train_steps(backend, golden_dir):
     pn = dict(zip(z["train.param_norm_names"].tolist(), z["train.param_norms"].tolist()))
     for n, p in model.named_parameters():
         np.testing.assert_allclose(float(p.detach().norm()), pn[n], rtol=1e-4, err_msg=n)
+
+
+def test_use_hubert_front_end_feeds_the_encoder(backend):
+    """Config 4 wiring (s2st_transformer.py:245-252): with --use-hubert the model runs the frozen HuBERT
+    front end on the collated audio, and the encoder (first conv now hubert_hidden wide) consumes its
+    features with the frame-level lengths.  Compared with oracle HuBERT -> oracle S2ST model."""
+    import hubert_oracle as HO
+    geo = dict(HO.TINY)
+    cfg = dict(NANO, use_hubert="true", hubert_hidden=geo["embed"])
+    a, task, model, crit, trainer = _build(backend, cfg, hubert_geometry=geo)
+    assert model.hubert is not None and model.engine.cfg.in_dim == geo["embed"]
+    model.hubert.load_state_dict(HO.synth_state(geo))
+    a2 = O.make_args(**cfg)
+    a2._hubert_input = True
+    m = O.S2STModel(a2)
+    load_synth(m, 0)
+    m.eval()
+    model.eval()
+    wave, pad, _ = HO.synth_audio(2, 9000, 5)
+    s = nano_batches()[0]
+    ni = s["net_input"]
+    out = model(None, None, wave, pad, ni["prev_output_tokens"], target_lengths=s["target_lengths"],
+                prev_src_text_tokens=ni["prev_src_text_tokens"], prev_tgt_text_tokens=ni["prev_tgt_text_tokens"])
+    backend.sync()
+    feats, fpm = HO.extract_features(HO.synth_state(geo), geo, wave, pad)
+    lens = (~fpm).long().sum(-1)
+    (rp, re_, rx), rasr, rst, _ = m(feats, lens, ni["prev_output_tokens"], s["target_lengths"],
+                                    ni["prev_src_text_tokens"], ni["prev_tgt_text_tokens"])
+    (post, eos, extra), asr, st = out
+    for x, y in ((post, rp), (eos, re_), (asr[0], rasr)):
+        assert float((x.cpu() - y).abs().max()) < 5e-4 * float(y.abs().max())

@@ -1,0 +1,92 @@
+"""Frozen HuBERT front end: the HIP path (through the C ABI,
+s2st_hubert_*) against the oracle and against golden vectors produced by the reference's own
+HubertModel (oracle/gen_golden_hubert.py)."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import hubert_oracle as HO
+
+HUB = "speech-to-speech-translation_amd.models.hubert"
+
+
+def make_frontend(backend, cfg, precise):
+    M = importlib.import_module(HUB)
+    f = M.HubertFrontend(backend.device, conv=cfg["conv"], embed=cfg["embed"], layers=cfg["layers"], heads=cfg["heads"],
+                         ffn=cfg["ffn"], conv_pos=cfg["conv_pos"], conv_pos_groups=cfg["conv_pos_groups"], precise=precise)
+    f.load_state_dict(HO.synth_state(cfg))
+    return f
+
+
+def test_oracle_against_reference_golden(golden_dir):
+    """CPU: the restatement reproduces what the reference HubertModel produced (pins the oracle)."""
+    for name in ("tiny", "base"):
+        z = np.load(os.path.join(golden_dir, f"hubert_{name}.npz"))
+        cfg = HO.HUBERT_CONFIGS[name]
+        wave, pad, _ = HO.synth_audio(int(z["B"]), int(z["N"]), int(z["seed"]))
+        y, fpm = HO.extract_features(HO.synth_state(cfg), cfg, wave, pad)
+        assert np.array_equal(fpm.numpy(), z["frame_pad"])
+        if name == "tiny":
+            np.testing.assert_allclose(y.numpy(), z["out"], rtol=0, atol=2e-5 * np.abs(z["out"]).max())
+        else:
+            np.testing.assert_allclose(y.numpy()[:, ::5, ::16], z["sample"], rtol=0, atol=2e-5 * np.abs(z["sample"]).max())
+            assert abs(float(y.abs().sum()) - z["sum"][1]) < 1e-4 * z["sum"][1]
+
+
+@pytest.mark.parametrize("precise", [True, False], ids=["bf16x3", "bf16"])
+def test_tiny_hubert_vs_golden_and_oracle(backend, golden_dir, precise):
+    """Whole front end on the tiny geometry: conv0 + GroupNorm + GELU, 6 conv GEMMs, LN, projection,
+    padded-frame zeroing, grouped weight-normed pos-conv (+SamePad), 2 post-LN layers with key
+    padding.  Tolerances: bf16x3 GEMMs 2e-4 of the output scale; bf16 operands 3e-2."""
+    z = np.load(os.path.join(golden_dir, "hubert_tiny.npz"))
+    cfg = HO.TINY
+    f = make_frontend(backend, cfg, precise)
+    wave, pad, lens = HO.synth_audio(int(z["B"]), int(z["N"]), int(z["seed"]))
+    y, fpm = f.extract_features(wave, pad)
+    backend.sync()
+    assert np.array_equal(fpm.cpu().numpy(), z["frame_pad"])  # bit-exact (integer / bool work)
+    ref = torch.from_numpy(z["out"])
+    tol = 2e-4 if precise else 3e-2
+    valid = ~torch.from_numpy(z["frame_pad"])
+    err = ((y.cpu() - ref).abs() * valid.unsqueeze(-1)).max() / ref.abs().max()
+    assert float(err) < tol, float(err)
+    # state_dict round trip in the reference's names / layouts
+    sd = f.state_dict()
+    for k, v in HO.synth_state(cfg).items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+        assert float((sd[k].cpu() - v).abs().max()) == 0.0, k
+
+
+def test_tiny_hubert_other_batch_against_oracle(backend):
+    """A second seeded batch (different lengths, no golden): HIP path vs the oracle."""
+    cfg = HO.TINY
+    f = make_frontend(backend, cfg, True)
+    wave, pad, _ = HO.synth_audio(2, 2500, 21)
+    y, fpm = f.extract_features(wave, pad)
+    backend.sync()
+    yo, fo = HO.extract_features(HO.synth_state(cfg), cfg, wave, pad)
+    assert torch.equal(fpm.cpu(), fo)
+    err = ((y.cpu() - yo).abs() * (~fo).unsqueeze(-1)).max() / yo.abs().max()
+    assert float(err) < 2e-4, float(err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precise", [True, False], ids=["bf16x3", "bf16"])
+def test_base_hubert_golden(backend, golden_dir, precise):
+    """hubert_base geometry (7 convs x 512, 12 x 768, pos-conv k128 g16) against the reference's golden."""
+    if backend.kind != "hip":
+        pytest.skip("base geometry runs on the GPU")
+    z = np.load(os.path.join(golden_dir, "hubert_base.npz"))
+    cfg = HO.BASE
+    f = make_frontend(backend, cfg, precise)
+    wave, pad, _ = HO.synth_audio(int(z["B"]), int(z["N"]), int(z["seed"]))
+    y, fpm = f.extract_features(wave, pad)
+    backend.sync()
+    assert np.array_equal(fpm.cpu().numpy(), z["frame_pad"])
+    valid = (~torch.from_numpy(z["frame_pad"]))[:, ::5].unsqueeze(-1)
+    ref = torch.from_numpy(z["sample"])
+    err = ((y.cpu()[:, ::5, ::16] - ref).abs() * valid).max() / ref.abs().max()
+    assert float(err) < (3e-4 if precise else 4e-2), float(err)

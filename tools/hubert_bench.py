@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Time the frozen HuBERT-base front end on the GPU: python tools/hubert_bench.py [B] [seconds]"""
+import importlib, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import torch
+import s2st_amd  # noqa
+import hubert_oracle as HO
+M = importlib.import_module("speech-to-speech-translation_amd.models.hubert")
+dev = torch.device("cuda:0")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+secs = float(sys.argv[2]) if len(sys.argv) > 2 else 8.0
+N = int(16000 * secs)
+for precise in (False, True):
+    f = M.HubertFrontend(dev, precise=precise)
+    f.load_state_dict(HO.synth_state(HO.BASE))
+    wave, pad, _ = HO.synth_audio(B, N, 3)
+    wave, pad = wave.to(dev), pad
+    for _ in range(2):
+        f.extract_features(wave, pad)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    it = 3
+    for _ in range(it):
+        y, _ = f.extract_features(wave, pad)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / it
+    gmac = 7.2e9 * B * secs  # ~7.2 GMAC per second of audio, forward only
+    print(f"precise={precise} B={B} {secs}s audio: {dt*1e3:.1f} ms  -> {B*secs/dt:.0f} audio-s/s, ~{2*gmac/dt/1e12:.1f} TFLOP/s", flush=True)
