@@ -78,6 +78,31 @@ typedef struct {
  * examples/s2s_trans/models/s2st_transformer.py:135-139,452-455, tacotron2.py:95-126. */
 int s2st_gemm_f32(const s2st_gemm_args* args, void* stream);
 
+/* Fused multi-head attention (bf16 operands, head width 64 or 128): masks + fp32 online softmax +
+ * dropout + P*V in one kernel; backward recomputes the probabilities from the saved log-sum-exp.
+ * Replaces fairseq/modules/multihead_attention.py:224-367 (and the same steps inside
+ * F.multi_head_attention_forward, :170-192).  Row (b, t) of head h of q lives at
+ * q + (b*T + t)*ldq + h*dh (bf16 elements); k / v likewise with S rows; o, oh and doh are dense
+ * [B*T][H*dh]; dq / dk / dv (fp32) are addressed like q / k / v.  The dropout mask of element
+ * (b, h, t, s) is drop(seed, ((b*H + h)*T + t)*ld_drop + s) -- the unfused kernels' index space. */
+typedef struct {
+  const uint16_t *q, *k, *v;
+  int64_t ldq, ldk, ldv;
+  float* o;
+  uint16_t* oh;       /* optional bf16 copy of o */
+  float* lse;         /* [B*H*T] log-sum-exp of the masked, scaled scores */
+  const int32_t* klen; /* [B] valid keys per batch element, or NULL */
+  int32_t B, H, T, S, dh, causal;
+  float scale, drop_p;
+  uint64_t seed;
+  int32_t ld_drop;
+  const uint16_t* doh; /* backward: bf16 dO */
+  float *dq, *dk, *dv; /* backward outputs (overwritten) */
+} s2st_attn_args;
+int s2st_flash_attn_fwd_bf16(const s2st_attn_args* args, void* stream);
+/* dO: fp32 [B*T][H*dh]; dvec_scratch: B*H*T floats */
+int s2st_flash_attn_bwd_bf16(const s2st_attn_args* args, const float* dO, float* dvec_scratch, void* stream);
+
 /* fairseq/modules/layer_norm.py:11-35 (LayerNorm / FusedLayerNorm), forward; saves mean, rstd */
 int s2st_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int32_t rows, int32_t cols, float eps, void* stream);
 

@@ -1,0 +1,482 @@
+// Fused multi-head attention for gfx950 (fast / bf16-operand mode): scores, key-padding + causal masks,
+// fp32 online softmax, dropout on the probabilities and the P*V product in ONE kernel -- the
+// [B,H,T,S] score / probability tensors of the unfused path are never written to HBM -- plus the two
+// backward kernels (dK,dV and dQ) that recompute the probabilities from the saved log-sum-exp.
+//
+// Reference arithmetic replaced: fairseq/modules/multihead_attention.py:224 (q * dh^-0.5), :332 (bmm),
+// :343-355 (masks -> -inf), :360-366 (fp32 softmax, dropout), :367 (bmm) and the same steps inside
+// F.multi_head_attention_forward (:170-192); backward = the autograd of those ops.
+//
+// Layout / MFMA plan (v_mfma_f32_16x16x32_bf16, accumulator: col = lane & 15, row = 4 (lane >> 4) + r):
+//  * a wave owns 16 "column" items (queries in fwd / dQ, keys in dK,dV); their bf16 fragments stay in
+//    registers for the whole kernel; the other side is streamed through LDS in tiles of 32 rows;
+//  * the score tile is computed TRANSPOSED (rows = streamed items on the accumulator rows), so the
+//    probabilities a lane holds are exactly the B-operand fragment of the next MFMA (which sums over
+//    the streamed index): no LDS round trip, no cross-lane movement.  k-slot (g, j) of that MFMA is
+//    streamed row 4g + j (j < 4) / 16 + 4g + (j - 4); the A operand (V^T, dO^T, Q^T or K^T) is read
+//    from a natural [row][dh] LDS image with ds_read_b64_tr_b16 in the same order;
+//  * LDS images: "row image" [32][dh] with 16-byte chunk c at c ^ (row & (CH-1)) for ds_read_b128
+//    fragments, "tr image" [32][dh] with 32-byte pair c at c ^ f(row) for the transposed reads.
+// Softmax state (running max, partial sums) lives per lane: the 4 lanes that share a column reduce the
+// max with two shuffles per tile and the sum once at the end.
+#include "s2st_ops.h"
+
+namespace {
+
+typedef unsigned short bf16_t;
+
+template <int DH>
+struct Img {
+  static constexpr int PITCH = DH * 2;     // bytes per row
+  static constexpr int CH = DH / 8;        // 16-byte chunks per row
+  static constexpr int BYTES = 32 * PITCH;
+  __device__ static __forceinline__ int trkey(int row) { return DH >= 128 ? (row & 7) : ((row >> 1) & 3); }
+  // store 16-byte chunk `ch` of row `row` into both images' positions
+  __device__ static __forceinline__ int row_off(int row, int ch) { return row * PITCH + ((ch ^ (row & (CH - 1))) << 4); }
+  __device__ static __forceinline__ int tr_off(int row, int ch) {
+    return row * PITCH + (((((ch >> 1) ^ trkey(row)) << 1) | (ch & 1)) << 4);
+  }
+  // A-style fragment (rows rt..rt+15, k = 32 ks + 8 (l>>4) + j) from a row image
+  __device__ static __forceinline__ bf16x8 row_frag(const unsigned char* img, int rt, int ks, int lane) {
+    const int row = rt + (lane & 15), ch = 4 * ks + (lane >> 4);
+    return *reinterpret_cast<const bf16x8*>(img + row_off(row, ch));
+  }
+  // transposed fragment from a tr image: lane -> column dt*16 + (l & 15); k-slot (g, j) = row
+  // 4g + j (j < 4) / 16 + 4g + (j - 4)
+  __device__ static __forceinline__ bf16x8 tr_frag(const unsigned char* img, int dt, int lane) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int r0 = 4 * g + q, r1 = 16 + 4 * g + q;
+    s16x4 lo = lds_read_tr16(img + r0 * PITCH + ((dt ^ trkey(r0)) << 5) + 8 * p);
+    s16x4 hi = lds_read_tr16(img + r1 * PITCH + ((dt ^ trkey(r1)) << 5) + 8 * p);
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+  }
+};
+
+// cooperative staging of a [32][DH] bf16 tile (rows r0.., zero beyond nrows): fetch() issues the
+// 16-byte global loads into registers (so they fly during the MFMAs of the previous tile), commit()
+// writes them into a row image and/or a tr image.  256 threads; DH/8 chunks per row.
+template <int DH>
+struct TileRegs {
+  static constexpr int CH = DH / 8, N = 32 * CH / 256;
+  uint4 r[N];
+  __device__ __forceinline__ void fetch(const bf16_t* __restrict__ base, long ld, int r0, int nrows, int tid) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int f = tid + 256 * i, row = f / CH, ch = f - row * CH;
+      r[i] = make_uint4(0, 0, 0, 0);
+      if (r0 + row < nrows) r[i] = *reinterpret_cast<const uint4*>(base + (long)(r0 + row) * ld + ch * 8);
+    }
+  }
+  __device__ __forceinline__ void commit(unsigned char* rimg, unsigned char* timg, int tid) const {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int f = tid + 256 * i, row = f / CH, ch = f - row * CH;
+      if (rimg) *reinterpret_cast<uint4*>(rimg + Img<DH>::row_off(row, ch)) = r[i];
+      if (timg) *reinterpret_cast<uint4*>(timg + Img<DH>::tr_off(row, ch)) = r[i];
+    }
+  }
+};
+
+// register fragments of 16 rows (clamped) of a [rows][DH] bf16 matrix, A-style (== B-style of X^T)
+template <int DH>
+__device__ __forceinline__ void load_frags(const bf16_t* __restrict__ base, long ld, int r0, int nrows, int lane,
+                                           bf16x8 (&fr)[DH / 32]) {
+  const int row = min(r0 + (lane & 15), nrows - 1);
+#pragma unroll
+  for (int ks = 0; ks < DH / 32; ++ks)
+    fr[ks] = *reinterpret_cast<const bf16x8*>(base + (long)row * ld + 32 * ks + 8 * (lane >> 4));
+}
+
+__device__ __forceinline__ unsigned pack2(float a, float b) { return pack_bf16x4(a, b, 0.f, 0.f).x; }
+
+__device__ __forceinline__ bf16x8 pack_frag(const float (&v)[8]) {
+  union { uint4 u; bf16x8 f; } cv;
+  const uint2 a = pack_bf16x4(v[0], v[1], v[2], v[3]), b = pack_bf16x4(v[4], v[5], v[6], v[7]);
+  cv.u = make_uint4(a.x, a.y, b.x, b.y);
+  return cv.f;
+}
+
+struct AttnArgs {
+  const bf16_t *q, *k, *v;       // bf16 projections; row (b, t) at base + (b * rows + t) * ld + h * DH
+  long ldq, ldk, ldv;
+  float* o;                       // fwd out: [B*T][H*DH] fp32 (ld = H*DH)
+  bf16_t* oh;                     // bf16 copy of o (or null)
+  float* lse;                     // [B*H*T]
+  const int* klen;                // [B] valid keys (or null)
+  int B, H, T, S, causal;
+  float scale, drop_p;
+  uint64_t seed;
+  int ld_drop;                    // row stride of the dropout index space (== unfused path's score ld)
+  // backward
+  const bf16_t* doh;              // bf16 dO [B*T][H*DH]
+  const float* dvec;              // D[b,h,t] = rowsum(dO * O)
+  float *dq, *dk, *dv;            // fp32 gradients, addressed like q / k / v (ldq / ldk / ldv)
+};
+
+// ------------------------------------------------------------------------------------------------
+// forward: grid (ceil(T / 64), B * H); 4 waves x 16 queries; key tiles of 32
+// ------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void flash_fwd_kernel(AttnArgs a) {
+  constexpr int KS = DH / 32, DT = DH / 16;
+  if (a.T <= 0 || a.S <= 0) return;  // empty problem (kernel preload)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * Img<DH>::BYTES];
+  unsigned char* kimg = smem;                      // row image of the K tile
+  unsigned char* vimg = smem + Img<DH>::BYTES;     // tr image of the V tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int qi = q0 + (lane & 15);                 // this lane's query (column)
+  const bf16_t* qb = a.q + (long)b * a.T * a.ldq + h * DH;
+  const bf16_t* kb = a.k + (long)b * a.S * a.ldk + h * DH;
+  const bf16_t* vb = a.v + (long)b * a.S * a.ldv + h * DH;
+  int klim = a.klen ? min((int)a.klen[b], a.S) : a.S;
+  const int kmax = a.causal ? min(klim, (int)blockIdx.x * 64 + 64) : klim;  // keys any query of the block sees
+
+  bf16x8 qf[KS];
+  load_frags<DH>(qb, a.ldq, q0, a.T, lane, qf);
+  f32x4 o[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f;
+  const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+  const uint64_t drow = ((uint64_t)bh * a.T + qi) * (uint64_t)a.ld_drop;
+
+  TileRegs<DH> tk, tv;
+  if (kmax > 0) {
+    tk.fetch(kb, a.ldk, 0, a.S, tid);
+    tv.fetch(vb, a.ldv, 0, a.S, tid);
+  }
+  for (int kt = 0; kt < kmax; kt += 32) {
+    __syncthreads();  // everyone is done with the previous tile's images
+    tk.commit(kimg, nullptr, tid);
+    tv.commit(nullptr, vimg, tid);
+    __syncthreads();
+    if (kt + 32 < kmax) {  // next tile's loads fly during this tile's MFMAs
+      tk.fetch(kb, a.ldk, kt + 32, a.S, tid);
+      tv.fetch(vb, a.ldv, kt + 32, a.S, tid);
+    }
+    // S^T tiles: rows = keys kt + 16 t2 + 4g + r, col = query
+    f32x4 x[2];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      x[t2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        x[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Img<DH>::row_frag(kimg, 16 * t2, ks, lane), qf[ks], x[t2], 0, 0, 0);
+    }
+    float s[8];
+    float mt = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int key = kt + 16 * (e >> 2) + 4 * g + (e & 3);
+      const bool ok = key < klim && (!a.causal || key <= qi);
+      s[e] = ok ? x[e >> 2][e & 3] * a.scale : -INFINITY;
+      mt = fmaxf(mt, s[e]);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 16));
+    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    const float mn = fmaxf(m, mt);
+    const float mu = mn == -INFINITY ? 0.f : mn;
+    const float alpha = __expf(m - mu);  // m = -inf -> 0
+    float p[8], ps = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      p[e] = __expf(s[e] - mu);
+      ps += p[e];
+      if (a.drop_p > 0.f) {
+        const int key = kt + 16 * (e >> 2) + 4 * g + (e & 3);
+        p[e] *= drop_scale(a.seed, drow + key, a.drop_p, inv_keep);
+      }
+    }
+    l = l * alpha + ps;
+    m = mn;
+    const bf16x8 pf = pack_frag(p);
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      o[d] *= alpha;
+      o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Img<DH>::tr_frag(vimg, d, lane), pf, o[d], 0, 0, 0);
+    }
+  }
+  l += __shfl_xor(l, 16);
+  l += __shfl_xor(l, 32);
+  const float inv_l = l > 0.f ? 1.f / l : 0.f;
+  if (qi < a.T) {
+    const long ro = ((long)b * a.T + qi) * ((long)a.H * DH) + h * DH;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      const float4 v = make_float4(o[d][0] * inv_l, o[d][1] * inv_l, o[d][2] * inv_l, o[d][3] * inv_l);
+      *reinterpret_cast<float4*>(a.o + ro + 16 * d + 4 * g) = v;
+      if (a.oh) *reinterpret_cast<uint2*>(a.oh + ro + 16 * d + 4 * g) = pack_bf16x4(v.x, v.y, v.z, v.w);
+    }
+    if (g == 0 && a.lse) a.lse[(long)bh * a.T + qi] = l > 0.f ? m + __logf(l) : -INFINITY;
+  }
+}
+
+// D[b,h,t] = sum_d dO[b,t,h,d] * O[b,t,h,d]   (one wave per (b,t,h) row of DH elements)
+__global__ __launch_bounds__(256) void attn_dvec_kernel(const float* __restrict__ dO, const float* __restrict__ O,
+                                                        float* __restrict__ D, int B, int H, int T, int DH) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // over B*T*H
+  const int lane = threadIdx.x & 63;
+  if (row >= (long)B * T * H) return;
+  const int h = (int)(row % H);
+  const long bt = row / H;
+  const float* a = dO + bt * ((long)H * DH) + (long)h * DH;
+  const float* o = O + bt * ((long)H * DH) + (long)h * DH;
+  float s = 0.f;
+  for (int d = lane; d < DH; d += 64) s += a[d] * o[d];
+  s = wave_sum(s);
+  if (lane == 0) {
+    const int t = (int)(bt % T), b = (int)(bt / T);
+    D[((long)b * H + h) * T + t] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward dK, dV: grid (ceil(S / 64), B * H); 4 waves x 16 keys (columns); query tiles of 32 (rows)
+//   X[q][key] = Q K^T ; P = exp(scale X - lse[q]) ; Pd = dropout(P)
+//   dV^T[d][key] += dO^T[d][q] Pd[q][key]
+//   dP[q][key] = dO[q][:] . V[key][:] ; dS = P * (mask * dP / keep - D[q])
+//   dK^T[d][key] += Q^T[d][q] dS[q][key]   (scaled at the end)
+// ------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void flash_bwd_kv_kernel(AttnArgs a) {
+  constexpr int KS = DH / 32, DT = DH / 16;
+  if (a.T <= 0 || a.S <= 0) return;  // empty problem (kernel preload)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * Img<DH>::BYTES];
+  unsigned char* q_row = smem;
+  unsigned char* q_tr = smem + Img<DH>::BYTES;
+  unsigned char* do_row = smem + 2 * Img<DH>::BYTES;
+  unsigned char* do_tr = smem + 3 * Img<DH>::BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int k0 = blockIdx.x * 64 + wave * 16;
+  const int ki = k0 + (lane & 15);  // this lane's key (column)
+  const bf16_t* qb = a.q + (long)b * a.T * a.ldq + h * DH;
+  const bf16_t* kb = a.k + (long)b * a.S * a.ldk + h * DH;
+  const bf16_t* vb = a.v + (long)b * a.S * a.ldv + h * DH;
+  const bf16_t* dob = a.doh + (long)b * a.T * ((long)a.H * DH) + h * DH;
+  const int klim = a.klen ? min((int)a.klen[b], a.S) : a.S;
+  const bool key_ok = ki < klim;
+  const int qbeg = a.causal ? (blockIdx.x * 64) & ~31 : 0;  // queries < first key of the block see none of it
+
+  bf16x8 kf[KS], vf[KS];
+  load_frags<DH>(kb, a.ldk, k0, a.S, lane, kf);
+  load_frags<DH>(vb, a.ldv, k0, a.S, lane, vf);
+  f32x4 dk[DT], dv[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) dk[d] = dv[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+
+  TileRegs<DH> tq, td;
+  if (qbeg < a.T) {
+    tq.fetch(qb, a.ldq, qbeg, a.T, tid);
+    td.fetch(dob, (long)a.H * DH, qbeg, a.T, tid);
+  }
+  for (int qt = qbeg; qt < a.T; qt += 32) {
+    __syncthreads();
+    tq.commit(q_row, q_tr, tid);
+    td.commit(do_row, do_tr, tid);
+    __syncthreads();
+    if (qt + 32 < a.T) {
+      tq.fetch(qb, a.ldq, qt + 32, a.T, tid);
+      td.fetch(dob, (long)a.H * DH, qt + 32, a.T, tid);
+    }
+    f32x4 x[2], dp[2];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      x[t2] = dp[t2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        x[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Img<DH>::row_frag(q_row, 16 * t2, ks, lane), kf[ks], x[t2], 0, 0, 0);
+        dp[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Img<DH>::row_frag(do_row, 16 * t2, ks, lane), vf[ks], dp[t2], 0, 0, 0);
+      }
+    }
+    float pd[8], ds[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int q = qt + 16 * (e >> 2) + 4 * g + (e & 3);
+      const bool ok = key_ok && q < a.T && (!a.causal || ki <= q);
+      float p = 0.f, dsv = 0.f, pdv = 0.f;
+      if (ok) {
+        const long r = (long)bh * a.T + q;
+        p = __expf(x[e >> 2][e & 3] * a.scale - a.lse[r]);
+        float keep = 1.f;
+        if (a.drop_p > 0.f) keep = drop_scale(a.seed, (uint64_t)r * a.ld_drop + ki, a.drop_p, inv_keep);
+        pdv = p * keep;
+        dsv = p * (keep * dp[e >> 2][e & 3] - a.dvec[r]);
+      }
+      pd[e] = pdv;
+      ds[e] = dsv;
+    }
+    const bf16x8 pf = pack_frag(pd), sf = pack_frag(ds);
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Img<DH>::tr_frag(do_tr, d, lane), pf, dv[d], 0, 0, 0);
+      dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Img<DH>::tr_frag(q_tr, d, lane), sf, dk[d], 0, 0, 0);
+    }
+  }
+  if (ki < a.S) {
+    float* dkp = a.dk + ((long)b * a.S + ki) * a.ldk + h * DH;
+    float* dvp = a.dv + ((long)b * a.S + ki) * a.ldv + h * DH;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      *reinterpret_cast<float4*>(dkp + 16 * d + 4 * g) =
+          make_float4(dk[d][0] * a.scale, dk[d][1] * a.scale, dk[d][2] * a.scale, dk[d][3] * a.scale);
+      *reinterpret_cast<float4*>(dvp + 16 * d + 4 * g) = make_float4(dv[d][0], dv[d][1], dv[d][2], dv[d][3]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward dQ: grid (ceil(T / 64), B * H); 4 waves x 16 queries (columns); key tiles of 32 (rows)
+//   X^T[key][q] = K Q^T ; dP^T[key][q] = V dO^T ; dS^T = P^T * (mask dP^T / keep - D[q])
+//   dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+// ------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void flash_bwd_q_kernel(AttnArgs a) {
+  constexpr int KS = DH / 32, DT = DH / 16;
+  if (a.T <= 0 || a.S <= 0) return;  // empty problem (kernel preload)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * Img<DH>::BYTES];
+  unsigned char* k_row = smem;
+  unsigned char* k_tr = smem + Img<DH>::BYTES;
+  unsigned char* v_row = smem + 2 * Img<DH>::BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int qi = q0 + (lane & 15);
+  const bf16_t* qb = a.q + (long)b * a.T * a.ldq + h * DH;
+  const bf16_t* kb = a.k + (long)b * a.S * a.ldk + h * DH;
+  const bf16_t* vb = a.v + (long)b * a.S * a.ldv + h * DH;
+  const bf16_t* dob = a.doh + (long)b * a.T * ((long)a.H * DH) + h * DH;
+  const int klim = a.klen ? min((int)a.klen[b], a.S) : a.S;
+  const int kmax = a.causal ? min(klim, (int)blockIdx.x * 64 + 64) : klim;
+
+  bf16x8 qf[KS], dof[KS];
+  load_frags<DH>(qb, a.ldq, q0, a.T, lane, qf);
+  load_frags<DH>(dob, (long)a.H * DH, q0, a.T, lane, dof);
+  f32x4 dq[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+  const bool q_ok = qi < a.T;
+  const long r = (long)bh * a.T + min(qi, a.T - 1);
+  const float lse = a.lse[r], dvec = a.dvec[r];
+  const uint64_t drow = (uint64_t)r * a.ld_drop;
+
+  TileRegs<DH> tk, tv;
+  if (kmax > 0) {
+    tk.fetch(kb, a.ldk, 0, a.S, tid);
+    tv.fetch(vb, a.ldv, 0, a.S, tid);
+  }
+  for (int kt = 0; kt < kmax; kt += 32) {
+    __syncthreads();
+    tk.commit(k_row, k_tr, tid);
+    tv.commit(v_row, nullptr, tid);
+    __syncthreads();
+    if (kt + 32 < kmax) {
+      tk.fetch(kb, a.ldk, kt + 32, a.S, tid);
+      tv.fetch(vb, a.ldv, kt + 32, a.S, tid);
+    }
+    f32x4 x[2], dp[2];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      x[t2] = dp[t2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        x[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Img<DH>::row_frag(k_row, 16 * t2, ks, lane), qf[ks], x[t2], 0, 0, 0);
+        dp[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Img<DH>::row_frag(v_row, 16 * t2, ks, lane), dof[ks], dp[t2], 0, 0, 0);
+      }
+    }
+    float ds[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int key = kt + 16 * (e >> 2) + 4 * g + (e & 3);
+      const bool ok = q_ok && key < klim && (!a.causal || key <= qi);
+      float dsv = 0.f;
+      if (ok) {
+        const float p = __expf(x[e >> 2][e & 3] * a.scale - lse);
+        float keep = 1.f;
+        if (a.drop_p > 0.f) keep = drop_scale(a.seed, drow + key, a.drop_p, inv_keep);
+        dsv = p * (keep * dp[e >> 2][e & 3] - dvec);
+      }
+      ds[e] = dsv;
+    }
+    const bf16x8 sf = pack_frag(ds);
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+      dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Img<DH>::tr_frag(k_tr, d, lane), sf, dq[d], 0, 0, 0);
+  }
+  if (q_ok) {
+    float* dqp = a.dq + ((long)b * a.T + qi) * a.ldq + h * DH;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+      *reinterpret_cast<float4*>(dqp + 16 * d + 4 * g) =
+          make_float4(dq[d][0] * a.scale, dq[d][1] * a.scale, dq[d][2] * a.scale, dq[d][3] * a.scale);
+  }
+}
+
+bool attn_args_ok(const s2st_attn_args& p) {
+  auto al = [](const void* x, int n) { return ((uintptr_t)x % n) == 0; };
+  return (p.dh == 64 || p.dh == 128) && p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && al(p.q, 16) &&
+         al(p.k, 16) && al(p.v, 16) && p.B > 0 && p.H > 0 && p.T > 0 && p.S > 0;
+}
+
+AttnArgs to_args(const s2st_attn_args& p) {
+  AttnArgs a{};
+  a.q = p.q; a.k = p.k; a.v = p.v;
+  a.ldq = p.ldq; a.ldk = p.ldk; a.ldv = p.ldv;
+  a.o = p.o; a.oh = p.oh; a.lse = p.lse; a.klen = p.klen;
+  a.B = p.B; a.H = p.H; a.T = p.T; a.S = p.S; a.causal = p.causal;
+  a.scale = p.scale; a.drop_p = p.drop_p; a.seed = p.seed; a.ld_drop = p.ld_drop;
+  a.doh = p.doh; a.dq = p.dq; a.dk = p.dk; a.dv = p.dv;
+  return a;
+}
+
+}  // namespace
+
+int s2st_flash_attn_supported(int dh) { return dh == 64 || dh == 128; }
+
+// empty launches of every instantiation: code objects resident before the first timed step
+int s2st_flash_attn_preload(hipStream_t st) {
+  AttnArgs a{};
+  hipLaunchKernelGGL(flash_fwd_kernel<128>, dim3(1, 1), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(flash_fwd_kernel<64>, dim3(1, 1), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(flash_bwd_kv_kernel<128>, dim3(1, 1), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(flash_bwd_kv_kernel<64>, dim3(1, 1), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(flash_bwd_q_kernel<128>, dim3(1, 1), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(flash_bwd_q_kernel<64>, dim3(1, 1), dim3(256), 0, st, a);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+
+int s2st_flash_attn_fwd(const s2st_attn_args* p, hipStream_t st) {
+  if (!p || !attn_args_ok(*p) || !p->o || !p->lse) return S2ST_ERR_ARG;
+  AttnArgs a = to_args(*p);
+  dim3 grid((p->T + 63) / 64, p->B * p->H);
+  if (p->dh == 128) hipLaunchKernelGGL(flash_fwd_kernel<128>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(flash_fwd_kernel<64>, grid, dim3(256), 0, st, a);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+
+// dO (fp32, for D) + its bf16 copy; o / lse from the forward; writes dq, dk, dv (fp32, overwrite)
+int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_scratch, hipStream_t st) {
+  if (!p || !attn_args_ok(*p) || !p->doh || !dO || !dvec_scratch || !p->dq || !p->dk || !p->dv || !p->lse || !p->o)
+    return S2ST_ERR_ARG;
+  AttnArgs a = to_args(*p);
+  a.dvec = dvec_scratch;
+  const long rows = (long)p->B * p->T * p->H;
+  hipLaunchKernelGGL(attn_dvec_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, dO, (const float*)p->o,
+                     dvec_scratch, p->B, p->H, p->T, p->dh);
+  dim3 gk((p->S + 63) / 64, p->B * p->H), gq((p->T + 63) / 64, p->B * p->H);
+  if (p->dh == 128) {
+    hipLaunchKernelGGL(flash_bwd_kv_kernel<128>, gk, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(flash_bwd_q_kernel<128>, gq, dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(flash_bwd_kv_kernel<64>, gk, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(flash_bwd_q_kernel<64>, gq, dim3(256), 0, st, a);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}

@@ -119,6 +119,11 @@ int s2st_adam_f32(float* p, float* g, float* m, float* v, int64_t n, const float
 int64_t s2st_layernorm_bwd_scratch(int32_t rows, int32_t cols) { return (int64_t)s2st_layernorm_bwd_blocks(rows) * 2 * cols; }
 int64_t s2st_ctc_workspace(int32_t B, int32_t E, int32_t Lmax) { return s2st_ctc_workspace_floats(B, E, Lmax); }
 
+int s2st_flash_attn_fwd_bf16(const s2st_attn_args* args, void* stream) { return s2st_flash_attn_fwd(args, (hipStream_t)stream); }
+int s2st_flash_attn_bwd_bf16(const s2st_attn_args* args, const float* dO, float* dvec_scratch, void* stream) {
+  return s2st_flash_attn_bwd(args, dO, dvec_scratch, (hipStream_t)stream);
+}
+
 int s2st_profile_gemm(int32_t enable) { s2st_gemm_profile_enable(enable); return 0; }
 int s2st_profile_gemm_read(double* flops, double* ms, int64_t* launches) {
   long n = 0;

@@ -90,6 +90,7 @@ struct s2st_engine {
     hipStreamWaitEvent(st_, ev_join_, 0);
     side_used = false;
   }
+  bool use_flash = true;  // S2ST_NO_FLASH=1: unfused attention everywhere (A/B switch)
   int ffn_act = 1;        // 1 relu (s2st layers), 2 gelu (HuBERT layers)
   // ---- frozen HuBERT front end (config 4): same engine object in "hubert mode" -------------
   bool is_hubert = false;
@@ -458,6 +459,35 @@ struct s2st_engine {
     Ten* o = newT(B * T, C);
     o->want_gh = true;
     if (fm && C % 8 == 0) o->h = alloc_h(o->n());
+    // fused path (attention.hip): no [B,H,T,S] tensors in HBM.  The head-averaged attention map of
+    // the last decoder layer still needs the probabilities, so that one call stays unfused.
+    if (fm && use_flash && s2st_flash_attn_supported(dh) && !attn_mean_out && o->h && io.ldq % 8 == 0 &&
+        io.ldk % 8 == 0 && io.ldv % 8 == 0) {
+      const uint64_t sd = drop_p > 0.f ? next_seed() : 0;
+      float* lse = alloc((long)B * H * T);
+      s2st_attn_args fa{};
+      fa.q = half_of(io.qt) + io.qoff; fa.k = half_of(io.kt) + io.koff; fa.v = half_of(io.vt) + io.voff;
+      fa.ldq = io.ldq; fa.ldk = io.ldk; fa.ldv = io.ldv;
+      fa.o = o->d; fa.oh = o->h; fa.lse = lse; fa.klen = klen;
+      fa.B = B; fa.H = H; fa.T = T; fa.S = S; fa.dh = dh; fa.causal = causal;
+      fa.scale = 1.0f / sqrtf((float)dh); fa.drop_p = drop_p; fa.seed = sd; fa.ld_drop = ld;
+      if (live()) chk(s2st_flash_attn_fwd(&fa, st_));
+      AttnIO io3 = io;
+      tape.push_back([=]() {
+        if (!o->g) return;
+        bool aq, ak, av;
+        float* gq = gradbuf(io3.qt, aq);
+        float* gk = gradbuf(io3.kt, ak);
+        float* gv = gradbuf(io3.vt, av);
+        (void)aq; (void)ak; (void)av;  // disjoint column blocks, each written exactly once
+        float* dvec = alloc((long)B * H * T);
+        s2st_attn_args fb = fa;
+        fb.doh = ghalf_of(o);
+        fb.dq = gq + io3.qoff; fb.dk = gk + io3.koff; fb.dv = gv + io3.voff;
+        if (live()) chk(s2st_flash_attn_bwd(&fb, o->g, dvec, st_));
+      });
+      return o;
+    }
     float* p = alloc((long)B * H * T * ld);
     float* pd = drop_p > 0.f ? alloc((long)B * H * T * ld) : p;
     bf16raw* pdh = fm ? alloc_h((long)B * H * T * ld) : nullptr;  // bf16 dropout(p): the P*V / dV operand
@@ -1015,6 +1045,9 @@ struct s2st_engine {
         ctc_lp = outs.ctc_lprobs ? outs.ctc_lprobs : alloc((long)B * E * c.src_vocab);
         ctc_ws = alloc(s2st_ctc_workspace_floats(B, E, bt.Ls));
       }
+      // training: the CTC gradient w.r.t. the logits comes out of the same alpha/beta sweep as the
+      // loss, so it is produced here (per unit of upstream gradient) and only scaled in the backward
+      float* ctc_dl = (tr && ctc_logits) ? alloc(ctc_logits->n()) : nullptr;
       const float nr = (float)bt.ntokens, nf = nr * c.out_dim;
       if (live()) {
         hipMemsetAsync(stats, 0, sizeof(float) * 32, st_);
@@ -1022,7 +1055,7 @@ struct s2st_engine {
                           stats + S2ST_STAT_L1_SUM, 0, 0, 0, nullptr, nullptr, nullptr, st_));
         if (ctc_logits)
           chk(s2st_ctc(ctc_logits->d, (const long*)bt.src_txt, bt.Ls, bt.ctc_in_lens, bt.src_txt_lens, B, E,
-                       c.src_vocab, ctc_lp, ctc_per, nullptr, 0.f, ctc_ws, st_));
+                       c.src_vocab, ctc_lp, ctc_per, ctc_dl, ctc_dl ? c.ctc_weight / B : 0.f, ctc_ws, st_));
         if (asr_logits)
           chk(s2st_ls_ce(asr_logits->d, (const long*)bt.src_txt, B * bt.Ls, c.src_vocab, 1, c.label_smoothing,
                          stats + S2ST_STAT_ASR_NLL, nullptr, 0.f, st_));
@@ -1047,9 +1080,12 @@ struct s2st_engine {
         if (ctc_logits) {
           bool a;
           float* dl = gradbuf(ctc_logits, a);
-          if (live())
-            chk(s2st_ctc(ctc_logits->d, (const long*)bt.src_txt, bt.Ls, bt.ctc_in_lens, bt.src_txt_lens, B, E,
-                         c.src_vocab, ctc_lp, ctc_per, dl, gs * c.ctc_weight / B, ctc_ws, st_));
+          if (live()) {
+            if (ctc_dl) chk(s2st_dropout(ctc_dl, dl, ctc_logits->n(), gs, 0.f, 0, 0, st_));  // dl = gs * ctc_dl
+            else
+              chk(s2st_ctc(ctc_logits->d, (const long*)bt.src_txt, bt.Ls, bt.ctc_in_lens, bt.src_txt_lens, B, E,
+                           c.src_vocab, ctc_lp, ctc_per, dl, gs * c.ctc_weight / B, ctc_ws, st_));
+          }
         }
         if (asr_logits) {
           bool a;
@@ -1104,8 +1140,9 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   s2st_engine* e = new s2st_engine();
   e->c = *cfg;
   e->f32_operands = getenv("S2ST_F32_OPERANDS") && atoi(getenv("S2ST_F32_OPERANDS")) != 0;
+  e->use_flash = !(getenv("S2ST_NO_FLASH") && atoi(getenv("S2ST_NO_FLASH")) != 0);
   e->build_params();
-  if (!cfg->precise && s2st_gemm_bf16_preload(nullptr) != 0) { delete e; return S2ST_ERR_LAUNCH; }
+  if (!cfg->precise && (s2st_gemm_bf16_preload(nullptr) != 0 || s2st_flash_attn_preload(nullptr) != 0)) { delete e; return S2ST_ERR_LAUNCH; }
   if (!cfg->precise && !(getenv("S2ST_NO_SIDE_STREAM") && atoi(getenv("S2ST_NO_SIDE_STREAM")))) {
     if (hipStreamCreateWithFlags(&e->side_, hipStreamNonBlocking) != hipSuccess) e->side_ = nullptr;
     if (e->side_ && (hipEventCreateWithFlags(&e->ev_fork_, hipEventDisableTiming) != hipSuccess ||
@@ -1238,8 +1275,9 @@ int s2st_hubert_create(const s2st_hubert_config* cfg, s2st_engine** out) {
   e->c.enc_dim = cfg->embed;
   e->ffn_act = 2;
   e->f32_operands = getenv("S2ST_F32_OPERANDS") && atoi(getenv("S2ST_F32_OPERANDS")) != 0;
+  e->use_flash = !(getenv("S2ST_NO_FLASH") && atoi(getenv("S2ST_NO_FLASH")) != 0);
   e->build_params_hubert();
-  if (!cfg->precise && s2st_gemm_bf16_preload(nullptr) != 0) { delete e; return S2ST_ERR_LAUNCH; }
+  if (!cfg->precise && (s2st_gemm_bf16_preload(nullptr) != 0 || s2st_flash_attn_preload(nullptr) != 0)) { delete e; return S2ST_ERR_LAUNCH; }
   *out = e;
   return 0;
 }

@@ -143,6 +143,14 @@ int s2st_bn_bwd(const float* dy, Split dysp, const float* x, const float* mean, 
                 uint64_t seed, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------
+// fused attention (attention.hip)
+// ---------------------------------------------------------------------------------------
+int s2st_flash_attn_supported(int dh);
+int s2st_flash_attn_preload(hipStream_t st);
+int s2st_flash_attn_fwd(const s2st_attn_args* p, hipStream_t st);
+int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_scratch, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------
 // HuBERT front end (hubert.hip): waveform conv, GroupNorm(C, C) + GELU, pos-conv input re-layout
 // ---------------------------------------------------------------------------------------
 int s2st_hubert_conv0(const float* x, const float* w, float* y, int B, int N, int T, int C, int k, int stride,

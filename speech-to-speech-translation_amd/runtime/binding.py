@@ -151,6 +151,44 @@ def _gemm_bf16(A, B, Cout, M, N, K, kw):
     check(lib().s2st_gemm_f32(C.byref(g), C.c_void_p(stream_ptr())), "s2st_gemm_f32")
 
 
+class AttnArgs(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("ldq", C.c_int64), ("ldk", C.c_int64),
+                ("ldv", C.c_int64), ("o", C.c_void_p), ("oh", C.c_void_p), ("lse", C.c_void_p), ("klen", C.c_void_p),
+                ("B", C.c_int32), ("H", C.c_int32), ("T", C.c_int32), ("S", C.c_int32), ("dh", C.c_int32),
+                ("causal", C.c_int32), ("scale", C.c_float), ("drop_p", C.c_float), ("seed", C.c_uint64),
+                ("ld_drop", C.c_int32), ("doh", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p)]
+
+
+def flash_attention(q, k, v, H, *, klen=None, causal=False, scale=None, drop_p=0.0, seed=0, dO=None):
+    """Fused attention on bf16 [B, T, H*dh] / [B, S, H*dh] projections (s2st_flash_attn_*_bf16).
+    Returns (o fp32, lse) and, when dO (fp32 [B, T, H*dh]) is given, also (dq, dk, dv) fp32."""
+    require_device(q)
+    B, T, Cm = q.shape
+    S = k.shape[1]
+    dh = Cm // H
+    a = AttnArgs()
+    a.q, a.k, a.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
+    a.ldq = a.ldk = a.ldv = Cm
+    o = torch.zeros(B, T, Cm, dtype=torch.float32, device=q.device)
+    lse = torch.zeros(B * H * T, dtype=torch.float32, device=q.device)
+    a.o, a.oh, a.lse, a.klen = o.data_ptr(), None, lse.data_ptr(), ptr(klen)
+    a.B, a.H, a.T, a.S, a.dh, a.causal = B, H, T, S, dh, 1 if causal else 0
+    a.scale = scale if scale is not None else dh ** -0.5
+    a.drop_p, a.seed, a.ld_drop = drop_p, seed, (S + 7) // 8 * 8
+    lib().s2st_flash_attn_fwd_bf16.argtypes = [C.POINTER(AttnArgs), C.c_void_p]
+    check(lib().s2st_flash_attn_fwd_bf16(C.byref(a), C.c_void_p(stream_ptr())), "s2st_flash_attn_fwd_bf16")
+    if dO is None:
+        return o, lse.view(B, H, T)
+    doh = dO.to(torch.bfloat16).contiguous()
+    dq, dk, dv = (torch.zeros_like(x, dtype=torch.float32) for x in (q, k, v))
+    scratch = torch.zeros(B * H * T, dtype=torch.float32, device=q.device)
+    a.doh, a.dq, a.dk, a.dv = doh.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    lib().s2st_flash_attn_bwd_bf16.argtypes = [C.POINTER(AttnArgs), C.c_void_p, C.c_void_p, C.c_void_p]
+    check(lib().s2st_flash_attn_bwd_bf16(C.byref(a), dO.data_ptr(), scratch.data_ptr(), C.c_void_p(stream_ptr())),
+          "s2st_flash_attn_bwd_bf16")
+    return o, lse.view(B, H, T), dq, dk, dv
+
+
 # ---------------------------------------------------------------------------------------------
 # generic call path: argtypes are derived from include/s2st_hip.h so the binding cannot drift
 # from the declared C ABI

@@ -109,6 +109,8 @@ static inline double atomicAdd(double* p, double v) {
 // ---- math ----------------------------------------------------------------------------------
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __fdividef(float a, float b) { return a / b; }
+#define __expf(x) expf(x)
+#define __logf(x) logf(x)
 
 // ---- MFMA: v_mfma_f32_16x16x32_bf16 ---------------------------------------------------------
 // A: lane l holds A[row l&15][k = 8*(l>>4) + j], B: B[k = 8*(l>>4)+j][col l&15], j = 0..7

@@ -1,0 +1,78 @@
+"""Fused attention kernels (attention.hip, through the C ABI) against a float64 restatement of
+fairseq MultiheadAttention's core (multihead_attention.py:224-367): masks, softmax, P*V and its
+autograd.  Inputs are bf16-rounded; probabilities / score gradients pass through bf16 inside the
+kernels, hence the 1-2 % tolerances."""
+import pytest
+import torch
+
+
+def reference(q, k, v, H, klen, causal, dO=None):
+    B, T, Cm = q.shape
+    S = k.shape[1]
+    dh = Cm // H
+    q, k, v = (x.double().requires_grad_(True) for x in (q, k, v))
+    qh = q.view(B, T, H, dh).permute(0, 2, 1, 3) * dh ** -0.5
+    kh = k.view(B, S, H, dh).permute(0, 2, 1, 3)
+    vh = v.view(B, S, H, dh).permute(0, 2, 1, 3)
+    s = qh @ kh.transpose(-1, -2)
+    mask = torch.zeros(B, 1, T, S, dtype=torch.bool)
+    if klen is not None:
+        mask |= (torch.arange(S)[None, :] >= klen[:, None])[:, None, None, :]
+    if causal:
+        mask |= (torch.arange(S)[None, :] > torch.arange(T)[:, None])[None, None]
+    s = s.masked_fill(mask, float("-inf"))
+    p = torch.softmax(s, -1)
+    o = (p @ vh).permute(0, 2, 1, 3).reshape(B, T, Cm)
+    lse = torch.logsumexp(s, -1)
+    if dO is None:
+        return o.detach(), lse.detach()
+    o.backward(dO.double())
+    return o.detach(), lse.detach(), q.grad, k.grad, v.grad
+
+
+def rel(x, y):
+    return float((x.double().cpu() - y).abs().max() / (y.abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize("dh,H", [(64, 2), (128, 1)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_flash_attention_fwd_bwd(backend, dh, H, causal):
+    B, T, S = 2, 37, 37 if causal else 45
+    Cm = H * dh
+    g = torch.Generator().manual_seed(dh + 7 * causal)
+    q = torch.randn(B, T, Cm, generator=g).to(torch.bfloat16)
+    k = torch.randn(B, S, Cm, generator=g).to(torch.bfloat16)
+    v = torch.randn(B, S, Cm, generator=g).to(torch.bfloat16)
+    dO = torch.randn(B, T, Cm, generator=g)
+    klen = torch.tensor([S, S - 9], dtype=torch.int32)
+    d = backend.device
+    o, lse, dq, dk, dv = backend.bd.flash_attention(q.to(d), k.to(d), v.to(d), H, klen=klen.to(d), causal=causal,
+                                                    dO=dO.to(d))
+    backend.sync()
+    ro, rl, rq, rk, rv = reference(q.float(), k.float(), v.float(), H, klen.long(), causal,
+                                   dO.to(torch.bfloat16).float())
+    assert rel(o, ro) < 1e-2
+    assert rel(lse, rl) < 1e-4
+    assert rel(dq, rq) < 2e-2 and rel(dk, rk) < 2e-2 and rel(dv, rv) < 2e-2
+    # keys beyond klen get no gradient
+    assert float(dk[1, S - 9:].abs().max()) == 0.0 and float(dv[1, S - 9:].abs().max()) == 0.0
+
+
+def test_flash_attention_dropout_matches_unfused_mask(backend):
+    """Same (seed, element) -> same keep decision as the unfused softmax kernel: o_fused == dropout(p) v."""
+    B, H, T, S, dh = 1, 1, 20, 24, 64
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(B, T, dh, generator=g).to(torch.bfloat16)
+    k = torch.randn(B, S, dh, generator=g).to(torch.bfloat16)
+    v = torch.randn(B, S, dh, generator=g).to(torch.bfloat16)
+    d = backend.device
+    o, _ = backend.bd.flash_attention(q.to(d), k.to(d), v.to(d), H, drop_p=0.3, seed=99)
+    sc = (q.float() @ k.float().transpose(1, 2)) * dh ** -0.5
+    ld = 24
+    s_buf = sc.view(1, 1, T, S).contiguous().to(d)
+    p = torch.zeros(1, 1, T, ld, device=d)
+    pd = torch.zeros(1, 1, T, ld, device=d)
+    backend.bd.call("s2st_softmax_fwd_f32", s_buf, p, pd, None, 1, 1, T, S, ld, 0, 0.3, 99)
+    backend.sync()
+    ref = pd[0, 0, :, :S].cpu().double() @ v[0].double()
+    assert rel(o[0], ref) < 1e-2

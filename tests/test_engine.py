@@ -270,3 +270,17 @@ def test_micro_engine_fast_mode_vs_oracle(backend, cfg):
     # gradients: bf16 rounding noise grows with depth on these 32/64-wide layers (the first prenet
     # layer, at the end of the longest backward path, moves by ~25 %); the whole gradient by ~6 %
     check_against_oracle(backend, e, m, s, out_tol=2e-2, grad_tol=0.35, loss_tol=1e-3, global_grad_tol=0.1)
+
+
+def test_micro_engine_fused_attention_vs_oracle(backend):
+    """Head width 64 (encoder / decoder dim 128, 2 heads): the fast mode takes the fused attention
+    kernels (attention.hip) for self- and cross-attention, forward and backward; the last decoder
+    layer's cross-attention stays unfused (its head-averaged map is an output)."""
+    D = importlib.import_module(DATA)
+    cfg = dict(MICRO, encoder_embed_dim=128, decoder_embed_dim=128, encoder_attention_heads=2,
+               decoder_attention_heads=2)
+    a, e = make_engine(backend, cfg, precise=False)
+    _, m = make_oracle(cfg)
+    c = D.SyntheticFisherCorpus(n_utts=4, seed=3, max_src=64, median_src=50, min_src=30)
+    s = c.collate_batch(range(4))
+    check_against_oracle(backend, e, m, s, out_tol=2e-2, grad_tol=0.35, loss_tol=1e-3, global_grad_tol=0.1)
