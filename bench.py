@@ -180,18 +180,26 @@ def main():
             torch.cuda.synchronize()
             vlog('warmup step', i, 'done')
     torch.cuda.synchronize()
+    if os.environ.get('S2ST_BENCH_VERBOSE') and args.warmup > 0:
+        # host cost of enqueueing ONE step into an empty queue (no back-pressure) vs its GPU time
+        th = time.perf_counter()
+        step(args.warmup - 1)
+        th1 = time.perf_counter() - th
+        torch.cuda.synchronize()
+        vlog('single step: host enqueue %.2f ms, until GPU done %.2f ms' % (th1 * 1e3, (time.perf_counter() - th) * 1e3))
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
+    t_issue = time.perf_counter() - t0  # host time to enqueue the steps (GPU-bound if << dt)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    vlog('timed region', dt)
+    vlog('timed region', dt, 'host issue time', t_issue)
     my_frames = float(sum(frames[args.warmup:]))
     my_flops = 3.0 * 2.0 * sum(macs[args.warmup:])  # fwd + bwd = 3 x fwd, 2 FLOP per MAC
     stat = torch.tensor([dt, my_frames, my_flops], dtype=torch.float64, device=dev)
@@ -221,10 +229,20 @@ def main():
         vlog('roofline leg done', nl.value, 'gemm launches')
         alg = 3.0 * 2.0 * sum(macs[args.warmup:args.warmup + n_replay])
         achieved = alg / (ms.value * 1e-3) / 1e12
+        # HBM traffic per launch of the same kernels: measured with rocprofv3 PMC passes (cannot run
+        # inside this process); the committed measurement is reported, with its source
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
+                tj = json.load(f)
+            traffic, traffic_src = round(tj["hbm_bytes_per_launch"]), tj["source"]
+        except Exception:
+            pass
         roofline = {
-            "bound": "mfma", "kernel": "gemm_kernel<BM,BN,layouts> (all GEMM launches of the step)",
+            "bound": "mfma", "kernel": "gemm_bf16_dma_kernel<BM,BN,layouts,4 stages,8 waves> (all GEMM launches of the step)",
             "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 5), "traffic": None,
+            "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 5), "traffic": traffic, "traffic_unit": "B/launch",
+            "traffic_source": traffic_src,
             "launches_per_step": nl.value // n_replay,
             "avg_launch_us": round(ms.value * 1e3 / max(nl.value, 1), 2),
             "gemm_ms_per_step": round(ms.value / n_replay, 3),
@@ -260,7 +278,7 @@ def main():
             "config": {"workload": "s2st_transformer base 12enc/6dec d512 nfps4 + aux ASR/ST(1x64) + CTC, "
                                    "recipe dropouts, max-tokens=20000 Fisher-shaped batches, update-freq 1",
                        "global_batch_mel_frames": round(total_frames / args.steps, 1),
-                       "parallelism": f"dp{world}", "gemm": "bf16 MFMA, fp32 accumulate, fp32 storage",
+                       "parallelism": f"dp{world}", "gemm": "bf16 MFMA operands (bf16 copies of fp32 tensors), fp32 accumulate, fp32 master weights / residual stream / softmax / losses",
                        "final_loss": round(last_loss, 4),
                        "model_tflops": round(total_flops / dt / 1e12, 2)},
         }
