@@ -292,6 +292,36 @@ int32_t s2st_engine_num_segments(const s2st_engine* e);
 /* after segment i has run, gradients in arena range [lo, hi) are final */
 int s2st_engine_segment_range(const s2st_engine* e, int32_t i, int64_t* lo, int64_t* hi);
 
+/* ---- AR inference (config 5): fairseq/speech_generator_for_s2st.py:46-110 drives these.
+ * decode_begin runs the encoder on `b` (eval mode; out->enc_out / tap0 / tap1 receive the encoder
+ * outputs) and fills the caller-owned `state` (self-attention K/V caches for max_steps frames + the
+ * static cross-attention K/V of every decoder layer).  decode_step consumes the previous output
+ * frame prev [B][out_dim] (zeros at step 0), appends to the caches and returns feat_out [B][out_dim]
+ * (pre-post-net features), eos_prob [B] = sigmoid(stop logit) and, optionally, the head-averaged
+ * cross-attention of the last layer attn_out [B][E].  `pos` [B] = positional-table row of this step
+ * (step + 2: fairseq's padding_idx + 1 offset).  Prenet dropout is always on (tacotron2.py:95-98):
+ * `seed` keys its mask.  postnet_eval = feat + postnet(feat) with BatchNorm running statistics. */
+int64_t s2st_engine_decode_state_floats(const s2st_engine* e, int32_t B, int32_t E, int32_t max_steps);
+int s2st_engine_decode_begin(s2st_engine* e, const s2st_batch* b, const s2st_outputs* out, float* state,
+                             int64_t state_floats, int32_t max_steps, float* workspace,
+                             int64_t workspace_floats, void* stream);
+int s2st_engine_decode_step(s2st_engine* e, int32_t step, const float* prev, const int32_t* pos,
+                            const int32_t* self_klen /* [B] or NULL: self-attention keys per utterance */,
+                            uint64_t seed, float* feat_out, float* eos_prob, float* attn_out, float* workspace,
+                            int64_t workspace_floats, void* stream);
+int s2st_engine_postnet_eval(s2st_engine* e, const float* feat, int32_t B, int32_t D, float* post_out,
+                             float* workspace, int64_t workspace_floats, void* stream);
+
+/* helpers of the generator and the Griffin-Lim vocoder (fairseq/models/text_to_speech/vocoder.py:84-144) */
+int s2st_argmax_dim1_f32(const float* x, int64_t* idx, int32_t B, int32_t E, int32_t D, void* stream);
+int s2st_affine_cols_f32(const float* x, const float* scale, const float* shift, float* y, int64_t rows, int32_t C, void* stream);
+int s2st_exp_transpose_f32(const float* x, float* y, int32_t T, int32_t C, void* stream);
+int s2st_clamp_min_f32(float* x, int64_t n, float lo, void* stream);
+int s2st_gl_polar_f32(const float* mag, const float* ang, float* X, int32_t F, int32_t T, void* stream);
+int s2st_gl_project_f32(const float* mag, const float* Y, float* X, int32_t F, int32_t T, void* stream);
+int s2st_reflect_pad_f32(const float* x, float* y, int32_t n, int32_t pad, void* stream);
+int s2st_gl_overlap_add_f32(const float* frames, const float* wsq, float* wave, int32_t T, int32_t n_fft, int32_t hop, int32_t n_out, void* stream);
+
 /* ---- frozen HuBERT front end of config 4 (--use-hubert): fairseq/models/hubert/hubert.py:412-461,
  * 518-534 (extract_features, eval, mask=False) with wav2vec2.py:736-905.  The handle is an
  * s2st_engine in "hubert mode": parameters are enumerated / bound with s2st_engine_param_info,

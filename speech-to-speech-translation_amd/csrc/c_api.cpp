@@ -124,6 +124,29 @@ int s2st_flash_attn_bwd_bf16(const s2st_attn_args* args, const float* dO, float*
   return s2st_flash_attn_bwd(args, dO, dvec_scratch, (hipStream_t)stream);
 }
 
+int s2st_argmax_dim1_f32(const float* x, int64_t* idx, int32_t B, int32_t E, int32_t D, void* stream) {
+  return s2st_argmax_dim1(x, (long*)idx, B, E, D, (hipStream_t)stream);
+}
+int s2st_affine_cols_f32(const float* x, const float* scale, const float* shift, float* y, int64_t rows, int32_t C, void* stream) {
+  return s2st_affine_cols(x, scale, shift, y, rows, C, (hipStream_t)stream);
+}
+int s2st_exp_transpose_f32(const float* x, float* y, int32_t T, int32_t C, void* stream) {
+  return s2st_exp_transpose(x, y, T, C, (hipStream_t)stream);
+}
+int s2st_clamp_min_f32(float* x, int64_t n, float lo, void* stream) { return s2st_clamp_min(x, n, lo, (hipStream_t)stream); }
+int s2st_gl_polar_f32(const float* mag, const float* ang, float* X, int32_t F, int32_t T, void* stream) {
+  return s2st_gl_polar(mag, ang, X, F, T, (hipStream_t)stream);
+}
+int s2st_gl_project_f32(const float* mag, const float* Y, float* X, int32_t F, int32_t T, void* stream) {
+  return s2st_gl_project(mag, Y, X, F, T, (hipStream_t)stream);
+}
+int s2st_reflect_pad_f32(const float* x, float* y, int32_t n, int32_t pad, void* stream) {
+  return s2st_reflect_pad(x, y, n, pad, (hipStream_t)stream);
+}
+int s2st_gl_overlap_add_f32(const float* frames, const float* wsq, float* wave, int32_t T, int32_t n_fft, int32_t hop, int32_t n_out, void* stream) {
+  return s2st_gl_overlap_add(frames, wsq, wave, T, n_fft, hop, n_out, (hipStream_t)stream);
+}
+
 int s2st_profile_gemm(int32_t enable) { s2st_gemm_profile_enable(enable); return 0; }
 int s2st_profile_gemm_read(double* flops, double* ms, int64_t* launches) {
   long n = 0;

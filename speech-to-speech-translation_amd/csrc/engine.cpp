@@ -90,6 +90,17 @@ struct s2st_engine {
     hipStreamWaitEvent(st_, ev_join_, 0);
     side_used = false;
   }
+  // ---- AR decoding state (config 5): caller-owned cache buffer laid out by decode_begin --------
+  bool stop_after_encoder = false;
+  Ten* enc_out_keep = nullptr;
+  struct Dec {
+    float* base = nullptr; int B = 0, E = 0, maxT = 0; const int* enc_lens = nullptr; const float* pe_dec = nullptr;
+  } dec_st;
+  float* dec_selfK(int l) const { return dec_st.base + (long)l * 2 * dec_st.B * dec_st.maxT * c.dec_dim; }
+  float* dec_selfV(int l) const { return dec_selfK(l) + (long)dec_st.B * dec_st.maxT * c.dec_dim; }
+  float* dec_crossKV(int l) const {
+    return dec_st.base + (long)c.dec_layers * 2 * dec_st.B * dec_st.maxT * c.dec_dim + (long)l * dec_st.B * dec_st.E * 2 * c.dec_dim;
+  }
   bool use_flash = true;  // S2ST_NO_FLASH=1: unfused attention everywhere (A/B switch)
   int ffn_act = 1;        // 1 relu (s2st layers), 2 gelu (HuBERT layers)
   // ---- frozen HuBERT front end (config 4): same engine object in "hubert mode" -------------
@@ -739,6 +750,149 @@ struct s2st_engine {
 
 
   // ------------------------------------------------------------------------------------
+  // incremental decoding (fairseq/speech_generator_for_s2st.py:46-110; s2st_transformer.py:369-456 with
+  // incremental_state; transformer_layer.py:301-446; multihead_attention.py:194-385 incremental path)
+  Ten* dec_attn(Ten* qt, int qoff, const float* K, const float* V, long ldk, long kbs, const int* klen, int nkeys,
+                int H, float* attn_mean, int S) {
+    const int Cd = c.dec_dim, B = dec_st.B;
+    Ten* o = newT(B, Cd);
+    if (live())
+      chk(s2st_decode_attn(qt->d + qoff, qt->cols, K, V, ldk, kbs, klen, nkeys, B, H, Cd / H,
+                           1.0f / sqrtf((float)(Cd / H)), o->d, Cd, attn_mean, S, st_));
+    return o;
+  }
+
+  int decode_step(int step, const float* prev, const int* pos, const int* self_klen, uint64_t sd, float* feat_out,
+                  float* eos_prob, float* attn_out) {
+    const int B = dec_st.B, Cd = c.dec_dim, H = c.dec_heads, E = dec_st.E, maxT = dec_st.maxT;
+    if (!dec_st.base || step < 0 || step >= maxT) return S2ST_ERR_ARG;
+    bt.training = 0;
+    seed = sd;
+    const bool pre = c.dec_pre_ln != 0;
+    Ten* x = newT(B, c.out_dim, const_cast<float*>(prev));
+    x->needs_grad = false;
+    // Prenet: dropout is ALWAYS on (tacotron2.py:95-98), also at inference
+    for (int i = 0; i < c.prenet_layers; ++i)
+      x = linear(x, prenet[i].w, prenet[i].b, prenet[i].N, prenet[i].K, 1, c.prenet_dropout);
+    x = linear(x, prenet.back().w, prenet.back().b, Cd, c.prenet_dim);
+    x = add_pe(x, pos, dec_st.pe_dec, 1.f, pos_alpha, 0.f);
+    for (int l = 0; l < c.dec_layers; ++l) {
+      const DecLayerP& L = dec[l];
+      // self-attention over the cached keys / values 0..step
+      Ten* xin = pre ? layernorm(x, L.ln1) : x;
+      Ten* kvq = linear(xin, L.sa.kvq_w, L.sa.kvq_b, 3 * Cd, Cd);
+      if (live()) {
+        Split xs{(long)3 * Cd, 0, 0, 0}, ys{(long)maxT * Cd, 0, 0, 0};
+        chk(s2st_copy_rows(kvq->d, xs, dec_selfK(l) + (long)step * Cd, ys, B, Cd, st_));
+        chk(s2st_copy_rows(kvq->d + Cd, xs, dec_selfV(l) + (long)step * Cd, ys, B, Cd, st_));
+      }
+      // keys >= self_klen[b] are masked: a finished utterance keeps its final length (the reference's
+      // cached key padding mask, speech_generator_for_s2st.py:88-89 + multihead_attention.py:268-277)
+      Ten* o = dec_attn(kvq, 2 * Cd, dec_selfK(l), dec_selfV(l), Cd, (long)maxT * Cd, self_klen, step + 1, H, nullptr, 0);
+      x = linear(o, L.sa.out_w, L.sa.out_b, Cd, Cd, 0, 0.f, x);
+      if (!pre) x = layernorm(x, L.ln1);
+      // encoder attention (static keys / values precomputed by decode_begin)
+      xin = pre ? layernorm(x, L.ln2) : x;
+      Ten* q = linear(xin, L.xa.q_w, L.xa.q_b, Cd, Cd);
+      const bool align = l == c.dec_layers - 1;
+      o = dec_attn(q, 0, dec_crossKV(l), dec_crossKV(l) + Cd, 2 * Cd, (long)E * 2 * Cd, dec_st.enc_lens, E, H,
+                   align ? attn_out : nullptr, E);
+      x = linear(o, L.xa.out_w, L.xa.out_b, Cd, Cd, 0, 0.f, x);
+      if (!pre) x = layernorm(x, L.ln2);
+      xin = pre ? layernorm(x, L.ln3) : x;
+      x = ffn_block(xin, L.fc1, L.fc2, x);
+      if (!pre) x = layernorm(x, L.ln3);
+    }
+    if (has_dec_ln) x = layernorm(x, dec_ln);
+    linear(x, feat_proj.w, feat_proj.b, c.out_dim, Cd, 0, 0.f, nullptr, feat_out);
+    Ten* eos = linear(x, eos_proj.w, eos_proj.b, 1, Cd);
+    if (live()) chk(s2st_sigmoid(eos->d, eos_prob, B, st_));
+    return err;
+  }
+
+  // conv weight in the GEMM layouts (scratch at the bottom of the workspace)
+  ConvW make_conv_scratch(const ConvP& p, bool need_wd, bool tr) {
+    ConvW s;
+    const bool fm = fast();
+    long n = (long)p.O * p.I * p.Kw;
+    s.wf = alloc(n);
+    s.wd = need_wd ? alloc(n) : nullptr;
+    s.dwf = alloc(n, tr);
+    if (live()) chk(s2st_conv_w_permute(P + p.w, s.wf, s.wd, p.O, p.I, p.Kw, st_));
+    s.wfh = fm ? cast_buf(s.wf, n) : nullptr;
+    s.wdh = fm && need_wd ? cast_buf(s.wd, n) : nullptr;
+    return s;
+  }
+
+  // post-net: 5 x (conv k5 -> BatchNorm -> tanh -> dropout), + residual (tacotron2.py:101-126).
+  // Training: batch statistics over ALL B*D rows; eval: running statistics.
+  Ten* postnet(Ten* feat, int B, int D, bool tr, std::vector<ConvW>& csp, float* post_out) {
+    const bool fm = fast();
+    Ten* cur = feat;  // plain holder of the current layer input
+    const int pp = c.postnet_k / 2;
+    float* curh = alloc((long)B * (D + 2 * pp) * c.out_dim, true);
+    if (live()) {
+      Split xs{(long)c.out_dim, 0, 0, 0};
+      Split ys{(long)c.out_dim, (long)(D + 2 * pp) * c.out_dim, D, 0};
+      chk(s2st_copy_rows(feat->d, xs, curh + (long)pp * c.out_dim, ys, B * D, c.out_dim, st_));
+    }
+    Ten* post = nullptr;
+    float* bn_tmp = alloc(2 * (long)(c.postnet_dim > c.out_dim ? c.postnet_dim : c.out_dim));
+    for (int i = 0; i < c.postnet_layers; ++i) {
+      const ConvP& pc = post_conv[i];
+      const BNP& bn = post_bn[i];
+      const bool last = i == c.postnet_layers - 1;
+      const bf16raw* curhh = fm ? cast_buf(curh, (long)B * (D + 2 * pp) * pc.I) : nullptr;
+      Ten* z = conv(ConvIn{curh, cur, D, curhh}, pc, B, 1, csp[i]);
+      float* mean = alloc(bn.C);
+      float* var = alloc(bn.C);
+      touch(bn.b + bn.C);
+      const float pdrop = tr ? c.postnet_dropout : 0.f;
+      const uint64_t sd = pdrop > 0.f ? next_seed() : 0;
+      float* nexth = nullptr;
+      Ten* out;
+      Split osp;
+      if (last) {
+        out = newT(B * D, bn.C, post_out);
+        osp = Split{(long)bn.C, 0, 0, 0};
+      } else {
+        nexth = alloc((long)B * (D + 2 * pp) * bn.C, true);
+        out = newT(B * D, bn.C, nexth + (long)pp * bn.C);
+        osp = Split{(long)bn.C, (long)(D + 2 * pp) * bn.C, D, 0};
+      }
+      if (live()) {
+        const float *m = BUF + bn.rm, *v = BUF + bn.rv;
+        if (tr) {
+          chk(s2st_bn_stats(z->d, B * D, bn.C, mean, var, BUF + bn.rm, BUF + bn.rv, 0.1f, bn_tmp, st_));
+          m = mean; v = var;
+        }
+        chk(s2st_bn_apply(z->d, m, v, P + bn.g, P + bn.b, out->d, osp, last ? feat->d : nullptr, B * D,
+                          bn.C, 1e-5f, last ? 0 : 1, pdrop, sd, st_));
+      }
+      BNP bnp = bn;
+      tape.push_back([=]() {
+        if (!out->g) return;
+        if (last) {  // post = feat + postnet(feat): the residual branch
+          bool acc;
+          float* df = gradbuf(feat, acc);
+          if (live()) chk(s2st_dropout(out->g, df, feat->n(), 1.f, 0.f, 0, acc ? 1 : 0, st_));
+        }
+        bool acc;
+        float* dz = gradbuf(z, acc);
+        (void)acc;
+        Split ps{(long)bnp.C, 0, 0, 0};
+        if (live())
+          chk(s2st_bn_bwd(out->g, ps, z->d, mean, var, P + bnp.g, P + bnp.b, dz, ps, G + bnp.g, G + bnp.b,
+                          bn_tmp, B * D, bnp.C, 1e-5f, last ? 0 : 1, pdrop, sd, st_));
+      });
+      cur = out;
+      curh = nexth;
+      if (last) post = out;
+    }
+    return post;
+  }
+
+  // ------------------------------------------------------------------------------------
   // HuBERT (fairseq/models/hubert/hubert.py:412-461, 518-534; wav2vec2.py:736-905): parameters in
   // GEMM-ready layouts (conv weights [O][k][I], the weight-normed pos_conv as its effective weight
   // [G][E/G][k][E/G]); the host wrapper converts from the reference state_dict layouts.
@@ -894,17 +1048,7 @@ struct s2st_engine {
     skws = fm ? alloc(skws_n) : nullptr;
     skws_side = fm && side_ ? alloc(skws_n) : skws;
     typedef ConvW ConvScratch;
-    auto conv_scratch = [&](const ConvP& p, bool need_wd) {
-      ConvScratch s;
-      long n = (long)p.O * p.I * p.Kw;
-      s.wf = alloc(n);
-      s.wd = need_wd ? alloc(n) : nullptr;
-      s.dwf = alloc(n, tr);
-      if (live()) chk(s2st_conv_w_permute(P + p.w, s.wf, s.wd, p.O, p.I, p.Kw, st_));
-      s.wfh = fm ? cast_buf(s.wf, n) : nullptr;
-      s.wdh = fm && need_wd ? cast_buf(s.wd, n) : nullptr;
-      return s;
-    };
+    auto conv_scratch = [&](const ConvP& p, bool need_wd) { return make_conv_scratch(p, need_wd, tr); };
     ConvScratch cs0 = conv_scratch(sub[0], false), cs1 = conv_scratch(sub[1], true);
     std::vector<ConvScratch> csp;
     for (auto& pc : post_conv) csp.push_back(conv_scratch(pc, true));
@@ -941,6 +1085,10 @@ struct s2st_engine {
     if (c.has_asr && tap_asr) tap_asr = layernorm(tap_asr, asr_norm, outs.tap0);
     if (c.has_st && tap_st) tap_st = layernorm(tap_st, st_norm, outs.tap1);
     mark();
+    if (stop_after_encoder) {  // decode_begin: the AR loop drives the decoder itself
+      enc_out_keep = enc_out;
+      return err;
+    }
     // ---- decoder: prenet (dropout always on), alpha * positions, layers ---------------------------
     Ten* prev = newT(B * D, c.out_dim, const_cast<float*>(bt.prev));
     prev->needs_grad = false;
@@ -960,68 +1108,7 @@ struct s2st_engine {
     if (has_dec_ln) y = layernorm(y, dec_ln);
     Ten* feat = linear(y, feat_proj.w, feat_proj.b, c.out_dim, Cd, 0, 0.f, nullptr, outs.feat);
     Ten* eos = linear(y, eos_proj.w, eos_proj.b, 1, Cd, 0, 0.f, nullptr, outs.eos);
-    // ---- post-net: 5 x (conv k5 -> BatchNorm(batch stats over ALL B*D rows) -> tanh -> dropout) ----
-    Ten* cur = feat;  // plain holder of the current layer input
-    const int pp = c.postnet_k / 2;
-    float* curh = alloc((long)B * (D + 2 * pp) * c.out_dim, true);
-    if (live()) {
-      Split xs{(long)c.out_dim, 0, 0, 0};
-      Split ys{(long)c.out_dim, (long)(D + 2 * pp) * c.out_dim, D, 0};
-      chk(s2st_copy_rows(feat->d, xs, curh + (long)pp * c.out_dim, ys, B * D, c.out_dim, st_));
-    }
-    Ten* post = nullptr;
-    float* bn_tmp = alloc(2 * (long)(c.postnet_dim > c.out_dim ? c.postnet_dim : c.out_dim));
-    for (int i = 0; i < c.postnet_layers; ++i) {
-      const ConvP& pc = post_conv[i];
-      const BNP& bn = post_bn[i];
-      const bool last = i == c.postnet_layers - 1;
-      const bf16raw* curhh = fm ? cast_buf(curh, (long)B * (D + 2 * pp) * pc.I) : nullptr;
-      Ten* z = conv(ConvIn{curh, cur, D, curhh}, pc, B, 1, csp[i]);
-      float* mean = alloc(bn.C);
-      float* var = alloc(bn.C);
-      touch(bn.b + bn.C);
-      const float pdrop = tr ? c.postnet_dropout : 0.f;
-      const uint64_t sd = pdrop > 0.f ? next_seed() : 0;
-      float* nexth = nullptr;
-      Ten* out;
-      Split osp;
-      if (last) {
-        out = newT(B * D, bn.C, outs.post_feat);
-        osp = Split{(long)bn.C, 0, 0, 0};
-      } else {
-        nexth = alloc((long)B * (D + 2 * pp) * bn.C, true);
-        out = newT(B * D, bn.C, nexth + (long)pp * bn.C);
-        osp = Split{(long)bn.C, (long)(D + 2 * pp) * bn.C, D, 0};
-      }
-      if (live()) {
-        const float *m = BUF + bn.rm, *v = BUF + bn.rv;
-        if (tr) {
-          chk(s2st_bn_stats(z->d, B * D, bn.C, mean, var, BUF + bn.rm, BUF + bn.rv, 0.1f, bn_tmp, st_));
-          m = mean; v = var;
-        }
-        chk(s2st_bn_apply(z->d, m, v, P + bn.g, P + bn.b, out->d, osp, last ? feat->d : nullptr, B * D,
-                          bn.C, 1e-5f, last ? 0 : 1, pdrop, sd, st_));
-      }
-      BNP bnp = bn;
-      tape.push_back([=]() {
-        if (!out->g) return;
-        if (last) {  // post = feat + postnet(feat): the residual branch
-          bool acc;
-          float* df = gradbuf(feat, acc);
-          if (live()) chk(s2st_dropout(out->g, df, feat->n(), 1.f, 0.f, 0, acc ? 1 : 0, st_));
-        }
-        bool acc;
-        float* dz = gradbuf(z, acc);
-        (void)acc;
-        Split ps{(long)bnp.C, 0, 0, 0};
-        if (live())
-          chk(s2st_bn_bwd(out->g, ps, z->d, mean, var, P + bnp.g, P + bnp.b, dz, ps, G + bnp.g, G + bnp.b,
-                          bn_tmp, B * D, bnp.C, 1e-5f, last ? 0 : 1, pdrop, sd, st_));
-      });
-      cur = out;
-      curh = nexth;
-      if (last) post = out;
-    }
+    Ten* post = postnet(feat, B, D, tr, csp, outs.post_feat);
     mark();
     // ---- CTC head on tap 0 (ctc_proj lives on the decoder, fed the encoder tap; :458-463) ----------
     Ten* ctc_logits = nullptr;
@@ -1253,6 +1340,91 @@ int s2st_engine_segment_range(const s2st_engine* e, int32_t i, int64_t* lo, int6
   *lo = e->marks[ns - i - 1].param_off;
   *hi = e->marks[ns - i].param_off;
   return 0;
+}
+
+// ---- AR decoding + eval post-net (config 5) ---------------------------------------------------
+int64_t s2st_engine_decode_state_floats(const s2st_engine* e, int32_t B, int32_t E, int32_t max_steps) {
+  const long Cd = e->c.dec_dim, L = e->c.dec_layers;
+  return L * 2 * B * (long)max_steps * Cd + L * (long)B * E * 2 * Cd + 64;
+}
+
+int s2st_engine_decode_begin(s2st_engine* e, const s2st_batch* b, const s2st_outputs* out, float* state,
+                             int64_t state_floats, int32_t max_steps, float* workspace, int64_t workspace_floats,
+                             void* stream) {
+  if (!e->P || !e->BUF || !state || !b || !out) return S2ST_ERR_ARG;
+  if (state_floats < s2st_engine_decode_state_floats(e, b->B, b->E, max_steps)) return S2ST_ERR_WORKSPACE;
+  e->reset_call();
+  e->bt = *b;
+  e->bt.training = 0;
+  e->bt.tgt = nullptr;
+  e->outs = *out;
+  e->dry = false;
+  e->ws = workspace;
+  e->ws_cap = workspace_floats;
+  e->st_ = (hipStream_t)stream;
+  e->stop_after_encoder = true;
+  int rc = e->forward();
+  e->stop_after_encoder = false;
+  if (rc) return rc;
+  e->dec_st.base = state;
+  e->dec_st.B = b->B; e->dec_st.E = b->E; e->dec_st.maxT = max_steps;
+  e->dec_st.enc_lens = b->enc_lens;
+  e->dec_st.pe_dec = b->pe_dec;
+  // static cross-attention keys / values of every decoder layer (static_kv=True)
+  for (int l = 0; l < e->c.dec_layers; ++l) {
+    const XAttnP& xa = e->dec[l].xa;
+    e->linear(e->enc_out_keep, xa.kv_w, xa.kv_b, 2 * e->c.dec_dim, e->c.enc_dim, 0, 0.f, nullptr, e->dec_crossKV(l));
+  }
+  e->tape.clear();
+  return e->err;
+}
+
+int s2st_engine_decode_step(s2st_engine* e, int32_t step, const float* prev, const int32_t* pos,
+                            const int32_t* self_klen, uint64_t seed, float* feat_out, float* eos_prob,
+                            float* attn_out, float* workspace, int64_t workspace_floats, void* stream) {
+  if (!e->P || !prev || !pos || !feat_out || !eos_prob) return S2ST_ERR_ARG;
+  s2st_engine::Dec keep = e->dec_st;
+  s2st_batch bt_keep = e->bt;
+  e->reset_call();
+  e->dec_st = keep;
+  e->bt = bt_keep;
+  e->dry = false;
+  e->ws = workspace;
+  e->ws_cap = workspace_floats;
+  e->st_ = (hipStream_t)stream;
+  e->skws = nullptr; e->skws_n = 0; e->skws_side = nullptr;
+  if (e->fast()) {
+    if (!e->PH) return S2ST_ERR_ARG;  // PH was refreshed by decode_begin's forward
+  }
+  int rc = e->decode_step(step, prev, pos, self_klen, seed, feat_out, eos_prob, attn_out);
+  e->tape.clear();
+  return rc;
+}
+
+int s2st_engine_postnet_eval(s2st_engine* e, const float* feat, int32_t B, int32_t D, float* post_out,
+                             float* workspace, int64_t workspace_floats, void* stream) {
+  if (!e->P || !e->BUF || !feat || !post_out) return S2ST_ERR_ARG;
+  s2st_engine::Dec keep = e->dec_st;
+  e->reset_call();
+  e->dec_st = keep;
+  e->dry = false;
+  e->ws = workspace;
+  e->ws_cap = workspace_floats;
+  e->st_ = (hipStream_t)stream;
+  e->bt.training = 0;
+  e->skws = nullptr; e->skws_n = 0; e->skws_side = nullptr;
+  if (e->fast()) {
+    if (!e->PH) return S2ST_ERR_ARG;
+    int rc = s2st_cast_bf16_rows(e->P, e->n_params, e->PH, e->n_params, 1, (int)e->n_params, e->st_);
+    if (rc) return rc;
+  }
+  std::vector<s2st_engine::ConvW> csp;
+  for (auto& pc : e->post_conv) csp.push_back(e->make_conv_scratch(pc, false, false));
+  Ten* f = e->newT(B * D, e->c.out_dim, const_cast<float*>(feat));
+  f->needs_grad = false;
+  e->postnet(f, B, D, false, csp, post_out);
+  e->tape.clear();
+  return e->err;
 }
 
 // ---- HuBERT front end ---------------------------------------------------------------------------

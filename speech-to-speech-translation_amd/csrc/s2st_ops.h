@@ -161,6 +161,23 @@ int s2st_posconv_prep(float* x, const int* lens, float* img, uint16_t* imgh, int
                       int Tp, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------
+// inference (infer.hip): incremental-decoding attention, stop / alignment / de-CMVN helpers, Griffin-Lim
+// ---------------------------------------------------------------------------------------
+int s2st_decode_attn(const float* q, long ldq, const float* kc, const float* vc, long ldk, long kbs, const int* klen,
+                     int nkeys, int B, int H, int dh, float scale, float* o, long ldo, float* attn_mean, int S,
+                     hipStream_t st);
+int s2st_sigmoid(const float* x, float* y, long n, hipStream_t st);
+int s2st_argmax_dim1(const float* x, long* idx, int B, int E, int D, hipStream_t st);
+int s2st_affine_cols(const float* x, const float* scale, const float* shift, float* y, long rows, int C, hipStream_t st);
+int s2st_exp_transpose(const float* x, float* y, int T, int C, hipStream_t st);
+int s2st_clamp_min(float* x, long n, float lo, hipStream_t st);
+int s2st_gl_polar(const float* mag, const float* ang, float* X, int F, int T, hipStream_t st);
+int s2st_gl_project(const float* mag, const float* Y, float* X, int F, int T, hipStream_t st);
+int s2st_reflect_pad(const float* x, float* y, int n, int pad, hipStream_t st);
+int s2st_gl_overlap_add(const float* frames, const float* wsq, float* wave, int T, int n_fft, int hop, int n_out,
+                        hipStream_t st);
+
+// ---------------------------------------------------------------------------------------
 // losses (losses.hip)
 // ---------------------------------------------------------------------------------------
 // stats (optional) += {sum|fo-t| + sum|fp-t|, sum(fo-t)^2 + sum(fp-t)^2, sum bce} over valid

@@ -337,6 +337,101 @@ class Engine:
         o["encoder_lens"] = keep["enc_lens"]
         return o
 
+    # -- AR decoding (config 5): encoder once, then one decoder step per output frame -------------
+    def decode_begin(self, src: torch.Tensor, src_lens: torch.Tensor, max_steps: int) -> Dict[str, torch.Tensor]:
+        """Runs the encoder (eval mode) and fills the decoding caches for ``max_steps`` frames."""
+        dev, c = self.device, self.cfg
+        src = src.to(dev, torch.float32).contiguous()
+        B, S, _ = src.shape
+        k = c.conv_k
+        E = conv_out_len(conv_out_len(S, k), k)
+        enc_lens = src_lens.cpu().long().clone()
+        for _ in range(2):
+            enc_lens = ((enc_lens.float() - 1) / 2 + 1).floor().long()
+        t = torch.arange(E).unsqueeze(0)
+        enc_pos = torch.where(t < enc_lens.unsqueeze(1), t + PAD + 1, torch.full_like(t, PAD)).to(torch.int32)
+        keep = {"src": src, "enc_lens": enc_lens.to(torch.int32).to(dev), "enc_pos": enc_pos.contiguous().to(dev)}
+        b = Batch()
+        b.B, b.S, b.D, b.E = B, S, 1, E
+        b.src, b.enc_lens, b.enc_pos = src.data_ptr(), keep["enc_lens"].data_ptr(), keep["enc_pos"].data_ptr()
+        b.pe_enc = self.pe(c.enc_dim, E + 2).data_ptr()
+        b.pe_dec = self.pe(c.dec_dim, max_steps + 2).data_ptr()
+        b.training, b.seed = 0, 0
+        # workspace: the encoder forward of this geometry (planned with the full schedule: a superset)
+        geo = ("enc", B, S)
+        need = self._plan.get(geo)
+        if need is None:
+            dry = Batch()
+            for f, _ in Batch._fields_:
+                setattr(dry, f, getattr(b, f))
+            need = int(self.lib.s2st_engine_workspace_floats(self.h, C.byref(dry)))
+            self._plan[geo] = need
+        if need < 0:
+            raise bd.S2STHipError(f"workspace planning failed ({need})")
+        need = max(need, 64 << 20)
+        if self.workspace is None or self.workspace.numel() < need:
+            self.workspace = None
+            self.workspace = torch.empty(int(need * 1.05) + 4096, dtype=torch.float32, device=dev)
+        o = {"encoder_out": torch.empty(B, E, c.enc_dim, device=dev)}
+        out = Outputs()
+        out.enc_out = o["encoder_out"].data_ptr()
+        if c.has_asr or c.has_ctc:
+            o["tap0"] = torch.empty(B, E, c.enc_dim, device=dev)
+            out.tap0 = o["tap0"].data_ptr()
+        if c.has_st:
+            o["tap1"] = torch.empty(B, E, c.enc_dim, device=dev)
+            out.tap1 = o["tap1"].data_ptr()
+        self.lib.s2st_engine_decode_state_floats.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+        self.lib.s2st_engine_decode_state_floats.restype = C.c_int64
+        n_state = int(self.lib.s2st_engine_decode_state_floats(self.h, B, E, max_steps))
+        state = torch.zeros(n_state, dtype=torch.float32, device=dev)
+        self.lib.s2st_engine_decode_begin.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(Outputs), C.c_void_p,
+                                                      C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
+        bd.check(self.lib.s2st_engine_decode_begin(self.h, C.byref(b), C.byref(out), state.data_ptr(), n_state,
+                                                   max_steps, self.workspace.data_ptr(), self.workspace.numel(),
+                                                   bd.stream_ptr()), "s2st_engine_decode_begin")
+        self._dec = dict(B=B, E=E, max_steps=max_steps, state=state, keep=keep, batch=b, outs=o)
+        o["encoder_lens"] = keep["enc_lens"]
+        return o
+
+    def decode_step(self, step: int, prev: torch.Tensor, seed: int, want_attn: bool = True,
+                    self_klen: Optional[torch.Tensor] = None):
+        """prev [B, out_dim] -> (feature_out [B, out_dim], eos_prob [B], attn [B, E] | None)."""
+        d, dev, c = self._dec, self.device, self.cfg
+        B, E = d["B"], d["E"]
+        prev = prev.to(dev, torch.float32).contiguous()
+        pos = torch.full((B,), step + PAD + 1, dtype=torch.int32, device=dev)
+        feat = torch.empty(B, c.out_dim, device=dev)
+        eos = torch.empty(B, device=dev)
+        attn = torch.empty(B, E, device=dev) if want_attn else None
+        klen = self_klen.to(dev, torch.int32).contiguous() if self_klen is not None else None
+        self.lib.s2st_engine_decode_step.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                     C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                     C.c_int64, C.c_void_p]
+        bd.check(self.lib.s2st_engine_decode_step(self.h, step, prev.data_ptr(), pos.data_ptr(), bd.ptr(klen), seed,
+                                                  feat.data_ptr(),
+                                                  eos.data_ptr(), bd.ptr(attn), self.workspace.data_ptr(),
+                                                  self.workspace.numel(), bd.stream_ptr()), "s2st_engine_decode_step")
+        d["last"] = (prev, pos, klen)
+        return feat, eos, attn
+
+    def postnet_eval(self, feat: torch.Tensor) -> torch.Tensor:
+        """feat [B, D, out_dim] -> feat + postnet(feat) with BatchNorm running statistics."""
+        dev = self.device
+        feat = feat.to(dev, torch.float32).contiguous()
+        B, D, _ = feat.shape
+        out = torch.empty_like(feat)
+        need = 64 * B * (D + 8) * max(self.cfg.postnet_dim, self.cfg.out_dim) + (8 << 20)
+        if self.workspace is None or self.workspace.numel() < need:
+            self.workspace = None
+            self.workspace = torch.empty(need, dtype=torch.float32, device=dev)
+        self.lib.s2st_engine_postnet_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                                      C.c_void_p, C.c_int64, C.c_void_p]
+        bd.check(self.lib.s2st_engine_postnet_eval(self.h, feat.data_ptr(), B, D, out.data_ptr(),
+                                                   self.workspace.data_ptr(), self.workspace.numel(), bd.stream_ptr()),
+                 "s2st_engine_postnet_eval")
+        return out
+
     def num_segments(self) -> int:
         return int(self.lib.s2st_engine_num_segments(self.h))
 

@@ -1,0 +1,100 @@
+"""AR mel generation on the HIP path: the counterpart of
+``fairseq/speech_generator_for_s2st.py:35-134`` (AutoRegressiveSpeechGenerator) with the same
+constructor arguments, stop rule, outputs and post-processing.  The decoder steps, the eval-mode
+post-net, the alignment argmax, the global-CMVN de-normalisation and the vocoder all run in
+libs2st_hip.so; this file is the reference's host loop (step counting, finished flags, slicing)."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from .runtime import binding as bd
+
+
+class SpeechGenerator:
+    def __init__(self, model, vocoder, data_cfg=None):
+        self.model, self.vocoder = model, vocoder
+        self.gcmvn_mean = self.gcmvn_std = None
+        stats = None
+        if data_cfg is not None:
+            stats = getattr(data_cfg, "global_cmvn_stats", None) if not isinstance(data_cfg, dict) else data_cfg.get("global_cmvn_stats")
+        if stats is not None:  # speech_generator_for_s2st.py:18-28: {"mean": [...], "std": [...]}
+            self.gcmvn_mean = torch.as_tensor(stats["mean"], dtype=torch.float32)
+            self.gcmvn_std = torch.as_tensor(stats["std"], dtype=torch.float32)
+
+    def gcmvn_denormalize(self, x: torch.Tensor) -> torch.Tensor:
+        """x [B, T, C] -> x * std + mean (speech_generator_for_s2st.py:18-28)."""
+        if self.gcmvn_mean is None:
+            return x
+        dev = x.device
+        y = torch.empty_like(x)
+        bd.call("s2st_affine_cols_f32", x.contiguous(), self.gcmvn_std.to(dev), self.gcmvn_mean.to(dev), y,
+                x.shape[0] * x.shape[1], x.shape[2])
+        return y
+
+    def get_waveform(self, feat):
+        return None if self.vocoder is None else self.vocoder(feat).squeeze(0)
+
+
+class AutoRegressiveSpeechGenerator(SpeechGenerator):
+    def __init__(self, model, vocoder, data_cfg=None, max_iter: int = 6000, eos_prob_threshold: float = 0.5,
+                 input_text: bool = False, seed: int = 1):
+        super().__init__(model, vocoder, data_cfg)
+        if input_text:
+            raise NotImplementedError("text-input (t2s) variant is outside this path")
+        self.max_iter, self.eos_prob_threshold, self.seed = max_iter, eos_prob_threshold, seed
+
+    @torch.no_grad()
+    def generate(self, model, sample, has_targ: bool = False, **kwargs) -> List[Dict[str, Optional[torch.Tensor]]]:
+        model.eval()
+        eng = model.engine
+        ni = sample["net_input"]
+        src, src_lens = model._front_end(ni.get("src_speech"), ni.get("src_speech_lens"),
+                                         ni.get("collated_audios_orig"), ni.get("padding_mask"))
+        bsz = src.shape[0]
+        c = eng.cfg
+        n_frames_per_step = model.args.n_frames_per_step
+        out_dim = c.out_dim
+        raw_dim = out_dim // n_frames_per_step
+        dev = eng.device
+        eng.decode_begin(src, src_lens, self.max_iter)
+        feat, attn, eos_prob = [], [], []
+        finished = torch.zeros(bsz, dtype=torch.bool)
+        out_lens = torch.full((bsz,), self.max_iter, dtype=torch.long)
+        prev = torch.zeros(bsz, out_dim, device=dev)  # bos frame
+        for step in range(self.max_iter):
+            cur_out_lens = out_lens.clone()
+            cur_out_lens.masked_fill_(cur_out_lens.eq(self.max_iter), step + 1)
+            cur_feat, cur_eos, cur_attn = eng.decode_step(step, prev, self.seed * 1000003 + step,
+                                                          self_klen=cur_out_lens)
+            feat.append(cur_feat.unsqueeze(1))
+            attn.append(cur_attn.unsqueeze(2))
+            eos_prob.append(cur_eos.unsqueeze(1))
+            cur_finished = cur_eos.cpu() > self.eos_prob_threshold  # the stop rule needs the host every step
+            out_lens.masked_fill_((~finished) & cur_finished, step + 1)
+            finished = finished | cur_finished
+            if int(finished.sum()) == bsz:
+                break
+            prev = cur_feat
+        feat = torch.cat(feat, dim=1)
+        feat = eng.postnet_eval(feat)  # postnet(feat) + feat, BatchNorm in eval mode
+        eos_prob = torch.cat(eos_prob, dim=1)
+        attn = torch.cat(attn, dim=2).contiguous()  # [B, E, D]
+        alignment = torch.empty(bsz, attn.shape[2], dtype=torch.long, device=dev)
+        bd.call("s2st_argmax_dim1_f32", attn, alignment, bsz, attn.shape[1], attn.shape[2])
+        feat = self.gcmvn_denormalize(feat.reshape(bsz, -1, raw_dim))
+        eos_prob = eos_prob.repeat_interleave(n_frames_per_step, dim=1)
+        attn = attn.repeat_interleave(n_frames_per_step, dim=2)
+        alignment = alignment.repeat_interleave(n_frames_per_step, dim=1)
+        out_lens = out_lens * n_frames_per_step
+        finalized = [{"feature": feat[b, :l], "eos_prob": eos_prob[b, :l], "attn": attn[b, :, :l],
+                      "alignment": alignment[b, :l], "waveform": self.get_waveform(feat[b, :l])}
+                     for b, l in zip(range(bsz), out_lens.tolist())]
+        if has_targ:
+            tgt = self.gcmvn_denormalize(sample["tgt_speech"].to(dev, torch.float32).reshape(bsz, -1, raw_dim))
+            tl = (sample["target_lengths"] * n_frames_per_step).tolist()
+            for b, l in enumerate(tl):
+                finalized[b]["targ_feature"] = tgt[b, :l]
+                finalized[b]["targ_waveform"] = self.get_waveform(tgt[b, :l])
+        return finalized
