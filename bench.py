@@ -171,6 +171,10 @@ def main():
     macs = [algorithmic_macs(s, a) for s in samples]
     vlog('batches prepared', [(len(ix), int(corpus.src_n_frames[ix].max())) for ix in mine])
 
+    # size workspace / output pool for the largest batch geometry up front (what a max-tokens data
+    # loader knows): no device allocation inside the loop
+    trainer.engine.reserve(prepared)
+
     def step(i):
         return trainer.train_step([_Prepared(prepared[i], samples[i])])
 

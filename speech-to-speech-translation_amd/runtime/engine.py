@@ -163,6 +163,7 @@ class Engine:
             self.lib.s2st_engine_bind_bf16.argtypes = [C.c_void_p, C.c_void_p]
             self.lib.s2st_engine_bind_bf16(h, self.params_bf16.data_ptr())
         self.workspace: Optional[torch.Tensor] = None
+        self._outpool: Optional[torch.Tensor] = None
         self._pe: Dict[int, torch.Tensor] = {}
         self._plan: Dict[tuple, int] = {}
         self._keep = None
@@ -303,8 +304,20 @@ class Engine:
             self.workspace = torch.empty(int(need * 1.05) + 4096, dtype=torch.float32, device=self.device)
         dev, c = self.device, self.cfg
         B, D, E = b.B, b.D, b.E
+        pool = self._outpool
+        cursor = [0]
 
         def buf(*shape):
+            # outputs are carved from the pool reserved by reserve() when it is large enough (no
+            # allocator traffic inside a training loop over many batch geometries)
+            n = 1
+            for d_ in shape:
+                n *= d_
+            n64 = (n + 63) // 64 * 64
+            if pool is not None and cursor[0] + n64 <= pool.numel():
+                t = pool[cursor[0]:cursor[0] + n].view(shape)
+                cursor[0] += n64
+                return t
             return torch.empty(shape, dtype=torch.float32, device=dev)
 
         o = {"post_feat_out": buf(B, D, c.out_dim), "feature_out": buf(B, D, c.out_dim),
@@ -431,6 +444,32 @@ class Engine:
                                                    self.workspace.data_ptr(), self.workspace.numel(), bd.stream_ptr()),
                  "s2st_engine_postnet_eval")
         return out
+
+    def reserve(self, batches, training: bool = True, want_attn: bool = False):
+        """Size the activation workspace and the output pool for the largest of ``batches`` (prepared
+        ``(Batch, keep)`` pairs) up front -- what a data loader with a max-tokens bound does once -- so a
+        loop over many batch geometries performs no device allocation (hipMalloc / hipFree stall the
+        queue)."""
+        need, out = 0, 0
+        c = self.cfg
+        for b, _ in batches:
+            b.training, b.want_attn = int(training), int(want_attn)
+            geo = (b.B, b.S, b.D, b.Ls, b.Lt, bool(b.tgt), b.training)
+            n = self._plan.get(geo)
+            if n is None:
+                n = int(self.lib.s2st_engine_workspace_floats(self.h, C.byref(b)))
+                self._plan[geo] = n
+            if n < 0:
+                raise bd.S2STHipError(f"workspace planning failed ({n})")
+            need = max(need, n)
+            o = 2 * b.B * b.D * c.out_dim + b.B * b.D + 3 * b.B * b.E * c.enc_dim + b.B * b.E * b.D \
+                + b.B * b.Ls * c.src_vocab + b.B * b.Lt * c.tgt_vocab + b.B * b.E * c.src_vocab + 32
+            out = max(out, o + 64 * 16)
+        if self.workspace is None or self.workspace.numel() < need:
+            self.workspace = None
+            self.workspace = torch.empty(int(need * 1.05) + 4096, dtype=torch.float32, device=self.device)
+        if self._outpool is None or self._outpool.numel() < out:
+            self._outpool = torch.empty(out, dtype=torch.float32, device=self.device)
 
     def num_segments(self) -> int:
         return int(self.lib.s2st_engine_num_segments(self.h))
