@@ -50,6 +50,12 @@ typedef struct {
   int32_t accumulate; /* C += value */
   uint64_t seed;
   const float* resid; /* added last; addressed like C; or NULL */
+  /* backward-of-activation epilogue (bf16-operand path): the result is the gradient w.r.t. the OUTPUT
+   * y of a previous ReLU+dropout layer; value = y(m,n) != 0 ? value * mask_scale : 0 (y given as its
+   * bf16 copy, addressed like C), and colsum[n] += sum_m value (that layer's bias gradient). */
+  const uint16_t* mask_y;
+  float mask_scale;
+  float* colsum;
 } s2st_gemm_epilogue;
 
 typedef struct {

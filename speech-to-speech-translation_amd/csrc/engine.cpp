@@ -43,6 +43,13 @@ struct Ten {  // plain [rows][cols] fp32 activation
   int rows = 0, cols = 0;
   bool needs_grad = true;
   bool want_gh = false;  // the gradient is consumed as a GEMM operand: its producer writes gh too
+  // produced by linear(act = ReLU, dropout p) with a single consumer (FFN hidden): the consumer's
+  // data-gradient GEMM applies the activation backward + bias gradient in its epilogue and leaves the
+  // ready bf16 operand in gpre_h (no fp32 gradient of this tensor is ever written)
+  int act_mode = 0;
+  float act_p = 0.f;
+  long act_bias = -1;
+  bf16raw* gpre_h = nullptr;
   long n() const { return (long)rows * cols; }
   int hld() const { return (cols + 7) & ~7; }
 };
@@ -101,6 +108,7 @@ struct s2st_engine {
   float* dec_crossKV(int l) const {
     return dec_st.base + (long)c.dec_layers * 2 * dec_st.B * dec_st.maxT * c.dec_dim + (long)l * dec_st.B * dec_st.E * 2 * c.dec_dim;
   }
+  bool use_act_fuse = true;  // S2ST_NO_ACT_FUSE=1: separate ReLU-dropout backward kernel (A/B switch)
   bool use_flash = true;  // S2ST_NO_FLASH=1: unfused attention everywhere (A/B switch)
   int ffn_act = 1;        // 1 relu (s2st layers), 2 gelu (HuBERT layers)
   // ---- frozen HuBERT front end (config 4): same engine object in "hubert mode" -------------
@@ -353,6 +361,7 @@ struct s2st_engine {
     const bool fm = fast();
     const bf16raw* xh = fm ? half_of(x) : nullptr;
     if (fm && N % 8 == 0) y->h = alloc_h(y->n());
+    if (fm && act == 1 && y->h && !resid) { y->act_mode = 1; y->act_p = drop_p; y->act_bias = b; }
     if (live()) {
       GemmArgs g{};
       g.A = fm ? gemm_rowmajor(xh, x->hld()) : gemm_rowmajor(x->d, x->cols);
@@ -369,7 +378,7 @@ struct s2st_engine {
       chk(s2st_gemm(g, st_));
     }
     tape.push_back([=]() {
-      if (!y->g) return;  // nothing flowed back
+      if (!y->g && !y->gpre_h) return;  // nothing flowed back
       float* dy = y->g;
       if (resid && resid->needs_grad) {
         if (!resid->g) resid->g = dy;  // alias: every reader of dy runs before resid's producers
@@ -379,7 +388,10 @@ struct s2st_engine {
       const int ldp = (N + 7) & ~7;
       const bf16raw* dph = nullptr;
       bool bias_done = false;
-      if (fm && N % 4 == 0) {
+      if (y->gpre_h) {  // the consumer's data-gradient GEMM already applied f' and the bias gradient
+        dph = y->gpre_h;
+        bias_done = true;
+      } else if (fm && N % 4 == 0) {
         // one pass: bf16 GEMM operand of f(dy) + bias gradient (no fp32 dpre is materialised)
         bf16raw* t = alloc_h((long)M * ldp);
         const int mode = act == 1 ? 1 : (drop_p > 0.f ? 2 : 0);
@@ -418,6 +430,8 @@ struct s2st_engine {
         bool acc;
         float* dx = gradbuf(x, acc);
         if (fm && !acc && x->want_gh && x->hld() == x->cols) x->gh = alloc_h(x->n());
+        const bool fuse_act = fm && !acc && x->act_mode == 1 && x->h && x->hld() == x->cols && use_act_fuse;
+        if (fuse_act) x->gpre_h = alloc_h(x->n());
         if (live()) {
           GemmArgs g{};  // dx[M][K] (+)= dpre W
           g.A = fm ? gemm_rowmajor(dph, ldp) : gemm_rowmajor(dpre, N);
@@ -425,6 +439,13 @@ struct s2st_engine {
           g.C = gemm_out(dx, x->cols);
           if (fm && !acc) g.C.h = x->gh;  // the consumer (attention backward) reads dO as a GEMM operand
           g.ep = gemm_epi_default();
+          if (fuse_act) {  // dx is the gradient w.r.t. a ReLU+dropout output: emit its pre-activation gradient
+            g.C.p = nullptr;
+            g.C.h = x->gpre_h;
+            g.ep.mask_y = x->h;
+            g.ep.mask_scale = x->act_p > 0.f ? 1.f / (1.f - x->act_p) : 1.f;
+            g.ep.colsum = x->act_bias >= 0 ? G + x->act_bias : nullptr;
+          }
           g.ep.accumulate = acc ? 1 : 0;
           g.ws = skws; g.ws_floats = skws_n;
           g.M = M; g.N = K; g.K = N; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
@@ -1113,6 +1134,22 @@ struct s2st_engine {
     // ---- CTC head on tap 0 (ctc_proj lives on the decoder, fed the encoder tap; :458-463) ----------
     Ten* ctc_logits = nullptr;
     if (c.has_ctc && tap_asr) ctc_logits = linear(tap_asr, ctc_proj.w, ctc_proj.b, c.src_vocab, C);
+    // The CTC sweep (one workgroup per utterance, ~E sequential steps: latency-bound, ~0.4 ms) runs on the
+    // second stream next to the aux decoders and the other loss kernels; joined before the loss is finalised.
+    float* ctc_per = (with_loss && c.has_ctc) ? alloc(B) : nullptr;
+    float *ctc_lp = nullptr, *ctc_ws = nullptr, *ctc_dl = nullptr;
+    if (with_loss && c.has_ctc && ctc_logits) {
+      ctc_lp = outs.ctc_lprobs ? outs.ctc_lprobs : alloc((long)B * E * c.src_vocab);
+      ctc_ws = alloc(s2st_ctc_workspace_floats(B, E, bt.Ls));
+      // training: the CTC gradient w.r.t. the logits comes out of the same alpha/beta sweep as the
+      // loss, so it is produced here (per unit of upstream gradient) and only scaled in the backward
+      ctc_dl = tr ? alloc(ctc_logits->n()) : nullptr;
+      if (live()) {
+        hipStream_t cs = fork_side();
+        chk(s2st_ctc(ctc_logits->d, (const long*)bt.src_txt, bt.Ls, bt.ctc_in_lens, bt.src_txt_lens, B, E,
+                     c.src_vocab, ctc_lp, ctc_per, ctc_dl, ctc_dl ? c.ctc_weight / B : 0.f, ctc_ws, cs));
+      }
+    }
     // ---- aux text decoders ---------------------------------------------------------------------------
     Ten *asr_logits = nullptr, *st_logits = nullptr;
     if (c.has_asr && tap_asr && bt.prev_src_txt)
@@ -1125,30 +1162,18 @@ struct s2st_engine {
     // ---- losses (s2st_loss.py:219-257) -----------------------------------------------------------------
     if (with_loss) {
       float* stats = outs.stats;
-      float* ctc_per = c.has_ctc ? alloc(B) : nullptr;
-      float* ctc_lp = nullptr;
-      float* ctc_ws = nullptr;
-      if (c.has_ctc && ctc_logits) {
-        ctc_lp = outs.ctc_lprobs ? outs.ctc_lprobs : alloc((long)B * E * c.src_vocab);
-        ctc_ws = alloc(s2st_ctc_workspace_floats(B, E, bt.Ls));
-      }
-      // training: the CTC gradient w.r.t. the logits comes out of the same alpha/beta sweep as the
-      // loss, so it is produced here (per unit of upstream gradient) and only scaled in the backward
-      float* ctc_dl = (tr && ctc_logits) ? alloc(ctc_logits->n()) : nullptr;
       const float nr = (float)bt.ntokens, nf = nr * c.out_dim;
       if (live()) {
         hipMemsetAsync(stats, 0, sizeof(float) * 32, st_);
         chk(s2st_mel_loss(feat->d, post->d, eos->d, bt.tgt, bt.tgt_lens, B, D, c.out_dim, c.bce_pos_weight,
                           stats + S2ST_STAT_L1_SUM, 0, 0, 0, nullptr, nullptr, nullptr, st_));
-        if (ctc_logits)
-          chk(s2st_ctc(ctc_logits->d, (const long*)bt.src_txt, bt.Ls, bt.ctc_in_lens, bt.src_txt_lens, B, E,
-                       c.src_vocab, ctc_lp, ctc_per, ctc_dl, ctc_dl ? c.ctc_weight / B : 0.f, ctc_ws, st_));
         if (asr_logits)
           chk(s2st_ls_ce(asr_logits->d, (const long*)bt.src_txt, B * bt.Ls, c.src_vocab, 1, c.label_smoothing,
                          stats + S2ST_STAT_ASR_NLL, nullptr, 0.f, st_));
         if (st_logits)
           chk(s2st_ls_ce(st_logits->d, (const long*)bt.tgt_txt, B * bt.Lt, c.tgt_vocab, 1, c.label_smoothing,
                          stats + S2ST_STAT_ST_NLL, nullptr, 0.f, st_));
+        join_side();  // CTC per-utterance losses
         chk(s2st_loss_finalize(stats, ctc_per, B, nf, nr, c.w_l1, c.w_mse, c.w_eos, c.ctc_weight,
                                c.asr_weight, c.st_weight, c.label_smoothing, c.src_vocab, c.tgt_vocab,
                                (float)bt.src_txt_ntokens, (float)bt.tgt_txt_ntokens, st_));
@@ -1228,6 +1253,7 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->c = *cfg;
   e->f32_operands = getenv("S2ST_F32_OPERANDS") && atoi(getenv("S2ST_F32_OPERANDS")) != 0;
   e->use_flash = !(getenv("S2ST_NO_FLASH") && atoi(getenv("S2ST_NO_FLASH")) != 0);
+  e->use_act_fuse = !(getenv("S2ST_NO_ACT_FUSE") && atoi(getenv("S2ST_NO_ACT_FUSE")) != 0);
   e->build_params();
   if (!cfg->precise && (s2st_gemm_bf16_preload(nullptr) != 0 || s2st_flash_attn_preload(nullptr) != 0)) { delete e; return S2ST_ERR_LAUNCH; }
   if (!cfg->precise && !(getenv("S2ST_NO_SIDE_STREAM") && atoi(getenv("S2ST_NO_SIDE_STREAM")))) {

@@ -187,6 +187,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
     }
     return;
   }
+  const bf16_t* ybase = g.ep.mask_y ? g.ep.mask_y + czoff : nullptr;
+  float cs[TN][4];  // column sums of the stored values (bias gradient of the masked layer)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) cs[j][0] = cs[j][1] = cs[j][2] = cs[j][3] = 0.f;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + wm * WM + i * 16 + (lane & 15);
@@ -200,6 +204,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = g.ep.alpha * acc[i][j][r];
       const bool full = cvec && n + 3 < g.N;
+      if (ybase) {  // backward of ReLU + dropout from the layer's output (launcher: N % 4 == 0, aligned rows)
+        const uint2 y4 = *reinterpret_cast<const uint2*>(ybase + roff + n);
+        const unsigned yw[4] = {y4.x & 0xffffu, y4.x >> 16, y4.y & 0xffffu, y4.y >> 16};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = (yw[r] & 0x7fffu) != 0 ? v[r] * g.ep.mask_scale : 0.f;  // +-0 -> no gradient
+          cs[j][r] += v[r];
+        }
+      }
       if (g.ep.bias && lead) {
         if (full) {
           const float4 b4 = *reinterpret_cast<const float4*>(g.ep.bias + n);
@@ -248,6 +261,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
           if (cbase) cbase[roff + n + r] = x;
           if (hbase) hbase[roff + n + r] = (bf16_t)(pack_bf16x4(x, 0.f, 0.f, 0.f).x & 0xffffu);
         }
+      }
+    }
+  }
+  if (g.ep.colsum && ybase) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * WN + j * 16 + (lane >> 4) * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = cs[j][r];
+        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
+        if ((lane & 15) == 0 && n + r < g.N) atomicAdd(g.ep.colsum + n + r, t);
       }
     }
   }
@@ -604,7 +629,8 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
             g.C.sp.ld % 4 == 0 && g.C.sp.bs % 4 == 0 && g.C.zo % 4 == 0 && g.C.zi % 4 == 0 &&
             (!g.ep.resid || (uintptr_t)g.ep.resid % 16 == 0) && (!g.ep.bias || (uintptr_t)g.ep.bias % 16 == 0))
                ? 1 : 0;
-  const bool linear_epi = !g.ep.act && g.ep.drop_p == 0.f;
+  if (g.ep.mask_y && (!g.cvec || g.N % 4 != 0)) return S2ST_ERR_SHAPE;
+  const bool linear_epi = !g.ep.act && g.ep.drop_p == 0.f && !g.ep.mask_y;
   struct Cand { int bm, bn; double eff; };
   const Cand cands[3] = {{128, 128, 1.0}, {128, 64, 0.8}, {64, 64, 0.55}};
   int bm = 64, bn = 64;

@@ -37,7 +37,7 @@ class GemmOut(C.Structure):
 class GemmEpilogue(C.Structure):
     _fields_ = [("alpha", C.c_float), ("act", C.c_int32), ("bias", C.c_void_p),
                 ("drop_p", C.c_float), ("accumulate", C.c_int32), ("seed", C.c_uint64),
-                ("resid", C.c_void_p)]
+                ("resid", C.c_void_p), ("mask_y", C.c_void_p), ("mask_scale", C.c_float), ("colsum", C.c_void_p)]
 
 
 class GemmArgs(C.Structure):
@@ -109,7 +109,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
          b_kmajor=True, b_ld=None, b_per=0, b_bs=0, b_zo=0, b_zi=0,
          c_ld=None, c_per=0, c_bs=0, c_zo=0, c_zi=0,
          batch=1, zdiv=1, alpha=1.0, bias=None, act=0, drop_p=0.0, seed=0, resid=None,
-         accumulate=False, precise=False, a_off=0, b_off=0, c_off=0, c_bf16=None, ws=None):
+         accumulate=False, precise=False, a_off=0, b_off=0, c_off=0, c_bf16=None, ws=None,
+         mask_y=None, mask_scale=1.0, colsum=None):
     """Raw GEMM entry (s2st_gemm_f32). Offsets are in elements.  A and B are both fp32 or both
     torch.bfloat16 tensors; ``Cout`` (fp32) may be None when only ``c_bf16`` is wanted."""
     require_device(A)
@@ -126,7 +127,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
                       b_zo, b_zi)
     g.C = GemmOut(Cout.data_ptr() + 4 * c_off, make_split(c_ld if c_ld is not None else N, c_per, c_bs),
                   c_zo, c_zi, None)
-    g.ep = GemmEpilogue(alpha, act, ptr(bias), drop_p, 1 if accumulate else 0, seed, ptr(resid))
+    g.ep = GemmEpilogue(alpha, act, ptr(bias), drop_p, 1 if accumulate else 0, seed, ptr(resid), None, 1.0, None)
     g.M, g.N, g.K, g.batch, g.zdiv, g.precise = M, N, K, batch, zdiv, 1 if precise else 0
     check(lib().s2st_gemm_f32(C.byref(g), C.c_void_p(stream_ptr())), "s2st_gemm_f32")
 
@@ -144,7 +145,8 @@ def _gemm_bf16(A, B, Cout, M, N, K, kw):
                   make_split(kw["c_ld"] if kw["c_ld"] is not None else N, kw["c_per"], kw["c_bs"]),
                   kw["c_zo"], kw["c_zi"], h.data_ptr() + 2 * kw["c_off"] if h is not None else None)
     g.ep = GemmEpilogue(kw["alpha"], kw["act"], ptr(kw["bias"]), kw["drop_p"], 1 if kw["accumulate"] else 0,
-                        kw["seed"], ptr(kw["resid"]))
+                        kw["seed"], ptr(kw["resid"]), ptr(kw.get("mask_y")), kw.get("mask_scale", 1.0),
+                        ptr(kw.get("colsum")))
     g.M, g.N, g.K, g.batch, g.zdiv, g.precise = M, N, K, kw["batch"], kw["zdiv"], 0
     if kw["ws"] is not None:
         g.ws, g.ws_floats = kw["ws"].data_ptr(), kw["ws"].numel()
