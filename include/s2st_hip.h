@@ -285,6 +285,9 @@ int s2st_engine_bind(s2st_engine* e, float* params, float* grads, float* buffers
 /* fast (precise == 0) mode only: caller-owned bf16 arena of param_floats elements; the engine
  * refreshes it from `params` at the start of every forward and feeds the GEMMs from it */
 int s2st_engine_bind_bf16(s2st_engine* e, uint16_t* params_bf16);
+/* optional second bf16 arena (param_floats elements): every training forward stores W^T of each 2-D
+ * weight there (on the engine's second stream) so the data-gradient GEMMs read K-contiguous operands */
+int s2st_engine_bind_bf16_transposed(s2st_engine* e, uint16_t* params_bf16_t);
 /* workspace (floats) one forward+backward of this batch geometry needs */
 int64_t s2st_engine_workspace_floats(s2st_engine* e, const s2st_batch* geometry);
 /* forward (+ losses if tgt != NULL).  Activations live in `workspace` until the next call. */

@@ -50,6 +50,22 @@ __global__ __launch_bounds__(256) void cast_bf16_rows_kernel(const float* __rest
   *reinterpret_cast<uint2*>(y + r * ldy + c) = pack_bf16x4(v[0], v[1], v[2], v[3]);
 }
 
+// bf16 [R][C] -> [C][R] through a 64 x 64 LDS tile (pre-transposed weight copies for the data-gradient GEMMs)
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
+                                                             int R, int C) {
+  __shared__ uint16_t tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (r0 + r < R && c0 + c < C) ? x[(long)(r0 + r) * C + c0 + c] : (uint16_t)0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (r0 + r < R && c0 + c < C) y[(long)(c0 + c) * R + r0 + r] = tile[r][c];
+  }
+}
+
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
 __global__ __launch_bounds__(256) void glu_fwd_kernel(const float* __restrict__ a,
@@ -387,6 +403,12 @@ int s2st_cast_bf16_rows(const float* x, long ldx, uint16_t* y, long ldy, long ro
   const int vec = ((uintptr_t)x % 16 == 0) && (ldx % 4 == 0);
   long n = rows * (ldy >> 2);
   hipLaunchKernelGGL(cast_bf16_rows_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, ldx, y, ldy, rows, cols, vec);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+
+int s2st_transpose_bf16(const uint16_t* x, uint16_t* y, int R, int C, hipStream_t st) {
+  if (R <= 0 || C <= 0) return 0;
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, st, x, y, R, C);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 

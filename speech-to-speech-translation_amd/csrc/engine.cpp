@@ -119,6 +119,17 @@ struct s2st_engine {
   } hp;
   float* skws = nullptr;  // split-K partial-sum scratch of the weight-gradient GEMMs (per call)
   long skws_n = 0;
+  bf16raw* PHT = nullptr;  // optional: transposed bf16 copies of the 2-D weights (same offsets): the
+                           // data-gradient GEMMs then read K-contiguous operands (~25 % faster here)
+  bool pht_valid = false;
+  struct WT { long off; int N, K; };
+  std::vector<WT> wt_list;  // the [N][K] matrices linear() multiplies by (fused k|v|q blocks as ONE matrix)
+  void reg_wt(long off, int N, int K) { if (N % 8 == 0 && K % 8 == 0) wt_list.push_back(WT{off, N, K}); }
+  bool has_wt(long off, int N, int K) const {
+    if (!pht_valid) return false;
+    for (const WT& t : wt_list) if (t.off == off && t.N == N && t.K == K) return true;
+    return false;
+  }
   bf16raw* PH = nullptr;  // bf16 copy of the parameter arena (same offsets), refreshed every forward
   bool f32_operands = false;  // debug A/B switch S2ST_F32_OPERANDS=1: bf16 MFMA on fp32-stored operands
   bool fast() const { return c.precise == 0 && !f32_operands; }
@@ -175,6 +186,7 @@ struct s2st_engine {
     l.N = N; l.K = K;
     l.w = add(pre + ".weight", {N, K});
     l.b = bias ? add(pre + ".bias", {N}) : -1;
+    reg_wt(l.w, N, K);
     return l;
   }
   LNP add_ln(const std::string& pre, int C) {
@@ -194,6 +206,8 @@ struct s2st_engine {
     add(pre + ".q_proj.bias", {C});
     a.out_w = add(pre + ".out_proj.weight", {C, C});
     a.out_b = add(pre + ".out_proj.bias", {C});
+    reg_wt(a.kvq_w, 3 * C, C);
+    reg_wt(a.out_w, C, C);
     return a;
   }
   XAttnP add_cross_attn(const std::string& pre, int C, int Cenc) {
@@ -206,6 +220,9 @@ struct s2st_engine {
     a.q_b = add(pre + ".q_proj.bias", {C});
     a.out_w = add(pre + ".out_proj.weight", {C, C});
     a.out_b = add(pre + ".out_proj.bias", {C});
+    reg_wt(a.kv_w, 2 * C, Cenc);
+    reg_wt(a.q_w, C, C);
+    reg_wt(a.out_w, C, C);
     return a;
   }
   DecLayerP add_dec_layer(const std::string& pre, int C, int ffn, int Cenc) {
@@ -435,7 +452,7 @@ struct s2st_engine {
         if (live()) {
           GemmArgs g{};  // dx[M][K] (+)= dpre W
           g.A = fm ? gemm_rowmajor(dph, ldp) : gemm_rowmajor(dpre, N);
-          g.B = fm ? gemm_colmajor(PH + w, K) : gemm_colmajor(P + w, K);
+          g.B = fm ? (has_wt(w, N, K) ? gemm_rowmajor(PHT + w, N) : gemm_colmajor(PH + w, K)) : gemm_colmajor(P + w, K);
           g.C = gemm_out(dx, x->cols);
           if (fm && !acc) g.C.h = x->gh;  // the consumer (attention backward) reads dO as a GEMM operand
           g.ep = gemm_epi_default();
@@ -1065,6 +1082,13 @@ struct s2st_engine {
     if (fm && !PH && !dry) return S2ST_ERR_ARG;
     // bf16 copy of the whole parameter arena (292 MB read + 146 MB written: ~0.08 ms)
     if (fm && live()) chk(s2st_cast_bf16_rows(P, n_params, PH, n_params, 1, (int)n_params, st_));
+    // transposed weight copies for the backward, made on the second stream (idle during the forward)
+    pht_valid = false;
+    if (fm && tr && PHT && live()) {
+      hipStream_t ts = side_ ? fork_side() : st_;
+      for (const WT& t : wt_list) chk(s2st_transpose_bf16(PH + t.off, PHT + t.off, t.N, t.K, ts));
+      pht_valid = true;
+    }
     skws_n = fm ? (long)16 << 20 : 0;
     skws = fm ? alloc(skws_n) : nullptr;
     skws_side = fm && side_ ? alloc(skws_n) : skws;
@@ -1225,6 +1249,7 @@ struct s2st_engine {
   int backward_segment(int seg) {
     int ns = n_segments();
     if (seg < 0 || seg >= ns) return S2ST_ERR_ARG;
+    if (seg == 0) join_side();  // transposed weights (and anything else the forward left on the side stream)
     size_t hi = marks[ns - seg].tape_idx, lo = marks[ns - seg - 1].tape_idx;
     for (size_t i = hi; i-- > lo;) {
       tape[i]();
@@ -1307,6 +1332,11 @@ int s2st_engine_bind(s2st_engine* e, float* params, float* grads, float* buffers
 
 int s2st_engine_bind_bf16(s2st_engine* e, uint16_t* params_bf16) {
   e->PH = params_bf16;
+  return 0;
+}
+
+int s2st_engine_bind_bf16_transposed(s2st_engine* e, uint16_t* params_bf16_t) {
+  e->PHT = params_bf16_t;
   return 0;
 }
 

@@ -93,6 +93,7 @@ int s2st_attn_headmean(const float* p, float* out, int B, int H, int T, int S, i
 // fp32 [rows][cols] (stride ldx) -> bf16 [rows][ldy] (ldy % 4 == 0, pad columns zeroed): the
 // bf16 copies the fast GEMM path reads
 int s2st_cast_bf16_rows(const float* x, long ldx, uint16_t* y, long ldy, long rows, int cols, hipStream_t st);
+int s2st_transpose_bf16(const uint16_t* x, uint16_t* y, int R, int C, hipStream_t st);  // [R][C] -> [C][R]
 // copy [rows][C] between split-addressed buffers (halo padding, zero-stuffing); C % 4 == 0
 int s2st_copy_rows(const float* x, Split xsp, float* y, Split ysp, int rows, int C,
                    hipStream_t st);

@@ -162,6 +162,11 @@ class Engine:
             self.params_bf16 = torch.zeros(self.n_params, dtype=torch.bfloat16, device=device)
             self.lib.s2st_engine_bind_bf16.argtypes = [C.c_void_p, C.c_void_p]
             self.lib.s2st_engine_bind_bf16(h, self.params_bf16.data_ptr())
+            import os as _os
+            if _os.environ.get("S2ST_NO_WT", "0") != "1":
+                self.params_bf16_t = torch.zeros(self.n_params, dtype=torch.bfloat16, device=device)
+                self.lib.s2st_engine_bind_bf16_transposed.argtypes = [C.c_void_p, C.c_void_p]
+                self.lib.s2st_engine_bind_bf16_transposed(h, self.params_bf16_t.data_ptr())
         self.workspace: Optional[torch.Tensor] = None
         self._outpool: Optional[torch.Tensor] = None
         self._pe: Dict[int, torch.Tensor] = {}
