@@ -194,20 +194,36 @@ __global__ __launch_bounds__(256) void dpre_kernel(const float* __restrict__ dy,
   const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (c < N) {
-    for (int r = r0 + wave; r < r1; r += 4) {
-      const long o = (long)r * N + c;
-      float4 d = *reinterpret_cast<const float4*>(dy + o);
-      if (MODE == 1) {
-        const float4 yv = *reinterpret_cast<const float4*>(y + o);
-        d.x = yv.x != 0.f ? d.x * inv_keep : 0.f; d.y = yv.y != 0.f ? d.y * inv_keep : 0.f;
-        d.z = yv.z != 0.f ? d.z * inv_keep : 0.f; d.w = yv.w != 0.f ? d.w * inv_keep : 0.f;
-      } else if (MODE == 2) {
-        d.x *= drop_scale(seed, (uint64_t)o, p, inv_keep); d.y *= drop_scale(seed, (uint64_t)o + 1, p, inv_keep);
-        d.z *= drop_scale(seed, (uint64_t)o + 2, p, inv_keep); d.w *= drop_scale(seed, (uint64_t)o + 3, p, inv_keep);
+    // 4 rows per pass with all loads issued first (the kernel is latency-bound otherwise)
+    for (int rb = r0 + wave; rb < r1; rb += 16) {
+      float4 d[4], yv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = rb + 4 * u;
+        d[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        yv[u] = d[u];
+        if (r < r1) {
+          d[u] = *reinterpret_cast<const float4*>(dy + (long)r * N + c);
+          if (MODE == 1) yv[u] = *reinterpret_cast<const float4*>(y + (long)r * N + c);
+        }
       }
-      *reinterpret_cast<uint2*>(dph + (long)r * ldp + c) = pack_bf16x4(d.x, d.y, d.z, d.w);
-      if (dpre) *reinterpret_cast<float4*>(dpre + o) = d;
-      a0 += d.x; a1 += d.y; a2 += d.z; a3 += d.w;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = rb + 4 * u;
+        if (r >= r1) continue;
+        const long o = (long)r * N + c;
+        float4 dd = d[u];
+        if (MODE == 1) {
+          dd.x = yv[u].x != 0.f ? dd.x * inv_keep : 0.f; dd.y = yv[u].y != 0.f ? dd.y * inv_keep : 0.f;
+          dd.z = yv[u].z != 0.f ? dd.z * inv_keep : 0.f; dd.w = yv[u].w != 0.f ? dd.w * inv_keep : 0.f;
+        } else if (MODE == 2) {
+          dd.x *= drop_scale(seed, (uint64_t)o, p, inv_keep); dd.y *= drop_scale(seed, (uint64_t)o + 1, p, inv_keep);
+          dd.z *= drop_scale(seed, (uint64_t)o + 2, p, inv_keep); dd.w *= drop_scale(seed, (uint64_t)o + 3, p, inv_keep);
+        }
+        *reinterpret_cast<uint2*>(dph + (long)r * ldp + c) = pack_bf16x4(dd.x, dd.y, dd.z, dd.w);
+        if (dpre) *reinterpret_cast<float4*>(dpre + o) = dd;
+        a0 += dd.x; a1 += dd.y; a2 += dd.z; a3 += dd.w;
+      }
     }
   } else if (c < ldp) {
     for (int r = r0 + wave; r < r1; r += 4) *reinterpret_cast<uint2*>(dph + (long)r * ldp + c) = make_uint2(0, 0);

@@ -78,46 +78,67 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
   float4 ag[LN_MAXV], ab[LN_MAXV];
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-    const float* xr = x + (long)row * cols;
-    const float* dyr = dy + (long)row * cols;
-    float* dxr = dx + (long)row * cols;
-    const float mu = mean[row], rs = rstd[row];
-    float4 xh[LN_MAXV], g[LN_MAXV];
-    float s1 = 0.f, s2 = 0.f;
+  // gamma stays in registers; two rows per iteration (independent loads / shuffle chains overlap:
+  // the loop is latency-bound at one row per wave)
+  float4 gm[LN_MAXV];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      int c4 = lane + 64 * i;
-      if (c4 < nv) {
-        float4 xv = reinterpret_cast<const float4*>(xr)[c4];
-        float4 dv = reinterpret_cast<const float4*>(dyr)[c4];
-        float4 gm = reinterpret_cast<const float4*>(gamma)[c4];
-        xh[i].x = (xv.x - mu) * rs; xh[i].y = (xv.y - mu) * rs;
-        xh[i].z = (xv.z - mu) * rs; xh[i].w = (xv.w - mu) * rs;
-        g[i].x = dv.x * gm.x; g[i].y = dv.y * gm.y; g[i].z = dv.z * gm.z; g[i].w = dv.w * gm.w;
-        s1 += g[i].x + g[i].y + g[i].z + g[i].w;
-        s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
-        ag[i].x += dv.x * xh[i].x; ag[i].y += dv.y * xh[i].y;
-        ag[i].z += dv.z * xh[i].z; ag[i].w += dv.w * xh[i].w;
-        ab[i].x += dv.x; ab[i].y += dv.y; ab[i].z += dv.z; ab[i].w += dv.w;
+  for (int i = 0; i < LN_MAXV; ++i) {
+    int c4 = lane + 64 * i;
+    gm[i] = c4 < nv ? reinterpret_cast<const float4*>(gamma)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int stride = gridDim.x * 4;
+  for (int row0 = blockIdx.x * 4 + wave; row0 < rows; row0 += 2 * stride) {
+    float4 xh[2][LN_MAXV], g[2][LN_MAXV];
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, rs[2];
+    bool on[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = row0 + u * stride;
+      on[u] = row < rows;
+      const int rr = on[u] ? row : row0;
+      const float* xr = x + (long)rr * cols;
+      const float* dyr = dy + (long)rr * cols;
+      const float mu = mean[rr];
+      rs[u] = rstd[rr];
+#pragma unroll
+      for (int i = 0; i < LN_MAXV; ++i) {
+        int c4 = lane + 64 * i;
+        if (c4 < nv) {
+          float4 xv = reinterpret_cast<const float4*>(xr)[c4];
+          float4 dv = reinterpret_cast<const float4*>(dyr)[c4];
+          if (!on[u]) dv = make_float4(0.f, 0.f, 0.f, 0.f);
+          xh[u][i].x = (xv.x - mu) * rs[u]; xh[u][i].y = (xv.y - mu) * rs[u];
+          xh[u][i].z = (xv.z - mu) * rs[u]; xh[u][i].w = (xv.w - mu) * rs[u];
+          g[u][i].x = dv.x * gm[i].x; g[u][i].y = dv.y * gm[i].y; g[u][i].z = dv.z * gm[i].z; g[u][i].w = dv.w * gm[i].w;
+          s1[u] += g[u][i].x + g[u][i].y + g[u][i].z + g[u][i].w;
+          s2[u] += g[u][i].x * xh[u][i].x + g[u][i].y * xh[u][i].y + g[u][i].z * xh[u][i].z + g[u][i].w * xh[u][i].w;
+          ag[i].x += dv.x * xh[u][i].x; ag[i].y += dv.y * xh[u][i].y;
+          ag[i].z += dv.z * xh[u][i].z; ag[i].w += dv.w * xh[u][i].w;
+          ab[i].x += dv.x; ab[i].y += dv.y; ab[i].z += dv.z; ab[i].w += dv.w;
+        }
       }
     }
-    s1 = wave_sum(s1) * invc;
-    s2 = wave_sum(s2) * invc;
+    s1[0] = wave_sum(s1[0]) * invc; s1[1] = wave_sum(s1[1]) * invc;
+    s2[0] = wave_sum(s2[0]) * invc; s2[1] = wave_sum(s2[1]) * invc;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      int c4 = lane + 64 * i;
-      if (c4 < nv) {
-        float4 o;
-        o.x = rs * (g[i].x - s1 - xh[i].x * s2);
-        o.y = rs * (g[i].y - s1 - xh[i].y * s2);
-        o.z = rs * (g[i].z - s1 - xh[i].z * s2);
-        o.w = rs * (g[i].w - s1 - xh[i].w * s2);
-        if (dx_accumulate) {
-          float4 p = reinterpret_cast<float4*>(dxr)[c4];
-          o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+    for (int u = 0; u < 2; ++u) {
+      if (!on[u]) continue;  // wave-uniform
+      float* dxr = dx + (long)(row0 + u * stride) * cols;
+#pragma unroll
+      for (int i = 0; i < LN_MAXV; ++i) {
+        int c4 = lane + 64 * i;
+        if (c4 < nv) {
+          float4 o;
+          o.x = rs[u] * (g[u][i].x - s1[u] - xh[u][i].x * s2[u]);
+          o.y = rs[u] * (g[u][i].y - s1[u] - xh[u][i].y * s2[u]);
+          o.z = rs[u] * (g[u][i].z - s1[u] - xh[u][i].z * s2[u]);
+          o.w = rs[u] * (g[u][i].w - s1[u] - xh[u][i].w * s2[u]);
+          if (dx_accumulate) {
+            float4 p = reinterpret_cast<float4*>(dxr)[c4];
+            o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+          }
+          reinterpret_cast<float4*>(dxr)[c4] = o;
         }
-        reinterpret_cast<float4*>(dxr)[c4] = o;
       }
     }
   }
