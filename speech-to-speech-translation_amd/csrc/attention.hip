@@ -216,22 +216,30 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(AttnArgs a) {
   }
 }
 
-// D[b,h,t] = sum_d dO[b,t,h,d] * O[b,t,h,d]   (one wave per (b,t,h) row of DH elements)
+// D[b,h,t] = sum_d dO[b,t,h,d] * O[b,t,h,d]: DH/4 lanes per (b,t,h) row, one float4 pair per lane
+template <int DH>
 __global__ __launch_bounds__(256) void attn_dvec_kernel(const float* __restrict__ dO, const float* __restrict__ O,
-                                                        float* __restrict__ D, int B, int H, int T, int DH) {
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // over B*T*H
-  const int lane = threadIdx.x & 63;
-  if (row >= (long)B * T * H) return;
-  const int h = (int)(row % H);
-  const long bt = row / H;
-  const float* a = dO + bt * ((long)H * DH) + (long)h * DH;
-  const float* o = O + bt * ((long)H * DH) + (long)h * DH;
+                                                        float* __restrict__ D, int B, int H, int T) {
+  constexpr int LPR = DH / 4;  // lanes per row (32 or 16)
+  const long row = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;  // over B*T*H
+  const int l = threadIdx.x % LPR;
+  const bool ok = row < (long)B * T * H;
   float s = 0.f;
-  for (int d = lane; d < DH; d += 64) s += a[d] * o[d];
-  s = wave_sum(s);
-  if (lane == 0) {
-    const int t = (int)(bt % T), b = (int)(bt / T);
-    D[((long)b * H + h) * T + t] = s;
+  int h = 0;
+  long bt = 0;
+  if (ok) {
+    h = (int)(row % H);
+    bt = row / H;
+    const long o = bt * ((long)H * DH) + (long)h * DH + 4 * l;
+    const float4 a = *reinterpret_cast<const float4*>(dO + o);
+    const float4 c = *reinterpret_cast<const float4*>(O + o);
+    s = a.x * c.x + a.y * c.y + a.z * c.z + a.w * c.w;
+  }
+#pragma unroll
+  for (int m = LPR / 2; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+  if (ok && l == 0) {
+    const int t = (int)(bt % T), bb = (int)(bt / T);
+    D[((long)bb * H + h) * T + t] = s;
   }
 }
 
@@ -468,8 +476,12 @@ int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_sc
   AttnArgs a = to_args(*p);
   a.dvec = dvec_scratch;
   const long rows = (long)p->B * p->T * p->H;
-  hipLaunchKernelGGL(attn_dvec_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, dO, (const float*)p->o,
-                     dvec_scratch, p->B, p->H, p->T, p->dh);
+  if (p->dh == 128)
+    hipLaunchKernelGGL(attn_dvec_kernel<128>, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, st, dO,
+                       (const float*)p->o, dvec_scratch, p->B, p->H, p->T);
+  else
+    hipLaunchKernelGGL(attn_dvec_kernel<64>, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, st, dO,
+                       (const float*)p->o, dvec_scratch, p->B, p->H, p->T);
   dim3 gk((p->S + 63) / 64, p->B * p->H), gq((p->T + 63) / 64, p->B * p->H);
   if (p->dh == 128) {
     hipLaunchKernelGGL(flash_bwd_kv_kernel<128>, gk, dim3(256), 0, st, a);

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void relu_drop_bwd_kernel(const float* __restr
 // 256 threads = 4 waves; a wave owns every 4th row of the block's row slab, a lane 4 columns.
 template <int MODE>
 __global__ __launch_bounds__(256) void dpre_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                   uint16_t* __restrict__ dph, long ldp, float* __restrict__ dpre,
+                                                   const uint16_t* __restrict__ yb, uint16_t* __restrict__ dph, long ldp, float* __restrict__ dpre,
                                                    float* __restrict__ dbias, int M, int N, int rows_per_block,
                                                    float p, float inv_keep, uint64_t seed) {
   __shared__ float red[4][256];
@@ -204,7 +204,14 @@ __global__ __launch_bounds__(256) void dpre_kernel(const float* __restrict__ dy,
         yv[u] = d[u];
         if (r < r1) {
           d[u] = *reinterpret_cast<const float4*>(dy + (long)r * N + c);
-          if (MODE == 1) yv[u] = *reinterpret_cast<const float4*>(y + (long)r * N + c);
+          if (MODE == 1) {
+            if (y) yv[u] = *reinterpret_cast<const float4*>(y + (long)r * N + c);
+            else {  // only the bf16 copy of the layer output exists: +-0 <=> fp32 zero (bf16 keeps the exponent range)
+              const uint2 q = *reinterpret_cast<const uint2*>(yb + (long)r * N + c);
+              yv[u] = make_float4((float)(q.x & 0x7fffu), (float)((q.x >> 16) & 0x7fffu), (float)(q.y & 0x7fffu),
+                                  (float)((q.y >> 16) & 0x7fffu));
+            }
+          }
         }
       }
 #pragma unroll
@@ -493,10 +500,11 @@ int s2st_relu_drop_bwd(const float* dy, const float* y, float* dz, long n, float
   return LAUNCH_OK();
 }
 
-int s2st_linear_bwd_prep(const float* dy, const float* y, int mode, float p, uint64_t seed, uint16_t* dph,
-                         long ldp, float* dpre, float* dbias, int M, int N, hipStream_t st) {
+int s2st_linear_bwd_prep(const float* dy, const float* y, const uint16_t* yb, int mode, float p, uint64_t seed,
+                         uint16_t* dph, long ldp, float* dpre, float* dbias, int M, int N, hipStream_t st) {
   if (M <= 0 || N <= 0) return 0;
-  if (N % 4 != 0 || ldp % 4 != 0 || ldp < N || ((uintptr_t)dy % 16) || (mode == 1 && ((uintptr_t)y % 16)))
+  if (N % 4 != 0 || ldp % 4 != 0 || ldp < N || ((uintptr_t)dy % 16) || (mode == 1 && !y && !yb) ||
+      (mode == 1 && y && ((uintptr_t)y % 16)) || (mode == 1 && !y && ((uintptr_t)yb % 8)))
     return S2ST_ERR_SHAPE;
   const int cb = (int)((ldp + 255) / 256);
   int slabs = (1024 + cb - 1) / cb;
@@ -505,9 +513,9 @@ int s2st_linear_bwd_prep(const float* dy, const float* y, int mode, float p, uin
   slabs = (M + rpb - 1) / rpb;
   const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
   dim3 grid(cb, slabs);
-  if (mode == 0) hipLaunchKernelGGL(dpre_kernel<0>, grid, dim3(256), 0, st, dy, y, dph, ldp, dpre, dbias, M, N, rpb, p, ik, seed);
-  else if (mode == 1) hipLaunchKernelGGL(dpre_kernel<1>, grid, dim3(256), 0, st, dy, y, dph, ldp, dpre, dbias, M, N, rpb, p, ik, seed);
-  else hipLaunchKernelGGL(dpre_kernel<2>, grid, dim3(256), 0, st, dy, y, dph, ldp, dpre, dbias, M, N, rpb, p, ik, seed);
+  if (mode == 0) hipLaunchKernelGGL(dpre_kernel<0>, grid, dim3(256), 0, st, dy, y, yb, dph, ldp, dpre, dbias, M, N, rpb, p, ik, seed);
+  else if (mode == 1) hipLaunchKernelGGL(dpre_kernel<1>, grid, dim3(256), 0, st, dy, y, yb, dph, ldp, dpre, dbias, M, N, rpb, p, ik, seed);
+  else hipLaunchKernelGGL(dpre_kernel<2>, grid, dim3(256), 0, st, dy, y, yb, dph, ldp, dpre, dbias, M, N, rpb, p, ik, seed);
   return LAUNCH_OK();
 }
 

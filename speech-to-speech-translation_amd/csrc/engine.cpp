@@ -108,6 +108,7 @@ struct s2st_engine {
   float* dec_crossKV(int l) const {
     return dec_st.base + (long)c.dec_layers * 2 * dec_st.B * dec_st.maxT * c.dec_dim + (long)l * dec_st.B * dec_st.E * 2 * c.dec_dim;
   }
+  bool use_only_h = true;  // S2ST_NO_ONLY_H=1: always keep the fp32 copy of GEMM-only tensors (A/B switch)
   bool use_act_fuse = true;  // S2ST_NO_ACT_FUSE=1: separate ReLU-dropout backward kernel (A/B switch)
   bool use_flash = true;  // S2ST_NO_FLASH=1: unfused attention everywhere (A/B switch)
   int ffn_act = 1;        // 1 relu (s2st layers), 2 gelu (HuBERT layers)
@@ -324,10 +325,10 @@ struct s2st_engine {
     if (p && zero && !dry) hipMemsetAsync(p, 0, sizeof(float) * n, st_);
     return p;
   }
-  Ten* newT(int rows, int cols, float* ext = nullptr) {
+  Ten* newT(int rows, int cols, float* ext = nullptr, bool f32 = true) {
     Ten* t = new Ten();
     t->rows = rows; t->cols = cols;
-    t->d = ext ? ext : alloc(t->n());
+    t->d = ext ? ext : (f32 ? alloc(t->n()) : nullptr);
     tens.push_back(t);
     return t;
   }
@@ -368,10 +369,13 @@ struct s2st_engine {
 
   // ------------------------------------------------------------------------------------
   // op: y = [resid +] dropout(act(x W^T + b))
+  // only_h: the caller guarantees every consumer reads the bf16 copy (fast mode): no fp32 result is
+  // allocated or written
   Ten* linear(Ten* x, long w, long b, int N, int K, int act = 0, float drop_p = 0.f,
-              Ten* resid = nullptr, float* ext_out = nullptr) {
+              Ten* resid = nullptr, float* ext_out = nullptr, bool only_h = false) {
     const int M = x->rows;
-    Ten* y = newT(M, N, ext_out);
+    only_h = only_h && fast() && use_only_h && N % 8 == 0 && !ext_out && !resid;
+    Ten* y = newT(M, N, ext_out, !only_h);
     touch(w + (long)N * K);
     if (b >= 0) touch(b + N);
     const uint64_t sd = drop_p > 0.f ? next_seed() : 0;
@@ -413,7 +417,8 @@ struct s2st_engine {
         bf16raw* t = alloc_h((long)M * ldp);
         const int mode = act == 1 ? 1 : (drop_p > 0.f ? 2 : 0);
         if (live())
-          chk(s2st_linear_bwd_prep(dy, y->d, mode, drop_p, sd, t, ldp, nullptr, b >= 0 ? G + b : nullptr, M, N, st_));
+          chk(s2st_linear_bwd_prep(dy, y->d, y->d ? nullptr : y->h, mode, drop_p, sd, t, ldp, nullptr,
+                                   b >= 0 ? G + b : nullptr, M, N, st_));
         dph = t;
         bias_done = true;
       } else {
@@ -473,8 +478,9 @@ struct s2st_engine {
     return y;
   }
 
-  Ten* layernorm(Ten* x, const LNP& p, float* ext_out = nullptr) {
-    Ten* y = newT(x->rows, x->cols, ext_out);
+  Ten* layernorm(Ten* x, const LNP& p, float* ext_out = nullptr, bool only_h = false) {
+    only_h = only_h && fast() && use_only_h && x->cols % 8 == 0 && !ext_out;
+    Ten* y = newT(x->rows, x->cols, ext_out, !only_h);
     float* mean = alloc(x->rows);
     float* rstd = alloc(x->rows);
     touch(p.b + p.C);
@@ -615,7 +621,7 @@ struct s2st_engine {
   Ten* self_attn_block(Ten* x, const AttnP& a, int B, int T, int H, const int* klen, int causal,
                        Ten* resid) {
     const int C = x->cols;
-    Ten* kvq = linear(x, a.kvq_w, a.kvq_b, 3 * C, C);
+    Ten* kvq = linear(x, a.kvq_w, a.kvq_b, 3 * C, C, 0, 0.f, nullptr, nullptr, true);
     AttnIO io{kvq, 2 * C, 3 * C, kvq, 0, 3 * C, kvq, C, 3 * C};
     Ten* o = attention(io, B, T, T, H, C / H, klen, causal, bt.training ? c.attn_dropout : 0.f, nullptr);
     return linear(o, a.out_w, a.out_b, C, C, 0, bt.training ? c.dropout : 0.f, resid);
@@ -623,21 +629,22 @@ struct s2st_engine {
   Ten* cross_attn_block(Ten* x, Ten* encx, const XAttnP& a, int B, int T, int S, int H,
                         const int* klen, Ten* resid, float* attn_mean_out) {
     const int C = x->cols;
-    Ten* q = linear(x, a.q_w, a.q_b, C, C);
-    Ten* kv = linear(encx, a.kv_w, a.kv_b, 2 * C, encx->cols);
+    Ten* q = linear(x, a.q_w, a.q_b, C, C, 0, 0.f, nullptr, nullptr, true);
+    Ten* kv = linear(encx, a.kv_w, a.kv_b, 2 * C, encx->cols, 0, 0.f, nullptr, nullptr, true);
     AttnIO io{q, 0, C, kv, 0, 2 * C, kv, C, 2 * C};
     Ten* o = attention(io, B, T, S, H, C / H, klen, 0, bt.training ? c.attn_dropout : 0.f, attn_mean_out);
     return linear(o, a.out_w, a.out_b, C, C, 0, bt.training ? c.dropout : 0.f, resid);
   }
   Ten* ffn_block(Ten* x, const LinP& fc1, const LinP& fc2, Ten* resid) {
-    Ten* h = linear(x, fc1.w, fc1.b, fc1.N, fc1.K, ffn_act, bt.training ? c.act_dropout : 0.f);
+    Ten* h = linear(x, fc1.w, fc1.b, fc1.N, fc1.K, ffn_act, bt.training ? c.act_dropout : 0.f, nullptr, nullptr,
+                    ffn_act == 1);
     return linear(h, fc2.w, fc2.b, fc2.N, fc2.K, 0, bt.training ? c.dropout : 0.f, resid);
   }
   Ten* enc_layer(Ten* x, const EncLayerP& l, int B, int T) {
     const int H = c.enc_heads;
-    if (c.enc_pre_ln) {
-      x = self_attn_block(layernorm(x, l.ln1), l.sa, B, T, H, bt.enc_lens, 0, x);
-      return ffn_block(layernorm(x, l.ln2), l.fc1, l.fc2, x);
+    if (c.enc_pre_ln) {  // the normalised activations only feed GEMMs: bf16 copy only
+      x = self_attn_block(layernorm(x, l.ln1, nullptr, true), l.sa, B, T, H, bt.enc_lens, 0, x);
+      return ffn_block(layernorm(x, l.ln2, nullptr, true), l.fc1, l.fc2, x);
     }
     x = layernorm(self_attn_block(x, l.sa, B, T, H, bt.enc_lens, 0, x), l.ln1);
     return layernorm(ffn_block(x, l.fc1, l.fc2, x), l.ln2);
@@ -645,9 +652,9 @@ struct s2st_engine {
   Ten* dec_layer(Ten* x, Ten* encx, const DecLayerP& l, int B, int T, int S, int H, bool pre_ln,
                  const int* self_klen, float* attn_mean_out) {
     if (pre_ln) {
-      x = self_attn_block(layernorm(x, l.ln1), l.sa, B, T, H, self_klen, 1, x);
-      x = cross_attn_block(layernorm(x, l.ln2), encx, l.xa, B, T, S, H, bt.enc_lens, x, attn_mean_out);
-      return ffn_block(layernorm(x, l.ln3), l.fc1, l.fc2, x);
+      x = self_attn_block(layernorm(x, l.ln1, nullptr, true), l.sa, B, T, H, self_klen, 1, x);
+      x = cross_attn_block(layernorm(x, l.ln2, nullptr, true), encx, l.xa, B, T, S, H, bt.enc_lens, x, attn_mean_out);
+      return ffn_block(layernorm(x, l.ln3, nullptr, true), l.fc1, l.fc2, x);
     }
     x = layernorm(self_attn_block(x, l.sa, B, T, H, self_klen, 1, x), l.ln1);
     x = layernorm(cross_attn_block(x, encx, l.xa, B, T, S, H, bt.enc_lens, x, attn_mean_out), l.ln2);
@@ -1279,6 +1286,7 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->f32_operands = getenv("S2ST_F32_OPERANDS") && atoi(getenv("S2ST_F32_OPERANDS")) != 0;
   e->use_flash = !(getenv("S2ST_NO_FLASH") && atoi(getenv("S2ST_NO_FLASH")) != 0);
   e->use_act_fuse = !(getenv("S2ST_NO_ACT_FUSE") && atoi(getenv("S2ST_NO_ACT_FUSE")) != 0);
+  e->use_only_h = !(getenv("S2ST_NO_ONLY_H") && atoi(getenv("S2ST_NO_ONLY_H")) != 0);
   e->build_params();
   if (!cfg->precise && (s2st_gemm_bf16_preload(nullptr) != 0 || s2st_flash_attn_preload(nullptr) != 0)) { delete e; return S2ST_ERR_LAUNCH; }
   if (!cfg->precise && !(getenv("S2ST_NO_SIDE_STREAM") && atoi(getenv("S2ST_NO_SIDE_STREAM")))) {

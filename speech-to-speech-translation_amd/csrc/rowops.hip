@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
       o.y = (v[i].y - mean) * rstd * g.y + b.y;
       o.z = (v[i].z - mean) * rstd * g.z + b.z;
       o.w = (v[i].w - mean) * rstd * g.w + b.w;
-      reinterpret_cast<float4*>(yr)[c4] = o;
+      if (y) reinterpret_cast<float4*>(yr)[c4] = o;
       if (yh) reinterpret_cast<uint2*>(yh + (long)row * cols)[c4] = pack_bf16x4(o.x, o.y, o.z, o.w);
     }
   }
@@ -67,11 +67,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   }
 }
 
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+constexpr int LNB_WAVES = 8;  // 512-thread blocks: 2 waves per SIMD keep enough loads in flight (HBM-bound)
+
+__global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
     int dx_accumulate, float* __restrict__ part, int rows, int cols) {
-  __shared__ float red[2][4][LN_MAXV * 64];  // [dgamma|dbeta][wave][float4 slot]
+  __shared__ float red[2][LNB_WAVES][LN_MAXV * 64];  // [dgamma|dbeta][wave][float4 slot]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = cols >> 2;
   const float invc = 1.f / cols;
@@ -86,8 +88,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     int c4 = lane + 64 * i;
     gm[i] = c4 < nv ? reinterpret_cast<const float4*>(gamma)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  const int stride = gridDim.x * 4;
-  for (int row0 = blockIdx.x * 4 + wave; row0 < rows; row0 += 2 * stride) {
+  const int stride = gridDim.x * LNB_WAVES;
+  for (int row0 = blockIdx.x * LNB_WAVES + wave; row0 < rows; row0 += 2 * stride) {
     float4 xh[2][LN_MAXV], g[2][LN_MAXV];
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, rs[2];
     bool on[2];
@@ -156,9 +158,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
       rb[wave * WSTRIDE + c4] = bv;
     }
     __syncthreads();
-    for (int c4 = threadIdx.x; c4 < nv; c4 += 256) {
-      float gsum = rg[c4] + rg[WSTRIDE + c4] + rg[2 * WSTRIDE + c4] + rg[3 * WSTRIDE + c4];
-      float bsum = rb[c4] + rb[WSTRIDE + c4] + rb[2 * WSTRIDE + c4] + rb[3 * WSTRIDE + c4];
+    for (int c4 = threadIdx.x; c4 < nv; c4 += 64 * LNB_WAVES) {
+      float gsum = 0.f, bsum = 0.f;
+#pragma unroll
+      for (int w = 0; w < LNB_WAVES; ++w) { gsum += rg[w * WSTRIDE + c4]; bsum += rb[w * WSTRIDE + c4]; }
       // per-block partials: [block][2][cols]
       part[((long)blockIdx.x * 2 + 0) * cols + c4 * 4 + comp] = gsum;
       part[((long)blockIdx.x * 2 + 1) * cols + c4 * 4 + comp] = bsum;
@@ -332,7 +335,7 @@ int s2st_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
 }
 
 int s2st_layernorm_bwd_blocks(int rows) {
-  int blocks = (rows + 3) / 4;
+  int blocks = (rows + LNB_WAVES - 1) / LNB_WAVES;
   return blocks > 256 ? 256 : blocks;
 }
 
@@ -343,7 +346,7 @@ int s2st_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
   if (rows <= 0) return 0;
   if (cols % 4 != 0 || cols > LN_MAXV * 256) return S2ST_ERR_SHAPE;
   int blocks = s2st_layernorm_bwd_blocks(rows);
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, x, gamma, mean,
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(64 * LNB_WAVES), 0, st, dy, x, gamma, mean,
                      rstd, dx, dx_accumulate, scratch, rows, cols);
   hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * cols + 31) / 32), dim3(256), 0, st,
                      (const float*)scratch, blocks, cols, dgamma, dbeta);

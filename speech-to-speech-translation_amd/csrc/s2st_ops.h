@@ -120,8 +120,9 @@ int s2st_relu_drop_bwd(const float* dy, const float* y, float* dz, long n, float
 // fused backward prologue of a linear layer (fast mode): dph = bf16(f(dy)) with row stride ldp
 // (pad columns zeroed), optional fp32 copy dpre, dbias += colsum(f(dy)).  mode 0: f = id ;
 // 1: ReLU+dropout backward from the layer OUTPUT y ; 2: dropout(seed) backward.  N % 4 == 0.
-int s2st_linear_bwd_prep(const float* dy, const float* y, int mode, float p, uint64_t seed, uint16_t* dph,
-                         long ldp, float* dpre, float* dbias, int M, int N, hipStream_t st);
+int s2st_linear_bwd_prep(const float* dy, const float* y, const uint16_t* yb /* bf16 y when y == null */, int mode,
+                         float p, uint64_t seed, uint16_t* dph, long ldp, float* dpre, float* dbias, int M, int N,
+                         hipStream_t st);
 int s2st_axpy(const float* x, float* y, long n, float a, hipStream_t st);  // y += a * x
 int s2st_scale(float* x, long n, float a, hipStream_t st);
 // conv weight W[O][I][Kw] -> Wf[O][Kw][I] (forward GEMM layout) and, if wd != null,
