@@ -331,6 +331,13 @@ int s2st_gl_project_f32(const float* mag, const float* Y, float* X, int32_t F, i
 int s2st_reflect_pad_f32(const float* x, float* y, int32_t n, int32_t pad, void* stream);
 int s2st_gl_overlap_add_f32(const float* frames, const float* wsq, float* wave, int32_t T, int32_t n_fft, int32_t hop, int32_t n_out, void* stream);
 
+/* MCD evaluation (examples/s2s_trans/tasks/s2s_translation.py:414-552): batched DTW over the padded
+ * [B][M][N] distance tensor (shapes [B][2] = (m, n) per element, or NULL), RMS feature distance, MFCC glue */
+int s2st_dtw_f32(const float* dist, const int32_t* shapes, int32_t B, int32_t M, int32_t N, float* cumdist, int32_t* backptr, int32_t* pathmap, void* stream);
+int s2st_rms_dist_f32(const float* x1, const float* x2, float* out, int32_t m, int32_t n, int32_t D, int64_t ldo, void* stream);
+int s2st_power_spec_f32(const float* Y, float* P, int32_t T, int32_t F, void* stream);
+int s2st_log_offset_f32(float* x, int64_t n, float eps, void* stream);
+
 /* ---- frozen HuBERT front end of config 4 (--use-hubert): fairseq/models/hubert/hubert.py:412-461,
  * 518-534 (extract_features, eval, mask=False) with wav2vec2.py:736-905.  The handle is an
  * s2st_engine in "hubert mode": parameters are enumerated / bound with s2st_engine_param_info,

@@ -77,6 +77,22 @@ def gl_golden():
     print("GL golden ok, wave len", rec["wave.4"].shape)
 
 
+def dtw_golden():
+    from examples.s2s_trans.tasks.s2s_translation import batch_dynamic_time_warping
+    g = torch.Generator().manual_seed(17)
+    d = torch.rand(3, 23, 31, generator=g)
+    d[1, :, 7] = d[1, :, 8]  # exact ties exercise the first-minimum rule
+    d[2, 5, :] = 0.25
+    shapes = torch.tensor([[23, 31], [17, 20], [9, 31]])
+    cum, bp, pm = batch_dynamic_time_warping(d, shapes)
+    c2, b2, p2 = IO.dtw(d, shapes)
+    assert torch.equal(bp, b2) and torch.equal(pm, p2) and torch.equal(cum, c2)
+    np.savez_compressed(os.path.join(OUT, "infer_dtw.npz"), dist=d.numpy(), shapes=shapes.numpy(), cum=cum.numpy(),
+                        backptr=bp.numpy(), pathmap=pm.numpy())
+    print("DTW golden ok, path lengths", pm.sum(dim=(1, 2)).tolist())
+
+
 if __name__ == "__main__":
+    dtw_golden()
     gl_golden()
     ar_golden()

@@ -201,3 +201,64 @@ def vocoder(feat: torch.Tensor, angles: np.ndarray, sample_rate, win_size, hop_s
     basis = torch.pinverse(slaney_mel_filters(sample_rate, n_fft, n_mels, f_min, f_max))  # F x n_mels
     spec = basis.matmul(x).clamp(min=0)
     return griffin_lim(spec, angles, n_fft, win_size, hop_size, n_iter)
+
+
+# ---- MCD (examples/s2s_trans/tasks/s2s_translation.py:414-552) ------------------------------------
+def dtw(distance: torch.Tensor, shapes=None):
+    """batch_dynamic_time_warping restated cell by cell (same first-minimum tie break over
+    [left, up-left, up], same sequential cumsum initialisation, same backtrace)."""
+    bsz, m, n = distance.shape
+    cum = torch.zeros_like(distance)
+    bp = torch.zeros(bsz, m, n, dtype=torch.int32) - 1
+    cum[:, 0, :] = distance[:, 0, :].cumsum(-1)
+    cum[:, :, 0] = distance[:, :, 0].cumsum(-1)
+    bp[:, 0, :] = 0
+    bp[:, :, 0] = 2
+    for i in range(1, m):
+        for j in range(1, n):
+            c = torch.stack([cum[:, i, j - 1], cum[:, i - 1, j - 1], cum[:, i - 1, j]], dim=1)
+            v, k = c.min(dim=1)
+            bp[:, i, j] = k.int()
+            cum[:, i, j] = v + distance[:, i, j]
+    pm = torch.zeros_like(bp)
+    for b in range(bsz):
+        i = m - 1 if shapes is None else int(shapes[b][0]) - 1
+        j = n - 1 if shapes is None else int(shapes[b][1]) - 1
+        pm[b, i, j] = 1
+        steps = 1
+        while (i != 0 or j != 0) and steps < 10000:
+            di, dj = {0: (0, -1), 1: (-1, -1), 2: (-1, 0)}[int(bp[b, i, j])]
+            i, j = i + di, j + dj
+            pm[b, i, j] = 1
+            steps += 1
+    return cum, bp, pm
+
+
+def mfcc(y: torch.Tensor, sr: int, n_mfcc=13, n_mels=80, f_min=20.0) -> torch.Tensor:
+    """torchaudio.transforms.MFCC(sr, n_mfcc, log_mels=True, melkwargs=...) restated from its documented
+    defaults (un-pinned: torchaudio is absent) -> [T, n_mfcc]."""
+    n_fft = win = int(0.05 * sr)
+    hop = int(0.0125 * sr)
+    spec = torch.stft(y.double(), n_fft, hop, win, window=torch.hann_window(win, periodic=True, dtype=torch.float64),
+                      center=True, pad_mode="reflect", return_complex=True).abs() ** 2  # [F, T]
+    F_ = n_fft // 2 + 1
+    all_freqs = torch.linspace(0, sr // 2, F_, dtype=torch.float64)
+    hz2mel = lambda f: 2595.0 * math.log10(1.0 + f / 700.0)
+    m_pts = torch.linspace(hz2mel(f_min), hz2mel(sr / 2.0), n_mels + 2, dtype=torch.float64)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    fb = torch.clamp(torch.min(-slopes[:, :-2] / f_diff[:-1], slopes[:, 2:] / f_diff[1:]), min=0.0)
+    mel = torch.log(spec.t() @ fb + 1e-6)
+    k = torch.arange(n_mfcc, dtype=torch.float64).unsqueeze(1)
+    dct = torch.cos(math.pi / n_mels * (torch.arange(n_mels, dtype=torch.float64) + 0.5) * k)
+    dct[0] *= 1.0 / math.sqrt(2.0)
+    dct *= math.sqrt(2.0 / n_mels)
+    return (mel @ dct.t()).float()
+
+
+def mcd(y1, y2, sr):
+    x1, x2 = mfcc(y1, sr), mfcc(y2, sr)
+    d = (torch.cdist(x1.unsqueeze(0), x2.unsqueeze(0), p=2).squeeze(0).pow(2) / x1.size(1)).pow(0.5)
+    cum, bp, pm = dtw(d.unsqueeze(0))
+    return float(cum[0, -1, -1] / pm[0].sum())

@@ -147,6 +147,15 @@ int s2st_gl_overlap_add_f32(const float* frames, const float* wsq, float* wave, 
   return s2st_gl_overlap_add(frames, wsq, wave, T, n_fft, hop, n_out, (hipStream_t)stream);
 }
 
+int s2st_dtw_f32(const float* dist, const int32_t* shapes, int32_t B, int32_t M, int32_t N, float* cumdist, int32_t* backptr, int32_t* pathmap, void* stream) {
+  return s2st_dtw(dist, shapes, B, M, N, cumdist, backptr, pathmap, (hipStream_t)stream);
+}
+int s2st_rms_dist_f32(const float* x1, const float* x2, float* out, int32_t m, int32_t n, int32_t D, int64_t ldo, void* stream) {
+  return s2st_rms_dist(x1, x2, out, m, n, D, ldo, (hipStream_t)stream);
+}
+int s2st_power_spec_f32(const float* Y, float* P, int32_t T, int32_t F, void* stream) { return s2st_power_spec(Y, P, T, F, (hipStream_t)stream); }
+int s2st_log_offset_f32(float* x, int64_t n, float eps, void* stream) { return s2st_log_offset(x, n, eps, (hipStream_t)stream); }
+
 int s2st_profile_gemm(int32_t enable) { s2st_gemm_profile_enable(enable); return 0; }
 int s2st_profile_gemm_read(double* flops, double* ms, int64_t* launches) {
   long n = 0;

@@ -181,6 +181,15 @@ int s2st_gl_overlap_add(const float* frames, const float* wsq, float* wave, int 
                         hipStream_t st);
 
 // ---------------------------------------------------------------------------------------
+// MCD evaluation (metrics.hip)
+// ---------------------------------------------------------------------------------------
+int s2st_dtw(const float* dist, const int* shapes, int B, int M, int N, float* cum, int* backptr, int* pathmap,
+             hipStream_t st);
+int s2st_rms_dist(const float* x1, const float* x2, float* out, int m, int n, int D, long ldo, hipStream_t st);
+int s2st_power_spec(const float* Y, float* P, int T, int F, hipStream_t st);
+int s2st_log_offset(float* x, long n, float eps, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------
 // losses (losses.hip)
 // ---------------------------------------------------------------------------------------
 // stats (optional) += {sum|fo-t| + sum|fp-t|, sum(fo-t)^2 + sum(fp-t)^2, sum bce} over valid

@@ -111,3 +111,35 @@ def test_vocoder_against_oracle(backend):
     ref = IO.vocoder(feat, ang, n_iter=2, **kw)
     assert w.shape == (1, ref.shape[0])
     assert float((w[0].cpu() - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+
+
+def test_dtw_against_reference_golden(backend, golden_dir):
+    """batch_dynamic_time_warping (s2s_translation.py:414-460): back pointers and path map bit-exact
+    (integers, incl. exact ties), cumulative distances bit-exact (same fp32 add order)."""
+    z = np.load(os.path.join(golden_dir, "infer_dtw.npz"))
+    M = importlib.import_module(PKG + ".metrics")
+    d = torch.from_numpy(z["dist"]).to(backend.device)
+    cum, bp, pm = M.batch_dynamic_time_warping(d, torch.from_numpy(z["shapes"]))
+    backend.sync()
+    assert np.array_equal(bp.cpu().numpy(), z["backptr"])
+    assert np.array_equal(pm.cpu().numpy(), z["pathmap"])
+    assert np.array_equal(cum.cpu().numpy(), z["cum"])
+    # the oracle restatement agrees too (pins it)
+    c2, b2, p2 = IO.dtw(torch.from_numpy(z["dist"]), torch.from_numpy(z["shapes"]))
+    assert np.array_equal(b2.numpy(), z["backptr"]) and np.array_equal(p2.numpy(), z["pathmap"])
+
+
+def test_mcd_against_oracle(backend):
+    """MFCC (dense-DFT / mel / DCT GEMMs) + RMS distance + DTW against the oracle restatement."""
+    M = importlib.import_module(PKG + ".metrics")
+    sr = 4000
+    g = torch.Generator().manual_seed(8)
+    y1 = [torch.randn(2300, generator=g) * 0.1, torch.randn(1500, generator=g) * 0.1]
+    y2 = [y1[0][200:] * 0.9 + 0.01 * torch.randn(2100, generator=g), torch.randn(1900, generator=g) * 0.1]
+    rets = M.batch_mel_cepstral_distortion(y1, y2, sr, device=backend.device)
+    backend.sync()
+    for b in range(2):
+        ref = IO.mcd(y1[b], y2[b], sr)
+        assert abs(float(rets[b][0]) - ref) < 2e-3 * ref, (b, float(rets[b][0]), ref)
+        x1 = IO.mfcc(y1[b], sr)
+        assert float((rets[b][1][0].cpu() - x1).abs().max()) < 2e-3 * float(x1.abs().max())
