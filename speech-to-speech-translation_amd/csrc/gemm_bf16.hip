@@ -659,7 +659,7 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
   g.splitk = 1;
   g.slab = nullptr;
   if (can_split_ && nt < 256) {
-    static const int target = getenv("S2ST_SPLITK_TARGET") ? atoi(getenv("S2ST_SPLITK_TARGET")) : 256;
+    static const int target = getenv("S2ST_SPLITK_TARGET") ? atoi(getenv("S2ST_SPLITK_TARGET")) : 128;
     int want = (int)((target + nt - 1) / nt);
     int maxs = g.K / (4 * BK);
     g.splitk = want < maxs ? want : maxs;
