@@ -495,13 +495,15 @@ int s2st_flash_attn_fwd(const s2st_attn_args* p, hipStream_t st) {
 }
 
 // dO (fp32, for D) + its bf16 copy; o / lse from the forward; writes dq, dk, dv (fp32, overwrite)
-int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_scratch, hipStream_t st) {
+// phase 0: everything; 1: only the D vector; 2: only dK,dV; 3: only dQ (the caller may overlap 2 and 3)
+int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_scratch, hipStream_t st, int phase) {
   if (!p || !attn_args_ok(*p) || !p->doh || !dO || !dvec_scratch || !p->dq || !p->dk || !p->dv || !p->lse || !p->o)
     return S2ST_ERR_ARG;
   AttnArgs a = to_args(*p);
   a.dvec = dvec_scratch;
   const long rows = (long)p->B * p->T * p->H;
-  if (p->dh == 128)
+  if (phase > 1) {
+  } else if (p->dh == 128)
     hipLaunchKernelGGL(attn_dvec_kernel<128>, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, st, dO,
                        (const float*)p->o, dvec_scratch, p->B, p->H, p->T);
   else
@@ -510,12 +512,13 @@ int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_sc
   auto go = [&](auto nwc) {
     constexpr int NW = decltype(nwc)::value;
     dim3 gk((p->S + 16 * NW - 1) / (16 * NW), p->B * p->H), gq((p->T + 16 * NW - 1) / (16 * NW), p->B * p->H);
+    const bool kv = phase == 0 || phase == 2, qq = phase == 0 || phase == 3;
     if (p->dh == 128) {
-      hipLaunchKernelGGL((flash_bwd_kv_kernel<128, NW>), gk, dim3(64 * NW), 0, st, a);
-      hipLaunchKernelGGL((flash_bwd_q_kernel<128, NW>), gq, dim3(64 * NW), 0, st, a);
+      if (kv) hipLaunchKernelGGL((flash_bwd_kv_kernel<128, NW>), gk, dim3(64 * NW), 0, st, a);
+      if (qq) hipLaunchKernelGGL((flash_bwd_q_kernel<128, NW>), gq, dim3(64 * NW), 0, st, a);
     } else {
-      hipLaunchKernelGGL((flash_bwd_kv_kernel<64, NW>), gk, dim3(64 * NW), 0, st, a);
-      hipLaunchKernelGGL((flash_bwd_q_kernel<64, NW>), gq, dim3(64 * NW), 0, st, a);
+      if (kv) hipLaunchKernelGGL((flash_bwd_kv_kernel<64, NW>), gk, dim3(64 * NW), 0, st, a);
+      if (qq) hipLaunchKernelGGL((flash_bwd_q_kernel<64, NW>), gq, dim3(64 * NW), 0, st, a);
     }
   };
   const int nw = attn_nw();

@@ -121,7 +121,7 @@ int64_t s2st_ctc_workspace(int32_t B, int32_t E, int32_t Lmax) { return s2st_ctc
 
 int s2st_flash_attn_fwd_bf16(const s2st_attn_args* args, void* stream) { return s2st_flash_attn_fwd(args, (hipStream_t)stream); }
 int s2st_flash_attn_bwd_bf16(const s2st_attn_args* args, const float* dO, float* dvec_scratch, void* stream) {
-  return s2st_flash_attn_bwd(args, dO, dvec_scratch, (hipStream_t)stream);
+  return s2st_flash_attn_bwd(args, dO, dvec_scratch, (hipStream_t)stream, 0);
 }
 
 int s2st_argmax_dim1_f32(const float* x, int64_t* idx, int32_t B, int32_t E, int32_t D, void* stream) {

@@ -493,9 +493,18 @@ struct s2st_engine {
       bool acc;
       float* dx = gradbuf(x, acc);
       float* scratch = alloc((long)s2st_layernorm_bwd_blocks(x->rows) * 2 * x->cols);
-      if (live())
-        chk(s2st_layernorm_bwd(y->g, x->d, P + pp.g, mean, rstd, dx, acc ? 1 : 0, G + pp.g, G + pp.b,
-                               scratch, x->rows, x->cols, st_));
+      if (live()) {
+        if (side_) {  // dx on the data path; the dgamma / dbeta reduce next to it on the second stream
+          chk(s2st_layernorm_bwd(y->g, x->d, P + pp.g, mean, rstd, dx, acc ? 1 : 0, G + pp.g, G + pp.b, scratch,
+                                 x->rows, x->cols, st_, 1));
+          hipStream_t rs = fork_side();
+          chk(s2st_layernorm_bwd(y->g, x->d, P + pp.g, mean, rstd, dx, acc ? 1 : 0, G + pp.g, G + pp.b, scratch,
+                                 x->rows, x->cols, rs, 2));
+        } else {
+          chk(s2st_layernorm_bwd(y->g, x->d, P + pp.g, mean, rstd, dx, acc ? 1 : 0, G + pp.g, G + pp.b, scratch,
+                                 x->rows, x->cols, st_));
+        }
+      }
     });
     return y;
   }
@@ -539,6 +548,8 @@ struct s2st_engine {
         s2st_attn_args fb = fa;
         fb.doh = ghalf_of(o);
         fb.dq = gq + io3.qoff; fb.dk = gk + io3.koff; fb.dv = gv + io3.voff;
+        // (dK,dV and dQ are independent, but joining the second stream here would also wait for its
+        // backlog of weight-gradient GEMMs: measured slower, so both stay on the data-path stream)
         if (live()) chk(s2st_flash_attn_bwd(&fb, o->g, dvec, st_));
       });
       return o;

@@ -632,7 +632,14 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
   if (g.ep.mask_y && (!g.cvec || g.N % 4 != 0)) return S2ST_ERR_SHAPE;
   const bool linear_epi = !g.ep.act && g.ep.drop_p == 0.f && !g.ep.mask_y;
   struct Cand { int bm, bn; double eff; };
-  const Cand cands[3] = {{128, 128, 1.0}, {128, 64, 0.8}, {64, 64, 0.55}};
+  static Cand cands[3] = {{128, 128, 1.0}, {128, 64, 0.8}, {64, 64, 0.55}};
+  static bool eff_init = false;
+  if (!eff_init) {  // tuning aid: S2ST_GEMM_EFF="e128x128,e128x64,e64x64"
+    const char* ev = getenv("S2ST_GEMM_EFF");
+    double a, b, c;
+    if (ev && sscanf(ev, "%lf,%lf,%lf", &a, &b, &c) == 3) { cands[0].eff = a; cands[1].eff = b; cands[2].eff = c; }
+    eff_init = true;
+  }
   int bm = 64, bn = 64;
   if (vec) {
     double best = 1e300;

@@ -342,14 +342,18 @@ int s2st_layernorm_bwd_blocks(int rows) {
 // scratch: s2st_layernorm_bwd_blocks(rows) * 2 * cols floats
 int s2st_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                        const float* rstd, float* dx, int dx_accumulate, float* dgamma,
-                       float* dbeta, float* scratch, int rows, int cols, hipStream_t st) {
+                       float* dbeta, float* scratch, int rows, int cols, hipStream_t st, int phase) {
   if (rows <= 0) return 0;
   if (cols % 4 != 0 || cols > LN_MAXV * 256) return S2ST_ERR_SHAPE;
   int blocks = s2st_layernorm_bwd_blocks(rows);
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(64 * LNB_WAVES), 0, st, dy, x, gamma, mean,
-                     rstd, dx, dx_accumulate, scratch, rows, cols);
-  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * cols + 31) / 32), dim3(256), 0, st,
-                     (const float*)scratch, blocks, cols, dgamma, dbeta);
+  // phase 0: both kernels; 1: only dx + per-block partials; 2: only the dgamma / dbeta reduce (lets the
+  // caller put the parameter-gradient reduce on another stream: it is off the backward's critical path)
+  if (phase != 2)
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(64 * LNB_WAVES), 0, st, dy, x, gamma, mean,
+                       rstd, dx, dx_accumulate, scratch, rows, cols);
+  if (phase != 1)
+    hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * cols + 31) / 32), dim3(256), 0, st,
+                       (const float*)scratch, blocks, cols, dgamma, dbeta);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 

@@ -67,7 +67,7 @@ int s2st_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
 int s2st_layernorm_bwd_blocks(int rows);  // scratch floats = blocks * 2 * cols
 int s2st_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                        const float* rstd, float* dx, int dx_accumulate, float* dgamma,
-                       float* dbeta, float* scratch, int rows, int cols, hipStream_t st);
+                       float* dbeta, float* scratch, int rows, int cols, hipStream_t st, int phase = 0);
 
 // attention probabilities: p = softmax(s + masks) rows of [B, H, T, S(ld)]
 //   key mask: col >= klen[b] -> -inf ; causal: col > row -> -inf
@@ -151,7 +151,7 @@ int s2st_bn_bwd(const float* dy, Split dysp, const float* x, const float* mean, 
 int s2st_flash_attn_supported(int dh);
 int s2st_flash_attn_preload(hipStream_t st);
 int s2st_flash_attn_fwd(const s2st_attn_args* p, hipStream_t st);
-int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_scratch, hipStream_t st);
+int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_scratch, hipStream_t st, int phase = 0);
 
 // ---------------------------------------------------------------------------------------
 // HuBERT front end (hubert.hip): waveform conv, GroupNorm(C, C) + GELU, pos-conv input re-layout
