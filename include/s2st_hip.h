@@ -298,6 +298,11 @@ int s2st_engine_forward(s2st_engine* e, const s2st_batch* b, const s2st_outputs*
  * gradient all-reduce of finished arena ranges (see s2st_engine_num_segments). */
 int s2st_engine_backward(s2st_engine* e, float gscale, int32_t segment, void* stream);
 int32_t s2st_engine_num_segments(const s2st_engine* e);
+/* The engine's second HIP stream (weight-gradient GEMMs, parameter-gradient reduces) or NULL.  After
+ * s2st_engine_backward(segment i) returns, the gradients of segment i are complete once BOTH the
+ * caller's stream and this stream have drained what was enqueued so far: a gradient all-reduce on
+ * another stream must wait on both (the data-path stream itself joins only after the last segment). */
+void* s2st_engine_side_stream(const s2st_engine* e);
 /* after segment i has run, gradients in arena range [lo, hi) are final */
 int s2st_engine_segment_range(const s2st_engine* e, int32_t i, int64_t* lo, int64_t* hi);
 

@@ -83,6 +83,7 @@ struct s2st_engine {
   hipStream_t side_ = nullptr;
   hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   bool side_used = false;
+  bool join_every_segment = false;  // S2ST_JOIN_EVERY_SEGMENT=1 (A/B switch)
   float* skws_side = nullptr;
   hipStream_t fork_side() {  // everything issued on st_ so far happens-before what follows on the returned stream
     if (!side_) return st_;
@@ -1273,7 +1274,10 @@ struct s2st_engine {
       tape[i]();
       if (err) break;
     }
-    join_side();  // the segment's weight gradients are complete in st_ order
+    // The segment's weight gradients live on the second stream.  A caller that overlaps the gradient
+    // all-reduce waits on that stream itself (s2st_engine_side_stream); the data path only joins once,
+    // after the last segment, so it never stalls behind the weight-gradient backlog.
+    if (seg == ns - 1 || join_every_segment) join_side();
     return err;
   }
 };
@@ -1295,6 +1299,7 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   s2st_engine* e = new s2st_engine();
   e->c = *cfg;
   e->f32_operands = getenv("S2ST_F32_OPERANDS") && atoi(getenv("S2ST_F32_OPERANDS")) != 0;
+  e->join_every_segment = getenv("S2ST_JOIN_EVERY_SEGMENT") && atoi(getenv("S2ST_JOIN_EVERY_SEGMENT")) != 0;
   e->use_flash = !(getenv("S2ST_NO_FLASH") && atoi(getenv("S2ST_NO_FLASH")) != 0);
   e->use_act_fuse = !(getenv("S2ST_NO_ACT_FUSE") && atoi(getenv("S2ST_NO_ACT_FUSE")) != 0);
   e->use_only_h = !(getenv("S2ST_NO_ONLY_H") && atoi(getenv("S2ST_NO_ONLY_H")) != 0);
@@ -1408,6 +1413,8 @@ int s2st_engine_backward(s2st_engine* e, float gscale, int32_t segment, void* st
 }
 
 int32_t s2st_engine_num_segments(const s2st_engine* e) { return e->n_segments(); }
+
+void* s2st_engine_side_stream(const s2st_engine* e) { return (void*)e->side_; }
 
 int s2st_engine_segment_range(const s2st_engine* e, int32_t i, int64_t* lo, int64_t* hi) {
   int ns = e->n_segments();

@@ -28,8 +28,10 @@ def world_size() -> int:
 class GradReducer:
     """SUM all-reduce of arena ranges as the backward finishes them."""
 
-    def __init__(self, grads: torch.Tensor, min_bucket_floats: int = 4 << 20):
+    def __init__(self, grads: torch.Tensor, min_bucket_floats: int = 4 << 20, extra_stream=None):
         self.grads = grads
+        # the engine's second stream (weight gradients): a range is final once both streams reached here
+        self.extra_stream = extra_stream
         self.min_bucket = min_bucket_floats
         self.cuda = grads.is_cuda
         self.stream = torch.cuda.Stream() if self.cuda else None
@@ -46,6 +48,8 @@ class GradReducer:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.stream.wait_event(ev)
+            if self.extra_stream is not None:
+                self.stream.wait_stream(self.extra_stream)
             with torch.cuda.stream(self.stream):
                 dist.all_reduce(view, op=dist.ReduceOp.SUM)
         else:

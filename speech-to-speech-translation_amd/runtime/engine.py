@@ -476,6 +476,15 @@ class Engine:
         if self._outpool is None or self._outpool.numel() < out:
             self._outpool = torch.empty(out, dtype=torch.float32, device=self.device)
 
+    def side_stream(self):
+        """torch view of the engine's second stream (None on the emulator / when disabled)."""
+        if bd.is_emulator() or not torch.cuda.is_available():
+            return None
+        self.lib.s2st_engine_side_stream.argtypes = [C.c_void_p]
+        self.lib.s2st_engine_side_stream.restype = C.c_void_p
+        p = self.lib.s2st_engine_side_stream(self.h)
+        return torch.cuda.ExternalStream(p) if p else None
+
     def num_segments(self) -> int:
         return int(self.lib.s2st_engine_num_segments(self.h))
 

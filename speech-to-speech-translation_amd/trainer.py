@@ -48,7 +48,7 @@ class Trainer:
         self.eps = getattr(args, "adam_eps", 1e-8)
         self.wd = getattr(args, "weight_decay", 0.0)
         self.seed = getattr(args, "seed", 1)
-        self.reducer = GradReducer(self.engine.grads) if is_dist() else None
+        self.reducer = GradReducer(self.engine.grads, extra_stream=self.engine.side_stream()) if is_dist() else None
         if is_dist():
             # DDP's constructor broadcast of parameters and buffers from rank 0
             torch.distributed.broadcast(self.engine.params, 0)
