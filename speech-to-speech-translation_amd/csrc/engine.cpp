@@ -713,11 +713,13 @@ struct s2st_engine {
         g.C = gemm_out(dwf, (long)pp.Kw * pp.I);
         g.ep = gemm_epi_default();
         g.ep.accumulate = 1;
-        g.ws = skws; g.ws_floats = skws_n;
+        // parameter gradients only: on the second stream, next to the data-gradient chain
+        hipStream_t ws_st = fm ? fork_side() : st_;
+        g.ws = ws_st == st_ ? skws : skws_side; g.ws_floats = skws_n;
         g.M = pp.O; g.N = pp.Kw * pp.I; g.K = M; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
-        chk(s2st_gemm(g, st_));
-        chk(s2st_colsum(z->g, pp.O, M, pp.O, G + pp.b, 1, st_));
-        chk(s2st_conv_w_unpermute_acc(dwf, G + pp.w, pp.O, pp.I, pp.Kw, st_));
+        chk(s2st_gemm(g, ws_st));
+        chk(s2st_colsum(z->g, pp.O, M, pp.O, G + pp.b, 1, ws_st));
+        chk(s2st_conv_w_unpermute_acc(dwf, G + pp.w, pp.O, pp.I, pp.Kw, ws_st));
       }
       if (in2.src && in2.src->needs_grad) {
         // dz placed at rows pad + stride*t of a zeroed [B][Tin + 2 pad][O] image
