@@ -81,7 +81,8 @@ struct s2st_engine {
   // weight-gradient GEMMs are off the backward critical path: they run on a second stream, next
   // to the data-gradient chain (each of these GEMMs alone fills about half of the 256 CUs)
   hipStream_t side_ = nullptr;
-  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr, ev_taps_ = nullptr;
+  bool overlap_aux = true;  // S2ST_NO_AUX_OVERLAP=1 (A/B switch)
   bool side_used = false;
   bool join_every_segment = false;  // S2ST_JOIN_EVERY_SEGMENT=1 (A/B switch)
   float* skws_side = nullptr;
@@ -1150,6 +1151,10 @@ struct s2st_engine {
     Ten* enc_out = has_enc_ln ? layernorm(x, enc_ln, outs.enc_out) : x;
     if (c.has_asr && tap_asr) tap_asr = layernorm(tap_asr, asr_norm, outs.tap0);
     if (c.has_st && tap_st) tap_st = layernorm(tap_st, st_norm, outs.tap1);
+    // the CTC head and the aux text decoders only need the encoder taps: they are issued (below, in tape
+    // order) on the second stream behind this event and run next to the mel decoder
+    const bool aux_on_side = side_ && ev_taps_ && live() && overlap_aux;
+    if (aux_on_side) hipEventRecord(ev_taps_, st_);
     mark();
     if (stop_after_encoder) {  // decode_begin: the AR loop drives the decoder itself
       enc_out_keep = enc_out;
@@ -1177,6 +1182,12 @@ struct s2st_engine {
     Ten* post = postnet(feat, B, D, tr, csp, outs.post_feat);
     mark();
     // ---- CTC head on tap 0 (ctc_proj lives on the decoder, fed the encoder tap; :458-463) ----------
+    hipStream_t main_st = st_;
+    if (aux_on_side) {
+      hipStreamWaitEvent(side_, ev_taps_, 0);
+      st_ = side_;
+      side_used = true;
+    }
     Ten* ctc_logits = nullptr;
     if (c.has_ctc && tap_asr) ctc_logits = linear(tap_asr, ctc_proj.w, ctc_proj.b, c.src_vocab, C);
     // The CTC sweep (one workgroup per utterance, ~E sequential steps: latency-bound, ~0.4 ms) runs on the
@@ -1190,7 +1201,7 @@ struct s2st_engine {
       // loss, so it is produced here (per unit of upstream gradient) and only scaled in the backward
       ctc_dl = tr ? alloc(ctc_logits->n()) : nullptr;
       if (live()) {
-        hipStream_t cs = fork_side();
+        hipStream_t cs = aux_on_side ? st_ : fork_side();
         chk(s2st_ctc(ctc_logits->d, (const long*)bt.src_txt, bt.Ls, bt.ctc_in_lens, bt.src_txt_lens, B, E,
                      c.src_vocab, ctc_lp, ctc_per, ctc_dl, ctc_dl ? c.ctc_weight / B : 0.f, ctc_ws, cs));
       }
@@ -1203,6 +1214,7 @@ struct s2st_engine {
     if (c.has_st && tap_st && bt.prev_tgt_txt)
       st_logits = aux_decoder(st, tap_st, (const long*)bt.prev_tgt_txt, bt.tgt_txt_pos, bt.tgt_txt_lens, B,
                               bt.Lt, pe_st, outs.st_logits);
+    st_ = main_st;
     mark();
     // ---- losses (s2st_loss.py:219-257) -----------------------------------------------------------------
     if (with_loss) {
@@ -1212,13 +1224,13 @@ struct s2st_engine {
         hipMemsetAsync(stats, 0, sizeof(float) * 32, st_);
         chk(s2st_mel_loss(feat->d, post->d, eos->d, bt.tgt, bt.tgt_lens, B, D, c.out_dim, c.bce_pos_weight,
                           stats + S2ST_STAT_L1_SUM, 0, 0, 0, nullptr, nullptr, nullptr, st_));
+        join_side();  // aux logits, CTC per-utterance losses
         if (asr_logits)
           chk(s2st_ls_ce(asr_logits->d, (const long*)bt.src_txt, B * bt.Ls, c.src_vocab, 1, c.label_smoothing,
                          stats + S2ST_STAT_ASR_NLL, nullptr, 0.f, st_));
         if (st_logits)
           chk(s2st_ls_ce(st_logits->d, (const long*)bt.tgt_txt, B * bt.Lt, c.tgt_vocab, 1, c.label_smoothing,
                          stats + S2ST_STAT_ST_NLL, nullptr, 0.f, st_));
-        join_side();  // CTC per-utterance losses
         chk(s2st_loss_finalize(stats, ctc_per, B, nf, nr, c.w_l1, c.w_mse, c.w_eos, c.ctc_weight,
                                c.asr_weight, c.st_weight, c.label_smoothing, c.src_vocab, c.tgt_vocab,
                                (float)bt.src_txt_ntokens, (float)bt.tgt_txt_ntokens, st_));
@@ -1260,6 +1272,7 @@ struct s2st_engine {
         }
       });
     }
+    join_side();  // nothing of this forward is left running on the second stream when it returns in st_ order
     mark();
     return err;
   }
@@ -1309,8 +1322,10 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   if (!cfg->precise && (s2st_gemm_bf16_preload(nullptr) != 0 || s2st_flash_attn_preload(nullptr) != 0)) { delete e; return S2ST_ERR_LAUNCH; }
   if (!cfg->precise && !(getenv("S2ST_NO_SIDE_STREAM") && atoi(getenv("S2ST_NO_SIDE_STREAM")))) {
     if (hipStreamCreateWithFlags(&e->side_, hipStreamNonBlocking) != hipSuccess) e->side_ = nullptr;
+    e->overlap_aux = !(getenv("S2ST_NO_AUX_OVERLAP") && atoi(getenv("S2ST_NO_AUX_OVERLAP")) != 0);
     if (e->side_ && (hipEventCreateWithFlags(&e->ev_fork_, hipEventDisableTiming) != hipSuccess ||
-                     hipEventCreateWithFlags(&e->ev_join_, hipEventDisableTiming) != hipSuccess)) {
+                     hipEventCreateWithFlags(&e->ev_join_, hipEventDisableTiming) != hipSuccess ||
+                     hipEventCreateWithFlags(&e->ev_taps_, hipEventDisableTiming) != hipSuccess)) {
       hipStreamDestroy(e->side_);
       e->side_ = nullptr;
     }
@@ -1326,6 +1341,7 @@ void s2st_engine_destroy(s2st_engine* e) {
     hipStreamDestroy(e->side_);
     hipEventDestroy(e->ev_fork_);
     hipEventDestroy(e->ev_join_);
+    if (e->ev_taps_) hipEventDestroy(e->ev_taps_);
   }
   e->reset_call();
   delete e;
