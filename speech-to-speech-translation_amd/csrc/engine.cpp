@@ -83,6 +83,9 @@ struct s2st_engine {
   hipStream_t side_ = nullptr;
   hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr, ev_taps_ = nullptr;
   bool overlap_aux = true;  // S2ST_NO_AUX_OVERLAP=1 (A/B switch)
+  hipEvent_t ev_auxb_ = nullptr;
+  size_t aux_wait_idx = 0, aux_lo_idx = 0, aux_hi_idx = 0;  // tape indices: tap-LN end; aux section [lo, hi)
+  bool aux_bwd_on_side = false;
   bool side_used = false;
   bool join_every_segment = false;  // S2ST_JOIN_EVERY_SEGMENT=1 (A/B switch)
   float* skws_side = nullptr;
@@ -120,6 +123,7 @@ struct s2st_engine {
   struct HubP {
     long conv_w[8]; long gn_g, gn_b; LNP ln; LinP proj; long pos_w, pos_b; std::vector<EncLayerP> L; LNP enc_ln;
   } hp;
+  float* ws_for(hipStream_t s) const { return (side_ && s == side_) ? skws_side : skws; }
   float* skws = nullptr;  // split-K partial-sum scratch of the weight-gradient GEMMs (per call)
   long skws_n = 0;
   bf16raw* PHT = nullptr;  // optional: transposed bf16 copies of the 2-D weights (same offsets): the
@@ -445,7 +449,7 @@ struct s2st_engine {
         g.ep = gemm_epi_default();
         g.ep.accumulate = 1;
         hipStream_t ws_st = fm ? fork_side() : st_;
-        g.ws = ws_st == st_ ? skws : skws_side; g.ws_floats = skws_n;
+        g.ws = ws_for(ws_st); g.ws_floats = skws_n;
         g.M = N; g.N = K; g.K = M; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
         chk(s2st_gemm(g, ws_st));
         if (b >= 0 && !bias_done) chk(s2st_colsum(dpre, N, M, N, G + b, 1, st_));
@@ -471,7 +475,7 @@ struct s2st_engine {
             g.ep.colsum = x->act_bias >= 0 ? G + x->act_bias : nullptr;
           }
           g.ep.accumulate = acc ? 1 : 0;
-          g.ws = skws; g.ws_floats = skws_n;
+          g.ws = ws_for(st_); g.ws_floats = skws_n;
           g.M = M; g.N = K; g.K = N; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
           chk(s2st_gemm(g, st_));
         }
@@ -716,7 +720,7 @@ struct s2st_engine {
         g.ep.accumulate = 1;
         // parameter gradients only: on the second stream, next to the data-gradient chain
         hipStream_t ws_st = fm ? fork_side() : st_;
-        g.ws = ws_st == st_ ? skws : skws_side; g.ws_floats = skws_n;
+        g.ws = ws_for(ws_st); g.ws_floats = skws_n;
         g.M = pp.O; g.N = pp.Kw * pp.I; g.K = M; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
         chk(s2st_gemm(g, ws_st));
         chk(s2st_colsum(z->g, pp.O, M, pp.O, G + pp.b, 1, ws_st));
@@ -1155,6 +1159,7 @@ struct s2st_engine {
     // order) on the second stream behind this event and run next to the mel decoder
     const bool aux_on_side = side_ && ev_taps_ && live() && overlap_aux;
     if (aux_on_side) hipEventRecord(ev_taps_, st_);
+    aux_wait_idx = tape.size();  // the tap layer-norm closures are the last ones pushed so far
     mark();
     if (stop_after_encoder) {  // decode_begin: the AR loop drives the decoder itself
       enc_out_keep = enc_out;
@@ -1183,6 +1188,7 @@ struct s2st_engine {
     mark();
     // ---- CTC head on tap 0 (ctc_proj lives on the decoder, fed the encoder tap; :458-463) ----------
     hipStream_t main_st = st_;
+    aux_lo_idx = tape.size();
     if (aux_on_side) {
       hipStreamWaitEvent(side_, ev_taps_, 0);
       st_ = side_;
@@ -1215,6 +1221,8 @@ struct s2st_engine {
       st_logits = aux_decoder(st, tap_st, (const long*)bt.prev_tgt_txt, bt.tgt_txt_pos, bt.tgt_txt_lens, B,
                               bt.Lt, pe_st, outs.st_logits);
     st_ = main_st;
+    aux_hi_idx = tape.size();
+    aux_bwd_on_side = aux_on_side && tr;
     mark();
     // ---- losses (s2st_loss.py:219-257) -----------------------------------------------------------------
     if (with_loss) {
@@ -1285,10 +1293,20 @@ struct s2st_engine {
     if (seg < 0 || seg >= ns) return S2ST_ERR_ARG;
     if (seg == 0) join_side();  // transposed weights (and anything else the forward left on the side stream)
     size_t hi = marks[ns - seg].tape_idx, lo = marks[ns - seg - 1].tape_idx;
+    hipStream_t main_st = st_;
     for (size_t i = hi; i-- > lo;) {
+      if (aux_bwd_on_side && live()) {
+        // the aux decoders' backward (CTC head + text decoders: many small kernels that only produce
+        // the taps' gradients and parameter gradients) runs on the second stream next to the mel
+        // decoder's backward; the data path waits for it right before the tap layer norms consume it
+        if (i + 1 == aux_hi_idx && st_ == main_st) st_ = fork_side();
+        if (i + 1 == aux_lo_idx && st_ != main_st) { hipEventRecord(ev_auxb_, st_); st_ = main_st; }
+        if (i + 1 == aux_wait_idx) hipStreamWaitEvent(main_st, ev_auxb_, 0);
+      }
       tape[i]();
       if (err) break;
     }
+    if (st_ != main_st) { hipEventRecord(ev_auxb_, st_); st_ = main_st; }
     // The segment's weight gradients live on the second stream.  A caller that overlaps the gradient
     // all-reduce waits on that stream itself (s2st_engine_side_stream); the data path only joins once,
     // after the last segment, so it never stalls behind the weight-gradient backlog.
@@ -1325,7 +1343,8 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
     e->overlap_aux = !(getenv("S2ST_NO_AUX_OVERLAP") && atoi(getenv("S2ST_NO_AUX_OVERLAP")) != 0);
     if (e->side_ && (hipEventCreateWithFlags(&e->ev_fork_, hipEventDisableTiming) != hipSuccess ||
                      hipEventCreateWithFlags(&e->ev_join_, hipEventDisableTiming) != hipSuccess ||
-                     hipEventCreateWithFlags(&e->ev_taps_, hipEventDisableTiming) != hipSuccess)) {
+                     hipEventCreateWithFlags(&e->ev_taps_, hipEventDisableTiming) != hipSuccess ||
+                     hipEventCreateWithFlags(&e->ev_auxb_, hipEventDisableTiming) != hipSuccess)) {
       hipStreamDestroy(e->side_);
       e->side_ = nullptr;
     }
@@ -1342,6 +1361,7 @@ void s2st_engine_destroy(s2st_engine* e) {
     hipEventDestroy(e->ev_fork_);
     hipEventDestroy(e->ev_join_);
     if (e->ev_taps_) hipEventDestroy(e->ev_taps_);
+    if (e->ev_auxb_) hipEventDestroy(e->ev_auxb_);
   }
   e->reset_call();
   delete e;
