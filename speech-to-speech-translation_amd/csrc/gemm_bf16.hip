@@ -513,19 +513,25 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_kernel(GemmArgs g) {
       DB::sanitize(cur + A_BYTES, kv, tid);
       __syncthreads();
     }
+    // all fragment reads of the K-step are issued up front (B first: every MFMA row needs all of it),
+    // the MFMAs then consume them in issue order behind counted lgkmcnt waits: LDS latency is paid once
+    // per K-step instead of once per read group
+    bf16x8 af[2][TM], bf[2][TN];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 af[TM], bf[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = LA::frag(cur, wm * WM + i * 16, s, lane);
+      for (int j = 0; j < TN; ++j) bf[s][j] = LB::frag(cur + A_BYTES, wn * WN + j * 16, s, lane);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = LB::frag(cur + A_BYTES, wn * WN + j * 16, s, lane);
+      for (int i = 0; i < TM; ++i) af[s][i] = LA::frag(cur, wm * WM + i * 16, s, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[s][j], af[s][i], acc[i][j], 0, 0, 0);
   }
   gemm_epilogue<BM, BN, WGN>(g, acc, m0, n0, wm, wn, lane, zb, ks, zq, zr);
 }
@@ -692,7 +698,10 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
   if (dma_ok) {
     int rc;
     static const int nw8 = getenv("S2ST_GEMM_NW8") ? atoi(getenv("S2ST_GEMM_NW8")) : 1;
-    if (bm == 128 && bn == 128) rc = nw8 ? launch_dma<128, 128, 4, 8>(g, grid, st) : launch_dma<128, 128, 4, 4>(g, grid, st);
+    static const int ns = getenv("S2ST_GEMM_NS") ? atoi(getenv("S2ST_GEMM_NS")) : 4;  // tuning aid (128x128 only)
+    if (bm == 128 && bn == 128 && nw8 && ns == 3) rc = launch_dma<128, 128, 3, 8>(g, grid, st);
+    else if (bm == 128 && bn == 128 && nw8 && ns == 5) rc = launch_dma<128, 128, 5, 8>(g, grid, st);
+    else if (bm == 128 && bn == 128) rc = nw8 ? launch_dma<128, 128, 4, 8>(g, grid, st) : launch_dma<128, 128, 4, 4>(g, grid, st);
     else if (bm == 128) rc = nw8 ? launch_dma<128, 64, 4, 8>(g, grid, st) : launch_dma<128, 64, 4, 4>(g, grid, st);
     else rc = launch_dma<64, 64, 4, 4>(g, grid, st);
     if (rc) return rc;
