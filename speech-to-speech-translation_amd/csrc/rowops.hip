@@ -335,8 +335,10 @@ int s2st_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
 }
 
 int s2st_layernorm_bwd_blocks(int rows) {
-  int blocks = (rows + LNB_WAVES - 1) / LNB_WAVES;
-  return blocks > 256 ? 256 : blocks;
+  // two rows per wave in ONE pass when possible (the kernel is latency-bound: a second dependent
+  // pass costs as much as the first), at most 512 blocks of partial sums
+  int blocks = (rows + 2 * LNB_WAVES - 1) / (2 * LNB_WAVES);
+  return blocks > 512 ? 512 : (blocks < 1 ? 1 : blocks);
 }
 
 // scratch: s2st_layernorm_bwd_blocks(rows) * 2 * cols floats
