@@ -103,7 +103,9 @@ typedef struct {
   uint64_t seed;
   int32_t ld_drop;
   const uint16_t* doh; /* backward: bf16 dO */
-  float *dq, *dk, *dv; /* backward outputs (overwritten) */
+  float *dq, *dk, *dv; /* backward outputs (overwritten); each may be NULL when its bf16 twin is given */
+  uint16_t *dqh, *dkh, *dvh; /* optional bf16 gradients, addressed like q / k / v */
+  float *dbq, *dbk, *dbv;    /* optional: += column sums of dq / dk / dv (the projections' bias gradients, [H*dh]) */
 } s2st_attn_args;
 int s2st_flash_attn_fwd_bf16(const s2st_attn_args* args, void* stream);
 /* dO: fp32 [B*T][H*dh]; dvec_scratch: B*H*T floats */

@@ -116,8 +116,36 @@ struct AttnArgs {
   // backward
   const bf16_t* doh;              // bf16 dO [B*T][H*DH]
   const float* dvec;              // D[b,h,t] = rowsum(dO * O)
-  float *dq, *dk, *dv;            // fp32 gradients, addressed like q / k / v (ldq / ldk / ldv)
+  float *dq, *dk, *dv;            // fp32 gradients, addressed like q / k / v (ldq / ldk / ldv); may be null
+  bf16_t *dqh, *dkh, *dvh;        // optional bf16 gradients (the operand of the projections' backward GEMMs)
+  float *dbq, *dbk, *dbv;         // optional: projection bias gradients += column sums (head h at + h * DH)
 };
+
+// store a [d][col] accumulator tile set as row `col`: fp32 and/or bf16, and add its column sums (over the
+// wave's 16 rows, rows >= limit excluded by `on`) to a bias gradient
+template <int DT>
+__device__ __forceinline__ void store_grad(const f32x4 (&t)[DT], float scale, bool on, float* fp, bf16_t* hp,
+                                           float* db, int lane) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int d = 0; d < DT; ++d) {
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = on ? t[d][r] * scale : 0.f;
+    if (on) {
+      if (fp) *reinterpret_cast<float4*>(fp + 16 * d + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+      if (hp) *reinterpret_cast<uint2*>(hp + 16 * d + 4 * g) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+    }
+    if (db) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float c = v[r];
+        c += __shfl_xor(c, 1); c += __shfl_xor(c, 2); c += __shfl_xor(c, 4); c += __shfl_xor(c, 8);
+        if ((lane & 15) == 0) atomicAdd(db + 16 * d + 4 * g + r, c);
+      }
+    }
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // forward: grid (ceil(T / 64), B * H); 4 waves x 16 queries; key tiles of 32
@@ -330,15 +358,14 @@ __global__ __launch_bounds__(64 * NW) void flash_bwd_kv_kernel(AttnArgs a) {
       dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Img<DH>::tr_frag(q_tr, d, lane), sf, dk[d], 0, 0, 0);
     }
   }
-  if (ki < a.S) {
-    float* dkp = a.dk + ((long)b * a.S + ki) * a.ldk + h * DH;
-    float* dvp = a.dv + ((long)b * a.S + ki) * a.ldv + h * DH;
-#pragma unroll
-    for (int d = 0; d < DT; ++d) {
-      *reinterpret_cast<float4*>(dkp + 16 * d + 4 * g) =
-          make_float4(dk[d][0] * a.scale, dk[d][1] * a.scale, dk[d][2] * a.scale, dk[d][3] * a.scale);
-      *reinterpret_cast<float4*>(dvp + 16 * d + 4 * g) = make_float4(dv[d][0], dv[d][1], dv[d][2], dv[d][3]);
-    }
+  {
+    const bool on = ki < a.S;
+    const long ko = ((long)b * a.S + min(ki, a.S - 1)) * a.ldk + h * DH;
+    const long vo = ((long)b * a.S + min(ki, a.S - 1)) * a.ldv + h * DH;
+    store_grad<DT>(dk, a.scale, on, a.dk ? a.dk + ko : nullptr, a.dkh ? a.dkh + ko : nullptr,
+                   a.dbk ? a.dbk + h * DH : nullptr, lane);
+    store_grad<DT>(dv, 1.f, on, a.dv ? a.dv + vo : nullptr, a.dvh ? a.dvh + vo : nullptr,
+                   a.dbv ? a.dbv + h * DH : nullptr, lane);
   }
 }
 
@@ -421,12 +448,10 @@ __global__ __launch_bounds__(64 * NW) void flash_bwd_q_kernel(AttnArgs a) {
     for (int d = 0; d < DT; ++d)
       dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Img<DH>::tr_frag(k_tr, d, lane), sf, dq[d], 0, 0, 0);
   }
-  if (q_ok) {
-    float* dqp = a.dq + ((long)b * a.T + qi) * a.ldq + h * DH;
-#pragma unroll
-    for (int d = 0; d < DT; ++d)
-      *reinterpret_cast<float4*>(dqp + 16 * d + 4 * g) =
-          make_float4(dq[d][0] * a.scale, dq[d][1] * a.scale, dq[d][2] * a.scale, dq[d][3] * a.scale);
+  {
+    const long qo = ((long)b * a.T + min(qi, a.T - 1)) * a.ldq + h * DH;
+    store_grad<DT>(dq, a.scale, q_ok, a.dq ? a.dq + qo : nullptr, a.dqh ? a.dqh + qo : nullptr,
+                   a.dbq ? a.dbq + h * DH : nullptr, lane);
   }
 }
 
@@ -452,6 +477,7 @@ AttnArgs to_args(const s2st_attn_args& p) {
   a.B = p.B; a.H = p.H; a.T = p.T; a.S = p.S; a.causal = p.causal;
   a.scale = p.scale; a.drop_p = p.drop_p; a.seed = p.seed; a.ld_drop = p.ld_drop;
   a.doh = p.doh; a.dq = p.dq; a.dk = p.dk; a.dv = p.dv;
+  a.dqh = p.dqh; a.dkh = p.dkh; a.dvh = p.dvh; a.dbq = p.dbq; a.dbk = p.dbk; a.dbv = p.dbv;
   return a;
 }
 
@@ -497,7 +523,7 @@ int s2st_flash_attn_fwd(const s2st_attn_args* p, hipStream_t st) {
 // dO (fp32, for D) + its bf16 copy; o / lse from the forward; writes dq, dk, dv (fp32, overwrite)
 // phase 0: everything; 1: only the D vector; 2: only dK,dV; 3: only dQ (the caller may overlap 2 and 3)
 int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_scratch, hipStream_t st, int phase) {
-  if (!p || !attn_args_ok(*p) || !p->doh || !dO || !dvec_scratch || !p->dq || !p->dk || !p->dv || !p->lse || !p->o)
+  if (!p || !attn_args_ok(*p) || !p->doh || !dO || !dvec_scratch || (!p->dq && !p->dqh) || (!p->dk && !p->dkh) || (!p->dv && !p->dvh) || !p->lse || !p->o)
     return S2ST_ERR_ARG;
   AttnArgs a = to_args(*p);
   a.dvec = dvec_scratch;

@@ -49,6 +49,7 @@ struct Ten {  // plain [rows][cols] fp32 activation
   int act_mode = 0;
   float act_p = 0.f;
   long act_bias = -1;
+  bool lin_plain = false;  // output of a bias-only linear (no activation / dropout / residual): its gradient IS the GEMM operand
   bf16raw* gpre_h = nullptr;
   long n() const { return (long)rows * cols; }
   int hld() const { return (cols + 7) & ~7; }
@@ -114,6 +115,8 @@ struct s2st_engine {
     return dec_st.base + (long)c.dec_layers * 2 * dec_st.B * dec_st.maxT * c.dec_dim + (long)l * dec_st.B * dec_st.E * 2 * c.dec_dim;
   }
   bool use_only_h = true;  // S2ST_NO_ONLY_H=1: always keep the fp32 copy of GEMM-only tensors (A/B switch)
+  bool use_attn_gfuse = false;  // S2ST_ATTN_GFUSE=1: attention backward emits bf16 projection gradients directly
+                                // (measured: no gain over the fused cast + column-sum kernel, so off)
   bool use_act_fuse = true;  // S2ST_NO_ACT_FUSE=1: separate ReLU-dropout backward kernel (A/B switch)
   bool use_flash = true;  // S2ST_NO_FLASH=1: unfused attention everywhere (A/B switch)
   int ffn_act = 1;        // 1 relu (s2st layers), 2 gelu (HuBERT layers)
@@ -389,6 +392,7 @@ struct s2st_engine {
     const bf16raw* xh = fm ? half_of(x) : nullptr;
     if (fm && N % 8 == 0) y->h = alloc_h(y->n());
     if (fm && act == 1 && y->h && !resid) { y->act_mode = 1; y->act_p = drop_p; y->act_bias = b; }
+    if (fm && act == 0 && drop_p == 0.f && !resid && y->h) { y->lin_plain = true; y->act_bias = b; }
     if (live()) {
       GemmArgs g{};
       g.A = fm ? gemm_rowmajor(xh, x->hld()) : gemm_rowmajor(x->d, x->cols);
@@ -545,18 +549,42 @@ struct s2st_engine {
       AttnIO io3 = io;
       tape.push_back([=]() {
         if (!o->g) return;
-        bool aq, ak, av;
-        float* gq = gradbuf(io3.qt, aq);
-        float* gk = gradbuf(io3.kt, ak);
-        float* gv = gradbuf(io3.vt, av);
-        (void)aq; (void)ak; (void)av;  // disjoint column blocks, each written exactly once
         float* dvec = alloc((long)B * H * T);
         s2st_attn_args fb = fa;
         fb.doh = ghalf_of(o);
-        fb.dq = gq + io3.qoff; fb.dk = gk + io3.koff; fb.dv = gv + io3.voff;
+        // q / k / v are column blocks of plain projections: their gradients are only ever read as bf16
+        // GEMM operands (+ bias column sums), so the kernels emit exactly that and no fp32 gradient
+        const bool gf = use_attn_gfuse && io3.qt->lin_plain && io3.kt->lin_plain && io3.vt->lin_plain &&
+                        !io3.qt->g && !io3.kt->g && !io3.vt->g;
+        if (gf) {
+          for (Ten* t : {io3.qt, io3.kt, io3.vt})
+            if (!t->gpre_h) t->gpre_h = alloc_h(t->n());
+          fb.dqh = io3.qt->gpre_h + io3.qoff; fb.dkh = io3.kt->gpre_h + io3.koff; fb.dvh = io3.vt->gpre_h + io3.voff;
+        } else {
+          bool aq, ak, av;
+          float* gq = gradbuf(io3.qt, aq);
+          float* gk = gradbuf(io3.kt, ak);
+          float* gv = gradbuf(io3.vt, av);
+          (void)aq; (void)ak; (void)av;  // disjoint column blocks, each written exactly once
+          fb.dq = gq + io3.qoff; fb.dk = gk + io3.koff; fb.dv = gv + io3.voff;
+        }
         // (dK,dV and dQ are independent, but joining the second stream here would also wait for its
         // backlog of weight-gradient GEMMs: measured slower, so both stay on the data-path stream)
         if (live()) chk(s2st_flash_attn_bwd(&fb, o->g, dvec, st_));
+        if (gf && live()) {
+          // projection bias gradients = column sums of the bf16 gradients: parameter gradients only, so
+          // on the second stream (atomics from inside the attention kernels contend on H*dh addresses)
+          hipStream_t bs = fork_side();
+          Ten* seen[3] = {nullptr, nullptr, nullptr};
+          int ns = 0;
+          for (Ten* t : {io3.qt, io3.kt, io3.vt}) {
+            bool dup = false;
+            for (int i = 0; i < ns; ++i) dup = dup || seen[i] == t;
+            if (dup || t->act_bias < 0) continue;
+            seen[ns++] = t;
+            chk(s2st_colsum_bf16(t->gpre_h, t->cols, t->rows, t->cols, G + t->act_bias, bs));
+          }
+        }
       });
       return o;
     }
@@ -1336,6 +1364,7 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->use_flash = !(getenv("S2ST_NO_FLASH") && atoi(getenv("S2ST_NO_FLASH")) != 0);
   e->use_act_fuse = !(getenv("S2ST_NO_ACT_FUSE") && atoi(getenv("S2ST_NO_ACT_FUSE")) != 0);
   e->use_only_h = !(getenv("S2ST_NO_ONLY_H") && atoi(getenv("S2ST_NO_ONLY_H")) != 0);
+  e->use_attn_gfuse = getenv("S2ST_ATTN_GFUSE") && atoi(getenv("S2ST_ATTN_GFUSE")) != 0;
   e->build_params();
   if (!cfg->precise && (s2st_gemm_bf16_preload(nullptr) != 0 || s2st_flash_attn_preload(nullptr) != 0)) { delete e; return S2ST_ERR_LAUNCH; }
   if (!cfg->precise && !(getenv("S2ST_NO_SIDE_STREAM") && atoi(getenv("S2ST_NO_SIDE_STREAM")))) {

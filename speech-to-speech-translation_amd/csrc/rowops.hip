@@ -308,6 +308,36 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   if (ty == 0 && c < cols) atomicAdd(&out[c], red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
 }
 
+// out[c] += sum_r bf16 x[r][c]: 4 columns per lane (8-byte loads), 4 waves over the rows of a slab
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __restrict__ x, long ld, int rows,
+                                                          int cols, float* __restrict__ out, int rows_per_block) {
+  __shared__ float red[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < cols)
+    for (int rb = r0 + wave; rb < r1; rb += 16) {  // 4 rows per pass, loads first (latency-bound otherwise)
+      uint2 q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = rb + 4 * u;
+        q[u] = r < r1 ? *reinterpret_cast<const uint2*>(x + (long)r * ld + c) : make_uint2(0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a0 += __uint_as_float(q[u].x << 16); a1 += __uint_as_float(q[u].x & 0xffff0000u);
+        a2 += __uint_as_float(q[u].y << 16); a3 += __uint_as_float(q[u].y & 0xffff0000u);
+      }
+    }
+  red[wave][lane * 4 + 0] = a0; red[wave][lane * 4 + 1] = a1;
+  red[wave][lane * 4 + 2] = a2; red[wave][lane * 4 + 3] = a3;
+  __syncthreads();
+  const int cc = blockIdx.x * 256 + threadIdx.x;
+  if (cc < cols)
+    atomicAdd(out + cc, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 __global__ __launch_bounds__(256) void headmean_kernel(const float* __restrict__ p,
                                                        float* __restrict__ out, int B, int H, int T,
                                                        int S, int ld) {
@@ -392,6 +422,18 @@ int s2st_colsum(const float* x, long ld, int rows, int cols, float* out, int acc
   if (rpb < 16) rpb = 16;
   slabs = (rows + rpb - 1) / rpb;
   hipLaunchKernelGGL(colsum_kernel, dim3(cb, slabs), dim3(256), 0, st, x, ld, rows, cols, out, rpb);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+
+int s2st_colsum_bf16(const uint16_t* x, long ld, int rows, int cols, float* out, hipStream_t st) {
+  if (rows <= 0 || cols <= 0) return 0;
+  if (cols % 4 || ld % 4 || ((uintptr_t)x % 8)) return S2ST_ERR_SHAPE;
+  const int cb = (cols + 255) / 256;
+  int slabs = (1024 + cb - 1) / cb;
+  int rpb = (rows + slabs - 1) / slabs;
+  if (rpb < 16) rpb = 16;
+  slabs = (rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cb, slabs), dim3(256), 0, st, x, ld, rows, cols, out, rpb);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 

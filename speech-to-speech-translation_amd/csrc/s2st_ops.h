@@ -83,6 +83,8 @@ int s2st_softmax_bwd(const float* p, const float* dpd, float* ds, int B, int H, 
 // column sums: out[c] (+)= sum_r x[r][c]   (bias gradients)
 int s2st_colsum(const float* x, long ld, int rows, int cols, float* out, int accumulate,
                 hipStream_t st);
+// out[c] += sum_r x[r][c] for a bf16 matrix (bias gradients of projections whose output gradient only exists in bf16)
+int s2st_colsum_bf16(const uint16_t* x, long ld, int rows, int cols, float* out, hipStream_t st);
 // mean over heads of attention probabilities: out[b][s][t] = mean_h p[b][h][t][s]
 int s2st_attn_headmean(const float* p, float* out, int B, int H, int T, int S, int ld,
                        hipStream_t st);

@@ -158,10 +158,12 @@ class AttnArgs(C.Structure):
                 ("ldv", C.c_int64), ("o", C.c_void_p), ("oh", C.c_void_p), ("lse", C.c_void_p), ("klen", C.c_void_p),
                 ("B", C.c_int32), ("H", C.c_int32), ("T", C.c_int32), ("S", C.c_int32), ("dh", C.c_int32),
                 ("causal", C.c_int32), ("scale", C.c_float), ("drop_p", C.c_float), ("seed", C.c_uint64),
-                ("ld_drop", C.c_int32), ("doh", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p)]
+                ("ld_drop", C.c_int32), ("doh", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p),
+                ("dqh", C.c_void_p), ("dkh", C.c_void_p), ("dvh", C.c_void_p), ("dbq", C.c_void_p), ("dbk", C.c_void_p),
+                ("dbv", C.c_void_p)]
 
 
-def flash_attention(q, k, v, H, *, klen=None, causal=False, scale=None, drop_p=0.0, seed=0, dO=None):
+def flash_attention(q, k, v, H, *, klen=None, causal=False, scale=None, drop_p=0.0, seed=0, dO=None, bf16_grads=False):
     """Fused attention on bf16 [B, T, H*dh] / [B, S, H*dh] projections (s2st_flash_attn_*_bf16).
     Returns (o fp32, lse) and, when dO (fp32 [B, T, H*dh]) is given, also (dq, dk, dv) fp32."""
     require_device(q)
@@ -185,9 +187,17 @@ def flash_attention(q, k, v, H, *, klen=None, causal=False, scale=None, drop_p=0
     dq, dk, dv = (torch.zeros_like(x, dtype=torch.float32) for x in (q, k, v))
     scratch = torch.zeros(B * H * T, dtype=torch.float32, device=q.device)
     a.doh, a.dq, a.dk, a.dv = doh.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    extra = None
+    if bf16_grads:  # also the bf16 copies + bias-gradient column sums
+        extra = [torch.zeros_like(x, dtype=torch.bfloat16) for x in (q, k, v)] + \
+                [torch.zeros(Cm, dtype=torch.float32, device=q.device) for _ in range(3)]
+        a.dqh, a.dkh, a.dvh = (t.data_ptr() for t in extra[:3])
+        a.dbq, a.dbk, a.dbv = (t.data_ptr() for t in extra[3:])
     lib().s2st_flash_attn_bwd_bf16.argtypes = [C.POINTER(AttnArgs), C.c_void_p, C.c_void_p, C.c_void_p]
     check(lib().s2st_flash_attn_bwd_bf16(C.byref(a), dO.data_ptr(), scratch.data_ptr(), C.c_void_p(stream_ptr())),
           "s2st_flash_attn_bwd_bf16")
+    if extra is not None:
+        return o, lse.view(B, H, T), dq, dk, dv, extra
     return o, lse.view(B, H, T), dq, dk, dv
 
 

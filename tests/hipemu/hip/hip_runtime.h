@@ -107,6 +107,7 @@ static inline double atomicAdd(double* p, double v) {
 }
 
 // ---- math ----------------------------------------------------------------------------------
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __fdividef(float a, float b) { return a / b; }
 #define __expf(x) expf(x)

@@ -56,6 +56,14 @@ def test_flash_attention_fwd_bwd(backend, dh, H, causal):
     assert rel(dq, rq) < 2e-2 and rel(dk, rk) < 2e-2 and rel(dv, rv) < 2e-2
     # keys beyond klen get no gradient
     assert float(dk[1, S - 9:].abs().max()) == 0.0 and float(dv[1, S - 9:].abs().max()) == 0.0
+    # bf16 gradient copies + fused bias-gradient column sums
+    _, _, dq2, dk2, dv2, (dqh, dkh, dvh, dbq, dbk, dbv) = backend.bd.flash_attention(
+        q.to(d), k.to(d), v.to(d), H, klen=klen.to(d), causal=causal, dO=dO.to(d), bf16_grads=True)
+    backend.sync()
+    for full, half, db in ((dq2, dqh, dbq), (dk2, dkh, dbk), (dv2, dvh, dbv)):
+        assert torch.equal(half.cpu(), full.cpu().to(torch.bfloat16))
+        ref_db = full.cpu().double().sum(dim=(0, 1))
+        assert float((db.cpu().double() - ref_db).abs().max()) < 1e-4 * float(ref_db.abs().max() + 1e-6)
 
 
 def test_flash_attention_dropout_matches_unfused_mask(backend):
