@@ -191,6 +191,20 @@ def main():
         th1 = time.perf_counter() - th
         torch.cuda.synchronize()
         vlog('single step: host enqueue %.2f ms, until GPU done %.2f ms' % (th1 * 1e3, (time.perf_counter() - th) * 1e3))
+        # forward / backward / optimizer split of one step on the caller's stream (un-profiled)
+        eng_ = trainer.engine
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        eng_.zero_grad()
+        ev[0].record()
+        eng_.forward(prepared[args.warmup - 1], training=True, with_loss=True)
+        ev[1].record()
+        eng_.backward(1.0)
+        ev[2].record()
+        step(args.warmup - 1)
+        ev[3].record()
+        torch.cuda.synchronize()
+        vlog('GPU time on the data-path stream: forward %.2f ms, backward %.2f ms, (next full step %.2f ms)' % (
+            ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3])))
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()

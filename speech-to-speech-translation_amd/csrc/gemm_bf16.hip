@@ -623,6 +623,7 @@ int s2st_gemm_bf16_preload(hipStream_t st) {
     rc |= launch_dma<128, 64, 4, 8>(g, grid, st);
     rc |= launch_dma<128, 64, 4, 4>(g, grid, st);
     rc |= launch_dma<64, 64, 4, 4>(g, grid, st);
+    rc |= launch_dma<64, 128, 3, 4>(g, grid, st);
   }
   return rc || hipGetLastError() != hipSuccess ? -1 : 0;
 }
@@ -655,6 +656,17 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
       // split-K candidates fill the chip anyway: cost by work / efficiency only
       double cost = (double)rounds * c.bm * c.bn / c.eff;
       if (cost < best) { best = cost; bm = c.bm; bn = c.bn; }
+    }
+  }
+  // under-filled launches (fewer 128x128 tiles than ~3/4 of the CUs, e.g. M ~ 4k tokens x N = 512): halve the
+  // tile rows -> twice the workgroups at 2 per CU (3-stage ring, 72 KB) so the whole chip works
+  static const int half_m = getenv("S2ST_GEMM_HALFM") ? atoi(getenv("S2ST_GEMM_HALFM")) : 0;
+  bool use_half_m = false;
+  if (vec && half_m && bm == 128 && bn == 128 && (g.A.kmajor || g.A.sp.per <= 0) && (g.B.kmajor || g.B.sp.per <= 0) &&
+      !(getenv("S2ST_GEMM_DMA") && atoi(getenv("S2ST_GEMM_DMA")) == 0)) {
+    const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch;
+    if (t128 < 200 && g.M >= 256 && !(g.ep.accumulate && !g.ep.act && g.ep.drop_p == 0.f && !g.ep.mask_y && g.K >= 8 * BK)) {
+      bm = 64; bn = 128; use_half_m = true;
     }
   }
   if (vec) {  // tuning aid: S2ST_GEMM_TILE=128x128|128x64|64x64 forces the tile
@@ -699,7 +711,8 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
     int rc;
     static const int nw8 = getenv("S2ST_GEMM_NW8") ? atoi(getenv("S2ST_GEMM_NW8")) : 1;
     static const int ns = getenv("S2ST_GEMM_NS") ? atoi(getenv("S2ST_GEMM_NS")) : 4;  // tuning aid (128x128 only)
-    if (bm == 128 && bn == 128 && nw8 && ns == 3) rc = launch_dma<128, 128, 3, 8>(g, grid, st);
+    if (bm == 64 && bn == 128) rc = launch_dma<64, 128, 3, 4>(g, grid, st);
+    else if (bm == 128 && bn == 128 && nw8 && ns == 3) rc = launch_dma<128, 128, 3, 8>(g, grid, st);
     else if (bm == 128 && bn == 128 && nw8 && ns == 5) rc = launch_dma<128, 128, 5, 8>(g, grid, st);
     else if (bm == 128 && bn == 128) rc = nw8 ? launch_dma<128, 128, 4, 8>(g, grid, st) : launch_dma<128, 128, 4, 4>(g, grid, st);
     else if (bm == 128) rc = nw8 ? launch_dma<128, 64, 4, 8>(g, grid, st) : launch_dma<128, 64, 4, 4>(g, grid, st);
