@@ -284,3 +284,23 @@ def test_micro_engine_fused_attention_vs_oracle(backend):
     c = D.SyntheticFisherCorpus(n_utts=4, seed=3, max_src=64, median_src=50, min_src=30)
     s = c.collate_batch(range(4))
     check_against_oracle(backend, e, m, s, out_tol=2e-2, grad_tol=0.35, loss_tol=1e-3, global_grad_tol=0.1)
+
+
+@pytest.mark.parametrize("precise", [True, False], ids=["bf16x3", "bf16"])
+def test_ragged_and_minimal_batches(backend, precise):
+    """Edge geometries through the whole path: a single shortest-allowed utterance (encoder length 10,
+    one or two decoder steps' worth of frames), and a ragged batch of 3 (not a multiple of 8) whose
+    lengths differ by 3x -- padded rows, key masks and BatchNorm-over-padding must all match the oracle."""
+    D = importlib.import_module(DATA)
+    cfg = dict(MICRO, encoder_embed_dim=128, decoder_embed_dim=128, encoder_attention_heads=2,
+               decoder_attention_heads=2) if not precise else MICRO
+    a, e = make_engine(backend, cfg, precise=precise)
+    _, m = make_oracle(cfg)
+    c1 = D.SyntheticFisherCorpus(n_utts=2, seed=5, max_src=41, median_src=40, min_src=40)
+    c2 = D.SyntheticFisherCorpus(n_utts=6, seed=6, max_src=130, median_src=70, min_src=40)
+    tol = dict(out_tol=2e-4, grad_tol=3e-3, loss_tol=3e-5) if precise else \
+        dict(out_tol=6e-2, grad_tol=0.5, loss_tol=2e-3, global_grad_tol=0.2)  # BatchNorm statistics over 5 rows
+    # (the single-utterance batch) amplify the bf16 operand rounding; the bf16x3 leg pins the arithmetic
+    for s in (c1.collate_batch([0]), c2.collate_batch([0, 3, 5])):
+        m.zero_grad()
+        check_against_oracle(backend, e, m, s, **tol)
