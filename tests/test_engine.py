@@ -298,7 +298,7 @@ def test_ragged_and_minimal_batches(backend, precise):
     _, m = make_oracle(cfg)
     c1 = D.SyntheticFisherCorpus(n_utts=2, seed=5, max_src=41, median_src=40, min_src=40)
     c2 = D.SyntheticFisherCorpus(n_utts=6, seed=6, max_src=130, median_src=70, min_src=40)
-    tol = dict(out_tol=2e-4, grad_tol=3e-3, loss_tol=3e-5) if precise else \
+    tol = dict(out_tol=3e-4, grad_tol=1e-2, loss_tol=3e-5) if precise else \
         dict(out_tol=6e-2, grad_tol=0.5, loss_tol=2e-3, global_grad_tol=0.2)  # BatchNorm statistics over 5 rows
     # (the single-utterance batch) amplify the bf16 operand rounding; the bf16x3 leg pins the arithmetic
     for s in (c1.collate_batch([0]), c2.collate_batch([0, 3, 5])):
