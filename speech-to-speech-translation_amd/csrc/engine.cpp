@@ -1035,16 +1035,13 @@ struct s2st_engine {
     int Tin = (N - hc.conv_k[0]) / hc.conv_stride[0] + 1;
     if (N < hc.conv_k[0] || Tin <= 0) return S2ST_ERR_SHAPE;
     Ten* a = newT(B * Tin, C0);
-    float* mean = alloc((long)B * C0);
-    float* var = alloc((long)B * C0);
-    float* tmp = alloc(2L * C0);
+    float* csum = alloc((long)B * C0);
+    float* sq = alloc((long)B * C0);
     if (fm) a->h = alloc_h(a->n());
     if (live()) {
-      chk(s2st_hubert_conv0(wave, P + hp.conv_w[0], a->d, B, N, Tin, C0, hc.conv_k[0], hc.conv_stride[0], st_));
-      for (int b = 0; b < B; ++b)
-        chk(s2st_bn_stats(a->d + (long)b * Tin * C0, Tin, C0, mean + (long)b * C0, var + (long)b * C0, nullptr, nullptr,
-                          0.f, tmp, st_));
-      chk(s2st_gn_gelu(a->d, mean, var, P + hp.gn_g, P + hp.gn_b, a->h, B, Tin, C0, 1e-5f, st_));
+      chk(s2st_hubert_conv0(wave, P + hp.conv_w[0], a->d, csum, B, N, Tin, C0, hc.conv_k[0], hc.conv_stride[0], st_));
+      // fast mode: conv1 only reads the bf16 copy, the fp32 activation is not rewritten
+      chk(s2st_gn_gelu(a->d, csum, sq, P + hp.gn_g, P + hp.gn_b, a->h, B, Tin, C0, 1e-5f, fm ? 0 : 1, st_));
     }
     // conv_i + GELU as GEMMs over the channel-last activations (no padding: windows never cross utterances)
     for (int i = 1; i < hc.n_conv; ++i) {

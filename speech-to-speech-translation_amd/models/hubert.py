@@ -175,7 +175,10 @@ class HubertFrontend:
         if not bool(((~fpm).long().cumsum(1)[:, -1:] == (~fpm).long().sum(1, keepdim=True)).all()) or \
                 bool((fpm[:, :-1] & ~fpm[:, 1:]).any()):
             raise ValueError("padding must be a suffix of every utterance")
-        lens = (~fpm).sum(1).to(torch.int32).to(self.device)
+        # pinned + non-blocking: a pageable H2D copy would synchronise with everything already queued
+        lens = (~fpm).sum(1).to(torch.int32)
+        if self.device.type == "cuda":
+            lens = lens.pin_memory().to(self.device, non_blocking=True)
         key = (B, N)
         if key not in self._plan:
             n = int(self.lib.s2st_hubert_workspace_floats(self.h, B, N))
@@ -190,4 +193,6 @@ class HubertFrontend:
                                               self.workspace.data_ptr(), self.workspace.numel(),
                                               C.c_void_p(bd.stream_ptr())), "s2st_hubert_forward")
         self._keep = (wave, lens)
-        return out, fpm.to(self.device)
+        if self.device.type == "cuda":
+            return out, fpm.pin_memory().to(self.device, non_blocking=True)
+        return out, fpm

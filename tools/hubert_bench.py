@@ -16,14 +16,19 @@ for precise in (False, True):
     f.load_state_dict(HO.synth_state(HO.BASE))
     wave, pad, _ = HO.synth_audio(B, N, 3)
     wave, pad = wave.to(dev), pad
-    for _ in range(2):
+    for _ in range(6):
         f.extract_features(wave, pad)
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); f.extract_features(wave, pad); e1.record(); torch.cuda.synchronize()
+    print(f"   GPU time of one call (events): {e0.elapsed_time(e1):.1f} ms")
     t = time.perf_counter()
-    it = 3
+    it = 10
     for _ in range(it):
         y, _ = f.extract_features(wave, pad)
+    th = (time.perf_counter() - t) / it
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / it
+    print(f"   host enqueue {th*1e3:.1f} ms per call")
     gmac = 7.2e9 * B * secs  # ~7.2 GMAC per second of audio, forward only
     print(f"precise={precise} B={B} {secs}s audio: {dt*1e3:.1f} ms  -> {B*secs/dt:.0f} audio-s/s, ~{2*gmac/dt/1e12:.1f} TFLOP/s", flush=True)
