@@ -148,6 +148,31 @@ class HubertFrontend:
         return out
 
     # -- forward --------------------------------------------------------------------------------------
+    def _to_device_async(self, t: torch.Tensor) -> torch.Tensor:
+        """Small host tensor -> device without stalling the queue: a pageable H2D copy synchronises with
+        everything already enqueued, and a fresh pin_memory() per call makes the caching host allocator
+        grow (its blocks are still in flight).  A ring of reusable pinned staging buffers, each guarded by
+        the event of its last copy, does neither."""
+        if self.device.type != "cuda":
+            return t
+        ring = self.__dict__.setdefault("_pin_ring", {})
+        key = (t.dtype, tuple(t.shape))
+        slots = ring.setdefault(key, {"i": 0, "bufs": []})
+        if len(slots["bufs"]) < 8:
+            slots["bufs"].append([torch.empty(t.shape, dtype=t.dtype).pin_memory(), None])
+            buf = slots["bufs"][-1]
+        else:
+            buf = slots["bufs"][slots["i"] % 8]
+            slots["i"] += 1
+            if buf[1] is not None:
+                buf[1].synchronize()  # only waits if 8 later copies are still behind this one
+        buf[0].copy_(t)
+        out = buf[0].to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        buf[1] = ev
+        return out
+
     def out_frames(self, n_samples: int) -> int:
         return int(self.lib.s2st_hubert_out_frames(self.h, n_samples))
 
@@ -175,10 +200,7 @@ class HubertFrontend:
         if not bool(((~fpm).long().cumsum(1)[:, -1:] == (~fpm).long().sum(1, keepdim=True)).all()) or \
                 bool((fpm[:, :-1] & ~fpm[:, 1:]).any()):
             raise ValueError("padding must be a suffix of every utterance")
-        # pinned + non-blocking: a pageable H2D copy would synchronise with everything already queued
-        lens = (~fpm).sum(1).to(torch.int32)
-        if self.device.type == "cuda":
-            lens = lens.pin_memory().to(self.device, non_blocking=True)
+        lens = self._to_device_async((~fpm).sum(1).to(torch.int32))
         key = (B, N)
         if key not in self._plan:
             n = int(self.lib.s2st_hubert_workspace_floats(self.h, B, N))
@@ -193,6 +215,4 @@ class HubertFrontend:
                                               self.workspace.data_ptr(), self.workspace.numel(),
                                               C.c_void_p(bd.stream_ptr())), "s2st_hubert_forward")
         self._keep = (wave, lens)
-        if self.device.type == "cuda":
-            return out, fpm.pin_memory().to(self.device, non_blocking=True)
-        return out, fpm
+        return out, self._to_device_async(fpm)
