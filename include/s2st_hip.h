@@ -338,6 +338,16 @@ int s2st_gl_project_f32(const float* mag, const float* Y, float* X, int32_t F, i
 int s2st_reflect_pad_f32(const float* x, float* y, int32_t n, int32_t pad, void* stream);
 int s2st_gl_overlap_add_f32(const float* frames, const float* wsq, float* wave, int32_t T, int32_t n_fft, int32_t hop, int32_t n_out, void* stream);
 
+/* Batched Griffin-Lim on the bf16 matrix cores (vocoder.py:100-123 for every utterance of a batch at once):
+ * U utterances of tl[u] <= Tmax frames, rows r = u * Tmax + t.  fp32 rows are stored for the GEMM as bf16
+ * [hi | lo | hi] (3 K) against constant bases [hi | hi | lo], i.e. the bf16x3 split folded into the
+ * contraction.  Spectra: [rows][re(F) pad | im(F) pad], halves Fp apart (Fp % 4 == 0).
+ *   polar_split: Xs = split(mag * exp(i a)), a = aux[rows][F] (from_spectrum 0) or angle(aux[rows][2 Fp]) (1)
+ *   frame_split: As[rows][3][n_fft] = split(frames of the reflect-padded waves [U][Lw]) */
+int s2st_gl_polar_split_f32(const float* mag, const float* aux, int32_t from_spectrum, const int32_t* tl, void* Xs, int32_t U, int32_t F, int32_t Fp, int32_t Tmax, void* stream);
+int s2st_gl_frame_split_f32(const float* wave, const int32_t* tl, void* As, int32_t U, int32_t Tmax, int32_t hop, int32_t n_fft, int32_t Lw, void* stream);
+int s2st_gl_overlap_add_b_f32(const float* frames, const float* wsq_all, const int64_t* wsq_off, const int32_t* tl, float* wave, int32_t U, int32_t Tmax, int32_t n_fft, int32_t hop, int32_t Lw, void* stream);
+
 /* MCD evaluation (examples/s2s_trans/tasks/s2s_translation.py:414-552): batched DTW over the padded
  * [B][M][N] distance tensor (shapes [B][2] = (m, n) per element, or NULL), RMS feature distance, MFCC glue */
 int s2st_dtw_f32(const float* dist, const int32_t* shapes, int32_t B, int32_t M, int32_t N, float* cumdist, int32_t* backptr, int32_t* pathmap, void* stream);

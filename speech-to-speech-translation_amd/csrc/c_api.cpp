@@ -156,6 +156,16 @@ int s2st_rms_dist_f32(const float* x1, const float* x2, float* out, int32_t m, i
 int s2st_power_spec_f32(const float* Y, float* P, int32_t T, int32_t F, void* stream) { return s2st_power_spec(Y, P, T, F, (hipStream_t)stream); }
 int s2st_log_offset_f32(float* x, int64_t n, float eps, void* stream) { return s2st_log_offset(x, n, eps, (hipStream_t)stream); }
 
+int s2st_gl_polar_split_f32(const float* mag, const float* aux, int32_t from_spectrum, const int32_t* tl, void* Xs, int32_t U, int32_t F, int32_t Fp, int32_t Tmax, void* stream) {
+  return s2st_gl_polar_split(mag, aux, from_spectrum, tl, (uint16_t*)Xs, U, F, Fp, Tmax, (hipStream_t)stream);
+}
+int s2st_gl_frame_split_f32(const float* wave, const int32_t* tl, void* As, int32_t U, int32_t Tmax, int32_t hop, int32_t n_fft, int32_t Lw, void* stream) {
+  return s2st_gl_frame_split(wave, tl, (uint16_t*)As, U, Tmax, hop, n_fft, Lw, (hipStream_t)stream);
+}
+int s2st_gl_overlap_add_b_f32(const float* frames, const float* wsq_all, const int64_t* wsq_off, const int32_t* tl, float* wave, int32_t U, int32_t Tmax, int32_t n_fft, int32_t hop, int32_t Lw, void* stream) {
+  return s2st_gl_overlap_add_b(frames, wsq_all, (const long*)wsq_off, tl, wave, U, Tmax, n_fft, hop, Lw, (hipStream_t)stream);
+}
+
 int s2st_profile_gemm(int32_t enable) { s2st_gemm_profile_enable(enable); return 0; }
 int s2st_profile_gemm_read(double* flops, double* ms, int64_t* launches) {
   long n = 0;

@@ -35,25 +35,43 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
                                                           int H, int dh, float scale, float* __restrict__ o, long ldo,
                                                           float* __restrict__ attn_mean, int S) {
   __shared__ float p[DA_MAXS];
-  __shared__ float qs[256];
+  __shared__ __attribute__((aligned(16))) float qs[256];
   __shared__ float red[4];
-  __shared__ float part[256];
+  __shared__ __attribute__((aligned(16))) float part[16 * 256];
   const int b = blockIdx.x / H, h = blockIdx.x - b * H, tid = threadIdx.x;
   const int n = klen ? min((int)klen[b], nkeys) : nkeys;
   if (tid < dh) qs[tid] = q[(long)b * ldq + h * dh + tid] * scale;
   __syncthreads();
   const float* kb = kc + (long)b * kbs + h * dh;
   const float* vb = vc + (long)b * kbs + h * dh;
+  // 16 lanes per key, one float4 each: a 64-wide head row is one coalesced 256-byte read; 16 keys per pass
+  const int g = tid >> 4, l4 = (tid & 15) * 4;
+  // (4 keys per thread and pass, loads clamped instead of predicated so that they issue back to back:
+  // the kernel is a chain of memory latencies otherwise)
   float mx = -INFINITY;
-  for (int s = tid; s < n; s += 256) {
-    const float* kr = kb + (long)s * ldk;
-    float a = 0.f;
-    for (int d = 0; d < dh; d += 4) {
-      const float4 kv = *reinterpret_cast<const float4*>(kr + d);
-      a += qs[d] * kv.x + qs[d + 1] * kv.y + qs[d + 2] * kv.z + qs[d + 3] * kv.w;
+  for (int s0 = 0; s0 < n; s0 += 64) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int d = l4; d < dh; d += 64) {
+      float4 kv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) kv[i] = *reinterpret_cast<const float4*>(kb + (long)min(s0 + g + 16 * i, n - 1) * ldk + d);
+      const float4 qv = *reinterpret_cast<const float4*>(qs + d);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] += qv.x * kv[i].x + qv.y * kv[i].y + qv.z * kv[i].z + qv.w * kv[i].w;
     }
-    p[s] = a;
-    mx = fmaxf(mx, a);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = a[i];
+      v += __shfl_xor(v, 8);
+      v += __shfl_xor(v, 4);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 1);
+      const int s = s0 + g + 16 * i;
+      if (s < n) {
+        if (l4 == 0) p[s] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
   }
   mx = block_max(mx, red);
   float sum = 0.f;
@@ -65,16 +83,29 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
   sum = block_sum(sum, red);
   const float inv = sum > 0.f ? 1.f / sum : 0.f;
   __syncthreads();
-  // o: thread -> (d = tid % dh, key slice tid / dh)
-  const int slices = 256 / dh, d = tid % dh, sl = tid / dh;
-  float acc = 0.f;
-  if (sl < slices)
-    for (int s = sl; s < n; s += slices) acc += p[s] * vb[(long)s * ldk + d];
-  part[tid] = acc;
+  // o: 16 key slices x (16 lanes x float4) per 64 head columns, slices combined in a fixed order
+  for (int d = l4; d < dh; d += 64) {
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < n; s0 += 64) {
+      float4 vv[4];
+      float w[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int s = s0 + g + 16 * i;
+        vv[i] = *reinterpret_cast<const float4*>(vb + (long)min(s, n - 1) * ldk + d);
+        w[i] = s < n ? p[s] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc.x += w[i] * vv[i].x; acc.y += w[i] * vv[i].y; acc.z += w[i] * vv[i].z; acc.w += w[i] * vv[i].w;
+      }
+    }
+    *reinterpret_cast<float4*>(part + g * dh + d) = acc;
+  }
   __syncthreads();
   if (tid < dh) {
     float a = 0.f;
-    for (int i = 0; i < slices; ++i) a += part[i * dh + tid];
+    for (int i = 0; i < 16; ++i) a += part[i * dh + tid];
     o[(long)b * ldo + h * dh + tid] = a * inv;
   }
   if (attn_mean)
@@ -147,6 +178,98 @@ __global__ __launch_bounds__(256) void gl_project_kernel(const float* __restrict
   X[(long)t * 2 * F + f] = m * cosf(a);
   X[(long)t * 2 * F + F + f] = m * sinf(a);
 }
+// ---- batched Griffin-Lim on the bf16 matrix cores: U utterances with T_u = tl[u] <= Tmax frames, rows
+// r = u * Tmax + t.  The dense-DFT GEMMs run as ONE bf16 GEMM each with the bf16x3 split folded into the
+// contraction dimension: an fp32 row x (K values) is stored as the bf16 row [hi(x) | lo(x) | hi(x)] (3K) and
+// the constant basis as [hi(b) | hi(b) | lo(b)], so the MFMA chain accumulates hi*hi + lo*hi + hi*lo in
+// fp32 (~2^-17 relative, the accuracy of the fp32-operand "precise" GEMM) at the bf16 kernel's speed.
+// Spectra are [rows][re(0..F) pad | im(0..F) pad] with the halves Fp = roundup(F, 16) apart; frames
+// t >= T_u and pad columns are written as zeros.
+__device__ __forceinline__ void store_split4(uint16_t* dst, long seg, const float v[4]) {
+  uint2 hi, lo;
+  split_bf16x4(v[0], v[1], v[2], v[3], hi, lo);
+  *reinterpret_cast<uint2*>(dst) = hi;
+  *reinterpret_cast<uint2*>(dst + seg) = lo;
+  *reinterpret_cast<uint2*>(dst + 2 * seg) = hi;
+}
+// MODE 0: X = mag * exp(i ang) from the initial angles (aux = ang [rows][F]);
+// MODE 1: X = mag * exp(i angle(Y)) from the re-analysed spectrum (aux = Y [rows][2 Fp])
+template <int MODE>
+__global__ __launch_bounds__(256) void gl_polar_split_kernel(const float* __restrict__ mag, const float* __restrict__ aux,
+                                                             const int* __restrict__ tl, uint16_t* __restrict__ Xs,
+                                                             int U, int F, int Fp, int Tmax) {
+  const int q = Fp / 4;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)U * Tmax * q) return;
+  const int f4 = (int)(i % q) * 4;
+  const long row = i / q;
+  const int t = (int)(row % Tmax), u = (int)(row / Tmax);
+  float re[4] = {0.f, 0.f, 0.f, 0.f}, im[4] = {0.f, 0.f, 0.f, 0.f};
+  if (t < tl[u]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int f = f4 + e;
+      if (f < F) {
+        const float m = mag[row * F + f];
+        const float a = MODE == 0 ? aux[row * F + f] : atan2f(aux[row * 2 * Fp + Fp + f], aux[row * 2 * Fp + f]);
+        re[e] = m * cosf(a);
+        im[e] = m * sinf(a);
+      }
+    }
+  }
+  uint16_t* xr = Xs + row * 6 * Fp;
+  store_split4(xr + f4, 2 * Fp, re);
+  store_split4(xr + Fp + f4, 2 * Fp, im);
+}
+// analysis frames of the reflect-padded waveforms, split for the STFT GEMM: As[row][3][n_fft]
+__global__ __launch_bounds__(256) void gl_frame_split_kernel(const float* __restrict__ wave, const int* __restrict__ tl,
+                                                             uint16_t* __restrict__ As, int U, int Tmax, int hop,
+                                                             int n_fft, int Lw) {
+  const int q = n_fft / 4;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)U * Tmax * q) return;
+  const int j4 = (int)(i % q) * 4;
+  const long row = i / q;
+  const int t = (int)(row % Tmax), u = (int)(row / Tmax);
+  const int T = tl[u], n = hop * (T - 1), pad = n_fft / 2;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (t < T && n > pad) {
+    const float* w = wave + (long)u * Lw;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int j = t * hop + j4 + e - pad;
+      if (j < 0) j = -j;
+      if (j >= n) j = 2 * (n - 1) - j;
+      v[e] = w[j];
+    }
+  }
+  store_split4(As + row * 3 * n_fft + j4, n_fft, v);
+}
+// per-utterance overlap-add of frames[u][t < T_u][n_fft]; wsq[T][..] is looked up per T_u through wsq_off
+__global__ __launch_bounds__(256) void gl_overlap_add_b_kernel(const float* __restrict__ frames,
+                                                               const float* __restrict__ wsq_all,
+                                                               const long* __restrict__ wsq_off,
+                                                               const int* __restrict__ tl, float* __restrict__ wave,
+                                                               int U, int Tmax, int n_fft, int hop, int Lw, float tiny) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)U * Lw) return;
+  const int u = (int)(i / Lw), q = (int)(i - (long)u * Lw);
+  const int T = tl[u];
+  float out = 0.f;
+  if (q < hop * (T - 1)) {
+    const int pos = q + n_fft / 2;
+    int t1 = pos / hop;
+    if (t1 > T - 1) t1 = T - 1;
+    const int t0 = pos - n_fft + 1 <= 0 ? 0 : (pos - n_fft + 1 + hop - 1) / hop;
+    float a = 0.f;
+    for (int t = t0; t <= t1; ++t) a += frames[((long)u * Tmax + t) * n_fft + (pos - t * hop)];
+    const float w = wsq_all[wsq_off[u] + pos];
+    if (w > tiny) a /= w;
+    out = a * ((float)n_fft / (float)hop);
+  }
+  wave[i] = out;
+}
+
 // reflect-pad a waveform by `pad` on both sides: y[i] = x[reflect(i - pad)]
 __global__ __launch_bounds__(256) void reflect_pad_kernel(const float* __restrict__ x, float* __restrict__ y, int n,
                                                           int pad) {
@@ -250,5 +373,35 @@ int s2st_gl_overlap_add(const float* frames, const float* wsq, float* wave, int 
   if (n_out <= 0) return 0;
   hipLaunchKernelGGL(gl_overlap_add_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, frames, wsq, wave,
                      T, n_fft, hop, n_out, 1.1754944e-38f);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+
+int s2st_gl_polar_split(const float* mag, const float* aux, int from_spectrum, const int* tl, uint16_t* Xs, int U, int F,
+                        int Fp, int Tmax, hipStream_t st) {
+  if (Fp % 4 || Fp < F) return S2ST_ERR_SHAPE;
+  const long n = (long)U * Tmax * (Fp / 4);
+  if (n <= 0) return 0;
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (from_spectrum)
+    hipLaunchKernelGGL(gl_polar_split_kernel<1>, grid, dim3(256), 0, st, mag, aux, tl, Xs, U, F, Fp, Tmax);
+  else
+    hipLaunchKernelGGL(gl_polar_split_kernel<0>, grid, dim3(256), 0, st, mag, aux, tl, Xs, U, F, Fp, Tmax);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+int s2st_gl_frame_split(const float* wave, const int* tl, uint16_t* As, int U, int Tmax, int hop, int n_fft, int Lw,
+                        hipStream_t st) {
+  if (n_fft % 4) return S2ST_ERR_SHAPE;
+  const long n = (long)U * Tmax * (n_fft / 4);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(gl_frame_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wave, tl, As, U, Tmax,
+                     hop, n_fft, Lw);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+int s2st_gl_overlap_add_b(const float* frames, const float* wsq_all, const long* wsq_off, const int* tl, float* wave,
+                          int U, int Tmax, int n_fft, int hop, int Lw, hipStream_t st) {
+  const long n = (long)U * Lw;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(gl_overlap_add_b_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, frames, wsq_all,
+                     wsq_off, tl, wave, U, Tmax, n_fft, hop, Lw, 1.1754944e-38f);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }

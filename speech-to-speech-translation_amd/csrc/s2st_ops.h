@@ -179,6 +179,12 @@ int s2st_clamp_min(float* x, long n, float lo, hipStream_t st);
 int s2st_gl_polar(const float* mag, const float* ang, float* X, int F, int T, hipStream_t st);
 int s2st_gl_project(const float* mag, const float* Y, float* X, int F, int T, hipStream_t st);
 int s2st_reflect_pad(const float* x, float* y, int n, int pad, hipStream_t st);
+int s2st_gl_polar_split(const float* mag, const float* aux, int from_spectrum, const int* tl, uint16_t* Xs, int U, int F,
+                        int Fp, int Tmax, hipStream_t st);
+int s2st_gl_frame_split(const float* wave, const int* tl, uint16_t* As, int U, int Tmax, int hop, int n_fft, int Lw,
+                        hipStream_t st);
+int s2st_gl_overlap_add_b(const float* frames, const float* wsq_all, const long* wsq_off, const int* tl, float* wave,
+                          int U, int Tmax, int n_fft, int hop, int Lw, hipStream_t st);
 int s2st_gl_overlap_add(const float* frames, const float* wsq, float* wave, int T, int n_fft, int hop, int n_out,
                         hipStream_t st);
 

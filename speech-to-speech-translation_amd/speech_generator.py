@@ -36,6 +36,15 @@ class SpeechGenerator:
     def get_waveform(self, feat):
         return None if self.vocoder is None else self.vocoder(feat).squeeze(0)
 
+    def get_waveforms(self, feats):
+        """All utterances of a batch through the vocoder together (same random-phase draws, in the same
+        order, as calling get_waveform per utterance like speech_generator.py:81-94 does)."""
+        if self.vocoder is None:
+            return [None] * len(feats)
+        if hasattr(self.vocoder, "batch"):
+            return [w.squeeze(0) for w in self.vocoder.batch(feats)]
+        return [self.get_waveform(f) for f in feats]
+
 
 class AutoRegressiveSpeechGenerator(SpeechGenerator):
     def __init__(self, model, vocoder, data_cfg=None, max_iter: int = 6000, eos_prob_threshold: float = 0.5,
@@ -88,13 +97,16 @@ class AutoRegressiveSpeechGenerator(SpeechGenerator):
         attn = attn.repeat_interleave(n_frames_per_step, dim=2)
         alignment = alignment.repeat_interleave(n_frames_per_step, dim=1)
         out_lens = out_lens * n_frames_per_step
+        lens = out_lens.tolist()
+        waves = self.get_waveforms([feat[b, :l] for b, l in enumerate(lens)])
         finalized = [{"feature": feat[b, :l], "eos_prob": eos_prob[b, :l], "attn": attn[b, :, :l],
-                      "alignment": alignment[b, :l], "waveform": self.get_waveform(feat[b, :l])}
-                     for b, l in zip(range(bsz), out_lens.tolist())]
+                      "alignment": alignment[b, :l], "waveform": waves[b]}
+                     for b, l in enumerate(lens)]
         if has_targ:
             tgt = self.gcmvn_denormalize(sample["tgt_speech"].to(dev, torch.float32).reshape(bsz, -1, raw_dim))
             tl = (sample["target_lengths"] * n_frames_per_step).tolist()
+            twaves = self.get_waveforms([tgt[b, :l] for b, l in enumerate(tl)])
             for b, l in enumerate(tl):
                 finalized[b]["targ_feature"] = tgt[b, :l]
-                finalized[b]["targ_waveform"] = self.get_waveform(tgt[b, :l])
+                finalized[b]["targ_waveform"] = twaves[b]
         return finalized

@@ -57,6 +57,14 @@ def slaney_mel_filters(sample_rate: int, n_fft: int, n_mels: int, f_min: float, 
     return torch.from_numpy(w.astype(np.float32))
 
 
+def random_phases(n_freq: int, n_frames: int) -> np.ndarray:
+    """The reference's initial phases np.angle(np.exp(2j*pi*np.random.rand(F, T))) (vocoder.py:101-102), same
+    draws from numpy's global RNG: angle(exp(i th)) is th wrapped into (-pi, pi], computed without the
+    complex exponential (the host-side cost of a long utterance is otherwise ~10 ms)."""
+    th = 2.0 * np.pi * np.random.rand(n_freq, n_frames)
+    return np.where(th > np.pi, th - 2.0 * np.pi, th)
+
+
 class GriffinLim:
     def __init__(self, n_fft: int, win_length: int, hop_length: int, n_iter: int, device, window_fn=torch.hann_window):
         self.n_fft, self.win_length, self.hop_length, self.n_iter, self.device = n_fft, win_length, hop_length, n_iter, device
@@ -68,6 +76,8 @@ class GriffinLim:
         self.inv_t = inv.t().contiguous().to(device)  # [n_fft][2F]: rows-of-output x K layout for the GEMM
         self.win_sq = win ** 2
         self._wss = {}
+        self.Fp = (self.F + 15) // 16 * 16
+        self._bb = None
 
     def _window_sum_square(self, n_frames: int) -> torch.Tensor:
         w = self._wss.get(n_frames)
@@ -104,7 +114,7 @@ class GriffinLim:
         Fq, T = specgram.shape
         assert Fq == self.F
         if angles is None:
-            angles = np.angle(np.exp(2j * np.pi * np.random.rand(Fq, T)))
+            angles = random_phases(Fq, T)
         mag = specgram.to(self.device, torch.float32).contiguous()
         ang = torch.from_numpy(np.ascontiguousarray(angles, dtype=np.float32)).to(self.device)
         X = torch.empty(T, 2 * Fq, device=self.device)
@@ -115,6 +125,80 @@ class GriffinLim:
             bd.call("s2st_gl_project_f32", mag, Y, X, Fq, T)
             wave = self._inverse(X, T)
         return wave
+
+
+    @staticmethod
+    def _split(x: torch.Tensor):
+        hi = x.to(torch.bfloat16)
+        return hi, (x - hi.float()).to(torch.bfloat16)
+
+    def _bases_bf16(self):
+        """Constant operands of the two GEMMs, [hi | hi | lo] along the contraction (see infer.hip)."""
+        if self._bb is None:
+            Fq, Fp, n = self.F, self.Fp, self.n_fft
+            fwd = torch.zeros(2 * Fp, n, device=self.device)  # rows: re(F) pad | im(F) pad
+            fwd[:Fq] = self.fwd[:Fq]
+            fwd[Fp:Fp + Fq] = self.fwd[Fq:]
+            hi, lo = self._split(fwd)
+            fwd3 = torch.cat([hi, hi, lo], dim=1).contiguous()  # [2Fp][3 n_fft]
+            inv = torch.zeros(n, 2 * Fp, device=self.device)  # columns in the spectrum layout
+            inv[:, :Fq] = self.inv_t[:, :Fq]
+            inv[:, Fp:Fp + Fq] = self.inv_t[:, Fq:]
+            hi, lo = self._split(inv)
+            inv3 = torch.cat([hi, hi, lo], dim=1).contiguous()  # [n_fft][3 * 2Fp]
+            self._bb = (fwd3, inv3)
+        return self._bb
+
+    def batch(self, specgrams, angles=None):
+        """Several utterances at once: ``specgrams`` is a list of [F, T_u] magnitudes, the result the list
+        of waveforms.  Griffin-Lim is sequential in its iterations but independent across utterances, so
+        every STFT / inverse STFT is ONE GEMM over all utterances' frames (rows beyond an utterance's T_u
+        are zero padding); the reference loops utterances (speech_generator.py:81-94 ->
+        vocoder.py:100-123).  The GEMMs run on the bf16 kernel with the hi/lo split folded into K."""
+        U = len(specgrams)
+        if U == 0:
+            return []
+        Fq, Fp, hop, n_fft, dev = self.F, self.Fp, self.hop_length, self.n_fft, self.device
+        Ts = [int(s.shape[1]) for s in specgrams]
+        Tmax = max(Ts)
+        if angles is None:  # the reference's per-utterance draws from numpy's global RNG, in order
+            angles = [random_phases(Fq, T) for T in Ts]
+        ang_h = torch.zeros(U, Tmax, Fq, dtype=torch.float32)
+        for u, a_ in enumerate(angles):
+            ang_h[u, :Ts[u]] = torch.from_numpy(np.ascontiguousarray(a_, dtype=np.float32)).t()
+        ang = ang_h.to(dev)
+        mag = torch.zeros(U, Tmax, Fq, device=dev)  # time-major: the kernels walk rows = frames
+        for u, s_ in enumerate(specgrams):
+            mag[u, :Ts[u]] = s_.to(dev, torch.float32).t()
+        tl = torch.tensor(Ts, dtype=torch.int32).to(dev)
+        offs, tabs, o = [], [], 0
+        for T in Ts:
+            w = self._window_sum_square(T)
+            offs.append(o)
+            tabs.append(w)
+            o += w.numel()
+        wsq_all = torch.cat(tabs)
+        wsq_off = torch.tensor(offs, dtype=torch.int64).to(dev)
+        fwd3, inv3 = self._bases_bf16()
+        M, Lw = U * Tmax, hop * (Tmax - 1)
+        Xs = torch.empty(M, 6 * Fp, dtype=torch.bfloat16, device=dev)
+        As = torch.empty(M, 3 * n_fft, dtype=torch.bfloat16, device=dev)
+        Y = torch.empty(M, 2 * Fp, device=dev)
+        frames = torch.empty(M, n_fft, device=dev)
+        wave = torch.empty(U, max(Lw, 1), device=dev)
+
+        def inverse():
+            bd.gemm(Xs, inv3, frames, M, n_fft, 6 * Fp)
+            bd.call("s2st_gl_overlap_add_b_f32", frames, wsq_all, wsq_off, tl, wave, U, Tmax, n_fft, hop, Lw)
+
+        bd.call("s2st_gl_polar_split_f32", mag, ang, 0, tl, Xs, U, Fq, Fp, Tmax)
+        inverse()
+        for _ in range(self.n_iter):
+            bd.call("s2st_gl_frame_split_f32", wave, tl, As, U, Tmax, hop, n_fft, Lw)
+            bd.gemm(As, fwd3, Y, M, 2 * Fp, 3 * n_fft)
+            bd.call("s2st_gl_polar_split_f32", mag, Y, 1, tl, Xs, U, Fq, Fp, Tmax)
+            inverse()
+        return [wave[u, :hop * (Ts[u] - 1)].clone() for u in range(U)]
 
 
 class GriffinLimVocoder:
@@ -135,6 +219,19 @@ class GriffinLimVocoder:
         bd.gemm(self.inv_mel, xt, spec, self.F, T, C_, b_kmajor=False, b_ld=T, precise=True)
         bd.call("s2st_clamp_min_f32", spec, self.F * T, 0.0)
         return self.gl(spec, angles).unsqueeze(0)
+
+    def batch(self, xs, angles=None):
+        """List of [T_u, n_mels] log-mels -> list of [1, N_u] waveforms, all utterances per GEMM."""
+        specs = []
+        for x in xs:
+            T, C_ = x.shape
+            xt = torch.empty(C_, T, device=self.device)
+            bd.call("s2st_exp_transpose_f32", x.to(self.device, torch.float32).contiguous(), xt, T, C_)
+            spec = torch.empty(self.F, T, device=self.device)
+            bd.gemm(self.inv_mel, xt, spec, self.F, T, C_, b_kmajor=False, b_ld=T, precise=True)
+            bd.call("s2st_clamp_min_f32", spec, self.F * T, 0.0)
+            specs.append(spec)
+        return [w.unsqueeze(0) for w in self.gl.batch(specs, angles)]
 
     @classmethod
     def from_data_cfg(cls, args, data_cfg, device=None):

@@ -96,6 +96,12 @@ def test_griffin_lim_against_reference_golden(backend, golden_dir, n_iter):
     ref = z[f"wave.{n_iter}"]
     assert wave.shape[0] == ref.shape[0]
     assert float(np.abs(wave.cpu().numpy() - ref).max()) < 2e-3 * float(np.abs(ref).max())
+    # the all-utterances-per-GEMM path (bf16 kernel, hi/lo split folded into K), here with a shorter neighbour
+    spec, ang = torch.from_numpy(z["spec"]), z["angles"]
+    short = spec.shape[1] // 2
+    both = gl.batch([spec[:, :short].contiguous(), spec], [ang[:, :short], ang])
+    backend.sync()
+    assert float(np.abs(both[1].cpu().numpy() - ref).max()) < 2e-3 * float(np.abs(ref).max())
 
 
 def test_vocoder_against_oracle(backend):
@@ -111,6 +117,32 @@ def test_vocoder_against_oracle(backend):
     ref = IO.vocoder(feat, ang, n_iter=2, **kw)
     assert w.shape == (1, ref.shape[0])
     assert float((w[0].cpu() - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+
+
+def test_batched_vocoder_equals_per_utterance(backend):
+    """Ragged batch through the all-utterances-per-GEMM path == one utterance at a time, same angles."""
+    V = importlib.import_module(PKG + ".vocoder")
+    kw = dict(sample_rate=16000, win_size=200, hop_size=64, n_fft=256, n_mels=20, f_min=20, f_max=8000)
+    voc = V.GriffinLimVocoder(spec_bwd_max_iter=3, device=backend.device, **kw)
+    g = torch.Generator().manual_seed(5)
+    lens = [17, 9, 23, 4]
+    feats = [torch.randn(T, 20, generator=g) * 0.5 - 1.0 for T in lens]
+    rs = np.random.RandomState(6)
+    angs = [IO.initial_angles((129, T), rs) for T in lens]
+    one = [voc(f, a) for f, a in zip(feats, angs)]
+    many = voc.batch(feats, angs)
+    backend.sync()
+    for a, b in zip(one, many):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) < 1e-4 * float(a.abs().max())
+    # default angles: the same global-RNG draws in the same order
+    np.random.seed(3)
+    one = [voc(f) for f in feats]
+    np.random.seed(3)
+    many = voc.batch(feats)
+    backend.sync()
+    for a, b in zip(one, many):
+        assert float((a - b).abs().max()) < 1e-4 * float(a.abs().max())
 
 
 def test_dtw_against_reference_golden(backend, golden_dir):

@@ -43,4 +43,13 @@ for b in range(min(B, 4)):
 torch.cuda.synchronize()
 dv = (time.perf_counter() - t) / min(B, 4)
 print(f"Griffin-Lim 64 iters on {feat.shape[0]} frames -> {w.shape[1]} samples: {dv*1e3:.1f} ms/utt ({w.shape[1]/24000/dv:.0f}x real time)")
-print(f"end-to-end: {B/(dt + dv*B):.2f} utt/s")
+print(f"end-to-end (per-utterance vocoder): {B/(dt + dv*B):.2f} utt/s")
+feats = [f["feature"] for f in fin]
+voc.batch(feats)
+torch.cuda.synchronize()
+t = time.perf_counter()
+ws = voc.batch(feats)
+torch.cuda.synchronize()
+db = time.perf_counter() - t
+print(f"Griffin-Lim batched over {B} utterances: {db*1e3:.1f} ms ({db/B*1e3:.2f} ms/utt)")
+print(f"end-to-end (batched vocoder): {B/(dt + db):.2f} utt/s")
