@@ -714,6 +714,8 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
     if (bm == 64 && bn == 128) rc = launch_dma<64, 128, 3, 4>(g, grid, st);
     else if (bm == 128 && bn == 128 && nw8 && ns == 3) rc = launch_dma<128, 128, 3, 8>(g, grid, st);
     else if (bm == 128 && bn == 128 && nw8 && ns == 5) rc = launch_dma<128, 128, 5, 8>(g, grid, st);
+    else if (bm == 128 && bn == 128 && nw8 && ns == 2) rc = launch_dma<128, 128, 2, 8>(g, grid, st);
+    else if (bm == 128 && bn == 64 && nw8 && ns == 2) rc = launch_dma<128, 64, 2, 8>(g, grid, st);
     else if (bm == 128 && bn == 128) rc = nw8 ? launch_dma<128, 128, 4, 8>(g, grid, st) : launch_dma<128, 128, 4, 4>(g, grid, st);
     else if (bm == 128) rc = nw8 ? launch_dma<128, 64, 4, 8>(g, grid, st) : launch_dma<128, 64, 4, 4>(g, grid, st);
     else rc = launch_dma<64, 64, 4, 4>(g, grid, st);

@@ -1,0 +1,190 @@
+"""Size-independent properties of the hot path at BASELINE.json's full size (configs[1] recipe geometry,
+a max-tokens 20000 batch of the synthetic Fisher corpus -- bench.py's workload), where the CPU oracle is
+too slow to be the checker:
+
+* a step is a pure function of (parameters, batch, seed): same seed -> bit-identical statistics,
+  another seed -> different dropout masks;
+* data-parallel sharding is exact where the model allows it: the summed statistics of the two halves of
+  a batch equal those of the whole batch (evaluation mode: the post-net BatchNorm couples utterances in
+  training mode, in the reference as well);
+* gradient accumulation over micro-batches (update_freq, fairseq/trainer.py:760-800) is a sum;
+* the bf16 fast path agrees with the bf16x3 precise path within the north-star tolerance (loss 1e-3);
+* valid frames do not see batch padding: encoder output and pre-post-net features of an utterance are
+  unchanged when the batch is padded further.
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import s2st_oracle as O
+from configs import CONFIGS
+from test_engine import DATA, ENG, LOSS_KEYS
+from synth_weights import synth_tensor
+
+NO_DROP = dict(dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, prenet_dropout=0.0, postnet_dropout=0.0)
+
+
+def _engine(backend, cfg, precise=False):
+    eng = importlib.import_module(ENG)
+    a = O.make_args(**cfg)
+    e = eng.Engine(a, backend.device, precise=precise)
+    for name, pv, gv, isb in e.named_views():
+        pv.copy_(torch.from_numpy(synth_tensor(name, tuple(pv.shape), 0)))
+    return a, e
+
+
+@pytest.fixture(scope="module")
+def workload():
+    """The first two max-tokens batches of the bench corpus (longest utterances first)."""
+    D = importlib.import_module(DATA)
+    corpus = D.SyntheticFisherCorpus(n_utts=4096, seed=1234)
+    batches = corpus.batches(max_tokens=20000, bsz_mult=8)
+    order = np.random.RandomState(7).permutation(len(batches))
+    return corpus, [batches[order[0]], batches[order[1]], list(batches[2][:8]) + list(batches[8][:8])]
+
+
+def _need_gpu(backend):
+    if backend.kind != "hip":
+        pytest.skip("full-size properties run on the GPU")
+
+
+def _rel(g, ref):
+    return float((g - ref).norm()) / float(ref.norm())
+
+
+def _grad_close(g, ref, tol):
+    return _rel(g, ref) <= tol
+
+
+def test_step_is_a_function_of_the_seed(backend, workload):
+    """Same seed -> the same step.  Everything up to the post-net is bit-identical; the post-net's
+    training-mode BatchNorm sums its batch statistics with fp32 atomics, whose last-bit noise the bf16
+    operand rounding of the fast path amplifies to ~1e-3 in post_feat_out and, through the backward sweep,
+    in the gradients (1e-6 in precise mode) -- two orders below what another seed's masks change."""
+    _need_gpu(backend)
+    corpus, b = workload
+    a, e = _engine(backend, CONFIGS["base_recipe"])
+    s = corpus.collate_batch(b[0])
+    runs = []
+    for seed in (11, 11, 12):
+        o = e.forward(s, training=True, seed=seed)
+        e.zero_grad()
+        e.backward(1.0)
+        backend.sync()
+        runs.append(({k: o[k].clone() for k in ("feature_out", "eos_out", "encoder_out", "post_feat_out", "stats")},
+                     e.grads.clone()))
+    (o0, g0), (o1, g1), (o2, g2) = runs
+    assert torch.isfinite(g0).all()
+    for k in ("feature_out", "eos_out", "encoder_out"):
+        assert torch.equal(o0[k], o1[k]), k
+        assert not torch.equal(o0[k], o2[k]), k
+    assert float((o0["post_feat_out"] - o1["post_feat_out"]).abs().max()) <= 5e-3 * float(o0["post_feat_out"].abs().max())
+    for k, i in LOSS_KEYS:
+        assert abs(float(o0["stats"][i]) - float(o1["stats"][i])) <= 1e-4 * max(1.0, abs(float(o0["stats"][i]))), k
+    assert _grad_close(g1, g0, 3e-3)
+    assert not _grad_close(g2, g0, 5e-2)
+
+
+# normalisation of each logged loss (s2st_loss.py:179-292, reduction="mean"): masked frames for the
+# spectrogram / stop losses, utterances for CTC (nn.CTCLoss mean), text tokens for the aux decoders
+LOSS_WEIGHT = {"l1_loss": "ntokens", "mse_loss": "ntokens", "eos_loss": "ntokens", "ctc_loss": "nsentences",
+               "aux_asr_loss": "src_txt_ntokens", "aux_st_loss": "tgt_txt_ntokens"}
+
+
+def test_shards_of_a_batch_add_up(backend, workload):
+    """What data parallelism relies on: every logged loss of a batch is the weighted mean of its shards'
+    (evaluation mode: the post-net BatchNorm couples utterances in training mode, as in the reference)."""
+    _need_gpu(backend)
+    corpus, b = workload
+    a, e = _engine(backend, dict(CONFIGS["base_recipe"], **NO_DROP))
+    ix = list(b[0])
+    sw = corpus.collate_batch(ix)
+    whole = e.forward(sw, training=False, seed=1)["stats"].double().cpu()
+    parts = []
+    for h in (ix[0::2], ix[1::2]):
+        sh = corpus.collate_batch(h)
+        parts.append((sh, e.forward(sh, training=False, seed=1)["stats"].double().cpu()))
+    for k, i in LOSS_KEYS:
+        if k == "loss":
+            continue
+        w = LOSS_WEIGHT[k]
+        got = sum(float(st[i]) * sh[w] for sh, st in parts) / sw[w]
+        assert abs(got - float(whole[i])) <= 2e-4 * max(1.0, abs(float(whole[i]))), (k, got, float(whole[i]))
+
+
+def test_gradient_accumulation_is_a_sum(backend, workload):
+    _need_gpu(backend)
+    corpus, b = workload
+    a, e = _engine(backend, CONFIGS["base_recipe"], precise=True)  # (fast mode: the ~1e-3 noise described above)
+    sa, sb = corpus.collate_batch(b[0]), corpus.collate_batch(b[1])
+    single = []
+    for s, seed in ((sa, 5), (sb, 6)):
+        e.forward(s, training=True, seed=seed)
+        e.zero_grad()
+        e.backward(1.0)
+        backend.sync()
+        single.append(e.grads.clone())
+    e.zero_grad()
+    for s, seed in ((sa, 5), (sb, 6)):
+        e.forward(s, training=True, seed=seed)
+        e.backward(1.0)
+    backend.sync()
+    assert _rel(e.grads, single[0] + single[1]) <= 5e-5, _rel(e.grads, single[0] + single[1])
+
+
+def test_fast_path_within_north_star_tolerance_of_precise(backend, workload):
+    _need_gpu(backend)
+    corpus, b = workload
+    s = corpus.collate_batch(b[0])
+    out = []
+    for precise in (True, False):
+        a, e = _engine(backend, dict(CONFIGS["base_recipe"], **NO_DROP), precise=precise)
+        o = e.forward(s, training=True, seed=1)
+        e.zero_grad()
+        e.backward(1.0)
+        backend.sync()
+        out.append((o["stats"].double().cpu(), e.grads.clone()))
+        del e
+    (sp, gp), (sf, gf) = out
+    tot = dict(LOSS_KEYS)["loss"]
+    assert abs(float(sf[tot]) - float(sp[tot])) <= 1e-3 * abs(float(sp[tot])), (float(sf[tot]), float(sp[tot]))
+    for k, i in LOSS_KEYS:  # components: within 5e-3 of themselves or 1e-3 of the total
+        assert abs(float(sf[i]) - float(sp[i])) <= max(5e-3 * abs(float(sp[i])), 1e-3 * abs(float(sp[tot]))), k
+    assert abs(float(gf.norm()) - float(gp.norm())) <= 1e-2 * float(gp.norm())
+    assert _grad_close(gf, gp, 5e-2)
+
+
+@pytest.mark.parametrize("precise,tol", [(True, 1e-4), (False, 2e-2)])
+def test_valid_frames_do_not_see_batch_padding(backend, workload, precise, tol):
+    """(bf16 mode: a different padded length changes tile counts, hence fp32 summation order in the last bit,
+    which operand rounding amplifies -- the tolerance is a few bf16 ulps of the largest activation.)"""
+    _need_gpu(backend)
+    corpus, b = workload
+    a, e = _engine(backend, dict(CONFIGS["base_recipe"], **NO_DROP), precise=precise)
+    ix = list(b[2])  # two length buckets in one batch
+    s = corpus.collate_batch(ix)
+    o = e.forward(s, training=False, seed=1)
+    enc, feat = o["encoder_out"].clone(), o["feature_out"].clone()  # [B, T', C], [B, D, 80 * r]
+    enc_len = o["encoder_lens"].tolist()
+    s2 = corpus.collate_batch(ix)
+    ni = s2["net_input"]
+    ni["src_speech"] = torch.nn.functional.pad(ni["src_speech"], (0, 0, 0, 64))
+    ni["prev_output_tokens"] = torch.nn.functional.pad(ni["prev_output_tokens"], (0, 0, 0, 5))
+    s2["tgt_speech"] = torch.nn.functional.pad(s2["tgt_speech"], (0, 0, 0, 5))
+    o2 = e.forward(s2, training=False, seed=1)
+    backend.sync()
+    tl = s["target_lengths"].tolist()
+    sl = ni["src_speech_lens"].tolist()
+    # the reference's conv subsampler does not mask between its layers, so an utterance that ends within the
+    # receptive field (2 x k5 s2 -> 7 frames) of the batch edge sees the difference between the conv's zero
+    # padding and what the first layer makes of batch padding; those are excluded, as they would be there
+    inner = [bi for bi in range(len(ix)) if sl[bi] + 8 <= max(sl)]
+    assert len(inner) >= 2
+    for bi in inner:
+        d = tl[bi]
+        assert float((o2["feature_out"][bi, :d] - feat[bi, :d]).abs().max()) <= tol * float(feat[bi, :d].abs().max())
+        t = enc_len[bi]
+        ref = enc[bi, :t]
+        assert float((o2["encoder_out"][bi, :t] - ref).abs().max()) <= tol * float(ref.abs().max())
