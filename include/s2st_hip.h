@@ -163,13 +163,16 @@ int s2st_conv_w_permute_f32(const float* w, float* wf, float* wd, int32_t O, int
 /* dW[O][I][Kw] += dWf[O][Kw][I] */
 int s2st_conv_w_unpermute_acc_f32(const float* dwf, float* dw, int32_t O, int32_t I, int32_t Kw, void* stream);
 
-/* tacotron2.py:112,125 BatchNorm1d(train): batch mean/var over all rows + running stats; tmp 2C floats */
+/* tacotron2.py:112,125 BatchNorm1d(train): batch mean/var over all rows + running stats; tmp: S2ST_BN_TMP_FLOATS(C) floats.
+ * Scratch of the BatchNorm statistics / backward reductions: results (2 C) and slab partials (64 x 2 C) -- the
+ * reductions are fixed-order (no atomics), so the statistics and everything downstream are reproducible */
+#define S2ST_BN_TMP_FLOATS(C) (130 * (long)(C))
 int s2st_bn_stats_f32(const float* x, int32_t rows, int32_t C, float* mean, float* var, float* run_mean, float* run_var, float momentum, float* tmp, void* stream);
 
 /* y = dropout([tanh](gamma*xhat+beta)) (+resid) */
 int s2st_bn_apply_f32(const float* x, const float* mean, const float* var, const float* gamma, const float* beta, float* y, s2st_split ysp, const float* resid, int32_t rows, int32_t C, float eps, int32_t tanh_, float drop_p, uint64_t seed, void* stream);
 
-/* backward of bn_apply (train-mode statistics) */
+/* backward of bn_apply (train-mode statistics); tmp: S2ST_BN_TMP_FLOATS(C) floats */
 int s2st_bn_bwd_f32(const float* dy, s2st_split dysp, const float* x, const float* mean, const float* var, const float* gamma, const float* beta, float* dx, s2st_split dxsp, float* dgamma, float* dbeta, float* tmp, int32_t rows, int32_t C, float eps, int32_t tanh_, float drop_p, uint64_t seed, void* stream);
 
 /* s2st_loss.py:294-315 compute_loss: masked L1+MSE (pre/post-net) + BCE(pos_weight) sums and gradients */

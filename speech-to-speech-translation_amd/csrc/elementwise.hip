@@ -284,11 +284,14 @@ __global__ __launch_bounds__(256) void conv_w_unpermute_acc_kernel(const float* 
 }
 
 // ---- column reductions with a per-element functor returning two values ------------------
+// Deterministic: row slabs write partial sums to scratch and a second small kernel folds them in slab order
+// (BatchNorm statistics feed every later activation, and with fp32 atomics their last-bit noise is amplified to
+// ~1e-3 by the bf16 operand rounding downstream; a ticket / last-block fold in one launch needs device-scope
+// fences, which on this multi-L2 chip cost more than the extra launch).  scratch: part [slabs][2][cols] floats.
+constexpr int CR_MAX_SLABS = 64;
 template <class F>
-__global__ __launch_bounds__(256) void colreduce2_kernel(F f, int rows, int cols,
-                                                         float* __restrict__ out0,
-                                                         float* __restrict__ out1,
-                                                         int rows_per_block) {
+__global__ __launch_bounds__(256) void colreduce2_kernel(F f, int rows, int cols, int rows_per_block,
+                                                         float* __restrict__ part) {
   __shared__ float red[2][4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
@@ -305,20 +308,56 @@ __global__ __launch_bounds__(256) void colreduce2_kernel(F f, int rows, int cols
   red[1][ty][tx] = a1;
   __syncthreads();
   if (ty == 0 && c < cols) {
-    atomicAdd(&out0[c], red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx]);
-    if (out1) atomicAdd(&out1[c], red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx]);
+    part[((long)blockIdx.y * 2 + 0) * cols + c] = (red[0][0][tx] + red[0][1][tx]) + (red[0][2][tx] + red[0][3][tx]);
+    part[((long)blockIdx.y * 2 + 1) * cols + c] = (red[1][0][tx] + red[1][1][tx]) + (red[1][2][tx] + red[1][3][tx]);
   }
 }
+// out = fold of the slab partials; optionally also acc += out (parameter gradients)
+__global__ __launch_bounds__(256) void colreduce2_fold_kernel(const float* __restrict__ part, int slabs, int cols,
+                                                              float* __restrict__ out0, float* __restrict__ out1,
+                                                              float* __restrict__ acc0, float* __restrict__ acc1) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  // loads in batches of 16 slabs issued together (a dependent load-add chain would cost one memory latency
+  // per slab); the adds stay in slab order
+  float s0 = 0.f, s1 = 0.f;
+  for (int sb = 0; sb < slabs; sb += 16) {
+    float v0[16], v1[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int s = min(sb + j, slabs - 1);
+      v0[j] = part[((long)s * 2 + 0) * cols + c];
+      v1[j] = part[((long)s * 2 + 1) * cols + c];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (sb + j < slabs) {
+        s0 += v0[j];
+        s1 += v1[j];
+      }
+  }
+  out0[c] = s0;
+  if (out1) out1[c] = s1;
+  if (acc0) acc0[c] += s0;
+  if (acc1) acc1[c] += s1;
+}
 
+// scratch = tmp + 2 * cols (s2st_bn_* pass tmp of S2ST_BN_TMP_FLOATS(C) floats)
+// out0 == nullptr: leave the fold to the caller's next kernel (*slabs_out partials per column)
 template <class F>
-int colreduce2(F f, int rows, int cols, float* out0, float* out1, hipStream_t st) {
+int colreduce2(F f, int rows, int cols, float* out0, float* out1, float* scratch, hipStream_t st,
+               float* acc0 = nullptr, float* acc1 = nullptr, int* slabs_out = nullptr) {
   int cb = (cols + 63) / 64;
   int slabs = (512 + cb - 1) / cb;
+  if (slabs > CR_MAX_SLABS) slabs = CR_MAX_SLABS;
   int rpb = (rows + slabs - 1) / slabs;
   if (rpb < 16) rpb = 16;
   slabs = (rows + rpb - 1) / rpb;
-  hipLaunchKernelGGL((colreduce2_kernel<F>), dim3(cb, slabs), dim3(256), 0, st, f, rows, cols, out0,
-                     out1, rpb);
+  hipLaunchKernelGGL((colreduce2_kernel<F>), dim3(cb, slabs), dim3(256), 0, st, f, rows, cols, rpb, scratch);
+  if (slabs_out) *slabs_out = slabs;
+  if (out0)
+    hipLaunchKernelGGL(colreduce2_fold_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, (const float*)scratch, slabs,
+                       cols, out0, out1, acc0, acc1);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
@@ -334,8 +373,9 @@ struct SqDevF {
   }
 };
 
+// sq_part: the squared-deviation slab partials [slabs][2][C] (folded here, in slab order)
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sum,
-                                                          const float* __restrict__ sq,
+                                                          const float* __restrict__ sq_part, int slabs,
                                                           float* __restrict__ mean,
                                                           float* __restrict__ var,
                                                           float* __restrict__ run_mean,
@@ -344,7 +384,16 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   int c = blockIdx.x * EW_BLOCK + threadIdx.x;
   if (c >= C) return;
   float m = sum[c] / rows;
-  float v = sq[c] / rows;
+  float sq = 0.f;
+  for (int sb = 0; sb < slabs; sb += 16) {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = sq_part[(long)min(sb + j, slabs - 1) * 2 * C + c];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (sb + j < slabs) sq += v[j];
+  }
+  float v = sq / rows;
   mean[c] = m;
   var[c] = v;
   if (run_mean) {
@@ -545,17 +594,18 @@ int s2st_conv_w_unpermute_acc(const float* dwf, float* dw, int O, int I, int Kw,
   return LAUNCH_OK();
 }
 
-// tmp: 2*C floats of scratch
+// tmp: S2ST_BN_TMP_FLOATS(C) floats of scratch
 int s2st_bn_stats(const float* x, int rows, int C, float* mean, float* var, float* run_mean,
                   float* run_var, float momentum, float* tmp, hipStream_t st) {
   if (rows <= 0 || C <= 0) return 0;
-  hipMemsetAsync(tmp, 0, sizeof(float) * 2 * C, st);
-  int rc = colreduce2(SumF{x, C}, rows, C, tmp, nullptr, st);
+  int rc = colreduce2(SumF{x, C}, rows, C, tmp, nullptr, tmp + 2 * (long)C, st);
   if (rc) return rc;
-  rc = colreduce2(SqDevF{x, tmp, C, 1.f / rows}, rows, C, tmp + C, nullptr, st);
+  int slabs = 0;
+  rc = colreduce2(SqDevF{x, tmp, C, 1.f / rows}, rows, C, nullptr, nullptr, tmp + 2 * (long)C, st, nullptr, nullptr, &slabs);
   if (rc) return rc;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + EW_BLOCK - 1) / EW_BLOCK), dim3(EW_BLOCK), 0, st,
-                     tmp, tmp + C, mean, var, run_mean, run_var, C, rows, momentum);
+                     (const float*)tmp, (const float*)(tmp + 2 * (long)C), slabs, mean, var, run_mean, run_var, C, rows,
+                     momentum);
   return LAUNCH_OK();
 }
 
@@ -576,12 +626,9 @@ int s2st_bn_bwd(const float* dy, Split dysp, const float* x, const float* mean, 
   long n = (long)rows * C;
   if (n <= 0) return 0;
   BnBwdF f{dy, dysp, x, mean, var, gamma, beta, C, eps, tanh_, drop_p, seed};
-  hipMemsetAsync(tmp, 0, sizeof(float) * 2 * C, st);
-  int rc = colreduce2(f, rows, C, tmp, tmp + C, st);
+  // sums of dy' and dy' * xhat; the fold also adds them to the parameter gradients
+  int rc = colreduce2(f, rows, C, tmp, tmp + C, tmp + 2 * (long)C, st, dbeta, dgamma);
   if (rc) return rc;
   hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, f, tmp, dx, dxsp, rows, C);
-  unsigned g = (C + EW_BLOCK - 1) / EW_BLOCK;
-  hipLaunchKernelGGL(add_vec_kernel, dim3(g), dim3(EW_BLOCK), 0, st, (const float*)tmp, dbeta, C);
-  hipLaunchKernelGGL(add_vec_kernel, dim3(g), dim3(EW_BLOCK), 0, st, (const float*)(tmp + C), dgamma, C);
   return LAUNCH_OK();
 }

@@ -773,6 +773,7 @@ struct s2st_engine {
           g.C = gemm_out(dx, pp.I);
           g.ep = gemm_epi_default();
           g.ep.accumulate = acc ? 1 : 0;
+          g.ws = ws_for(st_); g.ws_floats = skws_n;  // split-K through slabs (fixed order), not atomics
           g.M = B * Tin; g.N = pp.I; g.K = pp.Kw * pp.O; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
           chk(s2st_gemm(g, st_));
         }
@@ -929,7 +930,7 @@ struct s2st_engine {
       chk(s2st_copy_rows(feat->d, xs, curh + (long)pp * c.out_dim, ys, B * D, c.out_dim, st_));
     }
     Ten* post = nullptr;
-    float* bn_tmp = alloc(2 * (long)(c.postnet_dim > c.out_dim ? c.postnet_dim : c.out_dim));
+    float* bn_tmp = alloc(S2ST_BN_TMP_FLOATS(c.postnet_dim > c.out_dim ? c.postnet_dim : c.out_dim));
     for (int i = 0; i < c.postnet_layers; ++i) {
       const ConvP& pc = post_conv[i];
       const BNP& bn = post_bn[i];

@@ -567,10 +567,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   float* cp = C.p + zq * C.zo + zr * C.zi + split_off(C.sp, m) + n;
   const long sstride = (long)M * N;
   if ((N & 3) == 0 && ((uintptr_t)cp & 15) == 0) {
+    // slab loads are issued 8 at a time (a load-add chain costs one memory latency per slab); adds in slab order
     float4 a = accumulate ? *reinterpret_cast<const float4*>(cp) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < splitk; ++s) {
-      const float4 v = *reinterpret_cast<const float4*>(sp + s * sstride);
-      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    for (int sb = 0; sb < splitk; sb += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(sp + (long)min(sb + j, splitk - 1) * sstride);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (sb + j < splitk) { a.x += v[j].x; a.y += v[j].y; a.z += v[j].z; a.w += v[j].w; }
     }
     *reinterpret_cast<float4*>(cp) = a;
   } else {

@@ -94,6 +94,7 @@ static inline float atomicAdd(float* p, float v) {
   memcpy(&f, &old, 4);
   return f;
 }
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline double atomicAdd(double* p, double v) {

@@ -201,7 +201,7 @@ def test_batchnorm_train(backend, tanh_):
     xd, gd, bd_, dyd, resd = dev(backend, x, gam, bet, dy, res)
     mean, var = torch.zeros(Cc, device=backend.device), torch.zeros(Cc, device=backend.device)
     rm, rv = torch.zeros(Cc, device=backend.device), torch.ones(Cc, device=backend.device)
-    tmp = torch.zeros(2 * Cc, device=backend.device)
+    tmp = torch.full((130 * Cc,), float("nan"), device=backend.device)  # S2ST_BN_TMP_FLOATS(C)
     backend.bd.call("s2st_bn_stats_f32", xd, rows, Cc, mean, var, rm, rv, 0.1, tmp)
     y = torch.zeros_like(xd)
     sp = backend.bd.make_split(Cc)
