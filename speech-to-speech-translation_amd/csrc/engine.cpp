@@ -84,6 +84,9 @@ struct s2st_engine {
   hipStream_t side_ = nullptr;
   hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr, ev_taps_ = nullptr;
   bool overlap_aux = true;  // S2ST_NO_AUX_OVERLAP=1 (A/B switch)
+  bool hoist_kv = true;     // S2ST_NO_KV_HOIST=1 (A/B switch): cross-attention K|V projections inside the layers
+  hipEvent_t ev_kv_ = nullptr;
+  bool kv_wait_ = false;    // the data path has not yet waited for the hoisted K|V projections
   hipEvent_t ev_auxb_ = nullptr;
   size_t aux_wait_idx = 0, aux_lo_idx = 0, aux_hi_idx = 0;  // tape indices: tap-LN end; aux section [lo, hi)
   bool aux_bwd_on_side = false;
@@ -671,11 +674,18 @@ struct s2st_engine {
     Ten* o = attention(io, B, T, T, H, C / H, klen, causal, bt.training ? c.attn_dropout : 0.f, nullptr);
     return linear(o, a.out_w, a.out_b, C, C, 0, bt.training ? c.dropout : 0.f, resid);
   }
+  Ten* cross_kv(Ten* encx, const XAttnP& a, int C) {
+    return linear(encx, a.kv_w, a.kv_b, 2 * C, encx->cols, 0, 0.f, nullptr, nullptr, true);
+  }
   Ten* cross_attn_block(Ten* x, Ten* encx, const XAttnP& a, int B, int T, int S, int H,
-                        const int* klen, Ten* resid, float* attn_mean_out) {
+                        const int* klen, Ten* resid, float* attn_mean_out, Ten* kv_pre = nullptr) {
     const int C = x->cols;
     Ten* q = linear(x, a.q_w, a.q_b, C, C, 0, 0.f, nullptr, nullptr, true);
-    Ten* kv = linear(encx, a.kv_w, a.kv_b, 2 * C, encx->cols, 0, 0.f, nullptr, nullptr, true);
+    Ten* kv = kv_pre ? kv_pre : cross_kv(encx, a, C);
+    if (kv_pre && kv_wait_) {  // first consumer of the projections issued on the second stream
+      hipStreamWaitEvent(st_, ev_kv_, 0);
+      kv_wait_ = false;
+    }
     AttnIO io{q, 0, C, kv, 0, 2 * C, kv, C, 2 * C};
     Ten* o = attention(io, B, T, S, H, C / H, klen, 0, bt.training ? c.attn_dropout : 0.f, attn_mean_out);
     return linear(o, a.out_w, a.out_b, C, C, 0, bt.training ? c.dropout : 0.f, resid);
@@ -695,14 +705,14 @@ struct s2st_engine {
     return layernorm(ffn_block(x, l.fc1, l.fc2, x), l.ln2);
   }
   Ten* dec_layer(Ten* x, Ten* encx, const DecLayerP& l, int B, int T, int S, int H, bool pre_ln,
-                 const int* self_klen, float* attn_mean_out) {
+                 const int* self_klen, float* attn_mean_out, Ten* kv_pre = nullptr) {
     if (pre_ln) {
       x = self_attn_block(layernorm(x, l.ln1, nullptr, true), l.sa, B, T, H, self_klen, 1, x);
-      x = cross_attn_block(layernorm(x, l.ln2, nullptr, true), encx, l.xa, B, T, S, H, bt.enc_lens, x, attn_mean_out);
+      x = cross_attn_block(layernorm(x, l.ln2, nullptr, true), encx, l.xa, B, T, S, H, bt.enc_lens, x, attn_mean_out, kv_pre);
       return ffn_block(layernorm(x, l.ln3, nullptr, true), l.fc1, l.fc2, x);
     }
     x = layernorm(self_attn_block(x, l.sa, B, T, H, self_klen, 1, x), l.ln1);
-    x = layernorm(cross_attn_block(x, encx, l.xa, B, T, S, H, bt.enc_lens, x, attn_mean_out), l.ln2);
+    x = layernorm(cross_attn_block(x, encx, l.xa, B, T, S, H, bt.enc_lens, x, attn_mean_out, kv_pre), l.ln2);
     return layernorm(ffn_block(x, l.fc1, l.fc2, x), l.ln3);
   }
 
@@ -1184,12 +1194,32 @@ struct s2st_engine {
     // the CTC head and the aux text decoders only need the encoder taps: they are issued (below, in tape
     // order) on the second stream behind this event and run next to the mel decoder
     const bool aux_on_side = side_ && ev_taps_ && live() && overlap_aux;
-    if (aux_on_side) hipEventRecord(ev_taps_, st_);
+    const bool kv_on_side = side_ && ev_taps_ && ev_kv_ && live() && hoist_kv && !stop_after_encoder;
+    if (aux_on_side || kv_on_side) hipEventRecord(ev_taps_, st_);
     aux_wait_idx = tape.size();  // the tap layer-norm closures are the last ones pushed so far
     mark();
     if (stop_after_encoder) {  // decode_begin: the AR loop drives the decoder itself
       enc_out_keep = enc_out;
       return err;
+    }
+    // The cross-attention K|V projections of every decoder layer only need the encoder output: they are
+    // issued here, on the second stream, and run under the prenet and the first self-attention block (their
+    // backward -- data gradients into the encoder output, weight gradients -- then runs after the layers').
+    std::vector<Ten*> xkv(c.dec_layers, nullptr);
+    if (hoist_kv) {
+      hipStream_t main_st = st_;
+      if (kv_on_side) {
+        hipStreamWaitEvent(side_, ev_taps_, 0);
+        st_ = side_;
+        side_used = true;
+      }
+      for (int i = 0; i < c.dec_layers; ++i) xkv[i] = cross_kv(enc_out, dec[i].xa, Cd);
+      if (kv_on_side) {
+        hipEventRecord(ev_kv_, side_);
+        st_ = main_st;
+        kv_wait_ = true;
+      }
+      mark();
     }
     // ---- decoder: prenet (dropout always on), alpha * positions, layers ---------------------------
     Ten* prev = newT(B * D, c.out_dim, const_cast<float*>(bt.prev));
@@ -1203,7 +1233,7 @@ struct s2st_engine {
     float* attn_out = nullptr;
     for (int i = 0; i < c.dec_layers; ++i) {
       float* am = (i == c.dec_layers - 1 && bt.want_attn) ? outs.attn : nullptr;
-      y = dec_layer(y, enc_out, dec[i], B, D, E, c.dec_heads, c.dec_pre_ln != 0, bt.tgt_lens, am);
+      y = dec_layer(y, enc_out, dec[i], B, D, E, c.dec_heads, c.dec_pre_ln != 0, bt.tgt_lens, am, xkv[i]);
       if (i % 2 == 1) mark();
     }
     (void)attn_out;
@@ -1362,12 +1392,14 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->use_flash = !(getenv("S2ST_NO_FLASH") && atoi(getenv("S2ST_NO_FLASH")) != 0);
   e->use_act_fuse = !(getenv("S2ST_NO_ACT_FUSE") && atoi(getenv("S2ST_NO_ACT_FUSE")) != 0);
   e->use_only_h = !(getenv("S2ST_NO_ONLY_H") && atoi(getenv("S2ST_NO_ONLY_H")) != 0);
+  e->hoist_kv = !(getenv("S2ST_NO_KV_HOIST") && atoi(getenv("S2ST_NO_KV_HOIST")) != 0);
   e->use_attn_gfuse = getenv("S2ST_ATTN_GFUSE") && atoi(getenv("S2ST_ATTN_GFUSE")) != 0;
   e->build_params();
   if (!cfg->precise && (s2st_gemm_bf16_preload(nullptr) != 0 || s2st_flash_attn_preload(nullptr) != 0)) { delete e; return S2ST_ERR_LAUNCH; }
   if (!cfg->precise && !(getenv("S2ST_NO_SIDE_STREAM") && atoi(getenv("S2ST_NO_SIDE_STREAM")))) {
     if (hipStreamCreateWithFlags(&e->side_, hipStreamNonBlocking) != hipSuccess) e->side_ = nullptr;
     e->overlap_aux = !(getenv("S2ST_NO_AUX_OVERLAP") && atoi(getenv("S2ST_NO_AUX_OVERLAP")) != 0);
+    if (e->side_ && hipEventCreateWithFlags(&e->ev_kv_, hipEventDisableTiming) != hipSuccess) e->ev_kv_ = nullptr;
     if (e->side_ && (hipEventCreateWithFlags(&e->ev_fork_, hipEventDisableTiming) != hipSuccess ||
                      hipEventCreateWithFlags(&e->ev_join_, hipEventDisableTiming) != hipSuccess ||
                      hipEventCreateWithFlags(&e->ev_taps_, hipEventDisableTiming) != hipSuccess ||
@@ -1389,6 +1421,7 @@ void s2st_engine_destroy(s2st_engine* e) {
     hipEventDestroy(e->ev_join_);
     if (e->ev_taps_) hipEventDestroy(e->ev_taps_);
     if (e->ev_auxb_) hipEventDestroy(e->ev_auxb_);
+    if (e->ev_kv_) hipEventDestroy(e->ev_kv_);
   }
   e->reset_call();
   delete e;
