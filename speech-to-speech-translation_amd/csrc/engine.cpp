@@ -49,6 +49,12 @@ struct Ten {  // plain [rows][cols] fp32 activation
   int act_mode = 0;
   float act_p = 0.f;
   long act_bias = -1;
+  // produced by linear(no activation, dropout p) [+ residual]: the layer norm that consumes it first (hence last
+  // in the backward, when its gradient is complete) emits the bf16 operand dropout'(g) + bias gradient (gpre_h)
+  bool drop2_ok = false, ln_seen = false;
+  float drop2_p = 0.f;
+  uint64_t drop2_seed = 0;
+  long drop2_bias = -1;
   bool lin_plain = false;  // output of a bias-only linear (no activation / dropout / residual): its gradient IS the GEMM operand
   bf16raw* gpre_h = nullptr;
   long n() const { return (long)rows * cols; }
@@ -117,6 +123,7 @@ struct s2st_engine {
   float* dec_crossKV(int l) const {
     return dec_st.base + (long)c.dec_layers * 2 * dec_st.B * dec_st.maxT * c.dec_dim + (long)l * dec_st.B * dec_st.E * 2 * c.dec_dim;
   }
+  bool use_ln_fuse = true;  // S2ST_NO_LN_FUSE=1 (A/B switch): separate dropout-backward prologue pass
   bool use_only_h = true;  // S2ST_NO_ONLY_H=1: always keep the fp32 copy of GEMM-only tensors (A/B switch)
   bool use_attn_gfuse = false;  // S2ST_ATTN_GFUSE=1: attention backward emits bf16 projection gradients directly
                                 // (measured: no gain over the fused cast + column-sum kernel, so off)
@@ -396,6 +403,9 @@ struct s2st_engine {
     if (fm && N % 8 == 0) y->h = alloc_h(y->n());
     if (fm && act == 1 && y->h && !resid) { y->act_mode = 1; y->act_p = drop_p; y->act_bias = b; }
     if (fm && act == 0 && drop_p == 0.f && !resid && y->h) { y->lin_plain = true; y->act_bias = b; }
+    if (fm && act == 0 && drop_p > 0.f && N % 8 == 0 && use_ln_fuse) {
+      y->drop2_ok = true; y->drop2_p = drop_p; y->drop2_seed = sd; y->drop2_bias = b;
+    }
     if (live()) {
       GemmArgs g{};
       g.A = fm ? gemm_rowmajor(xh, x->hld()) : gemm_rowmajor(x->d, x->cols);
@@ -501,21 +511,28 @@ struct s2st_engine {
     if (live())
       chk(s2st_layernorm_fwd(x->d, P + p.g, P + p.b, y->d, mean, rstd, x->rows, x->cols, 1e-5f, st_, y->h));
     LNP pp = p;
+    // first layer norm applied to x (forward order): its backward is the last contribution to x's gradient
+    const bool fuse_cand = fast() && x->drop2_ok && !x->ln_seen && x->needs_grad;
+    x->ln_seen = true;
     tape.push_back([=]() {
       if (!y->g) return;
       bool acc;
       float* dx = gradbuf(x, acc);
-      float* scratch = alloc((long)s2st_layernorm_bwd_blocks(x->rows) * 2 * x->cols);
+      const bool fuse = fuse_cand && !x->gpre_h;
+      float* scratch = alloc((long)s2st_layernorm_bwd_blocks(x->rows) * (fuse ? 3 : 2) * x->cols);
+      bf16raw* dph = nullptr;
+      if (fuse) dph = x->gpre_h = alloc_h(x->n());
+      float* dbias = fuse && x->drop2_bias >= 0 ? G + x->drop2_bias : nullptr;
       if (live()) {
         if (side_) {  // dx on the data path; the dgamma / dbeta reduce next to it on the second stream
           chk(s2st_layernorm_bwd(y->g, x->d, P + pp.g, mean, rstd, dx, acc ? 1 : 0, G + pp.g, G + pp.b, scratch,
-                                 x->rows, x->cols, st_, 1));
+                                 x->rows, x->cols, st_, 1, dph, x->drop2_p, x->drop2_seed, dbias));
           hipStream_t rs = fork_side();
           chk(s2st_layernorm_bwd(y->g, x->d, P + pp.g, mean, rstd, dx, acc ? 1 : 0, G + pp.g, G + pp.b, scratch,
-                                 x->rows, x->cols, rs, 2));
+                                 x->rows, x->cols, rs, 2, dph, x->drop2_p, x->drop2_seed, dbias));
         } else {
           chk(s2st_layernorm_bwd(y->g, x->d, P + pp.g, mean, rstd, dx, acc ? 1 : 0, G + pp.g, G + pp.b, scratch,
-                                 x->rows, x->cols, st_));
+                                 x->rows, x->cols, st_, 0, dph, x->drop2_p, x->drop2_seed, dbias));
         }
       }
     });
@@ -1393,6 +1410,7 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->use_act_fuse = !(getenv("S2ST_NO_ACT_FUSE") && atoi(getenv("S2ST_NO_ACT_FUSE")) != 0);
   e->use_only_h = !(getenv("S2ST_NO_ONLY_H") && atoi(getenv("S2ST_NO_ONLY_H")) != 0);
   e->hoist_kv = !(getenv("S2ST_NO_KV_HOIST") && atoi(getenv("S2ST_NO_KV_HOIST")) != 0);
+  e->use_ln_fuse = !(getenv("S2ST_NO_LN_FUSE") && atoi(getenv("S2ST_NO_LN_FUSE")) != 0);
   e->use_attn_gfuse = getenv("S2ST_ATTN_GFUSE") && atoi(getenv("S2ST_ATTN_GFUSE")) != 0;
   e->build_params();
   if (!cfg->precise && (s2st_gemm_bf16_preload(nullptr) != 0 || s2st_flash_attn_preload(nullptr) != 0)) { delete e; return S2ST_ERR_LAUNCH; }

@@ -69,11 +69,21 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 
 constexpr int LNB_WAVES = 8;  // 512-thread blocks: 2 waves per SIMD keep enough loads in flight (HBM-bound)
 
+// FUSE: the input x of this layer norm is the output of a linear layer with dropout (x = resid + dropout(h W^T + b)),
+// and this backward completes x's gradient: the kernel then also emits that layer's backward prologue -- the bf16
+// GEMM operand dropout'(dx_total) (mask regenerated from (seed, element index)) and its column sums for the bias
+// gradient (a third row of partials) -- instead of a separate pass over dx.
+template <bool FUSE>
 __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
-    int dx_accumulate, float* __restrict__ part, int rows, int cols) {
-  __shared__ float red[2][LNB_WAVES][LN_MAXV * 64];  // [dgamma|dbeta][wave][float4 slot]
+    int dx_accumulate, float* __restrict__ part, int rows, int cols, uint16_t* __restrict__ dph, float drop_p,
+    float inv_keep, uint64_t seed) {
+  constexpr int NOUT = FUSE ? 3 : 2;
+  __shared__ float red[2][LNB_WAVES][LN_MAXV * 64];  // [dgamma|dbeta][wave][float4 slot] (reused for the third row)
+  float4 adb[FUSE ? LN_MAXV : 1];
+#pragma unroll
+  for (int i = 0; i < (FUSE ? LN_MAXV : 1); ++i) adb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = cols >> 2;
   const float invc = 1.f / cols;
@@ -140,6 +150,13 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
             o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
           }
           reinterpret_cast<float4*>(dxr)[c4] = o;
+          if (FUSE) {
+            const uint64_t e0 = (uint64_t)(row0 + u * stride) * cols + 4 * c4;
+            o.x *= drop_scale(seed, e0, drop_p, inv_keep); o.y *= drop_scale(seed, e0 + 1, drop_p, inv_keep);
+            o.z *= drop_scale(seed, e0 + 2, drop_p, inv_keep); o.w *= drop_scale(seed, e0 + 3, drop_p, inv_keep);
+            reinterpret_cast<uint2*>(dph + (long)(row0 + u * stride) * cols)[c4] = pack_bf16x4(o.x, o.y, o.z, o.w);
+            adb[i].x += o.x; adb[i].y += o.y; adb[i].z += o.z; adb[i].w += o.w;
+          }
         }
       }
     }
@@ -162,11 +179,26 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
       float gsum = 0.f, bsum = 0.f;
 #pragma unroll
       for (int w = 0; w < LNB_WAVES; ++w) { gsum += rg[w * WSTRIDE + c4]; bsum += rb[w * WSTRIDE + c4]; }
-      // per-block partials: [block][2][cols]
-      part[((long)blockIdx.x * 2 + 0) * cols + c4 * 4 + comp] = gsum;
-      part[((long)blockIdx.x * 2 + 1) * cols + c4 * 4 + comp] = bsum;
+      // per-block partials: [block][NOUT][cols]
+      part[((long)blockIdx.x * NOUT + 0) * cols + c4 * 4 + comp] = gsum;
+      part[((long)blockIdx.x * NOUT + 1) * cols + c4 * 4 + comp] = bsum;
     }
     __syncthreads();
+    if (FUSE) {
+#pragma unroll
+      for (int i = 0; i < LN_MAXV; ++i) {
+        int c4 = lane + 64 * i;
+        rg[wave * WSTRIDE + c4] = comp == 0 ? adb[i].x : comp == 1 ? adb[i].y : comp == 2 ? adb[i].z : adb[i].w;
+      }
+      __syncthreads();
+      for (int c4 = threadIdx.x; c4 < nv; c4 += 64 * LNB_WAVES) {
+        float dsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < LNB_WAVES; ++w) dsum += rg[w * WSTRIDE + c4];
+        part[((long)blockIdx.x * NOUT + 2) * cols + c4 * 4 + comp] = dsum;
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -176,13 +208,14 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
 __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ part,
                                                                    int nblocks, int cols,
                                                                    float* __restrict__ dgamma,
-                                                                   float* __restrict__ dbeta) {
+                                                                   float* __restrict__ dbeta, int nout,
+                                                                   float* __restrict__ dbias) {
   __shared__ float red[8][32];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + tx;  // over 2 * cols
-  const long ld = 2L * cols;
+  const int c = blockIdx.x * 32 + tx;  // over nout * cols
+  const long ld = (long)nout * cols;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  if (c < 2 * cols) {
+  if (c < nout * cols) {
     int b = ty;
     for (; b + 24 < nblocks; b += 32) {
       a0 += part[(long)b * ld + c];
@@ -194,12 +227,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* 
   }
   red[ty][tx] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  if (ty == 0 && c < 2 * cols) {
+  if (ty == 0 && c < nout * cols) {
     float v = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) v += red[i][tx];
     if (c < cols) dgamma[c] += v;
-    else dbeta[c - cols] += v;
+    else if (c < 2 * cols) dbeta[c - cols] += v;
+    else if (dbias) dbias[c - 2 * cols] += v;
   }
 }
 
@@ -371,21 +405,32 @@ int s2st_layernorm_bwd_blocks(int rows) {
   return blocks > 512 ? 512 : (blocks < 1 ? 1 : blocks);
 }
 
-// scratch: s2st_layernorm_bwd_blocks(rows) * 2 * cols floats
+// scratch: s2st_layernorm_bwd_blocks(rows) * (dph ? 3 : 2) * cols floats.
+// dph != null: fused backward prologue of the linear layer that produced x (see the kernel): dph [rows][cols] bf16 =
+// dropout'(dx_total) with the (seed, p) mask, dbias += its column sums (may be null).
 int s2st_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                        const float* rstd, float* dx, int dx_accumulate, float* dgamma,
-                       float* dbeta, float* scratch, int rows, int cols, hipStream_t st, int phase) {
+                       float* dbeta, float* scratch, int rows, int cols, hipStream_t st, int phase,
+                       uint16_t* dph, float drop_p, uint64_t seed, float* dbias) {
   if (rows <= 0) return 0;
   if (cols % 4 != 0 || cols > LN_MAXV * 256) return S2ST_ERR_SHAPE;
+  if (dph && ((uintptr_t)dph % 8 || drop_p < 0.f || drop_p >= 1.f)) return S2ST_ERR_ARG;
   int blocks = s2st_layernorm_bwd_blocks(rows);
-  // phase 0: both kernels; 1: only dx + per-block partials; 2: only the dgamma / dbeta reduce (lets the
-  // caller put the parameter-gradient reduce on another stream: it is off the backward's critical path)
-  if (phase != 2)
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(64 * LNB_WAVES), 0, st, dy, x, gamma, mean,
-                       rstd, dx, dx_accumulate, scratch, rows, cols);
-  if (phase != 1)
-    hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * cols + 31) / 32), dim3(256), 0, st,
-                       (const float*)scratch, blocks, cols, dgamma, dbeta);
+  // phase 0: both kernels; 1: only dx + per-block partials; 2: only the parameter-gradient reduce (lets the
+  // caller put that reduce on another stream: it is off the backward's critical path)
+  if (phase != 2) {
+    if (dph)
+      hipLaunchKernelGGL(layernorm_bwd_kernel<true>, dim3(blocks), dim3(64 * LNB_WAVES), 0, st, dy, x, gamma, mean,
+                         rstd, dx, dx_accumulate, scratch, rows, cols, dph, drop_p, 1.f / (1.f - drop_p), seed);
+    else
+      hipLaunchKernelGGL(layernorm_bwd_kernel<false>, dim3(blocks), dim3(64 * LNB_WAVES), 0, st, dy, x, gamma, mean,
+                         rstd, dx, dx_accumulate, scratch, rows, cols, (uint16_t*)nullptr, 0.f, 1.f, (uint64_t)0);
+  }
+  if (phase != 1) {
+    const int nout = dph ? 3 : 2;
+    hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((nout * cols + 31) / 32), dim3(256), 0, st,
+                       (const float*)scratch, blocks, cols, dgamma, dbeta, nout, dbias);
+  }
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 

@@ -64,10 +64,12 @@ int s2st_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
                        float* mean, float* rstd, int rows, int cols, float eps, hipStream_t st,
                        uint16_t* yh = nullptr /* optional bf16 copy of y */);
 // dx (=|+=) ...; dgamma += , dbeta += (per-block partials in `scratch`, then a reduce kernel)
-int s2st_layernorm_bwd_blocks(int rows);  // scratch floats = blocks * 2 * cols
+int s2st_layernorm_bwd_blocks(int rows);  // scratch floats = blocks * (dph ? 3 : 2) * cols
+// dph: optional fused backward prologue of the linear+dropout layer that produced x (rowops.hip)
 int s2st_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                        const float* rstd, float* dx, int dx_accumulate, float* dgamma,
-                       float* dbeta, float* scratch, int rows, int cols, hipStream_t st, int phase = 0);
+                       float* dbeta, float* scratch, int rows, int cols, hipStream_t st, int phase = 0,
+                       uint16_t* dph = nullptr, float drop_p = 0.f, uint64_t seed = 0, float* dbias = nullptr);
 
 // attention probabilities: p = softmax(s + masks) rows of [B, H, T, S(ld)]
 //   key mask: col >= klen[b] -> -inf ; causal: col > row -> -inf
