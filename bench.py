@@ -209,8 +209,13 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    step_ev = []
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
+        if os.environ.get('S2ST_BENCH_VERBOSE'):  # per-step GPU time (event per step end; not part of the metric)
+            e_ = torch.cuda.Event(enable_timing=True)
+            e_.record()
+            step_ev.append(e_)
     t_issue = time.perf_counter() - t0  # host time to enqueue the steps (GPU-bound if << dt)
     torch.cuda.synchronize()
     if world > 1:
@@ -218,6 +223,9 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     vlog('timed region', dt, 'host issue time', t_issue)
+    if step_ev:
+        vlog('per-step GPU ms (mel frames):', ' '.join('%.2f(%d)' % (step_ev[j - 1].elapsed_time(step_ev[j]), frames[args.warmup + j])
+                                                     for j in range(1, len(step_ev))))
     my_frames = float(sum(frames[args.warmup:]))
     my_flops = 3.0 * 2.0 * sum(macs[args.warmup:])  # fwd + bwd = 3 x fwd, 2 FLOP per MAC
     stat = torch.tensor([dt, my_frames, my_flops], dtype=torch.float64, device=dev)

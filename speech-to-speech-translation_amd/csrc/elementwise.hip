@@ -28,6 +28,17 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict_
       reinterpret_cast<const float4*>(x + split_off(xsp, r))[c];
 }
 
+// bf16 rows (4 elements = 8 bytes per thread)
+__global__ __launch_bounds__(256) void copy_rows_bf16_kernel(const uint16_t* __restrict__ x, Split xsp,
+                                                             uint16_t* __restrict__ y, Split ysp, int rows,
+                                                             int C4) {
+  long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  long n = (long)rows * C4;
+  if (i >= n) return;
+  int r = (int)(i / C4), c = (int)(i - (long)r * C4);
+  reinterpret_cast<uint2*>(y + split_off(ysp, r))[c] = reinterpret_cast<const uint2*>(x + split_off(xsp, r))[c];
+}
+
 // fp32 [rows][cols] (row stride ldx) -> bf16 [rows][ldy], columns [cols, ldy) zero-filled.
 // One thread per 4 output columns (ldy % 4 == 0); 16-byte loads when the source row allows.
 __global__ __launch_bounds__(256) void cast_bf16_rows_kernel(const float* __restrict__ x, long ldx,
@@ -82,7 +93,7 @@ __global__ __launch_bounds__(256) void glu_fwd_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ a,
                                                       const float* __restrict__ dy, Split dysp,
                                                       float* __restrict__ da, Split dasp, int rows,
-                                                      int C) {
+                                                      int C, uint16_t* __restrict__ dah, long ldh) {
   long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
   long n = (long)rows * C;
   if (i >= n) return;
@@ -91,8 +102,14 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
   float g = dy[split_off(dysp, r) + c];
   float s = sigmoidf_(ar[c + C]);
   float* dr = da + split_off(dasp, r);
-  dr[c] = g * s;
-  dr[c + C] = g * ar[c] * s * (1.f - s);
+  const float d0 = g * s, d1 = g * ar[c] * s * (1.f - s);
+  dr[c] = d0;
+  dr[c + C] = d1;
+  if (dah) {  // bf16 twin (the conv backward's GEMM operand)
+    const unsigned pk = pack_bf16x4(d0, d1, 0.f, 0.f).x;
+    dah[(long)r * ldh + c] = (uint16_t)(pk & 0xffffu);
+    dah[(long)r * ldh + c + C] = (uint16_t)(pk >> 16);
+  }
 }
 
 __global__ __launch_bounds__(256) void add_pe_kernel(const float* __restrict__ x,
@@ -259,7 +276,8 @@ __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long 
 __global__ __launch_bounds__(256) void conv_w_permute_kernel(const float* __restrict__ w,
                                                              float* __restrict__ wf,
                                                              float* __restrict__ wd, int O, int I,
-                                                             int Kw) {
+                                                             int Kw, uint16_t* __restrict__ wfh,
+                                                             uint16_t* __restrict__ wdh) {
   long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
   long n = (long)O * I * Kw;
   if (i >= n) return;
@@ -267,8 +285,11 @@ __global__ __launch_bounds__(256) void conv_w_permute_kernel(const float* __rest
   int c = (int)((i / Kw) % I);
   int o = (int)(i / ((long)Kw * I));
   float v = w[i];
+  const uint16_t vh = (uint16_t)(pack_bf16x4(v, 0.f, 0.f, 0.f).x & 0xffffu);  // bf16 twins of the same layouts
   if (wf) wf[((long)o * Kw + j) * I + c] = v;
   if (wd) wd[((long)c * Kw + (Kw - 1 - j)) * O + o] = v;
+  if (wfh) wfh[((long)o * Kw + j) * I + c] = vh;
+  if (wdh) wdh[((long)c * Kw + (Kw - 1 - j)) * O + o] = vh;
 }
 
 __global__ __launch_bounds__(256) void conv_w_unpermute_acc_kernel(const float* __restrict__ dwf,
@@ -438,7 +459,7 @@ struct BnBwdF {
 
 __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(BnBwdF f, const float* __restrict__ sums,
                                                         float* __restrict__ dx, Split dxsp,
-                                                        int rows, int C) {
+                                                        int rows, int C, uint16_t* __restrict__ dxh, long ldh) {
   long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
   long n = (long)rows * C;
   if (i >= n) return;
@@ -447,7 +468,9 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(BnBwdF f, const float* _
   float rstd = rsqrtf(f.var[c] + f.eps);
   float xh = (f.x[i] - f.mean[c]) * rstd;
   float inv = 1.f / rows;
-  dx[split_off(dxsp, r) + c] = f.gamma[c] * rstd * (v.x - sums[c] * inv - xh * sums[C + c] * inv);
+  const float d = f.gamma[c] * rstd * (v.x - sums[c] * inv - xh * sums[C + c] * inv);
+  dx[split_off(dxsp, r) + c] = d;
+  if (dxh) dxh[(long)r * ldh + c] = (uint16_t)(pack_bf16x4(d, 0.f, 0.f, 0.f).x & 0xffffu);  // bf16 twin
 }
 
 __global__ __launch_bounds__(256) void add_vec_kernel(const float* __restrict__ a,
@@ -466,6 +489,15 @@ int s2st_copy_rows(const float* x, Split xsp, float* y, Split ysp, int rows, int
   if (C % 4) return S2ST_ERR_SHAPE;
   long n = (long)rows * (C / 4);
   hipLaunchKernelGGL(copy_rows_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, xsp, y, ysp, rows, C / 4);
+  return LAUNCH_OK();
+}
+
+int s2st_copy_rows_bf16(const uint16_t* x, Split xsp, uint16_t* y, Split ysp, int rows, int C, hipStream_t st) {
+  if (rows <= 0 || C <= 0) return 0;
+  if (C % 4 || xsp.ld % 4 || ysp.ld % 4 || xsp.bs % 4 || ysp.bs % 4 || ((uintptr_t)x % 8) || ((uintptr_t)y % 8))
+    return S2ST_ERR_SHAPE;
+  long n = (long)rows * (C / 4);
+  hipLaunchKernelGGL(copy_rows_bf16_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, xsp, y, ysp, rows, C / 4);
   return LAUNCH_OK();
 }
 
@@ -492,10 +524,10 @@ int s2st_glu_fwd(const float* a, float* y, Split ysp, int rows, int C, hipStream
 }
 
 int s2st_glu_bwd(const float* a, const float* dy, Split dysp, float* da, Split dasp, int rows,
-                 int C, hipStream_t st) {
+                 int C, hipStream_t st, uint16_t* dah, long ldh) {
   long n = (long)rows * C;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(glu_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, a, dy, dysp, da, dasp, rows, C);
+  hipLaunchKernelGGL(glu_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, a, dy, dysp, da, dasp, rows, C, dah, ldh);
   return LAUNCH_OK();
 }
 
@@ -580,10 +612,11 @@ int s2st_scale(float* x, long n, float a, hipStream_t st) {
   return LAUNCH_OK();
 }
 
-int s2st_conv_w_permute(const float* w, float* wf, float* wd, int O, int I, int Kw, hipStream_t st) {
+int s2st_conv_w_permute(const float* w, float* wf, float* wd, int O, int I, int Kw, hipStream_t st, uint16_t* wfh,
+                        uint16_t* wdh) {
   long n = (long)O * I * Kw;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(conv_w_permute_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, w, wf, wd, O, I, Kw);
+  hipLaunchKernelGGL(conv_w_permute_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, w, wf, wd, O, I, Kw, wfh, wdh);
   return LAUNCH_OK();
 }
 
@@ -622,13 +655,13 @@ int s2st_bn_apply(const float* x, const float* mean, const float* var, const flo
 int s2st_bn_bwd(const float* dy, Split dysp, const float* x, const float* mean, const float* var,
                 const float* gamma, const float* beta, float* dx, Split dxsp, float* dgamma,
                 float* dbeta, float* tmp, int rows, int C, float eps, int tanh_, float drop_p,
-                uint64_t seed, hipStream_t st) {
+                uint64_t seed, hipStream_t st, uint16_t* dxh, long ldh) {
   long n = (long)rows * C;
   if (n <= 0) return 0;
   BnBwdF f{dy, dysp, x, mean, var, gamma, beta, C, eps, tanh_, drop_p, seed};
   // sums of dy' and dy' * xhat; the fold also adds them to the parameter gradients
   int rc = colreduce2(f, rows, C, tmp, tmp + C, tmp + 2 * (long)C, st, dbeta, dgamma);
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, f, tmp, dx, dxsp, rows, C);
+  hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, f, tmp, dx, dxsp, rows, C, dxh, ldh);
   return LAUNCH_OK();
 }

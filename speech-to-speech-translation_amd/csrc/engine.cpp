@@ -783,15 +783,23 @@ struct s2st_engine {
       }
       if (in2.src && in2.src->needs_grad) {
         // dz placed at rows pad + stride*t of a zeroed [B][Tin + 2 pad][O] image
-        float* up = alloc((long)B * Th * pp.O, true);
+        // fast mode builds the image directly in bf16 from dz's bf16 twin (no fp32 image, no cast pass)
+        const bool direct = fm && pp.O % 8 == 0;
+        float* up = direct ? nullptr : alloc((long)B * Th * pp.O, true);
+        bf16raw* upd = direct ? alloc_h((long)B * Th * pp.O) : nullptr;
         bool acc;
         float* dx = gradbuf(in2.src, acc);
         if (live()) {
           Split xs{(long)pp.O, 0, 0, 0};
           Split ys{(long)stride * pp.O, (long)Th * pp.O, Tout, 0};
-          chk(s2st_copy_rows(z->g, xs, up + (long)pad * pp.O, ys, M, pp.O, st_));
+          if (direct) {
+            hipMemsetAsync(upd, 0, sizeof(bf16raw) * (size_t)B * Th * pp.O, st_);
+            chk(s2st_copy_rows_bf16(dzh, xs, upd + (long)pad * pp.O, ys, M, pp.O, st_));
+          } else {
+            chk(s2st_copy_rows(z->g, xs, up + (long)pad * pp.O, ys, M, pp.O, st_));
+          }
         }
-        const bf16raw* uph = fm ? cast_buf(up, (long)B * Th * pp.O) : nullptr;
+        const bf16raw* uph = direct ? upd : (fm ? cast_buf(up, (long)B * Th * pp.O) : nullptr);
         if (live()) {
           GemmArgs g{};  // dx[(b,u)][c] = sum_(j',o) up[b][u + j'][o] * Wd[c][j'][o]
           g.A = fm ? gemm_rowmajor(uph, pp.O) : gemm_rowmajor(up, pp.O);
@@ -820,7 +828,8 @@ struct s2st_engine {
       float* dz = gradbuf(z, acc);
       (void)acc;  // single consumer
       Split ds{(long)Cc, 0, 0, 0}, das{(long)2 * Cc, 0, 0, 0};
-      if (live()) chk(s2st_glu_bwd(z->d, holder->g, ds, dz, das, z->rows, Cc, st_));
+      if (fast() && !z->gh) z->gh = alloc_h((long)z->rows * z->hld());  // the conv backward's GEMM operand
+      if (live()) chk(s2st_glu_bwd(z->d, holder->g, ds, dz, das, z->rows, Cc, st_, z->gh, z->hld()));
     });
     return holder;
   }
@@ -938,9 +947,11 @@ struct s2st_engine {
     s.wf = alloc(n);
     s.wd = need_wd ? alloc(n) : nullptr;
     s.dwf = alloc(n, tr);
-    if (live()) chk(s2st_conv_w_permute(P + p.w, s.wf, s.wd, p.O, p.I, p.Kw, st_));
-    s.wfh = fm ? cast_buf(s.wf, n) : nullptr;
-    s.wdh = fm && need_wd ? cast_buf(s.wd, n) : nullptr;
+    bf16raw* wfh = fm ? alloc_h((n + 7) / 8 * 8) : nullptr;
+    bf16raw* wdh = fm && need_wd ? alloc_h((n + 7) / 8 * 8) : nullptr;
+    if (live()) chk(s2st_conv_w_permute(P + p.w, s.wf, s.wd, p.O, p.I, p.Kw, st_, wfh, wdh));
+    s.wfh = wfh;
+    s.wdh = wdh;
     return s;
   }
 
@@ -1001,9 +1012,10 @@ struct s2st_engine {
         float* dz = gradbuf(z, acc);
         (void)acc;
         Split ps{(long)bnp.C, 0, 0, 0};
+        if (fast() && !z->gh) z->gh = alloc_h((long)z->rows * z->hld());  // the conv backward's GEMM operand
         if (live())
           chk(s2st_bn_bwd(out->g, ps, z->d, mean, var, P + bnp.g, P + bnp.b, dz, ps, G + bnp.g, G + bnp.b,
-                          bn_tmp, B * D, bnp.C, 1e-5f, last ? 0 : 1, pdrop, sd, st_));
+                          bn_tmp, B * D, bnp.C, 1e-5f, last ? 0 : 1, pdrop, sd, st_, z->gh, z->hld()));
       });
       cur = out;
       curh = nexth;

@@ -99,12 +99,13 @@ int s2st_attn_headmean(const float* p, float* out, int B, int H, int T, int S, i
 int s2st_cast_bf16_rows(const float* x, long ldx, uint16_t* y, long ldy, long rows, int cols, hipStream_t st);
 int s2st_transpose_bf16(const uint16_t* x, uint16_t* y, int R, int C, hipStream_t st);  // [R][C] -> [C][R]
 // copy [rows][C] between split-addressed buffers (halo padding, zero-stuffing); C % 4 == 0
+int s2st_copy_rows_bf16(const uint16_t* x, Split xsp, uint16_t* y, Split ysp, int rows, int C, hipStream_t st);
 int s2st_copy_rows(const float* x, Split xsp, float* y, Split ysp, int rows, int C,
                    hipStream_t st);
 // y[r][c] = a[r][c] * sigmoid(a[r][c + C])   a: [rows][2C] plain ; y rows via split
 int s2st_glu_fwd(const float* a, float* y, Split ysp, int rows, int C, hipStream_t st);
 int s2st_glu_bwd(const float* a, const float* dy, Split dysp, float* da, Split dasp, int rows,
-                 int C, hipStream_t st);
+                 int C, hipStream_t st, uint16_t* dah = nullptr /* optional bf16 twin [rows][ldh] */, long ldh = 0);
 // y[r][:] = dropout(scale * x[r][:] + alpha * table[pos[r]][:])   (alpha = *alpha_ptr or 1)
 int s2st_add_pe(const float* x, float* y, const int* pos, const float* table, int rows, int C,
                 float scale, const float* alpha_ptr, float drop_p, uint64_t seed, hipStream_t st);
@@ -131,8 +132,8 @@ int s2st_axpy(const float* x, float* y, long n, float a, hipStream_t st);  // y 
 int s2st_scale(float* x, long n, float a, hipStream_t st);
 // conv weight W[O][I][Kw] -> Wf[O][Kw][I] (forward GEMM layout) and, if wd != null,
 // Wd[I][Kw-1-j][O] (flipped; data-gradient GEMM layout)
-int s2st_conv_w_permute(const float* w, float* wf, float* wd, int O, int I, int Kw,
-                        hipStream_t st);
+int s2st_conv_w_permute(const float* w, float* wf, float* wd, int O, int I, int Kw, hipStream_t st,
+                        uint16_t* wfh = nullptr, uint16_t* wdh = nullptr /* optional bf16 twins */);
 // dW[O][I][Kw] += dWf[O][Kw][I]
 int s2st_conv_w_unpermute_acc(const float* dwf, float* dw, int O, int I, int Kw, hipStream_t st);
 // BatchNorm1d in training mode over [rows][C] (rows = ALL B*T positions, padded included,
@@ -147,7 +148,8 @@ int s2st_bn_apply(const float* x, const float* mean, const float* var, const flo
 int s2st_bn_bwd(const float* dy, Split dysp, const float* x, const float* mean, const float* var,
                 const float* gamma, const float* beta, float* dx, Split dxsp, float* dgamma,
                 float* dbeta, float* tmp, int rows, int C, float eps, int tanh_, float drop_p,
-                uint64_t seed, hipStream_t st);
+                uint64_t seed, hipStream_t st, uint16_t* dxh = nullptr /* optional bf16 twin [rows][ldh] */,
+                long ldh = 0);
 
 // ---------------------------------------------------------------------------------------
 // fused attention (attention.hip)
