@@ -40,6 +40,10 @@ struct Worker {
   int bar_arrived = 0;
   void (*tramp)(void*) = nullptr;
   void* args = nullptr;
+  // launches run on short-lived threads, each with its own thread_local Worker: the fiber stacks must go with it
+  ~Worker() {
+    for (Fiber& f : fibers) free(f.stack);
+  }
 };
 thread_local Worker* W = nullptr;
 
