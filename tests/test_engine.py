@@ -265,8 +265,6 @@ def test_fused_backward_paths_equal_the_unfused_ones(backend, cfg, switch, monke
     emits the preceding linear layer's dropout-backward operand + bias gradient, the hoisted cross-attention
     K|V projections, the ReLU-dropout backward in the data-gradient GEMM epilogue.  Same masks, same bf16
     operands: the gradients agree to fp32 summation order."""
-    if backend.kind == "emu" and (cfg is MICRO_POSTLN or switch == "S2ST_NO_ACT_FUSE"):
-        pytest.skip("the emulator runs the pre-LN layer-norm / K|V cases; all six run on the GPU")
     D = importlib.import_module(DATA)
     cfg = dict(cfg, dropout=0.1, attention_dropout=0.1, activation_dropout=0.05, prenet_dropout=0.5, postnet_dropout=0.5)
     c = D.SyntheticFisherCorpus(n_utts=4, seed=3, max_src=64, median_src=50, min_src=30)
