@@ -95,3 +95,56 @@ def test_two_rank_update_equals_single_process():
     for n, p in m.named_parameters():
         ref = p.detach()
         assert float((torch.from_numpy(params[n]) - ref).abs().max()) < 1e-3 * (float(ref.abs().max()) + 1e-6), n
+
+
+@pytest.mark.gpu
+def test_rccl_reducer_path_on_one_gpu(monkeypatch):
+    """Only one GPU is available to the tests, so the RCCL leg of the data-parallel path is driven with a
+    one-rank process group and `is_dist` forced on: parameter broadcast, segment-wise all-reduce on the
+    reducer's stream behind BOTH engine streams (the second one through torch.cuda.ExternalStream), the
+    device-side sample-size exchange and the fused scale/clip/Adam must reproduce the plain single-process
+    update (a SUM over one rank is the identity)."""
+    assert torch.cuda.is_available(), "gpu-marked test needs a HIP device"
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import s2st_amd  # noqa: F401
+    import s2st_oracle as O
+    from configs import CONFIGS
+    from synth_weights import synth_tensor
+    tasks = importlib.import_module(PKG + ".tasks")
+    tr = importlib.import_module(PKG + ".trainer")
+    dm = importlib.import_module(PKG + ".runtime.distributed")
+    D = importlib.import_module(PKG + ".data")
+    dev = torch.device("cuda", 0)
+    corpus = D.SyntheticFisherCorpus(n_utts=64, seed=5, max_src=400, median_src=200)
+    batches = [corpus.collate_batch(range(0, 16)), corpus.collate_batch(range(16, 32))]
+
+    def run(distributed):
+        a = O.make_args(**CONFIGS["base_recipe"])
+        a.lr, a.warmup_updates, a.clip_norm, a.seed = 1.5e-3, 4000, 1.0, 1
+        task = tasks.S2ST_TranslationTask.setup_task(a, device=dev)
+        model = task.build_model(a)
+        for name, pv, gv, isb in model.engine.named_views():
+            pv.copy_(torch.from_numpy(synth_tensor(name, tuple(pv.shape), 0)))
+        trainer = tr.Trainer(a, task, model, task.build_criterion(a))
+        assert (trainer.reducer is not None) == distributed
+        if distributed:
+            trainer.reducer.min_bucket = 1 << 20  # several buckets
+        for b in batches:
+            r = trainer.train_step([b])
+        torch.cuda.synchronize()
+        return model.engine.params.clone(), float(r["gnorm"])
+
+    p_ref, g_ref = run(False)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (29600 + os.getpid() % 2000), rank=0,
+                            world_size=1, device_id=dev)
+    try:
+        monkeypatch.setattr(dm, "is_dist", lambda: True)
+        monkeypatch.setattr(tr, "is_dist", lambda: True)
+        p_ddp, g_ddp = run(True)
+    finally:
+        dist.destroy_process_group()
+    assert abs(g_ddp - g_ref) <= 1e-5 * g_ref
+    assert float((p_ddp - p_ref).abs().max()) <= 1e-6
