@@ -187,8 +187,10 @@ int s2st_ctc_f32(const float* logits, const int64_t* targets, int32_t Lmax, cons
 /* fairseq/utils.py:345-385 gradient L2 norm (sum of squares, out +=) */
 int s2st_sumsq_f32(const float* x, int64_t n, float* out, void* stream);
 
-/* trainer.py:838-873 + adam.py:163-239: grad scale (gmul * *gmul_dev), clip-by-norm, fairseq Adam on a flat arena */
-int s2st_adam_f32(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float gmul, const float* gmul_dev, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int32_t step, float* gnorm_out, void* stream);
+/* trainer.py:838-873 + adam.py:163-239: grad scale (gmul * *gmul_dev), clip-by-norm, fairseq Adam on a flat arena.
+ * p_bf16 (optional): bf16 copy of the updated parameters (the GEMM-operand copy of the next forward, see
+ * s2st_engine_bind_bf16 / s2st_engine_bf16_is_fresh) */
+int s2st_adam_f32(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float gmul, const float* gmul_dev, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int32_t step, float* gnorm_out, void* p_bf16, void* stream);
 
 /* floats of workspace s2st_ctc_f32 needs */
 int64_t s2st_ctc_workspace(int32_t B, int32_t E, int32_t Lmax);
@@ -290,6 +292,9 @@ int s2st_engine_bind(s2st_engine* e, float* params, float* grads, float* buffers
 /* fast (precise == 0) mode only: caller-owned bf16 arena of param_floats elements; the engine
  * refreshes it from `params` at the start of every forward and feeds the GEMMs from it */
 int s2st_engine_bind_bf16(s2st_engine* e, uint16_t* params_bf16);
+/* The caller states that the bf16 arena already equals bf16(params) (s2st_adam_f32 wrote it with the update):
+ * the NEXT forward skips its refresh pass.  One-shot: any later forward refreshes again unless told anew. */
+int s2st_engine_bf16_is_fresh(s2st_engine* e);
 /* optional second bf16 arena (param_floats elements): every training forward stores W^T of each 2-D
  * weight there (on the engine's second stream) so the data-gradient GEMMs read K-contiguous operands */
 int s2st_engine_bind_bf16_transposed(s2st_engine* e, uint16_t* params_bf16_t);

@@ -139,6 +139,7 @@ struct s2st_engine {
   float* ws_for(hipStream_t s) const { return (side_ && s == side_) ? skws_side : skws; }
   float* skws = nullptr;  // split-K partial-sum scratch of the weight-gradient GEMMs (per call)
   long skws_n = 0;
+  bool ph_fresh = false;   // s2st_engine_bf16_is_fresh: PH already equals bf16(P) for the next forward
   bf16raw* PHT = nullptr;  // optional: transposed bf16 copies of the 2-D weights (same offsets): the
                            // data-gradient GEMMs then read K-contiguous operands (~25 % faster here)
   bool pht_valid = false;
@@ -1172,7 +1173,10 @@ struct s2st_engine {
     const bool fm = fast();
     if (fm && !PH && !dry) return S2ST_ERR_ARG;
     // bf16 copy of the whole parameter arena (292 MB read + 146 MB written: ~0.08 ms)
-    if (fm && live()) chk(s2st_cast_bf16_rows(P, n_params, PH, n_params, 1, (int)n_params, st_));
+    if (fm && live()) {
+      if (!ph_fresh) chk(s2st_cast_bf16_rows(P, n_params, PH, n_params, 1, (int)n_params, st_));
+      ph_fresh = false;
+    }
     // transposed weight copies for the backward, made on the second stream (idle during the forward)
     pht_valid = false;
     if (fm && tr && PHT && live()) {
@@ -1484,6 +1488,12 @@ int s2st_engine_bind(s2st_engine* e, float* params, float* grads, float* buffers
 
 int s2st_engine_bind_bf16(s2st_engine* e, uint16_t* params_bf16) {
   e->PH = params_bf16;
+  return 0;
+}
+
+int s2st_engine_bf16_is_fresh(s2st_engine* e) {
+  if (!e || !e->PH) return S2ST_ERR_ARG;
+  e->ph_fresh = true;
   return 0;
 }
 

@@ -29,29 +29,37 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 // gnorm = sqrt(sumsq) * gmul ; coef = max_norm > 0 ? min(1, max_norm / (gnorm + 1e-6)) : 1
 // g' = g * gmul * coef ; m = b1 m + (1-b1) g' ; v = b2 v + (1-b2) g'^2
 // p -= lr*wd*p ; p -= lr * sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)
+// ph (optional): bf16 copy of the updated parameters -- the GEMM operand copy the next forward would otherwise
+// make with a separate pass over the arena
+__device__ __forceinline__ float adam_one(float& g, float& m, float& v, float p, float coef, float b1, float b2,
+                                          float eps, float wd_lr, float step_size) {
+  g *= coef;
+  m = b1 * m + (1.f - b1) * g;
+  v = b2 * v + (1.f - b2) * g * g;
+  if (wd_lr != 0.f) p -= wd_lr * p;
+  return p - step_size * m / (sqrtf(v) + eps);
+}
+// One element per thread and iteration, 1024 blocks: ~5.2 TB/s over the 32 (+2) bytes per parameter -- the kernel is
+// HBM-bound; a float4 form and other grid sizes measured the same or slower (tools/adam_bench.py).
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
-                                                   float* __restrict__ m, float* __restrict__ v,
-                                                   long n, const float* __restrict__ sumsq,
-                                                   float gmul, const float* __restrict__ gmul_dev,
-                                                   float max_norm, float lr, float b1, float b2, float eps,
-                                                   float wd, float step_size,
-                                                   float* __restrict__ gnorm_out) {
+                                                          float* __restrict__ m, float* __restrict__ v,
+                                                          long n, const float* __restrict__ sumsq,
+                                                          float gmul, const float* __restrict__ gmul_dev,
+                                                          float max_norm, float lr, float b1, float b2, float eps,
+                                                          float wd, float step_size,
+                                                          float* __restrict__ gnorm_out, uint16_t* __restrict__ ph) {
   if (gmul_dev) gmul *= gmul_dev[0];
   const float gn = sqrtf(sumsq[0]) * gmul;
   if (gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) gnorm_out[0] = gn;
-  if (!(gn < INFINITY)) return;  // inf / nan gradients: skip the update (trainer.py:860-867)
+  if (!(gn < INFINITY)) return;
   float coef = gmul;
   if (max_norm > 0.f) coef *= fminf(1.f, max_norm / (gn + 1e-6f));
+  const float wd_lr = wd * lr;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    float gi = g[i] * coef;
-    g[i] = gi;
-    float mi = b1 * m[i] + (1.f - b1) * gi;
-    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    float pi = p[i];
-    if (wd != 0.f) pi -= wd * lr * pi;
-    p[i] = pi - step_size * mi / (sqrtf(vi) + eps);
+    float gi = g[i], mi = m[i], vi = v[i];
+    const float pi = adam_one(gi, mi, vi, p[i], coef, b1, b2, eps, wd_lr, step_size);
+    g[i] = gi; m[i] = mi; v[i] = vi; p[i] = pi;
+    if (ph) ph[i] = (uint16_t)(pack_bf16x4(pi, 0.f, 0.f, 0.f).x & 0xffffu);
   }
 }
 
@@ -68,13 +76,14 @@ int s2st_sumsq(const float* x, long n, float* out, hipStream_t st) {
 
 int s2st_adam(float* p, float* g, float* m, float* v, long n, const float* sumsq, float gmul,
               const float* gmul_dev, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step,
-              float* gnorm_out, hipStream_t st) {
+              float* gnorm_out, hipStream_t st, uint16_t* ph) {
   if (n <= 0) return 0;
   double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   float step_size = (float)((double)lr * sqrt(bc2) / bc1);
+  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 || (ph && (uintptr_t)ph % 8)) return S2ST_ERR_ARG;
   long blocks = (n + 256 * 4 - 1) / (256 * 4);
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, n, sumsq, gmul,
-                     gmul_dev, max_norm, lr, beta1, beta2, eps, wd, step_size, gnorm_out);
+                     gmul_dev, max_norm, lr, beta1, beta2, eps, wd, step_size, gnorm_out, ph);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }

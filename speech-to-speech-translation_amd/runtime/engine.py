@@ -348,6 +348,9 @@ class Engine:
         if c.has_ctc and with_loss:
             o["ctc_lprobs"] = buf(B, E, c.src_vocab)
             out.ctc_lprobs = o["ctc_lprobs"].data_ptr()
+        if self.params_bf16 is not None and getattr(self, "_ph_version", None) == self.params._version:
+            self.lib.s2st_engine_bf16_is_fresh(self.h)  # written by the optimizer kernel, parameters untouched since
+        self._ph_version = None
         rc = self.lib.s2st_engine_forward(self.h, C.byref(b), C.byref(out), self.workspace.data_ptr(),
                                           self.workspace.numel(), bd.stream_ptr())
         bd.check(rc, "s2st_engine_forward")
@@ -475,6 +478,12 @@ class Engine:
             self.workspace = torch.empty(int(need * 1.05) + 4096, dtype=torch.float32, device=self.device)
         if self._outpool is None or self._outpool.numel() < out:
             self._outpool = torch.empty(out, dtype=torch.float32, device=self.device)
+
+    def mark_bf16_fresh(self):
+        """The optimizer kernel just wrote ``params_bf16`` together with the update: remember the parameter
+        tensor's version so the next forward can skip its refresh pass -- unless something else (a state-dict
+        load, a manual copy_) touches ``params`` in between, which bumps the version."""
+        self._ph_version = self.params._version
 
     def side_stream(self):
         """torch view of the engine's second stream (None on the emulator / when disabled)."""

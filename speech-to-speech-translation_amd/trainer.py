@@ -54,6 +54,12 @@ class Trainer:
             torch.distributed.broadcast(self.engine.params, 0)
             torch.distributed.broadcast(self.engine.buffers, 0)
 
+    def _ph(self):
+        """bf16 parameter copy the optimizer kernel refreshes with the update (S2ST_ADAM_NO_PH=1: A/B switch,
+        the next forward then makes the copy itself)."""
+        import os
+        return None if os.environ.get("S2ST_ADAM_NO_PH") else self.engine.params_bf16
+
     def get_lr(self) -> float:
         return inverse_sqrt_lr(self.num_updates, self.lr, self.warmup)
 
@@ -96,7 +102,9 @@ class Trainer:
         lr = self.get_lr()
         bd.call("s2st_adam_f32", eng.params, eng.grads, self.exp_avg, self.exp_avg_sq, eng.n_params,
                 self.sumsq, gmul, gmul_dev, float(self.clip_norm), lr, self.betas[0], self.betas[1],
-                self.eps, self.wd, self.num_updates + 1, self.gnorm)
+                self.eps, self.wd, self.num_updates + 1, self.gnorm, self._ph())
+        if self._ph() is not None:
+            eng.mark_bf16_fresh()
         self.num_updates += 1
         self.model.set_num_updates(self.num_updates)
         return {"logs": logs, "sample_size": sample_size, "lr": lr, "gnorm": self.gnorm}

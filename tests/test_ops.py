@@ -356,8 +356,10 @@ def test_sumsq_adam(backend):
         ss = torch.zeros(1, device=backend.device)
         gno = torch.zeros(1, device=backend.device)
         backend.bd.call("s2st_sumsq_f32", gd, n, ss)
+        ph = torch.zeros(n, dtype=torch.bfloat16, device=backend.device)
         backend.bd.call("s2st_adam_f32", pd, gd, m, v, n, ss, 0.02, half, 0.5, 1e-2, 0.9, 0.999, 1e-8, 0.01,
-                        step, gno)
+                        step, gno, ph)
         backend.sync()
         close(gno, gn_ref.view(1), 1e-5, 1e-6)
         close(pd, pr.detach(), 1e-5, 1e-6)
+        assert torch.equal(ph, pd.to(torch.bfloat16))  # the fused bf16 copy == a cast of the new parameters
