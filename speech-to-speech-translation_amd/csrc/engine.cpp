@@ -1075,15 +1075,13 @@ struct s2st_engine {
     const int C0 = hc.conv_dim[0];
     int Tin = (N - hc.conv_k[0]) / hc.conv_stride[0] + 1;
     if (N < hc.conv_k[0] || Tin <= 0) return S2ST_ERR_SHAPE;
-    Ten* a = newT(B * Tin, C0);
-    float* csum = alloc((long)B * C0);
-    float* sq = alloc((long)B * C0);
+    // fast mode: conv1 only reads the bf16 copy, no fp32 activation is allocated or written
+    Ten* a = newT(B * Tin, C0, nullptr, !fm);
+    float* stats = alloc(2 * (long)B * C0);
     if (fm) a->h = alloc_h(a->n());
-    if (live()) {
-      chk(s2st_hubert_conv0(wave, P + hp.conv_w[0], a->d, csum, B, N, Tin, C0, hc.conv_k[0], hc.conv_stride[0], st_));
-      // fast mode: conv1 only reads the bf16 copy, the fp32 activation is not rewritten
-      chk(s2st_gn_gelu(a->d, csum, sq, P + hp.gn_g, P + hp.gn_b, a->h, B, Tin, C0, 1e-5f, fm ? 0 : 1, st_));
-    }
+    if (live())
+      chk(s2st_hubert_conv0_gn_gelu(wave, P + hp.conv_w[0], P + hp.gn_g, P + hp.gn_b, a->d, a->h, stats, B, N, Tin, C0,
+                                    hc.conv_k[0], hc.conv_stride[0], 1e-5f, st_));
     // conv_i + GELU as GEMMs over the channel-last activations (no padding: windows never cross utterances)
     for (int i = 1; i < hc.n_conv; ++i) {
       const int k = hc.conv_k[i], sd = hc.conv_stride[i], I = hc.conv_dim[i - 1], O = hc.conv_dim[i];

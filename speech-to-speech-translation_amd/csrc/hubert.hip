@@ -9,29 +9,52 @@
 
 namespace {
 
-// y[b][t][c] = sum_j w[c][j] * x[b][t * stride + j]     (no bias: conv_bias=False)
-// A workgroup owns CONV0_TT consecutive frames of one utterance and ALL channels: the samples it needs
-// sit in LDS (broadcast reads), a thread keeps the taps of its channels in registers and writes
-// coalesced rows.  Fused: per-(b, c) sums of the outputs (first GroupNorm pass) via one atomic per
-// channel per workgroup.
-constexpr int CONV0_TT = 32, CONV0_MAXK = 16, CONV0_CPT = 2;  // frames per block, max taps, channels per thread
-__global__ __launch_bounds__(256) void hubert_conv0_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                           float* __restrict__ y, float* __restrict__ csum, int B,
-                                                           int N, int T, int C, int k, int stride) {
-  __shared__ float xs[CONV0_TT * 8 + CONV0_MAXK];
-  const int b = blockIdx.y, t0 = blockIdx.x * CONV0_TT, tid = threadIdx.x;
-  const int nt = min(CONV0_TT, T - t0);
+// First block of the feature extractor, fused: y[b][t][c] = gelu(GroupNorm_c(conv0)[b][t][c]) with
+// conv0[b][t][c] = sum_j w[c][j] * x[b][t * stride + j] (no bias: conv_bias=False) and GroupNorm(C, C) statistics
+// over the T frames of each (utterance, channel).
+// The convolution has ONE input channel and k = 10 taps: recomputing it is ~30x cheaper than a round trip of its
+// [B][T][C] fp32 output through HBM (1.26 GB for 24 x 8 s of audio), and the waveform (12 MB) stays in L2.  So
+// the kernel runs three times over the waveform -- MODE 0: per-(b, c) sums; MODE 1: squared deviations from the
+// mean; MODE 2: normalise + GELU + store (bf16 copy for the next conv's GEMM and / or fp32) -- and the conv
+// output itself is never stored.  The three passes evaluate the same FMA chain, so the statistics are those of
+// exactly the values that get normalised.
+// A workgroup owns C0_TT consecutive frames of one utterance and ALL channels: the samples it needs sit in LDS
+// (broadcast reads), a thread keeps the taps of its two channels in registers and writes coalesced rows.
+constexpr int C0_TT = 128, CONV0_MAXK = 16, CONV0_CPT = 2;  // frames per block, max taps, channels per thread
+template <int MODE>
+__global__ __launch_bounds__(256) void hubert_conv0_gn_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              float* __restrict__ csum, float* __restrict__ sq,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ y,
+                                                              uint16_t* __restrict__ yh, int B, int N, int T, int C,
+                                                              int k, int stride, float eps) {
+  __shared__ float xs[C0_TT * 8 + CONV0_MAXK];
+  const int b = blockIdx.y, t0 = blockIdx.x * C0_TT, tid = threadIdx.x;
+  const int nt = min(C0_TT, T - t0);
   const int ns = (nt - 1) * stride + k;  // samples this block reads (stride <= 8 checked by the launcher)
   const float* xb = x + (long)b * N + (long)t0 * stride;
   for (int i = tid; i < ns; i += 256) xs[i] = xb[i];
   __syncthreads();
+  const float inv_t = 1.f / T;
   for (int c0 = tid * CONV0_CPT; c0 < C; c0 += 256 * CONV0_CPT) {
     float wr[CONV0_CPT][CONV0_MAXK];
 #pragma unroll
     for (int e = 0; e < CONV0_CPT; ++e)
 #pragma unroll
       for (int j = 0; j < CONV0_MAXK; ++j) wr[e][j] = j < k ? w[(long)(c0 + e) * k + j] : 0.f;
-    float sum[CONV0_CPT] = {0.f, 0.f};
+    float mu[CONV0_CPT] = {0.f, 0.f}, sc[CONV0_CPT] = {1.f, 1.f}, sh[CONV0_CPT] = {0.f, 0.f};
+    if (MODE >= 1) {
+#pragma unroll
+      for (int e = 0; e < CONV0_CPT; ++e) mu[e] = csum[(long)b * C + c0 + e] * inv_t;
+    }
+    if (MODE == 2) {
+#pragma unroll
+      for (int e = 0; e < CONV0_CPT; ++e) {
+        sc[e] = rsqrtf(sq[(long)b * C + c0 + e] * inv_t + eps) * gamma[c0 + e];
+        sh[e] = beta[c0 + e];
+      }
+    }
+    float acc[CONV0_CPT] = {0.f, 0.f};
     for (int t = 0; t < nt; ++t) {
       float a[CONV0_CPT] = {0.f, 0.f};
 #pragma unroll
@@ -42,73 +65,25 @@ __global__ __launch_bounds__(256) void hubert_conv0_kernel(const float* __restri
           for (int e = 0; e < CONV0_CPT; ++e) a[e] = fmaf(wr[e][j], xv, a[e]);
         }
       }
-      *reinterpret_cast<float2*>(y + ((long)b * T + t0 + t) * C + c0) = make_float2(a[0], a[1]);
+      if (MODE == 0) {
 #pragma unroll
-      for (int e = 0; e < CONV0_CPT; ++e) sum[e] += a[e];
-    }
-    if (csum) {
+        for (int e = 0; e < CONV0_CPT; ++e) acc[e] += a[e];
+      } else if (MODE == 1) {
 #pragma unroll
-      for (int e = 0; e < CONV0_CPT; ++e) atomicAdd(csum + (long)b * C + c0 + e, sum[e]);
-    }
-  }
-}
-
-// second GroupNorm pass, all utterances in one launch: sq[b][c] += sum_t (x[b][t][c] - mean[b][c])^2
-// (mean = csum / T).  grid (C / 256 * 4.., T slabs, B): a lane owns 4 channels, the 4 waves split the rows
-__global__ __launch_bounds__(256) void gn_sqdev_kernel(const float* __restrict__ x, const float* __restrict__ csum,
-                                                       float* __restrict__ sq, int T, int C, int rows_per_block) {
-  __shared__ float red[4][256];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.z;
-  const int c = blockIdx.x * 256 + lane * 4;
-  const int r0 = blockIdx.y * rows_per_block, r1 = min(T, r0 + rows_per_block);
-  float a[4] = {0.f, 0.f, 0.f, 0.f};
-  if (c < C) {
-    const float4 mu4 = *reinterpret_cast<const float4*>(csum + (long)b * C + c);
-    const float inv = 1.f / T;
-    const float mu[4] = {mu4.x * inv, mu4.y * inv, mu4.z * inv, mu4.w * inv};
-    for (int rb = r0 + wave; rb < r1; rb += 16) {
-      float4 v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int r = rb + 4 * u;
-        v[u] = r < r1 ? *reinterpret_cast<const float4*>(x + ((long)b * T + r) * C + c) : make_float4(mu[0], mu[1], mu[2], mu[3]);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float d0 = v[u].x - mu[0], d1 = v[u].y - mu[1], d2 = v[u].z - mu[2], d3 = v[u].w - mu[3];
-        a[0] += d0 * d0; a[1] += d1 * d1; a[2] += d2 * d2; a[3] += d3 * d3;
+        for (int e = 0; e < CONV0_CPT; ++e) { const float d = a[e] - mu[e]; acc[e] += d * d; }
+      } else {
+        const float o0 = gelu_erf((a[0] - mu[0]) * sc[0] + sh[0]), o1 = gelu_erf((a[1] - mu[1]) * sc[1] + sh[1]);
+        const long o = ((long)b * T + t0 + t) * C + c0;
+        if (y) *reinterpret_cast<float2*>(y + o) = make_float2(o0, o1);
+        if (yh) *reinterpret_cast<unsigned*>(yh + o) = pack_bf16x4(o0, o1, 0.f, 0.f).x;
       }
     }
-  }
+    if (MODE < 2) {
+      float* dst = MODE == 0 ? csum : sq;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) red[wave][lane * 4 + e] = a[e];
-  __syncthreads();
-  const int cc = blockIdx.x * 256 + threadIdx.x;
-  if (cc < C)
-    atomicAdd(sq + (long)b * C + cc, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
-}
-
-// y = gelu(gamma[c] * (x - mean[b][c]) * rsqrt(var[b][c] + eps) + beta[c]) in place (+ bf16 copy)
-// mean / var are given as sums over the T frames (csum, sq); `write_f32` = 0 keeps only the bf16 copy
-__global__ __launch_bounds__(256) void gn_gelu_kernel(float* __restrict__ x, const float* __restrict__ mean,
-                                                      const float* __restrict__ var, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, uint16_t* __restrict__ xh, int B,
-                                                      int T, int C, float eps, float inv_t, int write_f32) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  const int cq = C >> 2;
-  if (i >= (long)B * T * cq) return;
-  const int c = (int)(i % cq) * 4;
-  const long bt = i / cq;
-  const int b = (int)(bt / T);
-  float4 v = *reinterpret_cast<float4*>(x + bt * C + c);
-  float o[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float m = mean[(long)b * C + c + e] * inv_t, r = rsqrtf(var[(long)b * C + c + e] * inv_t + eps);
-    o[e] = gelu_erf((o[e] - m) * r * gamma[c + e] + beta[c + e]);
+      for (int e = 0; e < CONV0_CPT; ++e) atomicAdd(dst + (long)b * C + c0 + e, acc[e]);
+    }
   }
-  if (write_f32) *reinterpret_cast<float4*>(x + bt * C + c) = make_float4(o[0], o[1], o[2], o[3]);
-  if (xh) *reinterpret_cast<uint2*>(xh + bt * C + c) = pack_bf16x4(o[0], o[1], o[2], o[3]);
 }
 
 // x[b][t][:] = 0 for t >= lens[b] (in place), and the group-major, time-padded image
@@ -133,32 +108,22 @@ __global__ __launch_bounds__(256) void posconv_prep_kernel(float* __restrict__ x
 
 }  // namespace
 
-// conv0 + first GroupNorm pass: csum [B][C] (zeroed here) receives the per-utterance channel sums
-int s2st_hubert_conv0(const float* x, const float* w, float* y, float* csum, int B, int N, int T, int C, int k,
-                      int stride, hipStream_t st) {
-  if (C % 4 || k > CONV0_MAXK || stride > 8 || stride < 1) return S2ST_ERR_SHAPE;  // C % 4: the GroupNorm kernels
+// conv0 -> GroupNorm(C, C) over time -> GELU (see the kernel).  stats: scratch of 2 * B * C floats; y (fp32) and yh
+// (bf16), each optional, receive the [B][T][C] result.
+int s2st_hubert_conv0_gn_gelu(const float* x, const float* w, const float* gamma, const float* beta, float* y,
+                              uint16_t* yh, float* stats, int B, int N, int T, int C, int k, int stride, float eps,
+                              hipStream_t st) {
+  if (C % (2 * CONV0_CPT) || k > CONV0_MAXK || stride > 8 || stride < 1) return S2ST_ERR_SHAPE;
   if (B <= 0 || T <= 0) return 0;
-  if (csum) hipMemsetAsync(csum, 0, sizeof(float) * (size_t)B * C, st);
-  hipLaunchKernelGGL(hubert_conv0_kernel, dim3((T + CONV0_TT - 1) / CONV0_TT, B), dim3(256), 0, st, x, w, y, csum, B, N,
-                     T, C, k, stride);
-  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
-}
-
-// GroupNorm(C, C) over the T frames of each utterance + GELU: csum from conv0, sq = scratch [B][C]
-int s2st_gn_gelu(float* x, const float* csum, float* sq, const float* gamma, const float* beta, uint16_t* xh, int B,
-                 int T, int C, float eps, int write_f32, hipStream_t st) {
-  if (C % 4) return S2ST_ERR_SHAPE;
-  const long n = (long)B * T * (C / 4);
-  if (n <= 0) return 0;
-  hipMemsetAsync(sq, 0, sizeof(float) * (size_t)B * C, st);
-  const int cb = (C + 255) / 256;
-  int slabs = (2048 / (cb * B)) > 0 ? 2048 / (cb * B) : 1;
-  int rpb = (T + slabs - 1) / slabs;
-  if (rpb < 16) rpb = 16;
-  slabs = (T + rpb - 1) / rpb;
-  hipLaunchKernelGGL(gn_sqdev_kernel, dim3(cb, slabs, B), dim3(256), 0, st, (const float*)x, csum, sq, T, C, rpb);
-  hipLaunchKernelGGL(gn_gelu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, csum, (const float*)sq, gamma,
-                     beta, xh, B, T, C, eps, 1.f / T, write_f32);
+  float *csum = stats, *sq = stats + (long)B * C;
+  hipMemsetAsync(stats, 0, sizeof(float) * 2 * (size_t)B * C, st);
+  const dim3 grid((T + C0_TT - 1) / C0_TT, B);
+  hipLaunchKernelGGL(hubert_conv0_gn_kernel<0>, grid, dim3(256), 0, st, x, w, csum, sq, gamma, beta, y, yh, B, N, T, C,
+                     k, stride, eps);
+  hipLaunchKernelGGL(hubert_conv0_gn_kernel<1>, grid, dim3(256), 0, st, x, w, csum, sq, gamma, beta, y, yh, B, N, T, C,
+                     k, stride, eps);
+  hipLaunchKernelGGL(hubert_conv0_gn_kernel<2>, grid, dim3(256), 0, st, x, w, csum, sq, gamma, beta, y, yh, B, N, T, C,
+                     k, stride, eps);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 

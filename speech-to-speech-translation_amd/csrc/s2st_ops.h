@@ -162,10 +162,9 @@ int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_sc
 // ---------------------------------------------------------------------------------------
 // HuBERT front end (hubert.hip): waveform conv, GroupNorm(C, C) + GELU, pos-conv input re-layout
 // ---------------------------------------------------------------------------------------
-int s2st_hubert_conv0(const float* x, const float* w, float* y, float* csum, int B, int N, int T, int C, int k,
-                      int stride, hipStream_t st);
-int s2st_gn_gelu(float* x, const float* csum, float* sq, const float* gamma, const float* beta, uint16_t* xh, int B,
-                 int T, int C, float eps, int write_f32, hipStream_t st);
+int s2st_hubert_conv0_gn_gelu(const float* x, const float* w, const float* gamma, const float* beta, float* y,
+                              uint16_t* yh, float* stats /* 2 * B * C floats */, int B, int N, int T, int C, int k,
+                              int stride, float eps, hipStream_t st);
 int s2st_posconv_prep(float* x, const int* lens, float* img, uint16_t* imgh, int B, int T, int E, int G, int pad,
                       int Tp, hipStream_t st);
 
