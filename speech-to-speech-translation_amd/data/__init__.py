@@ -4,3 +4,6 @@ from .synthetic import (  # noqa: F401
     collate,
     BOS, PAD, EOS, UNK,
 )
+from .dictionary import Dictionary  # noqa: F401,E402
+from .data_cfg import S2STDataConfig  # noqa: F401,E402
+from .s2st_dataset import S2STDataset, S2STDatasetCreator  # noqa: F401,E402

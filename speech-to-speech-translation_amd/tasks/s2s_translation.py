@@ -2,8 +2,9 @@
 
 Mirror of examples/s2s_trans/tasks/s2s_translation.py:47-336 for the training path: flags,
 dictionaries, ``build_model`` / ``build_criterion`` / ``train_step`` / ``valid_step`` /
-``max_positions``.  Data comes from the seeded synthetic Fisher-shaped corpus
-(data/synthetic.py) -- the on-disk TSV/ZIP reader is a later row of the scope table.
+``max_positions``, ``load_dataset``.  ``data`` is either the literal "synthetic" (seeded Fisher-shaped corpus,
+data/synthetic.py: what bench.py uses) or a directory in the recipe's layout -- ``config.yaml``, dictionaries,
+``<split>.tsv`` manifests over .npy / zip features (data/s2st_dataset.py).
 """
 from __future__ import annotations
 
@@ -12,31 +13,14 @@ from typing import Dict
 
 import torch
 
-from ..data.synthetic import BOS, EOS, PAD, UNK, SyntheticFisherCorpus
+import os
+from pathlib import Path
+
+from ..data.data_cfg import S2STDataConfig
+from ..data.dictionary import Dictionary
+from ..data.s2st_dataset import S2STDatasetCreator
+from ..data.synthetic import SyntheticFisherCorpus
 from ..registry import register_task, CRITERIA, MODELS
-
-
-class Dictionary:
-    """Minimal symbol table with fairseq's special-symbol layout
-    (fairseq/data/dictionary.py:27-40): <s>=0, <pad>=1, </s>=2, <unk>=3."""
-
-    def __init__(self, n_symbols: int):
-        self.symbols = ["<s>", "<pad>", "</s>", "<unk>"] + [f"s{i}" for i in range(n_symbols - 4)]
-
-    def __len__(self):
-        return len(self.symbols)
-
-    def bos(self):
-        return BOS
-
-    def pad(self):
-        return PAD
-
-    def eos(self):
-        return EOS
-
-    def unk(self):
-        return UNK
 
 
 @register_task("s2s_translation")
@@ -56,16 +40,32 @@ class S2ST_TranslationTask:
         a("--src-vocab-size", type=int, default=44)
         a("--tgt-vocab-size", type=int, default=74)
 
-    def __init__(self, args, src_dict: Dictionary, tgt_dict: Dictionary, device=None):
+    def __init__(self, args, src_dict: Dictionary, tgt_dict: Dictionary, device=None, data_cfg=None):
         self.args = args
         self.src_dict, self.tgt_dict = src_dict, tgt_dict
         self.device = device
-        self.datasets: Dict[str, SyntheticFisherCorpus] = {}
+        self.data_cfg = data_cfg
+        self.speaker_to_id = None
+        self.datasets: Dict[str, object] = {}
 
     @classmethod
     def setup_task(cls, args, device=None, **kw):
-        return cls(args, Dictionary(getattr(args, "src_vocab_size", 44)),
-                   Dictionary(getattr(args, "tgt_vocab_size", 74)), device=device)
+        """s2s_translation.py:93-119: dictionaries from the data directory's config; synthetic tables otherwise."""
+        data = getattr(args, "data", "synthetic")
+        if data and data != "synthetic" and os.path.isdir(data):
+            data_cfg = S2STDataConfig(Path(data) / getattr(args, "config_yaml", "config.yaml"))
+            dicts = []
+            for name in (data_cfg.src_vocab_filename, data_cfg.tgt_vocab_filename):
+                path = Path(data) / name
+                if not path.is_file():
+                    raise FileNotFoundError(f"Dict not found: {path.as_posix()}")
+                dicts.append(Dictionary.load(path.as_posix()))
+            if getattr(args, "train_subset", None) is not None:
+                if not all(s.startswith("train") for s in args.train_subset.split(",")):
+                    raise ValueError('Train splits should be named like "train*".')
+            return cls(args, dicts[0], dicts[1], device=device, data_cfg=data_cfg)
+        return cls(args, Dictionary.with_size(getattr(args, "src_vocab_size", 44)),
+                   Dictionary.with_size(getattr(args, "tgt_vocab_size", 74)), device=device)
 
     @property
     def source_dictionary(self):
@@ -78,7 +78,16 @@ class S2ST_TranslationTask:
     def max_positions(self):
         return self.args.max_source_positions, self.args.max_target_positions
 
-    def load_dataset(self, split, n_utts=4096, seed=1234, **kw):
+    def load_dataset(self, split, n_utts=4096, seed=1234, epoch=1, **kw):
+        if self.data_cfg is not None:  # s2s_translation.py:121-135
+            use_hubert = str(getattr(self.args, "use_hubert", "false")).lower() in ("true", "1", "yes")
+            self.data_cfg.set_use_hubert(use_hubert)
+            self.data_cfg.set_kd_encoder(bool(getattr(self.args, "kd_encoder", False)))
+            self.datasets[split] = S2STDatasetCreator.from_tsv(
+                self.args.data, self.data_cfg, split, self.src_dict, self.tgt_dict, None, None,
+                is_train_split=split.startswith("train"), epoch=epoch, seed=getattr(self.args, "seed", 1),
+                n_frames_per_step=self.args.n_frames_per_step, speaker_to_id=self.speaker_to_id)
+            return self.datasets[split]
         self.datasets[split] = SyntheticFisherCorpus(
             n_utts=n_utts, seed=seed, n_frames_per_step=self.args.n_frames_per_step,
             src_vocab=len(self.src_dict), tgt_vocab=len(self.tgt_dict), **kw)
