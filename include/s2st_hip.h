@@ -356,6 +356,12 @@ int s2st_gl_polar_split_f32(const float* mag, const float* aux, int32_t from_spe
 int s2st_gl_frame_split_f32(const float* wave, const int32_t* tl, void* As, int32_t U, int32_t Tmax, int32_t hop, int32_t n_fft, int32_t Lw, void* stream);
 int s2st_gl_overlap_add_b_f32(const float* frames, const float* wsq_all, const int64_t* wsq_off, const int32_t* tl, float* wave, int32_t U, int32_t Tmax, int32_t n_fft, int32_t hop, int32_t Lw, void* stream);
 
+/* Host-side: max-tokens batching of length-sorted indices (fairseq/data/data_utils_fast.pyx:20-100,
+ * batch_by_size_vec; the reference builds it as a Cython extension).  num_tokens in index order, batch_ends: n + 1
+ * int32 slots; returns the number of batches (batch k = positions [batch_ends[k-1], batch_ends[k])), or a
+ * negative S2ST_ERR_* (an item longer than max_tokens: S2ST_ERR_SHAPE). */
+int64_t s2st_batch_by_size(const int64_t* num_tokens, int64_t n, int64_t max_tokens, int64_t max_sentences, int32_t bsz_mult, int32_t* batch_ends);
+
 /* MCD evaluation (examples/s2s_trans/tasks/s2s_translation.py:414-552): batched DTW over the padded
  * [B][M][N] distance tensor (shapes [B][2] = (m, n) per element, or NULL), RMS feature distance, MFCC glue */
 int s2st_dtw_f32(const float* dist, const int32_t* shapes, int32_t B, int32_t M, int32_t N, float* cumdist, int32_t* backptr, int32_t* pathmap, void* stream);

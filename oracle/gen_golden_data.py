@@ -36,6 +36,39 @@ from data_corpus import flatten_batch, make_corpus  # noqa: E402
 SCRATCH = "/tmp/s2st_data_corpus"  # the same absolute path the test uses (paths are written into the manifests)
 
 
+def batcher_cases():
+    """(name, num_tokens sorted descending, max_tokens, max_sentences, bsz_mult) -- incl. the tail-overflow corner."""
+    rs = np.random.RandomState(5)
+    cases = []
+    for k, (n, lo, hi, mt, ms, mult) in enumerate([(200, 40, 3000, 20000, -1, 8), (64, 10, 400, 1000, -1, 1),
+                                                  (97, 1, 50, 120, 7, 4), (33, 100, 101, 1000, -1, 8),
+                                                  (50, 5, 900, 900, 3, 2), (1, 7, 8, 100, -1, 8),
+                                                  (40, 20, 500, 0, 6, 4), (120, 30, 2000, 2000, -1, 16)]):
+        nt = np.sort(rs.randint(lo, hi, size=n))[::-1].astype(np.int64)
+        if k == 2:
+            nt = rs.randint(lo, hi, size=n).astype(np.int64)  # unsorted order exercises the tail-overflow branch
+        cases.append((f"case{k}", nt, mt, ms, mult))
+    return cases
+
+
+def batcher_golden():
+    """Outputs of the reference's own Cython batcher (built into oracle/_ref by oracle/build_ref.sh)."""
+    import subprocess
+    subprocess.check_call([os.path.join(HERE, "build_ref.sh")])
+    sys.path.insert(0, os.path.join(HERE, "_ref"))
+    import data_utils_fast as F
+    out = {}
+    for name, nt, mt, ms, mult in batcher_cases():
+        idx = np.arange(len(nt), dtype=np.int64)
+        b = F.batch_by_size_vec(idx, nt, mt, ms, mult)
+        out[name + ".num_tokens"] = nt
+        out[name + ".args"] = np.asarray([mt, ms, mult])
+        out[name + ".ends"] = np.cumsum([len(x) for x in b]).astype(np.int64)
+    dst = os.path.join(ROOT, "tests", "golden", "batcher.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst), "bytes")
+
+
 def main():
     root = make_corpus(SCRATCH)
     cfg = S2STDataConfig(Path(root) / "config.yaml")
@@ -60,6 +93,7 @@ def main():
         for k, v in flatten_batch(ds.collater([items[i] for i in pick])).items():
             out[f"{split}.batch.{k}"] = v
         out[f"{split}.batch_pick"] = np.asarray(pick)
+    batcher_golden()
     dst = os.path.join(ROOT, "tests", "golden", "data_path.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, len(out), "arrays,", os.path.getsize(dst), "bytes")

@@ -166,6 +166,48 @@ int s2st_gl_overlap_add_b_f32(const float* frames, const float* wsq_all, const i
   return s2st_gl_overlap_add_b(frames, wsq_all, (const long*)wsq_off, tl, wave, U, Tmax, n_fft, hop, Lw, (hipStream_t)stream);
 }
 
+// Host-side integer work of the data path: the max-tokens batcher (the reference compiles it as a Cython
+// extension, fairseq/data/data_utils_fast.pyx:20-100).  num_tokens[i] is the cost of the i-th index in the given
+// order; batch_ends[k] receives the exclusive end position of batch k.  A running batch plus a tail: the tail
+// joins the batch whenever the merged size is < bsz_mult or a multiple of it; on overflow of max_tokens
+// (sentences x longest) or max_sentences the batch is closed and the tail starts the next one; a tail that
+// overflows on its own is closed as well and the current item starts over.
+int64_t s2st_batch_by_size(const int64_t* num_tokens, int64_t n, int64_t max_tokens, int64_t max_sentences,
+                           int32_t bsz_mult, int32_t* batch_ends) {
+  if (n < 0 || (n > 0 && (!num_tokens || !batch_ends)) || bsz_mult < 1 || n > 0x7fffffff) return S2ST_ERR_ARG;
+  if (n == 0) return 0;
+  if (max_tokens > 0)
+    for (int64_t i = 0; i < n; ++i)
+      if (num_tokens[i] > max_tokens) return S2ST_ERR_SHAPE;  // "Sentences lengths should not exceed max_tokens"
+  for (int64_t i = 0; i <= n; ++i) batch_ends[i] = 0;  // n + 1 slots
+  int64_t count = 0, batch_start = 0, tail_max = 0, batch_max = 0;
+  for (int64_t pos = 0; pos < n; ++pos) {
+    tail_max = tail_max > num_tokens[pos] ? tail_max : num_tokens[pos];
+    const int64_t new_end = pos + 1;
+    int64_t new_max = batch_max > tail_max ? batch_max : tail_max;
+    const int64_t sentences = new_end - batch_start;
+    const bool overflow = (max_sentences > 0 && sentences > max_sentences) || (max_tokens > 0 && sentences * new_max > max_tokens);
+    const bool fits_mult = sentences < bsz_mult || sentences % bsz_mult == 0;
+    if (overflow) {
+      const int64_t tail_tokens = tail_max * (new_end - batch_ends[count]);
+      if (max_tokens > 0 && tail_tokens > max_tokens) {
+        batch_ends[++count] = (int32_t)pos;
+        tail_max = num_tokens[pos];
+      }
+      batch_start = batch_ends[count];
+      ++count;
+      new_max = tail_max;
+    }
+    if (overflow || fits_mult) {
+      batch_ends[count] = (int32_t)new_end;
+      batch_max = new_max;
+      tail_max = 0;
+    }
+  }
+  if (batch_ends[count] != n) ++count;
+  return count;
+}
+
 int s2st_profile_gemm(int32_t enable) { s2st_gemm_profile_enable(enable); return 0; }
 int s2st_profile_gemm_read(double* flops, double* ms, int64_t* launches) {
   long n = 0;

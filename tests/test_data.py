@@ -122,3 +122,50 @@ def test_on_disk_corpus_trains_through_the_task(backend, corpus):
         backend.sync()
         assert abs(float(r["logs"][0]["loss"]) - float(lo)) < 5e-5 * float(lo)
         assert abs(float(r["gnorm"]) - float(gn)) < 2e-3 * float(gn)
+
+
+def _batch_ends(batches):
+    return np.cumsum([len(b) for b in batches]).astype(np.int64)
+
+
+def test_native_batcher_equals_the_reference_cython_extension(golden_dir):
+    """s2st_batch_by_size (C library) and the oracle restatement against outputs of the reference's own
+    data_utils_fast extension (tests/golden/batcher.npz; integer work: exact), and -- when oracle/_ref holds that
+    extension, i.e. wherever build() ran with the reference present -- against the extension itself on fresh
+    random cases."""
+    import sys
+    D = importlib.import_module(PKG + ".data")
+    import data_oracle as DO
+    z = np.load(os.path.join(golden_dir, "batcher.npz"))
+    names = sorted({k.split(".")[0] for k in z.files})
+    assert len(names) >= 8
+    for name in names:
+        nt = z[name + ".num_tokens"]
+        mt, ms, mult = (int(v) for v in z[name + ".args"])
+        idx = np.arange(len(nt), dtype=np.int64)
+        for fn in (D.batch_by_size, DO.batch_by_size):
+            got = fn(idx, nt, mt, ms, mult)
+            assert np.array_equal(_batch_ends(got), z[name + ".ends"]), (name, fn.__module__)
+            assert np.array_equal(np.concatenate(got), idx)
+    ref_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+    try:
+        sys.path.insert(0, ref_dir)
+        import data_utils_fast as F
+    except ImportError:
+        return
+    rs = np.random.RandomState(17)
+    for _ in range(200):
+        n = int(rs.randint(1, 300))
+        nt = rs.randint(1, 800, size=n).astype(np.int64)
+        if rs.rand() < 0.7:
+            nt = np.sort(nt)[::-1].copy()
+        mt = int(rs.choice([0, 800, 1500, 5000]))
+        ms = int(rs.choice([-1, 0, 3, 16]))
+        mult = int(rs.choice([1, 2, 8]))
+        idx = rs.permutation(n).astype(np.int64)
+        want = F.batch_by_size_vec(idx, nt, mt, ms, mult)
+        got = D.batch_by_size(idx, nt, mt, ms, mult)
+        assert len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want))
+    with pytest.raises(AssertionError):
+        D.batch_by_size(np.arange(3), np.asarray([10, 2000, 5]), 1000, -1, 1)
+    assert D.batch_by_size(np.arange(0), np.arange(0), 100, -1, 8) == []
