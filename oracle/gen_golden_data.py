@@ -69,6 +69,48 @@ def batcher_golden():
     print("wrote", dst, os.path.getsize(dst), "bytes")
 
 
+def iterator_golden():
+    """Batch order per epoch / shard from the reference's EpochBatchIterator (+ resume position)."""
+    from fairseq.data import iterators as ref_it
+    sys.path.insert(0, os.path.join(HERE, "_ref"))
+    import data_utils_fast as F
+    name, nt, mt, ms, mult = batcher_cases()[0]
+    batches = [b.tolist() for b in F.batch_by_size_vec(np.arange(len(nt), dtype=np.int64), nt, mt, ms, mult)]
+
+    class DS(torch.utils.data.Dataset):
+        def __getitem__(self, i):
+            return int(i)
+
+        def __len__(self):
+            return len(nt)
+
+    out = {"n_batches": np.asarray(len(batches))}
+    for shards in (1, 3):
+        for sid in range(shards):
+            it = ref_it.EpochBatchIterator(DS(), lambda x: list(x), batches, seed=3, num_shards=shards, shard_id=sid, epoch=1)
+            for ep in (1, 2, 3):
+                seq = list(it.next_epoch_itr(shuffle=True))
+                out[f"s{shards}.{sid}.e{ep}.flat"] = np.asarray([i for b in seq for i in b], dtype=np.int64)
+                out[f"s{shards}.{sid}.e{ep}.lens"] = np.asarray([len(b) for b in seq], dtype=np.int64)
+                assert it.end_of_epoch()
+            st = it.state_dict()
+            out[f"s{shards}.{sid}.final_state"] = np.asarray([st["epoch"], st["iterations_in_epoch"]])
+    it = ref_it.EpochBatchIterator(DS(), lambda x: list(x), batches, seed=3, num_shards=3, shard_id=1, epoch=1)
+    itr = it.next_epoch_itr(shuffle=True)
+    for _ in range(2):
+        next(itr)
+    st = it.state_dict()
+    out["resume.state"] = np.asarray([st["epoch"], st["iterations_in_epoch"]])
+    it2 = ref_it.EpochBatchIterator(DS(), lambda x: list(x), batches, seed=3, num_shards=3, shard_id=1, epoch=1)
+    it2.load_state_dict(st)
+    rest = list(it2.next_epoch_itr(shuffle=True))
+    out["resume.flat"] = np.asarray([i for b in rest for i in b], dtype=np.int64)
+    out["resume.lens"] = np.asarray([len(b) for b in rest], dtype=np.int64)
+    dst = os.path.join(ROOT, "tests", "golden", "epoch_iterator.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst), "bytes")
+
+
 def main():
     root = make_corpus(SCRATCH)
     cfg = S2STDataConfig(Path(root) / "config.yaml")
@@ -94,6 +136,7 @@ def main():
             out[f"{split}.batch.{k}"] = v
         out[f"{split}.batch_pick"] = np.asarray(pick)
     batcher_golden()
+    iterator_golden()
     dst = os.path.join(ROOT, "tests", "golden", "data_path.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, len(out), "arrays,", os.path.getsize(dst), "bytes")

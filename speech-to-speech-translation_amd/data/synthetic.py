@@ -111,6 +111,9 @@ class SyntheticFisherCorpus:
     def collate_batch(self, indices: Sequence[int]) -> Dict:
         return collate([self[i] for i in indices])
 
+    def collater(self, items) -> Dict:
+        return collate(list(items))
+
 
 def batch_by_size(
     indices: np.ndarray,

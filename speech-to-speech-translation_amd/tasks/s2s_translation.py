@@ -11,6 +11,7 @@ from __future__ import annotations
 import argparse
 from typing import Dict
 
+import numpy as np
 import torch
 
 import os
@@ -95,6 +96,23 @@ class S2ST_TranslationTask:
 
     def dataset(self, split):
         return self.datasets[split]
+
+    def get_batch_iterator(self, dataset, max_tokens=None, max_sentences=None, max_positions=None,
+                           required_batch_size_multiple=8, seed=1, num_shards=1, shard_id=0, epoch=1, **kw):
+        """fairseq/tasks/fairseq_task.py:269-305: length-ordered indices (under numpy_seed(seed)), size filter,
+        max-tokens batches, then the sharded, per-epoch shuffled iterator."""
+        from ..data.iterators import EpochBatchIterator, numpy_seed
+        from ..data.synthetic import batch_by_size
+        with numpy_seed(seed):
+            indices = dataset.ordered_indices()
+        if max_positions is not None and hasattr(dataset, "filter_indices_by_size"):
+            indices, _ = dataset.filter_indices_by_size(indices, max_positions)
+        ntok = np.array([dataset.num_tokens(int(i)) for i in indices], dtype=np.int64)
+        batches = batch_by_size(np.asarray(indices, dtype=np.int64), ntok, max_tokens or 0, max_sentences or -1,
+                                required_batch_size_multiple)
+        collate = getattr(dataset, "collater", None) or (lambda items: dataset.collate_items(items))
+        return EpochBatchIterator(dataset, collate, batches, seed=seed, num_shards=num_shards, shard_id=shard_id,
+                                  epoch=epoch)
 
     def build_model(self, args):
         from .. import models  # noqa: F401  (registers the architecture)

@@ -169,3 +169,67 @@ def test_native_batcher_equals_the_reference_cython_extension(golden_dir):
     with pytest.raises(AssertionError):
         D.batch_by_size(np.arange(3), np.asarray([10, 2000, 5]), 1000, -1, 1)
     assert D.batch_by_size(np.arange(0), np.arange(0), 100, -1, 8) == []
+
+
+def test_epoch_iterator_order_equals_the_reference(golden_dir):
+    """Per-epoch shuffled, rank-sharded batch order and the resume position against the reference's
+    EpochBatchIterator (tests/golden/epoch_iterator.npz): every rank must see exactly the reference's batches."""
+    D = importlib.import_module(PKG + ".data")
+    zb = np.load(os.path.join(golden_dir, "batcher.npz"))
+    z = np.load(os.path.join(golden_dir, "epoch_iterator.npz"))
+    nt = zb["case0.num_tokens"]
+    mt, ms, mult = (int(v) for v in zb["case0.args"])
+    batches = [b.tolist() for b in D.batch_by_size(np.arange(len(nt), dtype=np.int64), nt, mt, ms, mult)]
+    assert len(batches) == int(z["n_batches"])
+
+    class DS:
+        def __getitem__(self, i):
+            return int(i)
+
+    def flat(seq):
+        return (np.asarray([i for b in seq for i in (b or [])], dtype=np.int64),
+                np.asarray([len(b) if b else 0 for b in seq], dtype=np.int64))
+
+    state0 = np.random.get_state()[1].copy()
+    for shards in (1, 3):
+        for sid in range(shards):
+            it = D.EpochBatchIterator(DS(), lambda items: list(items), batches, seed=3, num_shards=shards, shard_id=sid)
+            for ep in (1, 2, 3):
+                f, l = flat(list(it.next_epoch_itr(shuffle=True)))
+                assert np.array_equal(f, z[f"s{shards}.{sid}.e{ep}.flat"]), (shards, sid, ep)
+                assert np.array_equal(l, z[f"s{shards}.{sid}.e{ep}.lens"])
+                assert it.end_of_epoch()
+            st = it.state_dict()
+            assert [st["epoch"], st["iterations_in_epoch"]] == z[f"s{shards}.{sid}.final_state"].tolist()
+    assert np.array_equal(np.random.get_state()[1], state0)  # numpy_seed restores the global RNG
+    it = D.EpochBatchIterator(DS(), lambda items: list(items), batches, seed=3, num_shards=3, shard_id=1)
+    itr = it.next_epoch_itr(shuffle=True)
+    next(itr), next(itr)
+    st = it.state_dict()
+    assert [st["epoch"], st["iterations_in_epoch"]] == z["resume.state"].tolist()
+    it2 = D.EpochBatchIterator(DS(), lambda items: list(items), batches, seed=3, num_shards=3, shard_id=1)
+    it2.load_state_dict(st)
+    f, l = flat(list(it2.next_epoch_itr(shuffle=True)))
+    assert np.array_equal(f, z["resume.flat"]) and np.array_equal(l, z["resume.lens"])
+
+
+def test_task_batch_iterator_over_the_on_disk_set(corpus):
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import s2st_oracle as O
+    from test_engine import NANO
+    tasks = importlib.import_module(PKG + ".tasks")
+    a = O.make_args(**NANO)
+    a.data, a.config_yaml = corpus, "config.yaml"
+    task = tasks.S2ST_TranslationTask.setup_task(a)
+    ds = task.load_dataset("train_tiny")
+    seen = []
+    for sid in range(2):
+        it = task.get_batch_iterator(ds, max_tokens=150, max_positions=task.max_positions(),
+                                     required_batch_size_multiple=2, seed=5, num_shards=2, shard_id=sid)
+        for s in it.next_epoch_itr(shuffle=True):
+            if s:
+                assert s["net_input"]["src_speech"].shape[0] * s["net_input"]["src_speech"].shape[1] <= 150
+                seen += s["id"].tolist()
+    assert sorted(seen) == list(range(len(ds)))
