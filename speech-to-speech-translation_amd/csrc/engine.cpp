@@ -123,6 +123,7 @@ struct s2st_engine {
   float* dec_crossKV(int l) const {
     return dec_st.base + (long)c.dec_layers * 2 * dec_st.B * dec_st.maxT * c.dec_dim + (long)l * dec_st.B * dec_st.E * 2 * c.dec_dim;
   }
+  bool skip_resid_h = true;  // S2ST_RESID_H=1 (A/B switch): also write bf16 copies of residual-stream outputs
   bool use_ln_fuse = true;  // S2ST_NO_LN_FUSE=1 (A/B switch): separate dropout-backward prologue pass
   bool use_only_h = true;  // S2ST_NO_ONLY_H=1: always keep the fp32 copy of GEMM-only tensors (A/B switch)
   bool use_attn_gfuse = false;  // S2ST_ATTN_GFUSE=1: attention backward emits bf16 projection gradients directly
@@ -401,7 +402,9 @@ struct s2st_engine {
     const uint64_t sd = drop_p > 0.f ? next_seed() : 0;
     const bool fm = fast();
     const bf16raw* xh = fm ? half_of(x) : nullptr;
-    if (fm && N % 8 == 0) y->h = alloc_h(y->n());
+    // (a residual-stream output is read in fp32 by the next layer norm / residual add: no bf16 copy; a consumer that
+    // does want one gets it from half_of())
+    if (fm && N % 8 == 0 && !(resid && skip_resid_h)) y->h = alloc_h(y->n());
     if (fm && act == 1 && y->h && !resid) { y->act_mode = 1; y->act_p = drop_p; y->act_bias = b; }
     if (fm && act == 0 && drop_p == 0.f && !resid && y->h) { y->lin_plain = true; y->act_bias = b; }
     if (fm && act == 0 && drop_p > 0.f && N % 8 == 0 && use_ln_fuse) {
@@ -1424,6 +1427,7 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->use_act_fuse = !(getenv("S2ST_NO_ACT_FUSE") && atoi(getenv("S2ST_NO_ACT_FUSE")) != 0);
   e->use_only_h = !(getenv("S2ST_NO_ONLY_H") && atoi(getenv("S2ST_NO_ONLY_H")) != 0);
   e->hoist_kv = !(getenv("S2ST_NO_KV_HOIST") && atoi(getenv("S2ST_NO_KV_HOIST")) != 0);
+  e->skip_resid_h = !(getenv("S2ST_RESID_H") && atoi(getenv("S2ST_RESID_H")) != 0);
   e->use_ln_fuse = !(getenv("S2ST_NO_LN_FUSE") && atoi(getenv("S2ST_NO_LN_FUSE")) != 0);
   e->use_attn_gfuse = getenv("S2ST_ATTN_GFUSE") && atoi(getenv("S2ST_ATTN_GFUSE")) != 0;
   e->build_params();
