@@ -223,6 +223,16 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     vlog('timed region', dt, 'host issue time', t_issue)
+    if os.environ.get('S2ST_STALL_TRACE'):
+        import ctypes as C_
+        fn = eng.lib.s2st_engine_stall_report
+        fn.restype, fn.argtypes = C_.c_int64, [C_.c_void_p, C_.c_int32]
+        step(args.warmup)
+        torch.cuda.synchronize()
+        fn(eng.h, 0)
+        step(args.warmup + 1)
+        torch.cuda.synchronize()
+        vlog('cross-stream waits of one step on the data-path stream: %d us in total' % fn(eng.h, 1))
     if step_ev:
         vlog('per-step GPU ms (mel frames):', ' '.join('%.2f(%d)' % (step_ev[j - 1].elapsed_time(step_ev[j]), frames[args.warmup + j])
                                                      for j in range(1, len(step_ev))))

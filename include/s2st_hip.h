@@ -295,6 +295,9 @@ int s2st_engine_bind_bf16(s2st_engine* e, uint16_t* params_bf16);
 /* The caller states that the bf16 arena already equals bf16(params) (s2st_adam_f32 wrote it with the update):
  * the NEXT forward skips its refresh pass.  One-shot: any later forward refreshes again unless told anew. */
 int s2st_engine_bf16_is_fresh(s2st_engine* e);
+/* instrumentation (S2ST_STALL_TRACE=1): time the data-path stream spent in cross-stream waits since the last
+ * report, in microseconds (per-wait lines on stderr when verbose); call after synchronising the device */
+int64_t s2st_engine_stall_report(s2st_engine* e, int32_t verbose);
 /* optional second bf16 arena (param_floats elements): every training forward stores W^T of each 2-D
  * weight there (on the engine's second stream) so the data-gradient GEMMs read K-contiguous operands */
 int s2st_engine_bind_bf16_transposed(s2st_engine* e, uint16_t* params_bf16_t);

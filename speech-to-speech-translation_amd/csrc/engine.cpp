@@ -106,10 +106,25 @@ struct s2st_engine {
     side_used = true;
     return side_;
   }
+  // S2ST_STALL_TRACE=1: time spent by the data-path stream in each cross-stream wait (timing events around the
+  // wait; read back by s2st_engine_stall_report after the caller synchronised)
+  struct Stall { const char* what; hipEvent_t a, b; };
+  std::vector<Stall> stalls;
+  bool stall_trace = false;
+  void wait_traced(hipStream_t st, hipEvent_t ev, const char* what) {
+    if (!stall_trace) { hipStreamWaitEvent(st, ev, 0); return; }
+    Stall s{what, nullptr, nullptr};
+    hipEventCreate(&s.a);
+    hipEventCreate(&s.b);
+    hipEventRecord(s.a, st);
+    hipStreamWaitEvent(st, ev, 0);
+    hipEventRecord(s.b, st);
+    stalls.push_back(s);
+  }
   void join_side() {
     if (!side_ || !side_used) return;
     hipEventRecord(ev_join_, side_);
-    hipStreamWaitEvent(st_, ev_join_, 0);
+    wait_traced(st_, ev_join_, "join_side");
     side_used = false;
   }
   // ---- AR decoding state (config 5): caller-owned cache buffer laid out by decode_begin --------
@@ -123,6 +138,10 @@ struct s2st_engine {
   float* dec_crossKV(int l) const {
     return dec_st.base + (long)c.dec_layers * 2 * dec_st.B * dec_st.maxT * c.dec_dim + (long)l * dec_st.B * dec_st.E * 2 * c.dec_dim;
   }
+  bool tail_share = false;   // set while the last tape closures run (see linear()'s weight-gradient GEMM)
+  unsigned tail_count = 0;
+  int tail_closures = 0;     // S2ST_TAIL_SHARE=<n>: how many closures from the end share weight gradients; measured
+                             // (n = 12 / 24 / 48) within run-to-run noise of the ~0.19 ms tail wait, so off
   bool skip_resid_h = true;  // S2ST_RESID_H=1 (A/B switch): also write bf16 copies of residual-stream outputs
   bool use_ln_fuse = true;  // S2ST_NO_LN_FUSE=1 (A/B switch): separate dropout-backward prologue pass
   bool use_only_h = true;  // S2ST_NO_ONLY_H=1: always keep the fp32 copy of GEMM-only tensors (A/B switch)
@@ -469,7 +488,9 @@ struct s2st_engine {
         g.C = gemm_out(G + w, K);
         g.ep = gemm_epi_default();
         g.ep.accumulate = 1;
-        hipStream_t ws_st = fm ? fork_side() : st_;
+        // weight gradients go to the second stream -- except every other one at the very end of the backward
+        // sweep: nothing is left to overlap them with there, the data path would only wait for the backlog
+        hipStream_t ws_st = fm && !(tail_share && ((tail_count++) & 1)) ? fork_side() : st_;
         g.ws = ws_for(ws_st); g.ws_floats = skws_n;
         g.M = N; g.N = K; g.K = M; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
         chk(s2st_gemm(g, ws_st));
@@ -704,7 +725,7 @@ struct s2st_engine {
     Ten* q = linear(x, a.q_w, a.q_b, C, C, 0, 0.f, nullptr, nullptr, true);
     Ten* kv = kv_pre ? kv_pre : cross_kv(encx, a, C);
     if (kv_pre && kv_wait_) {  // first consumer of the projections issued on the second stream
-      hipStreamWaitEvent(st_, ev_kv_, 0);
+      wait_traced(st_, ev_kv_, "cross-attention K|V projections");
       kv_wait_ = false;
     }
     AttnIO io{q, 0, C, kv, 0, 2 * C, kv, C, 2 * C};
@@ -1391,11 +1412,13 @@ struct s2st_engine {
         // decoder's backward; the data path waits for it right before the tap layer norms consume it
         if (i + 1 == aux_hi_idx && st_ == main_st) st_ = fork_side();
         if (i + 1 == aux_lo_idx && st_ != main_st) { hipEventRecord(ev_auxb_, st_); st_ = main_st; }
-        if (i + 1 == aux_wait_idx) hipStreamWaitEvent(main_st, ev_auxb_, 0);
+        if (i + 1 == aux_wait_idx) wait_traced(main_st, ev_auxb_, "aux decoders' backward (tap gradients)");
       }
+      tail_share = tail_closures > 0 && seg == ns - 1 && i < lo + (size_t)tail_closures && side_ != nullptr;
       tape[i]();
       if (err) break;
     }
+    tail_share = false;
     if (st_ != main_st) { hipEventRecord(ev_auxb_, st_); st_ = main_st; }
     // The segment's weight gradients live on the second stream.  A caller that overlaps the gradient
     // all-reduce waits on that stream itself (s2st_engine_side_stream); the data path only joins once,
@@ -1427,6 +1450,8 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->use_act_fuse = !(getenv("S2ST_NO_ACT_FUSE") && atoi(getenv("S2ST_NO_ACT_FUSE")) != 0);
   e->use_only_h = !(getenv("S2ST_NO_ONLY_H") && atoi(getenv("S2ST_NO_ONLY_H")) != 0);
   e->hoist_kv = !(getenv("S2ST_NO_KV_HOIST") && atoi(getenv("S2ST_NO_KV_HOIST")) != 0);
+  e->stall_trace = getenv("S2ST_STALL_TRACE") && atoi(getenv("S2ST_STALL_TRACE")) != 0;
+  if (getenv("S2ST_TAIL_SHARE")) e->tail_closures = atoi(getenv("S2ST_TAIL_SHARE"));
   e->skip_resid_h = !(getenv("S2ST_RESID_H") && atoi(getenv("S2ST_RESID_H")) != 0);
   e->use_ln_fuse = !(getenv("S2ST_NO_LN_FUSE") && atoi(getenv("S2ST_NO_LN_FUSE")) != 0);
   e->use_attn_gfuse = getenv("S2ST_ATTN_GFUSE") && atoi(getenv("S2ST_ATTN_GFUSE")) != 0;
@@ -1491,6 +1516,24 @@ int s2st_engine_bind(s2st_engine* e, float* params, float* grads, float* buffers
 int s2st_engine_bind_bf16(s2st_engine* e, uint16_t* params_bf16) {
   e->PH = params_bf16;
   return 0;
+}
+
+// S2ST_STALL_TRACE=1: prints (stderr) and clears the cross-stream waits recorded since the last report; the caller
+// has synchronised the device.  Returns the total wait in microseconds.
+int64_t s2st_engine_stall_report(s2st_engine* e, int32_t verbose) {
+  if (!e) return S2ST_ERR_ARG;
+  double total = 0;
+  for (auto& s : e->stalls) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+      total += ms * 1e3;
+      if (verbose) fprintf(stderr, "[stall] %-44s %8.1f us\n", s.what, ms * 1e3);
+    }
+    hipEventDestroy(s.a);
+    hipEventDestroy(s.b);
+  }
+  e->stalls.clear();
+  return (int64_t)total;
 }
 
 int s2st_engine_bf16_is_fresh(s2st_engine* e) {
