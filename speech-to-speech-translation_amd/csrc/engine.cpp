@@ -1213,7 +1213,16 @@ struct s2st_engine {
     auto conv_scratch = [&](const ConvP& p, bool need_wd) { return make_conv_scratch(p, need_wd, tr); };
     ConvScratch cs0 = conv_scratch(sub[0], false), cs1 = conv_scratch(sub[1], true);
     std::vector<ConvScratch> csp;
-    for (auto& pc : post_conv) csp.push_back(conv_scratch(pc, true));
+    {
+      // the post-net's weight layouts are first needed at the end of the forward: prepared on the second stream
+      // (the data path meets that stream again at the first cross-attention, see cross_attn_block)
+      const bool post_on_side = fm && side_ && ev_taps_ && ev_kv_ && live() && hoist_kv && !stop_after_encoder &&
+                                c.dec_layers > 0;
+      hipStream_t main_st = st_;
+      if (post_on_side) st_ = fork_side();
+      for (auto& pc : post_conv) csp.push_back(conv_scratch(pc, true));
+      st_ = main_st;
+    }
 
     mark();
     // ---- encoder front: 2 x (conv k s2 -> GLU), sqrt(C) scale + positions + dropout -------------
