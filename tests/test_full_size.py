@@ -186,3 +186,40 @@ def test_valid_frames_do_not_see_batch_padding(backend, workload, precise, tol):
         t = enc_len[bi]
         ref = enc[bi, :t]
         assert float((o2["encoder_out"][bi, :t] - ref).abs().max()) <= tol * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("precise", [False, True])
+def test_longest_admissible_utterances(backend, precise):
+    """The size filter admits sources up to --max-source-positions = 3000 frames (speech_to_text_dataset.py:346-347):
+    a max-tokens batch of such utterances (6 x 3000, 750 encoder frames, ~450 decoder steps) must run on both GEMM
+    paths, and a second, short batch right after it must be unaffected by the larger one's leftovers in the
+    workspace (same result as on a fresh engine)."""
+    _need_gpu(backend)
+    D = importlib.import_module(DATA)
+    long_c = D.SyntheticFisherCorpus(n_utts=6, seed=2, min_src=2990, max_src=3000, median_src=3000.0, sigma=0.001)
+    assert int(long_c.src_n_frames.max()) == 3000
+    short_c = D.SyntheticFisherCorpus(n_utts=8, seed=4, min_src=40, max_src=60, median_src=50.0)
+    a, e = _engine(backend, dict(CONFIGS["base_recipe"], **NO_DROP), precise=precise)
+    sl, ss = long_c.collate_batch(range(6)), short_c.collate_batch(range(8))
+    o = e.forward(sl, training=True, seed=1)
+    e.zero_grad()
+    e.backward(1.0)
+    backend.sync()
+    assert torch.isfinite(o["stats"]).all() and torch.isfinite(e.grads).all()
+    assert o["encoder_out"].shape[1] == 750
+    o2 = e.forward(ss, training=True, seed=1)
+    e.zero_grad()
+    e.backward(1.0)
+    backend.sync()
+    st2, g2, outs2 = o2["stats"].clone(), e.grads.clone(), {k: o2[k].clone() for k in ("feature_out", "post_feat_out", "eos_out")}
+    del e
+    a, f = _engine(backend, dict(CONFIGS["base_recipe"], **NO_DROP), precise=precise)
+    o3 = f.forward(ss, training=True, seed=1)
+    f.zero_grad()
+    f.backward(1.0)
+    backend.sync()
+    for k, v in outs2.items():
+        assert torch.equal(o3[k], v), k
+    assert torch.allclose(o3["stats"], st2, rtol=1e-6, atol=0)  # (loss sums use atomics: last-bit order noise)
+    # (the fp32-operand GEMM of the precise path splits K with atomics: order noise of a few 1e-6)
+    assert _rel(f.grads, g2) <= (2e-5 if precise else 1e-6), _rel(f.grads, g2)
