@@ -48,6 +48,7 @@ class Trainer:
         self.eps = getattr(args, "adam_eps", 1e-8)
         self.wd = getattr(args, "weight_decay", 0.0)
         self.seed = getattr(args, "seed", 1)
+        self._dummy_batch = None
         self.reducer = GradReducer(self.engine.grads, extra_stream=self.engine.side_stream()) if is_dist() else None
         if is_dist():
             # DDP's constructor broadcast of parameters and buffers from rank 0
@@ -77,13 +78,25 @@ class Trainer:
         for i, sample in enumerate(samples):
             last = i == len(samples) - 1
             seg_hooks = hooks if last else None  # like no_sync(): reduce once, on the last micro-batch
+            # a rank whose shard ran out gets an empty batch (ShardedIterator fill value): it still has to take part
+            # in the gradient exchange, so it runs the first batch it ever saw with zero weight
+            # (trainer.py:1126-1160 _prepare_sample / ignore_grad, :786-789 sample_size *= 0)
+            is_dummy = sample is None or len(sample) == 0
+            if is_dummy:
+                if self._dummy_batch is None:
+                    raise RuntimeError("empty batch before any real batch was seen on this rank")
+                sample = self._dummy_batch
+            elif self._dummy_batch is None:
+                self._dummy_batch = sample
             if fast:
-                loss, ss, log = self._fast_micro_step(sample, seg_hooks)
+                loss, ss, log = self._fast_micro_step(sample, seg_hooks, 0.0 if is_dummy else 1.0)
             else:
                 self.criterion.grad_hooks = seg_hooks
-                loss, ss, log = self.task.train_step(sample, self.model, self.criterion, None, self.num_updates)
-            sample_size += ss
-            logs.append(log)
+                loss, ss, log = self.task.train_step(sample, self.model, self.criterion, None, self.num_updates,
+                                                     ignore_grad=is_dummy)
+            if not is_dummy:
+                sample_size += ss
+                logs.append(log)
         self._bump_bn_counters(len(samples))
         gmul_dev = None
         world = world_size()
@@ -96,6 +109,8 @@ class Trainer:
             self.gmul_dev.reciprocal_()
             gmul_dev, gmul = self.gmul_dev, 1.0
         else:
+            if sample_size <= 0:
+                raise RuntimeError("no real batch in this update")
             gmul = 1.0 / float(sample_size)
         self.sumsq.zero_()
         bd.call("s2st_sumsq_f32", eng.grads, eng.n_params, self.sumsq)
@@ -109,11 +124,11 @@ class Trainer:
         self.model.set_num_updates(self.num_updates)
         return {"logs": logs, "sample_size": sample_size, "lr": lr, "gnorm": self.gnorm}
 
-    def _fast_micro_step(self, sample, hooks):
+    def _fast_micro_step(self, sample, hooks, gscale: float = 1.0):
         eng = self.engine
         out = eng.forward(sample, training=True, want_attn=False, with_loss=True)
         self.criterion.last_outputs = out
-        eng.backward(1.0, on_segment=hooks)
+        eng.backward(gscale, on_segment=hooks)
         from .criterions.s2st_loss import LazyLog
         c = eng.cfg
         log = LazyLog(out["stats"], {"ntokens": sample["ntokens"], "nsentences": sample["nsentences"],

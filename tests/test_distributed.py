@@ -40,8 +40,9 @@ def _worker(rank, world, port, q):
     trainer = tr.Trainer(a, task, model, crit)
     trainer.reducer.min_bucket = 50_000  # several buckets even on the nano model
     mine = nano_batches()[rank]
-    for _ in range(2):
-        r = trainer.train_step([mine])
+    for u in range(3):
+        # third update: rank 1's shard has run out (the sharded iterator hands it an empty batch)
+        r = trainer.train_step([mine if (u < 2 or rank == 0) else {}])
     if rank == 0:
         q.put({n: p.detach().numpy().copy() for n, p in model.named_parameters()})
         q.put(float(r["gnorm"]))
@@ -77,11 +78,11 @@ def test_two_rank_update_equals_single_process():
     m.train()
     opt = O.FairseqAdam(m.parameters())
     b0, b1 = nano_batches()
-    for u in range(2):
+    for u in range(3):
         for p in m.parameters():
             p.grad = None
         ss = 0
-        for s in (b0, b1):
+        for s in ((b0, b1) if u < 2 else (b0,)):
             loss, n, _, _ = O.criterion_forward(m, s)
             loss.backward()  # accumulates
             ss += n
