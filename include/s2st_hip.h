@@ -359,6 +359,11 @@ int s2st_gl_polar_split_f32(const float* mag, const float* aux, int32_t from_spe
 int s2st_gl_frame_split_f32(const float* wave, const int32_t* tl, void* As, int32_t U, int32_t Tmax, int32_t hop, int32_t n_fft, int32_t Lw, void* stream);
 int s2st_gl_overlap_add_b_f32(const float* frames, const float* wsq_all, const int64_t* wsq_off, const int32_t* tl, float* wave, int32_t U, int32_t Tmax, int32_t n_fft, int32_t hop, int32_t Lw, void* stream);
 
+/* AR decoding (speech_generator_for_s2st.py:76-110: one decoder step for the B utterances of a batch): skinny
+ * y[M][N] = f(x[M][K] W[N][K]^T + bias) (+ resid), M <= 16, K % 32 == 0; x fp32 (rounded to bf16 in registers like the
+ * operand copies of s2st_gemm_f32), W bf16; act 0 / 1 relu / 2 gelu, dropout mask from (seed, m * N + n) */
+int s2st_gemm_skinny_f32(const float* x, int64_t ldx, const void* w_bf16, int64_t ldw, float* y, int64_t ldy, const float* bias, int32_t act, float drop_p, uint64_t seed, const float* resid, int64_t ldr, int32_t M, int32_t N, int32_t K, void* stream);
+
 /* Host-side: max-tokens batching of length-sorted indices (fairseq/data/data_utils_fast.pyx:20-100,
  * batch_by_size_vec; the reference builds it as a Cython extension).  num_tokens in index order, batch_ends: n + 1
  * int32 slots; returns the number of batches (batch k = positions [batch_ends[k-1], batch_ends[k])), or a

@@ -142,6 +142,7 @@ struct s2st_engine {
   unsigned tail_count = 0;
   int tail_closures = 0;     // S2ST_TAIL_SHARE=<n>: how many closures from the end share weight gradients; measured
                              // (n = 12 / 24 / 48) within run-to-run noise of the ~0.19 ms tail wait, so off
+  bool use_skinny = true;    // S2ST_NO_SKINNY=1 (A/B switch): tiled GEMMs for the AR decoding steps too
   bool skip_resid_h = true;  // S2ST_RESID_H=1 (A/B switch): also write bf16 copies of residual-stream outputs
   bool use_ln_fuse = true;  // S2ST_NO_LN_FUSE=1 (A/B switch): separate dropout-backward prologue pass
   bool use_only_h = true;  // S2ST_NO_ONLY_H=1: always keep the fp32 copy of GEMM-only tensors (A/B switch)
@@ -414,12 +415,22 @@ struct s2st_engine {
   Ten* linear(Ten* x, long w, long b, int N, int K, int act = 0, float drop_p = 0.f,
               Ten* resid = nullptr, float* ext_out = nullptr, bool only_h = false) {
     const int M = x->rows;
-    only_h = only_h && fast() && use_only_h && N % 8 == 0 && !ext_out && !resid;
+    const bool fm = fast();
+    // AR decoding: a handful of rows (one per utterance) -- the skinny kernel converts x in registers, so neither
+    // a bf16 copy of the input nor one of the output is made (fp32 in, fp32 out)
+    const bool skinny = fm && !bt.training && use_skinny && M <= 16 && K % 32 == 0 && x->d && x->cols == K &&
+                        (act == 0 || act == 1);
+    only_h = only_h && fast() && use_only_h && N % 8 == 0 && !ext_out && !resid && !skinny;
     Ten* y = newT(M, N, ext_out, !only_h);
     touch(w + (long)N * K);
     if (b >= 0) touch(b + N);
     const uint64_t sd = drop_p > 0.f ? next_seed() : 0;
-    const bool fm = fast();
+    if (skinny) {
+      if (live())
+        chk(s2st_gemm_skinny(x->d, K, PH + w, K, y->d, N, b >= 0 ? P + b : nullptr, act, drop_p, sd, resid ? resid->d : nullptr,
+                             N, M, N, K, st_));
+      return y;  // inference only: no tape entry
+    }
     const bf16raw* xh = fm ? half_of(x) : nullptr;
     // (a residual-stream output is read in fp32 by the next layer norm / residual add: no bf16 copy; a consumer that
     // does want one gets it from half_of())
@@ -1461,6 +1472,7 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->hoist_kv = !(getenv("S2ST_NO_KV_HOIST") && atoi(getenv("S2ST_NO_KV_HOIST")) != 0);
   e->stall_trace = getenv("S2ST_STALL_TRACE") && atoi(getenv("S2ST_STALL_TRACE")) != 0;
   if (getenv("S2ST_TAIL_SHARE")) e->tail_closures = atoi(getenv("S2ST_TAIL_SHARE"));
+  e->use_skinny = !(getenv("S2ST_NO_SKINNY") && atoi(getenv("S2ST_NO_SKINNY")) != 0);
   e->skip_resid_h = !(getenv("S2ST_RESID_H") && atoi(getenv("S2ST_RESID_H")) != 0);
   e->use_ln_fuse = !(getenv("S2ST_NO_LN_FUSE") && atoi(getenv("S2ST_NO_LN_FUSE")) != 0);
   e->use_attn_gfuse = getenv("S2ST_ATTN_GFUSE") && atoi(getenv("S2ST_ATTN_GFUSE")) != 0;

@@ -737,3 +737,81 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Skinny-M product for AR decoding (M = utterances of the batch, <= 16): y[M][N] = f(x[M][K] W[N][K]^T + b) (+ resid).
+// The tiled kernels above spend a whole 64x64 (or larger) tile, a DMA ring and a cast pass of x on 16 rows; here a
+// workgroup owns 16 output columns, its 4 waves split K (interleaved 32-wide steps), each wave reads its slice of
+// the 16 weight rows straight from HBM/L2 (16 bytes per lane, all loads of 4 steps in flight) and converts the
+// fp32 activations to bf16 in registers -- the same rounding the cast kernel applies, so every product is the one
+// the tiled path forms; only the fp32 summation order over K differs.  Partial accumulators meet in LDS.
+// MFMA roles: a = weight rows (-> accumulator rows n), b = activation rows (-> accumulator columns m), i.e. lane l
+// holds y[m = l & 15][n0 + 4 (l >> 4) + r], the layout of gemm_epilogue above (float4 stores along n).
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restrict__ A, long lda,
+                                                          const bf16_t* __restrict__ W, long ldw,
+                                                          float* __restrict__ C, long ldc,
+                                                          const float* __restrict__ bias, int act, float drop_p,
+                                                          uint64_t seed, const float* __restrict__ resid, long ldr,
+                                                          int M, int N, int K) {
+  __shared__ __attribute__((aligned(16))) float part[3][64 * 4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n0 = blockIdx.x * 16;
+  const int kc = (lane >> 4) * 8;
+  const float* arow = A + (long)min(lane & 15, M - 1) * lda + kc;
+  const bf16_t* wrow = W + (long)min(n0 + (lane & 15), N - 1) * ldw + kc;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int steps = K >> 5;
+  for (int s0 = wave; s0 < steps; s0 += 16) {
+    float4 a0[4], a1[4];
+    uint4 w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int s = min(s0 + 4 * u, steps - 1);  // clamped: loads stay unconditional (issued back to back)
+      a0[u] = *reinterpret_cast<const float4*>(arow + 32 * s);
+      a1[u] = *reinterpret_cast<const float4*>(arow + 32 * s + 4);
+      w[u] = *reinterpret_cast<const uint4*>(wrow + 32 * s);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (s0 + 4 * u >= steps) break;
+      union { uint4 q; bf16x8 v; } xa, wb;
+      const uint2 lo = pack_bf16x4(a0[u].x, a0[u].y, a0[u].z, a0[u].w), hi = pack_bf16x4(a1[u].x, a1[u].y, a1[u].z, a1[u].w);
+      xa.q = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      wb.q = w[u];
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb.v, xa.v, acc, 0, 0, 0);
+    }
+  }
+  if (wave > 0) *reinterpret_cast<f32x4*>(&part[wave - 1][lane * 4]) = acc;
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    const f32x4 p = *reinterpret_cast<const f32x4*>(&part[w][lane * 4]);
+    acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2]; acc[3] += p[3];
+  }
+  const int m = lane & 15, n = n0 + (lane >> 4) * 4;
+  if (m >= M || n >= N) return;
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (n + r >= N) break;
+    float x = v[r];
+    if (bias) x += bias[n + r];
+    if (act == 1) x = fmaxf(x, 0.f);
+    else if (act == 2) x = gelu_erf(x);
+    if (drop_p > 0.f) x *= drop_scale(seed, (uint64_t)m * (uint64_t)N + n + r, drop_p, inv_keep);
+    if (resid) x += resid[(long)m * ldr + n + r];
+    C[(long)m * ldc + n + r] = x;
+  }
+}
+
+// A fp32 [M][K] (row stride lda), W bf16 [N][K] (row stride ldw): M <= 16, K % 32 == 0, 16-byte aligned rows
+int s2st_gemm_skinny(const float* A, long lda, const bf16raw* W, long ldw, float* C, long ldc, const float* bias, int act,
+                     float drop_p, uint64_t seed, const float* resid, long ldr, int M, int N, int K, hipStream_t st) {
+  if (M <= 0 || N <= 0) return 0;
+  if (M > 16 || K <= 0 || K % 32 || lda % 4 || ldw % 8 || ((uintptr_t)A % 16) || ((uintptr_t)W % 16)) return S2ST_ERR_SHAPE;
+  hipLaunchKernelGGL(gemm_skinny_kernel, dim3((N + 15) / 16), dim3(256), 0, st, A, lda, reinterpret_cast<const bf16_t*>(W),
+                     ldw, C, ldc, bias, act, drop_p, seed, resid, ldr, M, N, K);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}

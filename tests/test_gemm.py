@@ -284,3 +284,40 @@ def test_bf16_tiles_splitk_conv_batched(backend):
     vh = v.view(Bn, S, H, Dh).permute(0, 2, 1, 3).double()
     Ro = (p.double() @ vh).permute(0, 2, 1, 3).reshape(Bn, T, Cm)
     assert _relerr(o, Ro) < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K,act,resid", [(16, 512, 512, 0, False), (16, 2048, 512, 1, False), (16, 512, 2048, 0, True),
+                                             (5, 80, 256, 0, False), (1, 1, 32, 2, True), (16, 1536, 512, 0, False)])
+def test_skinny_gemm(backend, M, N, K, act, resid):
+    """AR-decoding product (s2st_gemm_skinny_f32): bf16-rounded operands, fp32 accumulation, bias / activation /
+    residual -- against the same product formed in double from the rounded operands."""
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M + 2, K + 8, generator=g)[:M, :K]  # non-contiguous rows: exercises the row strides
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g) if resid else None
+    dev = backend.device
+    xd = torch.zeros(M + 2, K + 8, device=dev)
+    xd[:M, :K] = x.to(dev)
+    wd, bd_, y = w.to(dev), b.to(dev), torch.full((M, N + 4), float("nan"), device=dev)
+    rd = r.to(dev) if resid else None
+    backend.bd.call("s2st_gemm_skinny_f32", xd, K + 8, wd, K, y, N + 4, bd_, act, 0.0, 0, rd, N, M, N, K)
+    backend.sync()
+    ref = x.to(torch.bfloat16).double() @ w.double().t() + b.double()
+    if act == 1:
+        ref = ref.clamp_min(0)
+    elif act == 2:
+        ref = torch.nn.functional.gelu(ref)
+    if resid:
+        ref = ref + r.double()
+    got = y[:, :N].cpu().double()
+    assert torch.isnan(y[:, N:]).all()
+    assert float((got - ref).abs().max()) <= 2e-5 * (float(ref.abs().max()) + 1.0)
+    # dropout: same mask indexing as the tiled kernels' epilogue (element index m * N + n)
+    if act == 0 and not resid and N % 8 == 0:
+        y2 = torch.zeros(M, N, device=dev)
+        backend.bd.call("s2st_gemm_skinny_f32", xd, K + 8, wd, K, y2, N, bd_, 0, 0.5, 77, None, N, M, N, K)
+        y3 = torch.zeros(M, N, device=dev)
+        backend.bd.gemm(xd[:M].contiguous()[:, :K].contiguous().to(torch.bfloat16), wd, y3, M, N, K, bias=bd_, drop_p=0.5, seed=77)
+        backend.sync()
+        assert torch.equal(y2 == 0, y3 == 0) and float((y2 - y3).abs().max()) <= 1e-4 * (float(y3.abs().max()) + 1.0)
