@@ -139,15 +139,20 @@ struct s2st_engine {
     return dec_st.base + (long)c.dec_layers * 2 * dec_st.B * dec_st.maxT * c.dec_dim + (long)l * dec_st.B * dec_st.E * 2 * c.dec_dim;
   }
   bool tail_share = false;   // set while the last tape closures run (see linear()'s weight-gradient GEMM)
-  unsigned tail_count = 0;
+  unsigned tail_count = 0, wgrad_count = 0;
+  int wgrad_main_every = 7;  // S2ST_WGRAD_MAIN_EVERY=<n>: every n-th weight-gradient GEMM stays on the data-path stream
+                             // (0 = none).  Balances the two streams; measured on the bench workload: n = 3 .. 16,
+                             // best 7 (11.15 -> 10.89 ms/step together with the attention-backward bf16 gradients)
   int tail_closures = 0;     // S2ST_TAIL_SHARE=<n>: how many closures from the end share weight gradients; measured
                              // (n = 12 / 24 / 48) within run-to-run noise of the ~0.19 ms tail wait, so off
   bool use_skinny = true;    // S2ST_NO_SKINNY=1 (A/B switch): tiled GEMMs for the AR decoding steps too
   bool skip_resid_h = true;  // S2ST_RESID_H=1 (A/B switch): also write bf16 copies of residual-stream outputs
   bool use_ln_fuse = true;  // S2ST_NO_LN_FUSE=1 (A/B switch): separate dropout-backward prologue pass
   bool use_only_h = true;  // S2ST_NO_ONLY_H=1: always keep the fp32 copy of GEMM-only tensors (A/B switch)
-  bool use_attn_gfuse = false;  // S2ST_ATTN_GFUSE=1: attention backward emits bf16 projection gradients directly
-                                // (measured: no gain over the fused cast + column-sum kernel, so off)
+  bool use_attn_gfuse = true;  // S2ST_ATTN_GFUSE=0 (A/B switch): fp32 projection gradients + a cast / column-sum pass.
+                               // Emitting the bf16 GEMM operands from the attention backward takes 0.6 ms off the
+                               // data-path stream but makes the second stream the longer one (its final join grew from
+                               // 0.1 to 0.6 ms): it only pays together with wgrad_main_every below
   bool use_act_fuse = true;  // S2ST_NO_ACT_FUSE=1: separate ReLU-dropout backward kernel (A/B switch)
   bool use_flash = true;  // S2ST_NO_FLASH=1: unfused attention everywhere (A/B switch)
   int ffn_act = 1;        // 1 relu (s2st layers), 2 gelu (HuBERT layers)
@@ -501,7 +506,8 @@ struct s2st_engine {
         g.ep.accumulate = 1;
         // weight gradients go to the second stream -- except every other one at the very end of the backward
         // sweep: nothing is left to overlap them with there, the data path would only wait for the backlog
-        hipStream_t ws_st = fm && !(tail_share && ((tail_count++) & 1)) ? fork_side() : st_;
+        const bool on_main = (tail_share && ((tail_count++) & 1)) || (wgrad_main_every > 0 && (wgrad_count++ % wgrad_main_every) == 0);
+        hipStream_t ws_st = fm && !on_main ? fork_side() : st_;
         g.ws = ws_for(ws_st); g.ws_floats = skws_n;
         g.M = N; g.N = K; g.K = M; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
         chk(s2st_gemm(g, ws_st));
@@ -1472,10 +1478,11 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->hoist_kv = !(getenv("S2ST_NO_KV_HOIST") && atoi(getenv("S2ST_NO_KV_HOIST")) != 0);
   e->stall_trace = getenv("S2ST_STALL_TRACE") && atoi(getenv("S2ST_STALL_TRACE")) != 0;
   if (getenv("S2ST_TAIL_SHARE")) e->tail_closures = atoi(getenv("S2ST_TAIL_SHARE"));
+  if (getenv("S2ST_WGRAD_MAIN_EVERY")) e->wgrad_main_every = atoi(getenv("S2ST_WGRAD_MAIN_EVERY"));
   e->use_skinny = !(getenv("S2ST_NO_SKINNY") && atoi(getenv("S2ST_NO_SKINNY")) != 0);
   e->skip_resid_h = !(getenv("S2ST_RESID_H") && atoi(getenv("S2ST_RESID_H")) != 0);
   e->use_ln_fuse = !(getenv("S2ST_NO_LN_FUSE") && atoi(getenv("S2ST_NO_LN_FUSE")) != 0);
-  e->use_attn_gfuse = getenv("S2ST_ATTN_GFUSE") && atoi(getenv("S2ST_ATTN_GFUSE")) != 0;
+  e->use_attn_gfuse = !(getenv("S2ST_ATTN_GFUSE") && atoi(getenv("S2ST_ATTN_GFUSE")) == 0);
   e->build_params();
   if (!cfg->precise && (s2st_gemm_bf16_preload(nullptr) != 0 || s2st_flash_attn_preload(nullptr) != 0)) { delete e; return S2ST_ERR_LAUNCH; }
   if (!cfg->precise && !(getenv("S2ST_NO_SIDE_STREAM") && atoi(getenv("S2ST_NO_SIDE_STREAM")))) {

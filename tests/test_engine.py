@@ -258,7 +258,8 @@ def test_dropout_training_runs_and_is_seeded(backend):
 
 
 @pytest.mark.parametrize("cfg", [MICRO, MICRO_POSTLN], ids=["preln_aux", "postln"])
-@pytest.mark.parametrize("switch", ["S2ST_NO_LN_FUSE", "S2ST_NO_KV_HOIST", "S2ST_NO_ACT_FUSE"])
+@pytest.mark.parametrize("switch", ["S2ST_NO_LN_FUSE", "S2ST_NO_KV_HOIST", "S2ST_NO_ACT_FUSE", "S2ST_ATTN_GFUSE=0",
+                                    "S2ST_WGRAD_MAIN_EVERY=0"])
 def test_fused_backward_paths_equal_the_unfused_ones(backend, cfg, switch, monkeypatch):
     """The oracle cannot reproduce the dropout masks, so fusions that only exist with dropout on are checked
     against the engine's own unfused schedule (A/B switch) with the same seed: the layer-norm backward that also
@@ -272,7 +273,7 @@ def test_fused_backward_paths_equal_the_unfused_ones(backend, cfg, switch, monke
     res = []
     for off in (False, True):
         if off:
-            monkeypatch.setenv(switch, "1")
+            monkeypatch.setenv(*(switch.split("=") if "=" in switch else (switch, "1")))
         a, e = make_engine(backend, cfg, precise=False)
         o = e.forward(s, training=True, seed=9)
         e.zero_grad()
@@ -282,10 +283,13 @@ def test_fused_backward_paths_equal_the_unfused_ones(backend, cfg, switch, monke
         del e
     (s0, g0, v0), (s1, g1, v1) = res
     assert torch.allclose(s0, s1, rtol=1e-5, atol=1e-6)
-    assert float((g0 - g1).norm()) <= 2e-5 * float(g0.norm())
+    # (the attention backward's bf16 projection gradients are the same bits as the cast pass makes; only the q/k/v
+    # bias gradients are then summed from the rounded values instead of the fp32 ones)
+    tol = 50.0 if switch.startswith("S2ST_ATTN_GFUSE") else 1.0
+    assert float((g0 - g1).norm()) <= tol * 2e-5 * float(g0.norm())
     gmax = max(float(v.norm()) for v in v0.values())
     for n in v0:
-        assert float((v0[n] - v1[n]).norm()) <= 1e-4 * (float(v0[n].norm()) + 1e-2 * gmax), n
+        assert float((v0[n] - v1[n]).norm()) <= tol * 1e-4 * (float(v0[n].norm()) + 1e-2 * gmax), n
 
 
 @pytest.mark.parametrize("cfg", [MICRO, MICRO_POSTLN], ids=["preln_aux", "postln"])
