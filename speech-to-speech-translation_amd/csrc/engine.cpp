@@ -750,8 +750,10 @@ struct s2st_engine {
     return linear(o, a.out_w, a.out_b, C, C, 0, bt.training ? c.dropout : 0.f, resid);
   }
   Ten* ffn_block(Ten* x, const LinP& fc1, const LinP& fc2, Ten* resid) {
+    // the hidden activation only feeds fc2's GEMM: bf16 copy only (training needs the ReLU form of it for the fused
+    // backward; the frozen HuBERT layers, GELU, are forward-only)
     Ten* h = linear(x, fc1.w, fc1.b, fc1.N, fc1.K, ffn_act, bt.training ? c.act_dropout : 0.f, nullptr, nullptr,
-                    ffn_act == 1);
+                    ffn_act == 1 || is_hubert);
     return linear(h, fc2.w, fc2.b, fc2.N, fc2.K, 0, bt.training ? c.dropout : 0.f, resid);
   }
   Ten* enc_layer(Ten* x, const EncLayerP& l, int B, int T) {
