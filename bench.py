@@ -233,6 +233,20 @@ def main():
         step(args.warmup + 1)
         torch.cuda.synchronize()
         vlog('cross-stream waits of one step on the data-path stream: %d us in total' % fn(eng.h, 1))
+    if os.environ.get('S2ST_BENCH_VERBOSE'):
+        # PCIe-inclusive rate: the same steps fed from HOST batches (the collater's output), i.e. with the feature
+        # upload and the per-batch index preparation inside the timed region (reported in DESIGN.md, never as `value`)
+        n_h = min(args.steps, 10)
+        for i in range(min(args.warmup, 5)):  # (pins the staging slabs)
+            trainer.train_step([samples[i]])
+        torch.cuda.synchronize()
+        th0 = time.perf_counter()
+        for i in range(args.warmup, args.warmup + n_h):
+            trainer.train_step([samples[i]])
+        torch.cuda.synchronize()
+        th = time.perf_counter() - th0
+        vlog('host-fed (PCIe-inclusive): %.3f ms/step, %.0f mel-frames/s over %d steps' % (
+            th / n_h * 1e3, sum(frames[args.warmup:args.warmup + n_h]) / th, n_h))
     if step_ev:
         vlog('per-step GPU ms (mel frames):', ' '.join('%.2f(%d)' % (step_ev[j - 1].elapsed_time(step_ev[j]), frames[args.warmup + j])
                                                      for j in range(1, len(step_ev))))
