@@ -294,7 +294,9 @@ class S2STDatasetCreator:
                  is_train_split: bool, epoch: int, seed: int, n_frames_per_step: int = 1, speaker_to_id=None):
         names = splits.split(",")
         if len(names) > 1:
-            raise NotImplementedError("concatenated / temperature-resampled multi-split training sets "
-                                      "(speech_to_text_dataset.py:500-511) are not part of this path yet")
+            # the reference's creator fails here as well: it uses ResamplingDataset / ConcatDataset without
+            # importing them (examples/s2s_trans/data/s2st_dataset.py:577-589 -> NameError)
+            raise NotImplementedError("multi-split (comma-separated) training sets are not supported by the s2s_translation "
+                                      "dataset creator")
         return cls._from_list(names[0], is_train_split, cls._load_samples_from_tsv(root, names[0]), cfg, src_dict,
                               tgt_dict, pre_tokenizer, bpe_tokenizer, n_frames_per_step, speaker_to_id)
