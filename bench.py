@@ -147,6 +147,8 @@ def main():
     tasks = importlib.import_module(PKG + ".tasks")
     trainer_mod = importlib.import_module(PKG + ".trainer")
     bd = importlib.import_module(PKG + ".runtime.binding")
+    prefetch = importlib.import_module(PKG + ".runtime.prefetch")
+    PreparedBatch = prefetch.PreparedBatch
 
     a = O.make_args(**CONFIGS[args.config])
     a.lr, a.warmup_updates, a.clip_norm, a.seed = 1.5e-3, 4000, 1.0, 1
@@ -176,7 +178,7 @@ def main():
     trainer.engine.reserve(prepared)
 
     def step(i):
-        return trainer.train_step([_Prepared(prepared[i], samples[i])])
+        return trainer.train_step([PreparedBatch(prepared[i], samples[i])])
 
     for i in range(args.warmup):
         step(i)
@@ -237,16 +239,17 @@ def main():
         # PCIe-inclusive rate: the same steps fed from HOST batches (the collater's output), i.e. with the feature
         # upload and the per-batch index preparation inside the timed region (reported in DESIGN.md, never as `value`)
         n_h = min(args.steps, 10)
-        for i in range(min(args.warmup, 5)):  # (pins the staging slabs)
-            trainer.train_step([samples[i]])
-        torch.cuda.synchronize()
-        th0 = time.perf_counter()
-        for i in range(args.warmup, args.warmup + n_h):
-            trainer.train_step([samples[i]])
-        torch.cuda.synchronize()
-        th = time.perf_counter() - th0
-        vlog('host-fed (PCIe-inclusive): %.3f ms/step, %.0f mel-frames/s over %d steps' % (
-            th / n_h * 1e3, sum(frames[args.warmup:args.warmup + n_h]) / th, n_h))
+        for mode in ("in-line", "prefetched"):
+            feed = [samples[i] for i in range(args.warmup, args.warmup + n_h)]
+            src = iter(feed) if mode == "in-line" else prefetch.DevicePrefetcher(feed, eng, depth=3)
+            torch.cuda.synchronize()
+            th0 = time.perf_counter()
+            for smp in src:
+                trainer.train_step([smp])
+            torch.cuda.synchronize()
+            th = time.perf_counter() - th0
+            vlog('host-fed (PCIe-inclusive), %s uploads: %.3f ms/step, %.0f mel-frames/s over %d steps' % (
+                mode, th / n_h * 1e3, sum(frames[args.warmup:args.warmup + n_h]) / th, n_h))
     if step_ev:
         vlog('per-step GPU ms (mel frames):', ' '.join('%.2f(%d)' % (step_ev[j - 1].elapsed_time(step_ev[j]), frames[args.warmup + j])
                                                      for j in range(1, len(step_ev))))
@@ -340,20 +343,6 @@ def main():
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()
-
-
-class _Prepared(tuple):
-    """(Batch, keep) pair that also answers the few dict lookups the trainer makes."""
-
-    def __new__(cls, prepared, sample):
-        o = super().__new__(cls, prepared)
-        o.sample = sample
-        return o
-
-    def __getitem__(self, k):
-        if isinstance(k, str):
-            return self.sample[k]
-        return tuple.__getitem__(self, k)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,98 @@
+"""Upload the next batches while the GPU works on the current one.
+
+``Engine.prepare`` turns a collated host batch into device-resident inputs (features, length / position vectors).
+Its uploads are pageable copies: issued on the compute stream they synchronise with everything already enqueued, and
+the host can no longer run ahead of the GPU (bench.py, ``S2ST_BENCH_VERBOSE=1``: 12.3 instead of 10.9 ms per step).
+``DevicePrefetcher`` runs ``prepare`` for up to ``depth`` upcoming batches on a background thread and its own HIP
+stream -- what fairseq's ``BufferedIterator`` + pinned ``DataLoader`` do for the reference
+(fairseq/data/iterators.py:210-225, 565-640) -- and hands the trainer ``PreparedBatch`` objects.
+"""
+from __future__ import annotations
+
+import queue
+import threading
+from typing import Dict, Iterable, Iterator, Optional
+
+import torch
+
+
+class PreparedBatch(tuple):
+    """``(Batch, keep)`` pair of ``Engine.prepare`` that also answers the few dict look-ups the trainer makes on a
+    sample (``ntokens``, ``nsentences``, ...)."""
+
+    def __new__(cls, prepared, sample: Dict, ready: Optional["torch.cuda.Event"] = None):
+        o = super().__new__(cls, prepared)
+        o.sample, o.ready = sample, ready
+        return o
+
+    def __getitem__(self, k):
+        if isinstance(k, str):
+            return self.sample[k]
+        return tuple.__getitem__(self, k)
+
+    def __len__(self):  # a prepared batch is never the empty padding batch
+        return 2
+
+    def wait(self):
+        """Make the current stream wait for the upload and keep the buffers alive for it."""
+        if self.ready is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(self.ready)
+            for t in tuple.__getitem__(self, 1).values():
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(cur)
+            self.ready = None
+        return self
+
+
+class DevicePrefetcher:
+    def __init__(self, batches: Iterable[Dict], engine, depth: int = 2, training: bool = True):
+        self.engine, self.training = engine, training
+        self.q: "queue.Queue" = queue.Queue(maxsize=max(depth, 1))
+        self.cuda = engine.device.type == "cuda"
+        self.stream = torch.cuda.Stream(device=engine.device) if self.cuda else None
+        self._stop = False
+        self.thread = threading.Thread(target=self._run, args=(iter(batches),), daemon=True)
+        self.thread.start()
+
+    def _run(self, it: Iterator[Dict]):
+        try:
+            if self.cuda:
+                torch.cuda.set_device(self.engine.device)
+            for sample in it:
+                if self._stop:
+                    return
+                if sample is None or len(sample) == 0:
+                    self.q.put(sample)  # padding batch of a short shard: the trainer substitutes its dummy batch
+                    continue
+                if self.cuda:
+                    with torch.cuda.stream(self.stream):
+                        prepared = self.engine.prepare(sample, training=self.training, seed=0)  # (seed: set per step by forward)
+                        ev = torch.cuda.Event()
+                        ev.record(self.stream)
+                    self.q.put(PreparedBatch(prepared, sample, ev))
+                else:
+                    self.q.put(PreparedBatch(self.engine.prepare(sample, training=self.training, seed=0), sample))
+            self.q.put(StopIteration)
+        except BaseException as e:  # surfaced in the consumer
+            self.q.put(e)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item = self.q.get()
+        if item is StopIteration:
+            raise StopIteration
+        if isinstance(item, BaseException):
+            raise item
+        return item.wait() if isinstance(item, PreparedBatch) else item
+
+    def close(self):
+        self._stop = True
+        while self.thread.is_alive():
+            try:
+                self.q.get_nowait()
+            except queue.Empty:
+                pass
+            self.thread.join(timeout=0.05)

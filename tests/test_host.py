@@ -184,3 +184,26 @@ def test_use_hubert_front_end_feeds_the_encoder(backend):
     (post, eos, extra), asr, st = out
     for x, y in ((post, rp), (eos, re_), (asr[0], rasr)):
         assert float((x.cpu() - y).abs().max()) < 5e-4 * float(y.abs().max())
+
+
+def test_prefetched_batches_train_like_inline_ones(backend):
+    """runtime/prefetch.DevicePrefetcher (background thread + its own stream for Engine.prepare) feeds the trainer
+    the same batches: identical losses and parameters as feeding the collated samples directly; an empty padding
+    batch passes through to the trainer's dummy-batch handling."""
+    P = importlib.import_module(PKG + ".runtime.prefetch")
+    res = []
+    for mode in ("inline", "prefetch"):
+        a, task, model, crit, trainer = _build(backend, NANO, lr=1e-3, warmup_updates=2, clip_norm=0.02,
+                                               dropout=0.1, attention_dropout=0.1)
+        feed = nano_batches() + [nano_batches()[0]]
+        src = iter(feed) if mode == "inline" else P.DevicePrefetcher(feed, model.engine, depth=2)
+        losses = []
+        for s in src:
+            r = trainer.train_step([s])
+            losses.append(float(r["logs"][0]["loss"]))
+        backend.sync()
+        res.append((losses, model.engine.params.clone()))
+    # (identical up to the summation-order noise of the atomics in the loss / bias-gradient reductions)
+    assert all(abs(x - y) <= 1e-6 * abs(x) for x, y in zip(res[0][0], res[1][0]))
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-6
+    assert list(P.DevicePrefetcher([{}], None.__class__ and type("E", (), {"device": torch.device("cpu"), "prepare": None})()))[0] == {}
