@@ -35,11 +35,15 @@ def _check_third_update(trainer, z, backend):
     names = z["param_order"].tolist()
     mine = dict(trainer.model.named_parameters())
     assert [n for n, _ in trainer.model.named_parameters()] == names  # optimizer state is matched by this order
-    # an Adam step moves every element by ~lr (1e-3) * m / sqrt(v): agreement to 0.5 % of a full step
+    # an Adam step moves every element by ~lr (1e-3) * m / sqrt(v): agreement to 0.5 % of a full step.  Parameters whose
+    # gradient is mathematically zero (key-projection biases, conv biases in front of a BatchNorm) are driven by rounding
+    # noise alone and are not comparable between two implementations.
+    noise_driven = lambda n: n.endswith("k_proj.bias") or (".postnet.convolutions." in n and n.endswith(".0.bias"))  # noqa: E731
     for n, ref in zip(names, z["param_norms"].tolist()):
-        assert abs(float(mine[n].detach().double().norm()) - ref) <= 5e-6 * max(1.0, mine[n].numel() ** 0.5), n
+        if not noise_driven(n):
+            assert abs(float(mine[n].detach().double().norm()) - ref) <= 5e-6 * max(1.0, mine[n].numel() ** 0.5), n
     for k in z.files:
-        if k.startswith("param."):
+        if k.startswith("param.") and not noise_driven(k[6:]):
             got = mine[k[6:]].detach().cpu().numpy()
             assert np.abs(got - z[k]).max() <= 5e-6, k
 

@@ -202,8 +202,11 @@ def test_prefetched_batches_train_like_inline_ones(backend):
             r = trainer.train_step([s])
             losses.append(float(r["logs"][0]["loss"]))
         backend.sync()
-        res.append((losses, model.engine.params.clone()))
-    # (identical up to the summation-order noise of the atomics in the loss / bias-gradient reductions)
+        res.append((losses, {n: p.detach().clone() for n, p in model.named_parameters()}))
+    # (identical up to the summation-order noise of the atomics in the loss / bias-gradient reductions; parameters
+    # with a mathematically zero gradient follow that noise through Adam's normalisation and are left out)
     assert all(abs(x - y) <= 1e-6 * abs(x) for x, y in zip(res[0][0], res[1][0]))
-    assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-6
+    for n, p in res[0][1].items():
+        if not (n.endswith("k_proj.bias") or (".postnet.convolutions." in n and n.endswith(".0.bias"))):
+            assert float((p - res[1][1][n]).abs().max()) <= 1e-6, n
     assert list(P.DevicePrefetcher([{}], None.__class__ and type("E", (), {"device": torch.device("cpu"), "prepare": None})()))[0] == {}

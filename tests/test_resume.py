@@ -61,7 +61,7 @@ def test_checkpoint_resume_continues_identically(backend, tmp_path, prefetch):
     assert len(itr) == 2  # two batches per epoch: four updates cross an epoch boundary (new shuffle)
     straight = _run(trainer, itr, 4, prefetch)
     backend.sync()
-    p_straight = trainer.engine.params.clone()
+    p_straight = {n: p.detach().clone() for n, p in trainer.model.named_parameters()}
 
     task, trainer, itr = _setup(backend, corpus)
     first = _run(trainer, itr, 2, prefetch)
@@ -76,4 +76,10 @@ def test_checkpoint_resume_continues_identically(backend, tmp_path, prefetch):
     backend.sync()
     for x, y in zip(straight, first + second):
         assert abs(x - y) <= 2e-6 * abs(x), (straight, first + second)
-    assert float((trainer.engine.params - p_straight).abs().max()) <= 2e-6
+    # Parameters whose gradient is mathematically zero (key-projection biases: softmax is shift-invariant; conv biases
+    # in front of a BatchNorm) get Adam steps of size ~lr in the direction of pure rounding noise -- here and in the
+    # reference alike -- so they are not comparable between two runs; everything else must agree.
+    noise_driven = lambda n: n.endswith("k_proj.bias") or (".postnet.convolutions." in n and n.endswith(".0.bias"))  # noqa: E731
+    for n, p in trainer.model.named_parameters():
+        if not noise_driven(n):
+            assert float((p.detach() - p_straight[n]).abs().max()) <= 2e-6, n
