@@ -268,6 +268,11 @@ def main():
 
     # ---- roofline leg: replay the timed steps with per-launch HIP events around every GEMM -------
     roofline = None
+    if not args.no_roofline and world > 1 and rank != 0:
+        # the replay below contains the gradient all-reduce: every rank has to take the same steps
+        for i in range(args.warmup, args.warmup + min(args.steps, 5)):
+            step(i)
+        torch.cuda.synchronize()
     if not args.no_roofline and rank == 0:
         import ctypes as C
         lib = bd.lib()
