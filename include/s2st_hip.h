@@ -364,6 +364,9 @@ int s2st_gl_overlap_add_b_f32(const float* frames, const float* wsq_all, const i
  * operand copies of s2st_gemm_f32), W bf16; act 0 / 1 relu / 2 gelu, dropout mask from (seed, m * N + n) */
 int s2st_gemm_skinny_f32(const float* x, int64_t ldx, const void* w_bf16, int64_t ldw, float* y, int64_t ldy, const float* bias, int32_t act, float drop_p, uint64_t seed, const float* resid, int64_t ldr, int32_t M, int32_t N, int32_t K, void* stream);
 
+/* the same with the decoder's pre-LayerNorm fused in front: y = f(LayerNorm(x; gamma, beta, eps) W^T + bias), K % 64 == 0 */
+int s2st_ln_gemm_skinny_f32(const float* x, int64_t ldx, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* w_bf16, int64_t ldw, float* y, int64_t ldy, const float* bias, int32_t act, int32_t M, int32_t N, int32_t K, void* stream);
+
 /* Host-side: max-tokens batching of length-sorted indices (fairseq/data/data_utils_fast.pyx:20-100,
  * batch_by_size_vec; the reference builds it as a Cython extension).  num_tokens in index order, batch_ends: n + 1
  * int32 slots; returns the number of batches (batch k = positions [batch_ends[k-1], batch_ends[k])), or a

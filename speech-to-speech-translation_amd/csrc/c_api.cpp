@@ -211,6 +211,10 @@ int64_t s2st_batch_by_size(const int64_t* num_tokens, int64_t n, int64_t max_tok
 int s2st_gemm_skinny_f32(const float* x, int64_t ldx, const void* w_bf16, int64_t ldw, float* y, int64_t ldy, const float* bias, int32_t act, float drop_p, uint64_t seed, const float* resid, int64_t ldr, int32_t M, int32_t N, int32_t K, void* stream) {
   return s2st_gemm_skinny(x, ldx, (const bf16raw*)w_bf16, ldw, y, ldy, bias, act, drop_p, seed, resid, ldr, M, N, K, (hipStream_t)stream);
 }
+int s2st_ln_gemm_skinny_f32(const float* x, int64_t ldx, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* w_bf16, int64_t ldw, float* y, int64_t ldy, const float* bias, int32_t act, int32_t M, int32_t N, int32_t K, void* stream) {
+  if (!ln_gamma || !ln_beta) return S2ST_ERR_ARG;
+  return s2st_gemm_skinny(x, ldx, (const bf16raw*)w_bf16, ldw, y, ldy, bias, act, 0.f, 0, nullptr, 0, M, N, K, (hipStream_t)stream, ln_gamma, ln_beta, ln_eps);
+}
 
 int s2st_profile_gemm(int32_t enable) { s2st_gemm_profile_enable(enable); return 0; }
 int s2st_profile_gemm_read(double* flops, double* ms, int64_t* launches) {

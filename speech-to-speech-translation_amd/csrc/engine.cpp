@@ -145,6 +145,7 @@ struct s2st_engine {
                              // best 7 (11.15 -> 10.89 ms/step together with the attention-backward bf16 gradients)
   int tail_closures = 0;     // S2ST_TAIL_SHARE=<n>: how many closures from the end share weight gradients; measured
                              // (n = 12 / 24 / 48) within run-to-run noise of the ~0.19 ms tail wait, so off
+  bool use_ln_skinny = true; // S2ST_NO_LN_SKINNY=1 (A/B switch): separate layer-norm kernels in the AR decoding steps
   bool use_skinny = true;    // S2ST_NO_SKINNY=1 (A/B switch): tiled GEMMs for the AR decoding steps too
   bool skip_resid_h = true;  // S2ST_RESID_H=1 (A/B switch): also write bf16 copies of residual-stream outputs
   bool use_ln_fuse = true;  // S2ST_NO_LN_FUSE=1 (A/B switch): separate dropout-backward prologue pass
@@ -540,6 +541,22 @@ struct s2st_engine {
         }
       }
     });
+    return y;
+  }
+
+  // inference with a handful of rows (AR decoding): y = act(LayerNorm(x) W^T + b) in ONE skinny launch (the
+  // normalisation is applied while the rows are converted to bf16); otherwise layernorm() + linear()
+  Ten* ln_linear(Ten* x, const LNP& ln, long w, long b, int N, int K, int act = 0, float* ext_out = nullptr) {
+    const bool fused = fast() && !bt.training && use_skinny && use_ln_skinny && x->rows <= 16 && K % 64 == 0 &&
+                       x->d && x->cols == K && (act == 0 || act == 1);
+    if (!fused) return linear(layernorm(x, ln), w, b, N, K, act, 0.f, nullptr, ext_out);
+    Ten* y = newT(x->rows, N, ext_out);
+    touch(w + (long)N * K);
+    if (b >= 0) touch(b + N);
+    touch(ln.b + ln.C);
+    if (live())
+      chk(s2st_gemm_skinny(x->d, K, PH + w, K, y->d, N, b >= 0 ? P + b : nullptr, act, 0.f, 0, nullptr, 0, x->rows, N, K,
+                           st_, P + ln.g, P + ln.b, 1e-5f));
     return y;
   }
 
@@ -952,8 +969,7 @@ struct s2st_engine {
     for (int l = 0; l < c.dec_layers; ++l) {
       const DecLayerP& L = dec[l];
       // self-attention over the cached keys / values 0..step
-      Ten* xin = pre ? layernorm(x, L.ln1) : x;
-      Ten* kvq = linear(xin, L.sa.kvq_w, L.sa.kvq_b, 3 * Cd, Cd);
+      Ten* kvq = pre ? ln_linear(x, L.ln1, L.sa.kvq_w, L.sa.kvq_b, 3 * Cd, Cd) : linear(x, L.sa.kvq_w, L.sa.kvq_b, 3 * Cd, Cd);
       if (live()) {
         Split xs{(long)3 * Cd, 0, 0, 0}, ys{(long)maxT * Cd, 0, 0, 0};
         chk(s2st_copy_rows(kvq->d, xs, dec_selfK(l) + (long)step * Cd, ys, B, Cd, st_));
@@ -965,20 +981,27 @@ struct s2st_engine {
       x = linear(o, L.sa.out_w, L.sa.out_b, Cd, Cd, 0, 0.f, x);
       if (!pre) x = layernorm(x, L.ln1);
       // encoder attention (static keys / values precomputed by decode_begin)
-      xin = pre ? layernorm(x, L.ln2) : x;
-      Ten* q = linear(xin, L.xa.q_w, L.xa.q_b, Cd, Cd);
+      Ten* q = pre ? ln_linear(x, L.ln2, L.xa.q_w, L.xa.q_b, Cd, Cd) : linear(x, L.xa.q_w, L.xa.q_b, Cd, Cd);
       const bool align = l == c.dec_layers - 1;
       o = dec_attn(q, 0, dec_crossKV(l), dec_crossKV(l) + Cd, 2 * Cd, (long)E * 2 * Cd, dec_st.enc_lens, E, H,
                    align ? attn_out : nullptr, E);
       x = linear(o, L.xa.out_w, L.xa.out_b, Cd, Cd, 0, 0.f, x);
       if (!pre) x = layernorm(x, L.ln2);
-      xin = pre ? layernorm(x, L.ln3) : x;
-      x = ffn_block(xin, L.fc1, L.fc2, x);
-      if (!pre) x = layernorm(x, L.ln3);
+      if (pre) {
+        Ten* hdn = ln_linear(x, L.ln3, L.fc1.w, L.fc1.b, L.fc1.N, L.fc1.K, ffn_act);
+        x = linear(hdn, L.fc2.w, L.fc2.b, L.fc2.N, L.fc2.K, 0, 0.f, x);
+      } else {
+        x = layernorm(ffn_block(x, L.fc1, L.fc2, x), L.ln3);
+      }
     }
-    if (has_dec_ln) x = layernorm(x, dec_ln);
-    linear(x, feat_proj.w, feat_proj.b, c.out_dim, Cd, 0, 0.f, nullptr, feat_out);
-    Ten* eos = linear(x, eos_proj.w, eos_proj.b, 1, Cd);
+    Ten* eos;
+    if (has_dec_ln) {  // both heads read the normalised state
+      ln_linear(x, dec_ln, feat_proj.w, feat_proj.b, c.out_dim, Cd, 0, feat_out);
+      eos = ln_linear(x, dec_ln, eos_proj.w, eos_proj.b, 1, Cd);
+    } else {
+      linear(x, feat_proj.w, feat_proj.b, c.out_dim, Cd, 0, 0.f, nullptr, feat_out);
+      eos = linear(x, eos_proj.w, eos_proj.b, 1, Cd);
+    }
     if (live()) chk(s2st_sigmoid(eos->d, eos_prob, B, st_));
     return err;
   }
@@ -1481,6 +1504,7 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->stall_trace = getenv("S2ST_STALL_TRACE") && atoi(getenv("S2ST_STALL_TRACE")) != 0;
   if (getenv("S2ST_TAIL_SHARE")) e->tail_closures = atoi(getenv("S2ST_TAIL_SHARE"));
   if (getenv("S2ST_WGRAD_MAIN_EVERY")) e->wgrad_main_every = atoi(getenv("S2ST_WGRAD_MAIN_EVERY"));
+  e->use_ln_skinny = !(getenv("S2ST_NO_LN_SKINNY") && atoi(getenv("S2ST_NO_LN_SKINNY")) != 0);
   e->use_skinny = !(getenv("S2ST_NO_SKINNY") && atoi(getenv("S2ST_NO_SKINNY")) != 0);
   e->skip_resid_h = !(getenv("S2ST_RESID_H") && atoi(getenv("S2ST_RESID_H")) != 0);
   e->use_ln_fuse = !(getenv("S2ST_NO_LN_FUSE") && atoi(getenv("S2ST_NO_LN_FUSE")) != 0);

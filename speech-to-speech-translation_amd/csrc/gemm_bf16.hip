@@ -752,11 +752,37 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
                                                           float* __restrict__ C, long ldc,
                                                           const float* __restrict__ bias, int act, float drop_p,
                                                           uint64_t seed, const float* __restrict__ resid, long ldr,
-                                                          int M, int N, int K) {
+                                                          int M, int N, int K, const float* __restrict__ ln_g,
+                                                          const float* __restrict__ ln_b, float ln_eps) {
   __shared__ __attribute__((aligned(16))) float part[3][64 * 4];
+  __shared__ float ln_mean[16], ln_rstd[16];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n0 = blockIdx.x * 16;
   const int kc = (lane >> 4) * 8;
+  if (ln_g) {
+    // fused LayerNorm of the activation rows (the decoder's pre-LN in front of a projection): every workgroup
+    // recomputes the 16 row statistics (32 KB of L2-resident input) instead of a separate kernel + round trip.
+    // 16 threads per row, two passes (mean, then squared deviations) like layernorm_fwd_kernel.
+    const int row = min(tid >> 4, M - 1), j = tid & 15;
+    const float* xr = A + (long)row * lda;
+    float s = 0.f;
+    for (int c = 4 * j; c < K; c += 64) {
+      const float4 v = *reinterpret_cast<const float4*>(xr + c);
+      s += v.x + v.y + v.z + v.w;
+    }
+    s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
+    const float mean = s / K;
+    float q = 0.f;
+    for (int c = 4 * j; c < K; c += 64) {
+      const float4 v = *reinterpret_cast<const float4*>(xr + c);
+      const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
+      q += a * a + b * b + cc * cc + d * d;
+    }
+    q += __shfl_xor(q, 8); q += __shfl_xor(q, 4); q += __shfl_xor(q, 2); q += __shfl_xor(q, 1);
+    if (j == 0) { ln_mean[tid >> 4] = mean; ln_rstd[tid >> 4] = rsqrtf(q / K + ln_eps); }
+    __syncthreads();
+  }
+  const float mu = ln_g ? ln_mean[lane & 15] : 0.f, rs = ln_g ? ln_rstd[lane & 15] : 1.f;
   const float* arow = A + (long)min(lane & 15, M - 1) * lda + kc;
   const bf16_t* wrow = W + (long)min(n0 + (lane & 15), N - 1) * ldw + kc;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -775,6 +801,15 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
     for (int u = 0; u < 4; ++u) {
       if (s0 + 4 * u >= steps) break;
       union { uint4 q; bf16x8 v; } xa, wb;
+      if (ln_g) {
+        const int k = 32 * (s0 + 4 * u) + kc;
+        const float4 g0 = *reinterpret_cast<const float4*>(ln_g + k), g1 = *reinterpret_cast<const float4*>(ln_g + k + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(ln_b + k), b1 = *reinterpret_cast<const float4*>(ln_b + k + 4);
+        a0[u].x = (a0[u].x - mu) * rs * g0.x + b0.x; a0[u].y = (a0[u].y - mu) * rs * g0.y + b0.y;
+        a0[u].z = (a0[u].z - mu) * rs * g0.z + b0.z; a0[u].w = (a0[u].w - mu) * rs * g0.w + b0.w;
+        a1[u].x = (a1[u].x - mu) * rs * g1.x + b1.x; a1[u].y = (a1[u].y - mu) * rs * g1.y + b1.y;
+        a1[u].z = (a1[u].z - mu) * rs * g1.z + b1.z; a1[u].w = (a1[u].w - mu) * rs * g1.w + b1.w;
+      }
       const uint2 lo = pack_bf16x4(a0[u].x, a0[u].y, a0[u].z, a0[u].w), hi = pack_bf16x4(a1[u].x, a1[u].y, a1[u].z, a1[u].w);
       xa.q = make_uint4(lo.x, lo.y, hi.x, hi.y);
       wb.q = w[u];
@@ -807,11 +842,15 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
 }
 
 // A fp32 [M][K] (row stride lda), W bf16 [N][K] (row stride ldw): M <= 16, K % 32 == 0, 16-byte aligned rows
+// ln_g / ln_b (optional, K floats each): y = f(LayerNorm(x) W^T + b) -- the normalisation is applied to the rows
+// while they are converted (K % 64 == 0 then)
 int s2st_gemm_skinny(const float* A, long lda, const bf16raw* W, long ldw, float* C, long ldc, const float* bias, int act,
-                     float drop_p, uint64_t seed, const float* resid, long ldr, int M, int N, int K, hipStream_t st) {
+                     float drop_p, uint64_t seed, const float* resid, long ldr, int M, int N, int K, hipStream_t st,
+                     const float* ln_g, const float* ln_b, float ln_eps) {
   if (M <= 0 || N <= 0) return 0;
   if (M > 16 || K <= 0 || K % 32 || lda % 4 || ldw % 8 || ((uintptr_t)A % 16) || ((uintptr_t)W % 16)) return S2ST_ERR_SHAPE;
+  if (ln_g && (!ln_b || K % 64 || ((uintptr_t)ln_g % 16) || ((uintptr_t)ln_b % 16))) return S2ST_ERR_SHAPE;
   hipLaunchKernelGGL(gemm_skinny_kernel, dim3((N + 15) / 16), dim3(256), 0, st, A, lda, reinterpret_cast<const bf16_t*>(W),
-                     ldw, C, ldc, bias, act, drop_p, seed, resid, ldr, M, N, K);
+                     ldw, C, ldc, bias, act, drop_p, seed, resid, ldr, M, N, K, ln_g, ln_b, ln_eps);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }

@@ -55,7 +55,8 @@ int s2st_gemm(GemmArgs g, hipStream_t st);
 int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* tile_out);
 // skinny-M (<= 16 rows) y = f(x W^T + b) (+ resid) with fp32 x converted in registers (AR decoding)
 int s2st_gemm_skinny(const float* A, long lda, const bf16raw* W, long ldw, float* C, long ldc, const float* bias, int act,
-                     float drop_p, uint64_t seed, const float* resid, long ldr, int M, int N, int K, hipStream_t st);
+                     float drop_p, uint64_t seed, const float* resid, long ldr, int M, int N, int K, hipStream_t st,
+                     const float* ln_g = nullptr, const float* ln_b = nullptr, float ln_eps = 1e-5f /* optional fused LayerNorm of x */);
 int s2st_gemm_bf16_preload(hipStream_t st);  // load every instantiation (empty launches)  // gemm_bf16.hip (both operands bf16)
 void s2st_gemm_profile_enable(int on);
 int s2st_gemm_profile_read(double* flops, double* ms, long* launches);

@@ -321,3 +321,23 @@ def test_skinny_gemm(backend, M, N, K, act, resid):
         backend.bd.gemm(xd[:M].contiguous()[:, :K].contiguous().to(torch.bfloat16), wd, y3, M, N, K, bias=bd_, drop_p=0.5, seed=77)
         backend.sync()
         assert torch.equal(y2 == 0, y3 == 0) and float((y2 - y3).abs().max()) <= 1e-4 * (float(y3.abs().max()) + 1.0)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(16, 1536, 512, 0), (16, 2048, 512, 1), (3, 80, 256, 0), (16, 1, 512, 0)])
+def test_skinny_gemm_with_fused_layernorm(backend, M, N, K, act):
+    """s2st_ln_gemm_skinny_f32 == LayerNorm (fp32) -> bf16 rounding -> product, formed in double."""
+    g = torch.Generator().manual_seed(N + K)
+    x = torch.randn(M, K, generator=g) * 2 + 0.5
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b, gam, bet = torch.randn(N, generator=g), torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1
+    dev = backend.device
+    y = torch.zeros(M, N, device=dev)
+    backend.bd.call("s2st_ln_gemm_skinny_f32", x.to(dev), K, gam.to(dev), bet.to(dev), 1e-5, w.to(dev), K, y, N, b.to(dev), act, M, N, K)
+    backend.sync()
+    ln = torch.nn.functional.layer_norm(x, (K,), gam, bet, 1e-5)
+    ref = ln.to(torch.bfloat16).double() @ w.double().t() + b.double()
+    if act == 1:
+        ref = ref.clamp_min(0)
+    # a last-bit difference in the statistics can flip the bf16 rounding of single inputs: 2^-9 of one product term
+    assert float((y.cpu().double() - ref).abs().max()) <= 2e-3 * (float(ref.abs().max()) + 1.0)
+    assert float((y.cpu().double() - ref).abs().mean()) <= 1e-4 * (float(ref.abs().max()) + 1.0)
