@@ -55,6 +55,8 @@ def _take(ep, n):
 
 @pytest.mark.parametrize("prefetch", [False, True])
 def test_checkpoint_resume_continues_identically(backend, tmp_path, prefetch):
+    if prefetch and backend.kind == "emu":
+        pytest.skip("prefetched variant runs on the GPU (the emulator covers the prefetcher in tests/test_host.py)")
     C = importlib.import_module(PKG + ".checkpoint_utils")
     corpus = make_corpus(str(tmp_path / "corpus"))
     task, trainer, itr = _setup(backend, corpus)
