@@ -47,11 +47,15 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                                                           float gmul, const float* __restrict__ gmul_dev,
                                                           float max_norm, float lr, float b1, float b2, float eps,
                                                           float wd, float step_size,
-                                                          float* __restrict__ gnorm_out, uint16_t* __restrict__ ph) {
+                                                          float* __restrict__ gnorm_out, uint16_t* __restrict__ ph,
+                                                          int* __restrict__ skipped) {
   if (gmul_dev) gmul *= gmul_dev[0];
   const float gn = sqrtf(sumsq[0]) * gmul;
   if (gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) gnorm_out[0] = gn;
-  if (!(gn < INFINITY)) return;
+  if (!(gn < INFINITY)) {  // non-finite gradient norm: nothing is touched; the caller finds the count (trainer.py:860-867)
+    if (skipped && blockIdx.x == 0 && threadIdx.x == 0) skipped[0] += 1;
+    return;
+  }
   float coef = gmul;
   if (max_norm > 0.f) coef *= fminf(1.f, max_norm / (gn + 1e-6f));
   const float wd_lr = wd * lr;
@@ -76,7 +80,7 @@ int s2st_sumsq(const float* x, long n, float* out, hipStream_t st) {
 
 int s2st_adam(float* p, float* g, float* m, float* v, long n, const float* sumsq, float gmul,
               const float* gmul_dev, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step,
-              float* gnorm_out, hipStream_t st, uint16_t* ph) {
+              float* gnorm_out, hipStream_t st, uint16_t* ph, int* skipped) {
   if (n <= 0) return 0;
   double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   float step_size = (float)((double)lr * sqrt(bc2) / bc1);
@@ -84,6 +88,6 @@ int s2st_adam(float* p, float* g, float* m, float* v, long n, const float* sumsq
   long blocks = (n + 256 * 4 - 1) / (256 * 4);
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, n, sumsq, gmul,
-                     gmul_dev, max_norm, lr, beta1, beta2, eps, wd, step_size, gnorm_out, ph);
+                     gmul_dev, max_norm, lr, beta1, beta2, eps, wd, step_size, gnorm_out, ph, skipped);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }

@@ -239,4 +239,5 @@ int s2st_sumsq(const float* x, long n, float* out /* += */, hipStream_t st);
 // effective gradient multiplier = gmul * (gmul_dev ? *gmul_dev : 1)
 int s2st_adam(float* p, float* g, float* m, float* v, long n, const float* sumsq, float gmul,
               const float* gmul_dev, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step,
-              float* gnorm_out, hipStream_t st, uint16_t* p_bf16 = nullptr /* optional bf16 copy of the new p */);
+              float* gnorm_out, hipStream_t st, uint16_t* p_bf16 = nullptr /* optional bf16 copy of the new p */,
+              int* skipped = nullptr /* optional device counter: += 1 when the norm is non-finite and the update is skipped */);

@@ -86,6 +86,12 @@ class S2STTransformerModel(nn.Module):
         base_architecture(args)
         if getattr(args, "activation_fn", "relu") != "relu":
             raise NotImplementedError("the HIP path implements the reference default activation (relu)")
+        # speaker conditioning (s2st_transformer.py:197-208, 388-396) is not part of the HIP schedule: refuse the
+        # flags instead of silently training an unconditioned model
+        if getattr(args, "speaker_embed_dim", None) or getattr(args, "speaker_embed_dim_dec", None) or \
+                getattr(task, "speaker_to_id", None) or getattr(args, "speaker_emb_path", None):
+            raise NotImplementedError("--speaker-embed-dim* / speaker tables: speaker conditioning is not built "
+                                      "(the reference recipe run_baseline.sh does not use it)")
         if not hasattr(args, "src_vocab_size"):
             args.src_vocab_size = len(task.source_dictionary)
             args.tgt_vocab_size = len(task.target_dictionary)
@@ -108,7 +114,10 @@ class S2STTransformerModel(nn.Module):
                 raise ValueError("--hubert-hidden must equal the HuBERT embedding width")
             path = getattr(args, "load_pretrained_hubert_from", None)
             if path:
-                ck = torch.load(path, map_location="cpu")
+                # a fairseq HuBERT checkpoint pickles cfg / task_state objects next to the tensors: full unpickle,
+                # like the reference's checkpoint_utils (fairseq/checkpoint_utils.py:281-345)
+                from ..checkpoint_utils import load_checkpoint_to_cpu
+                ck = load_checkpoint_to_cpu(path)
                 self.hubert.load_state_dict(ck["model"] if "model" in ck else ck, strict=True)
         self.engine = Engine(args, device, precise=precise)
         self._views = {}

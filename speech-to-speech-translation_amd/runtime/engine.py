@@ -169,7 +169,18 @@ class Engine:
                 self.lib.s2st_engine_bind_bf16_transposed(h, self.params_bf16_t.data_ptr())
         self.workspace: Optional[torch.Tensor] = None
         self._outpool: Optional[torch.Tensor] = None
+        # Sinusoidal tables, one per width, allocated ONCE at the largest row count the flags allow (source /
+        # target positions, the generator's max_iter): prepared batches hold raw pointers into them, so a table is
+        # never freed while the engine lives -- should one still have to grow, the old one is retired, not released
+        # (its rows are a prefix of the new one, so outstanding pointers stay valid and equal).
         self._pe: Dict[int, torch.Tensor] = {}
+        self._pe_retired: List[torch.Tensor] = []
+        self._pe_rows = max(int(getattr(args, "max_source_positions", 3000)),
+                            int(getattr(args, "max_target_positions", 2400)),
+                            int(getattr(args, "max_iter", 6000))) + 2
+        for d_ in {self.cfg.enc_dim, self.cfg.dec_dim} | ({self.cfg.asr_dim} if self.cfg.has_asr else set()) | \
+                ({self.cfg.st_dim} if self.cfg.has_st else set()):
+            self.pe(d_, 1)
         self._plan: Dict[tuple, int] = {}
         self._keep = None
         self.step_seed = 1
@@ -196,8 +207,10 @@ class Engine:
     def pe(self, dim: int, rows: int) -> torch.Tensor:
         t = self._pe.get(dim)
         if t is None or t.shape[0] < rows:
-            n = max(rows, 64)
+            n = max(rows, self._pe_rows, 64)
             n = 1 << (n - 1).bit_length()
+            if t is not None:
+                self._pe_retired.append(t)  # batches prepared earlier still point into it
             t = sinusoidal_table(n + 2, dim).to(self.device)
             self._pe[dim] = t
         return t
@@ -286,7 +299,11 @@ class Engine:
     def forward(self, sample, training: bool = True, want_attn: bool = False,
                 with_loss: bool = True, seed: Optional[int] = None) -> Dict[str, torch.Tensor]:
         """``sample`` is a collater dict, or the ``(Batch, keep)`` pair returned by ``prepare``
-        (device-resident inputs, reused across steps by the data loader / bench)."""
+        (device-resident inputs, reused across steps by the data loader / bench).
+
+        After ``reserve()`` the tensor outputs (``post_feat_out``, ``encoder_out``, logits, ...) are slices of one
+        output pool: they are valid until the NEXT forward of this engine; clone what has to live longer.
+        ``stats`` (loss terms, counts) is its own tensor and stays valid."""
         if isinstance(sample, tuple):
             b, keep = sample
             b.training, b.want_attn = int(training), int(want_attn)
@@ -326,7 +343,10 @@ class Engine:
             return torch.empty(shape, dtype=torch.float32, device=dev)
 
         o = {"post_feat_out": buf(B, D, c.out_dim), "feature_out": buf(B, D, c.out_dim),
-             "eos_out": buf(B, D, 1), "encoder_out": buf(B, E, c.enc_dim), "stats": buf(32)}
+             "eos_out": buf(B, D, 1), "encoder_out": buf(B, E, c.enc_dim),
+             # the loss / logging scalars are read lazily, possibly after later forwards (LazyLog, update_freq > 1):
+             # they get a tensor of their own, never a slice of the pool, which the next forward overwrites
+             "stats": torch.empty(32, dtype=torch.float32, device=dev)}
         out = Outputs()
         out.post_feat, out.feat, out.eos = o["post_feat_out"].data_ptr(), o["feature_out"].data_ptr(), o["eos_out"].data_ptr()
         out.enc_out, out.stats = o["encoder_out"].data_ptr(), o["stats"].data_ptr()

@@ -339,3 +339,37 @@ def test_ragged_and_minimal_batches(backend, precise):
     for s in (c1.collate_batch([0]), c2.collate_batch([0, 3, 5])):
         m.zero_grad()
         check_against_oracle(backend, e, m, s, **tol)
+
+
+def test_prepared_batches_survive_table_growth_and_later_forwards(backend):
+    """ADVICE r1: (a) a batch prepared BEFORE the positional table had to grow still points at valid rows;
+    (b) the stats of a forward are not overwritten by the next forward (LazyLog reads them later)."""
+    a, e = make_engine(backend, NANO, precise=True)
+    D = importlib.import_module(DATA)
+    c = D.SyntheticFisherCorpus(n_utts=4, seed=3, max_src=44, median_src=40, min_src=30)
+    short = c.collate_batch(range(2))
+    long_c = D.SyntheticFisherCorpus(n_utts=2, seed=5, max_src=400, median_src=380, min_src=360)
+    long_b = long_c.collate_batch(range(2))
+    # start from tables that only just cover the short batch, as round 1's cache did
+    e._pe, e._pe_rows = {}, 0
+    ref = e.forward(short, training=False, seed=1)
+    backend.sync()
+    ref_post, ref_stats = ref["post_feat_out"].clone(), ref["stats"].clone()
+    e._pe, e._pe_rows = {}, 0
+    p_short = e.prepare(short, training=False, seed=1)  # pointers into the small tables
+    rows_before = {d: t.shape[0] for d, t in e._pe.items()}
+    e.reserve([p_short, e.prepare(long_b, training=False, seed=1)], training=False)
+    p_long = e.prepare(long_b, training=False, seed=1)
+    assert any(e._pe[d].shape[0] > n for d, n in rows_before.items()), "the long batch must have grown a table"
+    # churn the allocator the way a training loop would: a released table would be reused here
+    junk = [torch.full((t.numel(),), 7.0, device=backend.device) for t in e._pe_retired]
+    o_short = e.forward(p_short, training=False, seed=1)
+    backend.sync()
+    stats_short, snap = o_short["stats"], o_short["stats"].clone()
+    assert torch.equal(o_short["post_feat_out"], ref_post)
+    assert rel(snap, ref_stats) < 1e-6  # (loss sums use atomics: last-bit differences between runs)
+    o_long = e.forward(p_long, training=False, seed=1)
+    backend.sync()
+    assert torch.equal(stats_short, snap), "stats of an earlier forward were overwritten"
+    assert not torch.equal(o_long["stats"], snap)
+    del junk

@@ -357,9 +357,21 @@ def test_sumsq_adam(backend):
         gno = torch.zeros(1, device=backend.device)
         backend.bd.call("s2st_sumsq_f32", gd, n, ss)
         ph = torch.zeros(n, dtype=torch.bfloat16, device=backend.device)
+        skipped = torch.zeros(1, dtype=torch.int32, device=backend.device)
         backend.bd.call("s2st_adam_f32", pd, gd, m, v, n, ss, 0.02, half, 0.5, 1e-2, 0.9, 0.999, 1e-8, 0.01,
-                        step, gno, ph)
+                        step, gno, ph, skipped)
         backend.sync()
+        assert int(skipped) == 0
         close(gno, gn_ref.view(1), 1e-5, 1e-6)
         close(pd, pr.detach(), 1e-5, 1e-6)
         assert torch.equal(ph, pd.to(torch.bfloat16))  # the fused bf16 copy == a cast of the new parameters
+    # non-finite gradient norm: nothing is touched and the device counter says so (trainer.py:860-867)
+    before = (pd.clone(), m.clone(), v.clone())
+    gd[3] = float("inf")
+    ss.zero_()
+    backend.bd.call("s2st_sumsq_f32", gd, n, ss)
+    backend.bd.call("s2st_adam_f32", pd, gd, m, v, n, ss, 0.02, half, 0.5, 1e-2, 0.9, 0.999, 1e-8, 0.01, 4, gno, ph,
+                    skipped)
+    backend.sync()
+    assert int(skipped) == 1 and not bool(torch.isfinite(gno).all())
+    assert torch.equal(pd, before[0]) and torch.equal(m, before[1]) and torch.equal(v, before[2])
