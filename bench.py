@@ -24,10 +24,10 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 PKG = "speech-to-speech-translation_amd"
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+HBM_PEAK_GBPS = 8000.0          # HBM3E, same table
 
 
 def algorithmic_macs(sample, a):
@@ -41,7 +41,24 @@ def algorithmic_macs(sample, a):
     C, F, Cd, Fd = a.encoder_embed_dim, a.encoder_ffn_embed_dim, a.decoder_embed_dim, a.decoder_ffn_embed_dim
     P, out = a.prenet_dim, a.output_frame_dim * a.n_frames_per_step
     k = 5
-    m = (S / 2 * (a.input_feat_per_channel * k * 1024) + S / 4 * (512 * k * 2 * C)).sum()
+    hub = str(getattr(a, "use_hubert", "false")) == "true"
+    hub_macs = 0.0
+    if hub:
+        # frozen hubert_base forward (1x, no backward), SURVEY 8(d): per utterance of N samples: conv stack over its own
+        # frame counts, projection, grouped positional conv, 12 layers (+ scores) at T' frames; the encoder then sees
+        # T' frames of 768 features (subsample conv 0 is 768 -> 1024)
+        N = (ni["padding_mask"].shape[1] - ni["padding_mask"].long().sum(1)).double()
+        n, cin = N, 1
+        for (cd, ck, cs) in [(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)] * 2:
+            n = ((n - ck) / cs).floor() + 1
+            hub_macs += float((n * cd * ck * cin).sum())
+            cin = cd
+        T = n
+        hub_macs += float((T * (512 * 768 + 768 * 48 * 128 + 12 * (4 * 768 * 768 + 2 * 768 * 3072)) + 12 * 2 * 768 * T * T).sum())
+        S = T
+        E = (((S - 1) / 2 + 1).floor() - 1).div(2).add(1).floor()
+    in_dim = a.hubert_hidden if hub else a.input_feat_per_channel
+    m = (S / 2 * (in_dim * k * 1024) + S / 4 * (512 * k * 2 * C)).sum()
     m += (E * a.encoder_transformer_layers * (4 * C * C + 2 * C * F) + a.encoder_transformer_layers * 2 * E * E * C).sum()
     m += (D * (out * P + (a.prenet_layers - 1) * P * P + P * Cd)).sum()
     L = a.decoder_transformer_layers
@@ -59,7 +76,8 @@ def algorithmic_macs(sample, a):
             Lt = lens.double()
             m += (nl * (Lt * (4 * d * d + 2 * d * d + 2 * d * Fd) + E * 2 * C * d + 2 * d * (Lt * Lt / 2 + Lt * E))).sum()
             m += (Lt * ((512 * d if first else 0) + d * 512 + 512 * V)).sum()
-    return float(m)
+    # (frozen front end: forward only -- returned as fwd-equivalent MACs of a 3x fwd+bwd count)
+    return float(m) + hub_macs / 3.0
 
 
 _T0 = time.perf_counter()
@@ -83,33 +101,63 @@ def effective_cores():
 
 
 def cpu_leg(args):
-    """Child process: oracle (torch CPU fp32) fwd+bwd+clip+Adam on the given utterances."""
+    """Child process (the only place bench.py touches oracle/): the oracle's train step (torch CPU fp32, all usable
+    host cores) -- forward + backward + clip + Adam -- on the utterances of ONE timed batch of the GPU run:
+    3 warm-up + up to 10 timed steps, median; stops early when the time budget is used up and
+    says how many steps were timed.  With --use-hubert the frozen front end (HuBERT oracle) is inside the step."""
+    import statistics
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import s2st_amd  # noqa: F401
     import s2st_oracle as O
-    from configs import CONFIGS
+    C = importlib.import_module(PKG + ".configs")
     D = importlib.import_module(PKG + ".data")
     ncores = effective_cores()
     torch.set_num_threads(ncores)
     O.USE_TORCH_CTC = True  # the reference calls torch.nn.CTCLoss (s2st_loss.py:173-176)
-    ca = O.make_args(**CONFIGS[args.config])
-    corpus = D.SyntheticFisherCorpus(n_utts=args.n_utts, seed=1234)
-    sub = corpus.collate_batch([int(i) for i in args.cpu_leg.split(",")])
+    pa = C.recipe_args(args.config)
+    hub = str(pa.use_hubert) == "true"
+    ca = O.make_args(**vars(pa))
+    ca._hubert_input = hub
+    corpus = D.SyntheticFisherCorpus(n_utts=args.n_utts, seed=1234, with_audio=hub)
+    ids = [int(i) for i in args.cpu_leg.split(",")]
+    sub = corpus.collate_batch(ids)
+    front = lambda smp: smp  # noqa: E731
+    if hub:
+        import hubert_oracle as HO
+        geo = HO.HUBERT_CONFIGS["base"]
+        hstate = HO.synth_state(geo)
+
+        def front(smp):
+            ni = smp["net_input"]
+            with torch.no_grad():
+                f, fpm = HO.extract_features(hstate, geo, ni["collated_audios_orig"], ni["padding_mask"])
+            out = dict(smp)
+            out["net_input"] = dict(ni, src_speech=f, src_speech_lens=(~fpm).long().sum(-1))
+            return out
     torch.manual_seed(1)
     m = O.S2STModel(ca)
     m.train()
     opt = O.FairseqAdam(m.parameters())
-    O.train_step(m, opt, sub, 0, 1.5e-3, 4000, 1.0)  # warm-up
-    tcpu, n = 0.0, 0
-    while tcpu < args.cpu_seconds and n < 5:
+    t_all = time.perf_counter()
+    times, n_warm = [], 0
+    for u in range(3 + 10):
         t1 = time.perf_counter()
-        O.train_step(m, opt, sub, n + 1, 1.5e-3, 4000, 1.0)
-        tcpu += time.perf_counter() - t1
-        n += 1
+        O.train_step(m, opt, front(sub), u, 1.5e-3, 4000, 1.0)
+        dt1 = time.perf_counter() - t1
+        if u < 3:
+            n_warm += 1
+        else:
+            times.append(dt1)
+            if len(times) >= 3 and (time.perf_counter() - t_all) > args.cpu_seconds:
+                break
     fr = ca.n_frames_per_step * sub["ntokens"]
-    print(json.dumps({"value": round(fr * n / tcpu, 1), "unit": "mel-frames/s", "cores": ncores, "kind": "port",
-                      "sample": f"oracle (torch CPU fp32, {ncores} threads) fwd+bwd+clip+Adam on the first 8 utterances "
-                                f"of timed batch 0 ({fr} mel frames, src up to {int(sub['net_input']['src_speech'].shape[1])} "
-                                f"frames), 1 warm-up + {n} timed steps"}))
+    med = statistics.median(times)
+    print(json.dumps({"value": round(fr / med, 1), "unit": "mel-frames/s", "cores": ncores, "kind": "port",
+                      "sample": f"oracle (torch CPU fp32, {ncores} threads) fwd+bwd+clip+Adam"
+                                f"{' incl. the frozen HuBERT-base forward' if hub else ''} on "
+                                f"{'ALL' if args.cpu_whole else 'the first'} {len(ids)} utterances of timed batch 0 "
+                                f"({fr} mel frames, src up to {int(corpus.src_n_frames[ids].max())} frames), "
+                                f"{n_warm} warm-up + {len(times)} timed steps, median {med:.2f} s/step"}))
 
 
 def main():
@@ -120,7 +168,10 @@ def main():
     ap.add_argument("--config", default="base_recipe")
     ap.add_argument("--max-tokens", type=int, default=20000)
     ap.add_argument("--n-utts", type=int, default=4096)
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-baseline leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="time budget of the CPU-baseline leg (0 = skip)")
+    ap.add_argument("--cpu-utts", type=int, default=0, help="CPU leg: first N utterances of timed batch 0 (0 = the "
+                    "whole batch; default 8 for the HuBERT configuration, whose CPU front end is ~10x the model)")
+    ap.add_argument("--cpu-whole", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -142,25 +193,29 @@ def main():
         torch.distributed.init_process_group("nccl", device_id=dev)
 
     import s2st_amd  # noqa: F401
-    import s2st_oracle as O
-    from configs import CONFIGS
+    C_ = importlib.import_module(PKG + ".configs")
     tasks = importlib.import_module(PKG + ".tasks")
     trainer_mod = importlib.import_module(PKG + ".trainer")
     bd = importlib.import_module(PKG + ".runtime.binding")
     prefetch = importlib.import_module(PKG + ".runtime.prefetch")
-    PreparedBatch = prefetch.PreparedBatch
 
-    a = O.make_args(**CONFIGS[args.config])
-    a.lr, a.warmup_updates, a.clip_norm, a.seed = 1.5e-3, 4000, 1.0, 1
+    a = C_.recipe_args(args.config)  # named configurations live in the package (configs.py)
+    hub = str(a.use_hubert) == "true"
     task = tasks.S2ST_TranslationTask.setup_task(a, device=dev)
     torch.manual_seed(1)
     model = task.build_model(a)
+    if hub:  # hubert_base_ls960.pt is not on the box: random-init weights of that architecture
+        g_ = torch.Generator(device="cpu").manual_seed(2)
+        model.hubert.params.copy_(torch.randn(model.hubert.n_params, generator=g_) * 0.02)
+        for n_, off_, num_, shp_ in model.hubert.infos:
+            if len(shp_) == 1 and n_.endswith(".weight"):
+                model.hubert.params[off_:off_ + num_].fill_(1.0)  # norm gains
     criterion = task.build_criterion(a)
     trainer = trainer_mod.Trainer(a, task, model, criterion)
     eng = model.engine
     vlog('model built', eng.n_params, 'params')
 
-    corpus = task.load_dataset("train", n_utts=args.n_utts, seed=1234)
+    corpus = task.load_dataset("train", n_utts=args.n_utts, seed=1234, with_audio=hub)
     batches = corpus.batches(max_tokens=args.max_tokens, bsz_mult=8)
     # deterministic shuffle of the (length-sorted) batches, then deal round-robin to ranks
     import numpy as np
@@ -168,7 +223,11 @@ def main():
     need = (args.steps + args.warmup)
     mine = [batches[order[(i * world + rank) % len(batches)]] for i in range(need)]
     samples = [corpus.collate_batch(ix) for ix in mine]
-    prepared = [eng.prepare(s, training=True) for s in samples]  # device-resident inputs
+    if hub:
+        for s_ in samples:
+            s_["net_input"]["src_speech"] = None  # HuBERT mode: the collater hands over audio, no fbank tensor
+    # device-resident inputs (features / staged waveforms, length and position vectors)
+    prepared = [model.prepare_sample(s_, training=True) for s_ in samples]
     frames = [a.n_frames_per_step * s["ntokens"] for s in samples]
     macs = [algorithmic_macs(s, a) for s in samples]
     vlog('batches prepared', [(len(ix), int(corpus.src_n_frames[ix].max())) for ix in mine])
@@ -176,9 +235,14 @@ def main():
     # size workspace / output pool for the largest batch geometry up front (what a max-tokens data
     # loader knows): no device allocation inside the loop
     trainer.engine.reserve(prepared)
+    if hub:
+        wb = max((p_.hubert_io[0].shape for p_ in prepared), key=lambda sh: sh[0] * sh[1])
+        for p_ in prepared:
+            model.hubert.reserve(*p_.hubert_io[0].shape)
+        vlog('largest waveform batch', tuple(wb))
 
     def step(i):
-        return trainer.train_step([PreparedBatch(prepared[i], samples[i])])
+        return trainer.train_step([prepared[i]])
 
     for i in range(args.warmup):
         step(i)
@@ -186,7 +250,7 @@ def main():
             torch.cuda.synchronize()
             vlog('warmup step', i, 'done')
     torch.cuda.synchronize()
-    if os.environ.get('S2ST_BENCH_VERBOSE') and args.warmup > 0:
+    if os.environ.get('S2ST_BENCH_VERBOSE') and args.warmup > 0 and not hub:
         # host cost of enqueueing ONE step into an empty queue (no back-pressure) vs its GPU time
         th = time.perf_counter()
         step(args.warmup - 1)
@@ -241,7 +305,7 @@ def main():
         n_h = min(args.steps, 10)
         for mode in ("in-line", "prefetched"):
             feed = [samples[i] for i in range(args.warmup, args.warmup + n_h)]
-            src = iter(feed) if mode == "in-line" else prefetch.DevicePrefetcher(feed, eng, depth=3)
+            src = iter(feed) if mode == "in-line" else prefetch.DevicePrefetcher(feed, eng, depth=3, model=model if hub else None)
             torch.cuda.synchronize()
             th0 = time.perf_counter()
             for smp in src:
@@ -266,58 +330,97 @@ def main():
         total_frames, total_flops = my_frames, my_flops
     last_loss = float(trainer.criterion.last_outputs["stats"][16])
 
-    # ---- roofline leg: replay the timed steps with per-launch HIP events around every GEMM -------
+    # ---- roofline leg: replay the timed steps with per-DISPATCH timing (include/s2st_hip.h s2st_profile_*) ------
+    # Every launch of the dominant kernels carries its own start / stop event (hipExtLaunchKernelGGL): the elapsed
+    # time of a pair is that dispatch's begin -> end on the stream it ran on -- the duration a rocprofv3 kernel trace
+    # of this command reports (profiles/r02_*_kernel_stats.txt) -- so per-kernel sums cannot exceed the step.
     roofline = None
+    n_replay = args.steps
     if not args.no_roofline and world > 1 and rank != 0:
         # the replay below contains the gradient all-reduce: every rank has to take the same steps
-        for i in range(args.warmup, args.warmup + min(args.steps, 5)):
+        for i in range(args.warmup, args.warmup + n_replay):
             step(i)
         torch.cuda.synchronize()
     if not args.no_roofline and rank == 0:
         import ctypes as C
         lib = bd.lib()
-        n_replay = min(args.steps, 5)
-        lib.s2st_profile_gemm(1)
+        lib.s2st_profile_enable.argtypes = [C.c_int32]
+        lib.s2st_profile_report.argtypes = [C.c_char_p, C.c_int64]
+        lib.s2st_profile_report.restype = C.c_int64
+        lib.s2st_profile_enable(1)
         for i in range(args.warmup, args.warmup + n_replay):
             step(i)
         torch.cuda.synchronize()
-        lib.s2st_profile_gemm(0)
-        fl, ms, nl = C.c_double(), C.c_double(), C.c_int64()
-        lib.s2st_profile_gemm_read(C.byref(fl), C.byref(ms), C.byref(nl))
-        vlog('roofline leg done', nl.value, 'gemm launches')
-        alg = 3.0 * 2.0 * sum(macs[args.warmup:args.warmup + n_replay])
-        achieved = alg / (ms.value * 1e-3) / 1e12
-        # HBM traffic per launch of the same kernels: measured with rocprofv3 PMC passes (cannot run
-        # inside this process); the committed measurement is reported, with its source
+        lib.s2st_profile_enable(0)
+        buf = C.create_string_buffer(1 << 16)
+        n = lib.s2st_profile_report(buf, len(buf))
+        rows = {}
+        for ln in buf.value.decode().splitlines() if n > 0 else []:
+            tag, cnt, us, w1, w2 = ln.split("\t")
+            rows[tag] = dict(n=int(cnt), us=float(us), work=float(w1), work2=float(w2))
+        vlog('roofline leg done', sum(r["n"] for r in rows.values()), 'profiled launches')
+        if os.environ.get('S2ST_BENCH_VERBOSE'):
+            for tag, r in sorted(rows.items(), key=lambda kv: -kv[1]["us"]):
+                vlog('  %-52s launches/step %6.1f  avg %7.2f us  ms/step %6.3f' % (
+                    tag, r["n"] / n_replay, r["us"] / r["n"], r["us"] / n_replay * 1e-3))
+        mfma = {t: r for t, r in rows.items() if t.startswith(("gemm_bf16", "flash_"))}
+        gemm = {t: r for t, r in rows.items() if t.startswith("gemm_bf16")}
+        alg = 3.0 * 2.0 * sum(macs[args.warmup:args.warmup + n_replay])  # valid (un-padded) tokens, fwd + bwd
+        launched = sum(r["work"] for r in mfma.values())                  # as launched: padded rows / rectangles included
+        useful = alg / launched                                           # algorithmic share of the launched FLOPs
+        dom_tag, dom = max(gemm.items(), key=lambda kv: kv[1]["us"])
+        avg_us = dom["us"] / dom["n"]
+        alg_per_launch = useful * dom["work"] / dom["n"]
+        achieved = alg_per_launch / (avg_us * 1e-6) / 1e12
+        # HBM traffic per launch of the dominant kernel: rocprofv3 PMC passes of this command (cannot run inside this
+        # process); the committed measurement is reported, with its source
         traffic, traffic_src = None, None
         try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
                 tj = json.load(f)
-            traffic, traffic_src = round(tj["hbm_bytes_per_launch"]), tj["source"]
+            if tj.get("config", "base_recipe") == args.config:
+                traffic, traffic_src = round(tj["kernels"][dom_tag]["hbm_bytes_per_launch"]), tj["source"]
         except Exception:
             pass
+        gemm_us = sum(r["us"] for r in gemm.values())
         roofline = {
-            "bound": "mfma", "kernel": "gemm_bf16_dma_kernel<BM,BN,layouts,4 stages,8 waves> (all GEMM launches of the step)",
+            "bound": "mfma", "kernel": dom_tag + " (the GEMM instantiation with the largest share of the step)",
             "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 5), "traffic": traffic, "traffic_unit": "B/launch",
             "traffic_source": traffic_src,
-            "launches_per_step": nl.value // n_replay,
-            "avg_launch_us": round(ms.value * 1e3 / max(nl.value, 1), 2),
-            "gemm_ms_per_step": round(ms.value / n_replay, 3),
-            "as_launched_tflops": round(fl.value / (ms.value * 1e-3) / 1e12, 2),
+            "launches_per_step": round(dom["n"] / n_replay, 1), "avg_launch_us": round(avg_us, 2),
+            "ms_per_step": round(dom["us"] / n_replay * 1e-3, 3),
+            "algorithmic_gflop_per_launch": round(alg_per_launch / 1e9, 3),
+            "as_launched_gflop_per_launch": round(dom["work"] / dom["n"] / 1e9, 3),
+            "min_bytes_per_launch": round(dom["work2"] / dom["n"]),
+            "algorithmic_share_of_launched_flops": round(useful, 4),
+            "timing": "start/stop events attached to each dispatch (hipExtLaunchKernelGGL), %d replayed steps" % n_replay,
+            "all_gemm": {"launches_per_step": round(sum(r["n"] for r in gemm.values()) / n_replay, 1),
+                         "ms_per_step": round(gemm_us / n_replay * 1e-3, 3),
+                         "achieved": round(useful * sum(r["work"] for r in gemm.values()) / (gemm_us * 1e-6) / 1e12, 2),
+                         "frac": round(useful * sum(r["work"] for r in gemm.values()) / (gemm_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 5)},
             "algorithmic_gflop_per_step": round(alg / n_replay / 1e9, 1),
+            # the HBM-bound kernels of the step: bytes they have to move / their own dispatch time
+            "hbm_kernels": {t: {"gbps": round(r["work"] / (r["us"] * 1e-6) / 1e9, 1),
+                                "frac": round(r["work"] / (r["us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+                                "avg_launch_us": round(r["us"] / r["n"], 2),
+                                "launches_per_step": round(r["n"] / n_replay, 1)}
+                            for t, r in rows.items() if not t.startswith(("gemm_bf16", "flash_"))},
         }
 
-    # ---- CPU baseline leg: the oracle (torch fp32, all usable host cores) on a bounded sample, in a
-    #      child process with a hard time limit so a slow host can never stall the bench -----------
+    # ---- CPU baseline leg: the oracle (torch fp32, all usable host cores) on one timed batch, in a child process
+    #      with a hard time limit so a slow host can never stall the bench ----------------------------------------
     cpu = None
     if args.cpu_seconds > 0 and rank == 0 and world == 1:
         import subprocess
-        idx = ",".join(str(int(i)) for i in mine[args.warmup][:8])
+        n_cpu = args.cpu_utts or (8 if hub else 0)
+        ids = mine[args.warmup] if n_cpu <= 0 else mine[args.warmup][:n_cpu]
+        idx = ",".join(str(int(i)) for i in ids)
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-leg", idx, "--config", args.config,
-                                "--n-utts", str(args.n_utts), "--cpu-seconds", str(args.cpu_seconds)],
-                               capture_output=True, text=True, timeout=6 * args.cpu_seconds + 90)
+                                "--n-utts", str(args.n_utts), "--cpu-seconds", str(args.cpu_seconds),
+                                "--cpu-whole", str(int(n_cpu <= 0))],
+                               capture_output=True, text=True, timeout=8 * args.cpu_seconds + 120)
             for ln in r.stdout.splitlines():
                 if ln.startswith("{"):
                     cpu = json.loads(ln)
@@ -333,8 +436,14 @@ def main():
             "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "s2st_transformer base 12enc/6dec d512 nfps4 + aux ASR/ST(1x64) + CTC, "
-                                   "recipe dropouts, max-tokens=20000 Fisher-shaped batches, update-freq 1",
+            "config": {"workload": ("s2st_transformer base 12enc/6dec d512 nfps4 + aux ASR/ST(1x64) + CTC, "
+                                    "recipe dropouts, max-tokens=20000 Fisher-shaped batches, update-freq 1"
+                                    if not hub else
+                                    "frozen hubert_base front end on 16 kHz audio (--use-hubert true, random-init weights) "
+                                    "+ s2st_transformer base 12enc/6dec d512 nfps4 + aux ASR/ST(1x64), CTC off (the "
+                                    "reference fails with both, SURVEY B.7), recipe dropouts, max-tokens=20000 "
+                                    "(fbank-frame cost) Fisher-shaped batches, update-freq 1"),
+                       "name": args.config,
                        "global_batch_mel_frames": round(total_frames / args.steps, 1),
                        "parallelism": f"dp{world}", "gemm": "bf16 MFMA operands (bf16 copies of fp32 tensors), fp32 accumulate, fp32 master weights / residual stream / softmax / losses",
                        "final_loss": round(last_loss, 4),

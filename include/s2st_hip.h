@@ -402,11 +402,14 @@ int64_t s2st_hubert_workspace_floats(s2st_engine* e, int32_t B, int32_t N);
 int s2st_hubert_forward(s2st_engine* e, const float* wave, const int32_t* frame_lens, int32_t B, int32_t N,
                         float* out, float* workspace, int64_t workspace_floats, void* stream);
 
-/* Measurement aid (bench.py roofline leg): bracket every GEMM launch with HIP events on its
- * own stream; read returns the sum of as-launched FLOPs (2*M*N*K*batch), the sum of kernel
- * durations in ms and the launch count since enable, then clears. */
-int s2st_profile_gemm(int32_t enable);
-int s2st_profile_gemm_read(double* flops, double* ms, int64_t* launches);
+/* Measurement aid (bench.py roofline leg).  While enabled, the dominant kernels (GEMMs, split-K combine, fused
+ * attention, LayerNorm, optimizer) are launched with a start / stop event attached to the dispatch itself, on the
+ * stream they run on: the elapsed time of such a pair is the dispatch's own begin -> end (what rocprofv3
+ * --kernel-trace reports).  s2st_profile_report writes one line per kernel instantiation,
+ * "tag\tlaunches\ttotal_us\twork\twork2\n" (work = as-launched FLOPs of a GEMM / attention launch, or the bytes an
+ * HBM-bound kernel has to move), clears the registry and returns the text length (-1: buffer too small). */
+int s2st_profile_enable(int32_t enable);
+int64_t s2st_profile_report(char* out, int64_t cap);
 
 int s2st_version(void);
 /* number of HIP devices visible (0 = none: every compute entry point then fails) */

@@ -50,8 +50,33 @@ BASE_PARITY = dict(BASE, dropout=0.0, attention_dropout=0.0, activation_dropout=
 BASE_RECIPE = dict(BASE, dropout=0.1, attention_dropout=0.1, activation_dropout=0.01,
                    prenet_dropout=0.5, postnet_dropout=0.5)
 
+# BASELINE.json configs[3]: frozen hubert_base front end (--use-hubert true, 768-wide features at 50 fps) + the base
+# model + aux ASR/ST decoders; parity flavour (dropouts 0) and recipe flavour
+# CTC is OFF here, as in run_baseline.sh (ctc_weight=0.0): with --use-hubert and --ctc-weight > 0 the reference
+# itself fails -- s2st_loss.py:231-232 derives the CTC input lengths from the FBANK lengths (100 fps) while the
+# encoder now runs on 50 fps HuBERT frames, and F.ctc_loss raises "Expected input_lengths to have value at most E"
+# (reproduced by oracle/gen_golden_hubert_train.py with ctc_weight=0.3).
+HUBERT_TRAIN = dict(BASE_PARITY, use_hubert="true", hubert_hidden=768, ctc_weight=0.0)
+HUBERT_RECIPE = dict(BASE_RECIPE, use_hubert="true", hubert_hidden=768, ctc_weight=0.0)
+
 CONFIGS = {"tiny": TINY, "tiny_postln": TINY_POSTLN, "base": BASE_PARITY,
-           "base_recipe": BASE_RECIPE}
+           "base_recipe": BASE_RECIPE, "hubert_train": HUBERT_TRAIN, "base_recipe_hubert": HUBERT_RECIPE}
+
+
+def hubert_train_sample(which=0):
+    """Seeded batch behind tests/golden/s2st_hubert_train.npz: 4 utterances with 16 kHz audio (160 samples per fbank
+    frame); in HuBERT mode the collater hands over no fbank tensor, only its lengths (s2st_dataset.py:339-358)."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    D = importlib.import_module("speech-to-speech-translation_amd.data")
+    c = D.SyntheticFisherCorpus(n_utts=64, seed=11, with_audio=True, max_src=420, median_src=300)
+    s = c.collate_batch(list(range(4)) if which == 0 else list(range(4, 8)))
+    s["net_input"]["src_speech"] = None
+    return s
 
 
 def golden_sample(cfg_name, which=0):

@@ -125,6 +125,13 @@ def sub(x):
     return x if x.size <= 40000 else x.reshape(-1)[::SUB_STRIDE].copy()
 
 
+GRAD_STRIDE = 127
+
+
+def gsub(x):
+    return x.astype(np.float32) if x.size <= 4096 else x.reshape(-1)[::GRAD_STRIDE].astype(np.float32).copy()
+
+
 def run_config(name, out_dir, full=True, n_updates=3):
     cfg = CONFIGS[name]
     torch.manual_seed(0)
@@ -149,6 +156,12 @@ def run_config(name, out_dir, full=True, n_updates=3):
     for n in FULL_GRADS_TINY:
         if n in named and named[n].grad is not None:
             out[f"grad.{n}"] = sub(to_np(named[n].grad))
+    if not full:
+        # base size: a sample of EVERY gradient tensor (direction checks of the bf16 path, tests/test_engine.py):
+        # tensors up to 4096 elements whole, larger ones as flat[::GRAD_STRIDE]
+        for n in sorted(named):
+            if named[n].grad is not None:
+                out[f"gsub.{n}"] = gsub(to_np(named[n].grad))
     sd = model.state_dict()
     for k, v in sd.items():
         if "running_" in k or "num_batches" in k:

@@ -50,12 +50,14 @@ def synth_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int = 0) -> Dict[
     return {k: synth_tensor(k, v, seed) for k, v in shapes.items()}
 
 
-def load_synth(module, seed: int = 0):
-    """Fill a torch module (reference, oracle or HIP model) in place."""
+def load_synth(module, seed: int = 0, skip_prefix: str = None):
+    """Fill a torch module (reference, oracle or HIP model) in place.  Entries under ``skip_prefix`` keep their
+    current values (the frozen HuBERT inside the reference encoder is keyed by its own local names)."""
     import torch
 
     sd = module.state_dict()
-    new = {k: torch.from_numpy(synth_tensor(k, tuple(v.shape), seed)).to(v.dtype)
+    new = {k: (v if skip_prefix and k.startswith(skip_prefix) else
+               torch.from_numpy(synth_tensor(k, tuple(v.shape), seed)).to(v.dtype))
            for k, v in sd.items()}
     module.load_state_dict(new, strict=True)
     return module

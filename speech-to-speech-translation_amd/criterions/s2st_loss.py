@@ -136,6 +136,7 @@ class Tacotron2Criterion(torch.nn.Module):
         mine = (self.ctc_weight, self.asr_ce_weight, self.st_ce_weight, self.l1_loss_weight,
                 self.mse_loss_weight, self.eos_loss_weight, self.bce_pos_weight, self.eps)
         assert all(abs(a - b) < 1e-6 for a, b in zip(c_w, mine)), "criterion and model flags disagree"
+        sample = model.front_end_sample(sample)  # --use-hubert (s2st_transformer.py:245-252)
         out = eng.forward(sample, training=model.training, want_attn=False, with_loss=True)
         self.last_outputs = out
         stats = out["stats"]

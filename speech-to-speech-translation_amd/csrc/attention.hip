@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "s2st_ops.h"
+#include "s2st_prof.h"
 
 namespace {
 
@@ -510,8 +511,10 @@ int s2st_flash_attn_fwd(const s2st_attn_args* p, hipStream_t st) {
   auto go = [&](auto nwc) {
     constexpr int NW = decltype(nwc)::value;
     dim3 grid((p->T + 16 * NW - 1) / (16 * NW), p->B * p->H);
-    if (p->dh == 128) hipLaunchKernelGGL((flash_fwd_kernel<128, NW>), grid, dim3(64 * NW), 0, st, a);
-    else hipLaunchKernelGGL((flash_fwd_kernel<64, NW>), grid, dim3(64 * NW), 0, st, a);
+    // as-launched FLOPs over the padded T x S rectangle (QK^T and PV), halved for the causal form
+    const double fl = 4.0 * p->B * p->H * (double)p->T * p->S * p->dh * (p->causal ? 0.5 : 1.0);
+    if (p->dh == 128) s2st_launch("flash_fwd_kernel<128>", fl, 0.0, flash_fwd_kernel<128, NW>, grid, dim3(64 * NW), 0, st, a);
+    else s2st_launch("flash_fwd_kernel<64>", fl, 0.0, flash_fwd_kernel<64, NW>, grid, dim3(64 * NW), 0, st, a);
   };
   const int nw = attn_nw();
   if (nw == 1) go(std::integral_constant<int, 1>{});
@@ -539,12 +542,14 @@ int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_sc
     constexpr int NW = decltype(nwc)::value;
     dim3 gk((p->S + 16 * NW - 1) / (16 * NW), p->B * p->H), gq((p->T + 16 * NW - 1) / (16 * NW), p->B * p->H);
     const bool kv = phase == 0 || phase == 2, qq = phase == 0 || phase == 3;
+    // as-launched FLOPs: dK,dV pass = S^T recompute + dP + dV + dK (4 products), dQ pass = S + dP + dQ (3 products)
+    const double f1 = 2.0 * p->B * p->H * (double)p->T * p->S * p->dh * (p->causal ? 0.5 : 1.0);
     if (p->dh == 128) {
-      if (kv) hipLaunchKernelGGL((flash_bwd_kv_kernel<128, NW>), gk, dim3(64 * NW), 0, st, a);
-      if (qq) hipLaunchKernelGGL((flash_bwd_q_kernel<128, NW>), gq, dim3(64 * NW), 0, st, a);
+      if (kv) s2st_launch("flash_bwd_kv_kernel<128>", 4 * f1, 0.0, flash_bwd_kv_kernel<128, NW>, gk, dim3(64 * NW), 0, st, a);
+      if (qq) s2st_launch("flash_bwd_q_kernel<128>", 3 * f1, 0.0, flash_bwd_q_kernel<128, NW>, gq, dim3(64 * NW), 0, st, a);
     } else {
-      if (kv) hipLaunchKernelGGL((flash_bwd_kv_kernel<64, NW>), gk, dim3(64 * NW), 0, st, a);
-      if (qq) hipLaunchKernelGGL((flash_bwd_q_kernel<64, NW>), gq, dim3(64 * NW), 0, st, a);
+      if (kv) s2st_launch("flash_bwd_kv_kernel<64>", 4 * f1, 0.0, flash_bwd_kv_kernel<64, NW>, gk, dim3(64 * NW), 0, st, a);
+      if (qq) s2st_launch("flash_bwd_q_kernel<64>", 3 * f1, 0.0, flash_bwd_q_kernel<64, NW>, gq, dim3(64 * NW), 0, st, a);
     }
   };
   const int nw = attn_nw();

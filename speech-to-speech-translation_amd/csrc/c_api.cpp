@@ -216,12 +216,7 @@ int s2st_ln_gemm_skinny_f32(const float* x, int64_t ldx, const float* ln_gamma, 
   return s2st_gemm_skinny(x, ldx, (const bf16raw*)w_bf16, ldw, y, ldy, bias, act, 0.f, 0, nullptr, 0, M, N, K, (hipStream_t)stream, ln_gamma, ln_beta, ln_eps);
 }
 
-int s2st_profile_gemm(int32_t enable) { s2st_gemm_profile_enable(enable); return 0; }
-int s2st_profile_gemm_read(double* flops, double* ms, int64_t* launches) {
-  long n = 0;
-  int rc = s2st_gemm_profile_read(flops, ms, &n);
-  *launches = n;
-  return rc;
-}
+int s2st_profile_enable(int32_t enable) { s2st_profile_enable_impl(enable); return 0; }
+int64_t s2st_profile_report(char* out, int64_t cap) { return s2st_profile_report_impl(out, cap); }
 
 }  // extern "C"

@@ -16,9 +16,11 @@
 // accumulate / split-K atomics.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "s2st_ops.h"
+#include "s2st_prof.h"
 
 namespace {
 
@@ -275,38 +277,43 @@ bool vec_ok(const GemmOperand& o, int R, int K) {
 
 }  // namespace
 
-// ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream ----
+// ---- per-dispatch timing registry (bench.py roofline leg; s2st_prof.h) -----------------------------------------
 namespace {
-struct ProfRec { hipEvent_t a, b; double flops; int M, N, K, batch, akm, bkm, acc, bm, splitk; };
+struct ProfRec { const char* tag; hipEvent_t a, b; double work, work2; };
 std::vector<ProfRec> g_prof;
 bool g_prof_on = false;
 }  // namespace
 
-void s2st_gemm_profile_enable(int on) { g_prof_on = on != 0; }
+bool s2st_prof_enabled() { return g_prof_on; }
+void s2st_prof_push(const char* tag, hipEvent_t a, hipEvent_t b, double work, double work2) {
+  g_prof.push_back(ProfRec{tag, a, b, work, work2});
+}
+void s2st_profile_enable_impl(int on) { g_prof_on = on != 0; }
 
-int s2st_gemm_profile_read(double* flops, double* ms, long* launches) {
-  double f = 0, t = 0;
-  // tuning aid: S2ST_GEMM_PROFILE_DUMP=<path> appends one line per launch (shape, layout, tile, us)
-  const char* dump = getenv("S2ST_GEMM_PROFILE_DUMP");
-  FILE* df = dump ? fopen(dump, "a") : nullptr;
+// One text line per tag: "tag\tlaunches\ttotal_us\twork\twork2\n" (work = FLOPs or bytes summed over the launches);
+// clears the registry.  Returns the number of bytes written (without the terminating 0) or -1 if `cap` is too small.
+long s2st_profile_report_impl(char* out, long cap) {
+  struct Agg { const char* tag; long n; double us, work, work2; };
+  std::vector<Agg> aggs;
   for (auto& r : g_prof) {
     hipEventSynchronize(r.b);
     float e = 0.f;
     hipEventElapsedTime(&e, r.a, r.b);
-    t += e;
-    f += r.flops;
-    if (df)
-      fprintf(df, "%d,%d,%d,%d,%c%c,%d,%d,%d,%.2f\n", r.M, r.N, r.K, r.batch, r.akm ? 'K' : 'R',
-              r.bkm ? 'K' : 'R', r.acc, r.bm, r.splitk, e * 1e3);
     hipEventDestroy(r.a);
     hipEventDestroy(r.b);
+    Agg* f = nullptr;
+    for (auto& a : aggs) if (strcmp(a.tag, r.tag) == 0) { f = &a; break; }
+    if (!f) { aggs.push_back(Agg{r.tag, 0, 0, 0, 0}); f = &aggs.back(); }
+    f->n += 1; f->us += e * 1e3; f->work += r.work; f->work2 += r.work2;
   }
-  if (df) fclose(df);
-  *flops = f;
-  *ms = t;
-  *launches = (long)g_prof.size();
   g_prof.clear();
-  return 0;
+  long o = 0;
+  for (auto& a : aggs) {
+    int w = snprintf(out + o, cap > o ? (size_t)(cap - o) : 0, "%s\t%ld\t%.3f\t%.6e\t%.6e\n", a.tag, a.n, a.us, a.work, a.work2);
+    if (w < 0 || o + w >= cap) return -1;
+    o += w;
+  }
+  return o;
 }
 
 int s2st_gemm(GemmArgs g, hipStream_t st) {
@@ -315,24 +322,10 @@ int s2st_gemm(GemmArgs g, hipStream_t st) {
   const bool bf16_in = g.A.dtype == S2ST_BF16;
   if (bf16_in && g.precise) return S2ST_ERR_ARG;       // bf16x3 needs the fp32 values
   if (!bf16_in && (g.C.h || !g.C.p)) return S2ST_ERR_ARG;  // bf16 copy: fast path only
-  ProfRec rec{};
-  if (g_prof_on) {
-    hipEventCreate(&rec.a);
-    hipEventCreate(&rec.b);
-    rec.flops = 2.0 * g.M * g.N * (double)g.K * g.batch;
-    hipEventRecord(rec.a, st);
-  }
   if (g.zdiv <= 0) g.zdiv = 1;
   if (bf16_in) {
     int tile = 0;
-    int rc = s2st_gemm_bf16(g, st, &tile);
-    if (g_prof_on) {
-      rec.M = g.M; rec.N = g.N; rec.K = g.K; rec.batch = g.batch; rec.akm = g.A.kmajor; rec.bkm = g.B.kmajor;
-      rec.acc = g.ep.accumulate; rec.bm = tile; rec.splitk = 0;
-      hipEventRecord(rec.b, st);
-      g_prof.push_back(rec);
-    }
-    return rc;
+    return s2st_gemm_bf16(g, st, &tile);
   }
   g.avec = vec_ok(g.A, g.M, g.K) ? 1 : 0;
   g.bvec = vec_ok(g.B, g.N, g.K) ? 1 : 0;
@@ -368,12 +361,6 @@ int s2st_gemm(GemmArgs g, hipStream_t st) {
   } else {
     if (vec) launch_layouts<64, 64, false, true>(g, grid, st);
     else launch_layouts<64, 64, false, false>(g, grid, st);
-  }
-  if (g_prof_on) {
-    rec.M = g.M; rec.N = g.N; rec.K = g.K; rec.batch = g.batch; rec.akm = g.A.kmajor; rec.bkm = g.B.kmajor;
-    rec.acc = g.ep.accumulate; rec.bm = bm; rec.splitk = g.splitk;
-    hipEventRecord(rec.b, st);
-    g_prof.push_back(rec);
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

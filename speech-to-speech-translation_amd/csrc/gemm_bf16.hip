@@ -25,6 +25,7 @@
 #include <cstdlib>
 
 #include "s2st_ops.h"
+#include "s2st_prof.h"
 
 namespace {
 
@@ -536,23 +537,49 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_kernel(GemmArgs g) {
   gemm_epilogue<BM, BN, WGN>(g, acc, m0, n0, wm, wn, lane, zb, ks, zq, zr);
 }
 
+// as-launched work of one GEMM (profiling records): FLOPs, and the bytes it has to move at least -- both bf16
+// operands once, the result once per output copy, the old value / residual once when it is read
+double gemm_flops(const GemmArgs& g) { return 2.0 * g.M * g.N * (double)g.K * g.batch; }
+double gemm_min_bytes(const GemmArgs& g) {
+  const double mn = (double)g.M * g.N * g.batch;
+  return 2.0 * g.batch * ((double)g.M * g.K + (double)g.N * g.K) + mn * ((g.C.p ? 4 : 0) + (g.C.h ? 2 : 0)) +
+         mn * 4 * ((g.ep.accumulate ? 1 : 0) + (g.ep.resid ? 1 : 0));
+}
+// profiling tag of an instantiation, spelled like the kernel name in a rocprofv3 kernel trace
+template <int BM, int BN, bool AKM, bool BKM, int NS, int NW>
+const char* dma_tag() {
+  static char buf[80];
+  if (!buf[0])
+    snprintf(buf, sizeof buf, "gemm_bf16_dma_kernel<%d, %d, %s, %s, %d, %d>", BM, BN, AKM ? "true" : "false",
+             BKM ? "true" : "false", NS, NW);
+  return buf;
+}
+template <int BM, int BN, bool AKM, bool BKM, bool VEC>
+const char* staged_tag() {
+  static char buf[80];
+  if (!buf[0])
+    snprintf(buf, sizeof buf, "gemm_bf16_kernel<%d, %d, %s, %s, %s>", BM, BN, AKM ? "true" : "false",
+             BKM ? "true" : "false", VEC ? "true" : "false");
+  return buf;
+}
+
 template <int BM, int BN, int NS, int NW>
 int launch_dma(const GemmArgs& g, dim3 grid, hipStream_t st) {
   constexpr int LDS = NS * (BM + BN) * 128;
-  auto go = [&](auto kern) {
+  auto go = [&](auto kern, const char* tag) {
     static bool configured = false;  // one flag per instantiation (the lambda's operator() template)
     if (!configured) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
         return -1;
       configured = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), LDS, st, g);
+    s2st_launch(tag, gemm_flops(g), gemm_min_bytes(g), kern, grid, dim3(64 * NW), LDS, st, g);
     return 0;
   };
-  if (g.A.kmajor && g.B.kmajor) return go(gemm_bf16_dma_kernel<BM, BN, true, true, NS, NW>);
-  if (g.A.kmajor && !g.B.kmajor) return go(gemm_bf16_dma_kernel<BM, BN, true, false, NS, NW>);
-  if (!g.A.kmajor && g.B.kmajor) return go(gemm_bf16_dma_kernel<BM, BN, false, true, NS, NW>);
-  return go(gemm_bf16_dma_kernel<BM, BN, false, false, NS, NW>);
+  if (g.A.kmajor && g.B.kmajor) return go(gemm_bf16_dma_kernel<BM, BN, true, true, NS, NW>, dma_tag<BM, BN, true, true, NS, NW>());
+  if (g.A.kmajor && !g.B.kmajor) return go(gemm_bf16_dma_kernel<BM, BN, true, false, NS, NW>, dma_tag<BM, BN, true, false, NS, NW>());
+  if (!g.A.kmajor && g.B.kmajor) return go(gemm_bf16_dma_kernel<BM, BN, false, true, NS, NW>, dma_tag<BM, BN, false, true, NS, NW>());
+  return go(gemm_bf16_dma_kernel<BM, BN, false, false, NS, NW>, dma_tag<BM, BN, false, false, NS, NW>());
 }
 
 // C(m, n) (+)= sum_s slab[z][s][m][n]
@@ -589,14 +616,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 template <int BM, int BN, bool VEC>
 void launch_layouts(const GemmArgs& g, dim3 grid, hipStream_t st) {
+  const double fl = gemm_flops(g), by = gemm_min_bytes(g);
   if (g.A.kmajor && g.B.kmajor)
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, true, true, VEC>), grid, dim3(256), 0, st, g);
+    s2st_launch(staged_tag<BM, BN, true, true, VEC>(), fl, by, gemm_bf16_kernel<BM, BN, true, true, VEC>, grid, dim3(256), 0, st, g);
   else if (g.A.kmajor && !g.B.kmajor)
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, true, false, VEC>), grid, dim3(256), 0, st, g);
+    s2st_launch(staged_tag<BM, BN, true, false, VEC>(), fl, by, gemm_bf16_kernel<BM, BN, true, false, VEC>, grid, dim3(256), 0, st, g);
   else if (!g.A.kmajor && g.B.kmajor)
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, false, true, VEC>), grid, dim3(256), 0, st, g);
+    s2st_launch(staged_tag<BM, BN, false, true, VEC>(), fl, by, gemm_bf16_kernel<BM, BN, false, true, VEC>, grid, dim3(256), 0, st, g);
   else
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, false, false, VEC>), grid, dim3(256), 0, st, g);
+    s2st_launch(staged_tag<BM, BN, false, false, VEC>(), fl, by, gemm_bf16_kernel<BM, BN, false, false, VEC>, grid, dim3(256), 0, st, g);
 }
 
 // 16-byte fast path: aligned base, ld and batch strides multiples of 8 elements.  (K tails are
@@ -732,8 +760,10 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
   else launch_layouts<64, 64, true>(g, grid, st);
   if (use_slab) {
     const long nthr = (long)g.M * ((g.N + 3) / 4);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthr + 255) / 256), g.batch), dim3(256), 0, st,
-                       (const float*)g.slab, g.C, g.M, g.N, g.splitk, g.zdiv, g.ep.accumulate);
+    // bytes: every slab once, the result once (twice when it accumulates)
+    const double by = 4.0 * g.M * g.N * g.batch * (g.splitk + 1 + (g.ep.accumulate ? 1 : 0));
+    s2st_launch("splitk_reduce_kernel", by, 0.0, splitk_reduce_kernel, dim3((unsigned)((nthr + 255) / 256), g.batch),
+                dim3(256), 0, st, (const float*)g.slab, g.C, g.M, g.N, g.splitk, g.zdiv, g.ep.accumulate);
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -5,6 +5,7 @@
 // optimizer.step), fairseq/utils.py:345-395 (clip_grad_norm_; apex multi_tensor_l2norm),
 // fairseq/optim/adam.py:163-239 (Adam.step; apex FusedAdam), fused_adam.py:11-37.
 #include "s2st_ops.h"
+#include "s2st_prof.h"
 
 namespace {
 
@@ -74,7 +75,7 @@ int s2st_sumsq(const float* x, long n, float* out, hipStream_t st) {
   long blocks = (n / 4 + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, out);
+  s2st_launch("sumsq_kernel", 4.0 * n, 0.0, sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, out);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
@@ -87,7 +88,8 @@ int s2st_adam(float* p, float* g, float* m, float* v, long n, const float* sumsq
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 || (ph && (uintptr_t)ph % 8)) return S2ST_ERR_ARG;
   long blocks = (n + 256 * 4 - 1) / (256 * 4);
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, n, sumsq, gmul,
-                     gmul_dev, max_norm, lr, beta1, beta2, eps, wd, step_size, gnorm_out, ph, skipped);
+  // bytes: p, g, m, v read and written (32 B per parameter) + the bf16 copy (2 B)
+  s2st_launch("adam_kernel", (32.0 + (ph ? 2.0 : 0.0)) * n, 0.0, adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m,
+              v, n, sumsq, gmul, gmul_dev, max_norm, lr, beta1, beta2, eps, wd, step_size, gnorm_out, ph, skipped);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }

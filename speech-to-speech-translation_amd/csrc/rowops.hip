@@ -6,6 +6,7 @@
 // apex FusedLayerNorm), fairseq/modules/multihead_attention.py:343-366 (mask fill,
 // fp32 softmax, dropout) and the softmax inside F.multi_head_attention_forward (:170-192).
 #include "s2st_ops.h"
+#include "s2st_prof.h"
 
 namespace {
 
@@ -393,8 +394,9 @@ int s2st_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
                        uint16_t* yh) {
   if (rows <= 0) return 0;
   if (cols % 4 != 0 || cols > LN_MAXV * 256) return S2ST_ERR_SHAPE;
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, gamma, beta,
-                     y, mean, rstd, rows, cols, eps, yh);
+  // bytes: x read, y written in fp32 and / or bf16
+  s2st_launch("layernorm_fwd_kernel", (double)rows * cols * (4 + (y ? 4 : 0) + (yh ? 2 : 0)), 0.0, layernorm_fwd_kernel,
+              dim3((rows + 3) / 4), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, rows, cols, eps, yh);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
@@ -419,12 +421,15 @@ int s2st_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
   // phase 0: both kernels; 1: only dx + per-block partials; 2: only the parameter-gradient reduce (lets the
   // caller put that reduce on another stream: it is off the backward's critical path)
   if (phase != 2) {
+    // bytes: dy, x read; dx written (read too when it accumulates); the bf16 operand of the fused form
+    const double by = (double)rows * cols * (12 + (dx_accumulate ? 4 : 0) + (dph ? 2 : 0));
     if (dph)
-      hipLaunchKernelGGL(layernorm_bwd_kernel<true>, dim3(blocks), dim3(64 * LNB_WAVES), 0, st, dy, x, gamma, mean,
-                         rstd, dx, dx_accumulate, scratch, rows, cols, dph, drop_p, 1.f / (1.f - drop_p), seed);
+      s2st_launch("layernorm_bwd_kernel<true>", by, 0.0, layernorm_bwd_kernel<true>, dim3(blocks), dim3(64 * LNB_WAVES), 0, st,
+                  dy, x, gamma, mean, rstd, dx, dx_accumulate, scratch, rows, cols, dph, drop_p, 1.f / (1.f - drop_p), seed);
     else
-      hipLaunchKernelGGL(layernorm_bwd_kernel<false>, dim3(blocks), dim3(64 * LNB_WAVES), 0, st, dy, x, gamma, mean,
-                         rstd, dx, dx_accumulate, scratch, rows, cols, (uint16_t*)nullptr, 0.f, 1.f, (uint64_t)0);
+      s2st_launch("layernorm_bwd_kernel<false>", by, 0.0, layernorm_bwd_kernel<false>, dim3(blocks), dim3(64 * LNB_WAVES), 0,
+                  st, dy, x, gamma, mean, rstd, dx, dx_accumulate, scratch, rows, cols, (uint16_t*)nullptr, 0.f, 1.f,
+                  (uint64_t)0);
   }
   if (phase != 1) {
     const int nout = dph ? 3 : 2;

@@ -58,8 +58,8 @@ int s2st_gemm_skinny(const float* A, long lda, const bf16raw* W, long ldw, float
                      float drop_p, uint64_t seed, const float* resid, long ldr, int M, int N, int K, hipStream_t st,
                      const float* ln_g = nullptr, const float* ln_b = nullptr, float ln_eps = 1e-5f /* optional fused LayerNorm of x */);
 int s2st_gemm_bf16_preload(hipStream_t st);  // load every instantiation (empty launches)  // gemm_bf16.hip (both operands bf16)
-void s2st_gemm_profile_enable(int on);
-int s2st_gemm_profile_read(double* flops, double* ms, long* launches);
+void s2st_profile_enable_impl(int on);                 // per-dispatch timing registry (s2st_prof.h, gemm.hip)
+long s2st_profile_report_impl(char* out, long cap);
 
 // ---------------------------------------------------------------------------------------
 // row ops (rowops.hip)

@@ -184,10 +184,10 @@ class HubertFrontend:
             padding_mask = padding_mask[:, :-extra]
         return padding_mask.view(padding_mask.size(0), n_frames, -1).all(-1)
 
-    def extract_features(self, source: torch.Tensor, padding_mask: Optional[torch.Tensor] = None,
-                         mask: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
-        if mask:
-            raise NotImplementedError("the frozen front end runs with mask=False (s2st_transformer.py:248)")
+    def stage(self, source: torch.Tensor, padding_mask: Optional[torch.Tensor] = None):
+        """Host side of a call, done once per batch: upload the waveform, turn the sample-level padding mask into
+        frame counts (hubert.py:400-410).  Returns ``(wave_dev, frame_lens_dev int32, frame_pad_mask_host, T)``;
+        ``self.last_frame_lens`` holds the host copy of the frame counts."""
         wave = source.to(self.device, torch.float32).contiguous()
         bd.require_device(wave)
         B, N = wave.shape
@@ -200,7 +200,14 @@ class HubertFrontend:
         if not bool(((~fpm).long().cumsum(1)[:, -1:] == (~fpm).long().sum(1, keepdim=True)).all()) or \
                 bool((fpm[:, :-1] & ~fpm[:, 1:]).any()):
             raise ValueError("padding must be a suffix of every utterance")
-        lens = self._to_device_async((~fpm).sum(1).to(torch.int32))
+        self.last_frame_lens = (~fpm).sum(1).long()  # host copy: the encoder's length / position bookkeeping
+        lens = self._to_device_async(self.last_frame_lens.to(torch.int32))
+        return wave, lens, fpm, T
+
+    def forward_into(self, wave: torch.Tensor, lens: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """Device side: the frozen forward of staged inputs into ``out`` [B, T, embed] (no host work besides the
+        enqueue: what a training step repeats on a prepared batch)."""
+        B, N = wave.shape
         key = (B, N)
         if key not in self._plan:
             n = int(self.lib.s2st_hubert_workspace_floats(self.h, B, N))
@@ -210,9 +217,26 @@ class HubertFrontend:
         need = self._plan[key]
         if self.workspace is None or self.workspace.numel() < need:
             self.workspace = torch.empty(need, dtype=torch.float32, device=self.device)
-        out = torch.empty(B, T, self.embed, dtype=torch.float32, device=self.device)
         bd.check(self.lib.s2st_hubert_forward(self.h, wave.data_ptr(), lens.data_ptr(), B, N, out.data_ptr(),
                                               self.workspace.data_ptr(), self.workspace.numel(),
                                               C.c_void_p(bd.stream_ptr())), "s2st_hubert_forward")
         self._keep = (wave, lens)
+        return out
+
+    def reserve(self, B: int, N: int):
+        """Size the workspace for a [B, N] waveform batch up front (no allocation inside a training loop)."""
+        n = int(self.lib.s2st_hubert_workspace_floats(self.h, B, N))
+        if n < 0:
+            raise bd.S2STHipError(f"s2st_hubert_workspace_floats failed with code {n}")
+        self._plan[(B, N)] = n
+        if self.workspace is None or self.workspace.numel() < n:
+            self.workspace = torch.empty(n, dtype=torch.float32, device=self.device)
+
+    def extract_features(self, source: torch.Tensor, padding_mask: Optional[torch.Tensor] = None,
+                         mask: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+        if mask:
+            raise NotImplementedError("the frozen front end runs with mask=False (s2st_transformer.py:248)")
+        wave, lens, fpm, T = self.stage(source, padding_mask)
+        out = torch.empty(wave.shape[0], T, self.embed, dtype=torch.float32, device=self.device)
+        self.forward_into(wave, lens, out)
         return out, self._to_device_async(fpm)

@@ -217,6 +217,46 @@ class S2STTransformerModel(nn.Module):
         feats, pad = self.hubert.extract_features(collated_audios, padding_mask)
         return feats, (~pad).long().sum(-1)
 
+    def prepare_sample(self, sample, training: bool = True):
+        """Device-resident form of a collated sample (what ``DevicePrefetcher`` and bench.py hold): features, length
+        / position vectors uploaded once (``Engine.prepare``).  With --use-hubert the prepared batch owns the staged
+        waveform and a feature buffer [B, T', hubert_hidden] that ``front_end_sample`` refills on every step -- the
+        frozen front end is part of the training step (s2st_transformer.py:245-252), its host-side staging is not."""
+        from ..runtime.prefetch import PreparedBatch
+        if isinstance(sample, tuple) or sample is None or len(sample) == 0:
+            return sample
+        if self.hubert is None:
+            return PreparedBatch(self.engine.prepare(sample, training=training), sample)
+        ni = sample["net_input"]
+        if ni.get("collated_audios_orig") is None:
+            raise ValueError("--use-hubert needs net_input['collated_audios_orig'] / ['padding_mask'] "
+                             "(data config use_hubert: s2st_dataset.py:339-358)")
+        wave, lens_dev, _, T = self.hubert.stage(ni["collated_audios_orig"], ni["padding_mask"])
+        feats = torch.empty(wave.shape[0], T, self.hubert.embed, dtype=torch.float32, device=self.engine.device)
+        proto = dict(sample)
+        # the fbank lengths stay available as ctc_src_speech_lens: the criterion derives the CTC input lengths
+        # from them even in this mode (s2st_loss.py:231-232, SURVEY B.7)
+        proto["net_input"] = dict(ni, src_speech=feats, src_speech_lens=self.hubert.last_frame_lens.clone(),
+                                  ctc_src_speech_lens=ni["src_speech_lens"])
+        pb = PreparedBatch(self.engine.prepare(proto, training=training), sample)
+        pb.hubert_io = (wave, lens_dev, feats)
+        return pb
+
+    def front_end_sample(self, sample):
+        """Training / validation entry of the --use-hubert branch (s2st_transformer.py:245-252 as reached from
+        s2st_loss.py:207-218): a collated sample carries the raw audio and NO fbank tensor; the frozen HuBERT's
+        features take the place of ``src_speech`` / ``src_speech_lens``.  Non-HuBERT models pass through."""
+        if self.hubert is None or sample is None or len(sample) == 0:
+            return sample
+        if not isinstance(sample, tuple):
+            sample = self.prepare_sample(sample, training=self.training)
+        io = getattr(sample, "hubert_io", None)
+        if io is None:
+            raise ValueError("a batch prepared without the HuBERT front end was given to a --use-hubert model")
+        self.hubert.eval()
+        self.hubert.forward_into(*io)
+        return sample
+
     def forward(self, src_tokens, src_lengths, collated_audios, padding_mask, prev_output_tokens,
                 **kwargs):
         """Returns ``[(post_feat_out, eos_out, extra), (asr_logits, None) | None,

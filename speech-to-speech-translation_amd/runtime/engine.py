@@ -228,10 +228,19 @@ class Engine:
         E = conv_out_len(conv_out_len(S, k), k)
         # encoder lengths: floor((len - 1) / 2 + 1) twice (s2st_transformer.py:126-130)
         enc_lens = src_lens.clone()
-        ctc_lens = src_lens.clone()
+        # CTC input lengths come from the FBANK lengths, also when the encoder ran on HuBERT frames
+        # (s2st_loss.py:231-232; models/s2st_transformer.py front_end_sample keeps them)
+        ctc_src = ni.get("ctc_src_speech_lens")
+        ctc_lens = (ctc_src if ctc_src is not None else src_lens).cpu().long().clone()
         for _ in range(2):
             enc_lens = ((enc_lens.float() - 1) / 2 + 1).floor().long()
             ctc_lens = (ctc_lens - k + 2 * (k // 2)) // 2 + 1  # s2st_loss.py:231-232
+        if self.cfg.has_ctc and with_loss and int(ctc_lens.max()) > E:
+            # what F.ctc_loss tells the reference's user in this situation (--use-hubert with --ctc-weight > 0:
+            # fbank-rate lengths against HuBERT-rate encoder frames)
+            raise RuntimeError(f"Expected input_lengths to have value at most {E}, but got value "
+                               f"{int(ctc_lens.max())} (CTC input lengths are derived from the fbank lengths, "
+                               f"s2st_loss.py:231-232)")
         prev = ni["prev_output_tokens"].to(dev, torch.float32).contiguous()
         D = prev.shape[1]
         tgt_lens = sample["target_lengths"].cpu().long()

@@ -38,7 +38,7 @@ class PreparedBatch(tuple):
         if self.ready is not None:
             cur = torch.cuda.current_stream()
             cur.wait_event(self.ready)
-            for t in tuple.__getitem__(self, 1).values():
+            for t in list(tuple.__getitem__(self, 1).values()) + list(getattr(self, "hubert_io", None) or ()):
                 if torch.is_tensor(t) and t.is_cuda:
                     t.record_stream(cur)
             self.ready = None
@@ -46,14 +46,21 @@ class PreparedBatch(tuple):
 
 
 class DevicePrefetcher:
-    def __init__(self, batches: Iterable[Dict], engine, depth: int = 2, training: bool = True):
-        self.engine, self.training = engine, training
+    def __init__(self, batches: Iterable[Dict], engine, depth: int = 2, training: bool = True, model=None):
+        """``model``: pass the S2STTransformerModel of a --use-hubert run so that batches are staged through
+        ``model.prepare_sample`` (waveform upload + feature buffer) instead of ``engine.prepare``."""
+        self.engine, self.training, self.model = engine, training, model
         self.q: "queue.Queue" = queue.Queue(maxsize=max(depth, 1))
         self.cuda = engine.device.type == "cuda"
         self.stream = torch.cuda.Stream(device=engine.device) if self.cuda else None
         self._stop = False
         self.thread = threading.Thread(target=self._run, args=(iter(batches),), daemon=True)
         self.thread.start()
+
+    def _prepare(self, sample):
+        if self.model is not None:
+            return self.model.prepare_sample(sample, training=self.training)
+        return PreparedBatch(self.engine.prepare(sample, training=self.training, seed=0), sample)  # (seed: set per step by forward)
 
     def _run(self, it: Iterator[Dict]):
         try:
@@ -67,12 +74,13 @@ class DevicePrefetcher:
                     continue
                 if self.cuda:
                     with torch.cuda.stream(self.stream):
-                        prepared = self.engine.prepare(sample, training=self.training, seed=0)  # (seed: set per step by forward)
+                        pb = self._prepare(sample)
                         ev = torch.cuda.Event()
                         ev.record(self.stream)
-                    self.q.put(PreparedBatch(prepared, sample, ev))
+                        pb.ready = ev
+                    self.q.put(pb)
                 else:
-                    self.q.put(PreparedBatch(self.engine.prepare(sample, training=self.training, seed=0), sample))
+                    self.q.put(self._prepare(sample))
             self.q.put(StopIteration)
         except BaseException as e:  # surfaced in the consumer
             self.q.put(e)

@@ -140,6 +140,7 @@ class Trainer:
 
     def _fast_micro_step(self, sample, hooks, gscale: float = 1.0):
         eng = self.engine
+        sample = self.model.front_end_sample(sample)  # --use-hubert: frozen front end inside the step
         out = eng.forward(sample, training=True, want_attn=False, with_loss=True)
         self.criterion.last_outputs = out
         eng.backward(gscale, on_segment=hooks)

@@ -56,6 +56,52 @@ def _sub(x):
     return x if x.size <= 40000 else x.reshape(-1)[::SUB]
 
 
+GRAD_STRIDE = 127
+
+
+def gsub(x):
+    """Sampling rule of the ``gsub.*`` golden entries (oracle/gen_golden.py): tensors up to 4096 elements whole,
+    larger ones as flat[::127]."""
+    x = np.asarray(x)
+    return x.astype(np.float64) if x.size <= 4096 else x.reshape(-1)[::GRAD_STRIDE].astype(np.float64)
+
+
+def BF16_TENSOR_TOL(name):
+    """bf16-operand mode, base size, per-tensor Frobenius-relative gradient error against the reference: 5e-2 for
+    every tensor except the two prenet layers at the very end of the longest backward path (decoder stack -> prenet),
+    where the operand rounding has accumulated to 6.3e-2 (measured; bf16x3 mode: 4e-3 everywhere)."""
+    return 8e-2 if name.startswith("decoder.prenet.0.layers.") else 5e-2
+
+
+def check_gradient_direction(named_grads, z, per_tensor_tol, whole_tol, tag=""):
+    """Every gradient tensor against the reference's sampled gradient (``gsub.<name>``): Frobenius-relative
+    difference of the samples per tensor (a gradient with the right norm and the wrong direction fails), and of the
+    concatenation of all samples.  The floor (1e-3 of the largest tensor norm, spread over the sample) covers
+    tensors whose gradient is mathematically zero (k_proj biases: softmax shift invariance)."""
+    names = [k[5:] for k in z.files if k.startswith("gsub.")]
+    assert len(names) > 100 or tag == "tiny"
+    gmax = max(float(np.linalg.norm(z["gsub." + n])) for n in names)
+    num = den = 0.0
+    worst = []
+    for n in names:
+        ref = z["gsub." + n].astype(np.float64).reshape(-1)
+        mine = gsub(named_grads[n].detach().cpu().numpy()).reshape(-1)
+        d = float(np.linalg.norm(mine - ref))
+        r = float(np.linalg.norm(ref))
+        num += d * d
+        den += r * r
+        worst.append((d / (r + 1e-3 * gmax), n))
+    worst.sort(reverse=True)
+    whole = math.sqrt(num / den)
+    print(f"[gradient direction {tag}] whole {whole:.2e}; worst tensors " +
+          ", ".join(f"{n} {v:.2e}" for v, n in worst[:4]))
+    tol_of = per_tensor_tol if callable(per_tensor_tol) else (lambda n: per_tensor_tol)
+    bad = [(v, n) for v, n in worst if v >= tol_of(n)]
+    assert not bad, (tag, "per-tensor gradient direction", bad[:5])
+    assert whole < whole_tol, (tag, "whole-gradient", whole)
+    return worst[0], whole
+
+
 def make_engine(backend, cfg, precise):
     eng = importlib.import_module(ENG)
     a = O.make_args(**cfg)
@@ -231,6 +277,12 @@ def test_base_golden(backend, golden_dir):
         for n, pv, gv, isb in e.named_views():
             if not isb and n in gn:
                 assert abs(float(gv.norm()) - gn[n]) < gtol * (gn[n] + 1e-3 * gmax), (precise, n)
+        # gradient DIRECTION of every tensor against the reference's sampled gradients: the
+        # benchmarked bf16 mode is held to 5e-2 per tensor / 2e-2 for the whole gradient
+        grads = {n: gv for n, pv, gv, isb in e.named_views() if not isb}
+        w, whole = check_gradient_direction(grads, z, 5e-3 if precise else BF16_TENSOR_TOL, 2e-3 if precise else 2e-2,
+                                            tag="bf16x3" if precise else "bf16")
+        print(f"[base golden {'bf16x3' if precise else 'bf16'}] worst tensor {w[1]} {w[0]:.2e}, whole gradient {whole:.2e}")
         if precise:
             assert np.array_equal(O.stop_indices(o["eos_out"].cpu()).numpy(), z["int.stop_idx"])
         del e

@@ -2,6 +2,7 @@
 reference goldens (through the emulator build on CPU, the product library on GPU)."""
 import ctypes
 import importlib
+import math
 import os
 
 import numpy as np
@@ -210,3 +211,67 @@ def test_prefetched_batches_train_like_inline_ones(backend):
         if not (n.endswith("k_proj.bias") or (".postnet.convolutions." in n and n.endswith(".0.bias"))):
             assert float((p - res[1][1][n]).abs().max()) <= 1e-6, n
     assert list(P.DevicePrefetcher([{}], None.__class__ and type("E", (), {"device": torch.device("cpu"), "prepare": None})()))[0] == {}
+
+
+def _hubert_nano_setup(backend, **extra):
+    import hubert_oracle as HO
+    geo = dict(HO.TINY)
+    cfg = dict(NANO, use_hubert="true", hubert_hidden=geo["embed"], ctc_weight=0.0)
+    cfg.update(extra)
+    a, task, model, crit, trainer = _build(backend, cfg, hubert_geometry=geo, lr=1e-3, warmup_updates=2,
+                                           clip_norm=0.02)
+    model.hubert.load_state_dict(HO.synth_state(geo))
+    D = importlib.import_module(PKG + ".data")
+    c = D.SyntheticFisherCorpus(n_utts=4, seed=3, max_src=64, median_src=50, min_src=40, with_audio=True)
+    batches = []
+    for ix in (range(2), range(2, 4)):
+        s = c.collate_batch(ix)
+        s["net_input"]["src_speech"] = None  # HuBERT mode: the collater hands over audio only
+        batches.append(s)
+    return geo, cfg, a, task, model, crit, trainer, batches
+
+
+def _oracle_hubert_sample(geo, s):
+    """What the reference encoder's HuBERT branch feeds its subsampler (oracle front end)."""
+    import hubert_oracle as HO
+    ni = s["net_input"]
+    feats, fpm = HO.extract_features(HO.synth_state(geo), geo, ni["collated_audios_orig"], ni["padding_mask"])
+    out = dict(s)
+    out["net_input"] = dict(ni, src_speech=feats, src_speech_lens=(~fpm).long().sum(-1))
+    return out
+
+
+def test_use_hubert_training_steps_against_oracle(backend):
+    """BASELINE.json configs[3] composed as a TRAINING step at nano size: frozen HuBERT front end -> encoder ->
+    mel decoder + aux ASR/ST heads -> s2st_loss -> backward -> clip -> Adam, two updates, against oracle HuBERT ->
+    oracle model / criterion / optimizer (s2st_transformer.py:245-252, s2st_loss.py:179-292)."""
+    geo, cfg, a, task, model, crit, trainer, batches = _hubert_nano_setup(backend)
+    a2 = O.make_args(**cfg)
+    a2._hubert_input = True
+    m = O.S2STModel(a2)
+    load_synth(m, 0)
+    m.train()
+    opt = O.FairseqAdam(m.parameters())
+    for u, s in enumerate(batches):
+        r = trainer.train_step([s])
+        backend.sync()
+        loss, gn, lr, log, _ = O.train_step(m, opt, _oracle_hubert_sample(geo, s), u, 1e-3, 2, 0.02)
+        assert abs(float(r["logs"][0]["loss"]) - float(loss)) < 1e-4 * abs(float(loss))
+        assert abs(float(r["gnorm"]) - float(gn)) < 2e-3 * float(gn)
+    ref = dict(m.named_parameters())
+    for n, p in model.named_parameters():
+        assert float((p.detach().cpu() - ref[n].detach()).abs().max()) < 2e-3 * float(ref[n].abs().max()) + 1e-5, n
+    # the front end is frozen: no trainable parameter of the model belongs to it
+    assert not any("hubert" in n for n, _ in model.named_parameters())
+    # through the criterion / autograd node as fairseq would drive it
+    loss, ss, log = crit(model, batches[0])
+    assert ss == batches[0]["ntokens"] and math.isfinite(float(log["loss"]))
+
+
+def test_use_hubert_with_ctc_fails_like_the_reference(backend):
+    """s2st_loss.py:231-232 derives the CTC input lengths from the fbank lengths (100 fps) although the
+    encoder ran on HuBERT frames (50 fps); F.ctc_loss then raises 'Expected input_lengths to have value at most E'
+    in the reference (reproduced with the reference itself, oracle/gen_golden_hubert_train.py).  Same error here."""
+    geo, cfg, a, task, model, crit, trainer, batches = _hubert_nano_setup(backend, ctc_weight=0.3)
+    with pytest.raises(RuntimeError, match="Expected input_lengths to have value at most"):
+        trainer.train_step([batches[0]])

@@ -115,6 +115,9 @@ def test_forward_backward_base_checksums(golden_dir):
     for n, v in gn.items():
         np.testing.assert_allclose(float(named[n].grad.norm()), v, rtol=2e-3, atol=1e-7, err_msg=n)
     assert np.array_equal(O.stop_indices(outs["eos_out"]).numpy(), z["int.stop_idx"])
+    # direction of every gradient tensor (sampled) -- the same check the HIP path is held to
+    from test_engine import check_gradient_direction
+    check_gradient_direction({n: p.grad for n, p in named.items() if p.grad is not None}, z, 2e-3, 5e-4, tag="oracle")
 
 
 @pytest.mark.parametrize("name", ["tiny", "tiny_postln"])
