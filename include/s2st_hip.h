@@ -84,6 +84,11 @@ typedef struct {
  * examples/s2s_trans/models/s2st_transformer.py:135-139,452-455, tacotron2.py:95-126. */
 int s2st_gemm_f32(const s2st_gemm_args* args, void* stream);
 
+/* Up to 8 bf16-operand products (same operand layouts, batch 1, M, N >= 128, 16-byte aligned operands) in ONE persistent
+ * launch: a layer's weight-gradient GEMMs dW = dY^T X (torch.mm calls inside autograd's backward of every F.linear,
+ * fairseq/modules/transformer_layer.py:140-162) with K = tokens unsplit.  S2ST_ERR_SHAPE if a problem does not qualify. */
+int s2st_gemm_group_f32(const s2st_gemm_args* list, int32_t n, void* stream);
+
 /* Fused multi-head attention (bf16 operands, head width 64 or 128): masks + fp32 online softmax +
  * dropout + P*V in one kernel; backward recomputes the probabilities from the saved log-sum-exp.
  * Replaces fairseq/modules/multihead_attention.py:224-367 (and the same steps inside

@@ -216,6 +216,12 @@ int s2st_ln_gemm_skinny_f32(const float* x, int64_t ldx, const float* ln_gamma, 
   return s2st_gemm_skinny(x, ldx, (const bf16raw*)w_bf16, ldw, y, ldy, bias, act, 0.f, 0, nullptr, 0, M, N, K, (hipStream_t)stream, ln_gamma, ln_beta, ln_eps);
 }
 
+int s2st_gemm_group_f32(const s2st_gemm_args* list, int32_t n, void* stream) {
+  if (!list || n < 0) return S2ST_ERR_ARG;
+  for (int i = 0; i < n; ++i)
+    if (!s2st_gemm_group_ok(list[i])) return S2ST_ERR_SHAPE;
+  return s2st_gemm_bf16_group(list, n, (hipStream_t)stream);
+}
 int s2st_profile_enable(int32_t enable) { s2st_profile_enable_impl(enable); return 0; }
 int64_t s2st_profile_report(char* out, int64_t cap) { return s2st_profile_report_impl(out, cap); }
 

@@ -77,6 +77,41 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __r
   }
 }
 
+// All 2-D weights of the arena in ONE launch (the per-matrix form above cost ~108 launches of ~10 us per step): the
+// table of matrices rides in the kernel arguments; a workgroup finds its matrix by its tile index.  Rows and columns
+// are multiples of 8 (reg_wt), so both sides move 16-byte chunks.
+__global__ __launch_bounds__(256) void transpose_bf16_batched_kernel(const uint16_t* __restrict__ xb,
+                                                                     uint16_t* __restrict__ yb, s2st_transpose_table t) {
+  __shared__ uint16_t tile[64][72];
+  int lo = 0, hi = t.n - 1;
+  const unsigned id = blockIdx.x;
+  while (lo < hi) {  // last entry with tile0 <= id
+    const int mid = (lo + hi + 1) >> 1;
+    if (t.tile0[mid] <= id) lo = mid; else hi = mid - 1;
+  }
+  const int R = t.rows8[lo] * 8, C = t.cols8[lo] * 8;
+  const uint16_t* x = xb + t.off[lo];
+  uint16_t* y = yb + t.off[lo];
+  const int local = (int)(id - t.tile0[lo]), tc = (C + 63) / 64;
+  const int r0 = (local / tc) * 64, c0 = (local % tc) * 64;
+  for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+    const int r = i >> 3, c = (i & 7) * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r0 + r < R && c0 + c < C) v = *reinterpret_cast<const uint4*>(x + (long)(r0 + r) * C + c0 + c);
+    *reinterpret_cast<uint4*>(&tile[r][c]) = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+    const int c = i >> 3, r = (i & 7) * 8;
+    if (r0 + r < R && c0 + c < C) {
+      unsigned w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = (unsigned)tile[r + 2 * j][c] | ((unsigned)tile[r + 2 * j + 1][c] << 16);
+      *reinterpret_cast<uint4*>(y + (long)(c0 + c) * R + r0 + r) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+}
+
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
 __global__ __launch_bounds__(256) void glu_fwd_kernel(const float* __restrict__ a,
@@ -513,6 +548,13 @@ int s2st_cast_bf16_rows(const float* x, long ldx, uint16_t* y, long ldy, long ro
 int s2st_transpose_bf16(const uint16_t* x, uint16_t* y, int R, int C, hipStream_t st) {
   if (R <= 0 || C <= 0) return 0;
   hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, st, x, y, R, C);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+
+int s2st_transpose_bf16_batched(const uint16_t* x_base, uint16_t* y_base, const s2st_transpose_table& t, hipStream_t st) {
+  if (t.n <= 0) return 0;
+  if (t.n > S2ST_TRANSPOSE_MAX) return S2ST_ERR_ARG;
+  hipLaunchKernelGGL(transpose_bf16_batched_kernel, dim3(t.tile0[t.n]), dim3(256), 0, st, x_base, y_base, t);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 

@@ -140,7 +140,7 @@ struct s2st_engine {
   }
   bool tail_share = false;   // set while the last tape closures run (see linear()'s weight-gradient GEMM)
   unsigned tail_count = 0, wgrad_count = 0;
-  int wgrad_main_every = 7;  // S2ST_WGRAD_MAIN_EVERY=<n>: every n-th weight-gradient GEMM stays on the data-path stream
+  int wgrad_main_every = 0;  // S2ST_WGRAD_MAIN_EVERY=<n>: every n-th weight-gradient GEMM stays on the data-path stream
                              // (0 = none).  Balances the two streams; measured on the bench workload: n = 3 .. 16,
                              // best 7 (11.15 -> 10.89 ms/step together with the attention-backward bf16 gradients)
   int tail_closures = 0;     // S2ST_TAIL_SHARE=<n>: how many closures from the end share weight gradients; measured
@@ -177,6 +177,18 @@ struct s2st_engine {
     if (!pht_valid) return false;
     for (const WT& t : wt_list) if (t.off == off && t.N == N && t.K == K) return true;
     return false;
+  }
+  bool transpose_each = false;
+  std::vector<s2st_transpose_table> wt_tables;
+  void build_wt_tables() {
+    s2st_transpose_table cur{};
+    for (const WT& t : wt_list) {
+      if (cur.n == S2ST_TRANSPOSE_MAX) { wt_tables.push_back(cur); cur = s2st_transpose_table{}; }
+      const int i = cur.n++;
+      cur.off[i] = (unsigned)t.off; cur.rows8[i] = (unsigned short)(t.N / 8); cur.cols8[i] = (unsigned short)(t.K / 8);
+      cur.tile0[i + 1] = cur.tile0[i] + (unsigned)(((t.N + 63) / 64) * ((t.K + 63) / 64));
+    }
+    if (cur.n) wt_tables.push_back(cur);
   }
   bf16raw* PH = nullptr;  // bf16 copy of the parameter arena (same offsets), refreshed every forward
   bool f32_operands = false;  // debug A/B switch S2ST_F32_OPERANDS=1: bf16 MFMA on fp32-stored operands
@@ -415,6 +427,27 @@ struct s2st_engine {
   void touch(long off_end) { if (off_end > param_watermark) param_watermark = off_end; }
 
   // ------------------------------------------------------------------------------------
+  // weight-gradient GEMMs waiting for their group launch (S2ST_NO_WGRAD_GROUP=1: A/B switch, one launch each)
+  bool group_wgrad = true;
+  int group_flush_at = 4;  // S2ST_WGRAD_GROUP=<n>: problems per launch (<= S2ST_GROUP_MAX); 4 = one encoder layer
+  std::vector<GemmArgs> pending_wgrad;
+  void push_wgrad(const GemmArgs& g) {
+    for (const GemmArgs& p : pending_wgrad)
+      if (p.C.p == g.C.p) { flush_wgrad(); break; }  // two sums into one matrix must not share a launch
+    pending_wgrad.push_back(g);
+    if ((int)pending_wgrad.size() >= group_flush_at) flush_wgrad();
+  }
+  void flush_wgrad() {
+    if (pending_wgrad.empty()) return;
+    if (live()) {
+      // everything the products read was enqueued on st_ before this point
+      hipStream_t s = (side_ && st_ != side_) ? fork_side() : st_;
+      chk(s2st_gemm_bf16_group(pending_wgrad.data(), (int)pending_wgrad.size(), s));
+    }
+    pending_wgrad.clear();
+  }
+
+  // ------------------------------------------------------------------------------------
   // op: y = [resid +] dropout(act(x W^T + b))
   // only_h: the caller guarantees every consumer reads the bf16 copy (fast mode): no fp32 result is
   // allocated or written
@@ -508,10 +541,16 @@ struct s2st_engine {
         // weight gradients go to the second stream -- except every other one at the very end of the backward
         // sweep: nothing is left to overlap them with there, the data path would only wait for the backlog
         const bool on_main = (tail_share && ((tail_count++) & 1)) || (wgrad_main_every > 0 && (wgrad_count++ % wgrad_main_every) == 0);
-        hipStream_t ws_st = fm && !on_main ? fork_side() : st_;
-        g.ws = ws_for(ws_st); g.ws_floats = skws_n;
         g.M = N; g.N = K; g.K = M; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
-        chk(s2st_gemm(g, ws_st));
+        if (fm && !on_main && group_wgrad && s2st_gemm_group_ok(g)) {
+          // a layer's weight-gradient products leave together, as ONE persistent launch with K = tokens unsplit
+          // (no slabs, no combine kernels): see flush_wgrad()
+          push_wgrad(g);
+        } else {
+          hipStream_t ws_st = fm && !on_main ? fork_side() : st_;
+          g.ws = ws_for(ws_st); g.ws_floats = skws_n;
+          chk(s2st_gemm(g, ws_st));
+        }
         if (b >= 0 && !bias_done) chk(s2st_colsum(dpre, N, M, N, G + b, 1, st_));
       }
       if (x->needs_grad) {
@@ -1207,6 +1246,7 @@ struct s2st_engine {
 
   // ------------------------------------------------------------------------------------
   void reset_call() {
+    pending_wgrad.clear();
     for (Ten* t : tens) delete t;
     tens.clear();
     tape.clear();
@@ -1245,7 +1285,14 @@ struct s2st_engine {
     pht_valid = false;
     if (fm && tr && PHT && live()) {
       hipStream_t ts = side_ ? fork_side() : st_;
-      for (const WT& t : wt_list) chk(s2st_transpose_bf16(PH + t.off, PHT + t.off, t.N, t.K, ts));
+      // one launch per <= 200 matrices (the table rides in the kernel arguments); S2ST_TRANSPOSE_EACH=1: one
+      // launch per matrix (A/B switch)
+      if (transpose_each) {
+        for (const WT& t : wt_list) chk(s2st_transpose_bf16(PH + t.off, PHT + t.off, t.N, t.K, ts));
+      } else {
+        if (wt_tables.empty()) build_wt_tables();
+        for (const s2st_transpose_table& tb : wt_tables) chk(s2st_transpose_bf16_batched(PH, PHT, tb, ts));
+      }
       pht_valid = true;
     }
     skws_n = fm ? (long)16 << 20 : 0;
@@ -1461,8 +1508,8 @@ struct s2st_engine {
         // the aux decoders' backward (CTC head + text decoders: many small kernels that only produce
         // the taps' gradients and parameter gradients) runs on the second stream next to the mel
         // decoder's backward; the data path waits for it right before the tap layer norms consume it
-        if (i + 1 == aux_hi_idx && st_ == main_st) st_ = fork_side();
-        if (i + 1 == aux_lo_idx && st_ != main_st) { hipEventRecord(ev_auxb_, st_); st_ = main_st; }
+        if (i + 1 == aux_hi_idx && st_ == main_st) { flush_wgrad(); st_ = fork_side(); }
+        if (i + 1 == aux_lo_idx && st_ != main_st) { flush_wgrad(); hipEventRecord(ev_auxb_, st_); st_ = main_st; }
         if (i + 1 == aux_wait_idx) wait_traced(main_st, ev_auxb_, "aux decoders' backward (tap gradients)");
       }
       tail_share = tail_closures > 0 && seg == ns - 1 && i < lo + (size_t)tail_closures && side_ != nullptr;
@@ -1470,6 +1517,7 @@ struct s2st_engine {
       if (err) break;
     }
     tail_share = false;
+    flush_wgrad();  // the segment's gradients are final once its launches are enqueued
     if (st_ != main_st) { hipEventRecord(ev_auxb_, st_); st_ = main_st; }
     // The segment's weight gradients live on the second stream.  A caller that overlaps the gradient
     // all-reduce waits on that stream itself (s2st_engine_side_stream); the data path only joins once,
@@ -1498,6 +1546,13 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->f32_operands = getenv("S2ST_F32_OPERANDS") && atoi(getenv("S2ST_F32_OPERANDS")) != 0;
   e->join_every_segment = getenv("S2ST_JOIN_EVERY_SEGMENT") && atoi(getenv("S2ST_JOIN_EVERY_SEGMENT")) != 0;
   e->use_flash = !(getenv("S2ST_NO_FLASH") && atoi(getenv("S2ST_NO_FLASH")) != 0);
+  e->transpose_each = getenv("S2ST_TRANSPOSE_EACH") && atoi(getenv("S2ST_TRANSPOSE_EACH")) != 0;
+  e->group_wgrad = !(getenv("S2ST_NO_WGRAD_GROUP") && atoi(getenv("S2ST_NO_WGRAD_GROUP")) != 0);
+  if (getenv("S2ST_WGRAD_GROUP")) {
+    e->group_flush_at = atoi(getenv("S2ST_WGRAD_GROUP"));
+    if (e->group_flush_at < 1) e->group_flush_at = 1;
+    if (e->group_flush_at > S2ST_GROUP_MAX) e->group_flush_at = S2ST_GROUP_MAX;
+  }
   e->use_act_fuse = !(getenv("S2ST_NO_ACT_FUSE") && atoi(getenv("S2ST_NO_ACT_FUSE")) != 0);
   e->use_only_h = !(getenv("S2ST_NO_ONLY_H") && atoi(getenv("S2ST_NO_ONLY_H")) != 0);
   e->hoist_kv = !(getenv("S2ST_NO_KV_HOIST") && atoi(getenv("S2ST_NO_KV_HOIST")) != 0);

@@ -582,6 +582,188 @@ int launch_dma(const GemmArgs& g, dim3 grid, hipStream_t st) {
   return go(gemm_bf16_dma_kernel<BM, BN, false, false, NS, NW>, dma_tag<BM, BN, false, false, NS, NW>());
 }
 
+// ------------------------------------------------------------------------------------------------
+// Persistent, grouped form of the ring kernel.  One workgroup per CU walks tiles t = id, id + G, id + 2G, ... of the
+// concatenated tile list of up to S2ST_GROUP_MAX problems (same operand layouts, batch 1, no split-K), and the DMA
+// ring runs ACROSS tile and problem boundaries: while a tile's last K-steps are multiplied -- and while its epilogue
+// stores drain -- the first stages of the next tile are already landing.  The one-shot kernel above pays a full
+// prologue (every CU bursting its first three stages at once: ~4 us) and an epilogue per round of tiles, which for
+// the K = 512 ... 2048 products of a training step is most of a launch.  Grouping is what the weight-gradient GEMMs
+// of a layer use: four launches (+ split-K slabs and their combine kernels) become one with K = tokens unsplit.
+// vmcnt counts loads, LDS-DMA and stores together in issue order: right after an epilogue the stores are the
+// YOUNGEST operations, so the counted wait "all but the (stages ahead) x PER_STAGE youngest" still covers the stage
+// about to be read (it may wait for a few stores too: correct, slightly conservative).
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, bool AKM, bool BKM, int NS, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmGroup grp) {
+  constexpr int WGN = NW / 2;
+  constexpr int WM = BM / 2, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
+  typedef Dma<AKM, BM, NW> DA;
+  typedef Dma<BKM, BN, NW> DB;
+  typedef Stage<AKM, BM, true> LA;
+  typedef Stage<BKM, BN, true> LB;
+  constexpr int A_BYTES = DA::BYTES, B_BYTES = DB::BYTES, STAGE = A_BYTES + B_BYTES;
+  constexpr int PER_STAGE = DA::NI + DB::NI;
+  static_assert(NS >= 3 && NS <= 5, "ring depth");
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int G = gridDim.x, total = grp.total;
+
+  struct Tile { int pi, m0, n0, nt; };
+  auto locate = [&](int t, Tile& T) {
+    int pi = 0;
+    while (pi + 1 < grp.n && t >= grp.tile0[pi + 1]) ++pi;
+    const int nwg = grp.tile0[pi + 1] - grp.tile0[pi];
+    int id = t - grp.tile0[pi];
+    {  // XCD-aware order inside a problem: ids that share an XCD (id % 8) own a contiguous run of tiles
+      const int x = id & 7, q = nwg >> 3, r = nwg & 7;
+      id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+    }
+    const int tn = grp.g[pi].tiles_n;
+    const int tile_m = id / tn;
+    T.pi = pi;
+    T.m0 = tile_m * BM;
+    T.n0 = (id - tile_m * tn) * BN;
+    T.nt = (grp.g[pi].K + BK - 1) / BK;
+  };
+
+  // ---- issue cursor: the (tile, K-step) whose DMA goes out next ------------------------------------------
+  int ti = blockIdx.x, ki = 0, issued = 0;
+  bool issue_valid = ti < total;
+  Tile TI{0, 0, 0, 0};
+  DA da;
+  DB db;
+  auto init_issue = [&]() {
+    locate(ti, TI);
+    const GemmArgs& g = grp.g[TI.pi];
+    da.init(g.A, reinterpret_cast<const bf16_t*>(g.A.p), TI.m0, g.M, wave, lane);
+    db.init(g.B, reinterpret_cast<const bf16_t*>(g.B.p), TI.n0, g.N, wave, lane);
+  };
+  auto advance_issue = [&]() {
+    if (!issue_valid) return;
+    unsigned char* img = smem + (issued % NS) * STAGE;
+    const int K = grp.g[TI.pi].K;
+    da.issue(img, ki * BK, K, wave);
+    db.issue(img + A_BYTES, ki * BK, K, wave);
+    ++issued;
+    if (++ki == TI.nt) {
+      ti += G;
+      ki = 0;
+      issue_valid = ti < total;
+      if (issue_valid) init_issue();
+    }
+  };
+  if (issue_valid) init_issue();
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) advance_issue();
+
+  // ---- compute cursor ------------------------------------------------------------------------------------
+  int tc = blockIdx.x, kc = 0, computed = 0;
+  bool comp_valid = tc < total;
+  Tile TC{0, 0, 0, 0};
+  if (comp_valid) locate(tc, TC);
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  while (comp_valid) {
+    const int ahead = issued - computed - 1;  // ring stages younger than the one about to be read
+    if (ahead >= 3) S2ST_VMCNT(3 * PER_STAGE);
+    else if (ahead == 2) S2ST_VMCNT(2 * PER_STAGE);
+    else if (ahead == 1) S2ST_VMCNT(PER_STAGE);
+    else S2ST_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+    unsigned char* cur = smem + (computed % NS) * STAGE;
+    advance_issue();  // into the slot of step computed - 1: everyone is past its reads (barrier above)
+    const int K = grp.g[TC.pi].K;
+    if (kc == TC.nt - 1 && K - kc * BK < BK) {  // K tail: zero the invalid k of this stage
+      const int kv = K - kc * BK;
+      DA::sanitize(cur, kv, tid);
+      DB::sanitize(cur + A_BYTES, kv, tid);
+      __syncthreads();
+    }
+    bf16x8 af[2][TM], bf[2][TN];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[s][j] = LB::frag(cur + A_BYTES, wn * WN + j * 16, s, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[s][i] = LA::frag(cur, wm * WM + i * 16, s, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[s][j], af[s][i], acc[i][j], 0, 0, 0);
+    ++computed;
+    if (++kc == TC.nt) {
+      gemm_epilogue<BM, BN, WGN>(grp.g[TC.pi], acc, TC.m0, TC.n0, wm, wn, lane, 0, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      tc += G;
+      kc = 0;
+      comp_valid = tc < total;
+      if (comp_valid) locate(tc, TC);
+    }
+  }
+}
+
+template <int BM, int BN, bool AKM, bool BKM, int NS, int NW>
+const char* persistent_tag() {
+  static char buf[96];
+  if (!buf[0])
+    snprintf(buf, sizeof buf, "gemm_bf16_dma_persistent_kernel<%d, %d, %s, %s, %d, %d>", BM, BN, AKM ? "true" : "false",
+             BKM ? "true" : "false", NS, NW);
+  return buf;
+}
+
+int num_cus() {
+  static int n = 0;
+  if (!n) {
+    const char* ev = getenv("S2ST_GEMM_PERSIST_WGS");  // tuning aid
+    if (ev && atoi(ev) > 0) n = atoi(ev);
+    else {
+      int v = 0;
+      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess || v <= 0) v = 256;
+      n = v;
+    }
+  }
+  return n;
+}
+
+template <int BM, int BN, int NS, int NW>
+int launch_persistent(const GemmGroup& grp, hipStream_t st) {
+  constexpr int LDS = NS * (BM + BN) * 128;
+  double fl = 0, by = 0;
+  for (int i = 0; i < grp.n; ++i) { fl += gemm_flops(grp.g[i]); by += gemm_min_bytes(grp.g[i]); }
+  const int grid = grp.total < num_cus() ? grp.total : num_cus();
+  auto go = [&](auto kern, const char* tag) {
+    static bool configured = false;
+    if (!configured) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+        return -1;
+      configured = true;
+    }
+    s2st_launch(tag, fl, by, kern, dim3(grid), dim3(64 * NW), LDS, st, grp);
+    return 0;
+  };
+  const bool akm = grp.g[0].A.kmajor != 0, bkm = grp.g[0].B.kmajor != 0;
+  if (akm && bkm) return go(gemm_bf16_dma_persistent_kernel<BM, BN, true, true, NS, NW>, persistent_tag<BM, BN, true, true, NS, NW>());
+  if (akm && !bkm) return go(gemm_bf16_dma_persistent_kernel<BM, BN, true, false, NS, NW>, persistent_tag<BM, BN, true, false, NS, NW>());
+  if (!akm && bkm) return go(gemm_bf16_dma_persistent_kernel<BM, BN, false, true, NS, NW>, persistent_tag<BM, BN, false, true, NS, NW>());
+  return go(gemm_bf16_dma_persistent_kernel<BM, BN, false, false, NS, NW>, persistent_tag<BM, BN, false, false, NS, NW>());
+}
+
 // C(m, n) (+)= sum_s slab[z][s][m][n]
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, GemmOut C, int M, int N,
                                                             int splitk, int zdiv, int accumulate) {
@@ -634,7 +816,61 @@ bool vec_ok(const GemmOperand& o) {
          (o.zi % 8 == 0);
 }
 
+bool dma_layout_ok(const GemmArgs& g) { return (g.A.kmajor || g.A.sp.per <= 0) && (g.B.kmajor || g.B.sp.per <= 0); }
+
+// alignment flags the kernels / epilogue read; returns whether the 16-byte operand path applies
+bool prep_flags(GemmArgs& g) {
+  const bool vec = vec_ok(g.A) && vec_ok(g.B);
+  g.avec = g.bvec = vec ? 1 : 0;
+  g.cvec = ((!g.C.p || (uintptr_t)g.C.p % 16 == 0) && (!g.C.h || (uintptr_t)g.C.h % 8 == 0) &&
+            g.C.sp.ld % 4 == 0 && g.C.sp.bs % 4 == 0 && g.C.zo % 4 == 0 && g.C.zi % 4 == 0 &&
+            (!g.ep.resid || (uintptr_t)g.ep.resid % 16 == 0) && (!g.ep.bias || (uintptr_t)g.ep.bias % 16 == 0))
+               ? 1 : 0;
+  return vec;
+}
+
+int persist_mode() {  // S2ST_GEMM_PERSIST: 0 = one-shot kernels only, 1 = launches with more tiles than CUs (default), 2 = all
+  const char* ev = getenv("S2ST_GEMM_PERSIST");  // read per call: an A/B switch the tests flip
+  return ev ? atoi(ev) : 1;
+}
+
+template <int BN>
+void add_to_group(GemmGroup& grp, GemmArgs g) {
+  g.splitk = 1;
+  g.slab = nullptr;
+  g.kchunk = ((g.K + BK - 1) / BK) * BK;
+  g.tiles_n = (g.N + BN - 1) / BN;
+  const int i = grp.n++;
+  grp.g[i] = g;
+  grp.tile0[i + 1] = grp.tile0[i] + ((g.M + 127) / 128) * g.tiles_n;
+  grp.total = grp.tile0[i + 1];
+}
+
 }  // namespace
+
+bool s2st_gemm_group_ok(const GemmArgs& g0) {
+  GemmArgs g = g0;
+  if (g.A.dtype != S2ST_BF16 || g.B.dtype != S2ST_BF16 || g.precise || persist_mode() == 0) return false;
+  static const int use_dma = getenv("S2ST_GEMM_DMA") ? atoi(getenv("S2ST_GEMM_DMA")) : 1;
+  if (!use_dma || !prep_flags(g) || !dma_layout_ok(g) || g.batch != 1 || g.M < 128 || g.N < 128 || g.K < 1) return false;
+  if (g.ep.mask_y && (!g.cvec || g.N % 4 != 0)) return false;
+  return true;
+}
+
+// list[0..n): problems that passed s2st_gemm_group_ok, all with the layouts of list[0]
+int s2st_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t st) {
+  if (n <= 0) return 0;
+  if (n > S2ST_GROUP_MAX) return S2ST_ERR_ARG;
+  GemmGroup grp{};
+  for (int i = 0; i < n; ++i) {
+    GemmArgs g = list[i];
+    if (g.zdiv <= 0) g.zdiv = 1;
+    if (!prep_flags(g) || g.A.kmajor != list[0].A.kmajor || g.B.kmajor != list[0].B.kmajor) return S2ST_ERR_ARG;
+    add_to_group<128>(grp, g);
+  }
+  if (launch_persistent<128, 128, 4, 8>(grp, st)) return S2ST_ERR_LAUNCH;
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
 
 // Launch every kernel instantiation once on an empty problem (M = N = K = 0: no loads, no stores) so
 // that code objects are resident and the > 64 KiB dynamic-LDS attribute is set before the first
@@ -657,18 +893,18 @@ int s2st_gemm_bf16_preload(hipStream_t st) {
     rc |= launch_dma<128, 64, 4, 4>(g, grid, st);
     rc |= launch_dma<64, 64, 4, 4>(g, grid, st);
     rc |= launch_dma<64, 128, 3, 4>(g, grid, st);
+    GemmGroup grp{};  // no tiles: the persistent kernels fall straight through
+    grp.n = 1;
+    grp.g[0] = g;
+    rc |= launch_persistent<128, 128, 4, 8>(grp, st);
+    rc |= launch_persistent<128, 64, 4, 8>(grp, st);
   }
   return rc || hipGetLastError() != hipSuccess ? -1 : 0;
 }
 
 // tile choice: estimated time = rounds over the 256 CUs x per-tile work / per-tile efficiency
 int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
-  const bool vec = vec_ok(g.A) && vec_ok(g.B);
-  g.avec = g.bvec = vec ? 1 : 0;
-  g.cvec = ((!g.C.p || (uintptr_t)g.C.p % 16 == 0) && (!g.C.h || (uintptr_t)g.C.h % 8 == 0) &&
-            g.C.sp.ld % 4 == 0 && g.C.sp.bs % 4 == 0 && g.C.zo % 4 == 0 && g.C.zi % 4 == 0 &&
-            (!g.ep.resid || (uintptr_t)g.ep.resid % 16 == 0) && (!g.ep.bias || (uintptr_t)g.ep.bias % 16 == 0))
-               ? 1 : 0;
+  const bool vec = prep_flags(g);
   if (g.ep.mask_y && (!g.cvec || g.N % 4 != 0)) return S2ST_ERR_SHAPE;
   const bool linear_epi = !g.ep.act && g.ep.drop_p == 0.f && !g.ep.mask_y;
   struct Cand { int bm, bn; double eff; };
@@ -739,7 +975,17 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
   if (bm_out) *bm_out = bm * 1000 + bn;
   // LDS-DMA ring kernel: aligned operands; rows-contiguous operands need a plain k stride
   static const int use_dma = getenv("S2ST_GEMM_DMA") ? atoi(getenv("S2ST_GEMM_DMA")) : 1;
-  const bool dma_ok = vec && use_dma && (g.A.kmajor || g.A.sp.per <= 0) && (g.B.kmajor || g.B.sp.per <= 0);
+  const bool dma_ok = vec && use_dma && dma_layout_ok(g);
+  // more tiles than CUs: the persistent kernel keeps the DMA ring running across the tiles a workgroup walks
+  if (dma_ok && g.batch == 1 && g.splitk == 1 && bm == 128 && persist_mode() > 0 &&
+      (persist_mode() == 2 || nt > num_cus())) {
+    GemmGroup grp{};
+    int rc;
+    if (bn == 128) { add_to_group<128>(grp, g); rc = launch_persistent<128, 128, 4, 8>(grp, st); }
+    else { add_to_group<64>(grp, g); rc = launch_persistent<128, 64, 4, 8>(grp, st); }
+    if (rc) return rc;
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
   if (dma_ok) {
     int rc;
     static const int nw8 = getenv("S2ST_GEMM_NW8") ? atoi(getenv("S2ST_GEMM_NW8")) : 1;

@@ -51,6 +51,17 @@ inline GemmEpilogue gemm_epi_default() {
   return e;
 }
 
+// up to S2ST_GROUP_MAX bf16 problems with the same operand layouts in ONE persistent launch (gemm_bf16.hip): batch 1,
+// no split-K; total = tile0[n] tiles of the launcher's tile size
+#define S2ST_GROUP_MAX 8
+struct GemmGroup {
+  int n, total;
+  int tile0[S2ST_GROUP_MAX + 1];
+  GemmArgs g[S2ST_GROUP_MAX];
+};
+// true if g can join a group (aligned bf16 operands, plain strides, batch 1, >= 128 x 128 of output)
+bool s2st_gemm_group_ok(const GemmArgs& g);
+int s2st_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t st);
 int s2st_gemm(GemmArgs g, hipStream_t st);
 int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* tile_out);
 // skinny-M (<= 16 rows) y = f(x W^T + b) (+ resid) with fp32 x converted in registers (AR decoding)
@@ -102,6 +113,16 @@ int s2st_attn_headmean(const float* p, float* out, int B, int H, int T, int S, i
 // bf16 copies the fast GEMM path reads
 int s2st_cast_bf16_rows(const float* x, long ldx, uint16_t* y, long ldy, long rows, int cols, hipStream_t st);
 int s2st_transpose_bf16(const uint16_t* x, uint16_t* y, int R, int C, hipStream_t st);  // [R][C] -> [C][R]
+// every registered matrix [rows][cols] at element offset off of x_base -> its transpose at the same offset of y_base,
+// one launch (rows, cols multiples of 8; tile0 = running count of 64 x 64 tiles, tile0[n] = grid size)
+#define S2ST_TRANSPOSE_MAX 200
+struct s2st_transpose_table {
+  int n;
+  unsigned off[S2ST_TRANSPOSE_MAX];
+  unsigned short rows8[S2ST_TRANSPOSE_MAX], cols8[S2ST_TRANSPOSE_MAX];
+  unsigned tile0[S2ST_TRANSPOSE_MAX + 1];
+};
+int s2st_transpose_bf16_batched(const uint16_t* x_base, uint16_t* y_base, const s2st_transpose_table& t, hipStream_t st);
 // copy [rows][C] between split-addressed buffers (halo padding, zero-stuffing); C % 4 == 0
 int s2st_copy_rows_bf16(const uint16_t* x, Split xsp, uint16_t* y, Split ysp, int rows, int C, hipStream_t st);
 int s2st_copy_rows(const float* x, Split xsp, float* y, Split ysp, int rows, int C,

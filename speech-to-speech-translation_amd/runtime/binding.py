@@ -153,6 +153,26 @@ def _gemm_bf16(A, B, Cout, M, N, K, kw):
     check(lib().s2st_gemm_f32(C.byref(g), C.c_void_p(stream_ptr())), "s2st_gemm_f32")
 
 
+def gemm_args_bf16(A, B, Cout, M, N, K, *, a_kmajor=True, b_kmajor=True, a_ld=None, b_ld=None, c_ld=None, bias=None,
+                   act=0, resid=None, accumulate=False, c_bf16=None, alpha=1.0) -> GemmArgs:
+    """One batch-1 bf16 problem for ``gemm_group`` (plain strides)."""
+    g = GemmArgs()
+    g.A = GemmOperand(A.data_ptr(), 1 if a_kmajor else 0, 1, make_split(a_ld or (K if a_kmajor else M)), 0, 0)
+    g.B = GemmOperand(B.data_ptr(), 1 if b_kmajor else 0, 1, make_split(b_ld or (K if b_kmajor else N)), 0, 0)
+    g.C = GemmOut(ptr(Cout), make_split(c_ld or N), 0, 0, ptr(c_bf16))
+    g.ep = GemmEpilogue(alpha, act, ptr(bias), 0.0, 1 if accumulate else 0, 0, ptr(resid), None, 1.0, None)
+    g.M, g.N, g.K, g.batch, g.zdiv, g.precise = M, N, K, 1, 1, 0
+    return g
+
+
+def gemm_group(problems):
+    """s2st_gemm_group_f32: up to 8 bf16 problems of the same operand layouts in one persistent launch."""
+    arr = (GemmArgs * len(problems))(*problems)
+    fn = lib().s2st_gemm_group_f32
+    fn.argtypes = [C.POINTER(GemmArgs), C.c_int32, C.c_void_p]
+    check(fn(arr, len(problems), C.c_void_p(stream_ptr())), "s2st_gemm_group_f32")
+
+
 class AttnArgs(C.Structure):
     _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("ldq", C.c_int64), ("ldk", C.c_int64),
                 ("ldv", C.c_int64), ("o", C.c_void_p), ("oh", C.c_void_p), ("lse", C.c_void_p), ("klen", C.c_void_p),

@@ -311,7 +311,8 @@ def test_dropout_training_runs_and_is_seeded(backend):
 
 @pytest.mark.parametrize("cfg", [MICRO, MICRO_POSTLN], ids=["preln_aux", "postln"])
 @pytest.mark.parametrize("switch", ["S2ST_NO_LN_FUSE", "S2ST_NO_KV_HOIST", "S2ST_NO_ACT_FUSE", "S2ST_ATTN_GFUSE=0",
-                                    "S2ST_WGRAD_MAIN_EVERY=0"])
+                                    "S2ST_WGRAD_MAIN_EVERY=3", "S2ST_TRANSPOSE_EACH", "S2ST_NO_WGRAD_GROUP",
+                                    "S2ST_GEMM_PERSIST=0"])
 def test_fused_backward_paths_equal_the_unfused_ones(backend, cfg, switch, monkeypatch):
     """The oracle cannot reproduce the dropout masks, so fusions that only exist with dropout on are checked
     against the engine's own unfused schedule (A/B switch) with the same seed: the layer-norm backward that also
@@ -342,6 +343,16 @@ def test_fused_backward_paths_equal_the_unfused_ones(backend, cfg, switch, monke
     gmax = max(float(v.norm()) for v in v0.values())
     for n in v0:
         assert float((v0[n] - v1[n]).norm()) <= tol * 1e-4 * (float(v0[n].norm()) + 1e-2 * gmax), n
+
+
+@pytest.mark.parametrize("switch", ["S2ST_NO_WGRAD_GROUP", "S2ST_GEMM_PERSIST=0", "S2ST_GEMM_PERSIST=2", "S2ST_WGRAD_GROUP=8"])
+def test_grouped_weight_gradients_equal_single_launches(backend, switch, monkeypatch):
+    """128-wide layers, so that the weight-gradient products qualify for the grouped persistent launch (one launch
+    per <= 4 products, K = tokens unsplit) and the larger forward products for the persistent kernel: same
+    gradients as one split-K launch (+ slab combine) per product / the one-shot kernels."""
+    cfg = dict(MICRO, encoder_embed_dim=128, decoder_embed_dim=128, encoder_ffn_embed_dim=256, decoder_ffn_embed_dim=256,
+               encoder_attention_heads=2, decoder_attention_heads=2, prenet_dim=128, postnet_conv_dim=128)
+    test_fused_backward_paths_equal_the_unfused_ones(backend, cfg, switch, monkeypatch)
 
 
 @pytest.mark.parametrize("cfg", [MICRO, MICRO_POSTLN], ids=["preln_aux", "postln"])

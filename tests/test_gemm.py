@@ -341,3 +341,60 @@ def test_skinny_gemm_with_fused_layernorm(backend, M, N, K, act):
     # a last-bit difference in the statistics can flip the bf16 rounding of single inputs: 2^-9 of one product term
     assert float((y.cpu().double() - ref).abs().max()) <= 2e-3 * (float(ref.abs().max()) + 1.0)
     assert float((y.cpu().double() - ref).abs().mean()) <= 1e-4 * (float(ref.abs().max()) + 1.0)
+
+
+@pytest.mark.parametrize("akm,bkm", [(True, True), (True, False), (False, False), (False, True)])
+@pytest.mark.parametrize("K", [64, 200, 512])
+def test_bf16_persistent_kernel(backend, monkeypatch, akm, bkm, K):
+    """The persistent ring kernel (more tiles than workgroups: every workgroup walks several tiles with the DMA ring
+    running across tile boundaries -- K = 64 makes the prologue itself span tiles, K = 200 has a K tail) against the
+    exact product; epilogue variants with both output copies."""
+    monkeypatch.setenv("S2ST_GEMM_PERSIST", "2")
+    M, N = (640, 256) if backend.kind == "emu" else (4584, 2048)
+    g = torch.Generator().manual_seed(K + 2 * akm + bkm)
+    A, B = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g))
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    Am, a_ld = _pad_cols(A if akm else A.t().contiguous())
+    Bm, b_ld = _pad_cols(B if bkm else B.t().contiguous())
+    d = backend.device
+    R = A.double() @ B.double().t()
+    C = torch.full((M, N), 7.0, device=d)
+    Ch = torch.zeros(M, N, dtype=torch.bfloat16, device=d)
+    backend.bd.gemm(Am.to(d), Bm.to(d), C, M, N, K, a_kmajor=akm, b_kmajor=bkm, a_ld=a_ld, b_ld=b_ld, c_bf16=Ch)
+    backend.sync()
+    assert _relerr(C, R) < 2e-6
+    assert torch.equal(Ch.cpu(), C.cpu().to(torch.bfloat16))
+    C2 = torch.zeros(M, N, device=d)
+    backend.bd.gemm(Am.to(d), Bm.to(d), C2, M, N, K, a_kmajor=akm, b_kmajor=bkm, a_ld=a_ld, b_ld=b_ld, alpha=0.5,
+                    bias=bias.to(d), act=1, resid=res.to(d))
+    backend.sync()
+    assert _relerr(C2, torch.relu(0.5 * R + bias.double()) + res.double()) < 2e-6
+    # the one-shot kernel gives the same bits (same products, same summation order)
+    monkeypatch.setenv("S2ST_GEMM_PERSIST", "0")
+    C3 = torch.zeros(M, N, device=d)
+    backend.bd.gemm(Am.to(d), Bm.to(d), C3, M, N, K, a_kmajor=akm, b_kmajor=bkm, a_ld=a_ld, b_ld=b_ld)
+    backend.sync()
+    assert torch.equal(C3, C)
+
+
+def test_bf16_group_of_weight_gradients(backend):
+    """s2st_gemm_group_f32: a layer's weight-gradient products dW_i += dY_i^T X_i (different shapes, K = tokens, one with
+    a K tail) in one launch, against the exact sums."""
+    d = backend.device
+    g = torch.Generator().manual_seed(21)
+    T1, T2 = (200, 136) if backend.kind == "emu" else (4584, 3120)
+    shapes = [(256, 128, T1), (128, 256, T1), (128, 128, T2), (384, 128, T2)]
+    keep, probs, refs = [], [], []
+    for (N_out, K_in, T) in shapes:
+        dY, X = _bf(torch.randn(T, N_out, generator=g)), _bf(torch.randn(T, K_in, generator=g))
+        dW0 = torch.randn(N_out, K_in, generator=g)
+        dW = dW0.clone().to(d)
+        dYd, Xd = dY.to(d), X.to(d)
+        keep += [dYd, Xd, dW]
+        probs.append(backend.bd.gemm_args_bf16(dYd, Xd, dW, N_out, K_in, T, a_kmajor=False, a_ld=N_out, b_kmajor=False,
+                                               b_ld=K_in, accumulate=True))
+        refs.append((dW, dW0.double() + dY.double().t() @ X.double()))
+    backend.bd.gemm_group(probs)
+    backend.sync()
+    for dW, ref in refs:
+        assert _relerr(dW, ref) < 2e-6

@@ -78,7 +78,7 @@ def test_hubert_base_training_step_golden(backend, golden_dir, precise):
     # ---- one forward + backward on batch 0 against the reference's tensors / gradients ----------------
     s = model.front_end_sample(hubert_train_sample(0))
     assert np.array_equal(model.hubert.last_frame_lens.numpy(), z["int.hubert_frames"])
-    feats = s["net_input"]["src_speech"].double().cpu()
+    feats = s.hubert_io[2].double().cpu()  # the prepared batch's feature buffer, just refilled by the front end
     ref = z["sum.hubert_features"]
     assert abs(float(feats.abs().sum()) - ref[1]) < otol * ref[1]
     o = eng.forward(s, training=True, seed=1)
