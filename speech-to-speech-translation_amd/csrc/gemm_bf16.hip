@@ -636,18 +636,20 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
   Tile TI{0, 0, 0, 0};
   DA da;
   DB db;
+  int K_i = 0;  // (fields of the kernel-argument table are fetched by scalar loads, which share lgkmcnt with the LDS
+                // reads: everything the per-step code needs is copied into registers when a cursor enters a tile)
   auto init_issue = [&]() {
     locate(ti, TI);
     const GemmArgs& g = grp.g[TI.pi];
+    K_i = g.K;
     da.init(g.A, reinterpret_cast<const bf16_t*>(g.A.p), TI.m0, g.M, wave, lane);
     db.init(g.B, reinterpret_cast<const bf16_t*>(g.B.p), TI.n0, g.N, wave, lane);
   };
   auto advance_issue = [&]() {
     if (!issue_valid) return;
     unsigned char* img = smem + (issued % NS) * STAGE;
-    const int K = grp.g[TI.pi].K;
-    da.issue(img, ki * BK, K, wave);
-    db.issue(img + A_BYTES, ki * BK, K, wave);
+    da.issue(img, ki * BK, K_i, wave);
+    db.issue(img + A_BYTES, ki * BK, K_i, wave);
     ++issued;
     if (++ki == TI.nt) {
       ti += G;
@@ -657,11 +659,61 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
     }
   };
   if (issue_valid) init_issue();
+  // (NS - 2 stages here, the next one at the first read_step: a refill then always targets the slot of step
+  // nread - 2, whose fragment reads have been consumed by MFMAs that every wave has issued before the barrier)
 #pragma unroll
-  for (int s = 0; s < NS - 1; ++s) advance_issue();
+  for (int s = 0; s < NS - 2; ++s) advance_issue();
 
-  // ---- compute cursor ------------------------------------------------------------------------------------
-  int tc = blockIdx.x, kc = 0, computed = 0;
+  // ---- read cursor (the K-step whose fragments go LDS -> registers next) and multiply cursor ------------------
+  // The fragments of step c + 1 are read while the MFMAs of step c run (two register sets, the loop body is
+  // instantiated for both roles): with one set, every wave's LDS reads and MFMAs of a K-step are separate phases
+  // that the per-step barrier lines up across the workgroup -- LDS phase, then MFMA phase, ~3x the MFMA time.
+  struct Frag { bf16x8 a[2][TM], b[2][TN]; };
+  auto load_frags = [&](Frag& F, const unsigned char* cur) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) F.b[s][j] = LB::frag(cur + A_BYTES, wn * WN + j * 16, s, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) F.a[s][i] = LA::frag(cur, wm * WM + i * 16, s, lane);
+    }
+  };
+  int tr = blockIdx.x, kr = 0, nread = 0;  // nread: global index of the step the read cursor points at
+  bool read_valid = tr < total;
+  int nt_r = 0, K_r = 0;
+  auto init_read = [&]() {
+    Tile T;
+    locate(tr, T);
+    nt_r = T.nt;
+    K_r = grp.g[T.pi].K;
+  };
+  // waits for the stage of step `nread`, makes it visible to the workgroup, then reads its fragments into F
+  auto read_step = [&](Frag& F) {
+    const int ahead = issued - nread - 1;  // ring stages younger than the one about to be read
+    if (ahead >= 3) S2ST_VMCNT(3 * PER_STAGE);
+    else if (ahead == 2) S2ST_VMCNT(2 * PER_STAGE);
+    else if (ahead == 1) S2ST_VMCNT(PER_STAGE);
+    else S2ST_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+    advance_issue();  // into the slot of step nread - 2: everyone's MFMAs of it have been issued (barrier above)
+    unsigned char* cur = smem + (nread % NS) * STAGE;
+    if (kr == nt_r - 1 && K_r - kr * BK < BK) {  // K tail: zero the invalid k of this stage
+      const int kv = K_r - kr * BK;
+      DA::sanitize(cur, kv, tid);
+      DB::sanitize(cur + A_BYTES, kv, tid);
+      __syncthreads();
+    }
+    load_frags(F, cur);
+    ++nread;
+    if (++kr == nt_r) {
+      tr += G;
+      kr = 0;
+      read_valid = tr < total;
+      if (read_valid) init_read();
+    }
+  };
+
+  int tc = blockIdx.x, kc = 0;
   bool comp_valid = tc < total;
   Tile TC{0, 0, 0, 0};
   if (comp_valid) locate(tc, TC);
@@ -671,30 +723,13 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  while (comp_valid) {
-    const int ahead = issued - computed - 1;  // ring stages younger than the one about to be read
-    if (ahead >= 3) S2ST_VMCNT(3 * PER_STAGE);
-    else if (ahead == 2) S2ST_VMCNT(2 * PER_STAGE);
-    else if (ahead == 1) S2ST_VMCNT(PER_STAGE);
-    else S2ST_VMCNT(0);
-    __builtin_amdgcn_s_barrier();
-    unsigned char* cur = smem + (computed % NS) * STAGE;
-    advance_issue();  // into the slot of step computed - 1: everyone is past its reads (barrier above)
-    const int K = grp.g[TC.pi].K;
-    if (kc == TC.nt - 1 && K - kc * BK < BK) {  // K tail: zero the invalid k of this stage
-      const int kv = K - kc * BK;
-      DA::sanitize(cur, kv, tid);
-      DB::sanitize(cur + A_BYTES, kv, tid);
-      __syncthreads();
-    }
-    bf16x8 af[2][TM], bf[2][TN];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[s][j] = LB::frag(cur + A_BYTES, wn * WN + j * 16, s, lane);
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[s][i] = LA::frag(cur, wm * WM + i * 16, s, lane);
-    }
+  Frag F0, F1;
+  if (read_valid) {
+    init_read();
+    read_step(F0);
+  }
+  auto body = [&](Frag& Fc, Frag& Fn) {
+    if (read_valid) read_step(Fn);  // in flight under the MFMAs below
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -702,8 +737,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[s][j], af[s][i], acc[i][j], 0, 0, 0);
-    ++computed;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fc.b[s][j], Fc.a[s][i], acc[i][j], 0, 0, 0);
     if (++kc == TC.nt) {
       gemm_epilogue<BM, BN, WGN>(grp.g[TC.pi], acc, TC.m0, TC.n0, wm, wn, lane, 0, 0, 0, 0);
 #pragma unroll
@@ -715,6 +749,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
       comp_valid = tc < total;
       if (comp_valid) locate(tc, TC);
     }
+  };
+  while (comp_valid) {
+    body(F0, F1);
+    if (!comp_valid) break;
+    body(F1, F0);
   }
 }
 
@@ -746,7 +785,7 @@ int launch_persistent(const GemmGroup& grp, hipStream_t st) {
   constexpr int LDS = NS * (BM + BN) * 128;
   double fl = 0, by = 0;
   for (int i = 0; i < grp.n; ++i) { fl += gemm_flops(grp.g[i]); by += gemm_min_bytes(grp.g[i]); }
-  const int grid = grp.total < num_cus() ? grp.total : num_cus();
+  const int grid = grp.total < 1 ? 1 : (grp.total < num_cus() ? grp.total : num_cus());  // (preload: no tiles)
   auto go = [&](auto kern, const char* tag) {
     static bool configured = false;
     if (!configured) {
@@ -834,7 +873,7 @@ int persist_mode() {  // S2ST_GEMM_PERSIST: 0 = one-shot kernels only, 1 = launc
   return ev ? atoi(ev) : 1;
 }
 
-template <int BN>
+template <int BN, int BM = 128>
 void add_to_group(GemmGroup& grp, GemmArgs g) {
   g.splitk = 1;
   g.slab = nullptr;
@@ -842,7 +881,7 @@ void add_to_group(GemmGroup& grp, GemmArgs g) {
   g.tiles_n = (g.N + BN - 1) / BN;
   const int i = grp.n++;
   grp.g[i] = g;
-  grp.tile0[i + 1] = grp.tile0[i] + ((g.M + 127) / 128) * g.tiles_n;
+  grp.tile0[i + 1] = grp.tile0[i] + ((g.M + BM - 1) / BM) * g.tiles_n;
   grp.total = grp.tile0[i + 1];
 }
 
@@ -898,6 +937,7 @@ int s2st_gemm_bf16_preload(hipStream_t st) {
     grp.g[0] = g;
     rc |= launch_persistent<128, 128, 4, 8>(grp, st);
     rc |= launch_persistent<128, 64, 4, 8>(grp, st);
+    rc |= launch_dma<256, 128, 3, 8>(g, grid, st);
   }
   return rc || hipGetLastError() != hipSuccess ? -1 : 0;
 }
@@ -942,6 +982,7 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
     static const char* force = getenv("S2ST_GEMM_TILE");
     if (force && sscanf(force, "%dx%d", &bm, &bn) != 2) { bm = 64; bn = 64; }
   }
+  if (bm == 256 && !(vec && dma_layout_ok(g) && g.batch == 1)) { bm = 128; bn = 128; }  // 256-row tiles: ring kernels only
   const bool can_split_ = g.ep.accumulate && linear_epi && g.C.p && !g.C.h && !g.ep.bias && !g.ep.resid && g.K >= 8 * BK;
   if (vec && can_split_ && (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch < 256) { bm = 128; bn = 128; }
   const int tm = (g.M + bm - 1) / bm, tn = (g.N + bn - 1) / bn;
@@ -990,7 +1031,8 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
     int rc;
     static const int nw8 = getenv("S2ST_GEMM_NW8") ? atoi(getenv("S2ST_GEMM_NW8")) : 1;
     static const int ns = getenv("S2ST_GEMM_NS") ? atoi(getenv("S2ST_GEMM_NS")) : 4;  // tuning aid (128x128 only)
-    if (bm == 64 && bn == 128) rc = launch_dma<64, 128, 3, 4>(g, grid, st);
+    if (bm == 256 && bn == 128) rc = launch_dma<256, 128, 3, 8>(g, grid, st);
+    else if (bm == 64 && bn == 128) rc = launch_dma<64, 128, 3, 4>(g, grid, st);
     else if (bm == 128 && bn == 128 && nw8 && ns == 3) rc = launch_dma<128, 128, 3, 8>(g, grid, st);
     else if (bm == 128 && bn == 128 && nw8 && ns == 5) rc = launch_dma<128, 128, 5, 8>(g, grid, st);
     else if (bm == 128 && bn == 128 && nw8 && ns == 2) rc = launch_dma<128, 128, 2, 8>(g, grid, st);
