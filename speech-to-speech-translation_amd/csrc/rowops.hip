@@ -68,138 +68,119 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   }
 }
 
-constexpr int LNB_WAVES = 8;  // 512-thread blocks: 2 waves per SIMD keep enough loads in flight (HBM-bound)
-
-// FUSE: the input x of this layer norm is the output of a linear layer with dropout (x = resid + dropout(h W^T + b)),
-// and this backward completes x's gradient: the kernel then also emits that layer's backward prologue -- the bf16
-// GEMM operand dropout'(dx_total) (mask regenerated from (seed, element index)) and its column sums for the bias
-// gradient (a third row of partials) -- instead of a separate pass over dx.
+// LayerNorm backward in two independent kernels:
+//   * layernorm_bwd_dx_kernel (data path): one wave per row, row statistics by shuffles, dx (= | +=) and, FUSE, the
+//     bf16 GEMM operand dropout'(dx_total) of the linear layer that produced x.  No parameter-gradient work: the
+//     earlier single kernel folded per-block column sums through LDS (a dozen barriers per launch) behind its row
+//     pass and ran at 19 us for 4.6 k rows of 512 -- twice its memory time -- on the backward's critical path.
+//   * layernorm_bwd_param_kernel (parameter gradients, off the critical path: the engine puts it on its second
+//     stream): column sums over a slab of rows of dy * xhat (dgamma), dy (dbeta) and, FUSE, of the bf16 operand the
+//     dx kernel wrote (bias gradient of the producing layer), one float4 column chunk per thread, no reductions
+//     inside the slab; per-block partials are folded by layernorm_bwd_reduce_kernel in a fixed order.
 template <bool FUSE>
-__global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
+__global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
-    const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
-    int dx_accumulate, float* __restrict__ part, int rows, int cols, uint16_t* __restrict__ dph, float drop_p,
-    float inv_keep, uint64_t seed) {
-  constexpr int NOUT = FUSE ? 3 : 2;
-  __shared__ float red[2][LNB_WAVES][LN_MAXV * 64];  // [dgamma|dbeta][wave][float4 slot] (reused for the third row)
-  float4 adb[FUSE ? LN_MAXV : 1];
-#pragma unroll
-  for (int i = 0; i < (FUSE ? LN_MAXV : 1); ++i) adb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx, int dx_accumulate, int rows,
+    int cols, uint16_t* __restrict__ dph, float drop_p, float inv_keep, uint64_t seed) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;  // wave-uniform
   const int nv = cols >> 2;
   const float invc = 1.f / cols;
-  float4 ag[LN_MAXV], ab[LN_MAXV];
-#pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  // gamma stays in registers; two rows per iteration (independent loads / shuffle chains overlap:
-  // the loop is latency-bound at one row per wave)
-  float4 gm[LN_MAXV];
+  const float* xr = x + (long)row * cols;
+  const float* dyr = dy + (long)row * cols;
+  float* dxr = dx + (long)row * cols;
+  const float mu = mean[row], rs = rstd[row];
+  float4 xh[LN_MAXV], g[LN_MAXV], old[LN_MAXV];
+  float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
-    int c4 = lane + 64 * i;
-    gm[i] = c4 < nv ? reinterpret_cast<const float4*>(gamma)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  const int stride = gridDim.x * LNB_WAVES;
-  for (int row0 = blockIdx.x * LNB_WAVES + wave; row0 < rows; row0 += 2 * stride) {
-    float4 xh[2][LN_MAXV], g[2][LN_MAXV];
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, rs[2];
-    bool on[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int row = row0 + u * stride;
-      on[u] = row < rows;
-      const int rr = on[u] ? row : row0;
-      const float* xr = x + (long)rr * cols;
-      const float* dyr = dy + (long)rr * cols;
-      const float mu = mean[rr];
-      rs[u] = rstd[rr];
-#pragma unroll
-      for (int i = 0; i < LN_MAXV; ++i) {
-        int c4 = lane + 64 * i;
-        if (c4 < nv) {
-          float4 xv = reinterpret_cast<const float4*>(xr)[c4];
-          float4 dv = reinterpret_cast<const float4*>(dyr)[c4];
-          if (!on[u]) dv = make_float4(0.f, 0.f, 0.f, 0.f);
-          xh[u][i].x = (xv.x - mu) * rs[u]; xh[u][i].y = (xv.y - mu) * rs[u];
-          xh[u][i].z = (xv.z - mu) * rs[u]; xh[u][i].w = (xv.w - mu) * rs[u];
-          g[u][i].x = dv.x * gm[i].x; g[u][i].y = dv.y * gm[i].y; g[u][i].z = dv.z * gm[i].z; g[u][i].w = dv.w * gm[i].w;
-          s1[u] += g[u][i].x + g[u][i].y + g[u][i].z + g[u][i].w;
-          s2[u] += g[u][i].x * xh[u][i].x + g[u][i].y * xh[u][i].y + g[u][i].z * xh[u][i].z + g[u][i].w * xh[u][i].w;
-          ag[i].x += dv.x * xh[u][i].x; ag[i].y += dv.y * xh[u][i].y;
-          ag[i].z += dv.z * xh[u][i].z; ag[i].w += dv.w * xh[u][i].w;
-          ab[i].x += dv.x; ab[i].y += dv.y; ab[i].z += dv.z; ab[i].w += dv.w;
-        }
-      }
+    const int c4 = lane + 64 * i;
+    if (c4 < nv) {
+      const float4 xv = reinterpret_cast<const float4*>(xr)[c4];
+      const float4 dv = reinterpret_cast<const float4*>(dyr)[c4];
+      const float4 gm = reinterpret_cast<const float4*>(gamma)[c4];
+      if (dx_accumulate) old[i] = reinterpret_cast<const float4*>(dxr)[c4];
+      xh[i].x = (xv.x - mu) * rs; xh[i].y = (xv.y - mu) * rs; xh[i].z = (xv.z - mu) * rs; xh[i].w = (xv.w - mu) * rs;
+      g[i].x = dv.x * gm.x; g[i].y = dv.y * gm.y; g[i].z = dv.z * gm.z; g[i].w = dv.w * gm.w;
+      s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+      s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
     }
-    s1[0] = wave_sum(s1[0]) * invc; s1[1] = wave_sum(s1[1]) * invc;
-    s2[0] = wave_sum(s2[0]) * invc; s2[1] = wave_sum(s2[1]) * invc;
+  }
+  s1 = wave_sum(s1) * invc;
+  s2 = wave_sum(s2) * invc;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (!on[u]) continue;  // wave-uniform
-      float* dxr = dx + (long)(row0 + u * stride) * cols;
-#pragma unroll
-      for (int i = 0; i < LN_MAXV; ++i) {
-        int c4 = lane + 64 * i;
-        if (c4 < nv) {
-          float4 o;
-          o.x = rs[u] * (g[u][i].x - s1[u] - xh[u][i].x * s2[u]);
-          o.y = rs[u] * (g[u][i].y - s1[u] - xh[u][i].y * s2[u]);
-          o.z = rs[u] * (g[u][i].z - s1[u] - xh[u][i].z * s2[u]);
-          o.w = rs[u] * (g[u][i].w - s1[u] - xh[u][i].w * s2[u]);
-          if (dx_accumulate) {
-            float4 p = reinterpret_cast<float4*>(dxr)[c4];
-            o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
-          }
-          reinterpret_cast<float4*>(dxr)[c4] = o;
-          if (FUSE) {
-            const uint64_t e0 = (uint64_t)(row0 + u * stride) * cols + 4 * c4;
-            o.x *= drop_scale(seed, e0, drop_p, inv_keep); o.y *= drop_scale(seed, e0 + 1, drop_p, inv_keep);
-            o.z *= drop_scale(seed, e0 + 2, drop_p, inv_keep); o.w *= drop_scale(seed, e0 + 3, drop_p, inv_keep);
-            reinterpret_cast<uint2*>(dph + (long)(row0 + u * stride) * cols)[c4] = pack_bf16x4(o.x, o.y, o.z, o.w);
-            adb[i].x += o.x; adb[i].y += o.y; adb[i].z += o.z; adb[i].w += o.w;
-          }
-        }
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 < nv) {
+      float4 o;
+      o.x = rs * (g[i].x - s1 - xh[i].x * s2);
+      o.y = rs * (g[i].y - s1 - xh[i].y * s2);
+      o.z = rs * (g[i].z - s1 - xh[i].z * s2);
+      o.w = rs * (g[i].w - s1 - xh[i].w * s2);
+      if (dx_accumulate) { o.x += old[i].x; o.y += old[i].y; o.z += old[i].z; o.w += old[i].w; }
+      reinterpret_cast<float4*>(dxr)[c4] = o;
+      if (FUSE) {
+        const uint64_t e0 = (uint64_t)row * cols + 4 * c4;
+        o.x *= drop_scale(seed, e0, drop_p, inv_keep); o.y *= drop_scale(seed, e0 + 1, drop_p, inv_keep);
+        o.z *= drop_scale(seed, e0 + 2, drop_p, inv_keep); o.w *= drop_scale(seed, e0 + 3, drop_p, inv_keep);
+        reinterpret_cast<uint2*>(dph + (long)row * cols)[c4] = pack_bf16x4(o.x, o.y, o.z, o.w);
       }
     }
   }
-  // cross-wave reduction of the parameter gradients, then one atomic per column per block
-  float* rg = &red[0][0][0];
-  float* rb = &red[1][0][0];
-  constexpr int WSTRIDE = LN_MAXV * 64;  // one float4 component per pass
-  for (int comp = 0; comp < 4; ++comp) {
-#pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      int c4 = lane + 64 * i;
-      float gv = comp == 0 ? ag[i].x : comp == 1 ? ag[i].y : comp == 2 ? ag[i].z : ag[i].w;
-      float bv = comp == 0 ? ab[i].x : comp == 1 ? ab[i].y : comp == 2 ? ab[i].z : ab[i].w;
-      rg[wave * WSTRIDE + c4] = gv;
-      rb[wave * WSTRIDE + c4] = bv;
-    }
-    __syncthreads();
-    for (int c4 = threadIdx.x; c4 < nv; c4 += 64 * LNB_WAVES) {
-      float gsum = 0.f, bsum = 0.f;
-#pragma unroll
-      for (int w = 0; w < LNB_WAVES; ++w) { gsum += rg[w * WSTRIDE + c4]; bsum += rb[w * WSTRIDE + c4]; }
-      // per-block partials: [block][NOUT][cols]
-      part[((long)blockIdx.x * NOUT + 0) * cols + c4 * 4 + comp] = gsum;
-      part[((long)blockIdx.x * NOUT + 1) * cols + c4 * 4 + comp] = bsum;
-    }
-    __syncthreads();
-    if (FUSE) {
-#pragma unroll
-      for (int i = 0; i < LN_MAXV; ++i) {
-        int c4 = lane + 64 * i;
-        rg[wave * WSTRIDE + c4] = comp == 0 ? adb[i].x : comp == 1 ? adb[i].y : comp == 2 ? adb[i].z : adb[i].w;
+}
+
+// grid (row slabs, column blocks of 256 float4 chunks); block 256 threads = lanes_c chunk lanes x rl row lanes.
+// part: [gridDim.x][NOUT][cols]
+template <bool FUSE>
+__global__ __launch_bounds__(256) void layernorm_bwd_param_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const uint16_t* __restrict__ dph, float* __restrict__ part, int rows, int cols,
+    int rows_per_block) {
+  constexpr int NOUT = FUSE ? 3 : 2;
+  __shared__ float4 red[NOUT][256];
+  const int nv = cols >> 2;
+  const int cb = blockIdx.y * 256;                       // first chunk of this column block
+  const int lanes_c = min(nv - cb, 256);                 // chunk lanes in use
+  const int rl = 256 / lanes_c;                          // row lanes
+  const int cl = threadIdx.x % lanes_c, my_r = threadIdx.x / lanes_c;
+  const int c4 = cb + cl;
+  float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag, ad = ag;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  if (my_r < rl) {
+    for (int r = r0 + my_r; r < r1; r += rl) {
+      const float4 xv = reinterpret_cast<const float4*>(x + (long)r * cols)[c4];
+      const float4 dv = reinterpret_cast<const float4*>(dy + (long)r * cols)[c4];
+      const float mu = mean[r], rs = rstd[r];
+      ag.x += dv.x * ((xv.x - mu) * rs); ag.y += dv.y * ((xv.y - mu) * rs);
+      ag.z += dv.z * ((xv.z - mu) * rs); ag.w += dv.w * ((xv.w - mu) * rs);
+      ab.x += dv.x; ab.y += dv.y; ab.z += dv.z; ab.w += dv.w;
+      if (FUSE) {
+        const uint2 h = reinterpret_cast<const uint2*>(dph + (long)r * cols)[c4];
+        ad.x += __uint_as_float(h.x << 16); ad.y += __uint_as_float(h.x & 0xffff0000u);
+        ad.z += __uint_as_float(h.y << 16); ad.w += __uint_as_float(h.y & 0xffff0000u);
       }
-      __syncthreads();
-      for (int c4 = threadIdx.x; c4 < nv; c4 += 64 * LNB_WAVES) {
-        float dsum = 0.f;
-#pragma unroll
-        for (int w = 0; w < LNB_WAVES; ++w) dsum += rg[w * WSTRIDE + c4];
-        part[((long)blockIdx.x * NOUT + 2) * cols + c4 * 4 + comp] = dsum;
-      }
-      __syncthreads();
     }
+  }
+  // fold the row lanes (fixed order), one partial row per block
+  red[0][threadIdx.x] = ag;
+  red[1][threadIdx.x] = ab;
+  if (FUSE) red[2][threadIdx.x] = ad;
+  __syncthreads();
+  if (my_r == 0) {
+    for (int k = 1; k < rl; ++k) {
+      const float4 a = red[0][k * lanes_c + cl], b = red[1][k * lanes_c + cl];
+      ag.x += a.x; ag.y += a.y; ag.z += a.z; ag.w += a.w;
+      ab.x += b.x; ab.y += b.y; ab.z += b.z; ab.w += b.w;
+      if (FUSE) {
+        const float4 d = red[2][k * lanes_c + cl];
+        ad.x += d.x; ad.y += d.y; ad.z += d.z; ad.w += d.w;
+      }
+    }
+    float* p = part + (long)blockIdx.x * NOUT * cols;
+    reinterpret_cast<float4*>(p)[c4] = ag;
+    reinterpret_cast<float4*>(p + cols)[c4] = ab;
+    if (FUSE) reinterpret_cast<float4*>(p + 2 * cols)[c4] = ad;
   }
 }
 
@@ -400,15 +381,21 @@ int s2st_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
+static int ln_param_rows_per_block(int rows) {
+  // 32-row slabs (one partial row per block), at most 512 blocks
+  int rpb = 32;
+  while ((rows + rpb - 1) / rpb > 512) rpb *= 2;
+  return rpb;
+}
+
 int s2st_layernorm_bwd_blocks(int rows) {
-  // two rows per wave in ONE pass when possible (the kernel is latency-bound: a second dependent
-  // pass costs as much as the first), at most 512 blocks of partial sums
-  int blocks = (rows + 2 * LNB_WAVES - 1) / (2 * LNB_WAVES);
-  return blocks > 512 ? 512 : (blocks < 1 ? 1 : blocks);
+  const int rpb = ln_param_rows_per_block(rows);
+  const int b = (rows + rpb - 1) / rpb;
+  return b < 1 ? 1 : b;
 }
 
 // scratch: s2st_layernorm_bwd_blocks(rows) * (dph ? 3 : 2) * cols floats.
-// dph != null: fused backward prologue of the linear layer that produced x (see the kernel): dph [rows][cols] bf16 =
+// dph != null: fused backward prologue of the linear layer that produced x (see the kernels): dph [rows][cols] bf16 =
 // dropout'(dx_total) with the (seed, p) mask, dbias += its column sums (may be null).
 int s2st_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                        const float* rstd, float* dx, int dx_accumulate, float* dgamma,
@@ -417,22 +404,29 @@ int s2st_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
   if (rows <= 0) return 0;
   if (cols % 4 != 0 || cols > LN_MAXV * 256) return S2ST_ERR_SHAPE;
   if (dph && ((uintptr_t)dph % 8 || drop_p < 0.f || drop_p >= 1.f)) return S2ST_ERR_ARG;
-  int blocks = s2st_layernorm_bwd_blocks(rows);
-  // phase 0: both kernels; 1: only dx + per-block partials; 2: only the parameter-gradient reduce (lets the
-  // caller put that reduce on another stream: it is off the backward's critical path)
+  // phase 0: everything on st; 1: only dx (+ the fused bf16 operand); 2: only the parameter gradients (lets the
+  // caller put them on another stream: they are off the backward's critical path)
   if (phase != 2) {
     // bytes: dy, x read; dx written (read too when it accumulates); the bf16 operand of the fused form
     const double by = (double)rows * cols * (12 + (dx_accumulate ? 4 : 0) + (dph ? 2 : 0));
     if (dph)
-      s2st_launch("layernorm_bwd_kernel<true>", by, 0.0, layernorm_bwd_kernel<true>, dim3(blocks), dim3(64 * LNB_WAVES), 0, st,
-                  dy, x, gamma, mean, rstd, dx, dx_accumulate, scratch, rows, cols, dph, drop_p, 1.f / (1.f - drop_p), seed);
+      s2st_launch("layernorm_bwd_dx_kernel<true>", by, 0.0, layernorm_bwd_dx_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0,
+                  st, dy, x, gamma, mean, rstd, dx, dx_accumulate, rows, cols, dph, drop_p, 1.f / (1.f - drop_p), seed);
     else
-      s2st_launch("layernorm_bwd_kernel<false>", by, 0.0, layernorm_bwd_kernel<false>, dim3(blocks), dim3(64 * LNB_WAVES), 0,
-                  st, dy, x, gamma, mean, rstd, dx, dx_accumulate, scratch, rows, cols, (uint16_t*)nullptr, 0.f, 1.f,
-                  (uint64_t)0);
+      s2st_launch("layernorm_bwd_dx_kernel<false>", by, 0.0, layernorm_bwd_dx_kernel<false>, dim3((rows + 3) / 4), dim3(256),
+                  0, st, dy, x, gamma, mean, rstd, dx, dx_accumulate, rows, cols, (uint16_t*)nullptr, 0.f, 1.f, (uint64_t)0);
   }
   if (phase != 1) {
+    const int rpb = ln_param_rows_per_block(rows), blocks = s2st_layernorm_bwd_blocks(rows);
     const int nout = dph ? 3 : 2;
+    const dim3 grid(blocks, (cols / 4 + 255) / 256);
+    const double by = (double)rows * cols * (8 + (dph ? 2 : 0));
+    if (dph)
+      s2st_launch("layernorm_bwd_param_kernel<true>", by, 0.0, layernorm_bwd_param_kernel<true>, grid, dim3(256), 0, st, dy, x,
+                  mean, rstd, (const uint16_t*)dph, scratch, rows, cols, rpb);
+    else
+      s2st_launch("layernorm_bwd_param_kernel<false>", by, 0.0, layernorm_bwd_param_kernel<false>, grid, dim3(256), 0, st, dy,
+                  x, mean, rstd, (const uint16_t*)nullptr, scratch, rows, cols, rpb);
     hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((nout * cols + 31) / 32), dim3(256), 0, st,
                        (const float*)scratch, blocks, cols, dgamma, dbeta, nout, dbias);
   }

@@ -338,7 +338,9 @@ def test_fused_backward_paths_equal_the_unfused_ones(backend, cfg, switch, monke
     assert torch.allclose(s0, s1, rtol=1e-5, atol=1e-6)
     # (the attention backward's bf16 projection gradients are the same bits as the cast pass makes; only the q/k/v
     # bias gradients are then summed from the rounded values instead of the fp32 ones)
-    tol = 50.0 if switch.startswith("S2ST_ATTN_GFUSE") else 1.0
+    # (likewise the layer-norm backward's fused form: the bias gradient of the producing linear layer is the column sum
+    # of the bf16 operand it emitted, not of the fp32 values)
+    tol = 50.0 if switch.startswith(("S2ST_ATTN_GFUSE", "S2ST_NO_LN_FUSE")) else 1.0
     assert float((g0 - g1).norm()) <= tol * 2e-5 * float(g0.norm())
     gmax = max(float(v.norm()) for v in v0.values())
     for n in v0:
