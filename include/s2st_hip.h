@@ -20,6 +20,7 @@ extern "C" {
 #define S2ST_ERR_SHAPE (-2)
 #define S2ST_ERR_WORKSPACE (-3)
 #define S2ST_ERR_ARG (-4)
+#define S2ST_ERR_COMM (-5) /* no RCCL library could be bound, or an RCCL call failed (message on stderr) */
 
 /* offset of "slow index" i:  per <= 0 ? i*ld : (i / per) * bs + (i % per) * ld          */
 typedef struct { int64_t ld; int64_t bs; int32_t per; int32_t _pad; } s2st_split;
@@ -185,6 +186,10 @@ int s2st_mel_loss_f32(const float* feat, const float* post, const float* eos, co
 
 /* s2st_loss.py:33-50, 330-348: log_softmax + label-smoothed NLL + accuracy, and d/dlogits */
 int s2st_ls_ce_f32(const float* logits, const int64_t* target, int32_t rows, int32_t V, int64_t pad, float eps, float* stats, float* dlogits, float gscale, void* stream);
+
+/* s2st_transformer.py:458-463 get_normalized_probs (fairseq/utils.py log_softmax / softmax, fp32): y[r][0..V) =
+ * log_out ? log_softmax(x[r]) : softmax(x[r]); row strides ldx / ldy in floats */
+int s2st_log_softmax_rows_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int32_t rows, int32_t V, int32_t log_out, void* stream);
 
 /* s2st_loss.py:229-243 + s2st_transformer.py:458-463: log_softmax + CTCLoss(mean, zero_infinity); ws from s2st_ctc_workspace_floats */
 int s2st_ctc_f32(const float* logits, const int64_t* targets, int32_t Lmax, const int32_t* in_lens, const int32_t* tgt_lens, int32_t B, int32_t E, int32_t V, float* lprobs, float* loss_per_utt, float* dlogits, float gscale, float* ws, void* stream);
@@ -406,6 +411,22 @@ int64_t s2st_hubert_workspace_floats(s2st_engine* e, int32_t B, int32_t N);
  * (hubert.py:400-410 applied to the sample padding mask) -> out [B][T'][embed] fp32 */
 int s2st_hubert_forward(s2st_engine* e, const float* wave, const int32_t* frame_lens, int32_t B, int32_t N,
                         float* out, float* workspace, int64_t workspace_floats, void* stream);
+
+/* ======================================================================================
+ * Gradient exchange: SUM all-reduce over an RCCL communicator, one process per GPU.  Replaces the bucketed NCCL
+ * all-reduce torch DDP runs for the reference (fairseq/models/distributed_fairseq_model.py:58-67); the trainer hands
+ * over contiguous ranges of the flat gradient arena as the backward finishes them (s2st_engine_segment_range) and
+ * scales by 1 / sum(sample_size) in s2st_adam_f32.  RCCL is bound at run time (the copy the process already carries,
+ * else $S2ST_RCCL_LIB, else librccl.so.1): libs2st_hip.so has no link-time dependency on it.
+ *   rank 0: s2st_comm_unique_id(id) -> id (128 bytes) to every rank out of band -> all ranks: s2st_comm_init
+ * ====================================================================================== */
+typedef struct s2st_comm s2st_comm;
+int s2st_comm_available(void);
+int s2st_comm_unique_id(void* id128);
+int s2st_comm_init(const void* id128, int32_t world, int32_t rank, s2st_comm** out);
+/* buf[0..n) <- sum over ranks (in place), ordered on `stream` */
+int s2st_allreduce_sum_f32(s2st_comm* comm, float* buf, int64_t n, void* stream);
+int s2st_comm_destroy(s2st_comm* comm);
 
 /* Measurement aid (bench.py roofline leg).  While enabled, the dominant kernels (GEMMs, split-K combine, fused
  * attention, LayerNorm, optimizer) are launched with a start / stop event attached to the dispatch itself, on the

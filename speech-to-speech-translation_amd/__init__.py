@@ -7,3 +7,7 @@ The directory name contains hyphens, so import it with
 ``s2st_amd`` alias module at the repo root.
 """
 __version__ = "0.1.0"
+
+# ``--user-dir <this directory>``: fairseq imports the package and expects the plugin modules to register themselves
+# (examples/s2s_trans/__init__.py does ``from . import tasks, criterions, models``)
+from . import tasks, criterions, models  # noqa: E402,F401

@@ -12,7 +12,7 @@ from typing import Any, Dict, List
 
 import torch
 
-from ..registry import register_criterion
+from ..registry import CriterionBase, HAVE_FAIRSEQ, register_criterion
 from ..runtime.engine import STAT
 
 
@@ -96,12 +96,15 @@ class LazyLog(dict):
 
 
 @register_criterion("s2st_loss")
-class Tacotron2Criterion(torch.nn.Module):
+class Tacotron2Criterion(CriterionBase):  # fairseq's FairseqCriterion when fairseq is importable
     def __init__(self, task, sentence_avg=False, n_frames_per_step=4, use_guided_attention_loss=False,
                  guided_attention_loss_sigma=0.4, bce_pos_weight=1.0, ctc_weight=0.0, asr_ce_weight=0.0,
                  st_ce_weight=0.0, l1_loss_weight=1.0, mse_loss_weight=1.0, eos_loss_weight=1.0,
                  attn_loss_weight=1.0, label_smoothing=0.0, ignore_prefix_size=0, report_accuracy=False):
-        super().__init__()
+        if HAVE_FAIRSEQ:
+            super().__init__(task)
+        else:
+            super().__init__()
         if use_guided_attention_loss:
             # the reference raises a shape error with this flag on (fbank lengths are passed to a
             # [B, E, D] attention map, s2st_loss.py:227); nothing to be compatible with
@@ -165,6 +168,12 @@ class Tacotron2Criterion(torch.nn.Module):
                 cor = sum(log.get(f"{t}_n_correct", 0) for log in logging_outputs)
                 res[f"{t}_total"], res[f"{t}_n_correct"] = tot, cor
                 res[f"{t}_accuracy"] = round(cor * 100.0 / tot, 3)
+        # inference metrics (--eval-inference: s2st_loss.py:394-407)
+        if logging_outputs and "targ_frames" in logging_outputs[0]:
+            n = sum(log.get("targ_frames", 0) for log in logging_outputs)
+            for key, new_key in [("mcd_loss", "mcd_loss"), ("pred_frames", "pred_ratio"), ("nins", "ins_rate"),
+                                 ("ndel", "del_rate")]:
+                res[new_key] = sum(log.get(key, 0) for log in logging_outputs) / n
         try:  # pragma: no cover
             from fairseq import metrics
             for k, v in res.items():

@@ -280,6 +280,28 @@ __global__ void loss_finalize_kernel(float* __restrict__ stats, const float* __r
   stats[S2ST_STAT_LOSS] = l1 + mse + eos + ctc + asr + st;
 }
 
+// (log-)softmax over the last dimension, one wave per row (models' get_normalized_probs: s2st_transformer.py:458-463,
+// fairseq/utils.py log_softmax / softmax in fp32)
+__global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y,
+                                                               long ldy, int rows, int V, int log_out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (long)row * ldx;
+  float mx = -INFINITY;
+  for (int c = lane; c < V; c += 64) mx = fmaxf(mx, xr[c]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int c = lane; c < V; c += 64) s += expf(xr[c] - mx);
+  s = wave_sum(s);
+  const float ls = logf(s);
+  float* yr = y + (long)row * ldy;
+  for (int c = lane; c < V; c += 64) {
+    const float v = xr[c] - mx - ls;
+    yr[c] = log_out ? v : expf(v);
+  }
+}
+
 }  // namespace
 
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH)
@@ -329,4 +351,10 @@ int s2st_loss_finalize(float* stats, const float* ctc_per, int B, float nf, floa
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, stats, ctc_per, B, nf, nr, w_l1, w_mse,
                      w_eos, w_ctc, w_asr, w_st, eps, Vs, Vt, src_ntok, tgt_ntok);
   return LAUNCH_OK();
+}
+
+int s2st_log_softmax_rows(const float* x, long ldx, float* y, long ldy, int rows, int V, int log_out, hipStream_t st) {
+  if (rows <= 0 || V <= 0) return 0;
+  hipLaunchKernelGGL(log_softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, y, ldy, rows, V, log_out);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }

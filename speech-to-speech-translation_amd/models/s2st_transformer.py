@@ -15,7 +15,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 
-from ..registry import register_model, register_model_architecture
+from ..registry import ModelBase, register_model, register_model_architecture
 from ..runtime.engine import Engine
 
 
@@ -37,7 +37,7 @@ def _register(root: nn.Module, dotted: str, tensor: torch.Tensor, is_buffer: boo
 
 
 @register_model("s2st_transformer")
-class S2STTransformerModel(nn.Module):
+class S2STTransformerModel(ModelBase):  # fairseq's BaseFairseqModel when fairseq is importable, else nn.Module
     @staticmethod
     def add_args(parser):
         """Same flags as the reference (s2st_transformer.py:586-664)."""
@@ -286,9 +286,24 @@ class S2STTransformerModel(nn.Module):
                 "src_tokens": [], "src_lengths": []}
 
     def get_normalized_probs(self, net_output, log_probs, sample=None):
-        """CTC head over tap 0 (s2st_transformer.py:458-463); uses the engine's fused
-        log-softmax output when available."""
-        raise NotImplementedError("use criterion outputs['ctc_lprobs'] (fused log-softmax + CTC)")
+        """CTC head over tap 0 (the reference keeps it on the decoder, s2st_transformer.py:458-463):
+        ``(log_)softmax(ctc_proj(out_middle_layers[0]))`` -> [B, E, V].  The criterion does not come through here (its
+        fused log-softmax + CTC kernel reads the logits directly and also returns ``ctc_lprobs``); this entry serves
+        callers that hold a ``net_output`` -- e.g. greedy CTC decoding of the source transcript."""
+        if not self.engine.cfg.has_ctc:
+            raise ValueError("the model was built without a CTC head (--ctc-weight 0)")
+        tap = net_output[2]["out_middle_layers"][0].transpose(0, 1).contiguous()  # [B, E, C]
+        B, E, Cd = tap.shape
+        w = self._views["decoder.ctc_proj.weight"]
+        b = self._views["decoder.ctc_proj.bias"]
+        V = w.shape[0]
+        from ..runtime import binding as bd
+        ld = (V + 3) // 4 * 4
+        logits = torch.empty(B * E, ld, dtype=torch.float32, device=tap.device)
+        bd.gemm(tap.view(B * E, Cd), w, logits, B * E, V, Cd, c_ld=ld, bias=b, precise=True)
+        out = torch.empty(B * E, V, dtype=torch.float32, device=tap.device)
+        bd.call("s2st_log_softmax_rows_f32", logits, ld, out, V, B * E, V, 1 if log_probs else 0)
+        return out.view(B, E, V)
 
 
 @register_model_architecture("s2st_transformer", "s2st_transformer")

@@ -25,11 +25,65 @@ def world_size() -> int:
     return dist.get_world_size() if is_dist() else 1
 
 
+class NativeComm:
+    """RCCL communicator behind the C ABI (``s2st_comm_*`` / ``s2st_allreduce_sum_f32``, include/s2st_hip.h): the
+    128-byte unique id travels over the already-initialised ``torch.distributed`` group (any backend), the collective
+    itself is issued by libs2st_hip.so on the caller's HIP stream."""
+
+    def __init__(self):
+        import ctypes as C
+        from . import binding as bd
+        self.C, self.bd, self.lib = C, bd, bd.lib()
+        self.lib.s2st_comm_unique_id.argtypes = [C.c_void_p]
+        self.lib.s2st_comm_init.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        self.lib.s2st_allreduce_sum_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        self.lib.s2st_comm_destroy.argtypes = [C.c_void_p]
+        if not self.lib.s2st_comm_available():
+            raise bd.S2STHipError("no RCCL library could be bound (s2st_comm_available() == 0)")
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            bd.check(self.lib.s2st_comm_unique_id(buf), "s2st_comm_unique_id")
+        if world > 1:
+            box = [bytes(buf.raw)]
+            dist.broadcast_object_list(box, src=0)
+            buf = C.create_string_buffer(box[0], 128)
+        h = C.c_void_p()
+        bd.check(self.lib.s2st_comm_init(buf, world, rank, C.byref(h)), "s2st_comm_init")
+        self.h, self.world, self.rank = h, world, rank
+
+    def all_reduce_(self, t: torch.Tensor):
+        """In-place SUM over ranks, ordered on the current torch stream."""
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        self.bd.check(self.lib.s2st_allreduce_sum_f32(self.h, t.data_ptr(), t.numel(), self.bd.stream_ptr()),
+                      "s2st_allreduce_sum_f32")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.s2st_comm_destroy(self.h)
+            self.h = None
+
+
 class GradReducer:
-    """SUM all-reduce of arena ranges as the backward finishes them."""
+    """SUM all-reduce of arena ranges as the backward finishes them.
+
+    Three transports, same ordering logic (a range is reduced on the reducer's stream behind BOTH engine streams):
+    * device gradients, backend "nccl" (= RCCL): ``dist.all_reduce`` on the reducer's stream, or -- with
+      ``S2ST_NATIVE_ALLREDUCE=1`` -- the C ABI's own communicator (``NativeComm``);
+    * device gradients, backend "gloo": the range is staged through pinned host memory around a host all-reduce.  Slow
+      (it blocks the host), but it lets two ranks share ONE GPU, which RCCL refuses ("Duplicate GPU detected"): the
+      two-process GPU test of the exchange runs this way;
+    * host gradients (the CPU emulator tests): asynchronous gloo all-reduce."""
 
     def __init__(self, grads: torch.Tensor, min_bucket_floats: int = 4 << 20, extra_stream=None):
         self.grads = grads
+        import os
+        self.staged = grads.is_cuda and dist.is_initialized() and dist.get_backend() == "gloo"
+        self.native = None
+        if grads.is_cuda and not self.staged and os.environ.get("S2ST_NATIVE_ALLREDUCE", "0") == "1":
+            self.native = NativeComm()
+        self._pin = None
         # the engine's second stream (weight gradients): a range is final once both streams reached here
         self.extra_stream = extra_stream
         self.min_bucket = min_bucket_floats
@@ -51,7 +105,18 @@ class GradReducer:
             if self.extra_stream is not None:
                 self.stream.wait_stream(self.extra_stream)
             with torch.cuda.stream(self.stream):
-                dist.all_reduce(view, op=dist.ReduceOp.SUM)
+                if self.staged:
+                    if self._pin is None or self._pin.numel() < view.numel():
+                        self._pin = torch.empty(max(view.numel(), self.min_bucket), dtype=torch.float32).pin_memory()
+                    host = self._pin[:view.numel()]
+                    host.copy_(view, non_blocking=True)
+                    self.stream.synchronize()
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                    view.copy_(host, non_blocking=True)
+                elif self.native is not None:
+                    self.native.all_reduce_(view)
+                else:
+                    dist.all_reduce(view, op=dist.ReduceOp.SUM)
         else:
             self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
 
@@ -91,5 +156,22 @@ def all_reduce_scalars(t: torch.Tensor) -> torch.Tensor:
     """Fixed-layout fp32/fp64 statistics vector (sample sizes, loss sums): one small SUM
     all-reduce instead of the reference's pickled all_gather_list."""
     if is_dist():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if t.is_cuda and dist.get_backend() == "gloo":  # two ranks on one GPU (tests): through the host
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def broadcast_(t: torch.Tensor, src: int = 0) -> torch.Tensor:
+    """Parameter / buffer broadcast at start-up (DDP's constructor does the same)."""
+    if is_dist():
+        if t.is_cuda and dist.get_backend() == "gloo":
+            h = t.cpu()
+            dist.broadcast(h, src)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src)
     return t

@@ -21,11 +21,11 @@ from ..data.data_cfg import S2STDataConfig
 from ..data.dictionary import Dictionary
 from ..data.s2st_dataset import S2STDatasetCreator
 from ..data.synthetic import SyntheticFisherCorpus
-from ..registry import register_task, CRITERIA, MODELS
+from ..registry import HAVE_FAIRSEQ, TaskBase, register_task, CRITERIA, MODELS
 
 
 @register_task("s2s_translation")
-class S2ST_TranslationTask:
+class S2ST_TranslationTask(TaskBase):  # fairseq's LegacyFairseqTask when fairseq is importable
     @staticmethod
     def add_args(parser):
         """Flags of s2s_translation.py:49-71 that the training path reads."""
@@ -42,6 +42,8 @@ class S2ST_TranslationTask:
         a("--tgt-vocab-size", type=int, default=74)
 
     def __init__(self, args, src_dict: Dictionary, tgt_dict: Dictionary, device=None, data_cfg=None):
+        if HAVE_FAIRSEQ:
+            super().__init__(args)
         self.args = args
         self.src_dict, self.tgt_dict = src_dict, tgt_dict
         self.device = device
@@ -115,9 +117,65 @@ class S2ST_TranslationTask:
                                   epoch=epoch)
 
     def build_model(self, args):
+        """s2s_translation.py:174-184: the model, and with --eval-inference the generator validation uses."""
         from .. import models  # noqa: F401  (registers the architecture)
         args.n_frames_per_step = self.args.n_frames_per_step
-        return MODELS["s2st_transformer"].build_model(args, self)
+        model = MODELS["s2st_transformer"].build_model(args, self)
+        self.generator = None
+        if getattr(args, "eval_inference", False):
+            self.generator = self.build_generator_tts([model], args)
+        return model
+
+    @property
+    def sr(self):
+        """Target sample rate (s2s_translation.py:78: data config ``features.sample_rate``)."""
+        if self.data_cfg is not None:
+            feats = self.data_cfg.config.get("features") or {}
+            if feats.get("sample_rate"):
+                return int(feats["sample_rate"])
+        return int(getattr(self.args, "sample_rate", 24000))
+
+    def build_default_vocoder(self):
+        """s2s_translation.py:208-215 -> get_vocoder (fairseq/models/text_to_speech/vocoder.py:147-158): Griffin-Lim
+        from the data config's feature settings."""
+        from ..vocoder import GriffinLimVocoder
+        if self.data_cfg is not None:
+            return GriffinLimVocoder.from_data_cfg(self.args, self.data_cfg, device=self.device)
+        # synthetic data (no config.yaml): 80-bin log-mel at 24 kHz, hop 300 / window 1200 / n_fft 2048 -- the feature
+        # geometry SURVEY 8(d) assumes for the Fisher targets
+        a = self.args
+        return GriffinLimVocoder(
+            sample_rate=self.sr, win_size=int(getattr(a, "win_size", 1200)), hop_size=int(getattr(a, "hop_size", 300)),
+            n_fft=int(getattr(a, "n_fft", 2048)), n_mels=int(getattr(a, "output_frame_dim", 80)),
+            f_min=float(getattr(a, "f_min", 20.0)), f_max=float(getattr(a, "f_max", 8000.0)),
+            spec_bwd_max_iter=int(getattr(a, "spec_bwd_max_iter", 32)), device=self.device)
+
+    def build_generator_tts(self, models, cfg, vocoder=None, **unused):
+        """s2s_translation.py:186-204."""
+        from ..speech_generator import AutoRegressiveSpeechGenerator
+        if vocoder is None:
+            vocoder = self.build_default_vocoder()
+        return AutoRegressiveSpeechGenerator(
+            models[0], vocoder, self.data_cfg, max_iter=self.args.max_target_positions,
+            eos_prob_threshold=getattr(self.args, "eos_prob_threshold", 0.5),
+            input_text=getattr(self.args, "input_text", False))
+
+    def build_generator(self, models, args, seq_gen_cls=None, extra_gen_cls_kwargs=None):
+        """Text generator over an aux decoder (s2s_translation.py:312-336 -> FairseqTask.build_generator ->
+        SequenceGenerator; fairseq_cli/generate_for_s2st.py:107-111 swaps ``model.decoder`` for the aux ASR / ST
+        decoder first): here ``args.aux_decoder`` ("asr" | "st") picks the head."""
+        from ..sequence_generator import AuxSequenceGenerator
+        which = getattr(args, "aux_decoder", "st")
+        return AuxSequenceGenerator(
+            models[0], self.src_dict if which == "asr" else self.tgt_dict, which=which,
+            beam_size=getattr(args, "beam", 5), max_len_a=getattr(args, "max_len_a", 0),
+            max_len_b=getattr(args, "max_len_b", 200), min_len=getattr(args, "min_len", 1),
+            len_penalty=getattr(args, "lenpen", 1.0), unk_penalty=getattr(args, "unkpen", 0.0),
+            **(extra_gen_cls_kwargs or {}))
+
+    def reduce_metrics(self, logging_outputs, criterion):
+        """fairseq/tasks/fairseq_task.py:586-617: the criterion aggregates (s2st_loss.py:350-407)."""
+        return criterion.__class__.reduce_metrics(logging_outputs)
 
     def build_criterion(self, args):
         from .. import criterions  # noqa: F401
@@ -137,7 +195,33 @@ class S2ST_TranslationTask:
         return loss, sample_size, logging_output
 
     def valid_step(self, sample, model, criterion):
+        """fairseq_task.py:499-503 + s2s_translation.py:217-238: the loss, and with --eval-inference the MCD statistics
+        of an AR decode of the batch against its targets."""
         model.eval()
         with torch.no_grad():
             loss, sample_size, logging_output = criterion(model, sample)
+        if getattr(self.args, "eval_inference", False):
+            if getattr(self, "generator", None) is None:
+                self.generator = self.build_generator_tts([model], self.args)
+            hypos, inference_losses = self.valid_step_with_inference(sample, model, self.generator)
+            for k, v in inference_losses.items():
+                assert k not in logging_output
+                logging_output[k] = v
         return loss, sample_size, logging_output
+
+    def valid_step_with_inference(self, sample, model, generator):
+        """s2s_translation.py:240-264: AR-generate, vocode prediction and target, MFCC -> DTW -> mel-cepstral
+        distortion (HIP kernels: metrics.py), summed statistics."""
+        from ..metrics import batch_mel_cepstral_distortion
+        hypos = generator.generate(model, sample, has_targ=True)
+        losses = {"mcd_loss": 0.0, "targ_frames": 0.0, "pred_frames": 0.0, "nins": 0.0, "ndel": 0.0}
+        rets = batch_mel_cepstral_distortion([h["targ_waveform"] for h in hypos], [h["waveform"] for h in hypos],
+                                             self.sr, normalize_type=None)
+        for d, extra in rets:
+            pathmap = extra[-1]
+            losses["mcd_loss"] += float(d)
+            losses["targ_frames"] += pathmap.size(0)
+            losses["pred_frames"] += pathmap.size(1)
+            losses["nins"] += float((pathmap.sum(dim=1) - 1).sum())
+            losses["ndel"] += float((pathmap.sum(dim=0) - 1).sum())
+        return hypos, losses

@@ -19,7 +19,7 @@ from typing import Dict, List, Optional
 import torch
 
 from .runtime import binding as bd
-from .runtime.distributed import GradReducer, all_reduce_scalars, is_dist, world_size
+from .runtime.distributed import GradReducer, all_reduce_scalars, broadcast_, is_dist, world_size
 from .runtime.engine import STAT
 
 
@@ -56,8 +56,8 @@ class Trainer:
         self.reducer = GradReducer(self.engine.grads, extra_stream=self.engine.side_stream()) if is_dist() else None
         if is_dist():
             # DDP's constructor broadcast of parameters and buffers from rank 0
-            torch.distributed.broadcast(self.engine.params, 0)
-            torch.distributed.broadcast(self.engine.buffers, 0)
+            broadcast_(self.engine.params, 0)
+            broadcast_(self.engine.buffers, 0)
 
     def _ph(self):
         """bf16 parameter copy the optimizer kernel refreshes with the update (S2ST_ADAM_NO_PH=1: A/B switch,

@@ -18,5 +18,5 @@ for f in "$SRC"/*.hip "$SRC"/*.cpp "$HERE/emu_runtime.cpp"; do
   objs="$objs $o"
 done
 wait
-$CXX -shared -pthread $objs -o "$OUT/libs2st_emu.so"
+$CXX -shared -pthread $objs -ldl -o "$OUT/libs2st_emu.so"
 echo "$OUT/libs2st_emu.so"

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = "speech-to-speech-translation_amd"
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, on_gpu=False):
     for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -27,13 +27,17 @@ def _worker(rank, world, port, q):
     from synth_weights import load_synth
     from test_engine import NANO, nano_batches
     bd = importlib.import_module(PKG + ".runtime.binding")
-    bd.load_library(os.path.join(ROOT, "tests", "hipemu", "_build", "libs2st_emu.so"), emulator=True)
+    if on_gpu:  # the product library; both ranks share cuda:0 (RCCL refuses that, gloo through pinned host memory does not)
+        torch.cuda.set_device(0)
+        bd.load_library(bd.DEFAULT_LIB, emulator=False)
+    else:
+        bd.load_library(os.path.join(ROOT, "tests", "hipemu", "_build", "libs2st_emu.so"), emulator=True)
     tasks = importlib.import_module(PKG + ".tasks")
     tr = importlib.import_module(PKG + ".trainer")
     D = importlib.import_module(PKG + ".data")
     a = O.make_args(**NANO)
     a.precise_gemm, a.lr, a.warmup_updates, a.clip_norm = True, 1e-3, 1, 0.05
-    task = tasks.S2ST_TranslationTask.setup_task(a, device=torch.device("cpu"))
+    task = tasks.S2ST_TranslationTask.setup_task(a, device=torch.device("cuda", 0) if on_gpu else torch.device("cpu"))
     model = task.build_model(a)
     load_synth(model, rank)  # deliberately different per rank: the Trainer must broadcast rank 0's
     crit = task.build_criterion(a)
@@ -43,20 +47,32 @@ def _worker(rank, world, port, q):
     for u in range(3):
         # third update: rank 1's shard has run out (the sharded iterator hands it an empty batch)
         r = trainer.train_step([mine if (u < 2 or rank == 0) else {}])
+    if on_gpu:
+        assert trainer.reducer.staged and trainer.reducer.extra_stream is not None  # both engine streams are waited for
+        torch.cuda.synchronize()
     if rank == 0:
-        q.put({n: p.detach().numpy().copy() for n, p in model.named_parameters()})
+        q.put({n: p.detach().cpu().numpy().copy() for n, p in model.named_parameters()})
         q.put(float(r["gnorm"]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_update_equals_single_process():
+@pytest.mark.parametrize("where", ["emu", pytest.param("hip", marks=pytest.mark.gpu)])
+def test_two_rank_update_equals_single_process(where):
+    """Two processes, three updates (the third with an exhausted shard on rank 1), against the ORACLE's single-process
+    update over both batches.  ``emu``: host gradients, emulator build.  ``hip``: both ranks drive the product library on
+    the one GPU the test box has -- device gradients, the engine's two streams, the reducer's stream and events, the
+    device-side sample-size exchange -- with gloo carrying the bytes (RCCL refuses two ranks on one device)."""
     import subprocess
-    subprocess.check_call([os.path.join(ROOT, "tests", "hipemu", "build_emu.sh")], stdout=subprocess.DEVNULL)
+    on_gpu = where == "hip"
+    if on_gpu:
+        assert torch.cuda.is_available(), "gpu-marked test needs a HIP device"
+    else:
+        subprocess.check_call([os.path.join(ROOT, "tests", "hipemu", "build_emu.sh")], stdout=subprocess.DEVNULL)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, on_gpu)) for r in range(2)]
     for p in procs:
         p.start()
     params = q.get(timeout=900)
@@ -99,53 +115,31 @@ def test_two_rank_update_equals_single_process():
 
 
 @pytest.mark.gpu
-def test_rccl_reducer_path_on_one_gpu(monkeypatch):
-    """Only one GPU is available to the tests, so the RCCL leg of the data-parallel path is driven with a
-    one-rank process group and `is_dist` forced on: parameter broadcast, segment-wise all-reduce on the
-    reducer's stream behind BOTH engine streams (the second one through torch.cuda.ExternalStream), the
-    device-side sample-size exchange and the fused scale/clip/Adam must reproduce the plain single-process
-    update (a SUM over one rank is the identity)."""
+def test_native_communicator_through_the_c_abi():
+    """``s2st_comm_*`` / ``s2st_allreduce_sum_f32`` (include/s2st_hip.h): the library binds the RCCL copy the process
+    already carries, creates a communicator from a unique id and runs an in-place SUM all-reduce on a side stream.  One
+    GPU here, so one rank (the SUM is then the identity): this pins binding, call signature, stream ordering and error
+    codes; N > 1 is the driver's multi-GPU bench (``S2ST_NATIVE_ALLREDUCE=1``)."""
     assert torch.cuda.is_available(), "gpu-marked test needs a HIP device"
-    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    for p in (ROOT,):
         if p not in sys.path:
             sys.path.insert(0, p)
     import s2st_amd  # noqa: F401
-    import s2st_oracle as O
-    from configs import CONFIGS
-    from synth_weights import synth_tensor
-    tasks = importlib.import_module(PKG + ".tasks")
-    tr = importlib.import_module(PKG + ".trainer")
+    bd = importlib.import_module(PKG + ".runtime.binding")
+    bd.load_library(bd.DEFAULT_LIB, emulator=False)
     dm = importlib.import_module(PKG + ".runtime.distributed")
-    D = importlib.import_module(PKG + ".data")
-    dev = torch.device("cuda", 0)
-    corpus = D.SyntheticFisherCorpus(n_utts=64, seed=5, max_src=400, median_src=200)
-    batches = [corpus.collate_batch(range(0, 16)), corpus.collate_batch(range(16, 32))]
-
-    def run(distributed):
-        a = O.make_args(**CONFIGS["base_recipe"])
-        a.lr, a.warmup_updates, a.clip_norm, a.seed = 1.5e-3, 4000, 1.0, 1
-        task = tasks.S2ST_TranslationTask.setup_task(a, device=dev)
-        model = task.build_model(a)
-        for name, pv, gv, isb in model.engine.named_views():
-            pv.copy_(torch.from_numpy(synth_tensor(name, tuple(pv.shape), 0)))
-        trainer = tr.Trainer(a, task, model, task.build_criterion(a))
-        assert (trainer.reducer is not None) == distributed
-        if distributed:
-            trainer.reducer.min_bucket = 1 << 20  # several buckets
-        for b in batches:
-            r = trainer.train_step([b])
-        torch.cuda.synchronize()
-        return model.engine.params.clone(), float(r["gnorm"])
-
-    p_ref, g_ref = run(False)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (29600 + os.getpid() % 2000), rank=0,
-                            world_size=1, device_id=dev)
-    try:
-        monkeypatch.setattr(dm, "is_dist", lambda: True)
-        monkeypatch.setattr(tr, "is_dist", lambda: True)
-        p_ddp, g_ddp = run(True)
-    finally:
-        dist.destroy_process_group()
-    assert abs(g_ddp - g_ref) <= 1e-5 * g_ref
-    assert float((p_ddp - p_ref).abs().max()) <= 1e-6
+    torch.cuda.set_device(0)
+    comm = dm.NativeComm()
+    assert comm.world == 1 and comm.rank == 0
+    x = torch.randn(3_000_001, device="cuda:0")
+    ref = x.clone()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        comm.all_reduce_(x)
+    torch.cuda.current_stream().wait_stream(st)
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)
+    # argument errors come back as codes, not crashes
+    assert comm.lib.s2st_allreduce_sum_f32(None, x.data_ptr(), 4, None) == -4
+    comm.close()

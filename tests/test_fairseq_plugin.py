@@ -1,0 +1,74 @@
+"""The package as a fairseq ``--user-dir`` plugin: with fairseq importable -- the reference tree
+plus the stub omegaconf / hydra / bitarray packages of oracle/ref_shims, which only exist in the build container --
+``utils.import_user_module`` must leave the three names of the reference recipe in fairseq's own registries, pointing at
+this package's classes, and those classes must extend fairseq's bases.  Runs in a child process (importing fairseq
+rebinds the package's base classes).  Skipped where /root/reference is absent (the GPU box)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+
+CHILD = r'''
+import argparse, json, os, sys
+import numpy as np, torch
+ROOT, REF = sys.argv[1], sys.argv[2]
+sys.path.insert(0, os.path.join(ROOT, "oracle", "ref_shims")); sys.path.insert(0, REF)
+for n, t in dict(float=float, int=int, bool=bool, object=object, complex=complex, str=str).items():
+    if not hasattr(np, n): setattr(np, n, t)
+torch._C.has_cudnn = False
+import fairseq
+from fairseq import utils
+from fairseq.tasks import TASK_REGISTRY, LegacyFairseqTask
+from fairseq.models import MODEL_REGISTRY, ARCH_MODEL_REGISTRY, ARCH_CONFIG_REGISTRY, BaseFairseqModel
+from fairseq.criterions import CRITERION_REGISTRY, FairseqCriterion
+assert "s2s_translation" not in TASK_REGISTRY and "s2st_transformer" not in MODEL_REGISTRY
+utils.import_user_module(argparse.Namespace(user_dir=os.path.join(ROOT, "speech-to-speech-translation_amd")))
+pkg = sys.modules["speech-to-speech-translation_amd"]
+t, m, c = TASK_REGISTRY["s2s_translation"], MODEL_REGISTRY["s2st_transformer"], CRITERION_REGISTRY["s2st_loss"]
+out = dict(
+    task=t.__module__, model=m.__module__, criterion=c.__module__,
+    arch=ARCH_MODEL_REGISTRY["s2st_transformer"].__module__, arch_fn=ARCH_CONFIG_REGISTRY["s2st_transformer"].__module__,
+    bases=[issubclass(t, LegacyFairseqTask), issubclass(m, BaseFairseqModel), issubclass(c, FairseqCriterion)],
+    registered=pkg.registry.FAIRSEQ_REGISTERED)
+# the architecture function fills the reference's defaults on a bare namespace
+a = argparse.Namespace()
+ARCH_CONFIG_REGISTRY["s2st_transformer"](a)
+out["arch_defaults"] = [a.encoder_transformer_layers, a.decoder_transformer_layers, a.encoder_embed_dim, a.prenet_dim]
+# flags: the reference's parser options are all there
+p = argparse.ArgumentParser(); m.add_args(p); t.add_args(p)
+out["flags"] = sorted(o for act in p._actions for o in act.option_strings)
+print("RESULT " + json.dumps(out))
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference tree (build container only)")
+def test_names_resolve_through_fairseq_registries():
+    r = subprocess.run([sys.executable, "-c", CHILD, ROOT, REF], capture_output=True, text=True, timeout=300)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert line, r.stderr[-2000:]
+    out = json.loads(line[0][7:])
+    pkg = "speech-to-speech-translation_amd"
+    assert out["task"] == pkg + ".tasks.s2s_translation"
+    assert out["model"] == out["arch"] == out["arch_fn"] == pkg + ".models.s2st_transformer"
+    assert out["criterion"] == pkg + ".criterions.s2st_loss"
+    assert out["bases"] == [True, True, True]
+    assert out["registered"] == {"task": ["s2s_translation"], "model": ["s2st_transformer"], "arch": ["s2st_transformer"],
+                                 "criterion": ["s2st_loss"]}
+    assert out["arch_defaults"] == [12, 6, 512, 256]  # base_architecture, s2st_transformer.py:792-830
+    for flag in ("--middle-layers", "--asr-decoder-embed-dim", "--prenet-dropout", "--load-pretrained-hubert-from",
+                 "--n-frames-per-step", "--use-hubert", "--eval-inference"):
+        assert flag in out["flags"], flag
+
+
+def test_local_registry_without_fairseq():
+    """The GPU image has no fairseq: the same decorators fill the package's own tables."""
+    import importlib
+    import s2st_amd  # noqa: F401
+    reg = importlib.import_module("speech-to-speech-translation_amd.registry")
+    assert set(reg.TASKS) >= {"s2s_translation"} and set(reg.MODELS) >= {"s2st_transformer"}
+    assert set(reg.ARCHS) >= {"s2st_transformer"} and set(reg.CRITERIA) >= {"s2st_loss"}

@@ -85,3 +85,55 @@ def test_checkpoint_resume_continues_identically(backend, tmp_path, prefetch):
     for n, p in trainer.model.named_parameters():
         if not noise_driven(n):
             assert float((p.detach() - p_straight[n]).abs().max()) <= 2e-6, n
+
+
+NANO_FLAGS = ("--encoder-transformer-layers 2 --decoder-transformer-layers 1 --encoder-embed-dim 32 --decoder-embed-dim 32 "
+              "--encoder-ffn-embed-dim 64 --decoder-ffn-embed-dim 64 --encoder-attention-heads 2 --decoder-attention-heads 2 "
+              "--encoder-normalize-before --decoder-normalize-before --prenet-dim 16 --postnet-conv-dim 32 --postnet-layers 2 "
+              "--middle-layers 0,1 --asr-decoder-layers 1 --st-decoder-layers 1 --asr-decoder-embed-dim 16 "
+              "--st-decoder-embed-dim 16 --ctc-weight 0.3 --asr-ce-weight 0.3 --st-ce-weight 0.3 --dropout 0.1 "
+              "--attention-dropout 0.1 --activation-dropout 0.0 --prenet-dropout 0.0 --postnet-dropout 0.0 "
+              "--n-frames-per-step 4 --bce-pos-weight 5.0 --label-smoothing 0.1 --report-accuracy").split()
+
+
+def test_train_harness_runs_validates_checkpoints_and_resumes(backend, tmp_path):
+    """``train.main`` with the recipe's flag names (fairseq_cli/train.py counterpart): 4 updates in one go == 2 updates,
+    checkpoint_last.pt, a second invocation that resumes from it for 2 more; validation runs at the save points and a
+    checkpoint_best.pt is kept."""
+    from synth_weights import load_synth
+    T = importlib.import_module(PKG + ".train")
+    corpus = make_corpus(str(tmp_path / "corpus"))
+    # SpecAugment draws from numpy's global generator (as in the reference): no two runs see the same masks, so the
+    # resume comparison trains on the un-augmented features
+    cfg = open(os.path.join(corpus, "config.yaml")).read().replace("[src_global_cmvn, specaugment]", "[src_global_cmvn]")
+    open(os.path.join(corpus, "config_noaug.yaml"), "w").write(cfg)
+
+    def run(save_dir, max_update, extra=()):
+        argv = [corpus, "--config-yaml", "config_noaug.yaml", "--train-subset", "train_tiny", "--valid-subset", "dev_tiny",
+                "--task", "s2s_translation", "--arch", "s2st_transformer", "--criterion", "s2st_loss",
+                "--max-tokens", "120", "--required-batch-size-multiple", "2", "--max-update", str(max_update),
+                "--lr", "1e-3", "--warmup-updates", "2", "--clip-norm", "0.05", "--seed", "3", "--precise-gemm",
+                "--save-dir", str(save_dir), "--save-interval-updates", "2", "--log-interval", "1",
+                "--optimizer", "adam", "--lr-scheduler", "inverse_sqrt", "--fp16", "--find-unused-parameters",
+                "--user-dir", "ignored"] + NANO_FLAGS + list(extra)
+        return T.main(argv, device=backend.device, on_model_built=lambda m: load_synth(m, 0))
+
+    s4 = run(tmp_path / "a", 4)
+    backend.sync()
+    assert s4["num_updates"] == 4 and len(s4["train_loss"]) == 4
+    p4 = {n: p.detach().clone() for n, p in s4["trainer"].model.named_parameters()}
+    assert os.path.isfile(tmp_path / "a" / "checkpoint_last.pt") and os.path.isfile(tmp_path / "a" / "checkpoint_best.pt")
+    assert s4["valid"] and all(k in s4["valid"][0] for k in ("loss", "l1_loss", "ctc_loss", "asr_accuracy"))
+
+    s2 = run(tmp_path / "b", 2)
+    assert s2["num_updates"] == 2
+    s22 = run(tmp_path / "b", 4)  # second invocation: restores checkpoint_last.pt of the same --save-dir
+    backend.sync()
+    assert s22["num_updates"] == 4 and len(s22["train_loss"]) == 2
+    got = [l for _, l in s2["train_loss"]] + [l for _, l in s22["train_loss"]]
+    for (_, x), y in zip(s4["train_loss"], got):
+        assert abs(x - y) <= 2e-6 * abs(x), (s4["train_loss"], got)
+    noise_driven = lambda n: n.endswith("k_proj.bias") or (".postnet.convolutions." in n and n.endswith(".0.bias"))  # noqa: E731
+    for n, p in s22["trainer"].model.named_parameters():
+        if not noise_driven(n):
+            assert float((p.detach() - p4[n]).abs().max()) <= 2e-6, n
