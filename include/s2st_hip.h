@@ -392,6 +392,19 @@ int s2st_rms_dist_f32(const float* x1, const float* x2, float* out, int32_t m, i
 int s2st_power_spec_f32(const float* Y, float* P, int32_t T, int32_t F, void* stream);
 int s2st_log_offset_f32(float* x, int64_t n, float eps, void* stream);
 
+/* Aux ASR (which = 0) / ST (which = 1) text decoder, forward only, over an encoder tap: what the reference runs
+ * when fairseq_cli/generate_for_s2st.py:107-111 swaps model.decoder for model.aux_{asr,st}_decoder and
+ * SequenceGenerator calls decoder.forward(tokens, encoder_out) (examples/s2s_trans/models/s2st_transformer.py:483-578,
+ * fairseq/models/transformer/transformer_decoder.py:253-378).  tap [Bb][E][enc_dim] = the head's normalised tap of the
+ * encoder (outputs tap0 / tap1), one copy per hypothesis; prev_tokens [Bb][L] int64; positions [Bb][L] int32
+ * (make_positions); lens [Bb] = valid tokens per row; pe = sinusoidal table of width asr_dim / st_dim;
+ * logits_out [Bb][L][V].  s2st_engine_aux_decode_workspace gives the workspace floats for (Bb, L, E). */
+int64_t s2st_engine_aux_decode_workspace(s2st_engine* e, int32_t which, int32_t Bb, int32_t L, int32_t E);
+int s2st_engine_aux_decode(s2st_engine* e, int32_t which, const float* tap, const int32_t* enc_lens,
+                           const int64_t* prev_tokens, const int32_t* positions, const int32_t* lens, const float* pe,
+                           int32_t Bb, int32_t L, int32_t E, float* logits_out, float* workspace,
+                           int64_t workspace_floats, void* stream);
+
 /* ---- frozen HuBERT front end of config 4 (--use-hubert): fairseq/models/hubert/hubert.py:412-461,
  * 518-534 (extract_features, eval, mask=False) with wav2vec2.py:736-905.  The handle is an
  * s2st_engine in "hubert mode": parameters are enumerated / bound with s2st_engine_param_info,

@@ -1802,6 +1802,62 @@ int s2st_engine_postnet_eval(s2st_engine* e, const float* feat, int32_t B, int32
   return e->err;
 }
 
+// ---- aux ASR / ST text decoder, forward only (beam search over an aux head: generate_for_s2st.py:107-111) -----
+int s2st_engine_aux_decode(s2st_engine* e, int32_t which, const float* tap, const int32_t* enc_lens,
+                           const int64_t* prev_tokens, const int32_t* positions, const int32_t* lens, const float* pe,
+                           int32_t Bb, int32_t L, int32_t E, float* logits_out, float* workspace,
+                           int64_t workspace_floats, void* stream) {
+  if (!e || !e->P || !tap || !enc_lens || !prev_tokens || !positions || !lens || !pe || !logits_out) return S2ST_ERR_ARG;
+  if ((which == 0 && !e->c.has_asr) || (which == 1 && !e->c.has_st) || which < 0 || which > 1) return S2ST_ERR_ARG;
+  if (Bb <= 0 || L <= 0 || E <= 0) return S2ST_ERR_SHAPE;
+  if (!workspace) return S2ST_ERR_WORKSPACE;
+  e->reset_call();
+  e->dry = false;
+  e->ws = workspace;
+  e->ws_cap = workspace_floats;
+  e->st_ = (hipStream_t)stream;
+  e->bt = s2st_batch{};
+  e->bt.B = Bb; e->bt.E = E; e->bt.training = 0;
+  e->bt.enc_lens = enc_lens;
+  e->skws = nullptr; e->skws_n = 0; e->skws_side = nullptr;
+  if (e->fast()) {
+    if (!e->PH) return S2ST_ERR_ARG;
+    int rc = s2st_cast_bf16_rows(e->P, e->n_params, e->PH, e->n_params, 1, (int)e->n_params, e->st_);
+    if (rc) return rc;
+  }
+  hipStream_t keep_side = e->side_;
+  e->side_ = nullptr;  // forward only, one stream
+  Ten* t = e->newT(Bb * E, e->c.enc_dim, const_cast<float*>(tap));
+  t->needs_grad = false;
+  e->aux_decoder(which == 0 ? e->asr : e->st, t, (const long*)prev_tokens, positions, lens, Bb, L, pe, logits_out);
+  e->side_ = keep_side;
+  e->tape.clear();
+  return e->err;
+}
+
+int64_t s2st_engine_aux_decode_workspace(s2st_engine* e, int32_t which, int32_t Bb, int32_t L, int32_t E) {
+  if (!e || which < 0 || which > 1 || (which == 0 && !e->c.has_asr) || (which == 1 && !e->c.has_st)) return S2ST_ERR_ARG;
+  e->reset_call();
+  e->dry = true;
+  e->ws = reinterpret_cast<float*>(0x10000);
+  e->ws_cap = (long)1 << 50;
+  e->st_ = nullptr;
+  e->bt = s2st_batch{};
+  e->bt.B = Bb; e->bt.E = E; e->bt.training = 0;
+  e->skws = nullptr; e->skws_n = 0; e->skws_side = nullptr;
+  hipStream_t keep_side = e->side_;
+  e->side_ = nullptr;
+  Ten* t = e->newT(Bb * E, e->c.enc_dim, reinterpret_cast<float*>(0x10000));
+  t->needs_grad = false;
+  e->aux_decoder(which == 0 ? e->asr : e->st, t, nullptr, nullptr, nullptr, Bb, L, nullptr, reinterpret_cast<float*>(0x10000));
+  e->side_ = keep_side;
+  const long peak = e->ws_peak;
+  const int err = e->err;
+  e->reset_call();
+  e->dry = false;
+  return err ? (int64_t)err : (int64_t)peak + 1024;
+}
+
 // ---- HuBERT front end ---------------------------------------------------------------------------
 int s2st_hubert_create(const s2st_hubert_config* cfg, s2st_engine** out) {
   if (!cfg || !out || cfg->n_conv < 1 || cfg->n_conv > 8) return S2ST_ERR_ARG;

@@ -107,15 +107,15 @@ class Dictionary:
         words = line_tokenizer(line)
         if reverse_order:
             words = list(reversed(words))
-        ids = torch.empty(len(words) + (1 if append_eos else 0), dtype=torch.int32)
-        for i, w in enumerate(words):
+        ids = []  # (one tensor construction at the end: per-element tensor stores cost microseconds each)
+        for w in words:
             idx = self.add_symbol(w) if add_if_not_exist else self.index(w)
             if consumer is not None:
                 consumer(w, idx)
-            ids[i] = idx
+            ids.append(idx)
         if append_eos:
-            ids[len(words)] = self.eos_index
-        return ids
+            ids.append(self.eos_index)
+        return torch.tensor(ids, dtype=torch.int32)
 
     def string(self, tensor: Iterable, include_eos: bool = False, separator: str = " ") -> str:
         if torch.is_tensor(tensor) and tensor.dim() == 2:

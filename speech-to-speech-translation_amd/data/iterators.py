@@ -37,9 +37,64 @@ def shard(batches: Sequence, num_shards: int, shard_id: int, fill_value=()):
     return mine + [fill_value] * (n - len(mine))
 
 
+_WORKER_DATASET = None
+
+
+def _loader_init(dataset_bytes):
+    """Loader process start-up: its own copy of the dataset object (manifest columns, dictionaries, transform
+    settings -- no features), one intra-op thread (the tensors handled here are KB-sized)."""
+    global _WORKER_DATASET
+    import pickle
+    import torch
+    torch.set_num_threads(1)
+    _WORKER_DATASET = pickle.loads(dataset_bytes)
+
+
+def _loader_collate(indices):
+    ds = _WORKER_DATASET
+    if len(indices) == 0:
+        return {}
+    return ds.collater([ds[int(i)] for i in indices])
+
+
+class LoaderPool:
+    """``--num-workers N`` loader PROCESSES (the reference's ``DataLoader(num_workers=4)``, fairseq/data/iterators.py:
+    230-516): item loading is mostly interpreter work (manifest look-ups, .npy headers, dictionary encoding), which
+    threads cannot overlap.  Spawned (not forked: the parent may hold an initialised HIP runtime), created once per
+    iterator and reused across epochs; batches come back pickled, in submission order."""
+
+    def __init__(self, dataset, num_workers: int):
+        import pickle
+        import torch.multiprocessing as mp  # tensors of a collated batch travel as shared-memory handles, not bytes
+        self.pool = mp.get_context("spawn").Pool(num_workers, initializer=_loader_init, initargs=(pickle.dumps(dataset),))
+        self.num_workers = num_workers
+        self._pool = None
+
+    def submit(self, indices):
+        return self.pool.apply_async(_loader_collate, (list(map(int, indices)),))
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.terminate()
+            self.pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class _CountingIterator:
-    def __init__(self, batches: List, collate: Callable, start: int = 0):
+    """In-order batches of one epoch; with a ``LoaderPool`` up to ``2 * num_workers`` batches are in flight ahead of
+    the consumer and handed out in order."""
+
+    def __init__(self, batches: List, collate: Callable, start: int = 0, pool: Optional["LoaderPool"] = None):
         self.batches, self.collate, self.n = batches, collate, start
+        self.pool, self.pending = pool, {}
+        if pool is not None:
+            self.ahead = 2 * pool.num_workers
+            self._submitted = start
 
     def __len__(self):
         return len(self.batches)
@@ -53,6 +108,13 @@ class _CountingIterator:
     def __next__(self):
         if not self.has_next():
             raise StopIteration
+        if self.pool is not None:
+            while self._submitted < len(self.batches) and self._submitted < self.n + self.ahead:
+                self.pending[self._submitted] = self.pool.submit(self.batches[self._submitted])
+                self._submitted += 1
+            out = self.pending.pop(self.n).get()
+            self.n += 1
+            return out
         b = self.batches[self.n]
         self.n += 1
         return self.collate(b)
@@ -60,7 +122,10 @@ class _CountingIterator:
 
 class EpochBatchIterator:
     def __init__(self, dataset, collate_fn: Optional[Callable], batch_sampler: Sequence, seed: int = 1,
-                 num_shards: int = 1, shard_id: int = 0, epoch: int = 1, disable_shuffling: bool = False):
+                 num_shards: int = 1, shard_id: int = 0, epoch: int = 1, disable_shuffling: bool = False,
+                 num_workers: int = 0):
+        self.num_workers = num_workers
+        self._pool = None
         self.dataset = dataset
         self.collate_fn = collate_fn or (lambda items: dataset.collater(items))
         self.frozen_batches = tuple(batch_sampler)
@@ -91,7 +156,9 @@ class EpochBatchIterator:
         batches = self.epoch_batches(epoch, shuffle)
         if offset > 0 and offset >= len(batches):
             return None
-        return _CountingIterator(batches, self._collate, start=offset)
+        if self.num_workers > 0 and self._pool is None and hasattr(self.dataset, "collater"):
+            self._pool = LoaderPool(self.dataset, self.num_workers)
+        return _CountingIterator(batches, self._collate, start=offset, pool=self._pool)
 
     @property
     def next_epoch_idx(self):

@@ -272,19 +272,21 @@ class Engine:
             keep["tgt"] = sample["tgt_speech"].to(dev, torch.float32).contiguous()
             b.tgt = keep["tgt"].data_ptr()
         Ls = Lt = 0
-        if self.cfg.has_asr or self.cfg.has_ctc:
+        # (text tensors are absent when only the encoder / mel decoder is wanted -- forward_encoder, AR generation:
+        # the aux heads and the CTC loss are then skipped by the engine)
+        if (self.cfg.has_asr or self.cfg.has_ctc) and sample.get("src_text") is not None:
             st = sample["src_text"].cpu().long().contiguous()
             Ls = st.shape[1]
             keep["src_txt"] = st.to(dev)
             keep["src_txt_lens"] = sample["src_text_len"].to(torch.int32).to(dev)
             b.src_txt, b.src_txt_lens = keep["src_txt"].data_ptr(), keep["src_txt_lens"].data_ptr()
-        if self.cfg.has_asr:
+        if self.cfg.has_asr and ni.get("prev_src_text_tokens") is not None:
             pt = ni["prev_src_text_tokens"].cpu().long().contiguous()
             keep["prev_src_txt"] = pt.to(dev)
             keep["src_txt_pos"] = token_pos(pt).contiguous().to(dev)
             b.prev_src_txt, b.src_txt_pos = keep["prev_src_txt"].data_ptr(), keep["src_txt_pos"].data_ptr()
             b.pe_asr = self.pe(self.cfg.asr_dim, Ls + 2).data_ptr()
-        if self.cfg.has_st:
+        if self.cfg.has_st and sample.get("tgt_text") is not None and ni.get("prev_tgt_text_tokens") is not None:
             tt = sample["tgt_text"].cpu().long().contiguous()
             Lt = tt.shape[1]
             pt = ni["prev_tgt_text_tokens"].cpu().long().contiguous()

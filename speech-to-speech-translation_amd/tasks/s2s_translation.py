@@ -100,7 +100,7 @@ class S2ST_TranslationTask(TaskBase):  # fairseq's LegacyFairseqTask when fairse
         return self.datasets[split]
 
     def get_batch_iterator(self, dataset, max_tokens=None, max_sentences=None, max_positions=None,
-                           required_batch_size_multiple=8, seed=1, num_shards=1, shard_id=0, epoch=1, **kw):
+                           required_batch_size_multiple=8, seed=1, num_shards=1, shard_id=0, epoch=1, num_workers=0, **kw):
         """fairseq/tasks/fairseq_task.py:269-305: length-ordered indices (under numpy_seed(seed)), size filter,
         max-tokens batches, then the sharded, per-epoch shuffled iterator."""
         from ..data.iterators import EpochBatchIterator, numpy_seed
@@ -114,7 +114,7 @@ class S2ST_TranslationTask(TaskBase):  # fairseq's LegacyFairseqTask when fairse
                                 required_batch_size_multiple)
         collate = getattr(dataset, "collater", None) or (lambda items: dataset.collate_items(items))
         return EpochBatchIterator(dataset, collate, batches, seed=seed, num_shards=num_shards, shard_id=shard_id,
-                                  epoch=epoch)
+                                  epoch=epoch, num_workers=num_workers)
 
     def build_model(self, args):
         """s2s_translation.py:174-184: the model, and with --eval-inference the generator validation uses."""

@@ -43,8 +43,9 @@ def get_parser() -> argparse.ArgumentParser:
     a("--max-tokens", type=int, default=20000)
     a("--batch-size", "--max-sentences", type=int, default=None, dest="batch_size")
     a("--required-batch-size-multiple", type=int, default=8)
-    a("--num-workers", type=int, default=1, help="batches are staged by a background thread + HIP stream "
-                                                 "(runtime/prefetch.py); the value is the staging depth")
+    a("--num-workers", type=int, default=1, help="loader processes that read and collate batches ahead of the trainer "
+                                                 "(data/iterators.py); a further thread + HIP stream uploads them "
+                                                 "(runtime/prefetch.py)")
     a("--skip-invalid-size-inputs-valid-test", action="store_true")
     a("--disable-validation", action="store_true")
     a("--validate-interval", type=int, default=1)
@@ -181,6 +182,7 @@ def main(argv: Optional[List[str]] = None, device: Optional[torch.device] = None
         device = torch.device("cuda", local_rank)
     world, rank = _dist_init(local_rank if device.type == "cuda" else None)
     log = _Log(args.log_file, rank)
+    torch.set_num_threads(1)  # host-side torch work here is KB-sized index tensors: intra-op threads only add latency
     torch.manual_seed(args.seed)  # fairseq_cli/train.py:75-76
     task = TASKS[args.task].setup_task(args, device=device)
     if not hasattr(args, "src_vocab_size") or task.data_cfg is not None:
@@ -198,7 +200,9 @@ def main(argv: Optional[List[str]] = None, device: Optional[torch.device] = None
     epoch_itr = task.get_batch_iterator(
         task.dataset(args.train_subset), max_tokens=args.max_tokens, max_sentences=args.batch_size,
         max_positions=task.max_positions(), required_batch_size_multiple=args.required_batch_size_multiple,
-        seed=args.seed, num_shards=world, shard_id=rank)
+        seed=args.seed, num_shards=world, shard_id=rank,
+        # one worker = the staging thread below (it runs the iterator itself); more = a pool of loader processes
+        num_workers=args.num_workers if args.num_workers > 1 else 0)
     os.makedirs(args.save_dir, exist_ok=True)
     restore = args.restore_file if os.path.isabs(args.restore_file) else os.path.join(args.save_dir, args.restore_file)
     if os.path.isfile(restore):  # checkpoint_utils.load_checkpoint (fairseq/checkpoint_utils.py:190-278)
