@@ -226,8 +226,12 @@ typedef struct {
   int32_t asr_layers, asr_dim, st_layers, st_dim, src_vocab, tgt_vocab;
   int32_t no_scale_embedding;
   int32_t precise;                        /* 1: bf16x3 GEMMs (parity mode) */
+  /* s2st_transformer_mtl (examples/s2s_trans/models/s2st_transformer_mtl.py:223-386): a second CTC head, over the TARGET
+   * text, on the raw output of decoder layer tap_dec (--middle-layers-decoder); -1 / 0: none */
+  int32_t tap_dec, has_ctc_tgt;
   float dropout, attn_dropout, act_dropout, prenet_dropout, postnet_dropout;
   float ctc_weight, asr_weight, st_weight, w_l1, w_mse, w_eos, bce_pos_weight, label_smoothing;
+  float ctc_tgt_weight;                   /* s2st_loss_mtl.py:171-185 */
 } s2st_model_config;
 
 typedef struct {
@@ -288,7 +292,7 @@ enum {
   S2ST_STAT_ASR_NLL = 3, S2ST_STAT_ASR_SMOOTH = 4, S2ST_STAT_ASR_CORRECT = 5, S2ST_STAT_ASR_TOTAL = 6,
   S2ST_STAT_ST_NLL = 7, S2ST_STAT_ST_SMOOTH = 8, S2ST_STAT_ST_CORRECT = 9, S2ST_STAT_ST_TOTAL = 10,
   S2ST_STAT_LOSS = 16, S2ST_STAT_L1 = 17, S2ST_STAT_MSE = 18, S2ST_STAT_EOS = 19,
-  S2ST_STAT_CTC = 20, S2ST_STAT_ASR = 21, S2ST_STAT_ST = 22, S2ST_STAT_GNORM = 24
+  S2ST_STAT_CTC = 20, S2ST_STAT_ASR = 21, S2ST_STAT_ST = 22, S2ST_STAT_CTC_TGT = 23, S2ST_STAT_GNORM = 24
 };
 
 typedef struct s2st_engine s2st_engine;

@@ -59,7 +59,12 @@ BASE_RECIPE = dict(BASE, dropout=0.1, attention_dropout=0.1, activation_dropout=
 HUBERT_TRAIN = dict(BASE_PARITY, use_hubert="true", hubert_hidden=768, ctc_weight=0.0)
 HUBERT_RECIPE = dict(BASE_RECIPE, use_hubert="true", hubert_hidden=768, ctc_weight=0.0)
 
-CONFIGS = {"tiny": TINY, "tiny_postln": TINY_POSTLN, "base": BASE_PARITY,
+# s2st_transformer_mtl (tiny geometry): no aux decoders, source-text CTC on encoder tap 0, target-text CTC on the output
+# of decoder layer 0
+TINY_MTL = dict(TINY, asr_ce_weight=0.0, st_ce_weight=0.0, middle_layers="0", middle_layers_decoder="0",
+                ctc_weight=0.3, ctc_weight_tgt=0.2)
+
+CONFIGS = {"tiny_mtl": TINY_MTL, "tiny": TINY, "tiny_postln": TINY_POSTLN, "base": BASE_PARITY,
            "base_recipe": BASE_RECIPE, "hubert_train": HUBERT_TRAIN, "base_recipe_hubert": HUBERT_RECIPE}
 
 

@@ -406,6 +406,10 @@ class S2STDecoder(nn.Module):
         self.postnet = Postnet(self.out_dim, a.postnet_conv_dim, a.postnet_conv_kernel_size,
                                a.postnet_layers, a.postnet_dropout)
         self.ctc_proj = nn.Linear(a.encoder_embed_dim, a.src_vocab_size) if a.ctc_weight > 0 else None
+        # s2st_transformer_mtl.py:266-271: a second CTC head (target text) on a decoder layer's output
+        self.ctc_proj_tgt = (nn.Linear(a.decoder_embed_dim, a.tgt_vocab_size)
+                             if getattr(a, "ctc_weight_tgt", 0.0) > 0 else None)
+        self.middle_layers_decoder = [int(k) for k in str(getattr(a, "middle_layers_decoder", "6")).split(",")]
         self.embed_positions = _PositionalEmbeddingState()
 
     def forward(self, prev, enc, target_lengths):
@@ -419,9 +423,12 @@ class S2STDecoder(nn.Module):
         enc_pad = enc["encoder_padding_mask"] if bool(enc["encoder_padding_mask"].any()) else None
         fm = future_mask(x.shape[0])
         attn = None
+        taps_dec = []
         n = len(self.transformer_layers)
         for i, layer in enumerate(self.transformer_layers):
             x, a_ = layer(x, enc["encoder_out"], enc_pad, fm, self_pad, need_attn=(i == n - 1))
+            if i in self.middle_layers_decoder:
+                taps_dec.append(x)  # raw layer output, [D, B, C] (s2st_transformer_mtl.py:325-327)
             if a_ is not None:
                 attn = a_
         if attn is not None:
@@ -433,7 +440,7 @@ class S2STDecoder(nn.Module):
         eos = self.eos_proj(x)
         post = feat + self.postnet(feat)
         return post, eos, {"attn": attn, "feature_out": feat,
-                           "out_middle_layers": enc["out_middle_layers"]}
+                           "out_middle_layers": enc["out_middle_layers"], "out_middle_layers_decoder": taps_dec}
 
 
 class AuxTextDecoder(nn.Module):
@@ -645,6 +652,12 @@ def criterion_forward(model: S2STModel, sample: Dict, a=None):
         smask = ~lengths_to_padding_mask(sample["src_text_len"], sample["src_text"].shape[1])
         flat = sample["src_text"].masked_select(smask)
         ctc = ctc_loss_mean(lprobs_ctc, flat, ilens, sample["src_text_len"]) * a.ctc_weight
+    ctc_tgt = zero
+    if getattr(a, "ctc_weight_tgt", 0.0) > 0:  # s2st_loss_mtl.py:171-186
+        logits = model.decoder.ctc_proj_tgt(extra["out_middle_layers_decoder"][0].transpose(0, 1))
+        lp_t = F.log_softmax(logits.float(), dim=-1).transpose(0, 1)  # [D, B, V]
+        tmask = ~lengths_to_padding_mask(sample["tgt_text_len"], sample["tgt_text"].shape[1])
+        ctc_tgt = ctc_loss_mean(lp_t, sample["tgt_text"].masked_select(tmask), tl, sample["tgt_text_len"]) * a.ctc_weight_tgt
     log = {}
     asr_loss = st_loss = zero
     if a.asr_ce_weight > 0:
@@ -667,8 +680,9 @@ def criterion_forward(model: S2STModel, sample: Dict, a=None):
         log["st_total"] = int(m.sum())
     l1, mse, eos_loss, attn_loss = (l1 * a.l1_loss_weight, mse * a.mse_loss_weight,
                                     eos_loss * a.eos_loss_weight, attn_loss * a.attn_loss_weight)
-    loss = l1 + mse + eos_loss + attn_loss + ctc + asr_loss + st_loss
+    loss = l1 + mse + eos_loss + attn_loss + ctc + ctc_tgt + asr_loss + st_loss
     log.update({
+        "ctc_loss_tgt": ctc_tgt.detach(),
         "loss": loss.detach(), "ntokens": sample["ntokens"], "nsentences": sample["nsentences"],
         "sample_size": sample["ntokens"], "l1_loss": l1.detach(), "mse_loss": mse.detach(),
         "eos_loss": eos_loss.detach(), "attn_loss": attn_loss.detach(),

@@ -1,1 +1,2 @@
 from .s2st_loss import Tacotron2Criterion, label_smoothed_nll_loss  # noqa: F401
+from .s2st_loss_mtl import Tacotron2MTLCriterion  # noqa: F401

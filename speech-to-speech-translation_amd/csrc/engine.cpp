@@ -206,7 +206,7 @@ struct s2st_engine {
   LinP feat_proj, eos_proj;
   std::vector<ConvP> post_conv;
   std::vector<BNP> post_bn;
-  LinP ctc_proj;
+  LinP ctc_proj, ctc_proj_tgt;
   AuxP asr, st;
 
   // per-call state
@@ -359,6 +359,7 @@ struct s2st_engine {
       post_bn.push_back(bn);
     }
     if (c.has_ctc) ctc_proj = add_lin("decoder.ctc_proj", c.src_vocab, C);
+    if (c.has_ctc_tgt) ctc_proj_tgt = add_lin("decoder.ctc_proj_tgt", c.tgt_vocab, Cd);  // mtl variant
     // aux decoders: embedding dims follow the reference's in-place args mutation
     // (s2st_transformer.py:492-493, 541-542, 669-678)
     int cur = Cd;
@@ -1385,9 +1386,11 @@ struct s2st_engine {
     Ten* y = add_pe(h, bt.dec_pos, pe_dec, 1.f, pos_alpha, tr ? c.dropout : 0.f);
     mark();
     float* attn_out = nullptr;
+    Ten* tap_dec_t = nullptr;
     for (int i = 0; i < c.dec_layers; ++i) {
       float* am = (i == c.dec_layers - 1 && bt.want_attn) ? outs.attn : nullptr;
       y = dec_layer(y, enc_out, dec[i], B, D, E, c.dec_heads, c.dec_pre_ln != 0, bt.tgt_lens, am, xkv[i]);
+      if (c.has_ctc_tgt && i == c.tap_dec) tap_dec_t = y;  // raw layer output (s2st_transformer_mtl.py:325-327)
       if (i % 2 == 1) mark();
     }
     (void)attn_out;
@@ -1395,6 +1398,22 @@ struct s2st_engine {
     Ten* feat = linear(y, feat_proj.w, feat_proj.b, c.out_dim, Cd, 0, 0.f, nullptr, outs.feat);
     Ten* eos = linear(y, eos_proj.w, eos_proj.b, 1, Cd, 0, 0.f, nullptr, outs.eos);
     Ten* post = postnet(feat, B, D, tr, csp, outs.post_feat);
+    // ---- mtl variant: CTC over the TARGET text on a decoder layer's output (s2st_loss_mtl.py:171-186: input lengths =
+    //      decoder steps, targets = tgt_text incl. EOS) ------------------------------------------------------
+    Ten* ctc_tgt_logits = nullptr;
+    float *ctc_tgt_per = nullptr, *ctc_tgt_dl = nullptr;
+    if (c.has_ctc_tgt && tap_dec_t) {
+      ctc_tgt_logits = linear(tap_dec_t, ctc_proj_tgt.w, ctc_proj_tgt.b, c.tgt_vocab, Cd);
+      if (with_loss) {
+        ctc_tgt_per = alloc(B);
+        float* lp = alloc((long)B * D * c.tgt_vocab);
+        float* wsd = alloc(s2st_ctc_workspace_floats(B, D, bt.Lt));
+        ctc_tgt_dl = tr ? alloc(ctc_tgt_logits->n()) : nullptr;
+        if (live())
+          chk(s2st_ctc(ctc_tgt_logits->d, (const long*)bt.tgt_txt, bt.Lt, bt.tgt_lens, bt.tgt_txt_lens, B, D, c.tgt_vocab,
+                       lp, ctc_tgt_per, ctc_tgt_dl, ctc_tgt_dl ? c.ctc_tgt_weight / B : 0.f, wsd, st_));
+      }
+    }
     mark();
     // ---- CTC head on tap 0 (ctc_proj lives on the decoder, fed the encoder tap; :458-463) ----------
     hipStream_t main_st = st_;
@@ -1451,7 +1470,7 @@ struct s2st_engine {
                          stats + S2ST_STAT_ST_NLL, nullptr, 0.f, st_));
         chk(s2st_loss_finalize(stats, ctc_per, B, nf, nr, c.w_l1, c.w_mse, c.w_eos, c.ctc_weight,
                                c.asr_weight, c.st_weight, c.label_smoothing, c.src_vocab, c.tgt_vocab,
-                               (float)bt.src_txt_ntokens, (float)bt.tgt_txt_ntokens, st_));
+                               (float)bt.src_txt_ntokens, (float)bt.tgt_txt_ntokens, st_, ctc_tgt_per, c.ctc_tgt_weight));
       }
       tape.push_back([=]() {
         // roots of the backward: d loss / d {feat, post, eos, logits}
@@ -1473,6 +1492,11 @@ struct s2st_engine {
               chk(s2st_ctc(ctc_logits->d, (const long*)bt.src_txt, bt.Ls, bt.ctc_in_lens, bt.src_txt_lens, B, E,
                            c.src_vocab, ctc_lp, ctc_per, dl, gs * c.ctc_weight / B, ctc_ws, st_));
           }
+        }
+        if (ctc_tgt_logits && ctc_tgt_dl) {
+          bool a;
+          float* dl = gradbuf(ctc_tgt_logits, a);
+          if (live()) chk(s2st_dropout(ctc_tgt_dl, dl, ctc_tgt_logits->n(), gs, 0.f, 0, 0, st_));  // dl = gs * d(ctc_tgt)
         }
         if (asr_logits) {
           bool a;

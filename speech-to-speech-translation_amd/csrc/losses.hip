@@ -252,7 +252,8 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
 __global__ void loss_finalize_kernel(float* __restrict__ stats, const float* __restrict__ ctc_per, int B,
                                      float nf, float nr, float w_l1, float w_mse, float w_eos,
                                      float w_ctc, float w_asr, float w_st, float eps, int Vs, int Vt,
-                                     float src_ntok, float tgt_ntok) {
+                                     float src_ntok, float tgt_ntok, const float* __restrict__ ctc_tgt_per,
+                                     float w_ctc_tgt) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   float l1 = w_l1 * stats[S2ST_STAT_L1_SUM] / nf;
   float mse = w_mse * stats[S2ST_STAT_MSE_SUM] / nf;
@@ -261,6 +262,11 @@ __global__ void loss_finalize_kernel(float* __restrict__ stats, const float* __r
   if (ctc_per) {
     for (int b = 0; b < B; ++b) ctc += ctc_per[b];
     ctc = w_ctc * ctc / (float)B;
+  }
+  float ctc_tgt = 0.f;  // second CTC head of the mtl variant (s2st_loss_mtl.py:171-186)
+  if (ctc_tgt_per) {
+    for (int b = 0; b < B; ++b) ctc_tgt += ctc_tgt_per[b];
+    ctc_tgt = w_ctc_tgt * ctc_tgt / (float)B;
   }
   float asr = 0.f, st = 0.f;
   if (w_asr > 0.f && src_ntok > 0.f) {
@@ -277,7 +283,8 @@ __global__ void loss_finalize_kernel(float* __restrict__ stats, const float* __r
   stats[S2ST_STAT_CTC] = ctc;
   stats[S2ST_STAT_ASR] = asr;
   stats[S2ST_STAT_ST] = st;
-  stats[S2ST_STAT_LOSS] = l1 + mse + eos + ctc + asr + st;
+  stats[S2ST_STAT_CTC_TGT] = ctc_tgt;
+  stats[S2ST_STAT_LOSS] = l1 + mse + eos + ctc + ctc_tgt + asr + st;
 }
 
 // (log-)softmax over the last dimension, one wave per row (models' get_normalized_probs: s2st_transformer.py:458-463,
@@ -347,9 +354,9 @@ int s2st_ctc(const float* logits, const long* targets, int Lmax, const int* in_l
 
 int s2st_loss_finalize(float* stats, const float* ctc_per, int B, float nf, float nr, float w_l1,
                        float w_mse, float w_eos, float w_ctc, float w_asr, float w_st, float eps, int Vs,
-                       int Vt, float src_ntok, float tgt_ntok, hipStream_t st) {
+                       int Vt, float src_ntok, float tgt_ntok, hipStream_t st, const float* ctc_tgt_per, float w_ctc_tgt) {
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, stats, ctc_per, B, nf, nr, w_l1, w_mse,
-                     w_eos, w_ctc, w_asr, w_st, eps, Vs, Vt, src_ntok, tgt_ntok);
+                     w_eos, w_ctc, w_asr, w_st, eps, Vs, Vt, src_ntok, tgt_ntok, ctc_tgt_per, w_ctc_tgt);
   return LAUNCH_OK();
 }
 

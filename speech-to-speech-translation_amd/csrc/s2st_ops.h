@@ -250,7 +250,8 @@ int s2st_ctc(const float* logits, const long* targets, int Lmax, const int* in_l
 int s2st_log_softmax_rows(const float* x, long ldx, float* y, long ldy, int rows, int V, int log_out, hipStream_t st);
 int s2st_loss_finalize(float* stats, const float* ctc_per, int B, float nf, float nr, float w_l1,
                        float w_mse, float w_eos, float w_ctc, float w_asr, float w_st, float eps, int Vs,
-                       int Vt, float src_ntok, float tgt_ntok, hipStream_t st);
+                       int Vt, float src_ntok, float tgt_ntok, hipStream_t st, const float* ctc_tgt_per = nullptr,
+                       float w_ctc_tgt = 0.f);
 
 // ---------------------------------------------------------------------------------------
 // optimizer (optim.hip)

@@ -1,1 +1,2 @@
 from .s2st_transformer import S2STTransformerModel, base_architecture  # noqa: F401
+from .s2st_transformer_mtl import S2STTransformerMTLModel, mtl_architecture  # noqa: F401

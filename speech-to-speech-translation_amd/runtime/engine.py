@@ -24,9 +24,9 @@ class ModelConfig(C.Structure):
         "dec_heads", "enc_pre_ln", "dec_pre_ln", "in_dim", "conv_channels", "conv_k", "out_dim",
         "prenet_layers", "prenet_dim", "postnet_layers", "postnet_dim", "postnet_k", "tap_asr",
         "tap_st", "has_asr", "has_st", "has_ctc", "asr_layers", "asr_dim", "st_layers", "st_dim",
-        "src_vocab", "tgt_vocab", "no_scale_embedding", "precise")] + [(n, C.c_float) for n in (
+        "src_vocab", "tgt_vocab", "no_scale_embedding", "precise", "tap_dec", "has_ctc_tgt")] + [(n, C.c_float) for n in (
         "dropout", "attn_dropout", "act_dropout", "prenet_dropout", "postnet_dropout", "ctc_weight",
-        "asr_weight", "st_weight", "w_l1", "w_mse", "w_eos", "bce_pos_weight", "label_smoothing")]
+        "asr_weight", "st_weight", "w_l1", "w_mse", "w_eos", "bce_pos_weight", "label_smoothing", "ctc_tgt_weight")]
 
 
 class ParamInfo(C.Structure):
@@ -57,7 +57,7 @@ class Outputs(C.Structure):
 
 STAT = dict(L1_SUM=0, MSE_SUM=1, BCE_SUM=2, ASR_NLL=3, ASR_SMOOTH=4, ASR_CORRECT=5, ASR_TOTAL=6,
             ST_NLL=7, ST_SMOOTH=8, ST_CORRECT=9, ST_TOTAL=10, LOSS=16, L1=17, MSE=18, EOS=19,
-            CTC=20, ASR=21, ST=22, GNORM=24)
+            CTC=20, ASR=21, ST=22, CTC_TGT=23, GNORM=24)
 
 
 def config_from_args(a, precise: bool = False) -> ModelConfig:
@@ -94,6 +94,12 @@ def config_from_args(a, precise: bool = False) -> ModelConfig:
     c.ctc_weight, c.asr_weight, c.st_weight = a.ctc_weight, a.asr_ce_weight, a.st_ce_weight
     c.w_l1, c.w_mse, c.w_eos = a.l1_loss_weight, a.mse_loss_weight, a.eos_loss_weight
     c.bce_pos_weight, c.label_smoothing = a.bce_pos_weight, a.label_smoothing
+    # s2st_transformer_mtl: target-text CTC head on the output of decoder layer --middle-layers-decoder
+    c.ctc_tgt_weight = float(getattr(a, "ctc_weight_tgt", 0.0) or 0.0)
+    c.has_ctc_tgt = int(c.ctc_tgt_weight > 0)
+    c.tap_dec = int(str(getattr(a, "middle_layers_decoder", "6")).split(",")[0]) if c.has_ctc_tgt else -1
+    if c.has_ctc_tgt and not (0 <= c.tap_dec < c.dec_layers):
+        raise ValueError("--middle-layers-decoder must name a decoder layer (the reference would index an empty list)")
     return c
 
 
@@ -286,15 +292,17 @@ class Engine:
             keep["src_txt_pos"] = token_pos(pt).contiguous().to(dev)
             b.prev_src_txt, b.src_txt_pos = keep["prev_src_txt"].data_ptr(), keep["src_txt_pos"].data_ptr()
             b.pe_asr = self.pe(self.cfg.asr_dim, Ls + 2).data_ptr()
-        if self.cfg.has_st and sample.get("tgt_text") is not None and ni.get("prev_tgt_text_tokens") is not None:
+        if (self.cfg.has_st or self.cfg.has_ctc_tgt) and sample.get("tgt_text") is not None:
             tt = sample["tgt_text"].cpu().long().contiguous()
             Lt = tt.shape[1]
-            pt = ni["prev_tgt_text_tokens"].cpu().long().contiguous()
-            keep["tgt_txt"], keep["prev_tgt_txt"] = tt.to(dev), pt.to(dev)
+            keep["tgt_txt"] = tt.to(dev)
             keep["tgt_txt_lens"] = sample["tgt_text_len"].to(torch.int32).to(dev)
+            b.tgt_txt, b.tgt_txt_lens = keep["tgt_txt"].data_ptr(), keep["tgt_txt_lens"].data_ptr()
+        if self.cfg.has_st and sample.get("tgt_text") is not None and ni.get("prev_tgt_text_tokens") is not None:
+            pt = ni["prev_tgt_text_tokens"].cpu().long().contiguous()
+            keep["prev_tgt_txt"] = pt.to(dev)
             keep["tgt_txt_pos"] = token_pos(pt).contiguous().to(dev)
-            b.tgt_txt, b.prev_tgt_txt = keep["tgt_txt"].data_ptr(), keep["prev_tgt_txt"].data_ptr()
-            b.tgt_txt_lens, b.tgt_txt_pos = keep["tgt_txt_lens"].data_ptr(), keep["tgt_txt_pos"].data_ptr()
+            b.prev_tgt_txt, b.tgt_txt_pos = keep["prev_tgt_txt"].data_ptr(), keep["tgt_txt_pos"].data_ptr()
             b.pe_st = self.pe(self.cfg.st_dim, Lt + 2).data_ptr()
         b.Ls, b.Lt = Ls, Lt
         b.ntokens = int(sample["ntokens"])

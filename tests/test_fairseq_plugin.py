@@ -34,7 +34,9 @@ out = dict(
     task=t.__module__, model=m.__module__, criterion=c.__module__,
     arch=ARCH_MODEL_REGISTRY["s2st_transformer"].__module__, arch_fn=ARCH_CONFIG_REGISTRY["s2st_transformer"].__module__,
     bases=[issubclass(t, LegacyFairseqTask), issubclass(m, BaseFairseqModel), issubclass(c, FairseqCriterion)],
-    registered=pkg.registry.FAIRSEQ_REGISTERED)
+    registered=pkg.registry.FAIRSEQ_REGISTERED,
+    mtl=[TASK_REGISTRY["s2s_translation_mtl"].__module__, MODEL_REGISTRY["s2st_transformer_mtl"].__module__,
+         CRITERION_REGISTRY["s2st_loss_mtl"].__module__])
 # the architecture function fills the reference's defaults on a bare namespace
 a = argparse.Namespace()
 ARCH_CONFIG_REGISTRY["s2st_transformer"](a)
@@ -57,8 +59,12 @@ def test_names_resolve_through_fairseq_registries():
     assert out["model"] == out["arch"] == out["arch_fn"] == pkg + ".models.s2st_transformer"
     assert out["criterion"] == pkg + ".criterions.s2st_loss"
     assert out["bases"] == [True, True, True]
-    assert out["registered"] == {"task": ["s2s_translation"], "model": ["s2st_transformer"], "arch": ["s2st_transformer"],
-                                 "criterion": ["s2st_loss"]}
+    assert out["registered"] == {"task": ["s2s_translation", "s2s_translation_mtl"],
+                                 "model": ["s2st_transformer", "s2st_transformer_mtl"],
+                                 "arch": ["s2st_transformer", "s2st_transformer_mtl"],
+                                 "criterion": ["s2st_loss", "s2st_loss_mtl"]}
+    assert out["mtl"] == [pkg + ".tasks.s2s_translation_mtl", pkg + ".models.s2st_transformer_mtl",
+                          pkg + ".criterions.s2st_loss_mtl"]
     assert out["arch_defaults"] == [12, 6, 512, 256]  # base_architecture, s2st_transformer.py:792-830
     for flag in ("--middle-layers", "--asr-decoder-embed-dim", "--prenet-dropout", "--load-pretrained-hubert-from",
                  "--n-frames-per-step", "--use-hubert", "--eval-inference"):
