@@ -67,10 +67,12 @@ def gsub(x):
 
 
 def BF16_TENSOR_TOL(name):
-    """bf16-operand mode, base size, per-tensor Frobenius-relative gradient error against the reference: 5e-2 for
-    every tensor except the two prenet layers at the very end of the longest backward path (decoder stack -> prenet),
-    where the operand rounding has accumulated to 6.3e-2 (measured; bf16x3 mode: 4e-3 everywhere)."""
-    return 8e-2 if name.startswith("decoder.prenet.0.layers.") else 5e-2
+    """bf16-operand mode, base size, per-tensor Frobenius-relative gradient error against the reference.  Measured on
+    the 8-utterance base golden: 4.9e-2 for the worst tensor (first decoder layer's cross-attention projections, first
+    encoder layer's fc1) and 6.3e-2 for the first prenet layer at the very end of the longest backward path (decoder
+    stack -> prenet); bf16x3 mode: 4.3e-3 everywhere.  The bounds leave ~20 % head-room over the measured values (the
+    bias-gradient sums use atomics: a few 1e-3 of run-to-run spread on the small tensors)."""
+    return 8e-2 if name.startswith("decoder.prenet.0.layers.") else 6e-2
 
 
 def check_gradient_direction(named_grads, z, per_tensor_tol, whole_tol, tag=""):
