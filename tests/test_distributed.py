@@ -177,7 +177,10 @@ def test_two_ranks_in_bf16_mode_equal_one_process_accumulating_both_batches():
         if noise_driven(n):
             continue
         ref = p.detach().cpu()
-        assert float((torch.from_numpy(params[n]) - ref).abs().max()) < 2e-5, n
+        # three Adam updates of <= lr = 1e-3 each: a lost or doubled rank contribution moves parameters by O(1e-3);
+        # fp32 summation order moves sign-sensitive entries (|g| ~ noise) by up to ~1e-4 through Adam's normalisation
+        assert float((torch.from_numpy(params[n]) - ref).abs().max()) < 2e-4, n
+        assert float((torch.from_numpy(params[n]) - ref).abs().mean()) < 2e-6, n
 
 
 @pytest.mark.gpu
