@@ -229,9 +229,14 @@ typedef struct {
   /* s2st_transformer_mtl (examples/s2s_trans/models/s2st_transformer_mtl.py:223-386): a second CTC head, over the TARGET
    * text, on the raw output of decoder layer tap_dec (--middle-layers-decoder); -1 / 0: none */
   int32_t tap_dec, has_ctc_tgt;
+  /* t2s_transformer (examples/s2s_trans/models/t2s_transformer.py:37-126): a TEXT encoder front in place of the speech
+   * subsampler -- token embedding, enc_conv_layers x (Conv1d k=enc_conv_k + BatchNorm1d + ReLU + dropout), a linear
+   * projection, alpha-scaled positions; the batch's src_txt / src_txt_lens are then the encoder input (S = E = Ls) */
+  int32_t text_input, enc_conv_layers, enc_conv_k;
   float dropout, attn_dropout, act_dropout, prenet_dropout, postnet_dropout;
   float ctc_weight, asr_weight, st_weight, w_l1, w_mse, w_eos, bce_pos_weight, label_smoothing;
   float ctc_tgt_weight;                   /* s2st_loss_mtl.py:171-185 */
+  float enc_dropout;                      /* t2s encoder prenet dropout (nn.Dropout: training only) */
 } s2st_model_config;
 
 typedef struct {

@@ -64,7 +64,12 @@ HUBERT_RECIPE = dict(BASE_RECIPE, use_hubert="true", hubert_hidden=768, ctc_weig
 TINY_MTL = dict(TINY, asr_ce_weight=0.0, st_ce_weight=0.0, middle_layers="0", middle_layers_decoder="0",
                 ctc_weight=0.3, ctc_weight_tgt=0.2)
 
-CONFIGS = {"tiny_mtl": TINY_MTL, "tiny": TINY, "tiny_postln": TINY_POSTLN, "base": BASE_PARITY,
+# t2s_transformer (tiny geometry): text encoder front (3 x conv k5 + BatchNorm + ReLU), post-LN encoder, no CTC / aux
+TINY_T2S = dict(TINY, asr_ce_weight=0.0, st_ce_weight=0.0, ctc_weight=0.0, text_encoder=True, encoder_conv_layers=3,
+                encoder_conv_kernel_size=5, encoder_dropout=0.0, encoder_normalize_before=False,
+                decoder_normalize_before=False)
+
+CONFIGS = {"tiny_t2s": TINY_T2S, "tiny_mtl": TINY_MTL, "tiny": TINY, "tiny_postln": TINY_POSTLN, "base": BASE_PARITY,
            "base_recipe": BASE_RECIPE, "hubert_train": HUBERT_TRAIN, "base_recipe_hubert": HUBERT_RECIPE}
 
 

@@ -383,6 +383,44 @@ class S2STEncoder(nn.Module):
                 "encoder_lens": lens}
 
 
+class T2SEncoder(nn.Module):
+    """T2STransformerEncoder (examples/s2s_trans/models/t2s_transformer.py:37-126): text input."""
+
+    def __init__(self, a):
+        super().__init__()
+        self.a = a
+        C = a.encoder_embed_dim
+        self.embed_tokens = nn.Embedding(a.src_vocab_size, C, padding_idx=PAD)
+        k = a.encoder_conv_kernel_size
+        self.prenet = nn.ModuleList(
+            nn.Sequential(nn.Conv1d(C, C, kernel_size=k, padding=(k - 1) // 2), nn.BatchNorm1d(C), nn.ReLU(),
+                          nn.Dropout(a.encoder_dropout))
+            for _ in range(a.encoder_conv_layers))
+        self.prenet_proj = nn.Linear(C, C)
+        self.pos_emb_alpha = nn.Parameter(torch.ones(1))
+        self.transformer_layers = nn.ModuleList(
+            TransformerEncoderLayer(C, a.encoder_attention_heads, a.encoder_ffn_embed_dim, a.encoder_normalize_before,
+                                    a.dropout, a.attention_dropout, a.activation_dropout)
+            for _ in range(a.encoder_transformer_layers))
+        self.layer_norm = nn.LayerNorm(C) if a.encoder_normalize_before else None
+        self.embed_positions = _PositionalEmbeddingState()
+
+    def forward(self, src_tokens, src_lens):
+        x = self.embed_tokens(src_tokens).transpose(1, 2).contiguous()
+        for conv in self.prenet:
+            x = conv(x)
+        x = self.prenet_proj(x.transpose(1, 2).contiguous())
+        pad = src_tokens.eq(PAD)
+        x = x + self.pos_emb_alpha * positional_embedding(pad, x.shape[-1])
+        x = F.dropout(x, self.a.dropout, self.training).transpose(0, 1)
+        for layer in self.transformer_layers:
+            x = layer(x, pad)
+        if self.layer_norm is not None:
+            x = self.layer_norm(x)
+        return {"encoder_out": x, "encoder_padding_mask": pad, "out_middle_layers": [],
+                "encoder_lens": (~pad).long().sum(1)}
+
+
 class S2STDecoder(nn.Module):
     """S2STTransformerDecoder (s2st_transformer.py:319-477), teacher-forced path."""
 
@@ -498,7 +536,7 @@ class S2STModel(nn.Module):
     def __init__(self, a):
         super().__init__()
         self.a = a
-        self.encoder = S2STEncoder(a)
+        self.encoder = T2SEncoder(a) if getattr(a, "text_encoder", False) else S2STEncoder(a)
         self.decoder = S2STDecoder(a)
         # reference mutates args.decoder_embed_dim while building the aux decoders
         # (:492-493, :541-542): the ASR embedding is built at the main decoder dim, the ST
@@ -623,8 +661,10 @@ def criterion_forward(model: S2STModel, sample: Dict, a=None):
     tl = sample["target_lengths"]
     eos_tgt = (torch.arange(D).view(1, D).expand(B, -1) == (tl.view(B, 1) - 1)).float()
     ni = sample["net_input"]
+    text_in = getattr(a, "text_encoder", False)  # t2s_loss.py:110-121: src_tokens = src_text
     (post, eos, extra), asr, st, enc = model(
-        ni["src_speech"], ni["src_speech_lens"], ni["prev_output_tokens"], tl,
+        sample["src_text"] if text_in else ni["src_speech"],
+        sample["src_text_len"] if text_in else ni["src_speech_lens"], ni["prev_output_tokens"], tl,
         ni.get("prev_src_text_tokens") if a.asr_ce_weight > 0 else None,
         ni.get("prev_tgt_text_tokens") if a.st_ce_weight > 0 else None)
     mask = ~lengths_to_padding_mask(tl, D)

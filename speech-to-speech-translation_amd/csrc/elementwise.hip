@@ -469,7 +469,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
   if (i >= n) return;
   int r = (int)(i / C), c = (int)(i - (long)r * C);
   float u = gamma[c] * (x[i] - mean[c]) * rsqrtf(var[c] + eps) + beta[c];
-  if (tanh_) u = tanhf(u);
+  if (tanh_ == 1) u = tanhf(u);
+  else if (tanh_ == 2) u = fmaxf(u, 0.f);  // ReLU (t2s encoder prenet)
   if (drop_p > 0.f) u *= drop_scale(seed, (uint64_t)i, drop_p, 1.f / (1.f - drop_p));
   if (resid) u += resid[i];
   y[split_off(ysp, r) + c] = u;
@@ -484,9 +485,11 @@ struct BnBwdF {
     float xh = (x[i] - mean[c]) * rsqrtf(var[c] + eps);
     float g = dy[split_off(dysp, r) + c];
     if (drop_p > 0.f) g *= drop_scale(seed, (uint64_t)i, drop_p, 1.f / (1.f - drop_p));
-    if (tanh_) {
+    if (tanh_ == 1) {
       float t = tanhf(gamma[c] * xh + beta[c]);
       g *= (1.f - t * t);
+    } else if (tanh_ == 2) {
+      g = (gamma[c] * xh + beta[c]) > 0.f ? g : 0.f;
     }
     return make_float2(g, g * xh);
   }

@@ -310,15 +310,38 @@ struct s2st_engine {
     return a;
   }
 
+  // t2s text encoder front
+  long enc_embed = -1, enc_pos_alpha = -1;
+  std::vector<ConvP> enc_conv;
+  std::vector<BNP> enc_bn;
+  LinP enc_prenet_proj;
+
   void build_params() {
     const int C = c.enc_dim, Cd = c.dec_dim;
     // forward-use order == arena order (see file header)
+    if (c.text_input) {
+      enc_embed = add("encoder.embed_tokens.weight", {c.src_vocab, C});
+      for (int i = 0; i < c.enc_conv_layers; ++i) {
+        std::string pre = "encoder.prenet." + std::to_string(i);
+        enc_conv.push_back(ConvP{add(pre + ".0.weight", {C, C, c.enc_conv_k}), add(pre + ".0.bias", {C}), C, C, c.enc_conv_k});
+        BNP bn;
+        bn.C = C;
+        bn.g = add(pre + ".1.weight", {C});
+        bn.b = add(pre + ".1.bias", {C});
+        bn.rm = add(pre + ".1.running_mean", {C}, 1);
+        bn.rv = add(pre + ".1.running_var", {C}, 1);
+        enc_bn.push_back(bn);
+      }
+      enc_prenet_proj = add_lin("encoder.prenet_proj", C, C);
+      enc_pos_alpha = add("encoder.pos_emb_alpha", {1});
+    } else {
     sub[0] = ConvP{add("encoder.subsample.conv_layers.0.weight", {c.conv_channels, c.in_dim, c.conv_k}),
                    add("encoder.subsample.conv_layers.0.bias", {c.conv_channels}), c.conv_channels,
                    c.in_dim, c.conv_k};
     sub[1] = ConvP{add("encoder.subsample.conv_layers.1.weight", {2 * C, c.conv_channels / 2, c.conv_k}),
                    add("encoder.subsample.conv_layers.1.bias", {2 * C}), 2 * C, c.conv_channels / 2,
                    c.conv_k};
+    }
     for (int i = 0; i < c.enc_layers; ++i) {
       std::string pre = "encoder.transformer_layers." + std::to_string(i);
       EncLayerP l;
@@ -1132,6 +1155,69 @@ struct s2st_engine {
     return post;
   }
 
+  // t2s encoder prenet: n x (conv k -> BatchNorm -> ReLU -> dropout) over [B][T][C] (t2s_transformer.py:55-66, 86-90).
+  // Training: batch statistics over ALL B*T positions (padded ones included: their embedding is the zero row, their
+  // conv output the bias + neighbours); eval: running statistics.
+  Ten* text_prenet(Ten* emb, int B, int T, bool tr, std::vector<ConvW>& csp) {
+    const bool fm = fast();
+    const int C = c.enc_dim, pp = c.enc_conv_k / 2;
+    Ten* cur = emb;
+    float* curh = alloc((long)B * (T + 2 * pp) * C, true);
+    if (live()) {
+      Split xs{(long)C, 0, 0, 0};
+      Split ys{(long)C, (long)(T + 2 * pp) * C, T, 0};
+      chk(s2st_copy_rows(emb->d, xs, curh + (long)pp * C, ys, B * T, C, st_));
+    }
+    float* bn_tmp = alloc(S2ST_BN_TMP_FLOATS(C));
+    const int n = (int)enc_conv.size();
+    for (int i = 0; i < n; ++i) {
+      const ConvP& pc = enc_conv[i];
+      const BNP& bn = enc_bn[i];
+      const bool last = i == n - 1;
+      const bf16raw* curhh = fm ? cast_buf(curh, (long)B * (T + 2 * pp) * C) : nullptr;
+      Ten* z = conv(ConvIn{curh, cur, T, curhh}, pc, B, 1, csp[i]);
+      float* mean = alloc(C);
+      float* var = alloc(C);
+      touch(bn.b + C);
+      const float pdrop = tr ? c.enc_dropout : 0.f;
+      const uint64_t sd = pdrop > 0.f ? next_seed() : 0;
+      float* nexth = nullptr;
+      Ten* out;
+      Split osp;
+      if (last) {
+        out = newT(B * T, C);
+        osp = Split{(long)C, 0, 0, 0};
+      } else {
+        nexth = alloc((long)B * (T + 2 * pp) * C, true);
+        out = newT(B * T, C, nexth + (long)pp * C);
+        osp = Split{(long)C, (long)(T + 2 * pp) * C, T, 0};
+      }
+      if (live()) {
+        const float *m = BUF + bn.rm, *v = BUF + bn.rv;
+        if (tr) {
+          chk(s2st_bn_stats(z->d, B * T, C, mean, var, BUF + bn.rm, BUF + bn.rv, 0.1f, bn_tmp, st_));
+          m = mean; v = var;
+        }
+        chk(s2st_bn_apply(z->d, m, v, P + bn.g, P + bn.b, out->d, osp, nullptr, B * T, C, 1e-5f, 2 /* ReLU */, pdrop, sd, st_));
+      }
+      BNP bnp = bn;
+      tape.push_back([=]() {
+        if (!out->g) return;
+        bool acc;
+        float* dz = gradbuf(z, acc);
+        (void)acc;
+        Split ps{(long)bnp.C, 0, 0, 0};
+        if (fast() && !z->gh) z->gh = alloc_h((long)z->rows * z->hld());
+        if (live())
+          chk(s2st_bn_bwd(out->g, ps, z->d, mean, var, P + bnp.g, P + bnp.b, dz, ps, G + bnp.g, G + bnp.b, bn_tmp, B * T,
+                          bnp.C, 1e-5f, 2, pdrop, sd, st_, z->gh, z->hld()));
+      });
+      cur = out;
+      curh = nexth;
+    }
+    return cur;
+  }
+
   // ------------------------------------------------------------------------------------
   // HuBERT (fairseq/models/hubert/hubert.py:412-461, 518-534; wav2vec2.py:736-905): parameters in
   // GEMM-ready layouts (conv weights [O][k][I], the weight-normed pos_conv as its effective weight
@@ -1265,9 +1351,10 @@ struct s2st_engine {
   int forward() {
     const int B = bt.B, S = bt.S, D = bt.D, C = c.enc_dim, Cd = c.dec_dim;
     const int pad = c.conv_k / 2;
-    const int T1 = (S + 2 * pad - c.conv_k) / 2 + 1;
-    const int T2 = (T1 + 2 * pad - c.conv_k) / 2 + 1;
+    const int T1 = c.text_input ? S : (S + 2 * pad - c.conv_k) / 2 + 1;
+    const int T2 = c.text_input ? S : (T1 + 2 * pad - c.conv_k) / 2 + 1;
     if (T2 != bt.E) return S2ST_ERR_SHAPE;
+    if (c.text_input && (!bt.src_txt || bt.Ls != S)) return S2ST_ERR_ARG;  // tokens are the encoder input
     const int E = T2;
     const bool tr = bt.training != 0;
     const bool with_loss = bt.tgt != nullptr;
@@ -1302,7 +1389,14 @@ struct s2st_engine {
     skws_side = fm && side_ ? alloc(skws_n) : skws;
     typedef ConvW ConvScratch;
     auto conv_scratch = [&](const ConvP& p, bool need_wd) { return make_conv_scratch(p, need_wd, tr); };
-    ConvScratch cs0 = conv_scratch(sub[0], false), cs1 = conv_scratch(sub[1], true);
+    ConvScratch cs0{}, cs1{};
+    std::vector<ConvScratch> cst;  // t2s encoder prenet
+    if (c.text_input) {
+      for (auto& pc : enc_conv) cst.push_back(conv_scratch(pc, true));
+    } else {
+      cs0 = conv_scratch(sub[0], false);
+      cs1 = conv_scratch(sub[1], true);
+    }
     std::vector<ConvScratch> csp;
     {
       // the post-net's weight layouts are first needed at the end of the forward: prepared on the second stream
@@ -1316,6 +1410,22 @@ struct s2st_engine {
     }
 
     mark();
+    Ten* x = nullptr;
+    if (c.text_input) {
+      // ---- t2s text front (t2s_transformer.py:85-100): embedding -> conv/BatchNorm/ReLU prenet -> projection ->
+      //      x += alpha * positions -> dropout ------------------------------------------------------------------
+      Ten* emb = newT(B * E, C);
+      touch(enc_embed + (long)c.src_vocab * C);
+      if (live()) chk(s2st_embed_fwd((const long*)bt.src_txt, P + enc_embed, emb->d, B * E, C, 1.f, st_));
+      const long eoff = enc_embed;
+      tape.push_back([=]() {
+        if (!emb->g) return;
+        if (live()) chk(s2st_embed_bwd((const long*)bt.src_txt, emb->g, G + eoff, B * E, C, 1.f, 1, st_));
+      });
+      Ten* pn = text_prenet(emb, B, E, tr, cst);
+      Ten* pj = linear(pn, enc_prenet_proj.w, enc_prenet_proj.b, C, C);
+      x = add_pe(pj, bt.enc_pos, pe_enc, 1.f, enc_pos_alpha, tr ? c.dropout : 0.f);
+    } else {
     // ---- encoder front: 2 x (conv k s2 -> GLU), sqrt(C) scale + positions + dropout -------------
     float* xh0 = alloc((long)B * (S + 2 * pad) * c.in_dim, true);
     if (live()) {
@@ -1332,8 +1442,9 @@ struct s2st_engine {
     Ten* z2 = conv(ConvIn{g1h, g1, T1, g1hh}, sub[1], B, 2, cs1);
     float* x0d = alloc((long)B * E * C);
     Ten* x0 = glu_to(z2, x0d, Split{(long)C, 0, 0, 0}, C);
-    Ten* x = add_pe(x0, bt.enc_pos, pe_enc, c.no_scale_embedding ? 1.f : sqrtf((float)C), -1,
+    x = add_pe(x0, bt.enc_pos, pe_enc, c.no_scale_embedding ? 1.f : sqrtf((float)C), -1,
                     tr ? c.dropout : 0.f);
+    }
     mark();
     // ---- encoder layers, taps -----------------------------------------------------------------
     Ten *tap_asr = nullptr, *tap_st = nullptr;
@@ -1344,6 +1455,8 @@ struct s2st_engine {
       if (i % 3 == 2) mark();
     }
     Ten* enc_out = has_enc_ln ? layernorm(x, enc_ln, outs.enc_out) : x;
+    if (!has_enc_ln && outs.enc_out && live())  // post-LN encoder (t2s default): the last layer's output is the result
+      hipMemcpyAsync(outs.enc_out, x->d, sizeof(float) * (size_t)x->n(), hipMemcpyDeviceToDevice, st_);
     if (c.has_asr && tap_asr) tap_asr = layernorm(tap_asr, asr_norm, outs.tap0);
     if (c.has_st && tap_st) tap_st = layernorm(tap_st, st_norm, outs.tap1);
     // the CTC head and the aux text decoders only need the encoder taps: they are issued (below, in tape

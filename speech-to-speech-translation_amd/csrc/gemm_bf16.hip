@@ -785,7 +785,10 @@ int launch_persistent(const GemmGroup& grp, hipStream_t st) {
   constexpr int LDS = NS * (BM + BN) * 128;
   double fl = 0, by = 0;
   for (int i = 0; i < grp.n; ++i) { fl += gemm_flops(grp.g[i]); by += gemm_min_bytes(grp.g[i]); }
-  const int grid = grp.total < 1 ? 1 : (grp.total < num_cus() ? grp.total : num_cus());  // (preload: no tiles)
+  // S2ST_GROUP_WGS=<n> (tuning aid): cap for grouped launches, which share the chip with the data-path stream
+  static const int group_cap = getenv("S2ST_GROUP_WGS") ? atoi(getenv("S2ST_GROUP_WGS")) : 0;
+  const int cap = (grp.n > 1 && group_cap > 0) ? group_cap : num_cus();
+  const int grid = grp.total < 1 ? 1 : (grp.total < cap ? grp.total : cap);  // (preload: no tiles)
   auto go = [&](auto kern, const char* tag) {
     static bool configured = false;
     if (!configured) {

@@ -138,6 +138,10 @@ class S2STTransformerModel(ModelBase):  # fairseq's BaseFairseqModel when fairse
         for i in range(args.postnet_layers):
             _register(self, f"decoder.postnet.convolutions.{i}.1.num_batches_tracked",
                       torch.zeros((), dtype=torch.long, device=device), True)
+        if getattr(args, "text_encoder", False):  # t2s_transformer: BatchNorm counters of the encoder prenet
+            for i in range(args.encoder_conv_layers):
+                _register(self, f"encoder.prenet.{i}.1.num_batches_tracked",
+                          torch.zeros((), dtype=torch.long, device=device), True)
         self._num_updates = 0
         self.reset_parameters()
 
@@ -156,6 +160,9 @@ class S2STTransformerModel(ModelBase):  # fairseq's BaseFairseqModel when fairse
                     fan_in = self._fan_in(name)
                     bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
                     p.uniform_(-bound, bound)  # nn.Linear / nn.Conv1d default
+            elif name == "encoder.embed_tokens.weight":  # t2s: plain nn.Embedding(padding_idx) (t2s_transformer.py:52-53)
+                nn.init.normal_(p, mean=0, std=1.0)
+                p[1].zero_()
             elif "embed_tokens" in name:
                 nn.init.normal_(p, mean=0, std=p.shape[1] ** -0.5)
                 p[1].zero_()  # padding_idx
@@ -167,6 +174,8 @@ class S2STTransformerModel(ModelBase):  # fairseq's BaseFairseqModel when fairse
                 nn.init.xavier_uniform_(p)
             elif p.dim() == 3 and name.startswith("decoder."):
                 nn.init.xavier_uniform_(p, nn.init.calculate_gain("tanh"))  # decoder_init (:314-316)
+            elif p.dim() == 3 and name.startswith("encoder.prenet."):
+                nn.init.xavier_uniform_(p, nn.init.calculate_gain("relu"))  # encoder_init (t2s_transformer.py:32-34)
             else:
                 nn.init.kaiming_uniform_(p, a=math.sqrt(5))  # nn.Linear / nn.Conv1d default
         for name, b in self.named_buffers():

@@ -24,9 +24,9 @@ class ModelConfig(C.Structure):
         "dec_heads", "enc_pre_ln", "dec_pre_ln", "in_dim", "conv_channels", "conv_k", "out_dim",
         "prenet_layers", "prenet_dim", "postnet_layers", "postnet_dim", "postnet_k", "tap_asr",
         "tap_st", "has_asr", "has_st", "has_ctc", "asr_layers", "asr_dim", "st_layers", "st_dim",
-        "src_vocab", "tgt_vocab", "no_scale_embedding", "precise", "tap_dec", "has_ctc_tgt")] + [(n, C.c_float) for n in (
+        "src_vocab", "tgt_vocab", "no_scale_embedding", "precise", "tap_dec", "has_ctc_tgt", "text_input", "enc_conv_layers", "enc_conv_k")] + [(n, C.c_float) for n in (
         "dropout", "attn_dropout", "act_dropout", "prenet_dropout", "postnet_dropout", "ctc_weight",
-        "asr_weight", "st_weight", "w_l1", "w_mse", "w_eos", "bce_pos_weight", "label_smoothing", "ctc_tgt_weight")]
+        "asr_weight", "st_weight", "w_l1", "w_mse", "w_eos", "bce_pos_weight", "label_smoothing", "ctc_tgt_weight", "enc_dropout")]
 
 
 class ParamInfo(C.Structure):
@@ -98,6 +98,13 @@ def config_from_args(a, precise: bool = False) -> ModelConfig:
     c.ctc_tgt_weight = float(getattr(a, "ctc_weight_tgt", 0.0) or 0.0)
     c.has_ctc_tgt = int(c.ctc_tgt_weight > 0)
     c.tap_dec = int(str(getattr(a, "middle_layers_decoder", "6")).split(",")[0]) if c.has_ctc_tgt else -1
+    # t2s_transformer: text encoder front (t2s_transformer.py:37-126)
+    c.text_input = int(bool(getattr(a, "text_encoder", False)))
+    c.enc_conv_layers = int(getattr(a, "encoder_conv_layers", 3) or 0) if c.text_input else 0
+    c.enc_conv_k = int(getattr(a, "encoder_conv_kernel_size", 5) or 5)
+    c.enc_dropout = float(getattr(a, "encoder_dropout", 0.5) or 0.0) if c.text_input else 0.0
+    if c.text_input and (c.has_asr or c.has_st or c.has_ctc or c.has_ctc_tgt or c.enc_conv_k % 2 != 1):
+        raise ValueError("t2s_transformer: no aux heads / CTC heads; --encoder-conv-kernel-size must be odd")
     if c.has_ctc_tgt and not (0 <= c.tap_dec < c.dec_layers):
         raise ValueError("--middle-layers-decoder must name a decoder layer (the reference would index an empty list)")
     return c
@@ -227,6 +234,8 @@ class Engine:
                 with_loss: bool = True, seed: Optional[int] = None):
         a, dev = self.args, self.device
         ni = sample["net_input"]
+        if self.cfg.text_input:
+            return self._prepare_text(sample, training, want_attn, with_loss, seed)
         src = ni["src_speech"].to(dev, torch.float32).contiguous()
         B, S, _ = src.shape
         src_lens = ni["src_speech_lens"].cpu().long()
@@ -308,6 +317,45 @@ class Engine:
         b.ntokens = int(sample["ntokens"])
         b.src_txt_ntokens = int(sample.get("src_txt_ntokens", 0))
         b.tgt_txt_ntokens = int(sample.get("tgt_txt_ntokens", 0))
+        b.training, b.want_attn = int(training), int(want_attn)
+        if seed is None:
+            seed = self.step_seed
+            self.step_seed += 1
+        b.seed = seed
+        return b, keep
+
+    def _prepare_text(self, sample, training, want_attn, with_loss, seed):
+        """t2s_transformer: the encoder reads token ids -- ``sample["src_text"]`` / ``["src_text_len"]``, what the
+        reference's t2s criterion passes as ``src_tokens`` / ``src_lengths`` (criterions/t2s_loss.py:110-121)."""
+        dev = self.device
+        ni = sample["net_input"]
+        tok = sample["src_text"].cpu().long().contiguous()
+        B, S = tok.shape
+        lens = sample["src_text_len"].cpu().long()
+        t = torch.arange(S).unsqueeze(0)
+        pos = torch.where(t < lens.unsqueeze(1), t + PAD + 1, torch.full_like(t, PAD)).to(torch.int32)
+        # (positions from the PAD mask of the tokens themselves, t2s_transformer.py:93-95: right-padded batches)
+        prev = ni["prev_output_tokens"].to(dev, torch.float32).contiguous()
+        D = prev.shape[1]
+        tgt_lens = sample["target_lengths"].cpu().long()
+        td = torch.arange(D).unsqueeze(0)
+        dpos = torch.where(td < tgt_lens.unsqueeze(1), td + PAD + 1, torch.full_like(td, PAD)).to(torch.int32)
+        keep = {"prev": prev, "src_txt": tok.to(dev), "src_txt_lens": lens.to(torch.int32).to(dev),
+                "enc_lens": lens.to(torch.int32).to(dev), "enc_pos": pos.contiguous().to(dev),
+                "tgt_lens": tgt_lens.to(torch.int32).to(dev), "dec_pos": dpos.contiguous().to(dev)}
+        b = Batch()
+        b.B, b.S, b.D, b.E, b.Ls, b.Lt = B, S, D, S, S, 0
+        b.prev = prev.data_ptr()
+        b.src_txt, b.src_txt_lens = keep["src_txt"].data_ptr(), keep["src_txt_lens"].data_ptr()
+        b.enc_lens, b.enc_pos = keep["enc_lens"].data_ptr(), keep["enc_pos"].data_ptr()
+        b.ctc_in_lens = keep["enc_lens"].data_ptr()
+        b.tgt_lens, b.dec_pos = keep["tgt_lens"].data_ptr(), keep["dec_pos"].data_ptr()
+        b.pe_enc = self.pe(self.cfg.enc_dim, S + 2).data_ptr()
+        b.pe_dec = self.pe(self.cfg.dec_dim, D + 2).data_ptr()
+        if with_loss:
+            keep["tgt"] = sample["tgt_speech"].to(dev, torch.float32).contiguous()
+            b.tgt = keep["tgt"].data_ptr()
+        b.ntokens = int(sample["ntokens"])
         b.training, b.want_attn = int(training), int(want_attn)
         if seed is None:
             seed = self.step_seed

@@ -38,6 +38,7 @@ class S2ST_TranslationTask(TaskBase):  # fairseq's LegacyFairseqTask when fairse
         a("--eos-prob-threshold", type=float, default=0.5)
         a("--eval-inference", action="store_true")
         a("--use-hubert", type=str, default="false")
+        a("--input-text", type=str, default="false", help="text-to-speech mode (t2s_transformer): the encoder reads src_text")
         a("--src-vocab-size", type=int, default=44)
         a("--tgt-vocab-size", type=int, default=74)
 
@@ -120,7 +121,9 @@ class S2ST_TranslationTask(TaskBase):  # fairseq's LegacyFairseqTask when fairse
         """s2s_translation.py:174-184: the model, and with --eval-inference the generator validation uses."""
         from .. import models  # noqa: F401  (registers the architecture)
         args.n_frames_per_step = self.args.n_frames_per_step
-        model = MODELS["s2st_transformer"].build_model(args, self)
+        from ..registry import ARCHS
+        arch = getattr(args, "arch", None) or "s2st_transformer"  # --arch picks the registered model, as in fairseq
+        model = MODELS[ARCHS[arch][0] if arch in ARCHS else "s2st_transformer"].build_model(args, self)
         self.generator = None
         if getattr(args, "eval_inference", False):
             self.generator = self.build_generator_tts([model], args)
@@ -179,7 +182,8 @@ class S2ST_TranslationTask(TaskBase):  # fairseq's LegacyFairseqTask when fairse
 
     def build_criterion(self, args):
         from .. import criterions  # noqa: F401
-        return CRITERIA["s2st_loss"].build_criterion(args, self)
+        name = getattr(args, "criterion", None) or "s2st_loss"
+        return CRITERIA[name if name in CRITERIA else "s2st_loss"].build_criterion(args, self)
 
     def train_step(self, sample, model, criterion, optimizer, update_num, ignore_grad=False):
         """fairseq/tasks/fairseq_task.py:465-497."""
