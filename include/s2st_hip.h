@@ -85,6 +85,13 @@ typedef struct {
  * examples/s2s_trans/models/s2st_transformer.py:135-139,452-455, tacotron2.py:95-126. */
 int s2st_gemm_f32(const s2st_gemm_args* args, void* stream);
 
+/* Stream-K for the bf16 products launched on `stream` (s2st_gemm_f32 / s2st_gemm_group_f32): with a scratch buffer of
+ * s2st_gemm_streamk_scratch_floats() floats bound to the stream (first 4 KiB zero at bind time; NULL unbinds), launches
+ * whose 128 x 128 tiles do not fill whole rounds of CUs share the K-steps of all tiles evenly between one workgroup per
+ * CU; partial accumulators meet in the scratch.  Results equal the unsplit launch up to fp32 summation order. */
+int64_t s2st_gemm_streamk_scratch_floats(void);
+int s2st_gemm_streamk_scratch(float* scratch, int64_t floats, void* stream);
+
 /* Up to 8 bf16-operand products (same operand layouts, batch 1, M, N >= 128, 16-byte aligned operands) in ONE persistent
  * launch: a layer's weight-gradient GEMMs dW = dY^T X (torch.mm calls inside autograd's backward of every F.linear,
  * fairseq/modules/transformer_layer.py:140-162) with K = tokens unsplit.  S2ST_ERR_SHAPE if a problem does not qualify. */

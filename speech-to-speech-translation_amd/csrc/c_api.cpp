@@ -225,6 +225,12 @@ int s2st_gemm_group_f32(const s2st_gemm_args* list, int32_t n, void* stream) {
 int s2st_log_softmax_rows_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int32_t rows, int32_t V, int32_t log_out, void* stream) {
   return s2st_log_softmax_rows(x, ldx, y, ldy, rows, V, log_out, (hipStream_t)stream);
 }
+int64_t s2st_gemm_streamk_scratch_floats(void) { return S2ST_STREAMK_SCRATCH_FLOATS; }
+int s2st_gemm_streamk_scratch(float* scratch, int64_t floats, void* stream) {
+  if (scratch && floats < S2ST_STREAMK_SCRATCH_FLOATS) return S2ST_ERR_WORKSPACE;
+  s2st_gemm_streamk_bind((hipStream_t)stream, scratch, floats);
+  return 0;
+}
 int s2st_profile_enable(int32_t enable) { s2st_profile_enable_impl(enable); return 0; }
 int64_t s2st_profile_report(char* out, int64_t cap) { return s2st_profile_report_impl(out, cap); }
 

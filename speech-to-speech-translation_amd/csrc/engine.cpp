@@ -1333,8 +1333,10 @@ struct s2st_engine {
   }
 
   // ------------------------------------------------------------------------------------
+  bool use_streamk = true;  // S2ST_GEMM_STREAMK=0 (A/B switch, read by the GEMM launcher too)
   void reset_call() {
     pending_wgrad.clear();
+    s2st_gemm_streamk_unbind_all();  // the scratch lives in the previous call's workspace
     for (Ten* t : tens) delete t;
     tens.clear();
     tape.clear();
@@ -1387,6 +1389,19 @@ struct s2st_engine {
     skws_n = fm ? (long)16 << 20 : 0;
     skws = fm ? alloc(skws_n) : nullptr;
     skws_side = fm && side_ ? alloc(skws_n) : skws;
+    // stream-K scratch of the persistent GEMM kernel, one per stream (ticket counters zeroed here, before any fork)
+    if (fm && tr && use_streamk) {
+      float* sk0 = alloc(S2ST_STREAMK_SCRATCH_FLOATS);
+      float* sk1 = side_ ? alloc(S2ST_STREAMK_SCRATCH_FLOATS) : nullptr;
+      if (live()) {
+        hipMemsetAsync(sk0, 0, 4096, st_);
+        s2st_gemm_streamk_bind(st_, sk0, S2ST_STREAMK_SCRATCH_FLOATS);
+        if (sk1) {
+          hipMemsetAsync(sk1, 0, 4096, st_);
+          s2st_gemm_streamk_bind(side_, sk1, S2ST_STREAMK_SCRATCH_FLOATS);
+        }
+      }
+    }
     typedef ConvW ConvScratch;
     auto conv_scratch = [&](const ConvP& p, bool need_wd) { return make_conv_scratch(p, need_wd, tr); };
     ConvScratch cs0{}, cs1{};

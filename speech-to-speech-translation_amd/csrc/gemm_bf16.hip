@@ -594,7 +594,7 @@ int launch_dma(const GemmArgs& g, dim3 grid, hipStream_t st) {
 // YOUNGEST operations, so the counted wait "all but the (stages ahead) x PER_STAGE youngest" still covers the stage
 // about to be read (it may wait for a few stores too: correct, slightly conservative).
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, bool AKM, bool BKM, int NS, int NW>
+template <int BM, int BN, bool AKM, bool BKM, int NS, int NW, bool SK = false>
 __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmGroup grp) {
   constexpr int WGN = NW / 2;
   constexpr int WM = BM / 2, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
@@ -612,13 +612,41 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
   const int wm = wave / WGN, wn = wave % WGN;
   const int G = gridDim.x, total = grp.total;
 
+  // ---- stream-K: this workgroup's share [s_begin, s_end) of the K-steps of all tiles ---------------------------
+  // Logical index w = (XCD of the workgroup) * G/8 + ticket: workgroups of one XCD get adjacent ranges (their tiles share
+  // operand rows in that XCD's L2), and a lower index has STARTED earlier -- so a workgroup that waits for partial
+  // sums (always of lower indices, which never wait themselves) cannot wait for one that is not running yet.
+  int w = blockIdx.x, first_tile = blockIdx.x, first_k = 0, budget = 0x7fffffff;
+  long s_begin = 0, S_tot = 0;
+  if (SK) {
+    __shared__ int s_w;
+    if (tid == 0) {
+      const int x = blockIdx.x & 7;
+      s_w = x * (G >> 3) + atomicAdd(&grp.sk_ctr[x], 1);
+    }
+    __syncthreads();
+    w = __builtin_amdgcn_readfirstlane(s_w);
+    for (int p = 0; p < grp.n; ++p)
+      S_tot += (long)(grp.tile0[p + 1] - grp.tile0[p]) * ((grp.g[p].K + BK - 1) / BK);
+    s_begin = (long)w * S_tot / G;
+    budget = (int)((long)(w + 1) * S_tot / G - s_begin);
+    long s = s_begin;
+    first_tile = total;
+    for (int p = 0; p < grp.n; ++p) {
+      const long ntp = (grp.g[p].K + BK - 1) / BK, span = (long)(grp.tile0[p + 1] - grp.tile0[p]) * ntp;
+      if (s < span) { first_tile = grp.tile0[p] + (int)(s / ntp); first_k = (int)(s % ntp); break; }
+      s -= span;
+    }
+  }
+  const int stride = SK ? 1 : G;
+
   struct Tile { int pi, m0, n0, nt; };
   auto locate = [&](int t, Tile& T) {
     int pi = 0;
     while (pi + 1 < grp.n && t >= grp.tile0[pi + 1]) ++pi;
     const int nwg = grp.tile0[pi + 1] - grp.tile0[pi];
     int id = t - grp.tile0[pi];
-    {  // XCD-aware order inside a problem: ids that share an XCD (id % 8) own a contiguous run of tiles
+    if (!SK) {  // XCD-aware order inside a problem: ids that share an XCD (id % 8) own a contiguous run of tiles
       const int x = id & 7, q = nwg >> 3, r = nwg & 7;
       id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
     }
@@ -631,8 +659,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
   };
 
   // ---- issue cursor: the (tile, K-step) whose DMA goes out next ------------------------------------------
-  int ti = blockIdx.x, ki = 0, issued = 0;
-  bool issue_valid = ti < total;
+  int ti = first_tile, ki = first_k, issued = 0, left_i = budget;
+  bool issue_valid = SK ? (budget > 0 && ti < total) : ti < total;
   Tile TI{0, 0, 0, 0};
   DA da;
   DB db;
@@ -651,12 +679,14 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
     da.issue(img, ki * BK, K_i, wave);
     db.issue(img + A_BYTES, ki * BK, K_i, wave);
     ++issued;
-    if (++ki == TI.nt) {
-      ti += G;
+    --left_i;
+    const bool next_tile = ++ki == TI.nt;
+    if (next_tile) {
+      ti += stride;
       ki = 0;
-      issue_valid = ti < total;
-      if (issue_valid) init_issue();
     }
+    issue_valid = SK ? left_i > 0 : ti < total;
+    if (next_tile && issue_valid) init_issue();
   };
   if (issue_valid) init_issue();
   // (NS - 2 stages here, the next one at the first read_step: a refill then always targets the slot of step
@@ -678,8 +708,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
       for (int i = 0; i < TM; ++i) F.a[s][i] = LA::frag(cur, wm * WM + i * 16, s, lane);
     }
   };
-  int tr = blockIdx.x, kr = 0, nread = 0;  // nread: global index of the step the read cursor points at
-  bool read_valid = tr < total;
+  int tr = first_tile, kr = first_k, nread = 0, left_r = budget;  // nread: index of the step the read cursor points at
+  bool read_valid = SK ? (budget > 0 && tr < total) : tr < total;
   int nt_r = 0, K_r = 0;
   auto init_read = [&]() {
     Tile T;
@@ -705,23 +735,65 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
     }
     load_frags(F, cur);
     ++nread;
-    if (++kr == nt_r) {
-      tr += G;
+    --left_r;
+    const bool next_tile = ++kr == nt_r;
+    if (next_tile) {
+      tr += stride;
       kr = 0;
-      read_valid = tr < total;
-      if (read_valid) init_read();
     }
+    read_valid = SK ? left_r > 0 : tr < total;
+    if (next_tile && read_valid) init_read();
   };
 
-  int tc = blockIdx.x, kc = 0;
-  bool comp_valid = tc < total;
-  Tile TC{0, 0, 0, 0};
-  if (comp_valid) locate(tc, TC);
+  int tc = first_tile, kc = first_k, left_c = budget;
+  int k_first = first_k;  // > 0: the current tile was begun by lower-indexed workgroups (only my first tile can be)
+  bool comp_valid = SK ? (budget > 0 && tc < total) : tc < total;
   f32x4 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int NTHR = 64 * NW;
+  // partial accumulators of a workgroup: [TM*TN][NTHR] float4, i.e. 16-byte coalesced per lane
+  auto store_partial = [&]() {
+    float4* dst = reinterpret_cast<float4*>(grp.sk_part + (long)w * (BM * BN));
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        dst[(i * TN + j) * NTHR + tid] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    // hand-off to another workgroup (possibly another XCD): every wave drains its stores, the workgroup meets, one
+    // lane publishes with an agent-scope release (MI355X_MICROARCH.md, inter-workgroup visibility)
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&grp.sk_flag[w], grp.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto add_partials = [&]() {
+    // contributors: w - 1, w - 2, ... while their range reaches back before this tile's first step
+    const long tile_first_step = s_begin - k_first;
+    for (int c = w - 1; c >= 0; --c) {
+      if (tid == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(&grp.sk_flag[c], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != grp.epoch) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1 << 24)) break;  // bounded: a lost hand-off gives a wrong tile (caught by tests), not a hang
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      const float4* src = reinterpret_cast<const float4*>(grp.sk_part + (long)c * (BM * BN));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const float4 v = src[(i * TN + j) * NTHR + tid];
+          acc[i][j][0] += v.x; acc[i][j][1] += v.y; acc[i][j][2] += v.z; acc[i][j][3] += v.w;
+        }
+      if ((long)c * S_tot / G <= tile_first_step) break;  // c began at (or before) the tile's first step
+    }
+  };
+  Tile TC{0, 0, 0, 0};
+  if (comp_valid) locate(tc, TC);
 
   Frag F0, F1;
   if (read_valid) {
@@ -738,22 +810,35 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fc.b[s][j], Fc.a[s][i], acc[i][j], 0, 0, 0);
-    if (++kc == TC.nt) {
+    --left_c;
+    const bool tile_end = ++kc == TC.nt;
+    if (tile_end) {
+      if (SK && k_first > 0) add_partials();
       gemm_epilogue<BM, BN, WGN>(grp.g[TC.pi], acc, TC.m0, TC.n0, wm, wn, lane, 0, 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      tc += G;
+      tc += stride;
       kc = 0;
-      comp_valid = tc < total;
-      if (comp_valid) locate(tc, TC);
+      k_first = 0;
+    } else if (SK && left_c == 0) {
+      store_partial();  // my range ends inside this tile: a higher-indexed workgroup finishes it
     }
+    comp_valid = SK ? left_c > 0 : tc < total;
+    if (tile_end && comp_valid) locate(tc, TC);
   };
   while (comp_valid) {
     body(F0, F1);
     if (!comp_valid) break;
     body(F1, F0);
+  }
+  if (SK) {  // the last workgroup to leave re-arms the counters for the next launch on this stream
+    __syncthreads();
+    if (tid == 0 && atomicAdd(&grp.sk_ctr[8], 1) == G - 1) {
+#pragma unroll
+      for (int x = 0; x < 9; ++x) grp.sk_ctr[x] = 0;
+    }
   }
 }
 
@@ -762,6 +847,15 @@ const char* persistent_tag() {
   static char buf[96];
   if (!buf[0])
     snprintf(buf, sizeof buf, "gemm_bf16_dma_persistent_kernel<%d, %d, %s, %s, %d, %d>", BM, BN, AKM ? "true" : "false",
+             BKM ? "true" : "false", NS, NW);
+  return buf;
+}
+
+template <int BM, int BN, bool AKM, bool BKM, int NS, int NW>
+const char* streamk_tag() {
+  static char buf[104];
+  if (!buf[0])
+    snprintf(buf, sizeof buf, "gemm_bf16_dma_persistent_kernel<%d, %d, %s, %s, %d, %d, true>", BM, BN, AKM ? "true" : "false",
              BKM ? "true" : "false", NS, NW);
   return buf;
 }
@@ -780,15 +874,49 @@ int num_cus() {
   return n;
 }
 
+// ---- stream-K scratch per stream (bound by the training engine for its two streams at the start of a step) ----------
+struct SkScratch { hipStream_t st; float* p; long floats; };
+SkScratch g_sk[4];
+int g_sk_n = 0;
+int g_sk_epoch = 0;
+
+int streamk_mode() {  // S2ST_GEMM_STREAMK: 0 = whole tiles per workgroup, 1 = stream-K where a scratch buffer is bound (default)
+  const char* ev = getenv("S2ST_GEMM_STREAMK");
+  return ev ? atoi(ev) : 1;
+}
+
 template <int BM, int BN, int NS, int NW>
-int launch_persistent(const GemmGroup& grp, hipStream_t st) {
+int launch_persistent(const GemmGroup& grp_in, hipStream_t st) {
   constexpr int LDS = NS * (BM + BN) * 128;
+  GemmGroup grp = grp_in;
+  // stream-K when a scratch buffer is bound to this stream and the split pays: uneven rounds of whole tiles (or fewer
+  // tiles than CUs) and enough K-steps per workgroup that the partial-sum hand-off (64 KB out, 64 KB in) is small change
+  grp.sk = 0;
+  if (streamk_mode() > 0 && BM * BN == 128 * 128 && grp.total > 0) {
+    SkScratch* sc = nullptr;
+    for (int i = 0; i < g_sk_n; ++i) if (g_sk[i].st == st && g_sk[i].p) sc = &g_sk[i];
+    long steps = 0;
+    for (int i = 0; i < grp.n; ++i) steps += (long)(grp.tile0[i + 1] - grp.tile0[i]) * ((grp.g[i].K + BK - 1) / BK);
+    const int G = num_cus() & ~7;
+    const long rounds = (grp.total + G - 1) / G;
+    const double waste = 1.0 - (double)grp.total / (double)(rounds * G);  // idle share of the last round
+    const int min_steps = getenv("S2ST_STREAMK_MIN_STEPS") ? atoi(getenv("S2ST_STREAMK_MIN_STEPS")) : 8;
+    if (sc && G >= 8 && G <= S2ST_STREAMK_MAX_WGS && waste > 0.08 && steps >= (long)min_steps * G &&
+        sc->floats >= S2ST_STREAMK_SCRATCH_FLOATS) {
+      grp.sk = 1;
+      grp.epoch = ++g_sk_epoch;
+      if (g_sk_epoch > (1 << 30)) g_sk_epoch = 0;
+      grp.sk_ctr = reinterpret_cast<int*>(sc->p);
+      grp.sk_flag = reinterpret_cast<int*>(sc->p) + 16;
+      grp.sk_part = sc->p + 1024;
+    }
+  }
   double fl = 0, by = 0;
   for (int i = 0; i < grp.n; ++i) { fl += gemm_flops(grp.g[i]); by += gemm_min_bytes(grp.g[i]); }
   // S2ST_GROUP_WGS=<n> (tuning aid): cap for grouped launches, which share the chip with the data-path stream
   static const int group_cap = getenv("S2ST_GROUP_WGS") ? atoi(getenv("S2ST_GROUP_WGS")) : 0;
   const int cap = (grp.n > 1 && group_cap > 0) ? group_cap : num_cus();
-  const int grid = grp.total < 1 ? 1 : (grp.total < cap ? grp.total : cap);  // (preload: no tiles)
+  const int grid = grp.sk ? (num_cus() & ~7) : (grp.total < 1 ? 1 : (grp.total < cap ? grp.total : cap));  // (preload: no tiles)
   auto go = [&](auto kern, const char* tag) {
     static bool configured = false;
     if (!configured) {
@@ -800,6 +928,14 @@ int launch_persistent(const GemmGroup& grp, hipStream_t st) {
     return 0;
   };
   const bool akm = grp.g[0].A.kmajor != 0, bkm = grp.g[0].B.kmajor != 0;
+  if (grp.sk) {
+    if constexpr (BM == 128 && BN == 128) {
+      if (akm && bkm) return go(gemm_bf16_dma_persistent_kernel<BM, BN, true, true, NS, NW, true>, streamk_tag<BM, BN, true, true, NS, NW>());
+      if (akm && !bkm) return go(gemm_bf16_dma_persistent_kernel<BM, BN, true, false, NS, NW, true>, streamk_tag<BM, BN, true, false, NS, NW>());
+      if (!akm && bkm) return go(gemm_bf16_dma_persistent_kernel<BM, BN, false, true, NS, NW, true>, streamk_tag<BM, BN, false, true, NS, NW>());
+      return go(gemm_bf16_dma_persistent_kernel<BM, BN, false, false, NS, NW, true>, streamk_tag<BM, BN, false, false, NS, NW>());
+    }
+  }
   if (akm && bkm) return go(gemm_bf16_dma_persistent_kernel<BM, BN, true, true, NS, NW>, persistent_tag<BM, BN, true, true, NS, NW>());
   if (akm && !bkm) return go(gemm_bf16_dma_persistent_kernel<BM, BN, true, false, NS, NW>, persistent_tag<BM, BN, true, false, NS, NW>());
   if (!akm && bkm) return go(gemm_bf16_dma_persistent_kernel<BM, BN, false, true, NS, NW>, persistent_tag<BM, BN, false, true, NS, NW>());
@@ -889,6 +1025,13 @@ void add_to_group(GemmGroup& grp, GemmArgs g) {
 }
 
 }  // namespace
+
+void s2st_gemm_streamk_bind(hipStream_t st, float* scratch, long floats) {
+  for (int i = 0; i < g_sk_n; ++i)
+    if (g_sk[i].st == st) { g_sk[i].p = scratch; g_sk[i].floats = floats; return; }
+  if (g_sk_n < 4) g_sk[g_sk_n++] = SkScratch{st, scratch, floats};
+}
+void s2st_gemm_streamk_unbind_all() { g_sk_n = 0; }
 
 bool s2st_gemm_group_ok(const GemmArgs& g0) {
   GemmArgs g = g0;
@@ -982,7 +1125,7 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
     }
   }
   if (vec) {  // tuning aid: S2ST_GEMM_TILE=128x128|128x64|64x64 forces the tile
-    static const char* force = getenv("S2ST_GEMM_TILE");
+    const char* force = getenv("S2ST_GEMM_TILE");  // (read per call: the tests switch it)
     if (force && sscanf(force, "%dx%d", &bm, &bn) != 2) { bm = 64; bn = 64; }
   }
   if (bm == 256 && !(vec && dma_layout_ok(g) && g.batch == 1)) { bm = 128; bn = 128; }  // 256-row tiles: ring kernels only
@@ -1021,8 +1164,13 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
   static const int use_dma = getenv("S2ST_GEMM_DMA") ? atoi(getenv("S2ST_GEMM_DMA")) : 1;
   const bool dma_ok = vec && use_dma && dma_layout_ok(g);
   // more tiles than CUs: the persistent kernel keeps the DMA ring running across the tiles a workgroup walks
+  // ... and, with a stream-K scratch bound to the stream, also the 128 x 128 launches that leave CUs idle (N = 512
+  // layers: 144 tiles) when K is long enough to share (launch_persistent decides)
+  bool sk_bound = false;
+  if (streamk_mode() > 0 && bm == 128 && bn == 128)
+    for (int i = 0; i < g_sk_n; ++i) sk_bound = sk_bound || (g_sk[i].st == st && g_sk[i].p);
   if (dma_ok && g.batch == 1 && g.splitk == 1 && bm == 128 && persist_mode() > 0 &&
-      (persist_mode() == 2 || nt > num_cus())) {
+      (persist_mode() == 2 || nt > num_cus() || (sk_bound && (long)nt * ((g.K + BK - 1) / BK) >= 8L * num_cus()))) {
     GemmGroup grp{};
     int rc;
     if (bn == 128) { add_to_group<128>(grp, g); rc = launch_persistent<128, 128, 4, 8>(grp, st); }

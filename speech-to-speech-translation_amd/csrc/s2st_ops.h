@@ -58,7 +58,21 @@ struct GemmGroup {
   int n, total;
   int tile0[S2ST_GROUP_MAX + 1];
   GemmArgs g[S2ST_GROUP_MAX];
+  // stream-K form (sk != 0): the K-steps of ALL tiles are dealt out evenly to the workgroups; a workgroup whose range
+  // ends inside a tile leaves its partial accumulators in sk_part[w] and raises sk_flag[w] = epoch, the workgroup
+  // that reaches the tile's last K-step adds them and runs the epilogue.  sk_ctr: 8 per-XCD ticket counters + a
+  // completion counter (zero before the first launch; the last workgroup of a launch resets them).
+  int sk, epoch;
+  int* sk_ctr;
+  int* sk_flag;
+  float* sk_part;
 };
+// scratch for stream-K launches on `st` (nullptr: none -- the launcher then keeps whole tiles per workgroup);
+// floats >= S2ST_STREAMK_SCRATCH_FLOATS; the first 16 ints must be zero at bind time
+#define S2ST_STREAMK_MAX_WGS 512
+#define S2ST_STREAMK_SCRATCH_FLOATS (1024 + (long)S2ST_STREAMK_MAX_WGS * 128 * 128)
+void s2st_gemm_streamk_bind(hipStream_t st, float* scratch, long floats);
+void s2st_gemm_streamk_unbind_all();
 // true if g can join a group (aligned bf16 operands, plain strides, batch 1, >= 128 x 128 of output)
 bool s2st_gemm_group_ok(const GemmArgs& g);
 int s2st_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t st);

@@ -171,6 +171,12 @@ static inline void emu_global_load_lds(const void* g, void* l, unsigned size, in
 }
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_global_load_lds((const void*)(g), (void*)(l), size, off, aux)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) emu_sleep_us(20)  // (a workgroup waiting for another one: emulated blocks are ~1000x slower)
+#include <unistd.h>
+static inline void emu_sleep_us(int us) { usleep(us); }
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
 #define __builtin_amdgcn_s_barrier() emu_syncthreads()
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
@@ -211,6 +217,6 @@ static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 enum { hipDeviceAttributeMultiprocessorCount = 63 };
-static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 4; return hipSuccess; }  // 4 'CUs': persistent kernels walk several tiles
+static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 8; return hipSuccess; }  // 8 'CUs': persistent kernels walk several tiles, stream-K has one workgroup per 'XCD'
 using std::min;
 using std::max;

@@ -350,6 +350,7 @@ def test_bf16_persistent_kernel(backend, monkeypatch, akm, bkm, K):
     running across tile boundaries -- K = 64 makes the prologue itself span tiles, K = 200 has a K tail) against the
     exact product; epilogue variants with both output copies."""
     monkeypatch.setenv("S2ST_GEMM_PERSIST", "2")
+    monkeypatch.setenv("S2ST_GEMM_TILE", "128x128")  # (the small emulator shape would get 64 x 64 tiles: one-shot kernel)
     M, N = (640, 256) if backend.kind == "emu" else (4584, 2048)
     g = torch.Generator().manual_seed(K + 2 * akm + bkm)
     A, B = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g))
@@ -398,3 +399,54 @@ def test_bf16_group_of_weight_gradients(backend):
     backend.sync()
     for dW, ref in refs:
         assert _relerr(dW, ref) < 2e-6
+
+
+@pytest.mark.parametrize("akm,bkm", [(True, True), (True, False), (False, False)])
+@pytest.mark.parametrize("shape", ["wide", "narrow"])
+def test_bf16_stream_k(backend, monkeypatch, akm, bkm, shape):
+    """Stream-K form of the persistent kernel: the K-steps of all tiles are dealt out evenly, tiles that straddle two (or
+    more) workgroups are completed through partial accumulators in a bound scratch buffer.  Against the exact product and
+    against the unsplit launch (same products, different fp32 summation order); two launches in a row (the ticket
+    counters re-arm themselves)."""
+    import ctypes as C
+    monkeypatch.setenv("S2ST_GEMM_PERSIST", "1")
+    monkeypatch.setenv("S2ST_STREAMK_MIN_STEPS", "2")
+    monkeypatch.setenv("S2ST_GEMM_TILE", "128x128")
+    emu = backend.kind == "emu"
+    # wide: more tiles than workgroups, uneven rounds; narrow: fewer tiles than workgroups, long K (a tile spans several
+    # workgroups)
+    M, N, K = ((640, 256, 200) if emu else (4584, 2048, 512)) if shape == "wide" else ((384, 128, 1536) if emu else (4584, 512, 2048))
+    g = torch.Generator().manual_seed(K + 2 * akm + bkm)
+    A, B = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g))
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    Am, a_ld = _pad_cols(A if akm else A.t().contiguous())
+    Bm, b_ld = _pad_cols(B if bkm else B.t().contiguous())
+    d = backend.device
+    lib = backend.bd.lib()
+    lib.s2st_gemm_streamk_scratch_floats.restype = C.c_int64
+    lib.s2st_gemm_streamk_scratch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    scratch = torch.zeros(int(lib.s2st_gemm_streamk_scratch_floats()), device=d)
+    R = A.double() @ B.double().t()
+    ref = torch.relu(0.5 * R + bias.double()) + res.double()
+    kw = dict(a_kmajor=akm, b_kmajor=bkm, a_ld=a_ld, b_ld=b_ld, alpha=0.5, bias=bias.to(d), act=1, resid=res.to(d))
+    C0 = torch.zeros(M, N, device=d)
+    backend.bd.gemm(Am.to(d), Bm.to(d), C0, M, N, K, **kw)  # unsplit
+    backend.sync()
+    assert lib.s2st_gemm_streamk_scratch(scratch.data_ptr(), scratch.numel(), C.c_void_p(backend.bd.stream_ptr())) == 0
+    try:
+        outs = []
+        for _ in range(2):
+            C1 = torch.full((M, N), 7.0, device=d)
+            Ch = torch.zeros(M, N, dtype=torch.bfloat16, device=d)
+            backend.bd.gemm(Am.to(d), Bm.to(d), C1, M, N, K, c_bf16=Ch, **kw)
+            backend.sync()
+            outs.append(C1)
+            assert _relerr(C1, ref) < 2e-6
+            assert torch.equal(Ch.cpu(), C1.cpu().to(torch.bfloat16))
+        assert torch.equal(outs[0], outs[1])  # fixed order of the partial sums: run-to-run identical
+        assert _relerr(outs[0], C0.double().cpu()) < 1e-6
+        ctr = scratch[:9].view(torch.int32) if False else scratch.view(torch.int32)[:9]
+        assert int(ctr.abs().sum()) == 0, "ticket / completion counters must be re-armed by the last workgroup"
+        assert int(scratch.view(torch.int32)[16:16 + 512].max()) > 0, "no workgroup handed over a partial tile: stream-K did not run"
+    finally:
+        lib.s2st_gemm_streamk_scratch(None, 0, C.c_void_p(backend.bd.stream_ptr()))
