@@ -1333,7 +1333,9 @@ struct s2st_engine {
   }
 
   // ------------------------------------------------------------------------------------
-  bool use_streamk = true;  // S2ST_GEMM_STREAMK=0 (A/B switch, read by the GEMM launcher too)
+  // S2ST_GEMM_STREAMK=1: bind stream-K scratch buffers to the two streams (opt-in: on the products of this step the
+  // hand-off costs more than the idle tail it removes -- gemm_bf16.hip streamk_mode())
+  bool use_streamk = getenv("S2ST_GEMM_STREAMK") && atoi(getenv("S2ST_GEMM_STREAMK")) > 0;
   void reset_call() {
     pending_wgrad.clear();
     s2st_gemm_streamk_unbind_all();  // the scratch lives in the previous call's workspace

@@ -614,31 +614,74 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
 
   // ---- stream-K: this workgroup's share [s_begin, s_end) of the K-steps of all tiles ---------------------------
   // Logical index w = (XCD of the workgroup) * G/8 + ticket: workgroups of one XCD get adjacent ranges (their tiles share
-  // operand rows in that XCD's L2), and a lower index has STARTED earlier -- so a workgroup that waits for partial
-  // sums (always of lower indices, which never wait themselves) cannot wait for one that is not running yet.
-  int w = blockIdx.x, first_tile = blockIdx.x, first_k = 0, budget = 0x7fffffff;
+  // operand rows in that XCD's L2), and a lower index has STARTED earlier.  A share is up to three pieces: the tail of a
+  // tile begun by lower indices, whole tiles, and the head of a tile that higher indices complete.  The head goes FIRST
+  // (its partial accumulators are published within the first few microseconds), the tail LAST (the workgroup that
+  // owns a tile's last K-step adds the partials of the lower indices and runs the epilogue) -- so a wait is always for
+  // a lower index, which is running (no deadlock whatever else occupies the chip), and for data that was published a
+  // whole share earlier.
+  struct Cur { int ph, t, k, kend; };  // ph: 0 head piece, 1 whole tiles, 2 tail piece, 3 done
+  int w = blockIdx.x;
   long s_begin = 0, S_tot = 0;
+  bool has_h = false, has_t = false;
+  int hT = 0, hK0 = 0, hK1 = 0, f0 = blockIdx.x, f1 = total - 1, tT = 0, tK0 = 0;
   if (SK) {
-    __shared__ int s_w;
+    int* s_w = reinterpret_cast<int*>(smem);  // (no second LDS object beside the ring: the ring is not in use yet)
     if (tid == 0) {
       const int x = blockIdx.x & 7;
-      s_w = x * (G >> 3) + atomicAdd(&grp.sk_ctr[x], 1);
+      *s_w = x * (G >> 3) + atomicAdd(&grp.sk_ctr[x], 1);
     }
     __syncthreads();
-    w = __builtin_amdgcn_readfirstlane(s_w);
+    w = __builtin_amdgcn_readfirstlane(*s_w);
+    __syncthreads();
     for (int p = 0; p < grp.n; ++p)
       S_tot += (long)(grp.tile0[p + 1] - grp.tile0[p]) * ((grp.g[p].K + BK - 1) / BK);
     s_begin = (long)w * S_tot / G;
-    budget = (int)((long)(w + 1) * S_tot / G - s_begin);
-    long s = s_begin;
-    first_tile = total;
-    for (int p = 0; p < grp.n; ++p) {
-      const long ntp = (grp.g[p].K + BK - 1) / BK, span = (long)(grp.tile0[p + 1] - grp.tile0[p]) * ntp;
-      if (s < span) { first_tile = grp.tile0[p] + (int)(s / ntp); first_k = (int)(s % ntp); break; }
-      s -= span;
+    const long s_end = (long)(w + 1) * S_tot / G;
+    f0 = 0;
+    f1 = -1;
+    if (s_end > s_begin) {
+      auto where = [&](long s, int& t, int& k, int& nt) {
+        for (int p = 0; p < grp.n; ++p) {
+          const long ntp = (grp.g[p].K + BK - 1) / BK, span = (long)(grp.tile0[p + 1] - grp.tile0[p]) * ntp;
+          if (s < span || p == grp.n - 1) { t = grp.tile0[p] + (int)(s / ntp); k = (int)(s % ntp); nt = (int)ntp; return; }
+          s -= span;
+        }
+      };
+      int tA, kA, ntA, tB, kB, ntB;
+      where(s_begin, tA, kA, ntA);
+      where(s_end - 1, tB, kB, ntB);
+      const bool tail = kA > 0, head = kB + 1 < ntB;
+      if (tA == tB) {
+        if (head) { has_h = true; hT = tA; hK0 = kA; hK1 = kB + 1; }       // head or middle piece: published
+        else if (tail) { has_t = true; tT = tA; tK0 = kA; }                // tail only
+        else { f0 = tA; f1 = tA; }                                         // exactly one whole tile
+      } else {
+        if (head) { has_h = true; hT = tB; hK0 = 0; hK1 = kB + 1; }
+        if (tail) { has_t = true; tT = tA; tK0 = kA; }
+        f0 = tail ? tA + 1 : tA;
+        f1 = head ? tB - 1 : tB;
+      }
     }
   }
   const int stride = SK ? 1 : G;
+  auto enter_phase = [&](Cur& c, int ph) {  // the first phase >= ph that has work (kend of phases 1, 2: set on tile entry)
+    if (SK && ph <= 0 && has_h) { c.ph = 0; c.t = hT; c.k = hK0; c.kend = hK1; return; }
+    if (ph <= 1 && f0 <= f1) { c.ph = 1; c.t = f0; c.k = 0; c.kend = 0; return; }
+    if (SK && ph <= 2 && has_t) { c.ph = 2; c.t = tT; c.k = tK0; c.kend = 0; return; }
+    c.ph = 3;
+  };
+  auto step_cur = [&](Cur& c) -> bool {  // one K-step on; true when the cursor left its tile (or piece)
+    if (++c.k < c.kend) return false;
+    if (c.ph == 1) {
+      c.t += stride;
+      c.k = 0;
+      if (c.t > f1) enter_phase(c, 2);
+    } else {
+      enter_phase(c, c.ph + 1);
+    }
+    return true;
+  };
 
   struct Tile { int pi, m0, n0, nt; };
   auto locate = [&](int t, Tile& T) {
@@ -659,36 +702,31 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
   };
 
   // ---- issue cursor: the (tile, K-step) whose DMA goes out next ------------------------------------------
-  int ti = first_tile, ki = first_k, issued = 0, left_i = budget;
-  bool issue_valid = SK ? (budget > 0 && ti < total) : ti < total;
+  Cur ci;
+  enter_phase(ci, 0);
+  int issued = 0;
   Tile TI{0, 0, 0, 0};
   DA da;
   DB db;
   int K_i = 0;  // (fields of the kernel-argument table are fetched by scalar loads, which share lgkmcnt with the LDS
                 // reads: everything the per-step code needs is copied into registers when a cursor enters a tile)
   auto init_issue = [&]() {
-    locate(ti, TI);
+    locate(ci.t, TI);
+    if (ci.ph != 0) ci.kend = TI.nt;
     const GemmArgs& g = grp.g[TI.pi];
     K_i = g.K;
     da.init(g.A, reinterpret_cast<const bf16_t*>(g.A.p), TI.m0, g.M, wave, lane);
     db.init(g.B, reinterpret_cast<const bf16_t*>(g.B.p), TI.n0, g.N, wave, lane);
   };
   auto advance_issue = [&]() {
-    if (!issue_valid) return;
+    if (ci.ph == 3) return;
     unsigned char* img = smem + (issued % NS) * STAGE;
-    da.issue(img, ki * BK, K_i, wave);
-    db.issue(img + A_BYTES, ki * BK, K_i, wave);
+    da.issue(img, ci.k * BK, K_i, wave);
+    db.issue(img + A_BYTES, ci.k * BK, K_i, wave);
     ++issued;
-    --left_i;
-    const bool next_tile = ++ki == TI.nt;
-    if (next_tile) {
-      ti += stride;
-      ki = 0;
-    }
-    issue_valid = SK ? left_i > 0 : ti < total;
-    if (next_tile && issue_valid) init_issue();
+    if (step_cur(ci) && ci.ph != 3) init_issue();
   };
-  if (issue_valid) init_issue();
+  if (ci.ph != 3) init_issue();
   // (NS - 2 stages here, the next one at the first read_step: a refill then always targets the slot of step
   // nread - 2, whose fragment reads have been consumed by MFMAs that every wave has issued before the barrier)
 #pragma unroll
@@ -708,12 +746,14 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
       for (int i = 0; i < TM; ++i) F.a[s][i] = LA::frag(cur, wm * WM + i * 16, s, lane);
     }
   };
-  int tr = first_tile, kr = first_k, nread = 0, left_r = budget;  // nread: index of the step the read cursor points at
-  bool read_valid = SK ? (budget > 0 && tr < total) : tr < total;
+  Cur cr;
+  enter_phase(cr, 0);
+  int nread = 0;  // index of the step the read cursor points at
   int nt_r = 0, K_r = 0;
   auto init_read = [&]() {
     Tile T;
-    locate(tr, T);
+    locate(cr.t, T);
+    if (cr.ph != 0) cr.kend = T.nt;
     nt_r = T.nt;
     K_r = grp.g[T.pi].K;
   };
@@ -727,34 +767,30 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
     __builtin_amdgcn_s_barrier();
     advance_issue();  // into the slot of step nread - 2: everyone's MFMAs of it have been issued (barrier above)
     unsigned char* cur = smem + (nread % NS) * STAGE;
-    if (kr == nt_r - 1 && K_r - kr * BK < BK) {  // K tail: zero the invalid k of this stage
-      const int kv = K_r - kr * BK;
+    if (cr.k == nt_r - 1 && K_r - cr.k * BK < BK) {  // K tail: zero the invalid k of this stage
+      const int kv = K_r - cr.k * BK;
       DA::sanitize(cur, kv, tid);
       DB::sanitize(cur + A_BYTES, kv, tid);
       __syncthreads();
     }
     load_frags(F, cur);
     ++nread;
-    --left_r;
-    const bool next_tile = ++kr == nt_r;
-    if (next_tile) {
-      tr += stride;
-      kr = 0;
-    }
-    read_valid = SK ? left_r > 0 : tr < total;
-    if (next_tile && read_valid) init_read();
+    if (step_cur(cr) && cr.ph != 3) init_read();
   };
 
-  int tc = first_tile, kc = first_k, left_c = budget;
-  int k_first = first_k;  // > 0: the current tile was begun by lower-indexed workgroups (only my first tile can be)
-  bool comp_valid = SK ? (budget > 0 && tc < total) : tc < total;
+  Cur cc;
+  enter_phase(cc, 0);
   f32x4 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   constexpr int NTHR = 64 * NW;
-  // partial accumulators of a workgroup: [TM*TN][NTHR] float4, i.e. 16-byte coalesced per lane
+  // partial accumulators of a workgroup: [TM*TN][NTHR] float4, i.e. 16-byte coalesced per lane.  Hand-off between
+  // workgroups (any XCDs) as cdna_hip_programming.md Guideline 16 prescribes: every storing wave drains its stores, the
+  // workgroup meets, ONE lane releases at agent scope (L2 write-back), waits, then sets the flag with an agent-scope
+  // atomic; the consumer polls that word relaxed with one lane, acquires at agent scope (L1 invalidate), waits, the
+  // workgroup meets, and everyone reads with plain 16-byte loads.
   auto store_partial = [&]() {
     float4* dst = reinterpret_cast<float4*>(grp.sk_part + (long)w * (BM * BN));
 #pragma unroll
@@ -762,24 +798,27 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
 #pragma unroll
       for (int j = 0; j < TN; ++j)
         dst[(i * TN + j) * NTHR + tid] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-    // hand-off to another workgroup (possibly another XCD): every wave drains its stores, the workgroup meets, one
-    // lane publishes with an agent-scope release (MI355X_MICROARCH.md, inter-workgroup visibility)
-    __builtin_amdgcn_s_waitcnt(0);
+    S2ST_VMCNT(0);
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(&grp.sk_flag[w], grp.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      S2ST_VMCNT(0);
+      __hip_atomic_store(&grp.sk_flag[w], grp.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   };
   auto add_partials = [&]() {
-    // contributors: w - 1, w - 2, ... while their range reaches back before this tile's first step
-    const long tile_first_step = s_begin - k_first;
+    // contributors: w - 1, w - 2, ... while their share reaches back before this tile's first step
+    const long tile_first_step = s_begin - tK0;
     for (int c = w - 1; c >= 0; --c) {
       if (tid == 0) {
         int spins = 0;
-        while (__hip_atomic_load(&grp.sk_flag[c], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != grp.epoch) {
+        while (__hip_atomic_load(&grp.sk_flag[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != grp.epoch) {
           __builtin_amdgcn_s_sleep(2);
           if (++spins > (1 << 24)) break;  // bounded: a lost hand-off gives a wrong tile (caught by tests), not a hang
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        S2ST_VMCNT(0);
       }
-      __builtin_amdgcn_s_waitcnt(0);
       __syncthreads();
       const float4* src = reinterpret_cast<const float4*>(grp.sk_part + (long)c * (BM * BN));
 #pragma unroll
@@ -793,15 +832,19 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
     }
   };
   Tile TC{0, 0, 0, 0};
-  if (comp_valid) locate(tc, TC);
+  auto init_comp = [&]() {
+    locate(cc.t, TC);
+    if (cc.ph != 0) cc.kend = TC.nt;
+  };
+  if (cc.ph != 3) init_comp();
 
   Frag F0, F1;
-  if (read_valid) {
+  if (cr.ph != 3) {
     init_read();
     read_step(F0);
   }
   auto body = [&](Frag& Fc, Frag& Fn) {
-    if (read_valid) read_step(Fn);  // in flight under the MFMAs below
+    if (cr.ph != 3) read_step(Fn);  // in flight under the MFMAs below
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -810,27 +853,24 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fc.b[s][j], Fc.a[s][i], acc[i][j], 0, 0, 0);
-    --left_c;
-    const bool tile_end = ++kc == TC.nt;
-    if (tile_end) {
-      if (SK && k_first > 0) add_partials();
-      gemm_epilogue<BM, BN, WGN>(grp.g[TC.pi], acc, TC.m0, TC.n0, wm, wn, lane, 0, 0, 0, 0);
+    const int ph = cc.ph;
+    if (step_cur(cc)) {  // the last K-step of a whole tile or of a piece
+      if (SK && ph == 0) {
+        store_partial();  // a higher-indexed workgroup finishes this tile
+      } else {
+        if (SK && ph == 2) add_partials();
+        gemm_epilogue<BM, BN, WGN>(grp.g[TC.pi], acc, TC.m0, TC.n0, wm, wn, lane, 0, 0, 0, 0);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      tc += stride;
-      kc = 0;
-      k_first = 0;
-    } else if (SK && left_c == 0) {
-      store_partial();  // my range ends inside this tile: a higher-indexed workgroup finishes it
+      if (cc.ph != 3) init_comp();
     }
-    comp_valid = SK ? left_c > 0 : tc < total;
-    if (tile_end && comp_valid) locate(tc, TC);
   };
-  while (comp_valid) {
+  while (cc.ph != 3) {
     body(F0, F1);
-    if (!comp_valid) break;
+    if (cc.ph == 3) break;
     body(F1, F0);
   }
   if (SK) {  // the last workgroup to leave re-arms the counters for the next launch on this stream
@@ -880,7 +920,12 @@ SkScratch g_sk[4];
 int g_sk_n = 0;
 int g_sk_epoch = 0;
 
-int streamk_mode() {  // S2ST_GEMM_STREAMK: 0 = whole tiles per workgroup, 1 = stream-K where a scratch buffer is bound (default)
+// S2ST_GEMM_STREAMK: 0 = whole tiles per workgroup, 1 = stream-K where a scratch buffer is bound to the stream.  On by
+// default for callers that bind a scratch themselves (s2st_gemm_streamk_scratch); the training engine binds one only
+// with S2ST_GEMM_STREAMK=1 in the environment: measured on MI355X (tools/streamk_probe.py) the
+// hand-off -- L2 write-back behind the release, invalidate + 64 KB read behind the acquire -- costs 12-20 us per launch,
+// more than the idle last round of the 25-45 us products of a training step; it pays from ~2 rounds of long-K tiles on.
+int streamk_mode() {
   const char* ev = getenv("S2ST_GEMM_STREAMK");
   return ev ? atoi(ev) : 1;
 }

@@ -175,6 +175,7 @@ static inline void emu_global_load_lds(const void* g, void* l, unsigned size, in
 #include <unistd.h>
 static inline void emu_sleep_us(int us) { usleep(us); }
 #define __HIP_MEMORY_SCOPE_AGENT 4
+#define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(order)
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
 #define __builtin_amdgcn_s_barrier() emu_syncthreads()

@@ -443,9 +443,11 @@ def test_bf16_stream_k(backend, monkeypatch, akm, bkm, shape):
             outs.append(C1)
             assert _relerr(C1, ref) < 2e-6
             assert torch.equal(Ch.cpu(), C1.cpu().to(torch.bfloat16))
-        assert torch.equal(outs[0], outs[1])  # fixed order of the partial sums: run-to-run identical
-        assert _relerr(outs[0], C0.double().cpu()) < 1e-6
-        ctr = scratch[:9].view(torch.int32) if False else scratch.view(torch.int32)[:9]
+        neq = outs[0] != outs[1]  # fixed order of the partial sums: run-to-run identical
+        assert not bool(neq.any()), "%d elements differ between two runs, max %.3e, first at %s" % (
+            int(neq.sum()), float((outs[0] - outs[1]).abs().max()), neq.nonzero()[:4].tolist())
+        assert _relerr(outs[0], C0.double().cpu()) < 3e-6  # (fp32 sums of K = 2048 products in two groupings)
+        ctr = scratch.view(torch.int32)[:9]
         assert int(ctr.abs().sum()) == 0, "ticket / completion counters must be re-armed by the last workgroup"
         assert int(scratch.view(torch.int32)[16:16 + 512].max()) > 0, "no workgroup handed over a partial tile: stream-K did not run"
     finally:
