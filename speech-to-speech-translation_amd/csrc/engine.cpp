@@ -1722,7 +1722,13 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->build_params();
   if (!cfg->precise && (s2st_gemm_bf16_preload(nullptr) != 0 || s2st_flash_attn_preload(nullptr) != 0)) { delete e; return S2ST_ERR_LAUNCH; }
   if (!cfg->precise && !(getenv("S2ST_NO_SIDE_STREAM") && atoi(getenv("S2ST_NO_SIDE_STREAM")))) {
-    if (hipStreamCreateWithFlags(&e->side_, hipStreamNonBlocking) != hipSuccess) e->side_ = nullptr;
+    // the side stream carries weight gradients nobody waits for until the segment ends: lowest queue priority, so that
+    // when both queues have workgroups ready the data path (the critical chain of the backward) is dispatched first
+    // (S2ST_SIDE_PRIORITY=0: default priority, the A/B switch)
+    int pr_least = 0, pr_greatest = 0;
+    const bool low = !(getenv("S2ST_SIDE_PRIORITY") && atoi(getenv("S2ST_SIDE_PRIORITY")) == 0);
+    if (!low || hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest) != hipSuccess) pr_least = 0;
+    if (hipStreamCreateWithPriority(&e->side_, hipStreamNonBlocking, pr_least) != hipSuccess) e->side_ = nullptr;
     e->overlap_aux = !(getenv("S2ST_NO_AUX_OVERLAP") && atoi(getenv("S2ST_NO_AUX_OVERLAP")) != 0);
     if (e->side_ && hipEventCreateWithFlags(&e->ev_kv_, hipEventDisableTiming) != hipSuccess) e->ev_kv_ = nullptr;
     if (e->side_ && (hipEventCreateWithFlags(&e->ev_fork_, hipEventDisableTiming) != hipSuccess ||

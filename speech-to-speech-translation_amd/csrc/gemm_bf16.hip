@@ -1052,7 +1052,11 @@ bool prep_flags(GemmArgs& g) {
   return vec;
 }
 
-int persist_mode() {  // S2ST_GEMM_PERSIST: 0 = one-shot kernels only, 1 = launches with more tiles than CUs (default), 2 = all
+// S2ST_GEMM_PERSIST: 0 = one-shot kernels only, 1 = grouped launches persistent, single products one-shot (default:
+// with more tiles than CUs the hardware dispatcher back-fills CUs as one-shot workgroups retire, which balances better
+// than a fixed walk of 2.25 tiles per workgroup -- 10.05 vs 10.58 ms per training step, profiles/r02_ab_switches.txt),
+// 2 = every 128-row launch persistent, 3 = grouped launches and single products with more tiles than CUs
+int persist_mode() {
   const char* ev = getenv("S2ST_GEMM_PERSIST");  // read per call: an A/B switch the tests flip
   return ev ? atoi(ev) : 1;
 }
@@ -1215,7 +1219,7 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
   if (streamk_mode() > 0 && bm == 128 && bn == 128)
     for (int i = 0; i < g_sk_n; ++i) sk_bound = sk_bound || (g_sk[i].st == st && g_sk[i].p);
   if (dma_ok && g.batch == 1 && g.splitk == 1 && bm == 128 && persist_mode() > 0 &&
-      (persist_mode() == 2 || nt > num_cus() || (sk_bound && (long)nt * ((g.K + BK - 1) / BK) >= 8L * num_cus()))) {
+      (persist_mode() == 2 || (persist_mode() == 3 && nt > num_cus()) || (sk_bound && (long)nt * ((g.K + BK - 1) / BK) >= 8L * num_cus()))) {
     GemmGroup grp{};
     int rc;
     if (bn == 128) { add_to_group<128>(grp, g); rc = launch_persistent<128, 128, 4, 8>(grp, st); }

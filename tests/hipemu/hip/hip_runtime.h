@@ -205,6 +205,8 @@ static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hi
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipErrorInvalidValue; }  // no side streams in the emulator
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = nullptr; return hipErrorInvalidValue; }
+static inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 0; *greatest = 0; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
