@@ -173,6 +173,8 @@ def main():
                     "whole batch; default 8 for the HuBERT configuration, whose CPU front end is ~10x the model)")
     ap.add_argument("--cpu-whole", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--timeline", default=None, help="write the per-dispatch timeline (stream, start, duration on the GPU "
+                    "clock) of ONE replayed step to this file; tools/timeline.py summarises it")
     ap.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_leg:
@@ -405,8 +407,27 @@ def main():
                                 "frac": round(r["work"] / (r["us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
                                 "avg_launch_us": round(r["us"] / r["n"], 2),
                                 "launches_per_step": round(r["n"] / n_replay, 1)}
-                            for t, r in rows.items() if not t.startswith(("gemm_bf16", "flash_"))},
+                            for t, r in rows.items() if not t.startswith(("gemm_bf16", "flash_")) and r["work"] > 0},
         }
+
+    if args.timeline and rank == 0 and world == 1:
+        import ctypes as C
+        lib = bd.lib()
+        lib.s2st_profile_enable.argtypes = [C.c_int32]
+        lib.s2st_profile_timeline.argtypes = [C.c_char_p, C.c_int64]
+        lib.s2st_profile_timeline.restype = C.c_int64
+        step(args.warmup)
+        torch.cuda.synchronize()
+        lib.s2st_profile_enable(1)
+        step(args.warmup + 1)
+        torch.cuda.synchronize()
+        lib.s2st_profile_enable(0)
+        buf = C.create_string_buffer(1 << 20)
+        n = lib.s2st_profile_timeline(buf, len(buf))
+        os.makedirs(os.path.dirname(os.path.abspath(args.timeline)), exist_ok=True)
+        with open(args.timeline, "w") as f:
+            f.write(buf.value.decode() if n > 0 else "")
+        vlog("timeline of one step written to", args.timeline)
 
     # ---- CPU baseline leg: the oracle (torch fp32, all usable host cores) on one timed batch, in a child process
     #      with a hard time limit so a slow host can never stall the bench ----------------------------------------

@@ -465,6 +465,9 @@ int s2st_comm_destroy(s2st_comm* comm);
  * HBM-bound kernel has to move), clears the registry and returns the text length (-1: buffer too small). */
 int s2st_profile_enable(int32_t enable);
 int64_t s2st_profile_report(char* out, int64_t cap);
+/* Same registry as one line per dispatch in launch order: "tag\tstream\tstart_us\tdur_us\n" (stream = index in order of
+ * first use, start on the GPU clock relative to the first dispatch).  Clears the registry. */
+int64_t s2st_profile_timeline(char* out, int64_t cap);
 
 int s2st_version(void);
 /* number of HIP devices visible (0 = none: every compute entry point then fails) */

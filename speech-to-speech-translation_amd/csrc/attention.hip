@@ -491,12 +491,12 @@ int s2st_flash_attn_preload(hipStream_t st) {
   AttnArgs a{};
   auto go = [&](auto nwc) {
     constexpr int NW = decltype(nwc)::value;
-    hipLaunchKernelGGL((flash_fwd_kernel<128, NW>), dim3(1, 1), dim3(64 * NW), 0, st, a);
-    hipLaunchKernelGGL((flash_fwd_kernel<64, NW>), dim3(1, 1), dim3(64 * NW), 0, st, a);
-    hipLaunchKernelGGL((flash_bwd_kv_kernel<128, NW>), dim3(1, 1), dim3(64 * NW), 0, st, a);
-    hipLaunchKernelGGL((flash_bwd_kv_kernel<64, NW>), dim3(1, 1), dim3(64 * NW), 0, st, a);
-    hipLaunchKernelGGL((flash_bwd_q_kernel<128, NW>), dim3(1, 1), dim3(64 * NW), 0, st, a);
-    hipLaunchKernelGGL((flash_bwd_q_kernel<64, NW>), dim3(1, 1), dim3(64 * NW), 0, st, a);
+    S2ST_LAUNCH((flash_fwd_kernel<128, NW>), dim3(1, 1), dim3(64 * NW), 0, st, a);
+    S2ST_LAUNCH((flash_fwd_kernel<64, NW>), dim3(1, 1), dim3(64 * NW), 0, st, a);
+    S2ST_LAUNCH((flash_bwd_kv_kernel<128, NW>), dim3(1, 1), dim3(64 * NW), 0, st, a);
+    S2ST_LAUNCH((flash_bwd_kv_kernel<64, NW>), dim3(1, 1), dim3(64 * NW), 0, st, a);
+    S2ST_LAUNCH((flash_bwd_q_kernel<128, NW>), dim3(1, 1), dim3(64 * NW), 0, st, a);
+    S2ST_LAUNCH((flash_bwd_q_kernel<64, NW>), dim3(1, 1), dim3(64 * NW), 0, st, a);
   };
   const int nw = attn_nw();
   if (nw == 1) go(std::integral_constant<int, 1>{});
@@ -533,10 +533,10 @@ int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_sc
   const long rows = (long)p->B * p->T * p->H;
   if (phase > 1) {
   } else if (p->dh == 128)
-    hipLaunchKernelGGL(attn_dvec_kernel<128>, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, st, dO,
+    S2ST_LAUNCH(attn_dvec_kernel<128>, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, st, dO,
                        (const float*)p->o, dvec_scratch, p->B, p->H, p->T);
   else
-    hipLaunchKernelGGL(attn_dvec_kernel<64>, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, st, dO,
+    S2ST_LAUNCH(attn_dvec_kernel<64>, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, st, dO,
                        (const float*)p->o, dvec_scratch, p->B, p->H, p->T);
   auto go = [&](auto nwc) {
     constexpr int NW = decltype(nwc)::value;

@@ -232,6 +232,7 @@ int s2st_gemm_streamk_scratch(float* scratch, int64_t floats, void* stream) {
   return 0;
 }
 int s2st_profile_enable(int32_t enable) { s2st_profile_enable_impl(enable); return 0; }
-int64_t s2st_profile_report(char* out, int64_t cap) { return s2st_profile_report_impl(out, cap); }
+int64_t s2st_profile_report(char* out, int64_t cap) { return s2st_profile_report_impl(out, cap, 0); }
+int64_t s2st_profile_timeline(char* out, int64_t cap) { return s2st_profile_report_impl(out, cap, 1); }
 
 }  // extern "C"

@@ -7,6 +7,7 @@
 // (BatchNorm1d + tanh + dropout in the post-net), transformer_decoder.py:303-320 (token
 // embedding), fairseq/modules/fairseq_dropout.py:16-27.
 #include "s2st_ops.h"
+#include "s2st_prof.h"
 
 namespace {
 
@@ -409,10 +410,10 @@ int colreduce2(F f, int rows, int cols, float* out0, float* out1, float* scratch
   int rpb = (rows + slabs - 1) / slabs;
   if (rpb < 16) rpb = 16;
   slabs = (rows + rpb - 1) / rpb;
-  hipLaunchKernelGGL((colreduce2_kernel<F>), dim3(cb, slabs), dim3(256), 0, st, f, rows, cols, rpb, scratch);
+  S2ST_LAUNCH((colreduce2_kernel<F>), dim3(cb, slabs), dim3(256), 0, st, f, rows, cols, rpb, scratch);
   if (slabs_out) *slabs_out = slabs;
   if (out0)
-    hipLaunchKernelGGL(colreduce2_fold_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, (const float*)scratch, slabs,
+    S2ST_LAUNCH(colreduce2_fold_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, (const float*)scratch, slabs,
                        cols, out0, out1, acc0, acc1);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
@@ -526,7 +527,7 @@ int s2st_copy_rows(const float* x, Split xsp, float* y, Split ysp, int rows, int
   if (rows <= 0) return 0;
   if (C % 4) return S2ST_ERR_SHAPE;
   long n = (long)rows * (C / 4);
-  hipLaunchKernelGGL(copy_rows_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, xsp, y, ysp, rows, C / 4);
+  S2ST_LAUNCH(copy_rows_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, xsp, y, ysp, rows, C / 4);
   return LAUNCH_OK();
 }
 
@@ -535,7 +536,7 @@ int s2st_copy_rows_bf16(const uint16_t* x, Split xsp, uint16_t* y, Split ysp, in
   if (C % 4 || xsp.ld % 4 || ysp.ld % 4 || xsp.bs % 4 || ysp.bs % 4 || ((uintptr_t)x % 8) || ((uintptr_t)y % 8))
     return S2ST_ERR_SHAPE;
   long n = (long)rows * (C / 4);
-  hipLaunchKernelGGL(copy_rows_bf16_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, xsp, y, ysp, rows, C / 4);
+  S2ST_LAUNCH(copy_rows_bf16_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, xsp, y, ysp, rows, C / 4);
   return LAUNCH_OK();
 }
 
@@ -544,27 +545,27 @@ int s2st_cast_bf16_rows(const float* x, long ldx, uint16_t* y, long ldy, long ro
   if (ldy % 4 != 0 || ldy < cols) return S2ST_ERR_SHAPE;
   const int vec = ((uintptr_t)x % 16 == 0) && (ldx % 4 == 0);
   long n = rows * (ldy >> 2);
-  hipLaunchKernelGGL(cast_bf16_rows_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, ldx, y, ldy, rows, cols, vec);
+  S2ST_LAUNCH(cast_bf16_rows_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, ldx, y, ldy, rows, cols, vec);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
 int s2st_transpose_bf16(const uint16_t* x, uint16_t* y, int R, int C, hipStream_t st) {
   if (R <= 0 || C <= 0) return 0;
-  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, st, x, y, R, C);
+  S2ST_LAUNCH(transpose_bf16_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, st, x, y, R, C);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
 int s2st_transpose_bf16_batched(const uint16_t* x_base, uint16_t* y_base, const s2st_transpose_table& t, hipStream_t st) {
   if (t.n <= 0) return 0;
   if (t.n > S2ST_TRANSPOSE_MAX) return S2ST_ERR_ARG;
-  hipLaunchKernelGGL(transpose_bf16_batched_kernel, dim3(t.tile0[t.n]), dim3(256), 0, st, x_base, y_base, t);
+  S2ST_LAUNCH(transpose_bf16_batched_kernel, dim3(t.tile0[t.n]), dim3(256), 0, st, x_base, y_base, t);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
 int s2st_glu_fwd(const float* a, float* y, Split ysp, int rows, int C, hipStream_t st) {
   long n = (long)rows * C;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(glu_fwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, a, y, ysp, rows, C);
+  S2ST_LAUNCH(glu_fwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, a, y, ysp, rows, C);
   return LAUNCH_OK();
 }
 
@@ -572,7 +573,7 @@ int s2st_glu_bwd(const float* a, const float* dy, Split dysp, float* da, Split d
                  int C, hipStream_t st, uint16_t* dah, long ldh) {
   long n = (long)rows * C;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(glu_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, a, dy, dysp, da, dasp, rows, C, dah, ldh);
+  S2ST_LAUNCH(glu_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, a, dy, dysp, da, dasp, rows, C, dah, ldh);
   return LAUNCH_OK();
 }
 
@@ -580,7 +581,7 @@ int s2st_add_pe(const float* x, float* y, const int* pos, const float* table, in
                 float scale, const float* alpha_ptr, float drop_p, uint64_t seed, hipStream_t st) {
   long n = (long)rows * C;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(add_pe_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, y, pos, table, rows, C,
+  S2ST_LAUNCH(add_pe_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, y, pos, table, rows, C,
                      scale, alpha_ptr, drop_p, seed);
   return LAUNCH_OK();
 }
@@ -591,7 +592,7 @@ int s2st_pe_alpha_bwd(const float* dy, const int* pos, const float* table, int r
   if (n <= 0) return 0;
   unsigned g = ew_grid(n, 8);
   if (g > 1024) g = 1024;
-  hipLaunchKernelGGL(pe_alpha_bwd_kernel, dim3(g), dim3(EW_BLOCK), 0, st, dy, pos, table, rows, C,
+  S2ST_LAUNCH(pe_alpha_bwd_kernel, dim3(g), dim3(EW_BLOCK), 0, st, dy, pos, table, rows, C,
                      drop_p, seed, dalpha);
   return LAUNCH_OK();
 }
@@ -600,7 +601,7 @@ int s2st_embed_fwd(const long* tokens, const float* table, float* y, int rows, i
                    hipStream_t st) {
   long n = (long)rows * C;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(embed_fwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, tokens, table, y, rows, C, scale);
+  S2ST_LAUNCH(embed_fwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, tokens, table, y, rows, C, scale);
   return LAUNCH_OK();
 }
 
@@ -608,20 +609,20 @@ int s2st_embed_bwd(const long* tokens, const float* dy, float* dtable, int rows,
                    long pad, hipStream_t st) {
   long n = (long)rows * C;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, tokens, dy, dtable, rows, C, scale, pad);
+  S2ST_LAUNCH(embed_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, tokens, dy, dtable, rows, C, scale, pad);
   return LAUNCH_OK();
 }
 
 int s2st_dropout(const float* x, float* y, long n, float a, float p, uint64_t seed, int accumulate,
                  hipStream_t st) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, y, n, a, p, seed, accumulate);
+  S2ST_LAUNCH(dropout_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, y, n, a, p, seed, accumulate);
   return LAUNCH_OK();
 }
 
 int s2st_relu_drop_bwd(const float* dy, const float* y, float* dz, long n, float p, hipStream_t st) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, dy, y, dz, n,
+  S2ST_LAUNCH(relu_drop_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, dy, y, dz, n,
                      p > 0.f ? 1.f / (1.f - p) : 1.f);
   return LAUNCH_OK();
 }
@@ -639,21 +640,21 @@ int s2st_linear_bwd_prep(const float* dy, const float* y, const uint16_t* yb, in
   slabs = (M + rpb - 1) / rpb;
   const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
   dim3 grid(cb, slabs);
-  if (mode == 0) hipLaunchKernelGGL(dpre_kernel<0>, grid, dim3(256), 0, st, dy, y, yb, dph, ldp, dpre, dbias, M, N, rpb, p, ik, seed);
-  else if (mode == 1) hipLaunchKernelGGL(dpre_kernel<1>, grid, dim3(256), 0, st, dy, y, yb, dph, ldp, dpre, dbias, M, N, rpb, p, ik, seed);
-  else hipLaunchKernelGGL(dpre_kernel<2>, grid, dim3(256), 0, st, dy, y, yb, dph, ldp, dpre, dbias, M, N, rpb, p, ik, seed);
+  if (mode == 0) S2ST_LAUNCH(dpre_kernel<0>, grid, dim3(256), 0, st, dy, y, yb, dph, ldp, dpre, dbias, M, N, rpb, p, ik, seed);
+  else if (mode == 1) S2ST_LAUNCH(dpre_kernel<1>, grid, dim3(256), 0, st, dy, y, yb, dph, ldp, dpre, dbias, M, N, rpb, p, ik, seed);
+  else S2ST_LAUNCH(dpre_kernel<2>, grid, dim3(256), 0, st, dy, y, yb, dph, ldp, dpre, dbias, M, N, rpb, p, ik, seed);
   return LAUNCH_OK();
 }
 
 int s2st_axpy(const float* x, float* y, long n, float a, hipStream_t st) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(axpy_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, y, n, a);
+  S2ST_LAUNCH(axpy_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, y, n, a);
   return LAUNCH_OK();
 }
 
 int s2st_scale(float* x, long n, float a, hipStream_t st) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(scale_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, n, a);
+  S2ST_LAUNCH(scale_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, n, a);
   return LAUNCH_OK();
 }
 
@@ -661,14 +662,14 @@ int s2st_conv_w_permute(const float* w, float* wf, float* wd, int O, int I, int 
                         uint16_t* wdh) {
   long n = (long)O * I * Kw;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(conv_w_permute_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, w, wf, wd, O, I, Kw, wfh, wdh);
+  S2ST_LAUNCH(conv_w_permute_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, w, wf, wd, O, I, Kw, wfh, wdh);
   return LAUNCH_OK();
 }
 
 int s2st_conv_w_unpermute_acc(const float* dwf, float* dw, int O, int I, int Kw, hipStream_t st) {
   long n = (long)O * I * Kw;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(conv_w_unpermute_acc_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, dwf, dw, O, I, Kw);
+  S2ST_LAUNCH(conv_w_unpermute_acc_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, dwf, dw, O, I, Kw);
   return LAUNCH_OK();
 }
 
@@ -681,7 +682,7 @@ int s2st_bn_stats(const float* x, int rows, int C, float* mean, float* var, floa
   int slabs = 0;
   rc = colreduce2(SqDevF{x, tmp, C, 1.f / rows}, rows, C, nullptr, nullptr, tmp + 2 * (long)C, st, nullptr, nullptr, &slabs);
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + EW_BLOCK - 1) / EW_BLOCK), dim3(EW_BLOCK), 0, st,
+  S2ST_LAUNCH(bn_finalize_kernel, dim3((C + EW_BLOCK - 1) / EW_BLOCK), dim3(EW_BLOCK), 0, st,
                      (const float*)tmp, (const float*)(tmp + 2 * (long)C), slabs, mean, var, run_mean, run_var, C, rows,
                      momentum);
   return LAUNCH_OK();
@@ -692,7 +693,7 @@ int s2st_bn_apply(const float* x, const float* mean, const float* var, const flo
                   float eps, int tanh_, float drop_p, uint64_t seed, hipStream_t st) {
   long n = (long)rows * C;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, mean, var, gamma,
+  S2ST_LAUNCH(bn_apply_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, mean, var, gamma,
                      beta, y, ysp, resid, rows, C, eps, tanh_, drop_p, seed);
   return LAUNCH_OK();
 }
@@ -707,6 +708,6 @@ int s2st_bn_bwd(const float* dy, Split dysp, const float* x, const float* mean, 
   // sums of dy' and dy' * xhat; the fold also adds them to the parameter gradients
   int rc = colreduce2(f, rows, C, tmp, tmp + C, tmp + 2 * (long)C, st, dbeta, dgamma);
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, f, tmp, dx, dxsp, rows, C, dxh, ldh);
+  S2ST_LAUNCH(bn_bwd_dx_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, f, tmp, dx, dxsp, rows, C, dxh, ldh);
   return LAUNCH_OK();
 }

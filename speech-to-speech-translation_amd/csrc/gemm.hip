@@ -259,13 +259,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 template <int BM, int BN, bool PRECISE, bool VEC>
 void launch_layouts(const GemmArgs& g, dim3 grid, hipStream_t st) {
   if (g.A.kmajor && g.B.kmajor)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, PRECISE, VEC>), grid, dim3(256), 0, st, g);
+    S2ST_LAUNCH((gemm_kernel<BM, BN, true, true, PRECISE, VEC>), grid, dim3(256), 0, st, g);
   else if (g.A.kmajor && !g.B.kmajor)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false, PRECISE, VEC>), grid, dim3(256), 0, st, g);
+    S2ST_LAUNCH((gemm_kernel<BM, BN, true, false, PRECISE, VEC>), grid, dim3(256), 0, st, g);
   else if (!g.A.kmajor && g.B.kmajor)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true, PRECISE, VEC>), grid, dim3(256), 0, st, g);
+    S2ST_LAUNCH((gemm_kernel<BM, BN, false, true, PRECISE, VEC>), grid, dim3(256), 0, st, g);
   else
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false, PRECISE, VEC>), grid, dim3(256), 0, st, g);
+    S2ST_LAUNCH((gemm_kernel<BM, BN, false, false, PRECISE, VEC>), grid, dim3(256), 0, st, g);
 }
 
 // aligned-float4 fast path: pointer/strides 16-byte aligned and the contiguous extent a multiple of 4
@@ -279,20 +279,43 @@ bool vec_ok(const GemmOperand& o, int R, int K) {
 
 // ---- per-dispatch timing registry (bench.py roofline leg; s2st_prof.h) -----------------------------------------
 namespace {
-struct ProfRec { const char* tag; hipEvent_t a, b; double work, work2; };
+struct ProfRec { const char* tag; hipEvent_t a, b; double work, work2; hipStream_t st; };
 std::vector<ProfRec> g_prof;
 bool g_prof_on = false;
 }  // namespace
 
 bool s2st_prof_enabled() { return g_prof_on; }
-void s2st_prof_push(const char* tag, hipEvent_t a, hipEvent_t b, double work, double work2) {
-  g_prof.push_back(ProfRec{tag, a, b, work, work2});
+void s2st_prof_push(const char* tag, hipEvent_t a, hipEvent_t b, double work, double work2, hipStream_t st) {
+  g_prof.push_back(ProfRec{tag, a, b, work, work2, st});
 }
 void s2st_profile_enable_impl(int on) { g_prof_on = on != 0; }
 
 // One text line per tag: "tag\tlaunches\ttotal_us\twork\twork2\n" (work = FLOPs or bytes summed over the launches);
 // clears the registry.  Returns the number of bytes written (without the terminating 0) or -1 if `cap` is too small.
-long s2st_profile_report_impl(char* out, long cap) {
+// Timeline form (mode 1): one line per dispatch in launch order, "tag\tstream\tstart_us\tdur_us\n" -- stream = index
+// in order of first use, start relative to the first dispatch's start (GPU clock, across streams).
+static long profile_timeline(char* out, long cap) {
+  std::vector<hipStream_t> streams;
+  long o = 0;
+  for (auto& r : g_prof) hipEventSynchronize(r.b);
+  for (auto& r : g_prof) {
+    int si = -1;
+    for (size_t i = 0; i < streams.size(); ++i) if (streams[i] == r.st) si = (int)i;
+    if (si < 0) { streams.push_back(r.st); si = (int)streams.size() - 1; }
+    float t0 = 0.f, e = 0.f;
+    hipEventElapsedTime(&t0, g_prof[0].a, r.a);
+    hipEventElapsedTime(&e, r.a, r.b);
+    int w = snprintf(out + o, cap > o ? (size_t)(cap - o) : 0, "%s\t%d\t%.3f\t%.3f\n", r.tag, si, t0 * 1e3, e * 1e3);
+    if (w < 0 || o + w >= cap) { o = -1; break; }
+    o += w;
+  }
+  for (auto& r : g_prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  g_prof.clear();
+  return o;
+}
+
+long s2st_profile_report_impl(char* out, long cap, int mode) {
+  if (mode == 1) return profile_timeline(out, cap);
   struct Agg { const char* tag; long n; double us, work, work2; };
   std::vector<Agg> aggs;
   for (auto& r : g_prof) {

@@ -1368,7 +1368,7 @@ int s2st_gemm_skinny(const float* A, long lda, const bf16raw* W, long ldw, float
   if (M <= 0 || N <= 0) return 0;
   if (M > 16 || K <= 0 || K % 32 || lda % 4 || ldw % 8 || ((uintptr_t)A % 16) || ((uintptr_t)W % 16)) return S2ST_ERR_SHAPE;
   if (ln_g && (!ln_b || K % 64 || ((uintptr_t)ln_g % 16) || ((uintptr_t)ln_b % 16))) return S2ST_ERR_SHAPE;
-  hipLaunchKernelGGL(gemm_skinny_kernel, dim3((N + 15) / 16), dim3(256), 0, st, A, lda, reinterpret_cast<const bf16_t*>(W),
+  S2ST_LAUNCH(gemm_skinny_kernel, dim3((N + 15) / 16), dim3(256), 0, st, A, lda, reinterpret_cast<const bf16_t*>(W),
                      ldw, C, ldc, bias, act, drop_p, seed, resid, ldr, M, N, K, ln_g, ln_b, ln_eps);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }

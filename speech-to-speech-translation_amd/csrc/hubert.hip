@@ -6,6 +6,7 @@
 // (ConvFeatureExtractionModel, first block: Conv1d(1, C, k, stride) -> Fp32GroupNorm(C, C) -> GELU),
 // :868-876 (index_put(x, padding_mask, 0) and the grouped pos_conv input).
 #include "s2st_ops.h"
+#include "s2st_prof.h"
 
 namespace {
 
@@ -118,11 +119,11 @@ int s2st_hubert_conv0_gn_gelu(const float* x, const float* w, const float* gamma
   float *csum = stats, *sq = stats + (long)B * C;
   hipMemsetAsync(stats, 0, sizeof(float) * 2 * (size_t)B * C, st);
   const dim3 grid((T + C0_TT - 1) / C0_TT, B);
-  hipLaunchKernelGGL(hubert_conv0_gn_kernel<0>, grid, dim3(256), 0, st, x, w, csum, sq, gamma, beta, y, yh, B, N, T, C,
+  S2ST_LAUNCH(hubert_conv0_gn_kernel<0>, grid, dim3(256), 0, st, x, w, csum, sq, gamma, beta, y, yh, B, N, T, C,
                      k, stride, eps);
-  hipLaunchKernelGGL(hubert_conv0_gn_kernel<1>, grid, dim3(256), 0, st, x, w, csum, sq, gamma, beta, y, yh, B, N, T, C,
+  S2ST_LAUNCH(hubert_conv0_gn_kernel<1>, grid, dim3(256), 0, st, x, w, csum, sq, gamma, beta, y, yh, B, N, T, C,
                      k, stride, eps);
-  hipLaunchKernelGGL(hubert_conv0_gn_kernel<2>, grid, dim3(256), 0, st, x, w, csum, sq, gamma, beta, y, yh, B, N, T, C,
+  S2ST_LAUNCH(hubert_conv0_gn_kernel<2>, grid, dim3(256), 0, st, x, w, csum, sq, gamma, beta, y, yh, B, N, T, C,
                      k, stride, eps);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
@@ -132,7 +133,7 @@ int s2st_posconv_prep(float* x, const int* lens, float* img, uint16_t* imgh, int
   if (E % G || (E / G) % 4) return S2ST_ERR_SHAPE;
   const long n = (long)B * T * (E / 4);
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(posconv_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, lens, img, imgh, B, T,
+  S2ST_LAUNCH(posconv_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, lens, img, imgh, B, T,
                      E, G, pad, Tp);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }

@@ -7,6 +7,7 @@
 // fairseq/models/text_to_speech/vocoder.py:84-110 + fairseq/data/audio/audio_utils.py:259-271
 // (Griffin-Lim: polar <-> rectangular spectra around the dense-DFT GEMMs, overlap-add).
 #include "s2st_ops.h"
+#include "s2st_prof.h"
 
 namespace {
 
@@ -308,21 +309,21 @@ int s2st_decode_attn(const float* q, long ldq, const float* kc, const float* vc,
   if (B <= 0) return 0;
   if (nkeys > DA_MAXS || dh > 256 || dh % 4 || 256 % dh) return S2ST_ERR_SHAPE;
   if (attn_mean) hipMemsetAsync(attn_mean, 0, sizeof(float) * (size_t)B * S, st);
-  hipLaunchKernelGGL(decode_attn_kernel, dim3(B * H), dim3(256), 0, st, q, ldq, kc, vc, ldk, kbs, klen, nkeys, H, dh,
+  S2ST_LAUNCH(decode_attn_kernel, dim3(B * H), dim3(256), 0, st, q, ldq, kc, vc, ldk, kbs, klen, nkeys, H, dh,
                      scale, o, ldo, attn_mean, S);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
 int s2st_sigmoid(const float* x, float* y, long n, hipStream_t st) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(sigmoid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n);
+  S2ST_LAUNCH(sigmoid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
 int s2st_argmax_dim1(const float* x, long* idx, int B, int E, int D, hipStream_t st) {
   const long n = (long)B * D;
   if (n <= 0 || E <= 0) return 0;
-  hipLaunchKernelGGL(argmax_dim1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, idx, B, E, D);
+  S2ST_LAUNCH(argmax_dim1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, idx, B, E, D);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
@@ -330,7 +331,7 @@ int s2st_affine_cols(const float* x, const float* scale, const float* shift, flo
                      hipStream_t st) {
   const long n = rows * C;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(affine_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, scale, shift, y, rows,
+  S2ST_LAUNCH(affine_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, scale, shift, y, rows,
                      C);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
@@ -338,40 +339,40 @@ int s2st_affine_cols(const float* x, const float* scale, const float* shift, flo
 int s2st_exp_transpose(const float* x, float* y, int T, int C, hipStream_t st) {
   const long n = (long)T * C;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(exp_transpose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, T, C);
+  S2ST_LAUNCH(exp_transpose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, T, C);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 int s2st_clamp_min(float* x, long n, float lo, hipStream_t st) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(clamp_min_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n, lo);
+  S2ST_LAUNCH(clamp_min_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n, lo);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
 int s2st_gl_polar(const float* mag, const float* ang, float* X, int F, int T, hipStream_t st) {
   const long n = (long)F * T;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(gl_polar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mag, ang, X, F, T);
+  S2ST_LAUNCH(gl_polar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mag, ang, X, F, T);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
 int s2st_gl_project(const float* mag, const float* Y, float* X, int F, int T, hipStream_t st) {
   const long n = (long)F * T;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(gl_project_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mag, Y, X, F, T);
+  S2ST_LAUNCH(gl_project_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mag, Y, X, F, T);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
 int s2st_reflect_pad(const float* x, float* y, int n, int pad, hipStream_t st) {
   if (n <= pad) return S2ST_ERR_SHAPE;
   const long m = (long)n + 2 * pad;
-  hipLaunchKernelGGL(reflect_pad_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, x, y, n, pad);
+  S2ST_LAUNCH(reflect_pad_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, x, y, n, pad);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
 int s2st_gl_overlap_add(const float* frames, const float* wsq, float* wave, int T, int n_fft, int hop, int n_out,
                         hipStream_t st) {
   if (n_out <= 0) return 0;
-  hipLaunchKernelGGL(gl_overlap_add_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, frames, wsq, wave,
+  S2ST_LAUNCH(gl_overlap_add_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, frames, wsq, wave,
                      T, n_fft, hop, n_out, 1.1754944e-38f);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
@@ -383,9 +384,9 @@ int s2st_gl_polar_split(const float* mag, const float* aux, int from_spectrum, c
   if (n <= 0) return 0;
   const dim3 grid((unsigned)((n + 255) / 256));
   if (from_spectrum)
-    hipLaunchKernelGGL(gl_polar_split_kernel<1>, grid, dim3(256), 0, st, mag, aux, tl, Xs, U, F, Fp, Tmax);
+    S2ST_LAUNCH(gl_polar_split_kernel<1>, grid, dim3(256), 0, st, mag, aux, tl, Xs, U, F, Fp, Tmax);
   else
-    hipLaunchKernelGGL(gl_polar_split_kernel<0>, grid, dim3(256), 0, st, mag, aux, tl, Xs, U, F, Fp, Tmax);
+    S2ST_LAUNCH(gl_polar_split_kernel<0>, grid, dim3(256), 0, st, mag, aux, tl, Xs, U, F, Fp, Tmax);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 int s2st_gl_frame_split(const float* wave, const int* tl, uint16_t* As, int U, int Tmax, int hop, int n_fft, int Lw,
@@ -393,7 +394,7 @@ int s2st_gl_frame_split(const float* wave, const int* tl, uint16_t* As, int U, i
   if (n_fft % 4) return S2ST_ERR_SHAPE;
   const long n = (long)U * Tmax * (n_fft / 4);
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(gl_frame_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wave, tl, As, U, Tmax,
+  S2ST_LAUNCH(gl_frame_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wave, tl, As, U, Tmax,
                      hop, n_fft, Lw);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
@@ -401,7 +402,7 @@ int s2st_gl_overlap_add_b(const float* frames, const float* wsq_all, const long*
                           int U, int Tmax, int n_fft, int hop, int Lw, hipStream_t st) {
   const long n = (long)U * Lw;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(gl_overlap_add_b_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, frames, wsq_all,
+  S2ST_LAUNCH(gl_overlap_add_b_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, frames, wsq_all,
                      wsq_off, tl, wave, U, Tmax, n_fft, hop, Lw, 1.1754944e-38f);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }

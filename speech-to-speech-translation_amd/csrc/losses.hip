@@ -6,6 +6,7 @@
 // (compute_loss), :33-50 + :330-348 (label_smoothed_nll_loss, accuracy), :229-243 with
 // s2st_transformer.py:458-463 (log_softmax + torch.nn.CTCLoss(mean, zero_infinity)).
 #include "s2st_ops.h"
+#include "s2st_prof.h"
 
 namespace {
 
@@ -321,7 +322,7 @@ int s2st_mel_loss(const float* feat, const float* post, const float* eos, const 
   if (n <= 0) return 0;
   long blocks = (n + 256 * 4 - 1) / (256 * 4);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(mel_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, st, feat, post, eos, tgt,
+  S2ST_LAUNCH(mel_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, st, feat, post, eos, tgt,
                      lens, B, D, F, pos_weight, stats, c_l1, c_mse, c_eos, dfeat, dpost, deos);
   return LAUNCH_OK();
 }
@@ -331,7 +332,7 @@ int s2st_ls_ce(const float* logits, const long* target, int rows, int V, long pa
   if (rows <= 0) return 0;
   int blocks = (rows + 3) / 4;
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(ls_ce_kernel, dim3(blocks), dim3(256), 0, st, logits, target, rows, V, pad, eps,
+  S2ST_LAUNCH(ls_ce_kernel, dim3(blocks), dim3(256), 0, st, logits, target, rows, V, pad, eps,
                      stats, dlogits, gscale);
   return LAUNCH_OK();
 }
@@ -347,7 +348,7 @@ int s2st_ctc(const float* logits, const long* targets, int Lmax, const int* in_l
   if (B <= 0) return 0;
   if (2 * Lmax + 1 > CTC_MAXS || V > CTC_MAXV) return S2ST_ERR_SHAPE;
   int ss = ((2 * Lmax + 1 + 3) / 4) * 4;
-  hipLaunchKernelGGL(ctc_kernel, dim3(B), dim3(256), 0, st, logits, targets, Lmax, in_lens, tgt_lens,
+  S2ST_LAUNCH(ctc_kernel, dim3(B), dim3(256), 0, st, logits, targets, Lmax, in_lens, tgt_lens,
                      E, V, lprobs, ws, ss, loss_per_utt, dlogits, gscale);
   return LAUNCH_OK();
 }
@@ -355,13 +356,13 @@ int s2st_ctc(const float* logits, const long* targets, int Lmax, const int* in_l
 int s2st_loss_finalize(float* stats, const float* ctc_per, int B, float nf, float nr, float w_l1,
                        float w_mse, float w_eos, float w_ctc, float w_asr, float w_st, float eps, int Vs,
                        int Vt, float src_ntok, float tgt_ntok, hipStream_t st, const float* ctc_tgt_per, float w_ctc_tgt) {
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, stats, ctc_per, B, nf, nr, w_l1, w_mse,
+  S2ST_LAUNCH(loss_finalize_kernel, dim3(1), dim3(64), 0, st, stats, ctc_per, B, nf, nr, w_l1, w_mse,
                      w_eos, w_ctc, w_asr, w_st, eps, Vs, Vt, src_ntok, tgt_ntok, ctc_tgt_per, w_ctc_tgt);
   return LAUNCH_OK();
 }
 
 int s2st_log_softmax_rows(const float* x, long ldx, float* y, long ldy, int rows, int V, int log_out, hipStream_t st) {
   if (rows <= 0 || V <= 0) return 0;
-  hipLaunchKernelGGL(log_softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, y, ldy, rows, V, log_out);
+  S2ST_LAUNCH(log_softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, y, ldy, rows, V, log_out);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }

@@ -6,6 +6,7 @@
 // [left, up-left, up], backtrace -> path map), :463-471 (compute_l2_dist / compute_rms_dist),
 // :526-552 (batch_mel_cepstral_distortion's MFCC features; torchaudio in the reference).
 #include "s2st_ops.h"
+#include "s2st_prof.h"
 
 namespace {
 
@@ -97,26 +98,26 @@ __global__ __launch_bounds__(256) void log_offset_kernel(float* __restrict__ x, 
 int s2st_dtw(const float* dist, const int* shapes, int B, int M, int N, float* cum, int* backptr, int* pathmap,
              hipStream_t st) {
   if (B <= 0 || M <= 0 || N <= 0) return 0;
-  hipLaunchKernelGGL(dtw_kernel, dim3(B), dim3(256), 0, st, dist, shapes, cum, backptr, pathmap, M, N);
+  S2ST_LAUNCH(dtw_kernel, dim3(B), dim3(256), 0, st, dist, shapes, cum, backptr, pathmap, M, N);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
 int s2st_rms_dist(const float* x1, const float* x2, float* out, int m, int n, int D, long ldo, hipStream_t st) {
   const long t = (long)m * n;
   if (t <= 0) return 0;
-  hipLaunchKernelGGL(rms_dist_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, st, x1, x2, out, m, n, D, ldo);
+  S2ST_LAUNCH(rms_dist_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, st, x1, x2, out, m, n, D, ldo);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
 int s2st_power_spec(const float* Y, float* P, int T, int F, hipStream_t st) {
   const long t = (long)T * F;
   if (t <= 0) return 0;
-  hipLaunchKernelGGL(power_spec_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, st, Y, P, T, F);
+  S2ST_LAUNCH(power_spec_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, st, Y, P, T, F);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
 int s2st_log_offset(float* x, long n, float eps, hipStream_t st) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(log_offset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n, eps);
+  S2ST_LAUNCH(log_offset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n, eps);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }

@@ -427,7 +427,7 @@ int s2st_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
     else
       s2st_launch("layernorm_bwd_param_kernel<false>", by, 0.0, layernorm_bwd_param_kernel<false>, grid, dim3(256), 0, st, dy,
                   x, mean, rstd, (const uint16_t*)nullptr, scratch, rows, cols, rpb);
-    hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((nout * cols + 31) / 32), dim3(256), 0, st,
+    S2ST_LAUNCH(layernorm_bwd_reduce_kernel, dim3((nout * cols + 31) / 32), dim3(256), 0, st,
                        (const float*)scratch, blocks, cols, dgamma, dbeta, nout, dbias);
   }
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
@@ -440,7 +440,7 @@ int s2st_softmax_fwd(const float* s, float* p, float* pd, const int* klen, int B
   if (rows <= 0) return 0;
   if (S > SM_MAXE * 64 || ld > SM_MAXE * 64) return S2ST_ERR_SHAPE;
   if (drop_p <= 0.f) pd = nullptr;
-  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, s, p,
+  S2ST_LAUNCH(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, s, p,
                      pd, klen, B, H, T, S, ld, causal, drop_p, seed, pdh);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
@@ -450,7 +450,7 @@ int s2st_softmax_bwd(const float* p, const float* dpd, float* ds, int B, int H, 
   long rows = (long)B * H * T;
   if (rows <= 0) return 0;
   if (S > SM_MAXE * 64 || ld > SM_MAXE * 64) return S2ST_ERR_SHAPE;
-  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p,
+  S2ST_LAUNCH(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p,
                      dpd, ds, rows, S, ld, drop_p, seed, dsh);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
@@ -465,7 +465,7 @@ int s2st_colsum(const float* x, long ld, int rows, int cols, float* out, int acc
   int rpb = (rows + slabs - 1) / slabs;
   if (rpb < 16) rpb = 16;
   slabs = (rows + rpb - 1) / rpb;
-  hipLaunchKernelGGL(colsum_kernel, dim3(cb, slabs), dim3(256), 0, st, x, ld, rows, cols, out, rpb);
+  S2ST_LAUNCH(colsum_kernel, dim3(cb, slabs), dim3(256), 0, st, x, ld, rows, cols, out, rpb);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
@@ -477,7 +477,7 @@ int s2st_colsum_bf16(const uint16_t* x, long ld, int rows, int cols, float* out,
   int rpb = (rows + slabs - 1) / slabs;
   if (rpb < 16) rpb = 16;
   slabs = (rows + rpb - 1) / rpb;
-  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cb, slabs), dim3(256), 0, st, x, ld, rows, cols, out, rpb);
+  S2ST_LAUNCH(colsum_bf16_kernel, dim3(cb, slabs), dim3(256), 0, st, x, ld, rows, cols, out, rpb);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
@@ -485,7 +485,7 @@ int s2st_attn_headmean(const float* p, float* out, int B, int H, int T, int S, i
                        hipStream_t st) {
   long n = (long)B * T * S;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(headmean_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, out,
+  S2ST_LAUNCH(headmean_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, out,
                      B, H, T, S, ld);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }

@@ -84,7 +84,7 @@ int s2st_gemm_skinny(const float* A, long lda, const bf16raw* W, long ldw, float
                      const float* ln_g = nullptr, const float* ln_b = nullptr, float ln_eps = 1e-5f /* optional fused LayerNorm of x */);
 int s2st_gemm_bf16_preload(hipStream_t st);  // load every instantiation (empty launches)  // gemm_bf16.hip (both operands bf16)
 void s2st_profile_enable_impl(int on);                 // per-dispatch timing registry (s2st_prof.h, gemm.hip)
-long s2st_profile_report_impl(char* out, long cap);
+long s2st_profile_report_impl(char* out, long cap, int mode = 0);
 
 // ---------------------------------------------------------------------------------------
 // row ops (rowops.hip)

@@ -11,7 +11,7 @@
 #include <hip/hip_ext.h>
 
 bool s2st_prof_enabled();
-void s2st_prof_push(const char* tag, hipEvent_t a, hipEvent_t b, double work, double work2);
+void s2st_prof_push(const char* tag, hipEvent_t a, hipEvent_t b, double work, double work2, hipStream_t st);
 
 // work: FLOPs (MFMA-bound kernels) or bytes (HBM-bound kernels) of this launch; work2: free second figure
 template <class K, class... A>
@@ -25,5 +25,8 @@ inline void s2st_launch(const char* tag, double work, double work2, K kern, dim3
   hipEventCreate(&a);
   hipEventCreate(&b);
   hipExtLaunchKernelGGL(kern, grid, block, lds, st, a, b, 0, args...);
-  s2st_prof_push(tag, a, b, work, work2);
+  s2st_prof_push(tag, a, b, work, work2, st);
 }
+
+// every other launch site: tag = the kernel expression as written, no work figure (timeline mode of the report)
+#define S2ST_LAUNCH(kern, grid, block, lds, st, ...) s2st_launch(#kern, 0.0, 0.0, kern, grid, block, lds, st, __VA_ARGS__)
