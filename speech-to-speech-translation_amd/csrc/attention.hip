@@ -283,17 +283,15 @@ __global__ __launch_bounds__(256) void attn_dvec_kernel(const float* __restrict_
 //   dK^T[d][key] += Q^T[d][q] dS[q][key]   (scaled at the end)
 // ------------------------------------------------------------------------------------------------
 template <int DH, int NW>
-__global__ __launch_bounds__(64 * NW) void flash_bwd_kv_kernel(AttnArgs a) {
+__device__ __forceinline__ void flash_bwd_kv_body(const AttnArgs& a, unsigned char* smem, const int bx) {
   constexpr int KS = DH / 32, DT = DH / 16;
-  if (a.T <= 0 || a.S <= 0) return;  // empty problem (kernel preload)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * Img<DH>::BYTES];
   unsigned char* q_row = smem;
   unsigned char* q_tr = smem + Img<DH>::BYTES;
   unsigned char* do_row = smem + 2 * Img<DH>::BYTES;
   unsigned char* do_tr = smem + 3 * Img<DH>::BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
-  const int k0 = blockIdx.x * (16 * NW) + wave * 16;
+  const int k0 = bx * (16 * NW) + wave * 16;
   const int ki = k0 + (lane & 15);  // this lane's key (column)
   const bf16_t* qb = a.q + (long)b * a.T * a.ldq + h * DH;
   const bf16_t* kb = a.k + (long)b * a.S * a.ldk + h * DH;
@@ -301,7 +299,7 @@ __global__ __launch_bounds__(64 * NW) void flash_bwd_kv_kernel(AttnArgs a) {
   const bf16_t* dob = a.doh + (long)b * a.T * ((long)a.H * DH) + h * DH;
   const int klim = a.klen ? min((int)a.klen[b], a.S) : a.S;
   const bool key_ok = ki < klim;
-  const int qbeg = a.causal ? (blockIdx.x * (16 * NW)) & ~31 : 0;  // queries < first key of the block see none of it
+  const int qbeg = a.causal ? (bx * (16 * NW)) & ~31 : 0;  // queries < first key of the block see none of it
 
   bf16x8 kf[KS], vf[KS];
   load_frags<DH>(kb, a.ldk, k0, a.S, lane, kf);
@@ -376,23 +374,21 @@ __global__ __launch_bounds__(64 * NW) void flash_bwd_kv_kernel(AttnArgs a) {
 //   dQ^T[d][q] += K^T[d][key] dS^T[key][q]
 // ------------------------------------------------------------------------------------------------
 template <int DH, int NW>
-__global__ __launch_bounds__(64 * NW) void flash_bwd_q_kernel(AttnArgs a) {
+__device__ __forceinline__ void flash_bwd_q_body(const AttnArgs& a, unsigned char* smem, const int bx) {
   constexpr int KS = DH / 32, DT = DH / 16;
-  if (a.T <= 0 || a.S <= 0) return;  // empty problem (kernel preload)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * Img<DH>::BYTES];
   unsigned char* k_row = smem;
   unsigned char* k_tr = smem + Img<DH>::BYTES;
   unsigned char* v_row = smem + 2 * Img<DH>::BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
-  const int q0 = blockIdx.x * (16 * NW) + wave * 16;
+  const int q0 = bx * (16 * NW) + wave * 16;
   const int qi = q0 + (lane & 15);
   const bf16_t* qb = a.q + (long)b * a.T * a.ldq + h * DH;
   const bf16_t* kb = a.k + (long)b * a.S * a.ldk + h * DH;
   const bf16_t* vb = a.v + (long)b * a.S * a.ldv + h * DH;
   const bf16_t* dob = a.doh + (long)b * a.T * ((long)a.H * DH) + h * DH;
   const int klim = a.klen ? min((int)a.klen[b], a.S) : a.S;
-  const int kmax = a.causal ? min(klim, (int)(blockIdx.x + 1) * (16 * NW)) : klim;
+  const int kmax = a.causal ? min(klim, (bx + 1) * (16 * NW)) : klim;
 
   bf16x8 qf[KS], dof[KS];
   load_frags<DH>(qb, a.ldq, q0, a.T, lane, qf);
@@ -456,6 +452,32 @@ __global__ __launch_bounds__(64 * NW) void flash_bwd_q_kernel(AttnArgs a) {
   }
 }
 
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW) void flash_bwd_kv_kernel(AttnArgs a) {
+  if (a.T <= 0 || a.S <= 0) return;  // empty problem (kernel preload)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * Img<DH>::BYTES];
+  flash_bwd_kv_body<DH, NW>(a, smem, (int)blockIdx.x);
+}
+
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW) void flash_bwd_q_kernel(AttnArgs a) {
+  if (a.T <= 0 || a.S <= 0) return;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * Img<DH>::BYTES];
+  flash_bwd_q_body<DH, NW>(a, smem, (int)blockIdx.x);
+}
+
+// Both passes in ONE launch: workgroups [0, nkx) of a (b, h) row are key blocks (dK, dV), the rest query blocks (dQ).
+// The two passes share nothing but their inputs, so one dispatch (one kernel boundary on the data-path stream instead of
+// two -- ~4 us each between dependent kernels, profiles/r02_b_timeline_summary_all_dispatches.txt) lets the short
+// query blocks fill the tail of the key blocks.
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW) void flash_bwd_kernel(AttnArgs a, int nkx) {
+  if (a.T <= 0 || a.S <= 0) return;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * Img<DH>::BYTES];
+  if ((int)blockIdx.x < nkx) flash_bwd_kv_body<DH, NW>(a, smem, (int)blockIdx.x);
+  else flash_bwd_q_body<DH, NW>(a, smem, (int)blockIdx.x - nkx);
+}
+
 // waves per workgroup (16 columns each): 2 -> T/32 x B*H workgroups, several resident per CU, so the
 // barrier / global-load latency of one overlaps the MFMAs of another (sequences here are 100-750 long)
 constexpr int ANW = 4;  // default (measured: 4 > 2 > 1 on the bench step)
@@ -497,6 +519,8 @@ int s2st_flash_attn_preload(hipStream_t st) {
     S2ST_LAUNCH((flash_bwd_kv_kernel<64, NW>), dim3(1, 1), dim3(64 * NW), 0, st, a);
     S2ST_LAUNCH((flash_bwd_q_kernel<128, NW>), dim3(1, 1), dim3(64 * NW), 0, st, a);
     S2ST_LAUNCH((flash_bwd_q_kernel<64, NW>), dim3(1, 1), dim3(64 * NW), 0, st, a);
+    S2ST_LAUNCH((flash_bwd_kernel<128, NW>), dim3(1, 1), dim3(64 * NW), 0, st, a, 1);
+    S2ST_LAUNCH((flash_bwd_kernel<64, NW>), dim3(1, 1), dim3(64 * NW), 0, st, a, 1);
   };
   const int nw = attn_nw();
   if (nw == 1) go(std::integral_constant<int, 1>{});
@@ -544,7 +568,12 @@ int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_sc
     const bool kv = phase == 0 || phase == 2, qq = phase == 0 || phase == 3;
     // as-launched FLOPs: dK,dV pass = S^T recompute + dP + dV + dK (4 products), dQ pass = S + dP + dQ (3 products)
     const double f1 = 2.0 * p->B * p->H * (double)p->T * p->S * p->dh * (p->causal ? 0.5 : 1.0);
-    if (p->dh == 128) {
+    const bool split = getenv("S2ST_ATTN_BWD_SPLIT") && atoi(getenv("S2ST_ATTN_BWD_SPLIT")) != 0;  // A/B switch (per call: tests flip it)
+    if (kv && qq && !split) {
+      dim3 g2(gk.x + gq.x, gk.y);
+      if (p->dh == 128) s2st_launch("flash_bwd_kernel<128>", 7 * f1, 0.0, flash_bwd_kernel<128, NW>, g2, dim3(64 * NW), 0, st, a, (int)gk.x);
+      else s2st_launch("flash_bwd_kernel<64>", 7 * f1, 0.0, flash_bwd_kernel<64, NW>, g2, dim3(64 * NW), 0, st, a, (int)gk.x);
+    } else if (p->dh == 128) {
       if (kv) s2st_launch("flash_bwd_kv_kernel<128>", 4 * f1, 0.0, flash_bwd_kv_kernel<128, NW>, gk, dim3(64 * NW), 0, st, a);
       if (qq) s2st_launch("flash_bwd_q_kernel<128>", 3 * f1, 0.0, flash_bwd_q_kernel<128, NW>, gq, dim3(64 * NW), 0, st, a);
     } else {
