@@ -188,11 +188,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    # S2ST_BENCH_SHARE_GPU=1 (a check of the N > 1 code path on a one-GPU box, never a measurement): every rank drives
+    # cuda:0 and gloo carries the gradient bytes through pinned host memory -- RCCL refuses two ranks on one device
+    share = world > 1 and os.environ.get("S2ST_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if share:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=dev)
 
     import s2st_amd  # noqa: F401
     C_ = importlib.import_module(PKG + ".configs")
@@ -321,7 +329,7 @@ def main():
                                                      for j in range(1, len(step_ev))))
     my_frames = float(sum(frames[args.warmup:]))
     my_flops = 3.0 * 2.0 * sum(macs[args.warmup:])  # fwd + bwd = 3 x fwd, 2 FLOP per MAC
-    stat = torch.tensor([dt, my_frames, my_flops], dtype=torch.float64, device=dev)
+    stat = torch.tensor([dt, my_frames, my_flops], dtype=torch.float64, device="cpu" if share else dev)
     if world > 1:
         tmax = stat[:1].clone()
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
