@@ -163,7 +163,7 @@ def cpu_leg(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)  # ~1 s of timed work: long enough for an external utilisation sampler
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="base_recipe")
     ap.add_argument("--max-tokens", type=int, default=20000)

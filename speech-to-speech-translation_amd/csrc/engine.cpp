@@ -467,7 +467,10 @@ struct s2st_engine {
     if (live()) {
       // everything the products read was enqueued on st_ before this point
       hipStream_t s = (side_ && st_ != side_) ? fork_side() : st_;
-      chk(s2st_gemm_bf16_group(pending_wgrad.data(), (int)pending_wgrad.size(), s));
+      // S2ST_TIMING_SKIP_WGRAD=1: a TIMING experiment only (wrong gradients): how much of the step is the weight-gradient
+      // products' share of the chip
+      static const bool skip = getenv("S2ST_TIMING_SKIP_WGRAD") && atoi(getenv("S2ST_TIMING_SKIP_WGRAD")) != 0;
+      if (!skip) chk(s2st_gemm_bf16_group(pending_wgrad.data(), (int)pending_wgrad.size(), s));
     }
     pending_wgrad.clear();
   }

@@ -728,9 +728,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
   };
   if (ci.ph != 3) init_issue();
   // (NS - 2 stages here, the next one at the first read_step: a refill then always targets the slot of step
-  // nread - 2, whose fragment reads have been consumed by MFMAs that every wave has issued before the barrier)
+  // nread - 2, whose fragment reads have been consumed by MFMAs that every wave has issued before the barrier.
+  // 256-row tiles keep ONE fragment register set (two would spill): the fragments of step n are read after the MFMAs
+  // of step n - 1, the slot of step n - 1 is free at the barrier of step n, so the ring runs one stage deeper)
+  constexpr bool DBUF = BM <= 128;
 #pragma unroll
-  for (int s = 0; s < NS - 2; ++s) advance_issue();
+  for (int s = 0; s < (DBUF ? NS - 2 : NS - 1); ++s) advance_issue();
 
   // ---- read cursor (the K-step whose fragments go LDS -> registers next) and multiply cursor ------------------
   // The fragments of step c + 1 are read while the MFMAs of step c run (two register sets, the loop body is
@@ -838,13 +841,18 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
   };
   if (cc.ph != 3) init_comp();
 
-  Frag F0, F1;
+  Frag F0;
+  Frag F1_[1];  // (dead, hence no registers, in the single-set form)
   if (cr.ph != 3) {
     init_read();
-    read_step(F0);
+    if (DBUF) read_step(F0);
   }
   auto body = [&](Frag& Fc, Frag& Fn) {
-    if (cr.ph != 3) read_step(Fn);  // in flight under the MFMAs below
+    if (DBUF) {
+      if (cr.ph != 3) read_step(Fn);  // in flight under the MFMAs below
+    } else {
+      read_step(Fc);
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -868,10 +876,14 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
       if (cc.ph != 3) init_comp();
     }
   };
-  while (cc.ph != 3) {
-    body(F0, F1);
-    if (cc.ph == 3) break;
-    body(F1, F0);
+  if constexpr (DBUF) {
+    while (cc.ph != 3) {
+      body(F0, F1_[0]);
+      if (cc.ph == 3) break;
+      body(F1_[0], F0);
+    }
+  } else {
+    while (cc.ph != 3) body(F0, F0);
   }
   if (SK) {  // the last workgroup to leave re-arms the counters for the next launch on this stream
     __syncthreads();
@@ -1102,6 +1114,22 @@ int s2st_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t st) {
     if (!prep_flags(g) || g.A.kmajor != list[0].A.kmajor || g.B.kmajor != list[0].B.kmajor) return S2ST_ERR_ARG;
     add_to_group<128>(grp, g);
   }
+  // S2ST_GROUP_TILE=256: 256 x 128 tiles (48 KB of operands per K-step for twice the FLOPs: half the workgroups, which
+  // leaves CUs to the data-path stream the group runs beside)
+  const char* gt = getenv("S2ST_GROUP_TILE");
+  bool big = gt && atoi(gt) == 256;
+  for (int i = 0; i < n && big; ++i) big = list[i].M >= 256;
+  if (big) {
+    GemmGroup g2{};
+    for (int i = 0; i < n; ++i) {
+      GemmArgs g = list[i];
+      if (g.zdiv <= 0) g.zdiv = 1;
+      prep_flags(g);
+      add_to_group<128, 256>(g2, g);
+    }
+    if (launch_persistent<256, 128, 3, 8>(g2, st)) return S2ST_ERR_LAUNCH;
+    return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+  }
   if (launch_persistent<128, 128, 4, 8>(grp, st)) return S2ST_ERR_LAUNCH;
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
@@ -1132,6 +1160,7 @@ int s2st_gemm_bf16_preload(hipStream_t st) {
     grp.g[0] = g;
     rc |= launch_persistent<128, 128, 4, 8>(grp, st);
     rc |= launch_persistent<128, 64, 4, 8>(grp, st);
+    rc |= launch_persistent<256, 128, 3, 8>(grp, st);
     rc |= launch_dma<256, 128, 3, 8>(g, grid, st);
   }
   return rc || hipGetLastError() != hipSuccess ? -1 : 0;
@@ -1219,7 +1248,7 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
   if (streamk_mode() > 0 && bm == 128 && bn == 128)
     for (int i = 0; i < g_sk_n; ++i) sk_bound = sk_bound || (g_sk[i].st == st && g_sk[i].p);
   if (dma_ok && g.batch == 1 && g.splitk == 1 && bm == 128 && persist_mode() > 0 &&
-      (persist_mode() == 2 || (persist_mode() == 3 && nt > num_cus()) || (sk_bound && (long)nt * ((g.K + BK - 1) / BK) >= 8L * num_cus()))) {
+      (persist_mode() == 2 || (persist_mode() == 3 && nt > num_cus()) || (sk_bound && (nt > num_cus() || (long)nt * ((g.K + BK - 1) / BK) >= 8L * num_cus())))) {
     GemmGroup grp{};
     int rc;
     if (bn == 128) { add_to_group<128>(grp, g); rc = launch_persistent<128, 128, 4, 8>(grp, st); }

@@ -378,13 +378,18 @@ def test_bf16_persistent_kernel(backend, monkeypatch, akm, bkm, K):
     assert torch.equal(C3, C)
 
 
-def test_bf16_group_of_weight_gradients(backend):
+@pytest.mark.parametrize("tile", [128, 256])
+def test_bf16_group_of_weight_gradients(backend, monkeypatch, tile):
     """s2st_gemm_group_f32: a layer's weight-gradient products dW_i += dY_i^T X_i (different shapes, K = tokens, one with
-    a K tail) in one launch, against the exact sums."""
+    a K tail) in one launch, against the exact sums; 128 x 128 tiles and (S2ST_GROUP_TILE=256) 256 x 128 tiles with a
+    ragged last tile row."""
+    monkeypatch.setenv("S2ST_GROUP_TILE", str(tile))
     d = backend.device
     g = torch.Generator().manual_seed(21)
     T1, T2 = (200, 136) if backend.kind == "emu" else (4584, 3120)
     shapes = [(256, 128, T1), (128, 256, T1), (128, 128, T2), (384, 128, T2)]
+    if tile == 256:
+        shapes = [(256, 128, T1), (512, 256, T1), (320, 128, T2), (384, 384, T2)]
     keep, probs, refs = [], [], []
     for (N_out, K_in, T) in shapes:
         dY, X = _bf(torch.randn(T, N_out, generator=g)), _bf(torch.randn(T, K_in, generator=g))
