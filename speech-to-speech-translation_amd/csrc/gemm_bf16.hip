@@ -56,6 +56,7 @@ struct Stage {
   static constexpr int RC = ROWS / 8;         // chunks per k row (rows-contiguous image)
   static constexpr int PITCH = KM ? 128 : ROWS * 2;
   static constexpr int BYTES = ROWS * 128;
+  static constexpr int READS_PER_FRAG = KM ? 1 : 2;  // LDS read instructions behind one frag()
   uint4 r[NCH];
   long off[NCH];  // KM: element offset of this chunk's row (clamped) ; !KM: clamped first row
   int tid;
@@ -130,6 +131,32 @@ struct Stage {
       }
       *reinterpret_cast<uint4*>(img + o) = r[i];
     }
+  }
+
+  // The same fragment in two steps for the LDS-DMA kernels (s2st_asm.h): raw() issues the read(s) -- transposed reads
+  // by hand, without the compiler's vmcnt(0) -- and done() builds the operand after the caller's lds_raw_wait().
+  struct Raw { bf16x8 v; s16x4 lo, hi; };
+  __device__ static __forceinline__ Raw raw(const unsigned char* img, int rt, int s, int lane) {
+    Raw r;
+    if (KM) {
+      r.v = frag(img, rt, s, lane);
+    } else {
+      const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+      const int kr = 32 * s + 8 * g + q;
+      const unsigned char* a = img + kr * PITCH + ((((rt >> 4) ^ kperm<ROWS>(kr))) << 5) + 8 * p;
+      r.lo = lds_read_tr16_raw(a);
+      r.hi = lds_read_tr16_raw(a + 4 * PITCH);  // k rows +4: same XOR key
+    }
+    return r;
+  }
+  __device__ static __forceinline__ bf16x8 done(Raw& r) {
+    if (KM) return r.v;
+    lds_raw_fence(r.lo);
+    lds_raw_fence(r.hi);
+    bf16x8 fr;
+    fr[0] = r.lo[0]; fr[1] = r.lo[1]; fr[2] = r.lo[2]; fr[3] = r.lo[3];
+    fr[4] = r.hi[0]; fr[5] = r.hi[1]; fr[6] = r.hi[2]; fr[7] = r.hi[3];
+    return fr;
   }
 
   // MFMA 16x16x32 operand fragment, tile rows [rt, rt+16) (rt % 16 == 0), k step s (0/1):
@@ -445,7 +472,22 @@ struct Dma {
   }
 };
 
-template <int BM, int BN, bool AKM, bool BKM, int NS, int NW>
+// scheduling-order helpers (the builtin wants literal counts): TM_ x (TN_ MFMAs, then this row's share of TOTAL
+// instructions of class MASK2)
+template <int MASK, int N>
+__device__ __forceinline__ void sched_group() {
+  if constexpr (N > 0) __builtin_amdgcn_sched_group_barrier(MASK, N, 0);
+}
+template <int I, int TM_, int TN_, int TOTAL, int SG2>
+__device__ __forceinline__ void sched_rows() {
+  if constexpr (I < TM_) {
+    sched_group<0x008, TN_>();
+    sched_group<SG2, (TOTAL * (I + 1)) / TM_ - (TOTAL * I) / TM_>();
+    sched_rows<I + 1, TM_, TN_, TOTAL, SG2>();
+  }
+}
+
+template <int BM, int BN, bool AKM, bool BKM, int NS, int NW, bool IL = false>
 __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_kernel(GemmArgs g) {
   constexpr int WGN = NW / 2;  // waves: 2 (M) x WGN (N)
   constexpr int WM = BM / 2, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
@@ -495,7 +537,44 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_kernel(GemmArgs g) {
       db.issue(smem + s * STAGE + A_BYTES, kbeg + s * BK, g.K, wave);
     }
 
-  for (int t = 0; t < nt; ++t) {
+  int t0 = 0;
+  if constexpr (IL) {
+    // Steady state as ONE basic block (no refill / K-tail conditions: those steps are left to the loop below) so that
+    // the scheduler can be told to spread the K-step's DMA pieces and fragment reads between its MFMAs: issued in
+    // three separate bursts behind the barrier, every wave of the CU is in its DMA phase (one texture-address path per
+    // CU, ~100 cycles of issue per 1 KB piece), then its LDS phase, then its MFMA phase, and the three do not overlap.
+    for (; t0 + NS - 1 < nt; ++t0) {
+      S2ST_VMCNT((NS - 2) * PER_STAGE);
+      __builtin_amdgcn_s_barrier();
+      unsigned char* cur = smem + (t0 % NS) * STAGE;
+      unsigned char* nxt = smem + ((t0 + NS - 1) % NS) * STAGE;
+      bf16x8 af[2][TM], bf[2][TN];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[s][j] = LB::frag(cur + A_BYTES, wn * WN + j * 16, s, lane);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[s][i] = LA::frag(cur, wm * WM + i * 16, s, lane);
+      }
+      da.issue(nxt, kbeg + (t0 + NS - 1) * BK, g.K, wave);
+      db.issue(nxt + A_BYTES, kbeg + (t0 + NS - 1) * BK, g.K, wave);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[s][j], af[s][i], acc[i][j], 0, 0, 0);
+      // the order the scheduler has to produce: the fragments of the first half K-step; under its MFMAs the fragment
+      // reads of the second half; under the second half's MFMAs the DMA pieces of the stage NS - 1 steps ahead
+      constexpr int RB = LB::READS_PER_FRAG, RA = LA::READS_PER_FRAG;
+      constexpr int HALF = TN * RB + TM * RA;  // LDS reads per half K-step
+      sched_group<0x100, HALF>();
+      sched_rows<0, TM, TN, HALF, 0x100>();
+      sched_rows<0, TM, TN, PER_STAGE, 0x010>();
+    }
+  }
+  for (int t = t0; t < nt; ++t) {
     // my DMA of stage t has landed once at most min(NS-2, nt-1-t) later stages are outstanding
     const int ahead = nt - 1 - t;
     if (ahead >= NS - 2) S2ST_VMCNT((NS - 2) * PER_STAGE);
@@ -518,12 +597,24 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_kernel(GemmArgs g) {
     // the MFMAs then consume them in issue order behind counted lgkmcnt waits: LDS latency is paid once
     // per K-step instead of once per read group
     bf16x8 af[2][TM], bf[2][TN];
+    {
+      typename LA::Raw ar[2][TM];
+      typename LB::Raw br[2][TN];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < 2; ++s) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[s][j] = LB::frag(cur + A_BYTES, wn * WN + j * 16, s, lane);
+        for (int j = 0; j < TN; ++j) br[s][j] = LB::raw(cur + A_BYTES, wn * WN + j * 16, s, lane);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[s][i] = LA::frag(cur, wm * WM + i * 16, s, lane);
+        for (int i = 0; i < TM; ++i) ar[s][i] = LA::raw(cur, wm * WM + i * 16, s, lane);
+      }
+      if (!AKM || !BKM) lds_raw_wait();
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[s][j] = LB::done(br[s][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[s][i] = LA::done(ar[s][i]);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -563,7 +654,7 @@ const char* staged_tag() {
   return buf;
 }
 
-template <int BM, int BN, int NS, int NW>
+template <int BM, int BN, int NS, int NW, bool IL = false>
 int launch_dma(const GemmArgs& g, dim3 grid, hipStream_t st) {
   constexpr int LDS = NS * (BM + BN) * 128;
   auto go = [&](auto kern, const char* tag) {
@@ -576,10 +667,10 @@ int launch_dma(const GemmArgs& g, dim3 grid, hipStream_t st) {
     s2st_launch(tag, gemm_flops(g), gemm_min_bytes(g), kern, grid, dim3(64 * NW), LDS, st, g);
     return 0;
   };
-  if (g.A.kmajor && g.B.kmajor) return go(gemm_bf16_dma_kernel<BM, BN, true, true, NS, NW>, dma_tag<BM, BN, true, true, NS, NW>());
-  if (g.A.kmajor && !g.B.kmajor) return go(gemm_bf16_dma_kernel<BM, BN, true, false, NS, NW>, dma_tag<BM, BN, true, false, NS, NW>());
-  if (!g.A.kmajor && g.B.kmajor) return go(gemm_bf16_dma_kernel<BM, BN, false, true, NS, NW>, dma_tag<BM, BN, false, true, NS, NW>());
-  return go(gemm_bf16_dma_kernel<BM, BN, false, false, NS, NW>, dma_tag<BM, BN, false, false, NS, NW>());
+  if (g.A.kmajor && g.B.kmajor) return go(gemm_bf16_dma_kernel<BM, BN, true, true, NS, NW, IL>, dma_tag<BM, BN, true, true, NS, NW>());
+  if (g.A.kmajor && !g.B.kmajor) return go(gemm_bf16_dma_kernel<BM, BN, true, false, NS, NW, IL>, dma_tag<BM, BN, true, false, NS, NW>());
+  if (!g.A.kmajor && g.B.kmajor) return go(gemm_bf16_dma_kernel<BM, BN, false, true, NS, NW, IL>, dma_tag<BM, BN, false, true, NS, NW>());
+  return go(gemm_bf16_dma_kernel<BM, BN, false, false, NS, NW, IL>, dma_tag<BM, BN, false, false, NS, NW>());
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -740,13 +831,25 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
   // instantiated for both roles): with one set, every wave's LDS reads and MFMAs of a K-step are separate phases
   // that the per-step barrier lines up across the workgroup -- LDS phase, then MFMA phase, ~3x the MFMA time.
   struct Frag { bf16x8 a[2][TM], b[2][TN]; };
-  auto load_frags = [&](Frag& F, const unsigned char* cur) {
+  // (rows-contiguous operands: transposed reads issued by hand -- s2st_asm.h -- and completed by finish_frags())
+  struct FragRaw { typename LA::Raw a[2][TM]; typename LB::Raw b[2][TN]; };
+  auto load_frags = [&](FragRaw& R, const unsigned char* cur) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) F.b[s][j] = LB::frag(cur + A_BYTES, wn * WN + j * 16, s, lane);
+      for (int j = 0; j < TN; ++j) R.b[s][j] = LB::raw(cur + A_BYTES, wn * WN + j * 16, s, lane);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) F.a[s][i] = LA::frag(cur, wm * WM + i * 16, s, lane);
+      for (int i = 0; i < TM; ++i) R.a[s][i] = LA::raw(cur, wm * WM + i * 16, s, lane);
+    }
+  };
+  auto finish_frags = [&](Frag& F, FragRaw& R) {
+    if (!AKM || !BKM) lds_raw_wait();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) F.b[s][j] = LB::done(R.b[s][j]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) F.a[s][i] = LA::done(R.a[s][i]);
     }
   };
   Cur cr;
@@ -761,7 +864,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
     K_r = grp.g[T.pi].K;
   };
   // waits for the stage of step `nread`, makes it visible to the workgroup, then reads its fragments into F
-  auto read_step = [&](Frag& F) {
+  auto read_step = [&](FragRaw& F) {
     const int ahead = issued - nread - 1;  // ring stages younger than the one about to be read
     if (ahead >= 3) S2ST_VMCNT(3 * PER_STAGE);
     else if (ahead == 2) S2ST_VMCNT(2 * PER_STAGE);
@@ -841,17 +944,19 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
   };
   if (cc.ph != 3) init_comp();
 
-  Frag F0;
-  Frag F1_[1];  // (dead, hence no registers, in the single-set form)
+  Frag F;            // the operands of the K-step being multiplied
+  FragRaw R0, R1_[1];  // reads in flight (the second set is dead, hence no registers, in the single-set form)
   if (cr.ph != 3) {
     init_read();
-    if (DBUF) read_step(F0);
+    if (DBUF) read_step(R0);
   }
-  auto body = [&](Frag& Fc, Frag& Fn) {
+  auto body = [&](FragRaw& Rc, FragRaw& Rn) {
     if (DBUF) {
-      if (cr.ph != 3) read_step(Fn);  // in flight under the MFMAs below
+      finish_frags(F, Rc);                // issued one K-step ago: landed under the previous MFMAs
+      if (cr.ph != 3) read_step(Rn);      // in flight under the MFMAs below
     } else {
-      read_step(Fc);
+      read_step(Rc);
+      finish_frags(F, Rc);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -860,7 +965,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fc.b[s][j], Fc.a[s][i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.b[s][j], F.a[s][i], acc[i][j], 0, 0, 0);
     const int ph = cc.ph;
     if (step_cur(cc)) {  // the last K-step of a whole tile or of a piece
       if (SK && ph == 0) {
@@ -878,12 +983,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
   };
   if constexpr (DBUF) {
     while (cc.ph != 3) {
-      body(F0, F1_[0]);
+      body(R0, R1_[0]);
       if (cc.ph == 3) break;
-      body(F1_[0], F0);
+      body(R1_[0], R0);
     }
   } else {
-    while (cc.ph != 3) body(F0, F0);
+    while (cc.ph != 3) body(R0, R0);
   }
   if (SK) {  // the last workgroup to leave re-arms the counters for the next launch on this stream
     __syncthreads();
@@ -1150,6 +1255,8 @@ int s2st_gemm_bf16_preload(hipStream_t st) {
     launch_layouts<64, 64, true>(g, grid, st);
     launch_layouts<64, 64, false>(g, grid, st);
     rc |= launch_dma<128, 128, 4, 8>(g, grid, st);
+    rc |= launch_dma<128, 128, 4, 8, true>(g, grid, st);
+    rc |= launch_dma<128, 64, 4, 8, true>(g, grid, st);
     rc |= launch_dma<128, 128, 4, 4>(g, grid, st);
     rc |= launch_dma<128, 64, 4, 8>(g, grid, st);
     rc |= launch_dma<128, 64, 4, 4>(g, grid, st);
@@ -1260,12 +1367,17 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
     int rc;
     static const int nw8 = getenv("S2ST_GEMM_NW8") ? atoi(getenv("S2ST_GEMM_NW8")) : 1;
     static const int ns = getenv("S2ST_GEMM_NS") ? atoi(getenv("S2ST_GEMM_NS")) : 4;  // tuning aid (128x128 only)
+    // interleaved steady state (per call: A/B); K-contiguous operands only (hand-issued transposed reads are not
+    // instructions the scheduler's groups can place)
+    const int il = (getenv("S2ST_GEMM_IL") ? atoi(getenv("S2ST_GEMM_IL")) : 1) && g.A.kmajor && g.B.kmajor;
     if (bm == 256 && bn == 128) rc = launch_dma<256, 128, 3, 8>(g, grid, st);
     else if (bm == 64 && bn == 128) rc = launch_dma<64, 128, 3, 4>(g, grid, st);
     else if (bm == 128 && bn == 128 && nw8 && ns == 3) rc = launch_dma<128, 128, 3, 8>(g, grid, st);
     else if (bm == 128 && bn == 128 && nw8 && ns == 5) rc = launch_dma<128, 128, 5, 8>(g, grid, st);
     else if (bm == 128 && bn == 128 && nw8 && ns == 2) rc = launch_dma<128, 128, 2, 8>(g, grid, st);
     else if (bm == 128 && bn == 64 && nw8 && ns == 2) rc = launch_dma<128, 64, 2, 8>(g, grid, st);
+    else if (bm == 128 && bn == 128 && nw8 && il) rc = launch_dma<128, 128, 4, 8, true>(g, grid, st);
+    else if (bm == 128 && bn == 64 && nw8 && il) rc = launch_dma<128, 64, 4, 8, true>(g, grid, st);
     else if (bm == 128 && bn == 128) rc = nw8 ? launch_dma<128, 128, 4, 8>(g, grid, st) : launch_dma<128, 128, 4, 4>(g, grid, st);
     else if (bm == 128) rc = nw8 ? launch_dma<128, 64, 4, 8>(g, grid, st) : launch_dma<128, 64, 4, 4>(g, grid, st);
     else rc = launch_dma<64, 64, 4, 4>(g, grid, st);

@@ -1,0 +1,22 @@
+// Hand-issued LDS reads for kernels whose LDS is filled by LDS-DMA (global_load_lds).
+//
+// hipcc cannot see that a ds_read_b64_tr_b16 BUILTIN reads a ring slot whose DMA has already been waited for: in
+// front of the first transposed read of every K-step it emits `s_waitcnt vmcnt(0)`, which drains the whole prefetch
+// ring (found in the ISA of every ring-kernel instantiation with a rows-contiguous operand: those ran unpipelined).
+// The instruction written as inline assembly carries no such wait; the caller orders it by hand:
+//     r = lds_read_tr16_raw(p) ...          issue (asynchronous: r is NOT valid yet)
+//     lds_raw_wait();                       s_waitcnt lgkmcnt(0), once per batch of reads
+//     lds_raw_fence(r) ...                  every later use of r is ordered behind the wait (cdna_hip_programming.md
+//                                           5.4 rule 18: a register-only consumer may otherwise be hoisted above it)
+// Included as <s2st_asm.h>: the wave64 emulator of tests/ ships a synchronous stand-in under the same name.
+#pragma once
+#include <cstdint>
+
+__device__ __forceinline__ s16x4 lds_read_tr16_raw(const unsigned char* p) {
+  s16x4 r;
+  const unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(p);
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(a));
+  return r;
+}
+__device__ __forceinline__ void lds_raw_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_raw_fence(s16x4& x) { asm volatile("" : "+v"(x)); }

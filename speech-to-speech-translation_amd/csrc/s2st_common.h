@@ -20,6 +20,8 @@ __device__ __forceinline__ s16x4 lds_read_tr16(const unsigned char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
 
+#include <s2st_asm.h>  // lds_read_tr16_raw / lds_raw_wait / lds_raw_fence (angle brackets: the test emulator shadows it)
+
 // 4 x f32 -> 4 x bf16 (round-to-nearest-even), packed in 8 bytes.
 // Lowers to two v_cvt_pk_bf16_f32 on gfx950.
 __device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d) {

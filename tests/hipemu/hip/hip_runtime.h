@@ -183,6 +183,7 @@ enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(mask, n, id) ((void)0)
 
 // ---- launch -------------------------------------------------------------------------------
 #include <tuple>
