@@ -637,12 +637,12 @@ double gemm_min_bytes(const GemmArgs& g) {
          mn * 4 * ((g.ep.accumulate ? 1 : 0) + (g.ep.resid ? 1 : 0));
 }
 // profiling tag of an instantiation, spelled like the kernel name in a rocprofv3 kernel trace
-template <int BM, int BN, bool AKM, bool BKM, int NS, int NW>
+template <int BM, int BN, bool AKM, bool BKM, int NS, int NW, bool IL = false>
 const char* dma_tag() {
-  static char buf[80];
+  static char buf[96];
   if (!buf[0])
-    snprintf(buf, sizeof buf, "gemm_bf16_dma_kernel<%d, %d, %s, %s, %d, %d>", BM, BN, AKM ? "true" : "false",
-             BKM ? "true" : "false", NS, NW);
+    snprintf(buf, sizeof buf, "gemm_bf16_dma_kernel<%d, %d, %s, %s, %d, %d, %s>", BM, BN, AKM ? "true" : "false",
+             BKM ? "true" : "false", NS, NW, IL ? "true" : "false");
   return buf;
 }
 template <int BM, int BN, bool AKM, bool BKM, bool VEC>
@@ -667,10 +667,10 @@ int launch_dma(const GemmArgs& g, dim3 grid, hipStream_t st) {
     s2st_launch(tag, gemm_flops(g), gemm_min_bytes(g), kern, grid, dim3(64 * NW), LDS, st, g);
     return 0;
   };
-  if (g.A.kmajor && g.B.kmajor) return go(gemm_bf16_dma_kernel<BM, BN, true, true, NS, NW, IL>, dma_tag<BM, BN, true, true, NS, NW>());
-  if (g.A.kmajor && !g.B.kmajor) return go(gemm_bf16_dma_kernel<BM, BN, true, false, NS, NW, IL>, dma_tag<BM, BN, true, false, NS, NW>());
-  if (!g.A.kmajor && g.B.kmajor) return go(gemm_bf16_dma_kernel<BM, BN, false, true, NS, NW, IL>, dma_tag<BM, BN, false, true, NS, NW>());
-  return go(gemm_bf16_dma_kernel<BM, BN, false, false, NS, NW, IL>, dma_tag<BM, BN, false, false, NS, NW>());
+  if (g.A.kmajor && g.B.kmajor) return go(gemm_bf16_dma_kernel<BM, BN, true, true, NS, NW, IL>, dma_tag<BM, BN, true, true, NS, NW, IL>());
+  if (g.A.kmajor && !g.B.kmajor) return go(gemm_bf16_dma_kernel<BM, BN, true, false, NS, NW, IL>, dma_tag<BM, BN, true, false, NS, NW, IL>());
+  if (!g.A.kmajor && g.B.kmajor) return go(gemm_bf16_dma_kernel<BM, BN, false, true, NS, NW, IL>, dma_tag<BM, BN, false, true, NS, NW, IL>());
+  return go(gemm_bf16_dma_kernel<BM, BN, false, false, NS, NW, IL>, dma_tag<BM, BN, false, false, NS, NW, IL>());
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1003,7 +1003,7 @@ template <int BM, int BN, bool AKM, bool BKM, int NS, int NW>
 const char* persistent_tag() {
   static char buf[96];
   if (!buf[0])
-    snprintf(buf, sizeof buf, "gemm_bf16_dma_persistent_kernel<%d, %d, %s, %s, %d, %d>", BM, BN, AKM ? "true" : "false",
+    snprintf(buf, sizeof buf, "gemm_bf16_dma_persistent_kernel<%d, %d, %s, %s, %d, %d, false>", BM, BN, AKM ? "true" : "false",
              BKM ? "true" : "false", NS, NW);
   return buf;
 }
@@ -1257,6 +1257,7 @@ int s2st_gemm_bf16_preload(hipStream_t st) {
     rc |= launch_dma<128, 128, 4, 8>(g, grid, st);
     rc |= launch_dma<128, 128, 4, 8, true>(g, grid, st);
     rc |= launch_dma<128, 64, 4, 8, true>(g, grid, st);
+    rc |= launch_dma<64, 64, 4, 4, true>(g, grid, st);
     rc |= launch_dma<128, 128, 4, 4>(g, grid, st);
     rc |= launch_dma<128, 64, 4, 8>(g, grid, st);
     rc |= launch_dma<128, 64, 4, 4>(g, grid, st);
@@ -1380,6 +1381,7 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
     else if (bm == 128 && bn == 64 && nw8 && il) rc = launch_dma<128, 64, 4, 8, true>(g, grid, st);
     else if (bm == 128 && bn == 128) rc = nw8 ? launch_dma<128, 128, 4, 8>(g, grid, st) : launch_dma<128, 128, 4, 4>(g, grid, st);
     else if (bm == 128) rc = nw8 ? launch_dma<128, 64, 4, 8>(g, grid, st) : launch_dma<128, 64, 4, 4>(g, grid, st);
+    else if (il) rc = launch_dma<64, 64, 4, 4, true>(g, grid, st);
     else rc = launch_dma<64, 64, 4, 4>(g, grid, st);
     if (rc) return rc;
   } else
