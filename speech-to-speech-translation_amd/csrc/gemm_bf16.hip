@@ -487,8 +487,10 @@ __device__ __forceinline__ void sched_rows() {
   }
 }
 
-template <int BM, int BN, bool AKM, bool BKM, int NS, int NW, bool IL = false>
-__global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_kernel(GemmArgs g) {
+// One tile of one problem: `id` = the workgroup's index among the `nwg` tiles of the problem, `by` = its batch /
+// split-K coordinate (the launch's blockIdx.y; 0 for grouped launches)
+template <int BM, int BN, bool AKM, bool BKM, int NS, int NW, bool IL>
+__device__ __forceinline__ void gemm_bf16_dma_tile(const GemmArgs& g, int id, const int nwg, const int by) {
   constexpr int WGN = NW / 2;  // waves: 2 (M) x WGN (N)
   constexpr int WM = BM / 2, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
   typedef Dma<AKM, BM, NW> DA;
@@ -502,15 +504,13 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_kernel(GemmArgs g) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int nwg = gridDim.x;
-  int id = blockIdx.x;
   {
     const int x = id & 7, q = nwg >> 3, r = nwg & 7;
     id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
   }
   const int tile_m = id / g.tiles_n, tile_n = id - tile_m * g.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int zb = blockIdx.y / g.splitk, ks = blockIdx.y - zb * g.splitk;
+  const int zb = by / g.splitk, ks = by - zb * g.splitk;
   const int zq = zb / g.zdiv, zr = zb - zq * g.zdiv;
   const bf16_t* abase = reinterpret_cast<const bf16_t*>(g.A.p) + zq * g.A.zo + zr * g.A.zi;
   const bf16_t* bbase = reinterpret_cast<const bf16_t*>(g.B.p) + zq * g.B.zo + zr * g.B.zi;
@@ -628,6 +628,22 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_kernel(GemmArgs g) {
   gemm_epilogue<BM, BN, WGN>(g, acc, m0, n0, wm, wn, lane, zb, ks, zq, zr);
 }
 
+template <int BM, int BN, bool AKM, bool BKM, int NS, int NW, bool IL = false>
+__global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_kernel(GemmArgs g) {
+  gemm_bf16_dma_tile<BM, BN, AKM, BKM, NS, NW, IL>(g, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y);
+}
+
+// Grouped one-shot form: the concatenated tile list of up to S2ST_GROUP_MAX problems (batch 1, K unsplit), one
+// workgroup per tile -- the plain K-loop above (no tile walk, no cursors: straight-line steady state) for a layer's
+// weight-gradient products, whose 72 K-steps amortise the prologue by themselves.
+template <int BM, int BN, bool AKM, bool BKM, int NS, int NW, bool IL = false>
+__global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_group_kernel(GemmGroup grp) {
+  int pi = 0;
+  const int t = blockIdx.x;
+  while (pi + 1 < grp.n && t >= grp.tile0[pi + 1]) ++pi;
+  gemm_bf16_dma_tile<BM, BN, AKM, BKM, NS, NW, IL>(grp.g[pi], t - grp.tile0[pi], grp.tile0[pi + 1] - grp.tile0[pi], 0);
+}
+
 // as-launched work of one GEMM (profiling records): FLOPs, and the bytes it has to move at least -- both bf16
 // operands once, the result once per output copy, the old value / residual once when it is read
 double gemm_flops(const GemmArgs& g) { return 2.0 * g.M * g.N * (double)g.K * g.batch; }
@@ -671,6 +687,35 @@ int launch_dma(const GemmArgs& g, dim3 grid, hipStream_t st) {
   if (g.A.kmajor && !g.B.kmajor) return go(gemm_bf16_dma_kernel<BM, BN, true, false, NS, NW, IL>, dma_tag<BM, BN, true, false, NS, NW, IL>());
   if (!g.A.kmajor && g.B.kmajor) return go(gemm_bf16_dma_kernel<BM, BN, false, true, NS, NW, IL>, dma_tag<BM, BN, false, true, NS, NW, IL>());
   return go(gemm_bf16_dma_kernel<BM, BN, false, false, NS, NW, IL>, dma_tag<BM, BN, false, false, NS, NW, IL>());
+}
+
+template <int BM, int BN, int NS, int NW>
+int launch_dma_group(const GemmGroup& grp, hipStream_t st) {
+  constexpr int LDS = NS * (BM + BN) * 128;
+  double fl = 0, by = 0;
+  for (int i = 0; i < grp.n; ++i) { fl += gemm_flops(grp.g[i]); by += gemm_min_bytes(grp.g[i]); }
+  auto go = [&](auto kern, const char* tag) {
+    static bool configured = false;
+    if (!configured) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+        return -1;
+      configured = true;
+    }
+    s2st_launch(tag, fl, by, kern, dim3(grp.total < 1 ? 1 : grp.total), dim3(64 * NW), LDS, st, grp);
+    return 0;
+  };
+  const bool akm = grp.g[0].A.kmajor != 0, bkm = grp.g[0].B.kmajor != 0;
+  static char tags[4][96];
+  auto tag = [&](int i) {
+    if (!tags[i][0])
+      snprintf(tags[i], sizeof tags[i], "gemm_bf16_dma_group_kernel<%d, %d, %s, %s, %d, %d, false>", BM, BN, (i & 2) ? "true" : "false",
+               (i & 1) ? "true" : "false", NS, NW);
+    return (const char*)tags[i];
+  };
+  if (akm && bkm) return go(gemm_bf16_dma_group_kernel<BM, BN, true, true, NS, NW>, tag(3));
+  if (akm && !bkm) return go(gemm_bf16_dma_group_kernel<BM, BN, true, false, NS, NW>, tag(2));
+  if (!akm && bkm) return go(gemm_bf16_dma_group_kernel<BM, BN, false, true, NS, NW>, tag(1));
+  return go(gemm_bf16_dma_group_kernel<BM, BN, false, false, NS, NW>, tag(0));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1235,6 +1280,15 @@ int s2st_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t st) {
     if (launch_persistent<256, 128, 3, 8>(g2, st)) return S2ST_ERR_LAUNCH;
     return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
   }
+  // default: one workgroup per tile of the concatenated list (plain K-loop: 9.65 vs 9.76 ms/step);
+  // S2ST_GROUP_ONESHOT=0: the persistent tile walk (also what S2ST_GROUP_TILE=256 and a bound stream-K scratch use)
+  const char* os = getenv("S2ST_GROUP_ONESHOT");
+  bool sk_bound = false;
+  for (int i = 0; i < g_sk_n; ++i) sk_bound = sk_bound || (g_sk[i].st == st && g_sk[i].p);
+  if (!(os && atoi(os) == 0) && !(sk_bound && streamk_mode() > 0)) {
+    if (launch_dma_group<128, 128, 4, 8>(grp, st)) return S2ST_ERR_LAUNCH;
+    return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+  }
   if (launch_persistent<128, 128, 4, 8>(grp, st)) return S2ST_ERR_LAUNCH;
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
@@ -1269,6 +1323,7 @@ int s2st_gemm_bf16_preload(hipStream_t st) {
     rc |= launch_persistent<128, 128, 4, 8>(grp, st);
     rc |= launch_persistent<128, 64, 4, 8>(grp, st);
     rc |= launch_persistent<256, 128, 3, 8>(grp, st);
+    { GemmGroup g0 = grp; g0.total = 0; g0.n = 1; rc |= launch_dma_group<128, 128, 4, 8>(g0, st); }
     rc |= launch_dma<256, 128, 3, 8>(g, grid, st);
   }
   return rc || hipGetLastError() != hipSuccess ? -1 : 0;

@@ -378,12 +378,16 @@ def test_bf16_persistent_kernel(backend, monkeypatch, akm, bkm, K):
     assert torch.equal(C3, C)
 
 
-@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("tile", [128, 256, "oneshot"])
 def test_bf16_group_of_weight_gradients(backend, monkeypatch, tile):
     """s2st_gemm_group_f32: a layer's weight-gradient products dW_i += dY_i^T X_i (different shapes, K = tokens, one with
     a K tail) in one launch, against the exact sums; 128 x 128 tiles and (S2ST_GROUP_TILE=256) 256 x 128 tiles with a
     ragged last tile row."""
-    monkeypatch.setenv("S2ST_GROUP_TILE", str(tile))
+    if tile == "oneshot":  # (default) one workgroup per tile of the concatenated list, plain K-loop
+        monkeypatch.setenv("S2ST_GROUP_ONESHOT", "1")
+    else:                  # the persistent tile walk
+        monkeypatch.setenv("S2ST_GROUP_ONESHOT", "0")
+        monkeypatch.setenv("S2ST_GROUP_TILE", str(tile))
     d = backend.device
     g = torch.Generator().manual_seed(21)
     T1, T2 = (200, 136) if backend.kind == "emu" else (4584, 3120)
