@@ -454,6 +454,17 @@ struct Dma {
     }
   }
 
+  // the same, one wave-instruction (piece j of NI) at a time: for loops that place the pieces between MFMAs themselves
+  __device__ __forceinline__ void issue_piece(unsigned char* img, int kt, int K, int wave, int j) const {
+    if (KM) {
+      const int ko = min(kt + chunk8, ((K + 7) & ~7) - 8);
+      __builtin_amdgcn_global_load_lds((gptr_t)(p[j] + ko), (lptr_t)(img + (wave * (ROWS / NW) + j * 8) * 128), 16, 0, 0);
+    } else {
+      const long k = min(kt + kr0[j], K - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(p[j] + k * ld), (lptr_t)(img + (wave * (64 / NW) + j * KR_PER_I) * PITCH), 16, 0, 0);
+    }
+  }
+
   // zero k >= kv (valid k of this stage) in the landed image
   __device__ static __forceinline__ void sanitize(unsigned char* img, int kv, int tid) {
     for (int f = tid; f < ROWS * 8; f += 64 * NW) {
@@ -543,35 +554,92 @@ __device__ __forceinline__ void gemm_bf16_dma_tile(const GemmArgs& g, int id, co
     // the scheduler can be told to spread the K-step's DMA pieces and fragment reads between its MFMAs: issued in
     // three separate bursts behind the barrier, every wave of the CU is in its DMA phase (one texture-address path per
     // CU, ~100 cycles of issue per 1 KB piece), then its LDS phase, then its MFMA phase, and the three do not overlap.
-    for (; t0 + NS - 1 < nt; ++t0) {
-      S2ST_VMCNT((NS - 2) * PER_STAGE);
-      __builtin_amdgcn_s_barrier();
-      unsigned char* cur = smem + (t0 % NS) * STAGE;
-      unsigned char* nxt = smem + ((t0 + NS - 1) % NS) * STAGE;
-      bf16x8 af[2][TM], bf[2][TN];
+    if constexpr (AKM && BKM) {
+      for (; t0 + NS - 1 < nt; ++t0) {
+        S2ST_VMCNT((NS - 2) * PER_STAGE);
+        __builtin_amdgcn_s_barrier();
+        unsigned char* cur = smem + (t0 % NS) * STAGE;
+        unsigned char* nxt = smem + ((t0 + NS - 1) % NS) * STAGE;
+        bf16x8 af[2][TM], bf[2][TN];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < 2; ++s) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[s][j] = LB::frag(cur + A_BYTES, wn * WN + j * 16, s, lane);
+          for (int j = 0; j < TN; ++j) bf[s][j] = LB::frag(cur + A_BYTES, wn * WN + j * 16, s, lane);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[s][i] = LA::frag(cur, wm * WM + i * 16, s, lane);
+          for (int i = 0; i < TM; ++i) af[s][i] = LA::frag(cur, wm * WM + i * 16, s, lane);
+        }
+        da.issue(nxt, kbeg + (t0 + NS - 1) * BK, g.K, wave);
+        db.issue(nxt + A_BYTES, kbeg + (t0 + NS - 1) * BK, g.K, wave);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[s][j], af[s][i], acc[i][j], 0, 0, 0);
+        // the order the scheduler has to produce: the fragments of the first half K-step; under its MFMAs the fragment
+        // reads of the second half; under the second half's MFMAs the DMA pieces of the stage NS - 1 steps ahead
+        constexpr int RB = LB::READS_PER_FRAG, RA = LA::READS_PER_FRAG;
+        constexpr int HALF = TN * RB + TM * RA;  // LDS reads per half K-step
+        sched_group<0x100, HALF>();
+        sched_rows<0, TM, TN, HALF, 0x100>();
+        sched_rows<0, TM, TN, PER_STAGE, 0x010>();
       }
-      da.issue(nxt, kbeg + (t0 + NS - 1) * BK, g.K, wave);
-      db.issue(nxt + A_BYTES, kbeg + (t0 + NS - 1) * BK, g.K, wave);
+    } else {
+      // a rows-contiguous operand: its transposed reads are hand-issued (s2st_asm.h), which the scheduler's groups cannot
+      // place -- the same order written out, pinned by sched_barrier(0): first half's fragments | per accumulator row of
+      // the first half: its MFMAs, then a share of the second half's reads | per row of the second half: its MFMAs, then
+      // one DMA piece of the stage NS - 1 steps ahead
+      for (; t0 + NS - 1 < nt; ++t0) {
+        S2ST_VMCNT((NS - 2) * PER_STAGE);
+        __builtin_amdgcn_s_barrier();
+        unsigned char* cur = smem + (t0 % NS) * STAGE;
+        unsigned char* nxt = smem + ((t0 + NS - 1) % NS) * STAGE;
+        const int kn = kbeg + (t0 + NS - 1) * BK;
+        typename LA::Raw ar[2][TM];
+        typename LB::Raw br[2][TN];
+        bf16x8 af[2][TM], bf[2][TN];
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+        for (int j = 0; j < TN; ++j) br[0][j] = LB::raw(cur + A_BYTES, wn * WN + j * 16, 0, lane);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) ar[0][i] = LA::raw(cur, wm * WM + i * 16, 0, lane);
+        lds_raw_wait();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = LB::done(br[0][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = LA::done(ar[0][i]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[s][j], af[s][i], acc[i][j], 0, 0, 0);
-      // the order the scheduler has to produce: the fragments of the first half K-step; under its MFMAs the fragment
-      // reads of the second half; under the second half's MFMAs the DMA pieces of the stage NS - 1 steps ahead
-      constexpr int RB = LB::READS_PER_FRAG, RA = LA::READS_PER_FRAG;
-      constexpr int HALF = TN * RB + TM * RA;  // LDS reads per half K-step
-      sched_group<0x100, HALF>();
-      sched_rows<0, TM, TN, HALF, 0x100>();
-      sched_rows<0, TM, TN, PER_STAGE, 0x010>();
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0][j], af[0][i], acc[i][j], 0, 0, 0);
+          if (i == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) br[1][j] = LB::raw(cur + A_BYTES, wn * WN + j * 16, 1, lane);
+          }
+          ar[1][i] = LA::raw(cur, wm * WM + i * 16, 1, lane);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        lds_raw_wait();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[1][j] = LB::done(br[1][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[1][i] = LA::done(ar[1][i]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[1][j], af[1][i], acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int q = (PER_STAGE * i) / TM; q < (PER_STAGE * (i + 1)) / TM; ++q) {
+            if (q < DA::NI) da.issue_piece(nxt, kn, g.K, wave, q);
+            else db.issue_piece(nxt + A_BYTES, kn, g.K, wave, q - DA::NI);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
   }
   for (int t = t0; t < nt; ++t) {
@@ -689,7 +757,7 @@ int launch_dma(const GemmArgs& g, dim3 grid, hipStream_t st) {
   return go(gemm_bf16_dma_kernel<BM, BN, false, false, NS, NW, IL>, dma_tag<BM, BN, false, false, NS, NW, IL>());
 }
 
-template <int BM, int BN, int NS, int NW>
+template <int BM, int BN, int NS, int NW, bool IL = false>
 int launch_dma_group(const GemmGroup& grp, hipStream_t st) {
   constexpr int LDS = NS * (BM + BN) * 128;
   double fl = 0, by = 0;
@@ -708,14 +776,14 @@ int launch_dma_group(const GemmGroup& grp, hipStream_t st) {
   static char tags[4][96];
   auto tag = [&](int i) {
     if (!tags[i][0])
-      snprintf(tags[i], sizeof tags[i], "gemm_bf16_dma_group_kernel<%d, %d, %s, %s, %d, %d, false>", BM, BN, (i & 2) ? "true" : "false",
-               (i & 1) ? "true" : "false", NS, NW);
+      snprintf(tags[i], sizeof tags[i], "gemm_bf16_dma_group_kernel<%d, %d, %s, %s, %d, %d, %s>", BM, BN, (i & 2) ? "true" : "false",
+               (i & 1) ? "true" : "false", NS, NW, IL ? "true" : "false");
     return (const char*)tags[i];
   };
-  if (akm && bkm) return go(gemm_bf16_dma_group_kernel<BM, BN, true, true, NS, NW>, tag(3));
-  if (akm && !bkm) return go(gemm_bf16_dma_group_kernel<BM, BN, true, false, NS, NW>, tag(2));
-  if (!akm && bkm) return go(gemm_bf16_dma_group_kernel<BM, BN, false, true, NS, NW>, tag(1));
-  return go(gemm_bf16_dma_group_kernel<BM, BN, false, false, NS, NW>, tag(0));
+  if (akm && bkm) return go(gemm_bf16_dma_group_kernel<BM, BN, true, true, NS, NW, IL>, tag(3));
+  if (akm && !bkm) return go(gemm_bf16_dma_group_kernel<BM, BN, true, false, NS, NW, IL>, tag(2));
+  if (!akm && bkm) return go(gemm_bf16_dma_group_kernel<BM, BN, false, true, NS, NW, IL>, tag(1));
+  return go(gemm_bf16_dma_group_kernel<BM, BN, false, false, NS, NW, IL>, tag(0));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1286,7 +1354,8 @@ int s2st_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t st) {
   bool sk_bound = false;
   for (int i = 0; i < g_sk_n; ++i) sk_bound = sk_bound || (g_sk[i].st == st && g_sk[i].p);
   if (!(os && atoi(os) == 0) && !(sk_bound && streamk_mode() > 0)) {
-    if (launch_dma_group<128, 128, 4, 8>(grp, st)) return S2ST_ERR_LAUNCH;
+    const int ilv = getenv("S2ST_GEMM_IL") ? atoi(getenv("S2ST_GEMM_IL")) : 2;
+    if (ilv >= 2 ? launch_dma_group<128, 128, 4, 8, true>(grp, st) : launch_dma_group<128, 128, 4, 8>(grp, st)) return S2ST_ERR_LAUNCH;
     return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
   }
   if (launch_persistent<128, 128, 4, 8>(grp, st)) return S2ST_ERR_LAUNCH;
@@ -1323,7 +1392,7 @@ int s2st_gemm_bf16_preload(hipStream_t st) {
     rc |= launch_persistent<128, 128, 4, 8>(grp, st);
     rc |= launch_persistent<128, 64, 4, 8>(grp, st);
     rc |= launch_persistent<256, 128, 3, 8>(grp, st);
-    { GemmGroup g0 = grp; g0.total = 0; g0.n = 1; rc |= launch_dma_group<128, 128, 4, 8>(g0, st); }
+    { GemmGroup g0 = grp; g0.total = 0; g0.n = 1; rc |= launch_dma_group<128, 128, 4, 8>(g0, st); rc |= launch_dma_group<128, 128, 4, 8, true>(g0, st); }
     rc |= launch_dma<256, 128, 3, 8>(g, grid, st);
   }
   return rc || hipGetLastError() != hipSuccess ? -1 : 0;
@@ -1423,9 +1492,9 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
     int rc;
     static const int nw8 = getenv("S2ST_GEMM_NW8") ? atoi(getenv("S2ST_GEMM_NW8")) : 1;
     static const int ns = getenv("S2ST_GEMM_NS") ? atoi(getenv("S2ST_GEMM_NS")) : 4;  // tuning aid (128x128 only)
-    // interleaved steady state (per call: A/B); K-contiguous operands only (hand-issued transposed reads are not
-    // instructions the scheduler's groups can place)
-    const int il = (getenv("S2ST_GEMM_IL") ? atoi(getenv("S2ST_GEMM_IL")) : 1) && g.A.kmajor && g.B.kmajor;
+    // interleaved steady state (per call: A/B): 1 = K-contiguous operands only, 2 (default) = every layout
+    const int ilv = getenv("S2ST_GEMM_IL") ? atoi(getenv("S2ST_GEMM_IL")) : 2;
+    const int il = ilv >= 2 || (ilv == 1 && g.A.kmajor && g.B.kmajor);
     if (bm == 256 && bn == 128) rc = launch_dma<256, 128, 3, 8>(g, grid, st);
     else if (bm == 64 && bn == 128) rc = launch_dma<64, 128, 3, 4>(g, grid, st);
     else if (bm == 128 && bn == 128 && nw8 && ns == 3) rc = launch_dma<128, 128, 3, 8>(g, grid, st);
