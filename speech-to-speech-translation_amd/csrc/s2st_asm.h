@@ -18,5 +18,7 @@ __device__ __forceinline__ s16x4 lds_read_tr16_raw(const unsigned char* p) {
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(a));
   return r;
 }
-__device__ __forceinline__ void lds_raw_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// (no "memory" clobber: the reads' results are ordered by the register fences below, and a clobber makes hipcc re-load
+// kernel-argument fields -- s_load + its own lgkmcnt wait -- in every K-step)
+__device__ __forceinline__ void lds_raw_wait() { asm volatile("s_waitcnt lgkmcnt(0)"); }
 __device__ __forceinline__ void lds_raw_fence(s16x4& x) { asm volatile("" : "+v"(x)); }
