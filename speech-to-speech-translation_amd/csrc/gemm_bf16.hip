@@ -179,10 +179,139 @@ struct Stage {
   }
 };
 
-// Epilogue shared by the two kernels.  acc holds C^T tiles: lane -> m = lane & 15, n = 4 (lane >> 4) + r.
-template <int BM, int BN, int WGN>
+// Straight-line epilogue for the common case (16-byte aligned outputs, N % 4 == 0, no split-K, no output mask, no GELU):
+// every wave-uniform choice is a template parameter or folded into arithmetic (bias = a zero vector when absent, ReLU =
+// max with 0 or -inf), so the eight accumulator blocks of a lane cost their loads, a few VALU operations and their
+// stores.  The general epilogue below tests ~12 kernel-argument conditions per block: measured with in-kernel clock
+// stamps (tools/gemm_stamp.sh) it took 5.3 k cycles per 128 x 128 tile with a bf16 output alone and 15.9 k with bias +
+// residual -- as long as the whole K-loop of a K = 512 product (7.6 k).
+template <int BM, int BN, int WGN, bool DROP, bool RESID, bool ACC, bool HASC, bool HASH, bool H16>
+__device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, f32x4 (&acc)[BM / 32][BN / (16 * WGN)], int m0, int n0,
+                                                   int wm, int wn, int lane, int zb, int zq, int zr,
+                                                   const float4 (*pre)[BN / (16 * WGN)]) {
+  constexpr int WM = BM / 2, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
+  const long czoff = zq * g.C.zo + zr * g.C.zi;
+  float* cbase = g.C.p + czoff;
+  bf16_t* hbase = g.C.h + czoff;
+  const float* rbase = g.ep.resid + czoff;
+  const int M = g.M, N = g.N;
+  const float alpha = g.ep.alpha, lo = g.ep.act == 1 ? 0.f : -__builtin_inff();
+  const float drop_p = g.ep.drop_p, inv_keep = DROP ? 1.f / (1.f - drop_p) : 1.f;
+  const uint64_t seed = g.ep.seed;
+  int ncol[TN];
+  bool nok[TN];
+  float4 b4[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * WN + j * 16 + (lane >> 4) * 4;
+    nok[j] = n < N;
+    ncol[j] = nok[j] ? n : N - 4;  // (N % 4 == 0, N >= 4: a valid, aligned column group for the loads of masked lanes)
+    b4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (g.ep.bias) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b4[j] = *reinterpret_cast<const float4*>(g.ep.bias + ncol[j]);
+  }
+  long roff[TM];
+  int mrow[TM];
+  bool mok[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * WM + i * 16 + (lane & 15);
+    mok[i] = m < M;
+    mrow[i] = mok[i] ? m : M - 1;
+    roff[i] = split_off(g.C.sp, mrow[i]);
+  }
+  // all loads of the tile first (residual / old value), then arithmetic and stores
+  float4 r4[RESID ? TM : 1][RESID ? TN : 1], c4[ACC ? TM : 1][ACC ? TN : 1];
+  // (pre: optionally, the same values already in registers.  Fetching them before the K-loop was tried: the 64 KB per
+  // workgroup delay the ring's prologue by ~6 k cycles and the step got slower, 9.28 vs 8.98 ms)
+  if (RESID) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        r4[RESID ? i : 0][RESID ? j : 0] = pre ? pre[i][j] : *reinterpret_cast<const float4*>(rbase + roff[i] + ncol[j]);
+  }
+  if (ACC) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        c4[ACC ? i : 0][ACC ? j : 0] = pre ? pre[i][j] : *reinterpret_cast<const float4*>(cbase + roff[i] + ncol[j]);
+  }
+  uint2 hp[(HASH && H16) ? TM : 1][(HASH && H16) ? TN : 1];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float v[4] = {fmaxf(alpha * acc[i][j][0] + b4[j].x, lo), fmaxf(alpha * acc[i][j][1] + b4[j].y, lo),
+                    fmaxf(alpha * acc[i][j][2] + b4[j].z, lo), fmaxf(alpha * acc[i][j][3] + b4[j].w, lo)};
+      if (DROP) {
+        const uint64_t e0 = ((uint64_t)zb * M + mrow[i]) * (uint64_t)N + ncol[j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= drop_scale(seed, e0 + r, drop_p, inv_keep);
+      }
+      if (RESID) {
+        const float4 t = r4[RESID ? i : 0][RESID ? j : 0];
+        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+      }
+      if (ACC) {
+        const float4 t = c4[ACC ? i : 0][ACC ? j : 0];
+        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+      }
+      if (mok[i] && nok[j]) {
+        if (HASC) *reinterpret_cast<float4*>(cbase + roff[i] + ncol[j]) = make_float4(v[0], v[1], v[2], v[3]);
+        if (HASH && !H16) *reinterpret_cast<uint2*>(hbase + roff[i] + ncol[j]) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+      }
+      if (HASH && H16) hp[(HASH && H16) ? i : 0][(HASH && H16) ? j : 0] = pack_bf16x4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  if (HASH && H16) {
+    // 16-byte bf16 stores (the store path moves ~7 B/clk/CU with 8-byte pieces, about twice that with 16-byte ones):
+    // lanes l and l ^ 16 hold columns 4g .. 4g+3 and 4g+4 .. 4g+7 of the same rows; for a pair of row blocks (i0, i1)
+    // the even group stores 8 columns of block i0, the odd group 8 columns of block i1, after one 8-byte exchange
+    const bool odd = (lane >> 4) & 1;
+#pragma unroll
+    for (int i = 0; i + 1 < TM; i += 2) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const uint2 mine = odd ? hp[i + 1][j] : hp[i][j], send = odd ? hp[i][j] : hp[i + 1][j];
+        uint2 got;
+        got.x = __shfl_xor(send.x, 16);
+        got.y = __shfl_xor(send.y, 16);
+        const uint4 o = odd ? make_uint4(got.x, got.y, mine.x, mine.y) : make_uint4(mine.x, mine.y, got.x, got.y);
+        const int n = n0 + wn * WN + j * 16 + ((lane >> 4) & 2) * 4;  // first of the 8 columns
+        const bool ok = (odd ? mok[i + 1] : mok[i]) && n < N;
+        const long ro = odd ? roff[i + 1] : roff[i];
+        if (ok) *reinterpret_cast<uint4*>(hbase + ro + n) = o;
+      }
+    }
+  }
+}
+
+// output forms that exist: fp32 only; bf16 only / fp32 + bf16 with the 16-byte bf16 stores (the launcher marks a product
+// fast only if its bf16 copy qualifies for them); accumulate only into an fp32-only output (weight gradients)
+template <int BM, int BN, int WGN, bool DROP, bool RESID, bool ACC>
+__device__ __forceinline__ void gemm_epilogue_fast_out(const GemmArgs& g, f32x4 (&acc)[BM / 32][BN / (16 * WGN)], int m0, int n0,
+                                                       int wm, int wn, int lane, int zb, int zq, int zr,
+                                                       const float4 (*pre)[BN / (16 * WGN)]) {
+  constexpr bool PAIRS = (BM / 32) % 2 == 0;  // row blocks per wave come in pairs (every tile shape in use)
+  if constexpr (ACC) {
+    gemm_epilogue_fast<BM, BN, WGN, DROP, RESID, ACC, true, false, false>(g, acc, m0, n0, wm, wn, lane, zb, zq, zr, pre);
+  } else {
+    if (g.C.p && g.C.h) gemm_epilogue_fast<BM, BN, WGN, DROP, RESID, ACC, true, true, PAIRS>(g, acc, m0, n0, wm, wn, lane, zb, zq, zr, pre);
+    else if (g.C.p) gemm_epilogue_fast<BM, BN, WGN, DROP, RESID, ACC, true, false, false>(g, acc, m0, n0, wm, wn, lane, zb, zq, zr, pre);
+    else gemm_epilogue_fast<BM, BN, WGN, DROP, RESID, ACC, false, true, PAIRS>(g, acc, m0, n0, wm, wn, lane, zb, zq, zr, pre);
+  }
+}
+
+// Epilogue shared by the kernels.  acc holds C^T tiles: lane -> m = lane & 15, n = 4 (lane >> 4) + r.  FAST: also carry
+// the straight-line forms above (the one-shot / grouped ring kernels; the other kernels keep compile time down without).
+template <int BM, int BN, int WGN, bool FAST = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM / 32][BN / (16 * WGN)], int m0,
-                                              int n0, int wm, int wn, int lane, int zb, int ks, int zq, int zr) {
+                                              int n0, int wm, int wn, int lane, int zb, int ks, int zq, int zr,
+                                              const float4 (*pre)[BN / (16 * WGN)] = nullptr) {
   constexpr int WM = BM / 2, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
   const long czoff = zq * g.C.zo + zr * g.C.zi;
   float* cbase = g.C.p ? g.C.p + czoff : nullptr;
@@ -191,6 +320,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
   const float inv_keep = g.ep.drop_p > 0.f ? 1.f / (1.f - g.ep.drop_p) : 1.f;
   const bool lead = (ks == 0);
   const bool cvec = g.cvec != 0;
+  if constexpr (FAST) {
+  if (g.cvec & 2) {  // (launcher, mark_fast_epilogue: aligned, N % 4 == 0, no split-K / slab / output mask / column sums / GELU)
+    const bool drop = g.ep.drop_p > 0.f, res = g.ep.resid != nullptr, accu = g.ep.accumulate != 0;
+    if (!drop && !res && !accu) gemm_epilogue_fast_out<BM, BN, WGN, false, false, false>(g, acc, m0, n0, wm, wn, lane, zb, zq, zr, pre);
+    else if (!drop && res && !accu) gemm_epilogue_fast_out<BM, BN, WGN, false, true, false>(g, acc, m0, n0, wm, wn, lane, zb, zq, zr, pre);
+    else if (!drop && !res && accu) gemm_epilogue_fast_out<BM, BN, WGN, false, false, true>(g, acc, m0, n0, wm, wn, lane, zb, zq, zr, pre);
+    else if (drop && !res && !accu) gemm_epilogue_fast_out<BM, BN, WGN, true, false, false>(g, acc, m0, n0, wm, wn, lane, zb, zq, zr, pre);
+    else gemm_epilogue_fast_out<BM, BN, WGN, true, true, false>(g, acc, m0, n0, wm, wn, lane, zb, zq, zr, pre);  // drop && res && !accu
+    return;
+  }
+  }
   if (g.slab) {
     // split-K partial: alpha * acc into slab[blockIdx.y][M][N] (dense); splitk_reduce_kernel combines
     float* sb = g.slab + (long)blockIdx.y * g.M * g.N;
@@ -529,6 +669,10 @@ __device__ __forceinline__ void gemm_bf16_dma_tile(const GemmArgs& g, int id, co
   const int kend = min(g.K, kbeg + g.kchunk);
   const int nt = (kend - kbeg + BK - 1) / BK;
 
+#ifdef S2ST_GEMM_STAMP  // tools/gemm_stamp.sh: a private build that writes per-workgroup cycle stamps into g.ws
+  long stamp[6];
+  stamp[0] = clock64();
+#endif
   DA da;
   DB db;
   da.init(g.A, abase, m0, g.M, wave, lane);
@@ -548,6 +692,12 @@ __device__ __forceinline__ void gemm_bf16_dma_tile(const GemmArgs& g, int id, co
       db.issue(smem + s * STAGE + A_BYTES, kbeg + s * BK, g.K, wave);
     }
 
+#ifdef S2ST_GEMM_STAMP
+  stamp[1] = clock64();
+  S2ST_VMCNT((NS - 2) * PER_STAGE);
+  __builtin_amdgcn_s_barrier();
+  stamp[2] = clock64();
+#endif
   int t0 = 0;
   if constexpr (IL) {
     // Steady state as ONE basic block (no refill / K-tail conditions: those steps are left to the loop below) so that
@@ -693,7 +843,19 @@ __device__ __forceinline__ void gemm_bf16_dma_tile(const GemmArgs& g, int id, co
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[s][j], af[s][i], acc[i][j], 0, 0, 0);
   }
-  gemm_epilogue<BM, BN, WGN>(g, acc, m0, n0, wm, wn, lane, zb, ks, zq, zr);
+#ifdef S2ST_GEMM_STAMP
+  stamp[3] = clock64();
+#endif
+  gemm_epilogue<BM, BN, WGN, IL>(g, acc, m0, n0, wm, wn, lane, zb, ks, zq, zr);  // (the production instantiations carry the fast forms)
+#ifdef S2ST_GEMM_STAMP
+  stamp[4] = clock64();
+  S2ST_VMCNT(0);
+  stamp[5] = clock64();
+  if (g.ws && tid == 0 && g.splitk == 1) {
+    long* o = reinterpret_cast<long*>(g.ws) + (long)blockIdx.x * 8;
+    for (int i = 0; i < 6; ++i) o[i] = stamp[i];
+  }
+#endif
 }
 
 template <int BM, int BN, bool AKM, bool BKM, int NS, int NW, bool IL = false>
@@ -993,6 +1155,18 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_persistent_kernel(GemmG
       __syncthreads();
     }
     load_frags(F, cur);
+    if (!AKM || !BKM) {
+      // hand-issued reads must not stay in flight across code the compiler is free to re-arrange (a tile's epilogue
+      // sits between this step and its MFMAs: a register move of a not-yet-written destination would copy garbage)
+      lds_raw_wait();
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) if (!BKM) { lds_raw_fence(F.b[s][j].lo); lds_raw_fence(F.b[s][j].hi); }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) if (!AKM) { lds_raw_fence(F.a[s][i].lo); lds_raw_fence(F.a[s][i].hi); }
+      }
+    }
     ++nread;
     if (step_cur(cr) && cr.ph != 3) init_read();
   };
@@ -1282,6 +1456,22 @@ bool prep_flags(GemmArgs& g) {
   return vec;
 }
 
+// bit 1 of cvec: the straight-line epilogue applies (gemm_epilogue_fast; S2ST_GEMM_FAST_EPI=0 is the A/B switch).
+// Called once split-K / slab decisions are made.
+void mark_fast_epilogue(GemmArgs& g) {
+  g.cvec &= 1;
+  const char* ev = getenv("S2ST_GEMM_FAST_EPI");
+  if (ev && atoi(ev) == 0) return;
+  const bool drop = g.ep.drop_p > 0.f, res = g.ep.resid != nullptr, accu = g.ep.accumulate != 0;
+  const bool combo = !accu || (!drop && !res && !g.C.h);  // instantiated: {-, resid, drop, drop + resid} x outputs, accumulate (fp32)
+  // the bf16 copy is stored 16 bytes (8 columns) per lane
+  const bool h16 = !g.C.h || ((uintptr_t)g.C.h % 16 == 0 && g.C.sp.ld % 8 == 0 && g.C.sp.bs % 8 == 0 && g.C.zo % 8 == 0 &&
+                              g.C.zi % 8 == 0 && g.N % 8 == 0);
+  if (g.cvec && g.N >= 4 && g.N % 4 == 0 && g.M >= 1 && g.splitk == 1 && !g.slab && !g.ep.mask_y && !g.ep.colsum &&
+      g.ep.act != 2 && combo && h16 && (g.C.p || g.C.h) && (!accu || g.C.p))
+    g.cvec |= 2;
+}
+
 // S2ST_GEMM_PERSIST: 0 = one-shot kernels only, 1 = grouped launches persistent, single products one-shot (default:
 // with more tiles than CUs the hardware dispatcher back-fills CUs as one-shot workgroups retire, which balances better
 // than a fixed walk of 2.25 tiles per workgroup -- 10.05 vs 10.58 ms per training step, profiles/r02_ab_switches.txt),
@@ -1297,6 +1487,7 @@ void add_to_group(GemmGroup& grp, GemmArgs g) {
   g.slab = nullptr;
   g.kchunk = ((g.K + BK - 1) / BK) * BK;
   g.tiles_n = (g.N + BN - 1) / BN;
+  mark_fast_epilogue(g);
   const int i = grp.n++;
   grp.g[i] = g;
   grp.tile0[i + 1] = grp.tile0[i] + ((g.M + BM - 1) / BM) * g.tiles_n;
@@ -1467,6 +1658,7 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
   g.tiles_n = tn;
   const bool use_slab = g.splitk > 1 && g.ws != nullptr;
   if (use_slab) g.slab = g.ws;
+  mark_fast_epilogue(g);
   dim3 grid(tm * tn, g.batch * g.splitk, 1);
   if (grid.y > 65535) return -2;
   if (bm_out) *bm_out = bm * 1000 + bn;
