@@ -270,21 +270,20 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, f32x4 (&ac
   if (HASH && H16) {
     // 16-byte bf16 stores (the store path moves ~7 B/clk/CU with 8-byte pieces, about twice that with 16-byte ones):
     // lanes l and l ^ 16 hold columns 4g .. 4g+3 and 4g+4 .. 4g+7 of the same rows; for a pair of row blocks (i0, i1)
-    // the even group stores 8 columns of block i0, the odd group 8 columns of block i1, after one 8-byte exchange
+    // one v_permlane16_swap per dword leaves the even groups with 8 columns of block i0 and the odd groups with 8
+    // columns of block i1
     const bool odd = (lane >> 4) & 1;
 #pragma unroll
     for (int i = 0; i + 1 < TM; i += 2) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const uint2 mine = odd ? hp[i + 1][j] : hp[i][j], send = odd ? hp[i][j] : hp[i + 1][j];
-        uint2 got;
-        got.x = __shfl_xor(send.x, 16);
-        got.y = __shfl_xor(send.y, 16);
-        const uint4 o = odd ? make_uint4(got.x, got.y, mine.x, mine.y) : make_uint4(mine.x, mine.y, got.x, got.y);
+        unsigned ax = hp[i][j].x, ay = hp[i][j].y, bx = hp[i + 1][j].x, by = hp[i + 1][j].y;
+        lane16_swap(ax, bx);
+        lane16_swap(ay, by);
         const int n = n0 + wn * WN + j * 16 + ((lane >> 4) & 2) * 4;  // first of the 8 columns
         const bool ok = (odd ? mok[i + 1] : mok[i]) && n < N;
         const long ro = odd ? roff[i + 1] : roff[i];
-        if (ok) *reinterpret_cast<uint4*>(hbase + ro + n) = o;
+        if (ok) *reinterpret_cast<uint4*>(hbase + ro + n) = make_uint4(ax, ay, bx, by);
       }
     }
   }

@@ -22,3 +22,12 @@ __device__ __forceinline__ s16x4 lds_read_tr16_raw(const unsigned char* p) {
 // kernel-argument fields -- s_load + its own lgkmcnt wait -- in every K-step)
 __device__ __forceinline__ void lds_raw_wait() { asm volatile("s_waitcnt lgkmcnt(0)"); }
 __device__ __forceinline__ void lds_raw_fence(s16x4& x) { asm volatile("" : "+v"(x)); }
+
+// v_permlane16_swap_b32 (gfx950): the odd 16-lane rows of `a` trade places with the even rows of `b` --
+//   a' = {a row 0, b row 0, a row 2, b row 2},  b' = {a row 1, b row 1, a row 3, b row 3}
+// (lane map checked on hardware: tools/ubench/permlane16_swap.hip).  One VALU instruction, no LDS crossbar.
+__device__ __forceinline__ void lane16_swap(unsigned& a, unsigned& b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
