@@ -289,6 +289,82 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, f32x4 (&ac
   }
 }
 
+// The backward of ReLU + dropout folded into a data-gradient product (dX_pre = mask(dY W) from the layer's bf16 output
+// y: zero where y == 0, scaled elsewhere), bf16 result only, plus the bias gradient (column sums, fp32 atomics): the
+// straight-line form of that case.
+template <int BM, int BN, int WGN>
+__device__ __forceinline__ void gemm_epilogue_fast_masky(const GemmArgs& g, f32x4 (&acc)[BM / 32][BN / (16 * WGN)], int m0, int n0,
+                                                         int wm, int wn, int lane, int zq, int zr) {
+  constexpr int WM = BM / 2, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
+  const long czoff = zq * g.C.zo + zr * g.C.zi;
+  bf16_t* hbase = g.C.h + czoff;
+  const bf16_t* ybase = g.ep.mask_y + czoff;
+  const int M = g.M, N = g.N;
+  const float alpha = g.ep.alpha * g.ep.mask_scale;
+  int ncol[TN];
+  bool nok[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * WN + j * 16 + (lane >> 4) * 4;
+    nok[j] = n < N;
+    ncol[j] = nok[j] ? n : N - 4;
+  }
+  long roff[TM];
+  bool mok[TM];
+  uint2 y4[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * WM + i * 16 + (lane & 15);
+    mok[i] = m < M;
+    roff[i] = split_off(g.C.sp, mok[i] ? m : M - 1);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) y4[i][j] = *reinterpret_cast<const uint2*>(ybase + roff[i] + ncol[j]);
+  }
+  float cs[TN][4];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) cs[j][0] = cs[j][1] = cs[j][2] = cs[j][3] = 0.f;
+  uint2 hp[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const unsigned yw[4] = {y4[i][j].x & 0x7fffu, (y4[i][j].x >> 16) & 0x7fffu, y4[i][j].y & 0x7fffu, (y4[i][j].y >> 16) & 0x7fffu};
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = yw[r] != 0 ? alpha * acc[i][j][r] : 0.f;  // +-0 -> no gradient
+        if (mok[i] && nok[j]) cs[j][r] += v[r];
+      }
+      hp[i][j] = pack_bf16x4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  const bool odd = (lane >> 4) & 1;
+#pragma unroll
+  for (int i = 0; i + 1 < TM; i += 2) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      unsigned ax = hp[i][j].x, ay = hp[i][j].y, bx = hp[i + 1][j].x, by = hp[i + 1][j].y;
+      lane16_swap(ax, bx);
+      lane16_swap(ay, by);
+      const int n = n0 + wn * WN + j * 16 + ((lane >> 4) & 2) * 4;
+      const bool ok = (odd ? mok[i + 1] : mok[i]) && n < N;
+      const long ro = odd ? roff[i + 1] : roff[i];
+      if (ok) *reinterpret_cast<uint4*>(hbase + ro + n) = make_uint4(ax, ay, bx, by);
+    }
+  }
+  if (g.ep.colsum) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = cs[j][r];
+        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
+        if ((lane & 15) == 0 && nok[j]) atomicAdd(g.ep.colsum + ncol[j] + r, t);
+      }
+    }
+  }
+}
+
 // output forms that exist: fp32 only; bf16 only / fp32 + bf16 with the 16-byte bf16 stores (the launcher marks a product
 // fast only if its bf16 copy qualifies for them); accumulate only into an fp32-only output (weight gradients)
 template <int BM, int BN, int WGN, bool DROP, bool RESID, bool ACC>
@@ -320,6 +396,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
   const bool lead = (ks == 0);
   const bool cvec = g.cvec != 0;
   if constexpr (FAST) {
+  if (g.cvec & 8) {  // (launcher: the masked bf16-only form, 16-byte stores)
+    if constexpr ((BM / 32) % 2 == 0) {
+      gemm_epilogue_fast_masky<BM, BN, WGN>(g, acc, m0, n0, wm, wn, lane, zq, zr);
+      return;
+    }
+  }
   if (g.cvec & 2) {  // (launcher, mark_fast_epilogue: aligned, N % 4 == 0, no split-K / slab / output mask / column sums / GELU)
     const bool drop = g.ep.drop_p > 0.f, res = g.ep.resid != nullptr, accu = g.ep.accumulate != 0;
     if (!drop && !res && !accu) gemm_epilogue_fast_out<BM, BN, WGN, false, false, false>(g, acc, m0, n0, wm, wn, lane, zb, zq, zr, pre);
@@ -1458,7 +1540,7 @@ bool prep_flags(GemmArgs& g) {
 // bit 1 of cvec: the straight-line epilogue applies (gemm_epilogue_fast; S2ST_GEMM_FAST_EPI=0 is the A/B switch).
 // Called once split-K / slab decisions are made.
 void mark_fast_epilogue(GemmArgs& g) {
-  g.cvec &= 1;
+  g.cvec &= 1;  // (bits 1 .. 3 are set below)
   const char* ev = getenv("S2ST_GEMM_FAST_EPI");
   if (ev && atoi(ev) == 0) return;
   const bool drop = g.ep.drop_p > 0.f, res = g.ep.resid != nullptr, accu = g.ep.accumulate != 0;
@@ -1469,6 +1551,10 @@ void mark_fast_epilogue(GemmArgs& g) {
   if (g.cvec && g.N >= 4 && g.N % 4 == 0 && g.M >= 1 && g.splitk == 1 && !g.slab && !g.ep.mask_y && !g.ep.colsum &&
       g.ep.act != 2 && combo && h16 && (g.C.p || g.C.h) && (!accu || g.C.p))
     g.cvec |= 2;
+  // bit 3: the masked data-gradient form (bf16 output only, nothing else in the epilogue but the column sums)
+  if (g.cvec && g.ep.mask_y && g.C.h && !g.C.p && h16 && g.N >= 8 && g.M >= 1 && g.splitk == 1 && !g.slab && !g.ep.bias &&
+      g.ep.act == 0 && !drop && !res && !accu && (uintptr_t)g.ep.mask_y % 16 == 0)
+    g.cvec |= 8;
 }
 
 // S2ST_GEMM_PERSIST: 0 = one-shot kernels only, 1 = grouped launches persistent, single products one-shot (default:
