@@ -150,7 +150,12 @@ struct s2st_engine {
   bool skip_resid_h = true;  // S2ST_RESID_H=1 (A/B switch): also write bf16 copies of residual-stream outputs
   bool use_ln_fuse = true;  // S2ST_NO_LN_FUSE=1 (A/B switch): separate dropout-backward prologue pass
   bool use_only_h = true;  // S2ST_NO_ONLY_H=1: always keep the fp32 copy of GEMM-only tensors (A/B switch)
-  bool use_attn_gfuse = true;  // S2ST_ATTN_GFUSE=0 (A/B switch): fp32 projection gradients + a cast / column-sum pass.
+  // S2ST_ATTN_GFUSE=1: the attention backward emits the bf16 projection gradients itself (no fp32 gradient, no cast /
+  // column-sum pass: -1.7 % step time).  OFF by default since round 2: with it a training step is not a function of
+  // (parameters, batch, seed) in a cold process -- the third update of the micro model lands on one of a few discrete
+  // gradient norms (1.3372 / 1.3363 / 1.3383; tools/cold_probe.sh) in 10 - 50 % of fresh
+  // processes, on one stream as well as on two, with every GEMM form; without it 22 of 22 fresh processes agree to 1e-7.
+  bool use_attn_gfuse = false;
                                // Emitting the bf16 GEMM operands from the attention backward takes 0.6 ms off the
                                // data-path stream but makes the second stream the longer one (its final join grew from
                                // 0.1 to 0.6 ms): it only pays together with wgrad_main_every below
@@ -1721,7 +1726,7 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->use_skinny = !(getenv("S2ST_NO_SKINNY") && atoi(getenv("S2ST_NO_SKINNY")) != 0);
   e->skip_resid_h = !(getenv("S2ST_RESID_H") && atoi(getenv("S2ST_RESID_H")) != 0);
   e->use_ln_fuse = !(getenv("S2ST_NO_LN_FUSE") && atoi(getenv("S2ST_NO_LN_FUSE")) != 0);
-  e->use_attn_gfuse = !(getenv("S2ST_ATTN_GFUSE") && atoi(getenv("S2ST_ATTN_GFUSE")) == 0);
+  e->use_attn_gfuse = getenv("S2ST_ATTN_GFUSE") && atoi(getenv("S2ST_ATTN_GFUSE")) != 0;
   e->build_params();
   if (!cfg->precise && (s2st_gemm_bf16_preload(nullptr) != 0 || s2st_flash_attn_preload(nullptr) != 0)) { delete e; return S2ST_ERR_LAUNCH; }
   if (!cfg->precise && !(getenv("S2ST_NO_SIDE_STREAM") && atoi(getenv("S2ST_NO_SIDE_STREAM")))) {

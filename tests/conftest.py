@@ -14,6 +14,31 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 EMU_LIB = os.path.join(ROOT, "tests", "hipemu", "_build", "libs2st_emu.so")
 
 
+def _poison_device_memory():
+    """S2ST_TEST_POISON=<GiB>[,nan|big]: fill that much device memory with a pattern and hand it back to the caching
+    allocator, so that every later torch.empty() of the session starts from poison instead of zeros / the previous
+    test's values -- a read of memory the step never wrote then shows up as NaN / huge values instead of passing by luck."""
+    spec = os.environ.get("S2ST_TEST_POISON")
+    if not spec:
+        return
+    import torch
+    if not torch.cuda.is_available():
+        return
+    gib, _, kind = spec.partition(",")
+    n = int(float(gib) * (1 << 30)) // 4
+    chunks = []
+    for _ in range(8):
+        t = torch.empty(n // 8, dtype=torch.float32, device="cuda:0")
+        t.fill_(float("nan") if kind != "big" else 3.0e38)
+        chunks.append(t)
+    torch.cuda.synchronize()
+    del chunks
+
+
+def pytest_sessionstart(session):
+    _poison_device_memory()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 

@@ -80,7 +80,8 @@ def test_step_is_a_function_of_the_seed(backend, workload):
         assert torch.equal(o0[k], o1[k]), k
         assert not torch.equal(o0[k], o2[k]), k
     for k, i in LOSS_KEYS:
-        assert abs(float(o0["stats"][i]) - float(o1["stats"][i])) <= 1e-6 * max(1.0, abs(float(o0["stats"][i]))), k
+        # (loss sums are folded with fp32 atomics: last-bit order noise, observed up to 1.1e-6 relative)
+        assert abs(float(o0["stats"][i]) - float(o1["stats"][i])) <= 3e-6 * max(1.0, abs(float(o0["stats"][i]))), k
     assert _rel(g1, g0) <= 1e-6, _rel(g1, g0)
     assert not _grad_close(g2, g0, 5e-2)
 
