@@ -388,9 +388,7 @@ class Engine:
             self._plan[geo] = need
         if need < 0:
             raise bd.S2STHipError(f"workspace planning failed ({need})")
-        if self.workspace is None or self.workspace.numel() < need:
-            self.workspace = None
-            self.workspace = torch.empty(int(need * 1.05) + 4096, dtype=torch.float32, device=self.device)
+        self._grow_workspace(need, int(need * 1.05) + 4096)
         dev, c = self.device, self.cfg
         B, D, E = b.B, b.D, b.E
         pool = self._outpool
@@ -477,9 +475,7 @@ class Engine:
         if need < 0:
             raise bd.S2STHipError(f"workspace planning failed ({need})")
         need = max(need, 64 << 20)
-        if self.workspace is None or self.workspace.numel() < need:
-            self.workspace = None
-            self.workspace = torch.empty(int(need * 1.05) + 4096, dtype=torch.float32, device=dev)
+        self._grow_workspace(need, int(need * 1.05) + 4096)
         o = {"encoder_out": torch.empty(B, E, c.enc_dim, device=dev)}
         out = Outputs()
         out.enc_out = o["encoder_out"].data_ptr()
@@ -530,15 +526,24 @@ class Engine:
         B, D, _ = feat.shape
         out = torch.empty_like(feat)
         need = 64 * B * (D + 8) * max(self.cfg.postnet_dim, self.cfg.out_dim) + (8 << 20)
-        if self.workspace is None or self.workspace.numel() < need:
-            self.workspace = None
-            self.workspace = torch.empty(need, dtype=torch.float32, device=dev)
+        self._grow_workspace(need, need)
         self.lib.s2st_engine_postnet_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                                       C.c_void_p, C.c_int64, C.c_void_p]
         bd.check(self.lib.s2st_engine_postnet_eval(self.h, feat.data_ptr(), B, D, out.data_ptr(),
                                                    self.workspace.data_ptr(), self.workspace.numel(), bd.stream_ptr()),
                  "s2st_engine_postnet_eval")
         return out
+
+    def _grow_workspace(self, need: int, alloc: int):
+        """(Re)allocate the per-call workspace when ``need`` floats do not fit.  Growing is rare (``reserve`` sizes it
+        up front) but must not pull the old buffer from under kernels of the previous call: those on the engine's second
+        stream are unknown to torch's allocator, which would hand the memory out again at once."""
+        if self.workspace is not None and self.workspace.numel() >= need:
+            return
+        if self.workspace is not None and self.workspace.is_cuda:
+            torch.cuda.synchronize(self.device)
+        self.workspace = None
+        self.workspace = torch.empty(alloc, dtype=torch.float32, device=self.device)
 
     def reserve(self, batches, training: bool = True, want_attn: bool = False):
         """Size the activation workspace and the output pool for the largest of ``batches`` (prepared
@@ -560,9 +565,7 @@ class Engine:
             o = 2 * b.B * b.D * c.out_dim + b.B * b.D + 3 * b.B * b.E * c.enc_dim + b.B * b.E * b.D \
                 + b.B * b.Ls * c.src_vocab + b.B * b.Lt * c.tgt_vocab + b.B * b.E * c.src_vocab + 32
             out = max(out, o + 64 * 16)
-        if self.workspace is None or self.workspace.numel() < need:
-            self.workspace = None
-            self.workspace = torch.empty(int(need * 1.05) + 4096, dtype=torch.float32, device=self.device)
+        self._grow_workspace(need, int(need * 1.05) + 4096)
         if self._outpool is None or self._outpool.numel() < out:
             self._outpool = torch.empty(out, dtype=torch.float32, device=self.device)
 

@@ -29,5 +29,10 @@ for n, t in model.named_parameters():
     out[n] = (float(g[off:off + t.numel()].abs().sum()), float(p[off:off + t.numel()].abs().sum()))
 r = trainer.train_step([b0]); torch.cuda.synchronize()
 out["__gnorm3__"] = float(r["gnorm"])
+g3 = eng.grads.double().cpu()
+for n, t in model.named_parameters():
+    off = (t.data_ptr() - eng.params.data_ptr()) // 4
+    out[n] = out[n] + (float(g3[off:off + t.numel()].abs().sum()), float(g3[off:off + t.numel()].sum()))
+out["__stats3__"] = [float(x) for x in trainer.criterion.last_outputs["stats"].double().cpu()[16:24]]
 json.dump(out, open(sys.argv[1], "w"))
 print("gnorm3 %.7f" % out["__gnorm3__"])
