@@ -722,10 +722,10 @@ struct s2st_engine {
         // (dK,dV and dQ are independent, but joining the second stream here would also wait for its
         // backlog of weight-gradient GEMMs: measured slower, so both stay on the data-path stream)
         if (live()) chk(s2st_flash_attn_bwd(&fb, o->g, dvec, st_));
-        if (gf && live()) {
+        if (gf) {
           // projection bias gradients = column sums of the bf16 gradients: parameter gradients only, so
           // on the second stream (atomics from inside the attention kernels contend on H*dh addresses)
-          hipStream_t bs = fork_side();
+          hipStream_t bs = live() ? fork_side() : st_;
           Ten* seen[3] = {nullptr, nullptr, nullptr};
           int ns = 0;
           for (Ten* t : {io3.qt, io3.kt, io3.vt}) {
@@ -733,7 +733,9 @@ struct s2st_engine {
             for (int i = 0; i < ns; ++i) dup = dup || seen[i] == t;
             if (dup || t->act_bias < 0) continue;
             seen[ns++] = t;
-            chk(s2st_colsum_bf16(t->gpre_h, t->cols, t->rows, t->cols, G + t->act_bias, bs));
+            // (fixed-order sums, no atomics: the key bias's gradient is pure rounding noise and must repeat)
+            float* part = alloc(s2st_colsum_bf16_scratch_floats(t->rows, t->cols));
+            if (live()) chk(s2st_colsum_bf16_ordered(t->gpre_h, t->cols, t->rows, t->cols, G + t->act_bias, part, bs));
           }
         }
       });

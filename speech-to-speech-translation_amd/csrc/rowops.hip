@@ -469,6 +469,79 @@ int s2st_colsum(const float* x, long ld, int rows, int cols, float* out, int acc
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
+// The same sums WITHOUT atomics: slab partials [slabs][cols] into `part`, folded in slab order by a second small kernel.
+// For column sums that are mathematically zero (the key projection's bias gradient: softmax is shift-invariant) the
+// result is pure rounding noise, and Adam turns the noise's sign into a parameter step -- with atomics the noise depends
+// on the order in which workgroups arrive, and a training run is not reproducible (Reproducibility).
+__global__ __launch_bounds__(256) void colsum_bf16_part_kernel(const uint16_t* __restrict__ x, long ld, int rows, int cols,
+                                                               float* __restrict__ part, int rows_per_block) {
+  __shared__ float red[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < cols)
+    for (int rb = r0 + wave; rb < r1; rb += 16) {
+      uint2 q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = rb + 4 * u;
+        q[u] = r < r1 ? *reinterpret_cast<const uint2*>(x + (long)r * ld + c) : make_uint2(0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a0 += __uint_as_float(q[u].x << 16); a1 += __uint_as_float(q[u].x & 0xffff0000u);
+        a2 += __uint_as_float(q[u].y << 16); a3 += __uint_as_float(q[u].y & 0xffff0000u);
+      }
+    }
+  red[wave][lane * 4 + 0] = a0; red[wave][lane * 4 + 1] = a1;
+  red[wave][lane * 4 + 2] = a2; red[wave][lane * 4 + 3] = a3;
+  __syncthreads();
+  const int cc = blockIdx.x * 256 + threadIdx.x;
+  if (cc < cols)
+    part[(long)blockIdx.y * cols + cc] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ part, int slabs, int cols,
+                                                          float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int sb = 0; sb < slabs; sb += 8) {  // 8 loads in flight, adds in slab order
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = part[(long)min(sb + j, slabs - 1) * cols + c];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (sb + j < slabs) s += v[j];
+  }
+  out[c] += s;
+}
+
+static void colsum_bf16_geometry(int rows, int cols, int& cb, int& slabs, int& rpb) {
+  cb = (cols + 255) / 256;
+  slabs = (256 + cb - 1) / cb;  // ~256 workgroups: enough to stream, few enough partials to fold quickly
+  rpb = (rows + slabs - 1) / slabs;
+  if (rpb < 16) rpb = 16;
+  slabs = (rows + rpb - 1) / rpb;
+}
+
+long s2st_colsum_bf16_scratch_floats(int rows, int cols) {
+  int cb, slabs, rpb;
+  colsum_bf16_geometry(rows, cols, cb, slabs, rpb);
+  return (long)slabs * cols;
+}
+
+int s2st_colsum_bf16_ordered(const uint16_t* x, long ld, int rows, int cols, float* out, float* scratch, hipStream_t st) {
+  if (rows <= 0 || cols <= 0) return 0;
+  if (cols % 4 || ld % 4 || ((uintptr_t)x % 8) || !scratch) return S2ST_ERR_SHAPE;
+  int cb, slabs, rpb;
+  colsum_bf16_geometry(rows, cols, cb, slabs, rpb);
+  S2ST_LAUNCH(colsum_bf16_part_kernel, dim3(cb, slabs), dim3(256), 0, st, x, ld, rows, cols, scratch, rpb);
+  S2ST_LAUNCH(colsum_fold_kernel, dim3(cb), dim3(256), 0, st, (const float*)scratch, slabs, cols, out);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+
 int s2st_colsum_bf16(const uint16_t* x, long ld, int rows, int cols, float* out, hipStream_t st) {
   if (rows <= 0 || cols <= 0) return 0;
   if (cols % 4 || ld % 4 || ((uintptr_t)x % 8)) return S2ST_ERR_SHAPE;

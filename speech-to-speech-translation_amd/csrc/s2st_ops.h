@@ -116,6 +116,9 @@ int s2st_colsum(const float* x, long ld, int rows, int cols, float* out, int acc
                 hipStream_t st);
 // out[c] += sum_r x[r][c] for a bf16 matrix (bias gradients of projections whose output gradient only exists in bf16)
 int s2st_colsum_bf16(const uint16_t* x, long ld, int rows, int cols, float* out, hipStream_t st);
+// the same without atomics (slab partials in `scratch`, s2st_colsum_bf16_scratch_floats floats, folded in a fixed order)
+long s2st_colsum_bf16_scratch_floats(int rows, int cols);
+int s2st_colsum_bf16_ordered(const uint16_t* x, long ld, int rows, int cols, float* out, float* scratch, hipStream_t st);
 // mean over heads of attention probabilities: out[b][s][t] = mean_h p[b][h][t][s]
 int s2st_attn_headmean(const float* p, float* out, int B, int H, int T, int S, int ld,
                        hipStream_t st);

@@ -1,5 +1,5 @@
-"""Cold process: two updates of the micro model ([b0, b1] each), then per-tensor checksums of the gradient arena and the
-parameters, and the third update's gradient norm -- to compare between processes (tools/cold_grad_diff.sh)."""
+"""Cold process: the three updates of the micro model ([b0, b1], [b0, b1], [b0]); after each, position-weighted checksums
+(sign- and order-sensitive) of every gradient and parameter tensor -- to compare between processes (tools/cold_grad_diff.sh)."""
 import importlib, os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
@@ -18,21 +18,17 @@ model = task.build_model(a); load_synth(model, 0)
 trainer = tr.Trainer(a, task, model, task.build_criterion(a))
 eng = model.engine
 b0, b1 = nano_batches()
-out = {}
-for u in range(2):
-    trainer.train_step([b0, b1])
-torch.cuda.synchronize()
-g = eng.grads.double().cpu(); p = eng.params.double().cpu()
-names = [n for n, _ in model.named_parameters()]
-for n, t in model.named_parameters():
-    off = (t.data_ptr() - eng.params.data_ptr()) // 4
-    out[n] = (float(g[off:off + t.numel()].abs().sum()), float(p[off:off + t.numel()].abs().sum()))
-r = trainer.train_step([b0]); torch.cuda.synchronize()
-out["__gnorm3__"] = float(r["gnorm"])
-g3 = eng.grads.double().cpu()
-for n, t in model.named_parameters():
-    off = (t.data_ptr() - eng.params.data_ptr()) // 4
-    out[n] = out[n] + (float(g3[off:off + t.numel()].abs().sum()), float(g3[off:off + t.numel()].sum()))
-out["__stats3__"] = [float(x) for x in trainer.criterion.last_outputs["stats"].double().cpu()[16:24]]
+out = {"steps": []}
+def chk(v):
+    w = torch.cos(torch.arange(v.numel(), dtype=torch.float64) * 0.37 + 1.0)
+    return [float((v * w).sum()), float(v.abs().sum())]
+for u, bs in enumerate([[b0, b1], [b0, b1], [b0]]):
+    r = trainer.train_step(list(bs)); torch.cuda.synchronize()
+    g = eng.grads.double().cpu(); p = eng.params.double().cpu()
+    rec = {"gnorm": float(r["gnorm"]), "stats": [float(x) for x in trainer.criterion.last_outputs["stats"].double().cpu()[16:24]], "t": {}}
+    for n, t in model.named_parameters():
+        off = (t.data_ptr() - eng.params.data_ptr()) // 4
+        rec["t"][n] = chk(g[off:off + t.numel()]) + chk(p[off:off + t.numel()])
+    out["steps"].append(rec)
 json.dump(out, open(sys.argv[1], "w"))
-print("gnorm3 %.7f" % out["__gnorm3__"])
+print("gnorm3 %.7f" % out["steps"][2]["gnorm"])
