@@ -240,7 +240,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void dpre_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                    const uint16_t* __restrict__ yb, uint16_t* __restrict__ dph, long ldp, float* __restrict__ dpre,
                                                    float* __restrict__ dbias, int M, int N, int rows_per_block,
-                                                   float p, float inv_keep, uint64_t seed) {
+                                                   float p, float inv_keep, uint64_t seed, float* __restrict__ part) {
   __shared__ float red[4][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 256 + lane * 4;
@@ -293,8 +293,11 @@ __global__ __launch_bounds__(256) void dpre_kernel(const float* __restrict__ dy,
   red[wave][lane * 4 + 2] = a2; red[wave][lane * 4 + 3] = a3;
   __syncthreads();
   const int cc = blockIdx.x * 256 + threadIdx.x;
-  if (cc < N)
-    atomicAdd(dbias + cc, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (cc < N) {
+    const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (part) part[(long)blockIdx.y * N + cc] = v;  // folded in slab order by the launcher's second kernel
+    else atomicAdd(dbias + cc, v);
+  }
 }
 
 __global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ x,
@@ -627,22 +630,35 @@ int s2st_relu_drop_bwd(const float* dy, const float* y, float* dz, long n, float
   return LAUNCH_OK();
 }
 
+static void dpre_geometry(int M, long ldp, int& cb, int& slabs, int& rpb) {
+  cb = (int)((ldp + 255) / 256);
+  slabs = (1024 + cb - 1) / cb;
+  rpb = (M + slabs - 1) / slabs;
+  if (rpb < 16) rpb = 16;
+  slabs = (M + rpb - 1) / rpb;
+}
+long s2st_linear_bwd_prep_scratch_floats(int M, int N, long ldp) {
+  if (M <= 0 || N <= 0) return 0;
+  int cb, slabs, rpb;
+  dpre_geometry(M, ldp, cb, slabs, rpb);
+  return (long)slabs * N;
+}
+
 int s2st_linear_bwd_prep(const float* dy, const float* y, const uint16_t* yb, int mode, float p, uint64_t seed,
-                         uint16_t* dph, long ldp, float* dpre, float* dbias, int M, int N, hipStream_t st) {
+                         uint16_t* dph, long ldp, float* dpre, float* dbias, int M, int N, hipStream_t st, float* part) {
   if (M <= 0 || N <= 0) return 0;
   if (N % 4 != 0 || ldp % 4 != 0 || ldp < N || ((uintptr_t)dy % 16) || (mode == 1 && !y && !yb) ||
       (mode == 1 && y && ((uintptr_t)y % 16)) || (mode == 1 && !y && ((uintptr_t)yb % 8)))
     return S2ST_ERR_SHAPE;
-  const int cb = (int)((ldp + 255) / 256);
-  int slabs = (1024 + cb - 1) / cb;
-  int rpb = (M + slabs - 1) / slabs;
-  if (rpb < 16) rpb = 16;
-  slabs = (M + rpb - 1) / rpb;
+  int cb, slabs, rpb;
+  dpre_geometry(M, ldp, cb, slabs, rpb);
   const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
   dim3 grid(cb, slabs);
-  if (mode == 0) S2ST_LAUNCH(dpre_kernel<0>, grid, dim3(256), 0, st, dy, y, yb, dph, ldp, dpre, dbias, M, N, rpb, p, ik, seed);
-  else if (mode == 1) S2ST_LAUNCH(dpre_kernel<1>, grid, dim3(256), 0, st, dy, y, yb, dph, ldp, dpre, dbias, M, N, rpb, p, ik, seed);
-  else S2ST_LAUNCH(dpre_kernel<2>, grid, dim3(256), 0, st, dy, y, yb, dph, ldp, dpre, dbias, M, N, rpb, p, ik, seed);
+  if (!dbias) part = nullptr;
+  if (mode == 0) S2ST_LAUNCH(dpre_kernel<0>, grid, dim3(256), 0, st, dy, y, yb, dph, ldp, dpre, dbias, M, N, rpb, p, ik, seed, part);
+  else if (mode == 1) S2ST_LAUNCH(dpre_kernel<1>, grid, dim3(256), 0, st, dy, y, yb, dph, ldp, dpre, dbias, M, N, rpb, p, ik, seed, part);
+  else S2ST_LAUNCH(dpre_kernel<2>, grid, dim3(256), 0, st, dy, y, yb, dph, ldp, dpre, dbias, M, N, rpb, p, ik, seed, part);
+  if (part) return s2st_colsum_fold(part, slabs, N, dbias, st);
   return LAUNCH_OK();
 }
 

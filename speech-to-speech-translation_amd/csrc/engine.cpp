@@ -156,6 +156,9 @@ struct s2st_engine {
   // gradient norms (1.3372 / 1.3363 / 1.3383; tools/cold_probe.sh) in 10 - 50 % of fresh
   // processes, on one stream as well as on two, with every GEMM form; without it 22 of 22 fresh processes agree to 1e-7.
   bool use_attn_gfuse = false;
+  // S2ST_ORDERED_BIAS_SUMS=1: bias-gradient column sums as slab partials + a fixed-order fold instead of fp32 atomics
+  // (one more small kernel per sum: ~1 % of the step; built while chasing the reproducibility issue, did not settle it)
+  bool ordered_sums = false;
                                // Emitting the bf16 GEMM operands from the attention backward takes 0.6 ms off the
                                // data-path stream but makes the second stream the longer one (its final join grew from
                                // 0.1 to 0.6 ms): it only pays together with wgrad_main_every below
@@ -545,9 +548,12 @@ struct s2st_engine {
         // one pass: bf16 GEMM operand of f(dy) + bias gradient (no fp32 dpre is materialised)
         bf16raw* t = alloc_h((long)M * ldp);
         const int mode = act == 1 ? 1 : (drop_p > 0.f ? 2 : 0);
+        // (bias sums in a fixed order: a bias whose gradient is mathematically zero -- key projections -- gets pure rounding
+        // noise, which must repeat from run to run)
+        float* part = (b >= 0 && ordered_sums) ? alloc(s2st_linear_bwd_prep_scratch_floats(M, N, ldp)) : nullptr;
         if (live())
           chk(s2st_linear_bwd_prep(dy, y->d, y->d ? nullptr : y->h, mode, drop_p, sd, t, ldp, nullptr,
-                                   b >= 0 ? G + b : nullptr, M, N, st_));
+                                   b >= 0 ? G + b : nullptr, M, N, st_, part));
         dph = t;
         bias_done = true;
       } else {
@@ -564,6 +570,8 @@ struct s2st_engine {
           dph = t;
         }
       }
+      // (fixed-order bias sums, see above)
+      float* cpart = (b >= 0 && !bias_done && ordered_sums) ? alloc(s2st_colsum_scratch_floats(M, N)) : nullptr;
       if (live()) {
         GemmArgs g{};  // dW[N][K] += dpre^T x
         g.A = fm ? gemm_colmajor(dph, ldp) : gemm_colmajor(dpre, N);
@@ -584,7 +592,7 @@ struct s2st_engine {
           g.ws = ws_for(ws_st); g.ws_floats = skws_n;
           chk(s2st_gemm(g, ws_st));
         }
-        if (b >= 0 && !bias_done) chk(s2st_colsum(dpre, N, M, N, G + b, 1, st_));
+        if (b >= 0 && !bias_done) chk(s2st_colsum(dpre, N, M, N, G + b, 1, st_, cpart));
       }
       if (x->needs_grad) {
         bool acc;
@@ -900,6 +908,8 @@ struct s2st_engine {
       if (!z->g) return;
       const int M = B * Tout;
       const bf16raw* dzh = fm ? ghalf_of(z) : nullptr;
+      // (fixed-order bias sums: a convolution bias in front of BatchNorm has a mathematically zero gradient)
+      float* cpart = ordered_sums ? alloc(s2st_colsum_scratch_floats(M, pp.O)) : nullptr;
       if (live()) {
         GemmArgs g{};  // dWf[O][(j,c)] += sum_(b,t) dz[(b,t)][o] * xh[b][t*stride + j][c]
         g.A = fm ? gemm_colmajor(dzh, z->hld()) : gemm_colmajor(z->g, pp.O);
@@ -913,7 +923,7 @@ struct s2st_engine {
         g.ws = ws_for(ws_st); g.ws_floats = skws_n;
         g.M = pp.O; g.N = pp.Kw * pp.I; g.K = M; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
         chk(s2st_gemm(g, ws_st));
-        chk(s2st_colsum(z->g, pp.O, M, pp.O, G + pp.b, 1, ws_st));
+        chk(s2st_colsum(z->g, pp.O, M, pp.O, G + pp.b, 1, ws_st, cpart));
         chk(s2st_conv_w_unpermute_acc(dwf, G + pp.w, pp.O, pp.I, pp.Kw, ws_st));
       }
       if (in2.src && in2.src->needs_grad) {
@@ -1729,6 +1739,7 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->skip_resid_h = !(getenv("S2ST_RESID_H") && atoi(getenv("S2ST_RESID_H")) != 0);
   e->use_ln_fuse = !(getenv("S2ST_NO_LN_FUSE") && atoi(getenv("S2ST_NO_LN_FUSE")) != 0);
   e->use_attn_gfuse = getenv("S2ST_ATTN_GFUSE") && atoi(getenv("S2ST_ATTN_GFUSE")) != 0;
+  e->ordered_sums = getenv("S2ST_ORDERED_BIAS_SUMS") && atoi(getenv("S2ST_ORDERED_BIAS_SUMS")) != 0;
   e->build_params();
   if (!cfg->precise && (s2st_gemm_bf16_preload(nullptr) != 0 || s2st_flash_attn_preload(nullptr) != 0)) { delete e; return S2ST_ERR_LAUNCH; }
   if (!cfg->precise && !(getenv("S2ST_NO_SIDE_STREAM") && atoi(getenv("S2ST_NO_SIDE_STREAM")))) {

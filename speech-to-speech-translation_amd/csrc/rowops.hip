@@ -308,9 +308,10 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
   }
 }
 
+// part != null: the slab's sums go to part[slab][cols] (folded in slab order by colsum_fold_kernel) instead of atomics
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long ld, int rows,
                                                      int cols, float* __restrict__ out,
-                                                     int rows_per_block) {
+                                                     int rows_per_block, float* __restrict__ part) {
   __shared__ float red[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
@@ -321,7 +322,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     for (int r = r0 + ty; r < r1; r += 4) a += x[(long)r * ld + c];
   red[ty][tx] = a;
   __syncthreads();
-  if (ty == 0 && c < cols) atomicAdd(&out[c], red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
+  if (ty == 0 && c < cols) {
+    const float v = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    if (part) part[(long)blockIdx.y * cols + c] = v;
+    else atomicAdd(&out[c], v);
+  }
 }
 
 // out[c] += sum_r bf16 x[r][c]: 4 columns per lane (8-byte loads), 4 waves over the rows of a slab
@@ -455,17 +460,36 @@ int s2st_softmax_bwd(const float* p, const float* dpd, float* ds, int B, int H, 
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
+__global__ void colsum_fold_kernel(const float* __restrict__ part, int slabs, int cols, float* __restrict__ out);
+static void colsum_geometry(int rows, int cols, int& cb, int& slabs, int& rpb) {
+  cb = (cols + 63) / 64;
+  slabs = (512 + cb - 1) / cb;
+  rpb = (rows + slabs - 1) / slabs;
+  if (rpb < 16) rpb = 16;
+  slabs = (rows + rpb - 1) / rpb;
+}
+long s2st_colsum_scratch_floats(int rows, int cols) {
+  if (rows <= 0 || cols <= 0) return 0;
+  int cb, slabs, rpb;
+  colsum_geometry(rows, cols, cb, slabs, rpb);
+  return (long)slabs * cols;
+}
+int s2st_colsum_fold(const float* part, int slabs, int cols, float* out, hipStream_t st) {
+  if (slabs <= 0 || cols <= 0) return 0;
+  S2ST_LAUNCH(colsum_fold_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, part, slabs, cols, out);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+
+// part (s2st_colsum_scratch_floats floats) != null: fixed-order sums (slab partials + fold) instead of fp32 atomics
 int s2st_colsum(const float* x, long ld, int rows, int cols, float* out, int accumulate,
-                hipStream_t st) {
+                hipStream_t st, float* part) {
   if (cols <= 0) return 0;
   if (!accumulate) hipMemsetAsync(out, 0, sizeof(float) * cols, st);
   if (rows <= 0) return 0;
-  int cb = (cols + 63) / 64;
-  int slabs = (512 + cb - 1) / cb;
-  int rpb = (rows + slabs - 1) / slabs;
-  if (rpb < 16) rpb = 16;
-  slabs = (rows + rpb - 1) / rpb;
-  S2ST_LAUNCH(colsum_kernel, dim3(cb, slabs), dim3(256), 0, st, x, ld, rows, cols, out, rpb);
+  int cb, slabs, rpb;
+  colsum_geometry(rows, cols, cb, slabs, rpb);
+  S2ST_LAUNCH(colsum_kernel, dim3(cb, slabs), dim3(256), 0, st, x, ld, rows, cols, out, rpb, part);
+  if (part) return s2st_colsum_fold(part, slabs, cols, out, st);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 

@@ -113,7 +113,9 @@ int s2st_softmax_bwd(const float* p, const float* dpd, float* ds, int B, int H, 
 
 // column sums: out[c] (+)= sum_r x[r][c]   (bias gradients)
 int s2st_colsum(const float* x, long ld, int rows, int cols, float* out, int accumulate,
-                hipStream_t st);
+                hipStream_t st, float* part = nullptr /* fixed-order sums through this scratch (s2st_colsum_scratch_floats) */);
+long s2st_colsum_scratch_floats(int rows, int cols);
+int s2st_colsum_fold(const float* part, int slabs, int cols, float* out, hipStream_t st);  // out[c] += sum_s part[s][c], in order
 // out[c] += sum_r x[r][c] for a bf16 matrix (bias gradients of projections whose output gradient only exists in bf16)
 int s2st_colsum_bf16(const uint16_t* x, long ld, int rows, int cols, float* out, hipStream_t st);
 // the same without atomics (slab partials in `scratch`, s2st_colsum_bf16_scratch_floats floats, folded in a fixed order)
@@ -169,7 +171,8 @@ int s2st_relu_drop_bwd(const float* dy, const float* y, float* dz, long n, float
 // 1: ReLU+dropout backward from the layer OUTPUT y ; 2: dropout(seed) backward.  N % 4 == 0.
 int s2st_linear_bwd_prep(const float* dy, const float* y, const uint16_t* yb /* bf16 y when y == null */, int mode,
                          float p, uint64_t seed, uint16_t* dph, long ldp, float* dpre, float* dbias, int M, int N,
-                         hipStream_t st);
+                         hipStream_t st, float* part = nullptr /* bias sums in a fixed order: s2st_linear_bwd_prep_scratch_floats */);
+long s2st_linear_bwd_prep_scratch_floats(int M, int N, long ldp);
 int s2st_axpy(const float* x, float* y, long n, float a, hipStream_t st);  // y += a * x
 int s2st_scale(float* x, long n, float a, hipStream_t st);
 // conv weight W[O][I][Kw] -> Wf[O][Kw][I] (forward GEMM layout) and, if wd != null,
