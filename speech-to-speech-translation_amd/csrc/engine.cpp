@@ -151,10 +151,9 @@ struct s2st_engine {
   bool use_ln_fuse = true;  // S2ST_NO_LN_FUSE=1 (A/B switch): separate dropout-backward prologue pass
   bool use_only_h = true;  // S2ST_NO_ONLY_H=1: always keep the fp32 copy of GEMM-only tensors (A/B switch)
   // S2ST_ATTN_GFUSE=1: the attention backward emits the bf16 projection gradients itself (no fp32 gradient, no cast /
-  // column-sum pass: -1.7 % step time).  OFF by default since round 2: with it a training step is not a function of
-  // (parameters, batch, seed) in a cold process -- the third update of the micro model lands on one of a few discrete
-  // gradient norms (1.3372 / 1.3363 / 1.3383; tools/cold_probe.sh) in 10 - 50 % of fresh
-  // processes, on one stream as well as on two, with every GEMM form; without it 22 of 22 fresh processes agree to 1e-7.
+  // column-sum pass: -1.2 ... -1.7 % step time).  OFF by default since round 2: multi-update trajectories of cold processes
+  // agreed to 1e-7 in 32 of 32 runs without it and in ~85 % with it (rounding noise of fp32 atomics, amplified by Adam on
+  // parameters whose gradient is mathematically zero: DESIGN.md section 5, Reproducibility).
   bool use_attn_gfuse = false;
   // S2ST_ORDERED_BIAS_SUMS=1: bias-gradient column sums as slab partials + a fixed-order fold instead of fp32 atomics
   // (one more small kernel per sum: ~1 % of the step; built while chasing the reproducibility issue, did not settle it)
