@@ -155,6 +155,7 @@ struct s2st_engine {
   // agreed to 1e-7 in 32 of 32 runs without it and in ~85 % with it (rounding noise of fp32 atomics, amplified by Adam on
   // parameters whose gradient is mathematically zero: DESIGN.md section 5, Reproducibility).
   bool use_attn_gfuse = false;
+  int attn_gfuse_mode = 0;
   // S2ST_ORDERED_BIAS_SUMS=1: bias-gradient column sums as slab partials + a fixed-order fold instead of fp32 atomics
   // (one more small kernel per sum: ~1 % of the step; built while chasing the reproducibility issue, did not settle it)
   bool ordered_sums = false;
@@ -728,8 +729,17 @@ struct s2st_engine {
         }
         // (dK,dV and dQ are independent, but joining the second stream here would also wait for its
         // backlog of weight-gradient GEMMs: measured slower, so both stay on the data-path stream)
+        // S2ST_ATTN_GFUSE=2: the projections' bias gradients come out of the attention kernels themselves (column sums of the
+        // fp32 accumulators BEFORE they are rounded to bf16, fp32 atomics per head column) instead of a column-sum pass over
+        // the rounded copies: no extra launches, and a key bias's mathematically zero gradient stays ~0
+        const bool gf_db = gf && attn_gfuse_mode == 2;
+        if (gf_db) {
+          if (io3.qt->act_bias >= 0) fb.dbq = G + io3.qt->act_bias + io3.qoff;
+          if (io3.kt->act_bias >= 0) fb.dbk = G + io3.kt->act_bias + io3.koff;
+          if (io3.vt->act_bias >= 0) fb.dbv = G + io3.vt->act_bias + io3.voff;
+        }
         if (live()) chk(s2st_flash_attn_bwd(&fb, o->g, dvec, st_));
-        if (gf) {
+        if (gf && !gf_db) {
           // projection bias gradients = column sums of the bf16 gradients: parameter gradients only, so
           // on the second stream (atomics from inside the attention kernels contend on H*dh addresses)
           hipStream_t bs = live() ? fork_side() : st_;
@@ -1738,6 +1748,7 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->skip_resid_h = !(getenv("S2ST_RESID_H") && atoi(getenv("S2ST_RESID_H")) != 0);
   e->use_ln_fuse = !(getenv("S2ST_NO_LN_FUSE") && atoi(getenv("S2ST_NO_LN_FUSE")) != 0);
   e->use_attn_gfuse = getenv("S2ST_ATTN_GFUSE") && atoi(getenv("S2ST_ATTN_GFUSE")) != 0;
+  e->attn_gfuse_mode = getenv("S2ST_ATTN_GFUSE") ? atoi(getenv("S2ST_ATTN_GFUSE")) : 0;
   e->ordered_sums = getenv("S2ST_ORDERED_BIAS_SUMS") && atoi(getenv("S2ST_ORDERED_BIAS_SUMS")) != 0;
   e->build_params();
   if (!cfg->precise && (s2st_gemm_bf16_preload(nullptr) != 0 || s2st_flash_attn_preload(nullptr) != 0)) { delete e; return S2ST_ERR_LAUNCH; }
