@@ -120,13 +120,16 @@ struct AttnArgs {
   float *dq, *dk, *dv;            // fp32 gradients, addressed like q / k / v (ldq / ldk / ldv); may be null
   bf16_t *dqh, *dkh, *dvh;        // optional bf16 gradients (the operand of the projections' backward GEMMs)
   float *dbq, *dbk, *dbv;         // optional: projection bias gradients += column sums (head h at + h * DH)
+  // db_part != 0: dbq / dbk / dbv point at PARTIAL-sum arrays [slot][H * DH] instead (slot = (b * blocks + block) * waves
+  // + wave: every element written exactly once, plain stores); the launcher folds them in slot order (no atomics)
+  int db_part;
 };
 
 // store a [d][col] accumulator tile set as row `col`: fp32 and/or bf16, and add its column sums (over the
 // wave's 16 rows, rows >= limit excluded by `on`) to a bias gradient
 template <int DT>
 __device__ __forceinline__ void store_grad(const f32x4 (&t)[DT], float scale, bool on, float* fp, bf16_t* hp,
-                                           float* db, int lane) {
+                                           float* db, int lane, bool db_store = false) {
   const int g = lane >> 4;
 #pragma unroll
   for (int d = 0; d < DT; ++d) {
@@ -142,7 +145,10 @@ __device__ __forceinline__ void store_grad(const f32x4 (&t)[DT], float scale, bo
       for (int r = 0; r < 4; ++r) {
         float c = v[r];
         c += __shfl_xor(c, 1); c += __shfl_xor(c, 2); c += __shfl_xor(c, 4); c += __shfl_xor(c, 8);
-        if ((lane & 15) == 0) atomicAdd(db + 16 * d + 4 * g + r, c);
+        if ((lane & 15) == 0) {
+          if (db_store) db[16 * d + 4 * g + r] = c;
+          else atomicAdd(db + 16 * d + 4 * g + r, c);
+        }
       }
     }
   }
@@ -361,10 +367,12 @@ __device__ __forceinline__ void flash_bwd_kv_body(const AttnArgs& a, unsigned ch
     const bool on = ki < a.S;
     const long ko = ((long)b * a.S + min(ki, a.S - 1)) * a.ldk + h * DH;
     const long vo = ((long)b * a.S + min(ki, a.S - 1)) * a.ldv + h * DH;
+    // (partial-sum mode: this wave's slot of the [slot][H * DH] arrays)
+    const long slot = a.db_part ? ((long)(b * (int)((a.S + 16 * NW - 1) / (16 * NW)) + bx) * NW + wave) * ((long)a.H * DH) : 0;
     store_grad<DT>(dk, a.scale, on, a.dk ? a.dk + ko : nullptr, a.dkh ? a.dkh + ko : nullptr,
-                   a.dbk ? a.dbk + h * DH : nullptr, lane);
+                   a.dbk ? a.dbk + slot + h * DH : nullptr, lane, a.db_part != 0);
     store_grad<DT>(dv, 1.f, on, a.dv ? a.dv + vo : nullptr, a.dvh ? a.dvh + vo : nullptr,
-                   a.dbv ? a.dbv + h * DH : nullptr, lane);
+                   a.dbv ? a.dbv + slot + h * DH : nullptr, lane, a.db_part != 0);
   }
 }
 
@@ -447,8 +455,9 @@ __device__ __forceinline__ void flash_bwd_q_body(const AttnArgs& a, unsigned cha
   }
   {
     const long qo = ((long)b * a.T + min(qi, a.T - 1)) * a.ldq + h * DH;
+    const long slot = a.db_part ? ((long)(b * (int)((a.T + 16 * NW - 1) / (16 * NW)) + bx) * NW + wave) * ((long)a.H * DH) : 0;
     store_grad<DT>(dq, a.scale, q_ok, a.dq ? a.dq + qo : nullptr, a.dqh ? a.dqh + qo : nullptr,
-                   a.dbq ? a.dbq + h * DH : nullptr, lane);
+                   a.dbq ? a.dbq + slot + h * DH : nullptr, lane, a.db_part != 0);
   }
 }
 
@@ -549,11 +558,32 @@ int s2st_flash_attn_fwd(const s2st_attn_args* p, hipStream_t st) {
 
 // dO (fp32, for D) + its bf16 copy; o / lse from the forward; writes dq, dk, dv (fp32, overwrite)
 // phase 0: everything; 1: only the D vector; 2: only dK,dV; 3: only dQ (the caller may overlap 2 and 3)
-int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_scratch, hipStream_t st, int phase) {
+// floats of scratch for the bias gradients in partial-sum form (0 when no bias gradient is asked for)
+long s2st_flash_attn_db_scratch_floats(const s2st_attn_args* p) {
+  if (!p || (!p->dbq && !p->dbk && !p->dbv)) return 0;
+  const int nw = attn_nw();
+  const long C = (long)p->H * p->dh;
+  const long sq = (long)p->B * ((p->T + 16 * nw - 1) / (16 * nw)) * nw, sk = (long)p->B * ((p->S + 16 * nw - 1) / (16 * nw)) * nw;
+  return (sq + 2 * sk) * C;
+}
+
+int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_scratch, hipStream_t st, int phase,
+                        float* db_part) {
   if (!p || !attn_args_ok(*p) || !p->doh || !dO || !dvec_scratch || (!p->dq && !p->dqh) || (!p->dk && !p->dkh) || (!p->dv && !p->dvh) || !p->lse || !p->o)
     return S2ST_ERR_ARG;
   AttnArgs a = to_args(*p);
   a.dvec = dvec_scratch;
+  // bias gradients without atomics: the kernels write per-(block, wave) partial sums, folded in slot order below
+  const int nwp = attn_nw();
+  const long Cp = (long)p->H * p->dh;
+  const long slots_q = (long)p->B * ((p->T + 16 * nwp - 1) / (16 * nwp)) * nwp, slots_k = (long)p->B * ((p->S + 16 * nwp - 1) / (16 * nwp)) * nwp;
+  const bool part = db_part && phase == 0 && (p->dbq || p->dbk || p->dbv);
+  if (part) {
+    a.db_part = 1;
+    a.dbq = p->dbq ? db_part : nullptr;
+    a.dbk = p->dbk ? db_part + slots_q * Cp : nullptr;
+    a.dbv = p->dbv ? db_part + (slots_q + slots_k) * Cp : nullptr;
+  }
   const long rows = (long)p->B * p->T * p->H;
   if (phase > 1) {
   } else if (p->dh == 128)
@@ -585,5 +615,38 @@ int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_sc
   if (nw == 1) go(std::integral_constant<int, 1>{});
   else if (nw == 2) go(std::integral_constant<int, 2>{});
   else go(std::integral_constant<int, 4>{});
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+
+// db[c] += sum over slots of the partial sums s2st_flash_attn_bwd(..., db_part) left, in slot order: one launch for the
+// three projections (blockIdx.y = q / k / v); any stream ordered behind the backward kernels
+__global__ __launch_bounds__(256) void attn_db_fold_kernel(const float* __restrict__ part, int slots_q, int slots_k, int C,
+                                                           float* __restrict__ dbq, float* __restrict__ dbk,
+                                                           float* __restrict__ dbv) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int which = blockIdx.y;
+  float* out = which == 0 ? dbq : (which == 1 ? dbk : dbv);
+  if (c >= C || !out) return;
+  const float* src = part + (which == 0 ? 0 : (which == 1 ? (long)slots_q * C : (long)(slots_q + slots_k) * C));
+  const int slots = which == 0 ? slots_q : slots_k;
+  float s = 0.f;
+  for (int sb = 0; sb < slots; sb += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[(long)min(sb + j, slots - 1) * C + c];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (sb + j < slots) s += v[j];
+  }
+  out[c] += s;
+}
+
+int s2st_flash_attn_db_fold(const s2st_attn_args* p, const float* db_part, hipStream_t st) {
+  if (!p || !db_part || (!p->dbq && !p->dbk && !p->dbv)) return 0;
+  const int nw = attn_nw();
+  const int C = p->H * p->dh;
+  const int slots_q = p->B * ((p->T + 16 * nw - 1) / (16 * nw)) * nw, slots_k = p->B * ((p->S + 16 * nw - 1) / (16 * nw)) * nw;
+  S2ST_LAUNCH(attn_db_fold_kernel, dim3((C + 255) / 256, 3), dim3(256), 0, st, db_part, slots_q, slots_k, C, p->dbq, p->dbk,
+              p->dbv);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }

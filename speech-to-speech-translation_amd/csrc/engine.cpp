@@ -150,10 +150,12 @@ struct s2st_engine {
   bool skip_resid_h = true;  // S2ST_RESID_H=1 (A/B switch): also write bf16 copies of residual-stream outputs
   bool use_ln_fuse = true;  // S2ST_NO_LN_FUSE=1 (A/B switch): separate dropout-backward prologue pass
   bool use_only_h = true;  // S2ST_NO_ONLY_H=1: always keep the fp32 copy of GEMM-only tensors (A/B switch)
-  // S2ST_ATTN_GFUSE=1: the attention backward emits the bf16 projection gradients itself (no fp32 gradient, no cast /
-  // column-sum pass: -1.2 ... -1.7 % step time).  OFF by default since round 2: multi-update trajectories of cold processes
-  // agreed to 1e-7 in 32 of 32 runs without it and in ~85 % with it (rounding noise of fp32 atomics, amplified by Adam on
-  // parameters whose gradient is mathematically zero: DESIGN.md section 5, Reproducibility).
+  // S2ST_ATTN_GFUSE=1 / 2 / 3: the attention backward emits the bf16 projection gradients itself (no fp32 gradient, no
+  // cast pass); the modes differ in where the projections' bias gradients come from (attention block below).  OFF by
+  // default since round 2: round 1's form (= 3, -1.2 ... -1.7 % step time) sums the ROUNDED gradients, which turns a key
+  // bias's mathematically zero gradient into a rounding residue that changes with any upstream ulp -- multi-update
+  // trajectories of cold processes then repeat in ~85 % of runs instead of 32 of 32; the exact forms (1: partial sums,
+  // 2: atomics) repeat but cost +3.8 % / +16 % (Reproducibility).
   bool use_attn_gfuse = false;
   int attn_gfuse_mode = 0;
   // S2ST_ORDERED_BIAS_SUMS=1: bias-gradient column sums as slab partials + a fixed-order fold instead of fp32 atomics
@@ -729,16 +731,21 @@ struct s2st_engine {
         }
         // (dK,dV and dQ are independent, but joining the second stream here would also wait for its
         // backlog of weight-gradient GEMMs: measured slower, so both stay on the data-path stream)
-        // S2ST_ATTN_GFUSE=2: the projections' bias gradients come out of the attention kernels themselves (column sums of the
-        // fp32 accumulators BEFORE they are rounded to bf16, fp32 atomics per head column) instead of a column-sum pass over
-        // the rounded copies: no extra launches, and a key bias's mathematically zero gradient stays ~0
-        const bool gf_db = gf && attn_gfuse_mode == 2;
+        // Bias gradients of the projections in the fused form.  S2ST_ATTN_GFUSE=1: out of the attention kernels' fp32
+        // accumulators BEFORE they are rounded to bf16, as per-(block, wave) partial sums folded in a fixed order (no
+        // atomics, no pass over the rounded copies; a key bias's mathematically zero gradient stays ~0 and repeats);
+        // =2: the same sums as fp32 atomics per head column (contention: slow); =3: column sums of the rounded bf16
+        // copies (round 1's form: a rounding residue of ~1e-5 instead of ~0)
+        const bool gf_db = gf && attn_gfuse_mode != 3;
+        float* dbp = nullptr;
         if (gf_db) {
           if (io3.qt->act_bias >= 0) fb.dbq = G + io3.qt->act_bias + io3.qoff;
           if (io3.kt->act_bias >= 0) fb.dbk = G + io3.kt->act_bias + io3.koff;
           if (io3.vt->act_bias >= 0) fb.dbv = G + io3.vt->act_bias + io3.voff;
+          if (attn_gfuse_mode != 2) dbp = alloc(s2st_flash_attn_db_scratch_floats(&fb));
         }
-        if (live()) chk(s2st_flash_attn_bwd(&fb, o->g, dvec, st_));
+        if (live()) chk(s2st_flash_attn_bwd(&fb, o->g, dvec, st_, 0, dbp));
+        if (dbp && live()) chk(s2st_flash_attn_db_fold(&fb, dbp, fork_side()));  // parameter gradients: second stream
         if (gf && !gf_db) {
           // projection bias gradients = column sums of the bf16 gradients: parameter gradients only, so
           // on the second stream (atomics from inside the attention kernels contend on H*dh addresses)

@@ -202,7 +202,10 @@ int s2st_bn_bwd(const float* dy, Split dysp, const float* x, const float* mean, 
 int s2st_flash_attn_supported(int dh);
 int s2st_flash_attn_preload(hipStream_t st);
 int s2st_flash_attn_fwd(const s2st_attn_args* p, hipStream_t st);
-int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_scratch, hipStream_t st, int phase = 0);
+int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_scratch, hipStream_t st, int phase = 0,
+                        float* db_part = nullptr /* bias gradients as partial sums + ordered fold: s2st_flash_attn_db_scratch_floats */);
+long s2st_flash_attn_db_scratch_floats(const s2st_attn_args* p);
+int s2st_flash_attn_db_fold(const s2st_attn_args* p, const float* db_part, hipStream_t st);  // db += fold(partials), slot order
 
 // ---------------------------------------------------------------------------------------
 // HuBERT front end (hubert.hip): waveform conv, GroupNorm(C, C) + GELU, pos-conv input re-layout
