@@ -28,6 +28,12 @@ class Tacotron2MTLCriterion(Tacotron2Criterion):
                          bce_pos_weight, ctc_weight)
         self.ctc_weight_tgt = ctc_weight_tgt
 
+    @staticmethod
+    def add_args(parser):
+        """The one field the mtl criterion's dataclass adds (s2st_loss_mtl.py:52-98 ``ctc_weight_tgt``)."""
+        parser.add_argument("--ctc-weight-tgt", type=float, default=0.0,
+                            help="weight of the CTC loss over the target text on a decoder layer's output")
+
     @classmethod
     def build_criterion(cls, args, task):
         crit = cls(task, getattr(args, "sentence_avg", False), args.n_frames_per_step,

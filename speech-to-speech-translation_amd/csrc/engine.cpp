@@ -479,7 +479,12 @@ struct s2st_engine {
       hipStream_t s = (side_ && st_ != side_) ? fork_side() : st_;
       // S2ST_TIMING_SKIP_WGRAD=1: a TIMING experiment only (wrong gradients): how much of the step is the weight-gradient
       // products' share of the chip
-      static const bool skip = getenv("S2ST_TIMING_SKIP_WGRAD") && atoi(getenv("S2ST_TIMING_SKIP_WGRAD")) != 0;
+      static const bool skip = [] {
+        const bool on = getenv("S2ST_TIMING_SKIP_WGRAD") && atoi(getenv("S2ST_TIMING_SKIP_WGRAD")) != 0;
+        if (on) fprintf(stderr, "[s2st] S2ST_TIMING_SKIP_WGRAD=1: weight-gradient products are SKIPPED -- gradients are WRONG, "
+                                "timing experiments only\n");
+        return on;
+      }();
       if (!skip) chk(s2st_gemm_bf16_group(pending_wgrad.data(), (int)pending_wgrad.size(), s));
     }
     pending_wgrad.clear();

@@ -24,6 +24,14 @@ from ..data.synthetic import SyntheticFisherCorpus
 from ..registry import HAVE_FAIRSEQ, TaskBase, register_task, CRITERIA, MODELS
 
 
+def _flag_is_true(v) -> bool:
+    """``--input-text`` / ``--use-hubert`` are STRING flags in the reference (s2s_translation.py:66-68); its task converts
+    its own namespace copy with ``convertobool`` (:39-45, :79-80).  Here the task, model and criterion share one
+    namespace and the model compares the string with 'true' (s2st_transformer.py:688), so the string stays as parsed
+    and every use site converts."""
+    return v is True or str(v).lower() in ("true", "1", "yes")
+
+
 @register_task("s2s_translation")
 class S2ST_TranslationTask(TaskBase):  # fairseq's LegacyFairseqTask when fairseq is importable
     @staticmethod
@@ -84,7 +92,7 @@ class S2ST_TranslationTask(TaskBase):  # fairseq's LegacyFairseqTask when fairse
 
     def load_dataset(self, split, n_utts=4096, seed=1234, epoch=1, **kw):
         if self.data_cfg is not None:  # s2s_translation.py:121-135
-            use_hubert = str(getattr(self.args, "use_hubert", "false")).lower() in ("true", "1", "yes")
+            use_hubert = _flag_is_true(getattr(self.args, "use_hubert", "false"))
             self.data_cfg.set_use_hubert(use_hubert)
             self.data_cfg.set_kd_encoder(bool(getattr(self.args, "kd_encoder", False)))
             self.datasets[split] = S2STDatasetCreator.from_tsv(
@@ -161,7 +169,7 @@ class S2ST_TranslationTask(TaskBase):  # fairseq's LegacyFairseqTask when fairse
         return AutoRegressiveSpeechGenerator(
             models[0], vocoder, self.data_cfg, max_iter=self.args.max_target_positions,
             eos_prob_threshold=getattr(self.args, "eos_prob_threshold", 0.5),
-            input_text=getattr(self.args, "input_text", False))
+            input_text=_flag_is_true(getattr(self.args, "input_text", False)))
 
     def build_generator(self, models, args, seq_gen_cls=None, extra_gen_cls_kwargs=None):
         """Text generator over an aux decoder (s2s_translation.py:312-336 -> FairseqTask.build_generator ->

@@ -105,15 +105,21 @@ def get_parser() -> argparse.ArgumentParser:
 
 
 def parse_args(argv: Optional[List[str]] = None) -> argparse.Namespace:
+    """fairseq/options.py:88-219 (``parse_args_and_arch``): a first pass finds ``--task`` / ``--arch`` / ``--criterion``,
+    then the flags of exactly those classes are added and the command line is parsed for good."""
     from . import criterions, models, tasks  # noqa: F401  (fill the registries)
+    pre, _ = get_parser().parse_known_args(argv)
+    if pre.arch not in ARCHS:
+        raise SystemExit(f"unknown --arch {pre.arch}; known: {sorted(ARCHS)}")
+    if pre.criterion not in CRITERIA:
+        raise SystemExit(f"unknown --criterion {pre.criterion}; known: {sorted(CRITERIA)}")
     p = get_parser()
-    TASKS["s2s_translation"].add_args(p)
-    MODELS["s2st_transformer"].add_args(p)
+    TASKS[pre.task].add_args(p)
+    MODELS[ARCHS[pre.arch][0]].add_args(p)
+    crit_args = getattr(CRITERIA[pre.criterion], "add_args", None)
+    if crit_args is not None:
+        crit_args(p)
     args = p.parse_args(argv)
-    if args.arch not in ARCHS:
-        raise SystemExit(f"unknown --arch {args.arch}; known: {sorted(ARCHS)}")
-    if args.criterion not in CRITERIA:
-        raise SystemExit(f"unknown --criterion {args.criterion}; known: {sorted(CRITERIA)}")
     if isinstance(args.adam_betas, str):
         args.adam_betas = tuple(float(x) for x in args.adam_betas.strip("()[] ").split(","))
     # store_true flags of the model parser that the architecture function must see as "unset"
@@ -211,11 +217,15 @@ def main(argv: Optional[List[str]] = None, device: Optional[torch.device] = None
         if extra and extra.get("train_iterator"):
             epoch_itr.load_state_dict(extra["train_iterator"])
         log(event="resume", file=restore, num_updates=trainer.num_updates, epoch=epoch_itr.epoch)
+    else:
+        extra = None
 
     max_update = args.max_update or float("inf")
     max_epoch = args.max_epoch or float("inf")
     summary = {"train_loss": [], "valid": [], "saved": []}
-    best = None
+    # fairseq/checkpoint_utils.py:41-46, 262-264: the best validation score survives a resume (a worse first validation
+    # after it must not overwrite checkpoint_best.pt)
+    best = extra.get("best") if extra else None
 
     # position of the TRAINER inside the epoch (the background stager runs ahead of it inside epoch_itr's own iterator,
     # so the iterator's counter is not the resume point)
@@ -226,11 +236,36 @@ def main(argv: Optional[List[str]] = None, device: Optional[torch.device] = None
             return {"version": 2, "epoch": epoch_itr.epoch + 1, "iterations_in_epoch": 0, "shuffle": True}
         return {"version": 2, "epoch": epoch_itr.epoch, "iterations_in_epoch": pos["consumed"], "shuffle": True}
 
+    def prune_checkpoints():
+        """fairseq/checkpoint_utils.py:137-187: --keep-last-epochs N keeps the N newest checkpoint<epoch>.pt,
+        --keep-best-checkpoints N the N best checkpoint.best_<metric>_<value>.pt."""
+        import re
+        def by_pattern(pattern):
+            rx, found = re.compile(pattern), []
+            for fn in os.listdir(args.save_dir):
+                m = rx.fullmatch(fn)
+                if m:
+                    found.append((float(m.group(1)), fn))
+            return [fn for _, fn in sorted(found, reverse=True)]
+        if args.keep_last_epochs > 0:
+            for fn in by_pattern(r"checkpoint(\d+)\.pt")[args.keep_last_epochs:]:
+                os.remove(os.path.join(args.save_dir, fn))
+        if args.keep_best_checkpoints > 0:
+            names = by_pattern(r"checkpoint\.best_%s_(\d+\.?\d*)\.pt" % re.escape(args.best_checkpoint_metric))
+            if not args.maximize_best_checkpoint_metric:
+                names = names[::-1]
+            for fn in names[args.keep_best_checkpoints:]:
+                os.remove(os.path.join(args.save_dir, fn))
+
     def save(tag_files: List[str], val: Optional[Dict[str, float]]):
         nonlocal best
-        if args.no_save or rank != 0:
+        if args.no_save:
             return
-        trainer.check_overflow()  # never write a checkpoint after a skipped (non-finite) update unnoticed
+        # every rank: a skipped (non-finite) update raises on all of them together -- rank 0 raising alone would leave
+        # the others blocked in the next all-reduce
+        trainer.check_overflow()
+        if rank != 0:
+            return
         state_extra = {"train_iterator": iter_state(), "val_loss": (val or {}).get(args.best_checkpoint_metric)}
         files = list(tag_files)
         if val and args.best_checkpoint_metric in val:
@@ -239,11 +274,14 @@ def main(argv: Optional[List[str]] = None, device: Optional[torch.device] = None
             if better:
                 best = v
                 files.append("checkpoint_best.pt")
+            if args.keep_best_checkpoints > 0:  # checkpoint_utils.py:95-104
+                files.append("checkpoint.best_%s_%.2f.pt" % (args.best_checkpoint_metric, v))
         state_extra["best"] = best
         for fn in files:
             path = os.path.join(args.save_dir, fn)
             checkpoint_utils.save_checkpoint(path, trainer, state_extra)
             summary["saved"].append(path)
+        prune_checkpoints()
 
     def validate_and_save(end_of_epoch: bool):
         """fairseq_cli/train.py:322-396."""
