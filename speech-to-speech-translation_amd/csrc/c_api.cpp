@@ -116,7 +116,7 @@ int s2st_adam_f32(float* p, float* g, float* m, float* v, int64_t n, const float
   return s2st_adam(p, g, m, v, n, sumsq, gmul, gmul_dev, max_norm, lr, beta1, beta2, eps, wd, step, gnorm_out, (hipStream_t)stream, (uint16_t*)p_bf16, skipped);
 }
 
-int64_t s2st_layernorm_bwd_scratch(int32_t rows, int32_t cols) { return (int64_t)s2st_layernorm_bwd_blocks(rows) * 2 * cols; }
+int64_t s2st_layernorm_bwd_scratch(int32_t rows, int32_t cols) { return (int64_t)s2st_layernorm_bwd_blocks(rows, cols) * 2 * cols; }
 int64_t s2st_ctc_workspace(int32_t B, int32_t E, int32_t Lmax) { return s2st_ctc_workspace_floats(B, E, Lmax); }
 
 int s2st_flash_attn_fwd_bf16(const s2st_attn_args* args, void* stream) { return s2st_flash_attn_fwd(args, (hipStream_t)stream); }

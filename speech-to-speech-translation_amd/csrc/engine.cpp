@@ -490,6 +490,20 @@ struct s2st_engine {
     pending_wgrad.clear();
   }
 
+  // layer-norm parameter gradients: the backward row kernels leave column-sum partials; one batched fold per backward
+  // segment (or per S2ST_LNFOLD_MAX layer norms) adds them to the gradient arena.  Parameter gradients only: the fold
+  // runs on the second stream behind everything enqueued on the stream the row kernels ran on.
+  s2st_lnfold_table pending_lnfold{};
+  bool ln_bwd_split = false;  // S2ST_LN_BWD_SPLIT=1 (A/B switch): round 2's separate parameter-gradient pass
+  void flush_lnfold() {
+    if (pending_lnfold.n == 0) return;
+    if (live()) {
+      hipStream_t s = (side_ && st_ != side_) ? fork_side() : st_;
+      chk(s2st_layernorm_bwd_fold(pending_lnfold, s));
+    }
+    pending_lnfold = s2st_lnfold_table{};
+  }
+
   // ------------------------------------------------------------------------------------
   // op: y = [resid +] dropout(act(x W^T + b))
   // only_h: the caller guarantees every consumer reads the bf16 copy (fast mode): no fp32 result is
@@ -665,12 +679,19 @@ struct s2st_engine {
       bool acc;
       float* dx = gradbuf(x, acc);
       const bool fuse = fuse_cand && !x->gpre_h;
-      float* scratch = alloc((long)s2st_layernorm_bwd_blocks(x->rows) * (fuse ? 3 : 2) * x->cols);
+      float* scratch = alloc((long)s2st_layernorm_bwd_blocks(x->rows, x->cols) * (fuse ? 3 : 2) * x->cols);
       bf16raw* dph = nullptr;
       if (fuse) dph = x->gpre_h = alloc_h(x->n());
       float* dbias = fuse && x->drop2_bias >= 0 ? G + x->drop2_bias : nullptr;
       if (live()) {
-        if (side_) {  // dx on the data path; the dgamma / dbeta reduce next to it on the second stream
+        if (!ln_bwd_split) {
+          // one row kernel on the data path (dx, the fused bf16 operand, and the column-sum partials of dgamma / dbeta /
+          // dbias); the partials of the segment's layer norms are folded together (flush_lnfold)
+          chk(s2st_layernorm_bwd(y->g, x->d, P + pp.g, mean, rstd, dx, acc ? 1 : 0, G + pp.g, G + pp.b, scratch,
+                                 x->rows, x->cols, st_, 3, dph, x->drop2_p, x->drop2_seed, dbias));
+          if (pending_lnfold.n == S2ST_LNFOLD_MAX) flush_lnfold();
+          chk(s2st_lnfold_add(pending_lnfold, scratch, x->rows, x->cols, fuse ? 3 : 2, G + pp.g, G + pp.b, dbias));
+        } else if (side_) {  // dx on the data path; the dgamma / dbeta reduce next to it on the second stream
           chk(s2st_layernorm_bwd(y->g, x->d, P + pp.g, mean, rstd, dx, acc ? 1 : 0, G + pp.g, G + pp.b, scratch,
                                  x->rows, x->cols, st_, 1, dph, x->drop2_p, x->drop2_seed, dbias));
           hipStream_t rs = fork_side();
@@ -678,7 +699,9 @@ struct s2st_engine {
                                  x->rows, x->cols, rs, 2, dph, x->drop2_p, x->drop2_seed, dbias));
         } else {
           chk(s2st_layernorm_bwd(y->g, x->d, P + pp.g, mean, rstd, dx, acc ? 1 : 0, G + pp.g, G + pp.b, scratch,
-                                 x->rows, x->cols, st_, 0, dph, x->drop2_p, x->drop2_seed, dbias));
+                                 x->rows, x->cols, st_, 1, dph, x->drop2_p, x->drop2_seed, dbias));
+          chk(s2st_layernorm_bwd(y->g, x->d, P + pp.g, mean, rstd, dx, acc ? 1 : 0, G + pp.g, G + pp.b, scratch,
+                                 x->rows, x->cols, st_, 2, dph, x->drop2_p, x->drop2_seed, dbias));
         }
       }
     });
@@ -1379,6 +1402,7 @@ struct s2st_engine {
   bool use_streamk = getenv("S2ST_GEMM_STREAMK") && atoi(getenv("S2ST_GEMM_STREAMK")) > 0;
   void reset_call() {
     pending_wgrad.clear();
+    pending_lnfold = s2st_lnfold_table{};
     s2st_gemm_streamk_unbind_all();  // the scratch lives in the previous call's workspace
     for (Ten* t : tens) delete t;
     tens.clear();
@@ -1704,8 +1728,8 @@ struct s2st_engine {
         // the aux decoders' backward (CTC head + text decoders: many small kernels that only produce
         // the taps' gradients and parameter gradients) runs on the second stream next to the mel
         // decoder's backward; the data path waits for it right before the tap layer norms consume it
-        if (i + 1 == aux_hi_idx && st_ == main_st) { flush_wgrad(); st_ = fork_side(); }
-        if (i + 1 == aux_lo_idx && st_ != main_st) { flush_wgrad(); hipEventRecord(ev_auxb_, st_); st_ = main_st; }
+        if (i + 1 == aux_hi_idx && st_ == main_st) { flush_wgrad(); flush_lnfold(); st_ = fork_side(); }
+        if (i + 1 == aux_lo_idx && st_ != main_st) { flush_wgrad(); flush_lnfold(); hipEventRecord(ev_auxb_, st_); st_ = main_st; }
         if (i + 1 == aux_wait_idx) wait_traced(main_st, ev_auxb_, "aux decoders' backward (tap gradients)");
       }
       tail_share = tail_closures > 0 && seg == ns - 1 && i < lo + (size_t)tail_closures && side_ != nullptr;
@@ -1714,6 +1738,7 @@ struct s2st_engine {
     }
     tail_share = false;
     flush_wgrad();  // the segment's gradients are final once its launches are enqueued
+    flush_lnfold();
     if (st_ != main_st) { hipEventRecord(ev_auxb_, st_); st_ = main_st; }
     // The segment's weight gradients live on the second stream.  A caller that overlaps the gradient
     // all-reduce waits on that stream itself (s2st_engine_side_stream); the data path only joins once,
@@ -1761,6 +1786,7 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->use_ln_fuse = !(getenv("S2ST_NO_LN_FUSE") && atoi(getenv("S2ST_NO_LN_FUSE")) != 0);
   e->use_attn_gfuse = getenv("S2ST_ATTN_GFUSE") && atoi(getenv("S2ST_ATTN_GFUSE")) != 0;
   e->attn_gfuse_mode = getenv("S2ST_ATTN_GFUSE") ? atoi(getenv("S2ST_ATTN_GFUSE")) : 0;
+  e->ln_bwd_split = getenv("S2ST_LN_BWD_SPLIT") && atoi(getenv("S2ST_LN_BWD_SPLIT")) != 0;
   e->ordered_sums = getenv("S2ST_ORDERED_BIAS_SUMS") && atoi(getenv("S2ST_ORDERED_BIAS_SUMS")) != 0;
   e->build_params();
   if (!cfg->precise && (s2st_gemm_bf16_preload(nullptr) != 0 || s2st_flash_attn_preload(nullptr) != 0)) { delete e; return S2ST_ERR_LAUNCH; }

@@ -219,6 +219,156 @@ __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* 
   }
 }
 
+// Round 3: ONE backward kernel on the data path.  The row pass above already holds dy, xhat and the rounded bf16 operand
+// in registers; a wave that walks RPW rows keeps the column sums of its rows in registers too (a lane owns the same
+// float4 column chunks in every row: no reduction inside the wave), the block's four waves meet once through 12 KB of
+// LDS, and the block writes ONE partial row per output -- the slab partials the parameter kernel used to produce in a
+// second pass over dy and x (18.8 MB per 4.6 k x 512 layer norm, 12 - 15 us on the second stream, 54 times a step).
+// The partials of all layer norms of a backward segment are folded by one batched launch (fixed order: run-to-run
+// identical sums).  All loads of a wave's RPW rows are issued before the first use.
+template <bool FUSE, int NV, int RPW>
+__global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx, int dx_accumulate, int rows,
+    int cols, uint16_t* __restrict__ dph, float drop_p, float inv_keep, uint64_t seed, float* __restrict__ part) {
+  constexpr int NOUT = FUSE ? 3 : 2;
+  __shared__ float4 red[3][64 * NV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = cols >> 2;
+  const float invc = 1.f / cols;
+  const int row0 = (blockIdx.x * 4 + wave) * RPW;
+  float4 gm[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = lane + 64 * i;
+    gm[i] = c4 < nv ? reinterpret_cast<const float4*>(gamma)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float4 xv[RPW][NV], dv[RPW][NV], old[RPW][NV];
+  float mu[RPW], rs[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int row = min(row0 + r, rows - 1);  // clamped: loads stay unconditional; results of rows >= rows are dropped
+    mu[r] = mean[row];
+    rs[r] = rstd[row];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c4 = lane + 64 * i;
+      if (c4 < nv) {
+        xv[r][i] = reinterpret_cast<const float4*>(x + (long)row * cols)[c4];
+        dv[r][i] = reinterpret_cast<const float4*>(dy + (long)row * cols)[c4];
+        if (dx_accumulate) old[r][i] = reinterpret_cast<const float4*>(dx + (long)row * cols)[c4];
+      }
+    }
+  }
+  float4 ag[NV], ab[NV], ad[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) ag[i] = ab[i] = ad[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int row = row0 + r;
+    if (row >= rows) break;  // wave-uniform
+    float4 xh[NV], g[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c4 = lane + 64 * i;
+      if (c4 < nv) {
+        const float4 a = xv[r][i], d = dv[r][i];
+        xh[i].x = (a.x - mu[r]) * rs[r]; xh[i].y = (a.y - mu[r]) * rs[r];
+        xh[i].z = (a.z - mu[r]) * rs[r]; xh[i].w = (a.w - mu[r]) * rs[r];
+        g[i].x = d.x * gm[i].x; g[i].y = d.y * gm[i].y; g[i].z = d.z * gm[i].z; g[i].w = d.w * gm[i].w;
+        s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+        s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
+        ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y; ag[i].z += d.z * xh[i].z; ag[i].w += d.w * xh[i].w;
+        ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+      }
+    }
+    s1 = wave_sum(s1) * invc;
+    s2 = wave_sum(s2) * invc;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c4 = lane + 64 * i;
+      if (c4 < nv) {
+        float4 o;
+        o.x = rs[r] * (g[i].x - s1 - xh[i].x * s2);
+        o.y = rs[r] * (g[i].y - s1 - xh[i].y * s2);
+        o.z = rs[r] * (g[i].z - s1 - xh[i].z * s2);
+        o.w = rs[r] * (g[i].w - s1 - xh[i].w * s2);
+        if (dx_accumulate) { o.x += old[r][i].x; o.y += old[r][i].y; o.z += old[r][i].z; o.w += old[r][i].w; }
+        reinterpret_cast<float4*>(dx + (long)row * cols)[c4] = o;
+        if (FUSE) {
+          const uint64_t e0 = (uint64_t)row * cols + 4 * c4;
+          o.x *= drop_scale(seed, e0, drop_p, inv_keep); o.y *= drop_scale(seed, e0 + 1, drop_p, inv_keep);
+          o.z *= drop_scale(seed, e0 + 2, drop_p, inv_keep); o.w *= drop_scale(seed, e0 + 3, drop_p, inv_keep);
+          const uint2 h = pack_bf16x4(o.x, o.y, o.z, o.w);
+          reinterpret_cast<uint2*>(dph + (long)row * cols)[c4] = h;
+          // the bias gradient of the producing layer sums the ROUNDED operand (what its weight-gradient product sees)
+          ad[i].x += __uint_as_float(h.x << 16); ad[i].y += __uint_as_float(h.x & 0xffff0000u);
+          ad[i].z += __uint_as_float(h.y << 16); ad[i].w += __uint_as_float(h.y & 0xffff0000u);
+        }
+      }
+    }
+  }
+  // the block's partial row of each output: waves 1 .. 3 hand their sums to wave 0 (added in wave order)
+  float* p = part + (long)blockIdx.x * NOUT * cols;
+  auto fold = [&](float4 (&acc)[NV], int o) {
+    if (wave > 0) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) red[wave - 1][lane + 64 * i] = acc[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c4 = lane + 64 * i;
+        float4 v = acc[i];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          const float4 t = red[w][c4];
+          v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        if (c4 < nv) reinterpret_cast<float4*>(p + (long)o * cols)[c4] = v;
+      }
+    }
+    __syncthreads();
+  };
+  fold(ag, 0);
+  fold(ab, 1);
+  if (FUSE) fold(ad, 2);
+}
+
+// the fold of layernorm_bwd_reduce_kernel for a whole table of layer norms in one launch
+__global__ __launch_bounds__(256) void layernorm_bwd_fold_batched_kernel(s2st_lnfold_table t) {
+  __shared__ float red[8][32];
+  int it = 0;
+  while (it + 1 < t.n && (int)blockIdx.x >= t.blk0[it + 1]) ++it;
+  const s2st_lnfold_item f = t.item[it];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = ((int)blockIdx.x - t.blk0[it]) * 32 + tx;  // over nout * cols
+  const long ld = (long)f.nout * f.cols;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < f.nout * f.cols) {
+    int b = ty;
+    for (; b + 24 < f.nblocks; b += 32) {
+      a0 += f.part[(long)b * ld + c];
+      a1 += f.part[(long)(b + 8) * ld + c];
+      a2 += f.part[(long)(b + 16) * ld + c];
+      a3 += f.part[(long)(b + 24) * ld + c];
+    }
+    for (; b < f.nblocks; b += 8) a0 += f.part[(long)b * ld + c];
+  }
+  red[ty][tx] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (ty == 0 && c < f.nout * f.cols) {
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v += red[i][tx];
+    if (c < f.cols) f.dgamma[c] += v;
+    else if (c < 2 * f.cols) f.dbeta[c - f.cols] += v;
+    else if (f.dbias) f.dbias[c - 2 * f.cols] += v;
+  }
+}
+
 constexpr int SM_MAXE = 16;  // elements per lane cached (S <= 1024)
 
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ s,
@@ -387,21 +537,54 @@ int s2st_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
 }
 
 static int ln_param_rows_per_block(int rows) {
-  // 32-row slabs (one partial row per block), at most 512 blocks
+  // (split form) 32-row slabs (one partial row per block), at most 512 blocks
   int rpb = 32;
   while ((rows + rpb - 1) / rpb > 512) rpb *= 2;
   return rpb;
 }
-
-int s2st_layernorm_bwd_blocks(int rows) {
+static int ln_split_blocks(int rows) {
   const int rpb = ln_param_rows_per_block(rows);
   const int b = (rows + rpb - 1) / rpb;
   return b < 1 ? 1 : b;
 }
+// fused form: 4 waves x RPW rows per block; RPW = 4 while a lane holds <= 2 float4 per row (cols <= 512), else 2
+static int ln_fused_rows_per_block(int cols) { return cols <= 512 ? 16 : 8; }
+static int ln_fused_blocks(int rows, int cols) {
+  const int rpb = ln_fused_rows_per_block(cols);
+  const int b = (rows + rpb - 1) / rpb;
+  return b < 1 ? 1 : b;
+}
 
-// scratch: s2st_layernorm_bwd_blocks(rows) * (dph ? 3 : 2) * cols floats.
+// partial rows either form writes (the scratch holds the larger of the two)
+int s2st_layernorm_bwd_blocks(int rows, int cols) {
+  const int a = ln_split_blocks(rows), b = ln_fused_blocks(rows, cols);
+  return a > b ? a : b;
+}
+
+int s2st_layernorm_bwd_fold(const s2st_lnfold_table& t, hipStream_t st) {
+  if (t.n <= 0) return 0;
+  S2ST_LAUNCH(layernorm_bwd_fold_batched_kernel, dim3(t.blk0[t.n]), dim3(256), 0, st, t);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+int s2st_lnfold_add(s2st_lnfold_table& t, const float* part, int rows, int cols, int nout, float* dgamma, float* dbeta,
+                    float* dbias) {
+  if (t.n >= S2ST_LNFOLD_MAX) return S2ST_ERR_ARG;
+  s2st_lnfold_item& f = t.item[t.n];
+  f.part = part; f.dgamma = dgamma; f.dbeta = dbeta; f.dbias = dbias;
+  f.nblocks = ln_fused_blocks(rows, cols); f.cols = cols; f.nout = nout;
+  t.blk0[t.n + 1] = t.blk0[t.n] + (nout * cols + 31) / 32;
+  ++t.n;
+  return 0;
+}
+
+// scratch: s2st_layernorm_bwd_blocks(rows, cols) * (dph ? 3 : 2) * cols floats.
 // dph != null: fused backward prologue of the linear layer that produced x (see the kernels): dph [rows][cols] bf16 =
 // dropout'(dx_total) with the (seed, p) mask, dbias += its column sums (may be null).
+// phase 0: everything on st (one row kernel that also leaves the column-sum partials + their fold);
+//       3: that row kernel alone -- the caller folds the partials of several layer norms in one launch
+//          (s2st_lnfold_add / s2st_layernorm_bwd_fold);
+//    1, 2: the round-2 split form (1: the dx row kernel; 2: a second pass over dy and x for the parameter gradients +
+//          its fold, which the engine used to put on its second stream) -- S2ST_LN_BWD_SPLIT=1, the A/B switch
 int s2st_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                        const float* rstd, float* dx, int dx_accumulate, float* dgamma,
                        float* dbeta, float* scratch, int rows, int cols, hipStream_t st, int phase,
@@ -409,10 +592,26 @@ int s2st_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
   if (rows <= 0) return 0;
   if (cols % 4 != 0 || cols > LN_MAXV * 256) return S2ST_ERR_SHAPE;
   if (dph && ((uintptr_t)dph % 8 || drop_p < 0.f || drop_p >= 1.f)) return S2ST_ERR_ARG;
-  // phase 0: everything on st; 1: only dx (+ the fused bf16 operand); 2: only the parameter gradients (lets the
-  // caller put them on another stream: they are off the backward's critical path)
-  if (phase != 2) {
+  if (phase == 0 || phase == 3) {
+    const int blocks = ln_fused_blocks(rows, cols);
     // bytes: dy, x read; dx written (read too when it accumulates); the bf16 operand of the fused form
+    const double by = (double)rows * cols * (12 + (dx_accumulate ? 4 : 0) + (dph ? 2 : 0));
+    const float ik = dph ? 1.f / (1.f - drop_p) : 1.f;
+#define LN_FUSED(FUSE, NV, RPW)                                                                                        \
+    s2st_launch("layernorm_bwd_fused_kernel<" #FUSE ">", by, 0.0, layernorm_bwd_fused_kernel<FUSE, NV, RPW>, dim3(blocks), \
+                dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, dx_accumulate, rows, cols, dph, drop_p, ik, seed, scratch)
+    if (cols <= 256) { if (dph) LN_FUSED(true, 1, 4); else LN_FUSED(false, 1, 4); }
+    else if (cols <= 512) { if (dph) LN_FUSED(true, 2, 4); else LN_FUSED(false, 2, 4); }
+    else { if (dph) LN_FUSED(true, 4, 2); else LN_FUSED(false, 4, 2); }
+#undef LN_FUSED
+    if (phase == 0) {
+      s2st_lnfold_table t{};
+      s2st_lnfold_add(t, scratch, rows, cols, dph ? 3 : 2, dgamma, dbeta, dbias);
+      return s2st_layernorm_bwd_fold(t, st);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+  }
+  if (phase != 2) {
     const double by = (double)rows * cols * (12 + (dx_accumulate ? 4 : 0) + (dph ? 2 : 0));
     if (dph)
       s2st_launch("layernorm_bwd_dx_kernel<true>", by, 0.0, layernorm_bwd_dx_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0,
@@ -422,7 +621,7 @@ int s2st_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
                   0, st, dy, x, gamma, mean, rstd, dx, dx_accumulate, rows, cols, (uint16_t*)nullptr, 0.f, 1.f, (uint64_t)0);
   }
   if (phase != 1) {
-    const int rpb = ln_param_rows_per_block(rows), blocks = s2st_layernorm_bwd_blocks(rows);
+    const int rpb = ln_param_rows_per_block(rows), blocks = ln_split_blocks(rows);
     const int nout = dph ? 3 : 2;
     const dim3 grid(blocks, (cols / 4 + 255) / 256);
     const double by = (double)rows * cols * (8 + (dph ? 2 : 0));

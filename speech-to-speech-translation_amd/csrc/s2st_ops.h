@@ -82,6 +82,11 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* tile_out);
 int s2st_gemm_skinny(const float* A, long lda, const bf16raw* W, long ldw, float* C, long ldc, const float* bias, int act,
                      float drop_p, uint64_t seed, const float* resid, long ldr, int M, int N, int K, hipStream_t st,
                      const float* ln_g = nullptr, const float* ln_b = nullptr, float ln_eps = 1e-5f /* optional fused LayerNorm of x */);
+// gemm_bf16_w4.hip: the 4-wave early-release ring form (2 - 3 workgroups per CU) for the short-K products of a step;
+// g / grp as prepared by s2st_gemm_bf16 / s2st_gemm_bf16_group for the tile (bm, bn)
+int s2st_gemm_bf16_w4(const GemmArgs& g, int bm, int bn, dim3 grid, hipStream_t st);
+int s2st_gemm_bf16_w4_group(const GemmGroup& grp, hipStream_t st);
+int s2st_gemm_bf16_w4_preload(hipStream_t st);
 int s2st_gemm_bf16_preload(hipStream_t st);  // load every instantiation (empty launches)  // gemm_bf16.hip (both operands bf16)
 void s2st_profile_enable_impl(int on);                 // per-dispatch timing registry (s2st_prof.h, gemm.hip)
 long s2st_profile_report_impl(char* out, long cap, int mode = 0);
@@ -93,7 +98,14 @@ int s2st_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
                        float* mean, float* rstd, int rows, int cols, float eps, hipStream_t st,
                        uint16_t* yh = nullptr /* optional bf16 copy of y */);
 // dx (=|+=) ...; dgamma += , dbeta += (per-block partials in `scratch`, then a reduce kernel)
-int s2st_layernorm_bwd_blocks(int rows);  // scratch floats = blocks * (dph ? 3 : 2) * cols
+int s2st_layernorm_bwd_blocks(int rows, int cols);  // scratch floats = blocks * (dph ? 3 : 2) * cols
+// column-sum partials of several layer-norm backward passes (phase 3 below), folded by ONE launch in a fixed order
+#define S2ST_LNFOLD_MAX 24
+struct s2st_lnfold_item { const float* part; float *dgamma, *dbeta, *dbias; int nblocks, cols, nout; };
+struct s2st_lnfold_table { int n; int blk0[S2ST_LNFOLD_MAX + 1]; s2st_lnfold_item item[S2ST_LNFOLD_MAX]; };
+int s2st_lnfold_add(s2st_lnfold_table& t, const float* part, int rows, int cols, int nout, float* dgamma, float* dbeta,
+                    float* dbias);
+int s2st_layernorm_bwd_fold(const s2st_lnfold_table& t, hipStream_t st);
 // dph: optional fused backward prologue of the linear+dropout layer that produced x (rowops.hip)
 int s2st_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                        const float* rstd, float* dx, int dx_accumulate, float* dgamma,

@@ -378,13 +378,50 @@ def test_bf16_persistent_kernel(backend, monkeypatch, akm, bkm, K):
     assert torch.equal(C3, C)
 
 
-@pytest.mark.parametrize("tile", [128, 256, "oneshot"])
+@pytest.mark.parametrize("akm,bkm", [(True, True), (True, False), (False, False), (False, True)])
+@pytest.mark.parametrize("K", [64, 200, 512])
+@pytest.mark.parametrize("tile", ["128x128", "128x64"])
+def test_bf16_w4_early_release_kernel(backend, monkeypatch, akm, bkm, K, tile):
+    """The 4-wave early-release ring form (gemm_bf16_w4.hip; S2ST_GEMM_W4=1): K = 64 is a single K-step (no refill), K =
+    200 has a K tail behind refills, K = 512 runs the steady state; every operand layout, both tile shapes; epilogue
+    variants with both output copies; bit-equal to the 8-wave ring kernel (same products, same summation order)."""
+    monkeypatch.setenv("S2ST_GEMM_W4", "1")
+    monkeypatch.setenv("S2ST_GEMM_PERSIST", "0")
+    monkeypatch.setenv("S2ST_GEMM_TILE", tile)
+    M, N = (384, 256) if backend.kind == "emu" else (4584, 1536)
+    g = torch.Generator().manual_seed(K + 2 * akm + bkm)
+    A, B = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g))
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    Am, a_ld = _pad_cols(A if akm else A.t().contiguous())
+    Bm, b_ld = _pad_cols(B if bkm else B.t().contiguous())
+    d = backend.device
+    R = A.double() @ B.double().t()
+    C = torch.full((M, N), 7.0, device=d)
+    Ch = torch.zeros(M, N, dtype=torch.bfloat16, device=d)
+    backend.bd.gemm(Am.to(d), Bm.to(d), C, M, N, K, a_kmajor=akm, b_kmajor=bkm, a_ld=a_ld, b_ld=b_ld, c_bf16=Ch)
+    backend.sync()
+    assert _relerr(C, R) < 2e-6
+    assert torch.equal(Ch.cpu(), C.cpu().to(torch.bfloat16))
+    C2 = torch.zeros(M, N, device=d)
+    backend.bd.gemm(Am.to(d), Bm.to(d), C2, M, N, K, a_kmajor=akm, b_kmajor=bkm, a_ld=a_ld, b_ld=b_ld, alpha=0.5,
+                    bias=bias.to(d), act=1, resid=res.to(d))
+    backend.sync()
+    assert _relerr(C2, torch.relu(0.5 * R + bias.double()) + res.double()) < 2e-6
+    monkeypatch.setenv("S2ST_GEMM_W4", "0")
+    C3 = torch.zeros(M, N, device=d)
+    backend.bd.gemm(Am.to(d), Bm.to(d), C3, M, N, K, a_kmajor=akm, b_kmajor=bkm, a_ld=a_ld, b_ld=b_ld)
+    backend.sync()
+    assert torch.equal(C3, C)
+
+
+@pytest.mark.parametrize("tile", [128, 256, "oneshot", "w4"])
 def test_bf16_group_of_weight_gradients(backend, monkeypatch, tile):
     """s2st_gemm_group_f32: a layer's weight-gradient products dW_i += dY_i^T X_i (different shapes, K = tokens, one with
     a K tail) in one launch, against the exact sums; 128 x 128 tiles and (S2ST_GROUP_TILE=256) 256 x 128 tiles with a
     ragged last tile row."""
-    if tile == "oneshot":  # (default) one workgroup per tile of the concatenated list, plain K-loop
+    if tile in ("oneshot", "w4"):  # (default) one workgroup per tile of the concatenated list, plain K-loop
         monkeypatch.setenv("S2ST_GROUP_ONESHOT", "1")
+        monkeypatch.setenv("S2ST_GEMM_W4", "2" if tile == "w4" else "0")  # w4: the 4-wave early-release form of it
     else:                  # the persistent tile walk
         monkeypatch.setenv("S2ST_GROUP_ONESHOT", "0")
         monkeypatch.setenv("S2ST_GROUP_TILE", str(tile))
