@@ -203,13 +203,19 @@ int s2st_ctc_f32(const float* logits, const int64_t* targets, int32_t Lmax, cons
 
 /* fairseq/utils.py:345-385 gradient L2 norm (sum of squares, out +=) */
 int s2st_sumsq_f32(const float* x, int64_t n, float* out, void* stream);
+/* the same sum left as per-block partial sums in parts[0 .. s2st_sumsq_parts_count(n)) (count <= 1024): plain stores,
+ * nothing to zero beforehand; s2st_adam_f32(sumsq = parts, sumsq_parts = count) adds them in index order, so the norm --
+ * and everything the clip coefficient touches -- repeats bit for bit from run to run */
+int s2st_sumsq_parts_f32(const float* x, int64_t n, float* parts, void* stream);
+int64_t s2st_sumsq_parts_count(int64_t n);
 
 /* trainer.py:838-873 + adam.py:163-239: grad scale (gmul * *gmul_dev), clip-by-norm, fairseq Adam on a flat arena.
  * p_bf16 (optional): bf16 copy of the updated parameters (the GEMM-operand copy of the next forward, see
  * s2st_engine_bind_bf16 / s2st_engine_bf16_is_fresh).  skipped (optional, device int32): incremented when the
  * gradient norm is non-finite; parameters, moments and gradients are then left untouched (the reference raises
- * FloatingPointError at trainer.py:860-867 -- the host reads this counter at its logging interval and does the same) */
-int s2st_adam_f32(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float gmul, const float* gmul_dev, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int32_t step, float* gnorm_out, void* p_bf16, int32_t* skipped, void* stream);
+ * FloatingPointError at trainer.py:860-867 -- the host reads this counter at its logging interval and does the same).
+ * sumsq_parts: 0 = sumsq is one float; > 0 = sumsq holds that many partial sums (s2st_sumsq_parts_f32) */
+int s2st_adam_f32(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float gmul, const float* gmul_dev, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int32_t step, float* gnorm_out, void* p_bf16, int32_t* skipped, int32_t sumsq_parts, void* stream);
 
 /* floats of workspace s2st_ctc_f32 needs */
 int64_t s2st_ctc_workspace(int32_t B, int32_t E, int32_t Lmax);

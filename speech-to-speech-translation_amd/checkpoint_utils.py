@@ -28,6 +28,22 @@ def load_checkpoint_to_cpu(path: str) -> Dict[str, Any]:
     return state
 
 
+def load_pretrained_component_from_model(model, component_type: str, checkpoint: str):
+    """fairseq/checkpoint_utils.py:784-812 for ``--load-pretrained-encoder-from`` / ``--load-pretrained-decoder-from``
+    (examples/s2s_trans/models/s2st_transformer.py:704-733): the ``encoder`` / ``decoder`` entries of the checkpoint's
+    model state are loaded into the module of that name, non-strictly like the reference (entries the module does not
+    have, or lacks, are skipped; a shape mismatch is an error, as in ``load_state_dict``).  The parameters are views of
+    the engine's arena, so the copy lands in place."""
+    if component_type not in ("encoder", "decoder"):
+        raise ValueError("component to load must be either the encoder or the decoder")
+    state = load_checkpoint_to_cpu(checkpoint)
+    comp = getattr(model, component_type)
+    sub = {k[len(component_type) + 1:]: v for k, v in state["model"].items() if k.startswith(component_type + ".")}
+    res = comp.load_state_dict(sub, strict=False)
+    # (the copies bump the arena tensor's version: the engine's next forward refreshes its bf16 operand copy)
+    return [k for k in sub if k not in res.unexpected_keys]
+
+
 def _arena_slices(engine):
     """name -> (offset, numel) of every trainable parameter inside the flat arenas."""
     base = engine.params.data_ptr()

@@ -141,13 +141,16 @@ __device__ __forceinline__ void store_grad(const f32x4 (&t)[DT], float scale, bo
       if (hp) *reinterpret_cast<uint2*>(hp + 16 * d + 4 * g) = pack_bf16x4(v[0], v[1], v[2], v[3]);
     }
     if (db) {
+      // column sums over the wave's 16 rows (the 16 lanes of a DPP row): four DPP adds per value (s2st_asm.h) -- round 2
+      // used four ds_bpermute shuffles per value here (128 per accumulator set on the data path: +3.8 % of a step)
+      float c[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float c = v[r];
-        c += __shfl_xor(c, 1); c += __shfl_xor(c, 2); c += __shfl_xor(c, 4); c += __shfl_xor(c, 8);
-        if ((lane & 15) == 0) {
-          if (db_store) db[16 * d + 4 * g + r] = c;
-          else atomicAdd(db + 16 * d + 4 * g + r, c);
+      for (int r = 0; r < 4; ++r) c[r] = row16_sum(v[r]);
+      if ((lane & 15) == 0) {
+        if (db_store) *reinterpret_cast<float4*>(db + 16 * d + 4 * g) = make_float4(c[0], c[1], c[2], c[3]);
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomicAdd(db + 16 * d + 4 * g + r, c[r]);
         }
       }
     }
@@ -565,6 +568,12 @@ long s2st_flash_attn_db_scratch_floats(const s2st_attn_args* p) {
   const long C = (long)p->H * p->dh;
   const long sq = (long)p->B * ((p->T + 16 * nw - 1) / (16 * nw)) * nw, sk = (long)p->B * ((p->S + 16 * nw - 1) / (16 * nw)) * nw;
   return (sq + 2 * sk) * C;
+}
+
+void s2st_flash_attn_db_layout(const s2st_attn_args* p, int* slots_q, int* slots_k) {
+  const int nw = attn_nw();
+  *slots_q = p->B * ((p->T + 16 * nw - 1) / (16 * nw)) * nw;
+  *slots_k = p->B * ((p->S + 16 * nw - 1) / (16 * nw)) * nw;
 }
 
 int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_scratch, hipStream_t st, int phase,

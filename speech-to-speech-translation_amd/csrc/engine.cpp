@@ -150,14 +150,15 @@ struct s2st_engine {
   bool skip_resid_h = true;  // S2ST_RESID_H=1 (A/B switch): also write bf16 copies of residual-stream outputs
   bool use_ln_fuse = true;  // S2ST_NO_LN_FUSE=1 (A/B switch): separate dropout-backward prologue pass
   bool use_only_h = true;  // S2ST_NO_ONLY_H=1: always keep the fp32 copy of GEMM-only tensors (A/B switch)
-  // S2ST_ATTN_GFUSE=1 / 2 / 3: the attention backward emits the bf16 projection gradients itself (no fp32 gradient, no
-  // cast pass); the modes differ in where the projections' bias gradients come from (attention block below).  OFF by
-  // default since round 2: round 1's form (= 3, -1.2 ... -1.7 % step time) sums the ROUNDED gradients, which turns a key
-  // bias's mathematically zero gradient into a rounding residue that changes with any upstream ulp -- multi-update
-  // trajectories of cold processes then repeat in ~85 % of runs instead of 32 of 32; the exact forms (1: partial sums,
-  // 2: atomics) repeat but cost +3.8 % / +16 % (Reproducibility).
-  bool use_attn_gfuse = false;
-  int attn_gfuse_mode = 0;
+  // S2ST_ATTN_GFUSE (default 1): the attention backward emits the bf16 projection gradients itself (no fp32 gradient, no
+  // cast pass: ~30 launches fewer on the data path); the modes differ in where the projections' bias gradients come from
+  // (attention block below).  1 (default since round 3): out of the kernels' fp32 accumulators BEFORE rounding, as per-(block,
+  // wave) partial sums by DPP row reductions, folded in a fixed order with the segment's layer-norm partials -- exact (a key
+  // bias's mathematically zero gradient stays ~0) and run-to-run identical; 2: the same sums as fp32 atomics; 3: column sums of
+  // the ROUNDED copies (round 1's form: a rounding residue instead of ~0 that changes with any upstream ulp -- multi-update
+  // trajectories of cold processes then repeat in ~85 % of runs); 0: off (fp32 gradients + cast pass).
+  bool use_attn_gfuse = true;
+  int attn_gfuse_mode = 1;
   // S2ST_ORDERED_BIAS_SUMS=1: bias-gradient column sums as slab partials + a fixed-order fold instead of fp32 atomics
   // (one more small kernel per sum: ~1 % of the step; built while chasing the reproducibility issue, did not settle it)
   bool ordered_sums = false;
@@ -773,7 +774,16 @@ struct s2st_engine {
           if (attn_gfuse_mode != 2) dbp = alloc(s2st_flash_attn_db_scratch_floats(&fb));
         }
         if (live()) chk(s2st_flash_attn_bwd(&fb, o->g, dvec, st_, 0, dbp));
-        if (dbp && live()) chk(s2st_flash_attn_db_fold(&fb, dbp, fork_side()));  // parameter gradients: second stream
+        if (dbp && live()) {
+          // parameter gradients: the partials join the segment's batched fold (flush_lnfold, second stream)
+          int sq = 0, sk = 0;
+          s2st_flash_attn_db_layout(&fb, &sq, &sk);
+          const int Cm = fb.H * fb.dh;
+          if (pending_lnfold.n + 3 > S2ST_LNFOLD_MAX) flush_lnfold();
+          if (fb.dbq) chk(s2st_fold_add(pending_lnfold, dbp, sq, Cm, 1, fb.dbq, nullptr, nullptr));
+          if (fb.dbk) chk(s2st_fold_add(pending_lnfold, dbp + (long)sq * Cm, sk, Cm, 1, fb.dbk, nullptr, nullptr));
+          if (fb.dbv) chk(s2st_fold_add(pending_lnfold, dbp + (long)(sq + sk) * Cm, sk, Cm, 1, fb.dbv, nullptr, nullptr));
+        }
         if (gf && !gf_db) {
           // projection bias gradients = column sums of the bf16 gradients: parameter gradients only, so
           // on the second stream (atomics from inside the attention kernels contend on H*dh addresses)
@@ -1784,8 +1794,8 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->use_skinny = !(getenv("S2ST_NO_SKINNY") && atoi(getenv("S2ST_NO_SKINNY")) != 0);
   e->skip_resid_h = !(getenv("S2ST_RESID_H") && atoi(getenv("S2ST_RESID_H")) != 0);
   e->use_ln_fuse = !(getenv("S2ST_NO_LN_FUSE") && atoi(getenv("S2ST_NO_LN_FUSE")) != 0);
-  e->use_attn_gfuse = getenv("S2ST_ATTN_GFUSE") && atoi(getenv("S2ST_ATTN_GFUSE")) != 0;
-  e->attn_gfuse_mode = getenv("S2ST_ATTN_GFUSE") ? atoi(getenv("S2ST_ATTN_GFUSE")) : 0;
+  e->attn_gfuse_mode = getenv("S2ST_ATTN_GFUSE") ? atoi(getenv("S2ST_ATTN_GFUSE")) : 1;
+  e->use_attn_gfuse = e->attn_gfuse_mode != 0;
   e->ln_bwd_split = getenv("S2ST_LN_BWD_SPLIT") && atoi(getenv("S2ST_LN_BWD_SPLIT")) != 0;
   e->ordered_sums = getenv("S2ST_ORDERED_BIAS_SUMS") && atoi(getenv("S2ST_ORDERED_BIAS_SUMS")) != 0;
   e->build_params();

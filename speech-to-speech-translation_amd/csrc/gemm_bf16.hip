@@ -965,12 +965,32 @@ int persist_mode() {
   return ev ? atoi(ev) : 1;
 }
 
-// S2ST_GEMM_W4 (read per call: an A/B switch): 0 = the 8-wave ring kernels (one workgroup per CU); 1 = 128-row
-// single products on the 4-wave early-release form (gemm_bf16_w4.hip, 2 - 3 workgroups per CU); 2 = grouped weight
-// gradients too
+// S2ST_GEMM_W4 (read per call: an A/B switch): 0 = the 8-wave ring kernels only (one workgroup per CU); -1 (default) =
+// the 4-wave early-release form (gemm_bf16_w4.hip, 2 - 3 workgroups per CU) for single products with at least one
+// 128 x 128 tile per CU, see w4_pick(); 1 = every 128-row single product on it; 2 = grouped weight gradients too
 int w4_mode() {
   const char* ev = getenv("S2ST_GEMM_W4");
-  return ev ? atoi(ev) : 0;
+  return ev ? atoi(ev) : -1;
+}
+
+// Which form runs a single product (measured per shape on MI355X with tools/gemm_forms_bench.py, kernel time from
+// events attached to the dispatch, profiles/r03_gemm_forms.txt).  With fewer 128 x 128 tiles than CUs (M ~ 4.6 k tokens x
+// N = 512: 144 tiles) nothing co-resides anyway and the 8-wave kernel's faster K-loop wins (17.5 vs 23.9 us at K = 2048);
+// from one tile per CU on, two or three co-resident workgroups hide each other's prologue / epilogue / barrier waits:
+// N = 1536 ... 2048 at K = 512 run 10 - 30 % shorter (4584 x 2048 x 512: 17.5 vs 21.4 us; 2800 x 1536 x 512: 11.1 vs 15.8).
+// Between the two 4-wave shapes the fuller last round wins: 128 x 128 tiles over 2 slots per CU against 128 x 64 tiles
+// over 3 (the pick agreed with the faster of the two on every measured shape).
+// Returns 0 (8-wave kernels), else bn of the 128-row 4-wave form.
+int w4_pick(const GemmArgs& g, bool dma_ok) {
+  const int mode = w4_mode();
+  if (mode == 0 || !dma_ok || g.M < 128) return 0;
+  const long tm = (g.M + 127) / 128;
+  const long t128 = tm * ((g.N + 127) / 128) * g.batch, t64 = tm * ((g.N + 63) / 64) * g.batch;
+  if (mode < 0 && t128 < num_cus()) return 0;
+  const long s128 = 2L * num_cus(), s64 = 3L * num_cus();
+  const double e128 = (double)t128 / (double)(((t128 + s128 - 1) / s128) * s128);
+  const double e64 = (double)t64 / (double)(((t64 + s64 - 1) / s64) * s64);
+  return (g.N > 64 && e128 >= e64) ? 128 : 64;
 }
 
 template <int BN, int BM = 128>
@@ -1107,6 +1127,17 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
   if (bm == 256 && !(vec && dma_layout_ok(g) && g.batch == 1)) { bm = 128; bn = 128; }  // 256-row tiles: ring kernels only
   const bool can_split_ = g.ep.accumulate && linear_epi && g.C.p && !g.C.h && !g.ep.bias && !g.ep.resid && g.K >= 8 * BK;
   if (vec && can_split_ && (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch < 256) { bm = 128; bn = 128; }
+  // the 4-wave early-release form (w4_pick above): a forced tile is honoured (S2ST_GEMM_W4 >= 1 puts it on that form)
+  int w4bn = 0;
+  {
+    static const int use_dma_w4 = getenv("S2ST_GEMM_DMA") ? atoi(getenv("S2ST_GEMM_DMA")) : 1;
+    const bool split_like = can_split_ && (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch < 256;
+    if (vec && use_dma_w4 && dma_layout_ok(g) && !split_like && persist_mode() != 2) {
+      if (getenv("S2ST_GEMM_TILE")) w4bn = (w4_mode() >= 1 && bm == 128 && (bn == 128 || bn == 64)) ? bn : 0;
+      else w4bn = w4_pick(g, true);
+      if (w4bn) { bm = 128; bn = w4bn; }
+    }
+  }
   const int tm = (g.M + bm - 1) / bm, tn = (g.N + bn - 1) / bn;
   const long nt = (long)tm * tn * g.batch;
   // split-K only for accumulating fp32 outputs with a linear epilogue (weight gradients): K is
@@ -1146,7 +1177,7 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
   bool sk_bound = false;
   if (streamk_mode() > 0 && bm == 128 && bn == 128)
     for (int i = 0; i < g_sk_n; ++i) sk_bound = sk_bound || (g_sk[i].st == st && g_sk[i].p);
-  if (dma_ok && g.batch == 1 && g.splitk == 1 && bm == 128 && persist_mode() > 0 &&
+  if (dma_ok && g.batch == 1 && g.splitk == 1 && bm == 128 && persist_mode() > 0 && !w4bn &&
       (persist_mode() == 2 || (persist_mode() == 3 && nt > num_cus()) || (sk_bound && (nt > num_cus() || (long)nt * ((g.K + BK - 1) / BK) >= 8L * num_cus())))) {
     GemmGroup grp{};
     int rc;
@@ -1159,7 +1190,7 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
     int rc;
     // (one instantiation per tile shape: the interleaved steady state, 8 waves for 128-row tiles; the round-2 A/B forms
     // -- plain loop, 4 waves, 2 / 3 / 5 ring stages, 64 x 128 -- were measured then and are no longer built)
-    if (bm == 128 && (bn == 128 || bn == 64) && w4_mode() >= 1) rc = s2st_gemm_bf16_w4(g, bm, bn, grid, st);
+    if (w4bn && g.splitk == 1) rc = s2st_gemm_bf16_w4(g, bm, bn, grid, st);
     else if (bm == 256 && bn == 128) rc = launch_dma<256, 128, 3, 8>(g, grid, st);
     else if (bm == 128 && bn == 128) rc = launch_dma<128, 128, 4, 8, true>(g, grid, st);
     else if (bm == 128) rc = launch_dma<128, 64, 4, 8, true>(g, grid, st);

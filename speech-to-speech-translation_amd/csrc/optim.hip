@@ -10,7 +10,7 @@
 namespace {
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n,
-                                                    float* __restrict__ out) {
+                                                    float* __restrict__ out, int parts) {
   __shared__ float red[4];
   float a = 0.f;
   long n4 = n >> 2;
@@ -24,7 +24,23 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   a = wave_sum(a);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    const float s = red[0] + red[1] + red[2] + red[3];
+    if (parts) out[blockIdx.x] = s;  // one partial per block, summed in index order by the consumer: no atomics
+    else atomicAdd(out, s);
+  }
+}
+
+// the gradient norm's sum of squares from the per-block partials of sumsq_kernel: every block of the consumer kernel
+// forms the SAME sum in the same order (thread t adds parts[t], parts[t + 256], ...; wave butterfly; waves in order)
+__device__ __forceinline__ float fold_sumsq_parts(const float* __restrict__ parts, int nparts) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) a += parts[i];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // gnorm = sqrt(sumsq) * gmul ; coef = max_norm > 0 ? min(1, max_norm / (gnorm + 1e-6)) : 1
@@ -49,9 +65,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                                                           float max_norm, float lr, float b1, float b2, float eps,
                                                           float wd, float step_size,
                                                           float* __restrict__ gnorm_out, uint16_t* __restrict__ ph,
-                                                          int* __restrict__ skipped) {
+                                                          int* __restrict__ skipped, int sumsq_parts) {
   if (gmul_dev) gmul *= gmul_dev[0];
-  const float gn = sqrtf(sumsq[0]) * gmul;
+  const float gn = sqrtf(sumsq_parts > 0 ? fold_sumsq_parts(sumsq, sumsq_parts) : sumsq[0]) * gmul;
   if (gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) gnorm_out[0] = gn;
   if (!(gn < INFINITY)) {  // non-finite gradient norm: nothing is touched; the caller finds the count (trainer.py:860-867)
     if (skipped && blockIdx.x == 0 && threadIdx.x == 0) skipped[0] += 1;
@@ -70,18 +86,29 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
 
 }  // namespace
 
+static long sumsq_blocks(long n) {
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > S2ST_SUMSQ_PARTS) blocks = S2ST_SUMSQ_PARTS;
+  return blocks < 1 ? 1 : blocks;
+}
 int s2st_sumsq(const float* x, long n, float* out, hipStream_t st) {
   if (n <= 0) return 0;
-  long blocks = (n / 4 + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
-  if (blocks < 1) blocks = 1;
-  s2st_launch("sumsq_kernel", 4.0 * n, 0.0, sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, out);
+  s2st_launch("sumsq_kernel", 4.0 * n, 0.0, sumsq_kernel, dim3((unsigned)sumsq_blocks(n)), dim3(256), 0, st, x, n, out, 0);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
+// parts[0 .. s2st_sumsq_nparts(n)) = per-block partial sums (plain stores: nothing to zero, nothing atomic); the
+// count is what s2st_adam takes as sumsq_parts
+int s2st_sumsq_parts(const float* x, long n, float* parts, hipStream_t st) {
+  if (n <= 0) return 0;
+  const long blocks = sumsq_blocks(n);
+  s2st_launch("sumsq_kernel", 4.0 * n, 0.0, sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, parts, 1);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+long s2st_sumsq_nparts(long n) { return n <= 0 ? 0 : sumsq_blocks(n); }
 
 int s2st_adam(float* p, float* g, float* m, float* v, long n, const float* sumsq, float gmul,
               const float* gmul_dev, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step,
-              float* gnorm_out, hipStream_t st, uint16_t* ph, int* skipped) {
+              float* gnorm_out, hipStream_t st, uint16_t* ph, int* skipped, int sumsq_parts) {
   if (n <= 0) return 0;
   double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   float step_size = (float)((double)lr * sqrt(bc2) / bc1);
@@ -90,6 +117,6 @@ int s2st_adam(float* p, float* g, float* m, float* v, long n, const float* sumsq
   if (blocks > 1024) blocks = 1024;
   // bytes: p, g, m, v read and written (32 B per parameter) + the bf16 copy (2 B)
   s2st_launch("adam_kernel", (32.0 + (ph ? 2.0 : 0.0)) * n, 0.0, adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m,
-              v, n, sumsq, gmul, gmul_dev, max_norm, lr, beta1, beta2, eps, wd, step_size, gnorm_out, ph, skipped);
+              v, n, sumsq, gmul, gmul_dev, max_norm, lr, beta1, beta2, eps, wd, step_size, gnorm_out, ph, skipped, sumsq_parts);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }

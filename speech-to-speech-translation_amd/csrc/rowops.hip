@@ -566,15 +566,19 @@ int s2st_layernorm_bwd_fold(const s2st_lnfold_table& t, hipStream_t st) {
   S2ST_LAUNCH(layernorm_bwd_fold_batched_kernel, dim3(t.blk0[t.n]), dim3(256), 0, st, t);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
-int s2st_lnfold_add(s2st_lnfold_table& t, const float* part, int rows, int cols, int nout, float* dgamma, float* dbeta,
-                    float* dbias) {
+int s2st_fold_add(s2st_lnfold_table& t, const float* part, int nblocks, int cols, int nout, float* out0, float* out1,
+                  float* out2) {
   if (t.n >= S2ST_LNFOLD_MAX) return S2ST_ERR_ARG;
   s2st_lnfold_item& f = t.item[t.n];
-  f.part = part; f.dgamma = dgamma; f.dbeta = dbeta; f.dbias = dbias;
-  f.nblocks = ln_fused_blocks(rows, cols); f.cols = cols; f.nout = nout;
+  f.part = part; f.dgamma = out0; f.dbeta = out1; f.dbias = out2;
+  f.nblocks = nblocks; f.cols = cols; f.nout = nout;
   t.blk0[t.n + 1] = t.blk0[t.n] + (nout * cols + 31) / 32;
   ++t.n;
   return 0;
+}
+int s2st_lnfold_add(s2st_lnfold_table& t, const float* part, int rows, int cols, int nout, float* dgamma, float* dbeta,
+                    float* dbias) {
+  return s2st_fold_add(t, part, ln_fused_blocks(rows, cols), cols, nout, dgamma, dbeta, dbias);
 }
 
 // scratch: s2st_layernorm_bwd_blocks(rows, cols) * (dph ? 3 : 2) * cols floats.

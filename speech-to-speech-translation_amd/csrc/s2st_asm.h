@@ -11,6 +11,7 @@
 // Included as <s2st_asm.h>: the wave64 emulator of tests/ ships a synchronous stand-in under the same name.
 #pragma once
 #include <cstdint>
+#include <type_traits>
 
 __device__ __forceinline__ s16x4 lds_read_tr16_raw(const unsigned char* p) {
   s16x4 r;
@@ -30,4 +31,18 @@ __device__ __forceinline__ void lane16_swap(unsigned& a, unsigned& b) {
   const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
   a = r[0];
   b = r[1];
+}
+
+// Sum over the 16 lanes of a DPP row (lanes with equal lane >> 4), result in every lane of the row: four VALU adds
+// with DPP operands (quad_perm xor 1, quad_perm xor 2, row_half_mirror, row_mirror) -- no LDS crossbar, no waits.
+// (__shfl_xor lowers to ds_bpermute_b32 + s_waitcnt: ~4x the issue cost per step and an lgkmcnt dependency.)
+__device__ __forceinline__ float row16_sum(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1, 0, 3, 2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2, 3, 0, 1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});  // row_half_mirror: lane i <-> 7 - i of each 8
+  v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror: lane i <-> 15 - i
+  return v;
 }

@@ -106,6 +106,9 @@ struct s2st_lnfold_table { int n; int blk0[S2ST_LNFOLD_MAX + 1]; s2st_lnfold_ite
 int s2st_lnfold_add(s2st_lnfold_table& t, const float* part, int rows, int cols, int nout, float* dgamma, float* dbeta,
                     float* dbias);
 int s2st_layernorm_bwd_fold(const s2st_lnfold_table& t, hipStream_t st);
+// any other [nblocks][nout][cols] array of partial rows: out_i[c] += sum_b part[b][i][c], b in order (out_i may be null)
+int s2st_fold_add(s2st_lnfold_table& t, const float* part, int nblocks, int cols, int nout, float* out0, float* out1,
+                  float* out2);
 // dph: optional fused backward prologue of the linear+dropout layer that produced x (rowops.hip)
 int s2st_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                        const float* rstd, float* dx, int dx_accumulate, float* dgamma,
@@ -217,6 +220,8 @@ int s2st_flash_attn_fwd(const s2st_attn_args* p, hipStream_t st);
 int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_scratch, hipStream_t st, int phase = 0,
                         float* db_part = nullptr /* bias gradients as partial sums + ordered fold: s2st_flash_attn_db_scratch_floats */);
 long s2st_flash_attn_db_scratch_floats(const s2st_attn_args* p);
+// layout of that scratch: [slots_q][C] (q) | [slots_k][C] (k) | [slots_k][C] (v), C = H * dh
+void s2st_flash_attn_db_layout(const s2st_attn_args* p, int* slots_q, int* slots_k);
 int s2st_flash_attn_db_fold(const s2st_attn_args* p, const float* db_part, hipStream_t st);  // db += fold(partials), slot order
 
 // ---------------------------------------------------------------------------------------
@@ -292,10 +297,16 @@ int s2st_loss_finalize(float* stats, const float* ctc_per, int B, float nf, floa
 // optimizer (optim.hip)
 // ---------------------------------------------------------------------------------------
 int s2st_sumsq(const float* x, long n, float* out /* += */, hipStream_t st);
+#define S2ST_SUMSQ_PARTS 1024
+// the same sum as s2st_sumsq_nparts(n) <= S2ST_SUMSQ_PARTS per-block partials: s2st_adam(sumsq_parts = count) adds
+// them in index order -- run-to-run identical, no zeroing pass, no atomics
+int s2st_sumsq_parts(const float* x, long n, float* parts, hipStream_t st);
+long s2st_sumsq_nparts(long n);
 // g *= gmul * clip ; clip = min(1, max_norm / (sqrt(sumsq)*gmul + 1e-6)) ; fairseq Adam.
 // step >= 1 is the Adam step count; gnorm_out (optional) receives sqrt(sumsq)*gmul.
 // effective gradient multiplier = gmul * (gmul_dev ? *gmul_dev : 1)
 int s2st_adam(float* p, float* g, float* m, float* v, long n, const float* sumsq, float gmul,
               const float* gmul_dev, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step,
               float* gnorm_out, hipStream_t st, uint16_t* p_bf16 = nullptr /* optional bf16 copy of the new p */,
-              int* skipped = nullptr /* optional device counter: += 1 when the norm is non-finite and the update is skipped */);
+              int* skipped = nullptr /* optional device counter: += 1 when the norm is non-finite and the update is skipped */,
+              int sumsq_parts = 0 /* > 0: sumsq points at that many partial sums (s2st_sumsq_parts) */);

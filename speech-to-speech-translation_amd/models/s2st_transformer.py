@@ -96,7 +96,27 @@ class S2STTransformerModel(ModelBase):  # fairseq's BaseFairseqModel when fairse
             args.src_vocab_size = len(task.source_dictionary)
             args.tgt_vocab_size = len(task.target_dictionary)
         device = getattr(task, "device", None) or torch.device("cuda", torch.cuda.current_device())
-        return cls(args, device=device, precise=bool(getattr(args, "precise_gemm", False)))
+        model = cls(args, device=device, precise=bool(getattr(args, "precise_gemm", False)))
+        cls.load_pretrained_components(model, args)
+        return model
+
+    @staticmethod
+    def load_pretrained_components(model, args):
+        """``--load-pretrained-encoder-from`` / ``--load-pretrained-decoder-from`` (s2st_transformer.py:704-733, used by
+        run_mix_tuning.sh:143-144): a path that does not exist is skipped with a warning, as the reference does."""
+        import logging
+        import os
+        from ..checkpoint_utils import load_pretrained_component_from_model
+        log = logging.getLogger(__name__)
+        for comp in ("encoder", "decoder"):
+            path = getattr(args, f"load_pretrained_{comp}_from", None)
+            if path is None:
+                continue
+            if not os.path.exists(path):
+                log.warning(f"skipped pretraining because {path} does not exist")
+                continue
+            loaded = load_pretrained_component_from_model(model, comp, path)
+            log.info(f"loaded pretrained {comp} from: {path} ({len(loaded)} tensors)")
 
     def __init__(self, args, device: torch.device, precise: bool = False):
         super().__init__()
@@ -136,12 +156,14 @@ class S2STTransformerModel(ModelBase):  # fairseq's BaseFairseqModel when fairse
             if k in self._modules:
                 _register(self, k + ".version", torch.tensor([3.0], device=device), True)
         for i in range(args.postnet_layers):
+            # (BatchNorm's update counter is bookkeeping the checkpoint carries, never read on the device: a host tensor,
+            # so that bumping it is not a kernel launch on the step's stream)
             _register(self, f"decoder.postnet.convolutions.{i}.1.num_batches_tracked",
-                      torch.zeros((), dtype=torch.long, device=device), True)
+                      torch.zeros((), dtype=torch.long), True)
         if getattr(args, "text_encoder", False):  # t2s_transformer: BatchNorm counters of the encoder prenet
             for i in range(args.encoder_conv_layers):
                 _register(self, f"encoder.prenet.{i}.1.num_batches_tracked",
-                          torch.zeros((), dtype=torch.long, device=device), True)
+                          torch.zeros((), dtype=torch.long), True)
         self._num_updates = 0
         self.reset_parameters()
 

@@ -39,7 +39,8 @@ class Trainer:
         n = self.engine.n_params
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._sumsq_nparts = int(bd._bind("s2st_sumsq_parts_count")(self.engine.n_params))
+        self.sumsq_parts = torch.zeros(max(self._sumsq_nparts, 1), dtype=torch.float32, device=dev)
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.gmul_dev = torch.ones(1, dtype=torch.float32, device=dev)
         self.skipped = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -116,12 +117,14 @@ class Trainer:
             if sample_size <= 0:
                 raise RuntimeError("no real batch in this update")
             gmul = 1.0 / float(sample_size)
-        self.sumsq.zero_()
-        bd.call("s2st_sumsq_f32", eng.grads, eng.n_params, self.sumsq)
+        # gradient norm: per-block partial sums folded in index order inside the Adam kernel (no zeroing pass, no atomics:
+        # the clip coefficient, hence the whole update, repeats bit for bit)
+        nparts = self._sumsq_nparts
+        bd.call("s2st_sumsq_parts_f32", eng.grads, eng.n_params, self.sumsq_parts)
         lr = self.get_lr()
         bd.call("s2st_adam_f32", eng.params, eng.grads, self.exp_avg, self.exp_avg_sq, eng.n_params,
-                self.sumsq, gmul, gmul_dev, float(self.clip_norm), lr, self.betas[0], self.betas[1],
-                self.eps, self.wd, self.num_updates + 1, self.gnorm, self._ph(), self.skipped)
+                self.sumsq_parts, gmul, gmul_dev, float(self.clip_norm), lr, self.betas[0], self.betas[1],
+                self.eps, self.wd, self.num_updates + 1, self.gnorm, self._ph(), self.skipped, nparts)
         if self._ph() is not None:
             eng.mark_bf16_fresh()
         self.num_updates += 1

@@ -11,3 +11,12 @@ static inline void lane16_swap(unsigned& a, unsigned& b) {
   a = na;
   b = nb;
 }
+static inline float row16_sum(float v) {
+  // the product's order of additions (quad xor 1, quad xor 2, half mirror, mirror): bit-equal sums
+  const int l = emu_lane();
+  v += emu_shfl_idx(v, l ^ 1);
+  v += emu_shfl_idx(v, l ^ 2);
+  v += emu_shfl_idx(v, (l & ~7) | (7 - (l & 7)));
+  v += emu_shfl_idx(v, (l & ~15) | (15 - (l & 15)));
+  return v;
+}

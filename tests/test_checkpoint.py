@@ -116,3 +116,39 @@ def test_flattened_fp16_master_state_and_errors(backend, golden_dir, tmp_path):
         C.load_checkpoint(path, _trainer(backend))
     with pytest.raises(FileNotFoundError):
         C.load_checkpoint(str(tmp_path / "missing.pt"), t)
+
+
+@pytest.mark.parametrize("component", ["encoder", "decoder"])
+def test_load_pretrained_component_from_reference_checkpoint(backend, golden_dir, component, tmp_path):
+    """``--load-pretrained-encoder-from`` / ``--load-pretrained-decoder-from`` (s2st_transformer.py:704-733 ->
+    fairseq/checkpoint_utils.py:784-812) with the reference-written checkpoint: the named component takes the
+    checkpoint's tensors, everything else keeps its initialisation; a missing file is skipped like in the reference."""
+    tasks = importlib.import_module(PKG + ".tasks")
+    path = os.path.join(golden_dir, "ckpt_nano.pt")
+    ref = torch.load(path, map_location="cpu", weights_only=False)["model"]
+
+    def build(**flags):
+        a = O.make_args(**CKPT_CFG)
+        a.precise_gemm = True
+        for k, v in flags.items():
+            setattr(a, k, v)
+        torch.manual_seed(11)
+        task = tasks.S2ST_TranslationTask.setup_task(a, device=backend.device)
+        return task.build_model(a)
+
+    plain = {k: v.detach().cpu().clone() for k, v in build().state_dict().items()}
+    model = build(**{f"load_pretrained_{component}_from": path})
+    got = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    n_loaded = n_kept = 0
+    for k, v in got.items():
+        if k.startswith(component + ".") and k in ref and not k.endswith("_float_tensor"):
+            assert torch.equal(v.float(), ref[k].float()), k
+            n_loaded += 1
+        elif k in plain and v.dtype.is_floating_point:
+            assert torch.equal(v, plain[k]), k  # same seed, same initialisation: untouched
+            n_kept += 1
+    assert n_loaded > 10 and n_kept > 10
+    assert any(not torch.equal(got[k].float(), plain[k].float()) for k in got if k.startswith(component + ".") and k in ref)
+    # a path that does not exist is skipped with a warning (s2st_transformer.py:707-710)
+    skipped = build(**{f"load_pretrained_{component}_from": str(tmp_path / "nope.pt")})
+    assert all(torch.equal(v.detach().cpu(), plain[k]) for k, v in skipped.state_dict().items() if v.dtype.is_floating_point)

@@ -312,7 +312,7 @@ def test_dropout_training_runs_and_is_seeded(backend):
 
 
 @pytest.mark.parametrize("cfg", [MICRO, MICRO_POSTLN], ids=["preln_aux", "postln"])
-@pytest.mark.parametrize("switch", ["S2ST_NO_LN_FUSE", "S2ST_NO_KV_HOIST", "S2ST_NO_ACT_FUSE", "S2ST_ATTN_GFUSE=1", "S2ST_ATTN_GFUSE=2", "S2ST_ATTN_GFUSE=3",
+@pytest.mark.parametrize("switch", ["S2ST_NO_LN_FUSE", "S2ST_NO_KV_HOIST", "S2ST_NO_ACT_FUSE", "S2ST_ATTN_GFUSE=0", "S2ST_ATTN_GFUSE=2", "S2ST_ATTN_GFUSE=3",
                                     "S2ST_WGRAD_MAIN_EVERY=3", "S2ST_TRANSPOSE_EACH", "S2ST_NO_WGRAD_GROUP",
                                     "S2ST_GEMM_PERSIST=0", "S2ST_ATTN_BWD_SPLIT", "S2ST_ORDERED_BIAS_SUMS", "S2ST_LN_BWD_SPLIT",
                                     "S2ST_GEMM_W4=2"])

@@ -338,8 +338,21 @@ def test_ctc(backend):
     assert torch.equal(lpo.argmax(-1).cpu(), lp.transpose(0, 1).argmax(-1))
 
 
-def test_sumsq_adam(backend):
-    n = 10007
+@pytest.mark.parametrize("parts", [False, True], ids=["scalar_sumsq", "partial_sums"])
+def test_sumsq_adam(backend, parts):
+    """parts: the gradient norm as per-block partial sums folded in index order inside the Adam kernel (no atomics:
+    what the trainer uses) instead of one atomically accumulated float."""
+    n = 10007 if not parts else 64 * 1024 + 5  # (64 blocks' worth of partials; torch's own fp32 norm drifts by 6e-5 at 3 M)
+    nparts = int(backend.bd._bind("s2st_sumsq_parts_count")(n)) if parts else 0
+    assert not parts or nparts > 1
+
+    def sumsq(gd, ss):
+        if parts:
+            backend.bd.call("s2st_sumsq_parts_f32", gd, n, ss)
+        else:
+            ss.zero_()
+            backend.bd.call("s2st_sumsq_f32", gd, n, ss)
+
     g_ = torch.Generator().manual_seed(1)
     p0, g0 = torch.randn(n, generator=g_), torch.randn(n, generator=g_) * 3
     pr = torch.nn.Parameter(p0.clone())
@@ -353,13 +366,13 @@ def test_sumsq_adam(backend):
         gn_ref = O.clip_grad_norm_([pr], 0.5)
         opt.step(1e-2)
         gd.copy_(gcur)
-        ss = torch.zeros(1, device=backend.device)
+        ss = torch.full((max(nparts, 1),), float("nan"), device=backend.device)  # (partials need no zeroing)
         gno = torch.zeros(1, device=backend.device)
-        backend.bd.call("s2st_sumsq_f32", gd, n, ss)
+        sumsq(gd, ss)
         ph = torch.zeros(n, dtype=torch.bfloat16, device=backend.device)
         skipped = torch.zeros(1, dtype=torch.int32, device=backend.device)
         backend.bd.call("s2st_adam_f32", pd, gd, m, v, n, ss, 0.02, half, 0.5, 1e-2, 0.9, 0.999, 1e-8, 0.01,
-                        step, gno, ph, skipped)
+                        step, gno, ph, skipped, nparts)
         backend.sync()
         assert int(skipped) == 0
         close(gno, gn_ref.view(1), 1e-5, 1e-6)
@@ -368,10 +381,9 @@ def test_sumsq_adam(backend):
     # non-finite gradient norm: nothing is touched and the device counter says so (trainer.py:860-867)
     before = (pd.clone(), m.clone(), v.clone())
     gd[3] = float("inf")
-    ss.zero_()
-    backend.bd.call("s2st_sumsq_f32", gd, n, ss)
+    sumsq(gd, ss)
     backend.bd.call("s2st_adam_f32", pd, gd, m, v, n, ss, 0.02, half, 0.5, 1e-2, 0.9, 0.999, 1e-8, 0.01, 4, gno, ph,
-                    skipped)
+                    skipped, nparts)
     backend.sync()
     assert int(skipped) == 1 and not bool(torch.isfinite(gno).all())
     assert torch.equal(pd, before[0]) and torch.equal(m, before[1]) and torch.equal(v, before[2])
