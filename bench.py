@@ -160,6 +160,234 @@ def cpu_leg(args):
                                 f"{n_warm} warm-up + {len(times)} timed steps, median {med:.2f} s/step"}))
 
 
+# ================================================================================================
+# --config infer_base (BASELINE.json configs[4]): AR mel decode + Griffin-Lim (64 iterations) on Fisher-shaped inputs,
+# base geometry, 1 GPU: utterances / s, and the MCD of the GPU path's waveforms against the CPU path's on the same inputs
+# ================================================================================================
+INFER_B = 16          # utterances per generator call (the reference's generate_waveform batches by --max-tokens)
+INFER_N_UTTS = 64     # 64 utterances of the synthetic Fisher-shaped distribution
+INFER_GL_ITERS = 64   # --spec-bwd-max-iter 64
+
+
+def infer_cpu_leg(args):
+    """Child process (the only place bench.py touches oracle/): the oracle's AR generator + Griffin-Lim vocoder (torch CPU
+    fp32, all usable host cores) on the first utterances of batch 0, weights and initial phases read from the files the
+    parent wrote; prints its rate and leaves the waveforms for the parent's MCD."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import s2st_amd  # noqa: F401
+    import s2st_oracle as O
+    import infer_oracle as IO
+    C = importlib.import_module(PKG + ".configs")
+    D = importlib.import_module(PKG + ".data")
+    ncores = effective_cores()
+    torch.set_num_threads(ncores)
+    job = torch.load(args.cpu_leg[len("infer:"):], weights_only=False)
+    pa = C.recipe_args("base_recipe", prenet_dropout=0.0)
+    m = O.S2STModel(O.make_args(**vars(pa)))
+    missing = m.load_state_dict(job["state"], strict=False)
+    assert not [k for k in missing.missing_keys if "num_batches_tracked" not in k and "_float_tensor" not in k and "version" not in k], missing
+    m.eval()
+    corpus = D.SyntheticFisherCorpus(n_utts=INFER_N_UTTS, seed=1234)
+    sub = corpus.collate_batch(job["ids"])
+    ni = sub["net_input"]
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        fin = IO.ar_generate(m, ni["src_speech"], ni["src_speech_lens"], job["max_iter"], 2.0, pa.n_frames_per_step)
+    t_dec = time.perf_counter() - t0
+    waves = []
+    t0 = time.perf_counter()
+    for f, ang in zip(fin, job["angles"]):
+        waves.append(IO.vocoder(f["feature"], ang, n_iter=INFER_GL_ITERS, **job["voc"]).numpy())
+    t_voc = time.perf_counter() - t0
+    np.savez(job["out"], **{f"wave.{i}": w for i, w in enumerate(waves)},
+             **{f"feature.{i}": f["feature"].numpy() for i, f in enumerate(fin)})
+    n = len(job["ids"])
+    print(json.dumps({"value": round(n / (t_dec + t_voc), 4), "unit": "utterances/s", "cores": ncores, "kind": "port",
+                      "sample": f"oracle (torch CPU fp32, {ncores} threads): AR decode of {n} utterances x {job['max_iter']} "
+                                f"steps ({t_dec:.1f} s, the decoder re-run on the prefix each step) + Griffin-Lim "
+                                f"{INFER_GL_ITERS} iterations per utterance ({t_voc:.1f} s)"}))
+
+
+def infer_main(args):
+    import numpy as np
+    if int(os.environ.get("WORLD_SIZE", 1)) != 1 or args.gpus != 1:
+        raise SystemExit("--config infer_base is a 1-GPU workload (BASELINE.json configs[4]): utterances are independent, "
+                         "N GPUs = N replicas of this run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    import s2st_amd  # noqa: F401
+    C_ = importlib.import_module(PKG + ".configs")
+    tasks = importlib.import_module(PKG + ".tasks")
+    G = importlib.import_module(PKG + ".speech_generator")
+    V = importlib.import_module(PKG + ".vocoder")
+    M = importlib.import_module(PKG + ".metrics")
+    D = importlib.import_module(PKG + ".data")
+    bd = importlib.import_module(PKG + ".runtime.binding")
+    a = C_.recipe_args("base_recipe")
+    task = tasks.S2ST_TranslationTask.setup_task(a, device=dev)
+    torch.manual_seed(1)
+    model = task.build_model(a)  # random-init weights of the architecture (no checkpoints on the box)
+    voc_kw = dict(sample_rate=24000, win_size=1200, hop_size=300, n_fft=2048, n_mels=80, f_min=20, f_max=8000)
+    voc = V.GriffinLimVocoder(spec_bwd_max_iter=INFER_GL_ITERS, device=dev, **voc_kw)
+    corpus = D.SyntheticFisherCorpus(n_utts=INFER_N_UTTS, seed=1234)
+    order = np.argsort(-corpus.src_n_frames, kind="stable")  # length-ordered batches, like the task's iterator
+    groups = [order[i:i + INFER_B].tolist() for i in range(0, INFER_N_UTTS, INFER_B)]
+    samples, iters = [], []
+    for ix in groups:
+        s_ = corpus.collate_batch(ix)
+        s_["net_input"]["collated_audios_orig"] = None
+        s_["net_input"]["padding_mask"] = None
+        samples.append(s_)
+        iters.append(int(s_["target_lengths"].max()))  # teacher length of the batch: deterministic work (SURVEY 8(d))
+    gens = [G.AutoRegressiveSpeechGenerator(model, voc, None, max_iter=it, eos_prob_threshold=2.0) for it in iters]
+
+    def step(i):
+        k = i % len(samples)
+        return gens[k].generate(model, samples[k])
+
+    for i in range(max(args.warmup, len(samples))):  # every batch geometry once: workspace sizes, code objects
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_utt = n_frames = 0
+    for i in range(args.steps):
+        fin = step(i)
+        n_utt += len(fin)
+        n_frames += sum(int(f["feature"].shape[0]) for f in fin)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    vlog("timed region", dt, "s for", n_utt, "utterances")
+    # decode / vocoder split of one batch (un-timed above)
+    tA = time.perf_counter()
+    g0 = G.AutoRegressiveSpeechGenerator(model, None, None, max_iter=iters[0], eos_prob_threshold=2.0)
+    f0 = g0.generate(model, samples[0])
+    torch.cuda.synchronize()
+    t_dec = time.perf_counter() - tA
+    tA = time.perf_counter()
+    voc.batch([f["feature"] for f in f0])
+    torch.cuda.synchronize()
+    t_voc = time.perf_counter() - tA
+
+    # ---- roofline: replay one pass over the batches with per-dispatch timing; the kernel with the largest share --------
+    roofline = None
+    if not args.no_roofline:
+        import ctypes as C
+        lib = bd.lib()
+        lib.s2st_profile_enable.argtypes = [C.c_int32]
+        lib.s2st_profile_report.argtypes = [C.c_char_p, C.c_int64]
+        lib.s2st_profile_report.restype = C.c_int64
+        lib.s2st_profile_enable(1)
+        for i in range(len(samples)):
+            step(i)
+        torch.cuda.synchronize()
+        lib.s2st_profile_enable(0)
+        buf = C.create_string_buffer(1 << 16)
+        n = lib.s2st_profile_report(buf, len(buf))
+        rows = {}
+        for ln in buf.value.decode().splitlines() if n > 0 else []:
+            tag, cnt, us, w1, w2 = ln.split("\t")
+            rows[tag] = dict(n=int(cnt), us=float(us), work=float(w1), work2=float(w2))
+        if os.environ.get("S2ST_BENCH_VERBOSE"):
+            for tag, r in sorted(rows.items(), key=lambda kv: -kv[1]["us"])[:25]:
+                vlog("  %-60s launches %7d  avg %7.2f us  total ms %8.3f" % (tag, r["n"], r["us"] / r["n"], r["us"] * 1e-3))
+        if rows:
+            tot_us = sum(r["us"] for r in rows.values())
+            dom_tag, dom = max(rows.items(), key=lambda kv: kv[1]["us"])
+            avg_us = dom["us"] / dom["n"]
+            is_mfma = dom_tag.startswith(("gemm", "flash_")) and dom["work"] > 0
+            if is_mfma:
+                ach = dom["work"] / dom["n"] / (avg_us * 1e-6) / 1e12
+                roofline = {"bound": "mfma", "kernel": dom_tag, "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 5), "traffic": None,
+                            "gflop_per_launch": round(dom["work"] / dom["n"] / 1e9, 3)}
+            else:
+                ach = dom["work"] / dom["n"] / (avg_us * 1e-6) / 1e9 if dom["work"] > 0 else None
+                roofline = {"bound": "hbm", "kernel": dom_tag, "achieved": None if ach is None else round(ach, 1),
+                            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None if ach is None else round(ach / HBM_PEAK_GBPS, 5),
+                            "traffic": None}
+            roofline.update({"avg_launch_us": round(avg_us, 2), "launches_per_utterance": round(dom["n"] / INFER_N_UTTS, 1),
+                             "share_of_kernel_time": round(dom["us"] / tot_us, 4),
+                             "kernel_ms_per_utterance": round(tot_us * 1e-3 / INFER_N_UTTS, 3),
+                             "launches_per_utterance_all_kernels": round(sum(r["n"] for r in rows.values()) / INFER_N_UTTS, 1),
+                             "timing": "start/stop events attached to each dispatch, one pass over the %d batches" % len(samples)})
+
+    # ---- CPU leg + MCD of the GPU path against the CPU path on the same inputs (Prenet dropout 0 on both sides: the
+    #      reference's always-on Prenet dropout makes the decode a random variable; the timed workload above keeps it on) --
+    cpu, mcd = None, None
+    if args.cpu_seconds > 0:
+        import subprocess
+        import tempfile
+        n_cpu = args.cpu_utts or 2
+        ids = groups[-1][-n_cpu:]  # the shortest utterances: the CPU decoder re-runs its prefix every step
+        sub = corpus.collate_batch(ids)
+        sub["net_input"]["collated_audios_orig"] = None
+        sub["net_input"]["padding_mask"] = None
+        mi = int(sub["target_lengths"].max())
+        a0 = C_.recipe_args("base_recipe", prenet_dropout=0.0)
+        m0 = tasks.S2ST_TranslationTask.setup_task(a0, device=dev).build_model(a0)
+        m0.load_state_dict(model.state_dict(), strict=True)
+        rs = np.random.RandomState(5)
+        F_ = voc_kw["n_fft"] // 2 + 1
+        # (the reference's initial phases, vocoder.py:101-102, here from a seeded generator and shared with the CPU leg)
+        angles = [np.angle(np.exp(2j * np.pi * rs.rand(F_, mi * a0.n_frames_per_step))).astype(np.float32) for _ in ids]
+        g_ = G.AutoRegressiveSpeechGenerator(m0, None, None, max_iter=mi, eos_prob_threshold=2.0)
+        fin0 = g_.generate(m0, sub)
+        waves_gpu = voc.batch([f["feature"] for f in fin0], angles)
+        torch.cuda.synchronize()
+        with tempfile.TemporaryDirectory() as td:
+            job = {"state": {k: v.detach().cpu() for k, v in model.state_dict().items()}, "ids": ids, "max_iter": mi,
+                   "angles": angles, "voc": voc_kw, "out": os.path.join(td, "cpu_out.npz")}
+            jp = os.path.join(td, "job.pt")
+            torch.save(job, jp)
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-leg", "infer:" + jp],
+                                   capture_output=True, text=True, timeout=10 * args.cpu_seconds + 300)
+                for ln in r.stdout.splitlines():
+                    if ln.startswith("{"):
+                        cpu = json.loads(ln)
+                if cpu is None:
+                    vlog("cpu leg produced no result:", r.stderr[-600:])
+                else:
+                    z = np.load(job["out"])
+                    y_cpu = [torch.from_numpy(z[f"wave.{i}"]).to(dev) for i in range(len(ids))]
+                    y_gpu = [w.reshape(-1).float() for w in waves_gpu]
+                    res = M.batch_mel_cepstral_distortion(y_gpu, y_cpu, voc_kw["sample_rate"], "path", device=dev)
+                    ferr = max(float((f["feature"].cpu() - torch.from_numpy(z[f"feature.{i}"])).abs().max())
+                               for i, f in enumerate(fin0))
+                    mcd = {"mcd_gpu_vs_cpu": round(float(sum(float(d) for d, _ in res) / len(res)), 4),
+                           "utterances": len(ids), "max_abs_feature_diff": round(ferr, 5),
+                           "note": "MFCC distance along the DTW path between the GPU path's waveform (bf16 operands) and the "
+                                   "CPU oracle's (fp32) for the same weights, inputs, Prenet dropout 0 and initial phases; "
+                                   "0 = identical"}
+            except subprocess.TimeoutExpired:
+                vlog("cpu leg timed out")
+
+    value = n_utt / dt
+    line = {"metric": "utterances/sec (AR mel decode + Griffin-Lim %d it) on Fisher-shaped inputs" % INFER_GL_ITERS,
+            "value": round(value, 2), "unit": "utterances/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "generate_waveform-shaped inference: s2st_transformer base 12enc/6dec d512 nfps4 (random-init), "
+                                   "%d Fisher-shaped utterances in length-ordered batches of %d, key/value-cached AR decode for the "
+                                   "batch's longest teacher length (stop threshold never reached: fixed work), Prenet dropout "
+                                   "0.5 on, post-net, Griffin-Lim %d iterations (n_fft 2048, hop 300) batched over the "
+                                   "utterances" % (INFER_N_UTTS, INFER_B, INFER_GL_ITERS),
+                       "name": "infer_base", "utterances_per_step": INFER_B, "mel_frames_per_s": round(n_frames / dt, 1),
+                       "decode_steps_per_batch": iters, "batch0_decode_ms": round(t_dec * 1e3, 2),
+                       "batch0_vocoder_ms": round(t_voc * 1e3, 2)}}
+    if roofline:
+        line["roofline"] = roofline
+    if cpu:
+        line["cpu_baseline"] = cpu
+        line["config"]["x_over_cpu"] = round(value / cpu["value"], 1)
+    if mcd:
+        line["mcd"] = mcd
+    print(json.dumps(line))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,7 +406,11 @@ def main():
     ap.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_leg:
-        return cpu_leg(args)
+        return infer_cpu_leg(args) if args.cpu_leg.startswith("infer:") else cpu_leg(args)
+    if args.config == "infer_base":
+        if args.steps == 100:
+            args.steps = 8  # (default: two passes over the four batches)
+        return infer_main(args)
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -283,6 +515,9 @@ def main():
             ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3])))
     if world > 1:
         torch.distributed.barrier()
+        if trainer.reducer is not None and trainer.reducer.cuda:
+            trainer.reducer.exposed_ms()  # (drop what the warm-up recorded)
+            trainer.reducer.measure_exposed = True
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     step_ev = []
@@ -299,6 +534,21 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     vlog('timed region', dt, 'host issue time', t_issue)
+    # N > 1: what the gradient exchange cost beyond what the backward hid (the compute stream's wait in
+    # GradReducer.finish(), GPU clock), and the ranges it was issued in
+    exchange = None
+    if world > 1 and trainer.reducer is not None and trainer.reducer.cuda:
+        trainer.reducer.measure_exposed = False
+        ex = trainer.reducer.exposed_ms()
+        bk = trainer.reducer.last_buckets
+        exchange = {"allreduce_exposed_ms": round(sum(ex) / max(len(ex), 1), 4),
+                    "allreduce_exposed_ms_max": round(max(ex) if ex else 0.0, 4),
+                    "buckets_mib": [round((hi - lo) * 4 / 2 ** 20, 1) for lo, hi in bk],
+                    "bytes_per_update": int(sum(hi - lo for lo, hi in bk) * 4), "dtype": "f32",
+                    "transport": ("gloo through pinned host memory (S2ST_BENCH_SHARE_GPU: a control-flow check, not a "
+                                  "measurement)" if share else
+                                  ("RCCL via the C ABI (s2st_allreduce_sum_f32)" if trainer.reducer.native is not None
+                                   else "RCCL via torch.distributed (backend nccl)"))}
     if os.environ.get('S2ST_STALL_TRACE'):
         import ctypes as C_
         fn = eng.lib.s2st_engine_stall_report
@@ -483,6 +733,8 @@ def main():
         if cpu:
             line["cpu_baseline"] = cpu
             line["config"]["x_over_cpu"] = round(value / cpu["value"], 1)
+        if exchange:
+            line["gradient_exchange"] = exchange  # rank 0's view
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()

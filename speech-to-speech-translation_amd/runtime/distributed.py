@@ -92,6 +92,11 @@ class GradReducer:
         self.pending: Optional[Tuple[int, int]] = None
         self.handles: List = []
         self.reduced: List[Tuple[int, int]] = []
+        # instrumentation (bench.py --gpus N): how long the compute stream waits in finish() for the exchange -- the part
+        # of the all-reduce that the backward did NOT hide -- and the ranges of the last update
+        self.measure_exposed = False
+        self._exposed_events: List = []
+        self.last_buckets: List[Tuple[int, int]] = []
 
     def _launch(self, lo: int, hi: int):
         if hi <= lo:
@@ -143,13 +148,32 @@ class GradReducer:
             self._launch(*self.pending)
             self.pending = None
         if self.cuda:
-            torch.cuda.current_stream().wait_stream(self.stream)
+            cur = torch.cuda.current_stream()
+            if self.measure_exposed:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(cur)
+                cur.wait_stream(self.stream)
+                b.record(cur)
+                self._exposed_events.append((a, b))
+            else:
+                cur.wait_stream(self.stream)
         for h in self.handles:
             h.wait()
         self.handles.clear()
         covered = sorted(self.reduced)
+        self.last_buckets = list(self.reduced)  # launch order: back to front
         self.reduced = []
         return covered
+
+    def exposed_ms(self) -> List[float]:
+        """Per update since the last call: milliseconds the compute stream spent waiting for the exchange in finish()
+        (synchronises the device)."""
+        if not self._exposed_events:
+            return []
+        torch.cuda.synchronize()
+        out = [a.elapsed_time(b) for a, b in self._exposed_events]
+        self._exposed_events = []
+        return out
 
 
 def all_reduce_scalars(t: torch.Tensor) -> torch.Tensor:

@@ -88,6 +88,21 @@ specaugment:
   time_mask_N: 2
   time_mask_T: 10
   time_mask_p: 0.5
+features:
+  eps: 1.0e-05
+  f_max: 8000
+  f_min: 20
+  hop_len_t: 0.004
+  hop_length: 64
+  n_fft: 256
+  n_mels: 80
+  n_stft: 129
+  sample_rate: 16000
+  type: spectrogram+melscale+log
+  win_len_t: 0.0125
+  win_length: 200
+  window_fn: hann
+sample_rate: 16000
 """)
     return root
 

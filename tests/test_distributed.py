@@ -225,3 +225,36 @@ def test_native_communicator_through_the_c_abi():
     # argument errors come back as codes, not crashes
     assert comm.lib.s2st_allreduce_sum_f32(None, x.data_ptr(), 4, None) == -4
     comm.close()
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_the_gpu_control_flow():
+    """``bench.py --gpus 2`` exactly as the driver launches it (``python -m torch.distributed.run --nproc-per-node 2 ...``),
+    with both ranks on the one GPU of this box (``S2ST_BENCH_SHARE_GPU=1``: gloo carries the gradient bytes, RCCL
+    refuses two ranks per device): the N > 1 control flow -- rendezvous on 127.0.0.1, parameter broadcast, round-robin
+    batches, range-wise exchange behind both engine streams, barriers around the timed region, max-over-ranks time,
+    rank-0-only JSON line with the whole-job value, the exchange's exposure figure and bucket list -- runs every round.
+    A control-flow check, not a measurement."""
+    import json
+    import socket
+    import subprocess
+    assert torch.cuda.is_available(), "gpu-marked test needs a HIP device"
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, S2ST_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+           "--no-roofline", "--cpu-seconds", "0", "--n-utts", "512"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 only
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["config"]["parallelism"] == "dp2"
+    ex = rec["gradient_exchange"]
+    assert ex["allreduce_exposed_ms"] >= 0 and ex["bytes_per_update"] > 280e6 and ex["dtype"] == "f32"
+    assert len(ex["buckets_mib"]) >= 3 and min(ex["buckets_mib"][:-1]) >= 16.0  # >= 16 MiB ranges (the tail may be smaller)
+    assert abs(rec["ms_per_step"] * rec["steps"] * rec["value"] / 1e3 - rec["config"]["global_batch_mel_frames"] * rec["steps"]) \
+        < 1e-3 * rec["config"]["global_batch_mel_frames"] * rec["steps"]

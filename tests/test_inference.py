@@ -66,6 +66,58 @@ def test_ar_generator_against_reference_golden(backend, golden_dir):
     assert len(set(lens)) > 1  # the golden batch mixes early stops and max_iter
 
 
+@pytest.mark.parametrize("mode", ["precise", "bf16"])
+def test_base_size_ar_generator_against_reference_golden(backend, golden_dir, mode):
+    """Config 5 at its stated size: the BASE model (12 / 6 layers, d 512, n_frames_per_step 4), 8 utterances, max_iter =
+    the longest teacher length, against the reference generator's output (oracle/gen_golden_infer_base.py; the stop
+    threshold sits >= 2e-3 away from every stop probability of the reference run).
+    precise (bf16x3 GEMMs): stop indices and alignments bit-exact, features 1e-3.
+    bf16 (the mode infer benchmarks run in: skinny-M GEMMs with bf16 weights and the fused pre-LayerNorm): the stop
+    indices must agree too -- each stop probability within 1.5e-3 of the reference's, inside the golden's margin -- and
+    the features within 2e-2 of the feature scale (bf16 operand rounding through 6 decoder layers x up to 110 steps of
+    feedback); alignments may differ where two encoder positions tie within rounding: at most 2 % of the frames."""
+    if backend.kind == "emu":
+        pytest.skip("base-size decode: GPU only (110 steps of the 12 / 6-layer model)")
+    z = np.load(os.path.join(golden_dir, "infer_ar_base.npz"))
+    gen_mod = importlib.import_module(PKG + ".speech_generator")
+    tasks = importlib.import_module(PKG + ".tasks")
+    cfg = dict(CONFIGS["base"], prenet_dropout=0.0)
+    a = O.make_args(**cfg)
+    a.precise_gemm = mode == "precise"
+    task = tasks.S2ST_TranslationTask.setup_task(a, device=backend.device)
+    model = task.build_model(a)
+    load_synth(model, 0)
+    gen = gen_mod.AutoRegressiveSpeechGenerator(model, None, None, max_iter=int(z["max_iter"]),
+                                                eos_prob_threshold=float(z["thr"]))
+    s = golden_sample("base", 0)
+    s["net_input"]["collated_audios_orig"] = None
+    s["net_input"]["padding_mask"] = None
+    fin = gen.generate(model, s)
+    backend.sync()
+    assert float(z["margin"]) >= 2e-3
+    lens, n_frames, n_align_diff = [], 0, 0
+    for b in range(int(z["n"])):
+        ref = z[f"feature.{b}"]
+        got = fin[b]["feature"].cpu().numpy()
+        assert got.shape == ref.shape, (mode, b, got.shape, ref.shape)  # the stop index, both modes
+        lens.append(ref.shape[0])
+        scale = max(1.0, float(np.abs(ref).max()))
+        perr = float(np.abs(fin[b]["eos_prob"].cpu().numpy() - z[f"eos_prob.{b}"]).max())
+        ferr = float(np.abs(got - ref).max())
+        same = np.array_equal(fin[b]["alignment"].cpu().numpy(), z[f"alignment.{b}"])
+        colmass = fin[b]["attn"].double().sum(dim=0).float().cpu().numpy()
+        assert float(np.abs(colmass - z[f"attn_sum.{b}"]).max()) < 1e-3  # every alignment column is a distribution
+        if mode == "precise":
+            assert ferr < 1e-3 * scale and perr < 2e-4 and same, (b, ferr, perr, same)
+        else:
+            assert ferr < 2e-2 * scale and perr < 1.5e-3, (b, ferr, perr)
+            n_frames += ref.shape[0]
+            n_align_diff += int((fin[b]["alignment"].cpu().numpy() != z[f"alignment.{b}"]).sum())
+    assert len(set(lens)) > 1  # the golden batch mixes early stops and max_iter
+    if mode == "bf16":
+        assert n_align_diff <= 0.02 * n_frames, (n_align_diff, n_frames)
+
+
 def test_gcmvn_denormalize_and_prenet_dropout_seeding(backend):
     gen_mod = importlib.import_module(PKG + ".speech_generator")
     cfg = dict(CONFIGS["tiny"], prenet_dropout=0.5)  # recipe value: always on, also at inference
@@ -175,3 +227,45 @@ def test_mcd_against_oracle(backend):
         assert abs(float(rets[b][0]) - ref) < 2e-3 * ref, (b, float(rets[b][0]), ref)
         x1 = IO.mfcc(y1[b], sr)
         assert float((rets[b][1][0].cpu() - x1).abs().max()) < 2e-3 * float(x1.abs().max())
+
+
+def test_generate_waveform_harness_on_disk_corpus(backend, tmp_path):
+    """The counterpart of examples/s2s_trans/generate_waveform.py:127-183 end to end on the miniature on-disk corpus: a
+    checkpoint written by the train harness (reference .pt layout) -> task / model from its cfg -> AR decode + Griffin-Lim
+    of a split -> per-utterance dumps named by manifest id.  The dumped features equal a direct generator call on the same
+    batch; a waveform file is 16-bit PCM at the feature sample rate with hop * frames samples."""
+    import wave
+    from data_corpus import make_corpus
+    from synth_weights import load_synth
+    from test_resume import NANO_FLAGS
+    T = importlib.import_module(PKG + ".train")
+    GW = importlib.import_module(PKG + ".generate_waveform")
+    corpus = make_corpus(str(tmp_path / "corpus"))
+    argv = [corpus, "--config-yaml", "config.yaml", "--train-subset", "train_tiny", "--valid-subset", "dev_tiny",
+            "--max-tokens", "120", "--required-batch-size-multiple", "2", "--max-update", "1", "--lr", "1e-3",
+            "--warmup-updates", "2", "--seed", "3", "--precise-gemm", "--save-dir", str(tmp_path / "ckpt"),
+            "--disable-validation", "--log-interval", "1"] + NANO_FLAGS
+    T.main(argv, device=backend.device, on_model_built=lambda m: load_synth(m, 0))
+    ckpt = str(tmp_path / "ckpt" / "checkpoint_last.pt")
+    assert os.path.isfile(ckpt)
+    out = tmp_path / "gen"
+    r = GW.main([corpus, "--config-yaml", "config.yaml", "--gen-subset", "dev_tiny", "--path", ckpt, "--results-path", str(out),
+                 "--max-tokens", "400", "--max-target-positions", "6", "--eos-prob-threshold", "2.0", "--spec-bwd-max-iter", "2",
+                 "--dump-features", "--dump-waveforms", "--dump-attentions", "--dump-eos-probs", "--dump-target",
+                 "--precise-gemm"], device=backend.device)
+    backend.sync()
+    assert r["utterances"] > 0 and r["mel_frames"] == r["utterances"] * 6 * 4  # never stops early: 6 steps x 4 frames
+    sr = r["sample_rate"]
+    feats = sorted(os.listdir(out / "feat"))
+    assert len(feats) == r["utterances"] and all(f.endswith(".npy") for f in feats)
+    for sub in ("feat_tgt", "attn", "eos", f"wav_{sr}hz_griffin_lim", f"wav_{sr}hz_griffin_lim_tgt"):
+        assert len(os.listdir(out / sub)) == r["utterances"], sub
+    f0 = np.load(out / "feat" / feats[0])
+    assert f0.shape == (24, 80) and np.isfinite(f0).all()
+    with wave.open(str(out / f"wav_{sr}hz_griffin_lim" / feats[0].replace(".npy", ".wav"))) as w:
+        assert w.getframerate() == sr and w.getsampwidth() == 2 and w.getnchannels() == 1
+        assert w.getnframes() > 0
+    # a rate the features do not have is refused, not silently ignored
+    with pytest.raises(SystemExit):
+        GW.main([corpus, "--gen-subset", "dev_tiny", "--path", ckpt, "--results-path", str(out), "--dump-features",
+                 "--output-sample-rate", str(sr + 1)], device=backend.device)

@@ -11,14 +11,14 @@ bd.load_library(bd.DEFAULT_LIB, emulator=False)
 d = torch.device("cuda:0")
 
 FORMS = [  # name, environment
-    ("r8 auto", {}),
+    ("auto", {}),
+    ("r8 auto", {"S2ST_GEMM_W4": "0"}),
     ("r8 128x128", {"S2ST_GEMM_TILE": "128x128"}),
     ("r8 128x64", {"S2ST_GEMM_TILE": "128x64"}),
     ("r8 64x64", {"S2ST_GEMM_TILE": "64x64"}),
     ("w4 128x128", {"S2ST_GEMM_W4": "1", "S2ST_GEMM_TILE": "128x128"}),
     ("w4 128x64/3", {"S2ST_GEMM_W4": "1", "S2ST_GEMM_TILE": "128x64", "S2ST_W4_NS64": "3"}),
     ("w4 128x64/2", {"S2ST_GEMM_W4": "1", "S2ST_GEMM_TILE": "128x64", "S2ST_W4_NS64": "2"}),
-    ("r8 64x512", {"S2ST_GEMM_TILE": "64x512"}),
 ]
 KEYS = sorted({k for _, e in FORMS for k in e})
 NSETS = 8
