@@ -321,7 +321,7 @@ def infer_main(args):
         import subprocess
         import tempfile
         n_cpu = args.cpu_utts or 2
-        ids = groups[-1][-n_cpu:]  # the shortest utterances: the CPU decoder re-runs its prefix every step
+        ids = groups[1][:n_cpu]  # utterances of the second batch: close to the corpus' mean decode length
         sub = corpus.collate_batch(ids)
         sub["net_input"]["collated_audios_orig"] = None
         sub["net_input"]["padding_mask"] = None
@@ -636,9 +636,16 @@ def main():
         # process); the committed measurement is reported, with its source
         traffic, traffic_src = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
                 tj = json.load(f)
-            if tj.get("config", "base_recipe") == args.config:
+            hb = C.create_string_buffer(32)
+            lib.s2st_source_hash.argtypes = [C.c_char_p, C.c_int32]
+            lib.s2st_source_hash(hb, 32)
+            if tj.get("source_hash") != hb.value.decode():
+                # measured on other sources than the loaded library was built from: not this kernel's figure any more
+                traffic_src = ("stale: profiles/r03_pmc_traffic.json was measured on sources %s, the loaded library is %s "
+                               "(tools/profile_round.sh re-measures)" % (tj.get("source_hash"), hb.value.decode()))
+            elif tj.get("config", "base_recipe") == args.config:
                 traffic, traffic_src = round(tj["kernels"][dom_tag]["hbm_bytes_per_launch"]), tj["source"]
         except Exception:
             pass

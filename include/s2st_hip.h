@@ -246,6 +246,12 @@ typedef struct {
    * subsampler -- token embedding, enc_conv_layers x (Conv1d k=enc_conv_k + BatchNorm1d + ReLU + dropout), a linear
    * projection, alpha-scaled positions; the batch's src_txt / src_txt_lens are then the encoder input (S = E = Ls) */
   int32_t text_input, enc_conv_layers, enc_conv_k;
+  /* speaker conditioning (examples/s2s_trans/models/s2st_transformer.py:203-206, 441-444; tables from
+   * tasks/s2s_translation.py:145-170): n_speakers > 0 adds encoder.embed_speaker.weight [n_speakers, enc_dim] -- the
+   * utterance's row is added to every encoder position before the dropout -- and decoder.embed_speaker.weight
+   * [n_speakers, out_dim] -- the row replaces the first frame of prev_output_tokens.  spk_frozen: tables loaded with
+   * Embedding.from_pretrained(freeze=True): no gradient is formed for them. */
+  int32_t n_speakers, spk_frozen;
   float dropout, attn_dropout, act_dropout, prenet_dropout, postnet_dropout;
   float ctc_weight, asr_weight, st_weight, w_l1, w_mse, w_eos, bce_pos_weight, label_smoothing;
   float ctc_tgt_weight;                   /* s2st_loss_mtl.py:171-185 */
@@ -289,6 +295,7 @@ typedef struct {
   int32_t training;               /* BatchNorm batch stats + dropout */
   int32_t want_attn;              /* also produce the head-averaged alignment [B,E,D] */
   uint64_t seed;                  /* dropout seed of this step */
+  const int64_t* speaker;         /* [B] speaker ids (sample["speaker"]); NULL = unconditioned */
 } s2st_batch;
 
 typedef struct { /* caller-owned device outputs; any pointer may be NULL (kept internal) */
@@ -470,6 +477,10 @@ int s2st_comm_destroy(s2st_comm* comm);
  * "tag\tlaunches\ttotal_us\twork\twork2\n" (work = as-launched FLOPs of a GEMM / attention launch, or the bytes an
  * HBM-bound kernel has to move), clears the registry and returns the text length (-1: buffer too small). */
 int s2st_profile_enable(int32_t enable);
+/* 16 hex digits identifying the kernel / engine sources this library was built from (sha256 prefix over csrc/ and
+ * include/, __graft_entry__.source_hash): measurements stored under profiles/ carry it, bench.py reports a stored PMC
+ * traffic figure only when it matches */
+int s2st_source_hash(char* out, int32_t cap);
 int64_t s2st_profile_report(char* out, int64_t cap);
 /* Same registry as one line per dispatch in launch order: "tag\tstream\tstart_us\tdur_us\n" (stream = index in order of
  * first use, start on the GPU clock relative to the first dispatch).  Clears the registry. */

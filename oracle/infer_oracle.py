@@ -15,6 +15,8 @@ from __future__ import annotations
 import math
 from typing import Dict, List, Optional
 
+import functools
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -50,12 +52,12 @@ def _decoder_prefix(dec, prev, enc, key_lens):
 
 @torch.no_grad()
 def ar_generate(m, src, src_lens, max_iter: int, eos_prob_threshold: float, n_frames_per_step: int,
-                gcmvn: Optional[Dict[str, np.ndarray]] = None) -> List[Dict[str, torch.Tensor]]:
+                gcmvn: Optional[Dict[str, np.ndarray]] = None, speaker=None) -> List[Dict[str, torch.Tensor]]:
     """Oracle model ``m`` (s2st_oracle.S2STModel, eval mode).  The reference decodes incrementally with
     a key/value cache; because the decoder is causal that equals re-running it on the whole prefix
     (done here) as long as the always-on Prenet dropout is 0 -- with p > 0 the output is random."""
     m.eval()
-    enc = m.encoder(src, src_lens)
+    enc = m.encoder(src, src_lens, speaker=speaker) if speaker is not None else m.encoder(src, src_lens)
     bsz = src.shape[0]
     out_dim = m.decoder.out_dim
     raw_dim = out_dim // n_frames_per_step
@@ -66,7 +68,10 @@ def ar_generate(m, src, src_lens, max_iter: int, eos_prob_threshold: float, n_fr
     for step in range(max_iter):
         cur_out_lens = out_lens.clone()
         cur_out_lens.masked_fill_(cur_out_lens.eq(max_iter), step + 1)
-        f_all, eos, a_all = _decoder_prefix(m.decoder, prefix, enc, cur_out_lens)
+        # with a speaker the reference's incremental decoder replaces its ONE input frame by the speaker row at every step
+        # (s2st_transformer.py:441-444 on the [B, 1, C] tensor the generator hands over): the whole prefix is speaker rows
+        px = prefix if speaker is None else m.decoder.embed_speaker(speaker).expand(-1, prefix.shape[1], -1)
+        f_all, eos, a_all = _decoder_prefix(m.decoder, px, enc, cur_out_lens)
         cur_feat = f_all[:, -1:, :]
         cur_eos = torch.sigmoid(eos[:, -1:, :]).squeeze(2)
         feat.append(cur_feat)
@@ -106,10 +111,14 @@ def get_fourier_basis(n_fft: int) -> torch.Tensor:  # audio_utils.py:226-231
     return torch.from_numpy(basis).float()
 
 
+# (the reference builds both bases ONCE, in the constructors named below; cached here per geometry so that the oracle
+# timed as a CPU baseline does not pay a 2050 x 2048 pseudo-inverse per Griffin-Lim iteration)
+@functools.lru_cache(maxsize=8)
 def stft_basis(n_fft, win_length):  # TTSSpectrogram.__init__
     return get_fourier_basis(n_fft) * get_window(n_fft, win_length)  # [2F, n_fft]
 
 
+@functools.lru_cache(maxsize=8)
 def istft_basis(n_fft, win_length, hop_length):  # GriffinLim.__init__
     basis = torch.pinverse(n_fft / hop_length * get_fourier_basis(n_fft)).T
     return basis * get_window(n_fft, win_length)  # [2F, n_fft]

@@ -93,6 +93,8 @@ def make_args(**kw) -> argparse.Namespace:
     d("attn_loss_weight", 1.0)
     d("use_guided_attention_loss", False)
     d("guided_attention_loss_sigma", 0.4)
+    d("speaker_embed_dim", 64)  # base_architecture (:796-797)
+    d("speaker_embed_dim_dec", 64)
     return a
 
 
@@ -361,12 +363,17 @@ class S2STEncoder(nn.Module):
         self.aux_asr_norm = nn.LayerNorm(a.encoder_embed_dim) if a.asr_ce_weight > 0 else None
         self.aux_st_norm = nn.LayerNorm(a.encoder_embed_dim) if a.st_ce_weight > 0 else None
         self.embed_positions = _PositionalEmbeddingState()
+        # speaker table: rows = len(args.speaker_to_id) of the flag's STRING (tasks/s2s_translation.py:156-160)
+        n_spk = len(a.speaker_to_id) if getattr(a, "speaker_to_id", None) is not None else 0
+        self.embed_speaker = nn.Embedding(n_spk, a.speaker_embed_dim) if n_spk else None
 
-    def forward(self, src, src_lens):
+    def forward(self, src, src_lens, speaker=None):
         x, lens = self.subsample(src, src_lens)  # [E, B, C]
         x = self.embed_scale * x
         pad = lengths_to_padding_mask(lens, x.shape[0])
         x = x + positional_embedding(pad, x.shape[-1]).transpose(0, 1)
+        if speaker is not None:  # s2st_transformer.py:203-206: every position, padded ones included
+            x = x + self.embed_speaker(speaker).transpose(0, 1)
         x = F.dropout(x, self.a.dropout, self.training)
         taps = []
         for i, layer in enumerate(self.transformer_layers):
@@ -443,14 +450,20 @@ class S2STDecoder(nn.Module):
         self.eos_proj = nn.Linear(a.decoder_embed_dim, 1)
         self.postnet = Postnet(self.out_dim, a.postnet_conv_dim, a.postnet_conv_kernel_size,
                                a.postnet_layers, a.postnet_dropout)
-        self.ctc_proj = nn.Linear(a.encoder_embed_dim, a.src_vocab_size) if a.ctc_weight > 0 else None
+        # (t2s_transformer.py:168-170: the text-input model's head reads feature_out, width out_dim)
+        self.ctc_proj = (nn.Linear(self.out_dim if getattr(a, "text_encoder", False) else a.encoder_embed_dim,
+                                   a.src_vocab_size) if a.ctc_weight > 0 else None)
         # s2st_transformer_mtl.py:266-271: a second CTC head (target text) on a decoder layer's output
         self.ctc_proj_tgt = (nn.Linear(a.decoder_embed_dim, a.tgt_vocab_size)
                              if getattr(a, "ctc_weight_tgt", 0.0) > 0 else None)
         self.middle_layers_decoder = [int(k) for k in str(getattr(a, "middle_layers_decoder", "6")).split(",")]
         self.embed_positions = _PositionalEmbeddingState()
+        n_spk = len(a.speaker_to_id) if getattr(a, "speaker_to_id", None) is not None else 0
+        self.embed_speaker = nn.Embedding(n_spk, a.speaker_embed_dim_dec) if n_spk else None
 
-    def forward(self, prev, enc, target_lengths):
+    def forward(self, prev, enc, target_lengths, speaker=None):
+        if speaker is not None:  # s2st_transformer.py:441-444: the speaker row replaces the first input frame
+            prev = torch.cat([self.embed_speaker(speaker), prev[:, 1:, :]], 1)
         pad = lengths_to_padding_mask(target_lengths, prev.shape[1])
         pos = positional_embedding(pad, self.a.decoder_embed_dim)
         x = self.prenet(prev)
@@ -555,9 +568,10 @@ class S2STModel(nn.Module):
                                                  a.st_decoder_layers, tap=1)
 
     def forward(self, src_tokens, src_lengths, prev_output_tokens, target_lengths,
-                prev_src_text_tokens=None, prev_tgt_text_tokens=None):
-        enc = self.encoder(src_tokens, src_lengths)
-        dec = self.decoder(prev_output_tokens, enc, target_lengths)
+                prev_src_text_tokens=None, prev_tgt_text_tokens=None, speaker=None):
+        enc = self.encoder(src_tokens, src_lengths, speaker=speaker) if speaker is not None else self.encoder(src_tokens, src_lengths)
+        dec = (self.decoder(prev_output_tokens, enc, target_lengths, speaker=speaker) if speaker is not None
+               else self.decoder(prev_output_tokens, enc, target_lengths))
         asr = st = None
         if self.aux_asr_decoder is not None:
             asr = self.aux_asr_decoder(prev_src_text_tokens, enc)
@@ -666,7 +680,8 @@ def criterion_forward(model: S2STModel, sample: Dict, a=None):
         sample["src_text"] if text_in else ni["src_speech"],
         sample["src_text_len"] if text_in else ni["src_speech_lens"], ni["prev_output_tokens"], tl,
         ni.get("prev_src_text_tokens") if a.asr_ce_weight > 0 else None,
-        ni.get("prev_tgt_text_tokens") if a.st_ce_weight > 0 else None)
+        ni.get("prev_tgt_text_tokens") if a.st_ce_weight > 0 else None,
+        **({"speaker": sample["speaker"]} if sample.get("speaker") is not None else {}))  # s2st_loss.py:217
     mask = ~lengths_to_padding_mask(tl, D)
     _eos = eos[mask].squeeze(-1)
     _et = eos_tgt[mask]
@@ -684,7 +699,11 @@ def criterion_forward(model: S2STModel, sample: Dict, a=None):
                                           a.guided_attention_loss_sigma)
     ctc = zero
     lprobs_ctc = None
-    if a.ctc_weight > 0:
+    if a.ctc_weight > 0 and text_in:  # t2s_loss.py:134-144: source text against the decoder's feature_out
+        lprobs_ctc = F.log_softmax(model.decoder.ctc_proj(extra["feature_out"]).float(), dim=-1).transpose(0, 1)  # [D, B, V]
+        smask = ~lengths_to_padding_mask(sample["src_text_len"], sample["src_text"].shape[1])
+        ctc = ctc_loss_mean(lprobs_ctc, sample["src_text"].masked_select(smask), tl, sample["src_text_len"]) * a.ctc_weight
+    elif a.ctc_weight > 0:
         ilens = ctc_input_lengths(ni["src_speech_lens"],
                                   [int(k) for k in a.conv_kernel_sizes.split(",")])
         logits = model.decoder.ctc_proj(extra["out_middle_layers"][0].transpose(0, 1))

@@ -20,10 +20,9 @@ class _T2SLog(LazyLog):
 class Tacotron2T2SCriterion(Tacotron2Criterion):
     def __init__(self, task, sentence_avg=False, n_frames_per_step=4, use_guided_attention_loss=False,
                  guided_attention_loss_sigma=0.4, bce_pos_weight=1.0, ctc_weight=0.0):
-        if ctc_weight > 0:
-            raise NotImplementedError("t2s_loss: the feature-level CTC head is not built (--ctc-weight 0)")
+        # --ctc-weight > 0: CTC of the source text against log_softmax(ctc_proj(feature_out)) (t2s_loss.py:134-144)
         super().__init__(task, sentence_avg, n_frames_per_step, use_guided_attention_loss, guided_attention_loss_sigma,
-                         bce_pos_weight, 0.0)
+                         bce_pos_weight, ctc_weight)
 
     @classmethod
     def build_criterion(cls, args, task):

@@ -235,6 +235,17 @@ int s2st_gemm_streamk_scratch(float* scratch, int64_t floats, void* stream) {
   s2st_gemm_streamk_bind((hipStream_t)stream, scratch, floats);
   return 0;
 }
+#ifndef S2ST_SOURCE_HASH
+#define S2ST_SOURCE_HASH "unknown"  // (__graft_entry__.build passes the hash of the sources; the test emulator build does not)
+#endif
+int s2st_source_hash(char* out, int32_t cap) {
+  const char* h = S2ST_SOURCE_HASH;
+  if (!out || cap < 2) return S2ST_ERR_ARG;
+  int i = 0;
+  for (; h[i] && i < cap - 1; ++i) out[i] = h[i];
+  out[i] = 0;
+  return 0;
+}
 int s2st_profile_enable(int32_t enable) { s2st_profile_enable_impl(enable); return 0; }
 int64_t s2st_profile_report(char* out, int64_t cap) { return s2st_profile_report_impl(out, cap, 0); }
 int64_t s2st_profile_timeline(char* out, int64_t cap) { return s2st_profile_report_impl(out, cap, 1); }

@@ -148,21 +148,57 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
   }
 }
 
+// spk_table / spk_ids (optional): the utterance's speaker embedding row is added to EVERY position of the utterance,
+// padded ones included, before the dropout (s2st_transformer.py:203-208); T = rows per utterance
 __global__ __launch_bounds__(256) void add_pe_kernel(const float* __restrict__ x,
                                                      float* __restrict__ y,
                                                      const int* __restrict__ pos,
                                                      const float* __restrict__ table, int rows,
                                                      int C, float scale,
                                                      const float* __restrict__ alpha_ptr,
-                                                     float drop_p, uint64_t seed) {
+                                                     float drop_p, uint64_t seed,
+                                                     const float* __restrict__ spk_table,
+                                                     const long* __restrict__ spk_ids, int T) {
   long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
   long n = (long)rows * C;
   if (i >= n) return;
   int r = (int)(i / C), c = (int)(i - (long)r * C);
   float alpha = alpha_ptr ? alpha_ptr[0] : 1.f;
   float v = scale * x[i] + alpha * table[(long)pos[r] * C + c];
+  if (spk_table) v += spk_table[spk_ids[r / T] * C + c];
   if (drop_p > 0.f) v *= drop_scale(seed, (uint64_t)i, drop_p, 1.f / (1.f - drop_p));
   y[i] = v;
+}
+
+// Gradient of a speaker-embedding table whose row ids[b] was added to (T_sum > 1: every one of the first T_sum rows
+// of) utterance b's block of `T` rows: dtable[s][c] += sum over {b : ids[b] == s}, t < T_sum of mask(b, t, c) * dy[b][t][c].
+// One thread per (speaker, column), utterances and rows in index order: no atomics, run-to-run identical.
+__global__ __launch_bounds__(256) void speaker_bwd_kernel(const float* __restrict__ dy, const long* __restrict__ ids, int B,
+                                                          int T, int T_sum, int C, int n_spk, float drop_p, uint64_t seed,
+                                                          float* __restrict__ dtable) {
+  const int c = blockIdx.x * 256 + threadIdx.x, sp = blockIdx.y;
+  if (c >= C || sp >= n_spk) return;
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  float a = 0.f;
+  for (int b = 0; b < B; ++b) {
+    if (ids[b] != sp) continue;
+    for (int t = 0; t < T_sum; ++t) {
+      const long i = ((long)b * T + t) * C + c;
+      float g = dy[i];
+      if (drop_p > 0.f) g *= drop_scale(seed, (uint64_t)i, drop_p, inv_keep);
+      a += g;
+    }
+  }
+  dtable[(long)sp * C + c] += a;
+}
+
+// y[b][t0][:] = table[ids[b]][:] for every utterance (the decoder's first input frame, s2st_transformer.py:441-444)
+__global__ __launch_bounds__(256) void speaker_set_rows_kernel(const float* __restrict__ table, const long* __restrict__ ids,
+                                                               float* __restrict__ y, int B, int T, int C) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * C) return;
+  const int b = (int)(i / C), c = (int)(i - (long)b * C);
+  y[(long)b * T * C + c] = table[ids[b] * C + c];
 }
 
 // dalpha += sum_i dy[i] * mask(i) * PE[pos(row)][c]
@@ -329,6 +365,42 @@ __global__ __launch_bounds__(256) void conv_w_permute_kernel(const float* __rest
   if (wd) wd[((long)c * Kw + (Kw - 1 - j)) * O + o] = v;
   if (wfh) wfh[((long)o * Kw + j) * I + c] = vh;
   if (wdh) wdh[((long)c * Kw + (Kw - 1 - j)) * O + o] = vh;
+}
+
+// The same re-layout through a 32 x 32 LDS tile per (o block, c block, tap j): reads walk c (stride Kw floats), the Wf
+// stores walk c, the Wd stores walk o -- every global access of a wave is one or a few contiguous runs (the per-element
+// kernel above scatters 2- and 4-byte stores at strides of I and O elements: 35 us for the 512 x 512 x 5 post-net
+// weights, seven times a step)
+__global__ __launch_bounds__(256) void conv_w_permute_tiled_kernel(const float* __restrict__ w, float* __restrict__ wf,
+                                                                   float* __restrict__ wd, int O, int I, int Kw,
+                                                                   uint16_t* __restrict__ wfh, uint16_t* __restrict__ wdh) {
+  __shared__ float tile[32][33];
+  const int j = blockIdx.z, o0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int o = o0 + r, c = c0 + tx;
+    float v = 0.f;
+    if (o < O && c < I) {
+      v = w[((long)o * I + c) * Kw + j];
+      const long i = ((long)o * Kw + j) * I + c;
+      if (wf) wf[i] = v;
+      if (wfh) wfh[i] = (uint16_t)(pack_bf16x4(v, 0.f, 0.f, 0.f).x & 0xffffu);
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  if (!wd && !wdh) return;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, o = o0 + tx;
+    if (o < O && c < I) {
+      const float v = tile[tx][r];
+      const long i = ((long)c * Kw + (Kw - 1 - j)) * O + o;
+      if (wd) wd[i] = v;
+      if (wdh) wdh[i] = (uint16_t)(pack_bf16x4(v, 0.f, 0.f, 0.f).x & 0xffffu);
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void conv_w_unpermute_acc_kernel(const float* __restrict__ dwf,
@@ -581,11 +653,27 @@ int s2st_glu_bwd(const float* a, const float* dy, Split dysp, float* da, Split d
 }
 
 int s2st_add_pe(const float* x, float* y, const int* pos, const float* table, int rows, int C,
-                float scale, const float* alpha_ptr, float drop_p, uint64_t seed, hipStream_t st) {
+                float scale, const float* alpha_ptr, float drop_p, uint64_t seed, hipStream_t st,
+                const float* spk_table, const long* spk_ids, int T) {
   long n = (long)rows * C;
   if (n <= 0) return 0;
+  if (spk_table && (!spk_ids || T <= 0)) return S2ST_ERR_ARG;
   S2ST_LAUNCH(add_pe_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, y, pos, table, rows, C,
-                     scale, alpha_ptr, drop_p, seed);
+                     scale, alpha_ptr, drop_p, seed, spk_table, spk_ids, T > 0 ? T : 1);
+  return LAUNCH_OK();
+}
+
+int s2st_speaker_bwd(const float* dy, const long* ids, int B, int T, int T_sum, int C, int n_spk, float drop_p,
+                     uint64_t seed, float* dtable, hipStream_t st) {
+  if (B <= 0 || C <= 0 || n_spk <= 0) return 0;
+  S2ST_LAUNCH(speaker_bwd_kernel, dim3((C + 255) / 256, n_spk), dim3(256), 0, st, dy, ids, B, T, T_sum, C, n_spk, drop_p,
+              seed, dtable);
+  return LAUNCH_OK();
+}
+
+int s2st_speaker_set_rows(const float* table, const long* ids, float* y, int B, int T, int C, hipStream_t st) {
+  if (B <= 0 || C <= 0) return 0;
+  S2ST_LAUNCH(speaker_set_rows_kernel, dim3((unsigned)(((long)B * C + 255) / 256)), dim3(256), 0, st, table, ids, y, B, T, C);
   return LAUNCH_OK();
 }
 
@@ -678,6 +766,11 @@ int s2st_conv_w_permute(const float* w, float* wf, float* wd, int O, int I, int 
                         uint16_t* wdh) {
   long n = (long)O * I * Kw;
   if (n <= 0) return 0;
+  if (O >= 32 && I >= 32 && Kw <= 64) {
+    S2ST_LAUNCH(conv_w_permute_tiled_kernel, dim3((I + 31) / 32, (O + 31) / 32, Kw), dim3(256), 0, st, w, wf, wd, O, I, Kw,
+                wfh, wdh);
+    return LAUNCH_OK();
+  }
   S2ST_LAUNCH(conv_w_permute_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, w, wf, wd, O, I, Kw, wfh, wdh);
   return LAUNCH_OK();
 }

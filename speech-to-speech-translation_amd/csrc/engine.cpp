@@ -321,6 +321,7 @@ struct s2st_engine {
     return a;
   }
 
+  long enc_spk = -1, dec_spk = -1;  // speaker-embedding tables (n_speakers > 0)
   // t2s text encoder front
   long enc_embed = -1, enc_pos_alpha = -1;
   std::vector<ConvP> enc_conv;
@@ -352,6 +353,7 @@ struct s2st_engine {
     sub[1] = ConvP{add("encoder.subsample.conv_layers.1.weight", {2 * C, c.conv_channels / 2, c.conv_k}),
                    add("encoder.subsample.conv_layers.1.bias", {2 * C}), 2 * C, c.conv_channels / 2,
                    c.conv_k};
+    if (c.n_speakers > 0) enc_spk = add("encoder.embed_speaker.weight", {c.n_speakers, C});
     }
     for (int i = 0; i < c.enc_layers; ++i) {
       std::string pre = "encoder.transformer_layers." + std::to_string(i);
@@ -368,6 +370,7 @@ struct s2st_engine {
     if (c.has_asr) asr_norm = add_ln("encoder.aux_asr_norm", C);
     if (c.has_st) st_norm = add_ln("encoder.aux_st_norm", C);
     pos_alpha = add("decoder.pos_emb_alpha", {1});
+    if (c.n_speakers > 0) dec_spk = add("decoder.embed_speaker.weight", {c.n_speakers, c.out_dim});
     for (int i = 0; i < c.prenet_layers; ++i)
       prenet.push_back(add_lin("decoder.prenet.0.layers." + std::to_string(i) + ".0",
                                c.prenet_dim, i == 0 ? c.out_dim : c.prenet_dim));
@@ -392,7 +395,8 @@ struct s2st_engine {
       bn.rv = add(pre + ".1.running_var", {co}, 1);
       post_bn.push_back(bn);
     }
-    if (c.has_ctc) ctc_proj = add_lin("decoder.ctc_proj", c.src_vocab, C);
+    // (t2s_transformer: the head reads the decoder's feature_out, t2s_transformer.py:168-170, 258)
+    if (c.has_ctc) ctc_proj = add_lin("decoder.ctc_proj", c.src_vocab, c.text_input ? c.out_dim : C);
     if (c.has_ctc_tgt) ctc_proj_tgt = add_lin("decoder.ctc_proj_tgt", c.tgt_vocab, Cd);  // mtl variant
     // aux decoders: embedding dims follow the reference's in-place args mutation
     // (s2st_transformer.py:492-493, 541-542, 669-678)
@@ -467,11 +471,23 @@ struct s2st_engine {
   int group_flush_at = 6;  // S2ST_WGRAD_GROUP=<n>: problems per launch (<= S2ST_GROUP_MAX); measured 2 .. 8 on the bench
                            // workload: 12.25 / 10.99 / 10.56 / 10.44 / 10.46 ms per step for 2 / 3 / 4 / 6 / 8
   std::vector<GemmArgs> pending_wgrad;
+  // A grouped launch is one workgroup per 128 x 128 tile with K = tokens unsplit (~70 K-steps each): what matters is how
+  // its tile count divides by the 256 CUs.  Six products of an encoder layer and a half are 288 tiles -- a full round
+  // plus a 12 % one that takes as long (70 us per launch); cutting at <= 256 tiles makes every launch one round (the
+  // layers' products are 16 ... 64 tiles each, so the cuts land on 256 exactly).  S2ST_WGRAD_TILES=0: count products only.
+  long pending_tiles = 0;
+  int group_tile_budget = 256;
+  static long wgrad_tiles(const GemmArgs& g) { return (long)((g.M + 127) / 128) * ((g.N + 127) / 128); }
   void push_wgrad(const GemmArgs& g) {
     for (const GemmArgs& p : pending_wgrad)
       if (p.C.p == g.C.p) { flush_wgrad(); break; }  // two sums into one matrix must not share a launch
+    const long t = wgrad_tiles(g);
+    if (group_tile_budget > 0 && !pending_wgrad.empty() && pending_tiles + t > group_tile_budget) flush_wgrad();
     pending_wgrad.push_back(g);
-    if ((int)pending_wgrad.size() >= group_flush_at) flush_wgrad();
+    pending_tiles += t;
+    if ((int)pending_wgrad.size() >= (group_tile_budget > 0 ? S2ST_GROUP_MAX : group_flush_at) ||
+        (group_tile_budget > 0 && pending_tiles >= group_tile_budget))
+      flush_wgrad();
   }
   void flush_wgrad() {
     if (pending_wgrad.empty()) return;
@@ -489,6 +505,7 @@ struct s2st_engine {
       if (!skip) chk(s2st_gemm_bf16_group(pending_wgrad.data(), (int)pending_wgrad.size(), s));
     }
     pending_wgrad.clear();
+    pending_tiles = 0;
   }
 
   // layer-norm parameter gradients: the backward row kernels leave column-sum partials; one batched fold per backward
@@ -1033,15 +1050,23 @@ struct s2st_engine {
     return holder;
   }
 
-  Ten* add_pe(Ten* x, const int* pos, const float* table, float scale, long alpha_off, float drop_p) {
+  // spk_off >= 0: + the utterance's speaker-embedding row at every one of its T positions (before the dropout)
+  Ten* add_pe(Ten* x, const int* pos, const float* table, float scale, long alpha_off, float drop_p, long spk_off = -1,
+              int T = 0) {
     Ten* y = newT(x->rows, x->cols);
     const uint64_t sd = drop_p > 0.f ? next_seed() : 0;
     if (alpha_off >= 0) touch(alpha_off + 1);
+    const bool spk = spk_off >= 0 && bt.speaker != nullptr;
+    if (spk) touch(spk_off + (long)c.n_speakers * x->cols);
+    const long* spk_ids = (const long*)bt.speaker;
+    const int Bn = T > 0 ? x->rows / T : 0;
     if (live())
       chk(s2st_add_pe(x->d, y->d, pos, table, x->rows, x->cols, scale, alpha_off >= 0 ? P + alpha_off : nullptr,
-                      drop_p, sd, st_));
+                      drop_p, sd, st_, spk ? P + spk_off : nullptr, spk ? spk_ids : nullptr, T));
     tape.push_back([=]() {
       if (!y->g) return;
+      if (spk && !c.spk_frozen && live())
+        chk(s2st_speaker_bwd(y->g, spk_ids, Bn, T, T, x->cols, c.n_speakers, drop_p, sd, G + spk_off, st_));
       if (alpha_off >= 0 && live())
         chk(s2st_pe_alpha_bwd(y->g, pos, table, x->rows, x->cols, drop_p, sd, G + alpha_off, st_));
       if (x->needs_grad) {
@@ -1099,6 +1124,16 @@ struct s2st_engine {
     const bool pre = c.dec_pre_ln != 0;
     Ten* x = newT(B, c.out_dim, const_cast<float*>(prev));
     x->needs_grad = false;
+    if (dec_spk >= 0 && bt.speaker) {
+      // the reference's decoder replaces prev_output_tokens[:, 0] with the speaker row and keeps [:, 1:]
+      // (s2st_transformer.py:441-444); its generator hands over ONE frame per step (speech_generator_for_s2st.py:84-99),
+      // so during incremental decoding EVERY step's input is the speaker row and the fed-back feature is dropped.
+      // Reproduced as is (results identical to the reference's).
+      Ten* sp = newT(B, c.out_dim);
+      if (live()) chk(s2st_embed_fwd((const long*)bt.speaker, P + dec_spk, sp->d, B, c.out_dim, 1.f, st_));
+      sp->needs_grad = false;
+      x = sp;
+    }
     // Prenet: dropout is ALWAYS on (tacotron2.py:95-98), also at inference
     for (int i = 0; i < c.prenet_layers; ++i)
       x = linear(x, prenet[i].w, prenet[i].b, prenet[i].N, prenet[i].K, 1, c.prenet_dropout);
@@ -1149,8 +1184,9 @@ struct s2st_engine {
     ConvW s;
     const bool fm = fast();
     long n = (long)p.O * p.I * p.Kw;
-    s.wf = alloc(n);
-    s.wd = need_wd ? alloc(n) : nullptr;
+    // (fast mode reads only the bf16 twins of the two layouts: no fp32 copies are made)
+    s.wf = fm ? nullptr : alloc(n);
+    s.wd = (need_wd && !fm) ? alloc(n) : nullptr;
     s.dwf = alloc(n, tr);
     bf16raw* wfh = fm ? alloc_h((n + 7) / 8 * 8) : nullptr;
     bf16raw* wdh = fm && need_wd ? alloc_h((n + 7) / 8 * 8) : nullptr;
@@ -1412,6 +1448,7 @@ struct s2st_engine {
   bool use_streamk = getenv("S2ST_GEMM_STREAMK") && atoi(getenv("S2ST_GEMM_STREAMK")) > 0;
   void reset_call() {
     pending_wgrad.clear();
+    pending_tiles = 0;
     pending_lnfold = s2st_lnfold_table{};
     s2st_gemm_streamk_unbind_all();  // the scratch lives in the previous call's workspace
     for (Ten* t : tens) delete t;
@@ -1535,7 +1572,7 @@ struct s2st_engine {
     float* x0d = alloc((long)B * E * C);
     Ten* x0 = glu_to(z2, x0d, Split{(long)C, 0, 0, 0}, C);
     x = add_pe(x0, bt.enc_pos, pe_enc, c.no_scale_embedding ? 1.f : sqrtf((float)C), -1,
-                    tr ? c.dropout : 0.f);
+                    tr ? c.dropout : 0.f, enc_spk, E);
     }
     mark();
     // ---- encoder layers, taps -----------------------------------------------------------------
@@ -1553,7 +1590,9 @@ struct s2st_engine {
     if (c.has_st && tap_st) tap_st = layernorm(tap_st, st_norm, outs.tap1);
     // the CTC head and the aux text decoders only need the encoder taps: they are issued (below, in tape
     // order) on the second stream behind this event and run next to the mel decoder
-    const bool aux_on_side = side_ && ev_taps_ && live() && overlap_aux;
+    // (t2s feature-level CTC head: it reads the DECODER's output, not an encoder tap -- nothing to overlap, and its
+    // backward adds to feature_out's gradient like the post-net's: kept on the data-path stream)
+    const bool aux_on_side = side_ && ev_taps_ && live() && overlap_aux && !(c.text_input && c.has_ctc);
     const bool kv_on_side = side_ && ev_taps_ && ev_kv_ && live() && hoist_kv && !stop_after_encoder;
     if (aux_on_side || kv_on_side) hipEventRecord(ev_taps_, st_);
     aux_wait_idx = tape.size();  // the tap layer-norm closures are the last ones pushed so far
@@ -1584,6 +1623,24 @@ struct s2st_engine {
     // ---- decoder: prenet (dropout always on), alpha * positions, layers ---------------------------
     Ten* prev = newT(B * D, c.out_dim, const_cast<float*>(bt.prev));
     prev->needs_grad = false;
+    if (dec_spk >= 0 && bt.speaker) {
+      // the speaker's row replaces the first input frame (s2st_transformer.py:441-444): a copy of prev_output_tokens
+      // with row (b, 0) overwritten; its gradient there is the table's gradient
+      Ten* pv = newT(B * D, c.out_dim);
+      touch(dec_spk + (long)c.n_speakers * c.out_dim);
+      if (live()) {
+        hipMemcpyAsync(pv->d, bt.prev, sizeof(float) * (size_t)pv->n(), hipMemcpyDeviceToDevice, st_);
+        chk(s2st_speaker_set_rows(P + dec_spk, (const long*)bt.speaker, pv->d, B, D, c.out_dim, st_));
+      }
+      pv->needs_grad = tr && !c.spk_frozen;
+      const long doff = dec_spk;
+      tape.push_back([=]() {
+        if (!pv->g || c.spk_frozen) return;
+        if (live())
+          chk(s2st_speaker_bwd(pv->g, (const long*)bt.speaker, B, D, 1, c.out_dim, c.n_speakers, 0.f, 0, G + doff, st_));
+      });
+      prev = pv;
+    }
     Ten* h = prev;
     for (int i = 0; i < c.prenet_layers; ++i)
       h = linear(h, prenet[i].w, prenet[i].b, prenet[i].N, prenet[i].K, 1, c.prenet_dropout);
@@ -1629,20 +1686,26 @@ struct s2st_engine {
       side_used = true;
     }
     Ten* ctc_logits = nullptr;
-    if (c.has_ctc && tap_asr) ctc_logits = linear(tap_asr, ctc_proj.w, ctc_proj.b, c.src_vocab, C);
+    if (c.has_ctc && tap_asr && !c.text_input) ctc_logits = linear(tap_asr, ctc_proj.w, ctc_proj.b, c.src_vocab, C);
+    // t2s_transformer (criterions/t2s_loss.py:134-144): CTC of the SOURCE TEXT against the decoder's feature_out --
+    // log_softmax(ctc_proj(feature_out)) [D, B, V], input lengths = decoder steps, targets = src_text, blank 0
+    const bool t2s_ctc = c.text_input && c.has_ctc;
+    if (t2s_ctc) ctc_logits = linear(feat, ctc_proj.w, ctc_proj.b, c.src_vocab, c.out_dim);
+    const int ctc_T = t2s_ctc ? D : E;
+    const int* ctc_ilens = t2s_ctc ? bt.tgt_lens : bt.ctc_in_lens;
     // The CTC sweep (one workgroup per utterance, ~E sequential steps: latency-bound, ~0.4 ms) runs on the
     // second stream next to the aux decoders and the other loss kernels; joined before the loss is finalised.
     float* ctc_per = (with_loss && c.has_ctc) ? alloc(B) : nullptr;
     float *ctc_lp = nullptr, *ctc_ws = nullptr, *ctc_dl = nullptr;
     if (with_loss && c.has_ctc && ctc_logits) {
-      ctc_lp = outs.ctc_lprobs ? outs.ctc_lprobs : alloc((long)B * E * c.src_vocab);
-      ctc_ws = alloc(s2st_ctc_workspace_floats(B, E, bt.Ls));
+      ctc_lp = (outs.ctc_lprobs && !t2s_ctc) ? outs.ctc_lprobs : alloc((long)B * ctc_T * c.src_vocab);
+      ctc_ws = alloc(s2st_ctc_workspace_floats(B, ctc_T, bt.Ls));
       // training: the CTC gradient w.r.t. the logits comes out of the same alpha/beta sweep as the
       // loss, so it is produced here (per unit of upstream gradient) and only scaled in the backward
       ctc_dl = tr ? alloc(ctc_logits->n()) : nullptr;
       if (live()) {
         hipStream_t cs = aux_on_side ? st_ : fork_side();
-        chk(s2st_ctc(ctc_logits->d, (const long*)bt.src_txt, bt.Ls, bt.ctc_in_lens, bt.src_txt_lens, B, E,
+        chk(s2st_ctc(ctc_logits->d, (const long*)bt.src_txt, bt.Ls, ctc_ilens, bt.src_txt_lens, B, ctc_T,
                      c.src_vocab, ctc_lp, ctc_per, ctc_dl, ctc_dl ? c.ctc_weight / B : 0.f, ctc_ws, cs));
       }
     }
@@ -1694,7 +1757,7 @@ struct s2st_engine {
           if (live()) {
             if (ctc_dl) chk(s2st_dropout(ctc_dl, dl, ctc_logits->n(), gs, 0.f, 0, 0, st_));  // dl = gs * ctc_dl
             else
-              chk(s2st_ctc(ctc_logits->d, (const long*)bt.src_txt, bt.Ls, bt.ctc_in_lens, bt.src_txt_lens, B, E,
+              chk(s2st_ctc(ctc_logits->d, (const long*)bt.src_txt, bt.Ls, ctc_ilens, bt.src_txt_lens, B, ctc_T,
                            c.src_vocab, ctc_lp, ctc_per, dl, gs * c.ctc_weight / B, ctc_ws, st_));
           }
         }
@@ -1796,6 +1859,7 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->use_ln_fuse = !(getenv("S2ST_NO_LN_FUSE") && atoi(getenv("S2ST_NO_LN_FUSE")) != 0);
   e->attn_gfuse_mode = getenv("S2ST_ATTN_GFUSE") ? atoi(getenv("S2ST_ATTN_GFUSE")) : 1;
   e->use_attn_gfuse = e->attn_gfuse_mode != 0;
+  if (getenv("S2ST_WGRAD_TILES")) e->group_tile_budget = atoi(getenv("S2ST_WGRAD_TILES"));
   e->ln_bwd_split = getenv("S2ST_LN_BWD_SPLIT") && atoi(getenv("S2ST_LN_BWD_SPLIT")) != 0;
   e->ordered_sums = getenv("S2ST_ORDERED_BIAS_SUMS") && atoi(getenv("S2ST_ORDERED_BIAS_SUMS")) != 0;
   e->build_params();

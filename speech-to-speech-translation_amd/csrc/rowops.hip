@@ -5,6 +5,8 @@
 // Reference call sites replaced: fairseq/modules/layer_norm.py:11-35 (F.layer_norm /
 // apex FusedLayerNorm), fairseq/modules/multihead_attention.py:343-366 (mask fill,
 // fp32 softmax, dropout) and the softmax inside F.multi_head_attention_forward (:170-192).
+#include <cstdlib>
+
 #include "s2st_ops.h"
 #include "s2st_prof.h"
 
@@ -263,37 +265,52 @@ __global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(
   float4 ag[NV], ab[NV], ad[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) ag[i] = ab[i] = ad[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // Three straight-line phases over the wave's RPW rows (no control flow between rows, so the rows' shuffle reductions
+  // interleave instead of forming one dependent chain per row): A) xhat, dy * gamma, the column sums and the two row
+  // sums' lane partials; B) the 2 * RPW wave reductions; C) dx, the fused bf16 operand, stores.  Rows past the end
+  // (clamped loads) are masked out of the column sums and not stored.
+  float s1[RPW], s2[RPW];
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
-    const int row = row0 + r;
-    if (row >= rows) break;  // wave-uniform
-    float4 xh[NV], g[NV];
-    float s1 = 0.f, s2 = 0.f;
+    const float live = row0 + r < rows ? 1.f : 0.f;
+    s1[r] = s2[r] = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c4 = lane + 64 * i;
       if (c4 < nv) {
         const float4 a = xv[r][i], d = dv[r][i];
-        xh[i].x = (a.x - mu[r]) * rs[r]; xh[i].y = (a.y - mu[r]) * rs[r];
-        xh[i].z = (a.z - mu[r]) * rs[r]; xh[i].w = (a.w - mu[r]) * rs[r];
-        g[i].x = d.x * gm[i].x; g[i].y = d.y * gm[i].y; g[i].z = d.z * gm[i].z; g[i].w = d.w * gm[i].w;
-        s1 += g[i].x + g[i].y + g[i].z + g[i].w;
-        s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
-        ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y; ag[i].z += d.z * xh[i].z; ag[i].w += d.w * xh[i].w;
-        ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+        float4 xh, g;
+        xh.x = (a.x - mu[r]) * rs[r]; xh.y = (a.y - mu[r]) * rs[r];
+        xh.z = (a.z - mu[r]) * rs[r]; xh.w = (a.w - mu[r]) * rs[r];
+        g.x = d.x * gm[i].x; g.y = d.y * gm[i].y; g.z = d.z * gm[i].z; g.w = d.w * gm[i].w;
+        s1[r] += g.x + g.y + g.z + g.w;
+        s2[r] += g.x * xh.x + g.y * xh.y + g.z * xh.z + g.w * xh.w;
+        ag[i].x += live * d.x * xh.x; ag[i].y += live * d.y * xh.y; ag[i].z += live * d.z * xh.z; ag[i].w += live * d.w * xh.w;
+        ab[i].x += live * d.x; ab[i].y += live * d.y; ab[i].z += live * d.z; ab[i].w += live * d.w;
+        xv[r][i] = xh;  // (registers reused: xv now holds xhat, dv holds dy * gamma)
+        dv[r][i] = g;
       }
     }
-    s1 = wave_sum(s1) * invc;
-    s2 = wave_sum(s2) * invc;
+  }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    s1[r] = wave_sum(s1[r]) * invc;
+    s2[r] = wave_sum(s2[r]) * invc;
+  }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int row = row0 + r;
+    const bool live = row < rows;  // wave-uniform
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c4 = lane + 64 * i;
-      if (c4 < nv) {
+      if (c4 < nv && live) {
+        const float4 xh = xv[r][i], g = dv[r][i];
         float4 o;
-        o.x = rs[r] * (g[i].x - s1 - xh[i].x * s2);
-        o.y = rs[r] * (g[i].y - s1 - xh[i].y * s2);
-        o.z = rs[r] * (g[i].z - s1 - xh[i].z * s2);
-        o.w = rs[r] * (g[i].w - s1 - xh[i].w * s2);
+        o.x = rs[r] * (g.x - s1[r] - xh.x * s2[r]);
+        o.y = rs[r] * (g.y - s1[r] - xh.y * s2[r]);
+        o.z = rs[r] * (g.z - s1[r] - xh.z * s2[r]);
+        o.w = rs[r] * (g.w - s1[r] - xh.w * s2[r]);
         if (dx_accumulate) { o.x += old[r][i].x; o.y += old[r][i].y; o.z += old[r][i].z; o.w += old[r][i].w; }
         reinterpret_cast<float4*>(dx + (long)row * cols)[c4] = o;
         if (FUSE) {
@@ -548,7 +565,12 @@ static int ln_split_blocks(int rows) {
   return b < 1 ? 1 : b;
 }
 // fused form: 4 waves x RPW rows per block; RPW = 4 while a lane holds <= 2 float4 per row (cols <= 512), else 2
-static int ln_fused_rows_per_block(int cols) { return cols <= 512 ? 16 : 8; }
+// (S2ST_LN_RPW=2, tuning aid: 2 rows per wave also for narrow rows -- twice the blocks and partial rows)
+static int ln_rpw(int cols) {
+  static const int ev = getenv("S2ST_LN_RPW") ? atoi(getenv("S2ST_LN_RPW")) : 4;
+  return (cols <= 512 && ev != 2) ? 4 : 2;
+}
+static int ln_fused_rows_per_block(int cols) { return 4 * ln_rpw(cols); }
 static int ln_fused_blocks(int rows, int cols) {
   const int rpb = ln_fused_rows_per_block(cols);
   const int b = (rows + rpb - 1) / rpb;
@@ -604,8 +626,9 @@ int s2st_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
 #define LN_FUSED(FUSE, NV, RPW)                                                                                        \
     s2st_launch("layernorm_bwd_fused_kernel<" #FUSE ">", by, 0.0, layernorm_bwd_fused_kernel<FUSE, NV, RPW>, dim3(blocks), \
                 dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, dx_accumulate, rows, cols, dph, drop_p, ik, seed, scratch)
-    if (cols <= 256) { if (dph) LN_FUSED(true, 1, 4); else LN_FUSED(false, 1, 4); }
-    else if (cols <= 512) { if (dph) LN_FUSED(true, 2, 4); else LN_FUSED(false, 2, 4); }
+    const int rpw = ln_rpw(cols);
+    if (cols <= 256) { if (rpw == 4) { if (dph) LN_FUSED(true, 1, 4); else LN_FUSED(false, 1, 4); } else { if (dph) LN_FUSED(true, 1, 2); else LN_FUSED(false, 1, 2); } }
+    else if (cols <= 512) { if (rpw == 4) { if (dph) LN_FUSED(true, 2, 4); else LN_FUSED(false, 2, 4); } else { if (dph) LN_FUSED(true, 2, 2); else LN_FUSED(false, 2, 2); } }
     else { if (dph) LN_FUSED(true, 4, 2); else LN_FUSED(false, 4, 2); }
 #undef LN_FUSED
     if (phase == 0) {

@@ -166,8 +166,16 @@ int s2st_glu_fwd(const float* a, float* y, Split ysp, int rows, int C, hipStream
 int s2st_glu_bwd(const float* a, const float* dy, Split dysp, float* da, Split dasp, int rows,
                  int C, hipStream_t st, uint16_t* dah = nullptr /* optional bf16 twin [rows][ldh] */, long ldh = 0);
 // y[r][:] = dropout(scale * x[r][:] + alpha * table[pos[r]][:])   (alpha = *alpha_ptr or 1)
+// spk_table / spk_ids (optional): + spk_table[spk_ids[row / T]] before the dropout (speaker conditioning of the encoder)
 int s2st_add_pe(const float* x, float* y, const int* pos, const float* table, int rows, int C,
-                float scale, const float* alpha_ptr, float drop_p, uint64_t seed, hipStream_t st);
+                float scale, const float* alpha_ptr, float drop_p, uint64_t seed, hipStream_t st,
+                const float* spk_table = nullptr, const long* spk_ids = nullptr, int T = 0);
+// dtable[s] += sum over utterances b with ids[b] == s of the (dropout-masked) first T_sum rows of dy's block b ([B][T][C]);
+// fixed summation order (no atomics)
+int s2st_speaker_bwd(const float* dy, const long* ids, int B, int T, int T_sum, int C, int n_spk, float drop_p,
+                     uint64_t seed, float* dtable, hipStream_t st);
+// y[b][0][:] = table[ids[b]] for y [B][T][C]
+int s2st_speaker_set_rows(const float* table, const long* ids, float* y, int B, int T, int C, hipStream_t st);
 // dalpha += sum dropmask * dy * table[pos]
 int s2st_pe_alpha_bwd(const float* dy, const int* pos, const float* table, int rows, int C,
                       float drop_p, uint64_t seed, float* dalpha, hipStream_t st);

@@ -86,12 +86,11 @@ class S2STTransformerModel(ModelBase):  # fairseq's BaseFairseqModel when fairse
         base_architecture(args)
         if getattr(args, "activation_fn", "relu") != "relu":
             raise NotImplementedError("the HIP path implements the reference default activation (relu)")
-        # speaker conditioning (s2st_transformer.py:197-208, 388-396) is not part of the HIP schedule: refuse the
-        # flags instead of silently training an unconditioned model
-        if getattr(args, "speaker_embed_dim", None) or getattr(args, "speaker_embed_dim_dec", None) or \
-                getattr(task, "speaker_to_id", None) or getattr(args, "speaker_emb_path", None):
-            raise NotImplementedError("--speaker-embed-dim* / speaker tables: speaker conditioning is not built "
-                                      "(the reference recipe run_baseline.sh does not use it)")
+        # speaker conditioning (s2st_transformer.py:203-206, 441-444; tables tasks/s2s_translation.py:153-172): on when the
+        # task was given --speaker-to-id; the engine config checks the widths
+        if getattr(args, "speaker_to_id", None) is None and getattr(task, "speaker_to_id", None) is not None:
+            import json
+            args.speaker_to_id = json.dumps(task.speaker_to_id)
         if not hasattr(args, "src_vocab_size"):
             args.src_vocab_size = len(task.source_dictionary)
             args.tgt_vocab_size = len(task.target_dictionary)
@@ -166,6 +165,18 @@ class S2STTransformerModel(ModelBase):  # fairseq's BaseFairseqModel when fairse
                           torch.zeros((), dtype=torch.long), True)
         self._num_updates = 0
         self.reset_parameters()
+        # speaker tables from the data directory's speaker_emb_filename: Embedding.from_pretrained(freeze=True)
+        # (tasks/s2s_translation.py:161-171) -- loaded, excluded from training
+        if self.engine.cfg.spk_frozen:
+            import numpy as np
+            mat = torch.from_numpy(np.load(args.speaker_emb_path)).float()
+            for n_, p_ in self.named_parameters():
+                if n_.endswith("embed_speaker.weight"):
+                    if tuple(mat.shape) != tuple(p_.shape):
+                        raise ValueError(f"{args.speaker_emb_path}: {tuple(mat.shape)} does not fit {n_} {tuple(p_.shape)}")
+                    with torch.no_grad():
+                        p_.copy_(mat)
+                    p_.requires_grad = False
 
     # -- initialisation: the reference's schemes ("Init") -----------------
     @torch.no_grad()
@@ -182,6 +193,8 @@ class S2STTransformerModel(ModelBase):  # fairseq's BaseFairseqModel when fairse
                     fan_in = self._fan_in(name)
                     bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
                     p.uniform_(-bound, bound)  # nn.Linear / nn.Conv1d default
+            elif name.endswith("embed_speaker.weight"):  # torch.nn.Embedding default (tasks/s2s_translation.py:158-160)
+                nn.init.normal_(p, mean=0, std=1.0)
             elif name == "encoder.embed_tokens.weight":  # t2s: plain nn.Embedding(padding_idx) (t2s_transformer.py:52-53)
                 nn.init.normal_(p, mean=0, std=1.0)
                 p[1].zero_()
@@ -221,9 +234,10 @@ class S2STTransformerModel(ModelBase):  # fairseq's BaseFairseqModel when fairse
         return sample["src_text"] if test_type == "asr" else sample["tgt_text"]
 
     def _run(self, src_tokens, src_lengths, prev_output_tokens, target_lengths,
-             prev_src_text_tokens=None, prev_tgt_text_tokens=None, want_attn=True):
+             prev_src_text_tokens=None, prev_tgt_text_tokens=None, want_attn=True, speaker=None):
         B, D, _ = prev_output_tokens.shape
         sample = {
+            "speaker": speaker,
             "net_input": {"src_speech": src_tokens, "src_speech_lens": src_lengths,
                           "prev_output_tokens": prev_output_tokens,
                           "prev_src_text_tokens": prev_src_text_tokens,
@@ -294,7 +308,7 @@ class S2STTransformerModel(ModelBase):  # fairseq's BaseFairseqModel when fairse
         (st_logits, None) | None]`` as s2st_transformer.py:752-786."""
         src_tokens, src_lengths = self._front_end(src_tokens, src_lengths, collated_audios, padding_mask)
         o = self._run(src_tokens, src_lengths, prev_output_tokens, kwargs["target_lengths"],
-                      kwargs.get("prev_src_text_tokens"), kwargs.get("prev_tgt_text_tokens"))
+                      kwargs.get("prev_src_text_tokens"), kwargs.get("prev_tgt_text_tokens"), speaker=kwargs.get("speaker"))
         taps = [o[k].transpose(0, 1) for k in ("tap0", "tap1") if k in o]
         extra = {"attn": o.get("attn"), "feature_out": o["feature_out"], "out_middle_layers": taps}
         asr = (o["asr_logits"], None) if "asr_logits" in o else None
@@ -306,7 +320,7 @@ class S2STTransformerModel(ModelBase):  # fairseq's BaseFairseqModel when fairse
         src_tokens, src_lengths = self._front_end(src_tokens, src_lengths, collated_audios, padding_mask)
         B = src_tokens.shape[0]
         dummy = torch.zeros(B, 1, self.engine.cfg.out_dim)
-        o = self._run(src_tokens, src_lengths, dummy, torch.ones(B, dtype=torch.long), want_attn=False)
+        o = self._run(src_tokens, src_lengths, dummy, torch.ones(B, dtype=torch.long), want_attn=False, speaker=speaker)
         lens = o["encoder_lens"].long()
         E = o["encoder_out"].shape[1]
         pad = torch.arange(E, device=lens.device).unsqueeze(0) >= lens.unsqueeze(1)

@@ -26,8 +26,8 @@ class T2STransformerModel(S2STTransformerModel):
     @classmethod
     def build_model(cls, args, task):
         t2s_architecture(args)
-        if getattr(args, "ctc_weight", 0.0) or getattr(args, "asr_ce_weight", 0.0) or getattr(args, "st_ce_weight", 0.0):
-            raise NotImplementedError("t2s_transformer: the CTC / aux heads are not built (--ctc-weight 0)")
+        if getattr(args, "asr_ce_weight", 0.0) or getattr(args, "st_ce_weight", 0.0):
+            raise ValueError("t2s_transformer has no aux ASR / ST decoders (t2s_transformer.py:279-371)")
         args.text_encoder = True
         args.src_vocab_size = len(task.source_dictionary)  # T2STransformerEncoder(args, task.src_dict, ...)
         return super().build_model(args, task)

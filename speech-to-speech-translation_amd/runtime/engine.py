@@ -24,7 +24,8 @@ class ModelConfig(C.Structure):
         "dec_heads", "enc_pre_ln", "dec_pre_ln", "in_dim", "conv_channels", "conv_k", "out_dim",
         "prenet_layers", "prenet_dim", "postnet_layers", "postnet_dim", "postnet_k", "tap_asr",
         "tap_st", "has_asr", "has_st", "has_ctc", "asr_layers", "asr_dim", "st_layers", "st_dim",
-        "src_vocab", "tgt_vocab", "no_scale_embedding", "precise", "tap_dec", "has_ctc_tgt", "text_input", "enc_conv_layers", "enc_conv_k")] + [(n, C.c_float) for n in (
+        "src_vocab", "tgt_vocab", "no_scale_embedding", "precise", "tap_dec", "has_ctc_tgt", "text_input", "enc_conv_layers", "enc_conv_k",
+        "n_speakers", "spk_frozen")] + [(n, C.c_float) for n in (
         "dropout", "attn_dropout", "act_dropout", "prenet_dropout", "postnet_dropout", "ctc_weight",
         "asr_weight", "st_weight", "w_l1", "w_mse", "w_eos", "bce_pos_weight", "label_smoothing", "ctc_tgt_weight", "enc_dropout")]
 
@@ -47,7 +48,7 @@ class Batch(C.Structure):
                 ("pe_enc", _P), ("pe_dec", _P), ("pe_asr", _P), ("pe_st", _P),
                 ("ntokens", C.c_int32), ("src_txt_ntokens", C.c_int32),
                 ("tgt_txt_ntokens", C.c_int32), ("training", C.c_int32), ("want_attn", C.c_int32),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("speaker", _P)]
 
 
 class Outputs(C.Structure):
@@ -81,7 +82,7 @@ def config_from_args(a, precise: bool = False) -> ModelConfig:
     c.out_dim = a.output_frame_dim * a.n_frames_per_step
     c.prenet_layers, c.prenet_dim = a.prenet_layers, a.prenet_dim
     c.postnet_layers, c.postnet_dim, c.postnet_k = a.postnet_layers, a.postnet_conv_dim, a.postnet_conv_kernel_size
-    c.tap_asr = mids[0] if (has_asr or has_ctc) else -1
+    c.tap_asr = mids[0] if (has_asr or (has_ctc and not getattr(a, "text_encoder", False))) else -1
     c.tap_st = mids[1] if has_st and len(mids) > 1 else -1
     c.has_asr, c.has_st, c.has_ctc = int(has_asr), int(has_st), int(has_ctc)
     c.asr_layers, c.asr_dim = a.asr_decoder_layers, a.asr_decoder_embed_dim
@@ -103,8 +104,22 @@ def config_from_args(a, precise: bool = False) -> ModelConfig:
     c.enc_conv_layers = int(getattr(a, "encoder_conv_layers", 3) or 0) if c.text_input else 0
     c.enc_conv_k = int(getattr(a, "encoder_conv_kernel_size", 5) or 5)
     c.enc_dropout = float(getattr(a, "encoder_dropout", 0.5) or 0.0) if c.text_input else 0.0
-    if c.text_input and (c.has_asr or c.has_st or c.has_ctc or c.has_ctc_tgt or c.enc_conv_k % 2 != 1):
-        raise ValueError("t2s_transformer: no aux heads / CTC heads; --encoder-conv-kernel-size must be odd")
+    # speaker conditioning: table rows = len(args.speaker_to_id) -- of the STRING the flag carries, as in the reference
+    # (tasks/s2s_translation.py:156-160) -- and widths that the additions themselves require
+    spk = getattr(a, "speaker_to_id", None)
+    c.n_speakers = len(spk) if spk is not None else 0
+    c.spk_frozen = int(c.n_speakers > 0 and getattr(a, "speaker_emb_path", None) is not None)
+    if c.n_speakers > 0:
+        if c.text_input:
+            raise NotImplementedError("speaker conditioning of the t2s text encoder is not built")
+        if getattr(a, "speaker_embed_dim", 64) != c.enc_dim:
+            raise ValueError(f"--speaker-embed-dim {getattr(a, 'speaker_embed_dim', 64)} must equal --encoder-embed-dim "
+                             f"{c.enc_dim}: the row is added to the encoder states (s2st_transformer.py:203-206)")
+        if getattr(a, "speaker_embed_dim_dec", 64) != c.out_dim:
+            raise ValueError(f"--speaker-embed-dim-dec {getattr(a, 'speaker_embed_dim_dec', 64)} must equal output_frame_dim * "
+                             f"n_frames_per_step = {c.out_dim}: the row replaces the first input frame (:441-444)")
+    if c.text_input and (c.has_asr or c.has_st or c.has_ctc_tgt or c.enc_conv_k % 2 != 1):
+        raise ValueError("t2s_transformer: no aux heads / target-text CTC head; --encoder-conv-kernel-size must be odd")
     if c.has_ctc_tgt and not (0 <= c.tap_dec < c.dec_layers):
         raise ValueError("--middle-layers-decoder must name a decoder layer (the reference would index an empty list)")
     return c
@@ -314,6 +329,15 @@ class Engine:
             b.prev_tgt_txt, b.tgt_txt_pos = keep["prev_tgt_txt"].data_ptr(), keep["tgt_txt_pos"].data_ptr()
             b.pe_st = self.pe(self.cfg.st_dim, Lt + 2).data_ptr()
         b.Ls, b.Lt = Ls, Lt
+        if self.cfg.n_speakers > 0:
+            spk = sample.get("speaker")
+            if spk is None:
+                spk = ni.get("speaker")
+            if spk is not None:  # [B, 1] ids (s2st_dataset.py:386-390)
+                keep["speaker"] = spk.reshape(-1).to(torch.int64).contiguous().to(dev)
+                if int(keep["speaker"].numel()) != B:
+                    raise ValueError("sample['speaker'] must hold one id per utterance")
+                b.speaker = keep["speaker"].data_ptr()
         b.ntokens = int(sample["ntokens"])
         b.src_txt_ntokens = int(sample.get("src_txt_ntokens", 0))
         b.tgt_txt_ntokens = int(sample.get("tgt_txt_ntokens", 0))
@@ -444,8 +468,10 @@ class Engine:
         return o
 
     # -- AR decoding (config 5): encoder once, then one decoder step per output frame -------------
-    def decode_begin(self, src: torch.Tensor, src_lens: torch.Tensor, max_steps: int) -> Dict[str, torch.Tensor]:
-        """Runs the encoder (eval mode) and fills the decoding caches for ``max_steps`` frames."""
+    def decode_begin(self, src: torch.Tensor, src_lens: torch.Tensor, max_steps: int,
+                     speaker: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """Runs the encoder (eval mode) and fills the decoding caches for ``max_steps`` frames.  ``speaker``: [B, 1] ids
+        of a speaker-conditioned model (kept for the decoding steps)."""
         dev, c = self.device, self.cfg
         src = src.to(dev, torch.float32).contiguous()
         B, S, _ = src.shape
@@ -463,6 +489,9 @@ class Engine:
         b.pe_enc = self.pe(c.enc_dim, E + 2).data_ptr()
         b.pe_dec = self.pe(c.dec_dim, max_steps + 2).data_ptr()
         b.training, b.seed = 0, 0
+        if c.n_speakers > 0 and speaker is not None:
+            keep["speaker"] = speaker.reshape(-1).to(torch.int64).contiguous().to(dev)
+            b.speaker = keep["speaker"].data_ptr()
         # workspace: the encoder forward of this geometry (planned with the full schedule: a superset)
         geo = ("enc", B, S)
         need = self._plan.get(geo)

@@ -67,7 +67,7 @@ class AutoRegressiveSpeechGenerator(SpeechGenerator):
         out_dim = c.out_dim
         raw_dim = out_dim // n_frames_per_step
         dev = eng.device
-        eng.decode_begin(src, src_lens, self.max_iter)
+        eng.decode_begin(src, src_lens, self.max_iter, speaker=sample.get("speaker"))
         feat, attn, eos_prob = [], [], []
         finished = torch.zeros(bsz, dtype=torch.bool)
         out_lens = torch.full((bsz,), self.max_iter, dtype=torch.long)

@@ -47,6 +47,8 @@ class S2ST_TranslationTask(TaskBase):  # fairseq's LegacyFairseqTask when fairse
         a("--eval-inference", action="store_true")
         a("--use-hubert", type=str, default="false")
         a("--input-text", type=str, default="false", help="text-to-speech mode (t2s_transformer): the encoder reads src_text")
+        a("--speaker-to-id", type=str, default=None, help="use speaker feature: JSON map speaker name -> id "
+                                                       "(s2s_translation.py:71)")
         a("--src-vocab-size", type=int, default=44)
         a("--tgt-vocab-size", type=int, default=74)
 
@@ -57,7 +59,12 @@ class S2ST_TranslationTask(TaskBase):  # fairseq's LegacyFairseqTask when fairse
         self.src_dict, self.tgt_dict = src_dict, tgt_dict
         self.device = device
         self.data_cfg = data_cfg
+        # s2s_translation.py:82-83: the task parses the JSON; ``args.speaker_to_id`` itself stays the STRING, and the
+        # reference sizes the embedding tables by ``len(args.speaker_to_id)`` -- the string's length (:156-160)
         self.speaker_to_id = None
+        if getattr(args, "speaker_to_id", None) is not None:
+            import json
+            self.speaker_to_id = json.loads(args.speaker_to_id) if isinstance(args.speaker_to_id, str) else dict(args.speaker_to_id)
         self.datasets: Dict[str, object] = {}
 
     @classmethod
@@ -125,10 +132,17 @@ class S2ST_TranslationTask(TaskBase):  # fairseq's LegacyFairseqTask when fairse
         return EpochBatchIterator(dataset, collate, batches, seed=seed, num_shards=num_shards, shard_id=shard_id,
                                   epoch=epoch, num_workers=num_workers)
 
+    def get_speaker_embeddings_path(self):
+        """s2s_translation.py:145-151: ``speaker_emb_filename`` of the data config, under the data directory."""
+        if self.data_cfg is not None and self.data_cfg.config.get("speaker_emb_filename") is not None:
+            return os.path.join(self.args.data, self.data_cfg.config.get("speaker_emb_filename"))
+        return None
+
     def build_model(self, args):
         """s2s_translation.py:174-184: the model, and with --eval-inference the generator validation uses."""
         from .. import models  # noqa: F401  (registers the architecture)
         args.n_frames_per_step = self.args.n_frames_per_step
+        args.speaker_emb_path = self.get_speaker_embeddings_path()  # :179
         from ..registry import ARCHS
         arch = getattr(args, "arch", None) or "s2st_transformer"  # --arch picks the registered model, as in fairseq
         model = MODELS[ARCHS[arch][0] if arch in ARCHS else "s2st_transformer"].build_model(args, self)

@@ -70,12 +70,13 @@ def test_ar_generator_against_reference_golden(backend, golden_dir):
 def test_base_size_ar_generator_against_reference_golden(backend, golden_dir, mode):
     """Config 5 at its stated size: the BASE model (12 / 6 layers, d 512, n_frames_per_step 4), 8 utterances, max_iter =
     the longest teacher length, against the reference generator's output (oracle/gen_golden_infer_base.py; the stop
-    threshold sits >= 2e-3 away from every stop probability of the reference run).
+    threshold sits >= 4e-3 away from every stop probability of the reference run).
     precise (bf16x3 GEMMs): stop indices and alignments bit-exact, features 1e-3.
     bf16 (the mode infer benchmarks run in: skinny-M GEMMs with bf16 weights and the fused pre-LayerNorm): the stop
-    indices must agree too -- each stop probability within 1.5e-3 of the reference's, inside the golden's margin -- and
-    the features within 2e-2 of the feature scale (bf16 operand rounding through 6 decoder layers x up to 110 steps of
-    feedback); alignments may differ where two encoder positions tie within rounding: at most 2 % of the frames."""
+    indices must agree too -- each stop probability within 3.5e-3 of the reference's (measured on MI355X: 2.4e-3), inside
+    the golden's margin of >= 4e-3 -- and the features within 2e-2 of the feature scale (measured 6e-3: bf16 operand
+    rounding through 6 decoder layers x up to 110 steps of feedback); alignments may differ where two encoder positions
+    tie within rounding: at most 2 % of the frames."""
     if backend.kind == "emu":
         pytest.skip("base-size decode: GPU only (110 steps of the 12 / 6-layer model)")
     z = np.load(os.path.join(golden_dir, "infer_ar_base.npz"))
@@ -94,7 +95,7 @@ def test_base_size_ar_generator_against_reference_golden(backend, golden_dir, mo
     s["net_input"]["padding_mask"] = None
     fin = gen.generate(model, s)
     backend.sync()
-    assert float(z["margin"]) >= 2e-3
+    assert float(z["margin"]) >= 4e-3
     lens, n_frames, n_align_diff = [], 0, 0
     for b in range(int(z["n"])):
         ref = z[f"feature.{b}"]
@@ -110,7 +111,7 @@ def test_base_size_ar_generator_against_reference_golden(backend, golden_dir, mo
         if mode == "precise":
             assert ferr < 1e-3 * scale and perr < 2e-4 and same, (b, ferr, perr, same)
         else:
-            assert ferr < 2e-2 * scale and perr < 1.5e-3, (b, ferr, perr)
+            assert ferr < 2e-2 * scale and perr < 3.5e-3, (b, ferr, perr)
             n_frames += ref.shape[0]
             n_align_diff += int((fin[b]["alignment"].cpu().numpy() != z[f"alignment.{b}"]).sum())
     assert len(set(lens)) > 1  # the golden batch mixes early stops and max_iter

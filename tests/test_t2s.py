@@ -113,3 +113,58 @@ def test_tiny_t2s_through_task_model_criterion_against_reference_golden(backend,
     post, eos, extra = model(s["src_text"], s["src_text_len"], s["net_input"]["prev_output_tokens"],
                              target_lengths=s["target_lengths"])
     assert post.shape == s["tgt_speech"].shape and extra["attn"].shape[0] == post.shape[0]
+
+
+# ---- the feature-level CTC head (t2s_transformer.py:168-170, 258; t2s_loss.py:134-144) --------------------------------
+def test_oracle_with_ctc_head_against_reference_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, "s2st_tiny_t2s_ctc.npz"))
+    a, m = make_oracle(dict(CONFIGS["tiny_t2s"], ctc_weight=0.3))
+    assert set(m.state_dict().keys()) == set(z["sd_names"].tolist())
+    assert tuple(m.decoder.ctc_proj.weight.shape) == (a.src_vocab_size, 320)
+    loss, ss, log, outs = O.criterion_forward(m, golden_sample("tiny", 0))
+    loss.backward()
+    for k in KEYS + ("ctc_loss",):
+        np.testing.assert_allclose(float(log[k]), float(z[f"log.{k}"]), rtol=2e-5, atol=2e-6, err_msg=k)
+    check_gradient_direction({n: p.grad for n, p in m.named_parameters() if p.grad is not None}, z, 2e-3, 5e-4, tag="tiny")
+
+
+def test_micro_text_front_with_ctc_head_against_oracle(backend):
+    D = importlib.import_module(PKG + ".data")
+    cfg = dict(MICRO, asr_ce_weight=0.0, st_ce_weight=0.0, ctc_weight=0.3, text_encoder=True, encoder_conv_layers=2,
+               encoder_conv_kernel_size=5, encoder_dropout=0.0, encoder_normalize_before=False)
+    c = D.SyntheticFisherCorpus(n_utts=4, seed=3, max_src=64, median_src=50, min_src=30)
+    s = c.collate_batch(range(4))
+    e, m = _engine_vs_oracle(backend, cfg, s, True, 3e-4, 1e-2, 3e-5)
+    assert e.cfg.has_ctc == 1 and e.cfg.tap_asr == -1
+    _, _, log, _ = O.criterion_forward(m, s)
+    o = e.forward(s, training=True, seed=1)
+    backend.sync()
+    assert float(log["ctc_loss"]) > 0
+    assert abs(float(o["stats"][20]) - float(log["ctc_loss"])) < 3e-5 * max(1.0, float(log["ctc_loss"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precise", [True, False], ids=["bf16x3", "bf16"])
+def test_tiny_t2s_with_ctc_head_against_reference_golden(backend, golden_dir, precise):
+    if backend.kind != "hip":
+        pytest.skip("tiny-size goldens run on the GPU")
+    z = np.load(os.path.join(golden_dir, "s2st_tiny_t2s_ctc.npz"))
+    tasks = importlib.import_module(PKG + ".tasks")
+    a = O.make_args(**dict(CONFIGS["tiny_t2s"], ctc_weight=0.3))
+    a.precise_gemm, a.arch, a.criterion = precise, "t2s_transformer", "t2s_loss"
+    task = tasks.S2ST_TranslationTask.setup_task(a, device=backend.device)
+    model = task.build_model(a)
+    assert set(model.state_dict().keys()) == set(z["sd_names"].tolist())
+    load_synth(model, 0)
+    crit = task.build_criterion(a)
+    model.train()
+    loss, ss, log = crit(model, golden_sample("tiny", 0))
+    model.engine.zero_grad()
+    loss.backward()
+    backend.sync()
+    ltol = 5e-5 if precise else 1e-3
+    for k in KEYS + ("ctc_loss",):
+        r = float(z[f"log.{k}"])
+        assert abs(float(log[k]) - r) < ltol * max(1.0, abs(r)), (k, float(log[k]), r)
+    grads = {n: gv for n, pv, gv, isb in model.engine.named_views() if not isb}
+    check_gradient_direction(grads, z, 1.5e-2 if precise else 1.5e-1, 5e-3 if precise else 5e-2, tag="tiny")

@@ -23,7 +23,9 @@ def per_kernel(db_path, counter):
 def main():
     fdb, wdb, cfg, out = sys.argv[1:5]
     f, w = per_kernel(fdb, "FETCH_SIZE"), per_kernel(wdb, "WRITE_SIZE")
-    res = {"config": cfg, "source": f"profiles/{out.split('/')[-1].replace('_traffic.json', '')}_fetch_size.txt, ..._write_size.txt "
+    import importlib, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    res = {"config": cfg, "source_hash": importlib.import_module("__graft_entry__").source_hash(), "source": f"profiles/{out.split('/')[-1].replace('_traffic.json', '')}_fetch_size.txt, ..._write_size.txt "
            "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py; KiB per dispatch; FETCH_SIZE x2 on gfx950)",
            "kernels": {}}
     for k in sorted(set(f) | set(w)):
