@@ -297,7 +297,8 @@ def infer_main(args):
             tot_us = sum(r["us"] for r in rows.values())
             dom_tag, dom = max(rows.items(), key=lambda kv: kv[1]["us"])
             avg_us = dom["us"] / dom["n"]
-            is_mfma = dom_tag.startswith(("gemm", "flash_")) and dom["work"] > 0
+            # (the skinny-M decode GEMM streams its weights once per launch: HBM / L2-bound, its work figure is bytes)
+            is_mfma = dom_tag.startswith(("gemm", "flash_")) and dom["work"] > 0 and dom_tag != "gemm_skinny_kernel"
             if is_mfma:
                 ach = dom["work"] / dom["n"] / (avg_us * 1e-6) / 1e12
                 roofline = {"bound": "mfma", "kernel": dom_tag, "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,

@@ -57,6 +57,10 @@ typedef struct {
   const uint16_t* mask_y;
   float mask_scale;
   float* colsum;
+  /* colsum_part != NULL: instead of atomic adds into colsum, every (row tile, wave row) writes its partial column sums
+   * to colsum_part[(2 * tile_m + wave_m) * N + n] -- 2 * ceil(M / tile rows) partial rows (the tile rows come back from
+   * s2st_gemm_f32_tile), folded in index order by the caller: run-to-run identical sums */
+  float* colsum_part;
 } s2st_gemm_epilogue;
 
 typedef struct {

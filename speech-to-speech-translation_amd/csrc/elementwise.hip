@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void pe_alpha_bwd_kernel(const float* __restri
                                                            const float* __restrict__ table,
                                                            int rows, int C, float drop_p,
                                                            uint64_t seed,
-                                                           float* __restrict__ dalpha) {
+                                                           float* __restrict__ dalpha, float* __restrict__ part) {
   __shared__ float red[4];
   long n = (long)rows * C;
   float a = 0.f;
@@ -221,7 +221,11 @@ __global__ __launch_bounds__(256) void pe_alpha_bwd_kernel(const float* __restri
   a = wave_sum(a);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(dalpha, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    const float v = red[0] + red[1] + red[2] + red[3];
+    if (part) part[blockIdx.x] = v;  // folded in block order by the caller (no atomics)
+    else atomicAdd(dalpha, v);
+  }
 }
 
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const long* __restrict__ tok,
@@ -678,13 +682,16 @@ int s2st_speaker_set_rows(const float* table, const long* ids, float* y, int B, 
 }
 
 int s2st_pe_alpha_bwd(const float* dy, const int* pos, const float* table, int rows, int C,
-                      float drop_p, uint64_t seed, float* dalpha, hipStream_t st) {
+                      float drop_p, uint64_t seed, float* dalpha, hipStream_t st, float* part, int* nparts_out) {
   long n = (long)rows * C;
+  if (nparts_out) *nparts_out = 0;
   if (n <= 0) return 0;
   unsigned g = ew_grid(n, 8);
   if (g > 1024) g = 1024;
+  if (!nparts_out) part = nullptr;
   S2ST_LAUNCH(pe_alpha_bwd_kernel, dim3(g), dim3(EW_BLOCK), 0, st, dy, pos, table, rows, C,
-                     drop_p, seed, dalpha);
+                     drop_p, seed, dalpha, part);
+  if (part) *nparts_out = (int)g;
   return LAUNCH_OK();
 }
 
@@ -696,10 +703,27 @@ int s2st_embed_fwd(const long* tokens, const float* table, float* y, int rows, i
   return LAUNCH_OK();
 }
 
+// dtable[v][c] += scale * sum over {r : tok[r] == v, v != pad} of dy[r][c], rows in index order: one thread per (v, c)
+__global__ __launch_bounds__(256) void embed_bwd_ordered_kernel(const long* __restrict__ tok, const float* __restrict__ dy,
+                                                                float* __restrict__ dtable, int rows, int C, int V,
+                                                                float scale, long pad) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int v = blockIdx.y;
+  if (c >= C || v >= V || v == pad) return;
+  float a = 0.f;
+  for (int r = 0; r < rows; ++r)
+    if (tok[r] == v) a += dy[(long)r * C + c];
+  dtable[(long)v * C + c] += scale * a;
+}
+
 int s2st_embed_bwd(const long* tokens, const float* dy, float* dtable, int rows, int C, float scale,
-                   long pad, hipStream_t st) {
+                   long pad, hipStream_t st, int V) {
   long n = (long)rows * C;
   if (n <= 0) return 0;
+  if (V > 0) {
+    S2ST_LAUNCH(embed_bwd_ordered_kernel, dim3((C + 255) / 256, V), dim3(256), 0, st, tokens, dy, dtable, rows, C, V, scale, pad);
+    return LAUNCH_OK();
+  }
   S2ST_LAUNCH(embed_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, tokens, dy, dtable, rows, C, scale, pad);
   return LAUNCH_OK();
 }
@@ -733,7 +757,9 @@ long s2st_linear_bwd_prep_scratch_floats(int M, int N, long ldp) {
 }
 
 int s2st_linear_bwd_prep(const float* dy, const float* y, const uint16_t* yb, int mode, float p, uint64_t seed,
-                         uint16_t* dph, long ldp, float* dpre, float* dbias, int M, int N, hipStream_t st, float* part) {
+                         uint16_t* dph, long ldp, float* dpre, float* dbias, int M, int N, hipStream_t st, float* part,
+                         int* slabs_out) {
+  if (slabs_out) *slabs_out = 0;
   if (M <= 0 || N <= 0) return 0;
   if (N % 4 != 0 || ldp % 4 != 0 || ldp < N || ((uintptr_t)dy % 16) || (mode == 1 && !y && !yb) ||
       (mode == 1 && y && ((uintptr_t)y % 16)) || (mode == 1 && !y && ((uintptr_t)yb % 8)))
@@ -746,6 +772,7 @@ int s2st_linear_bwd_prep(const float* dy, const float* y, const uint16_t* yb, in
   if (mode == 0) S2ST_LAUNCH(dpre_kernel<0>, grid, dim3(256), 0, st, dy, y, yb, dph, ldp, dpre, dbias, M, N, rpb, p, ik, seed, part);
   else if (mode == 1) S2ST_LAUNCH(dpre_kernel<1>, grid, dim3(256), 0, st, dy, y, yb, dph, ldp, dpre, dbias, M, N, rpb, p, ik, seed, part);
   else S2ST_LAUNCH(dpre_kernel<2>, grid, dim3(256), 0, st, dy, y, yb, dph, ldp, dpre, dbias, M, N, rpb, p, ik, seed, part);
+  if (part && slabs_out) { *slabs_out = slabs; return LAUNCH_OK(); }
   if (part) return s2st_colsum_fold(part, slabs, N, dbias, st);
   return LAUNCH_OK();
 }

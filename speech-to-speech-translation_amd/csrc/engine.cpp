@@ -159,9 +159,13 @@ struct s2st_engine {
   // trajectories of cold processes then repeat in ~85 % of runs); 0: off (fp32 gradients + cast pass).
   bool use_attn_gfuse = true;
   int attn_gfuse_mode = 1;
-  // S2ST_ORDERED_BIAS_SUMS=1: bias-gradient column sums as slab partials + a fixed-order fold instead of fp32 atomics
-  // (one more small kernel per sum: ~1 % of the step; built while chasing the reproducibility issue, did not settle it)
-  bool ordered_sums = false;
+  // Ordered sums (default since round 3; S2ST_ORDERED_BIAS_SUMS=0 restores the atomics, an A/B switch): every sum that
+  // used fp32 atomics -- bias-gradient column sums (linear backward prologue, conv biases, the masked data-gradient
+  // GEMM epilogue), embedding-row gradients, the decoder's position scale -- is formed as partial rows + a fold in index
+  // order, so a gradient is a function of (parameters, batch, seed) down to the last bit.  Round 2 had this as an
+  // option at +3 % of a step (one small fold launch per sum); the folds now ride in the segment's batched fold launch
+  // (pending_lnfold), i.e. cost no launches of their own.
+  bool ordered_sums = true;
                                // Emitting the bf16 GEMM operands from the attention backward takes 0.6 ms off the
                                // data-path stream but makes the second stream the longer one (its final join grew from
                                // 0.1 to 0.6 ms): it only pays together with wgrad_main_every below
@@ -471,12 +475,12 @@ struct s2st_engine {
   int group_flush_at = 6;  // S2ST_WGRAD_GROUP=<n>: problems per launch (<= S2ST_GROUP_MAX); measured 2 .. 8 on the bench
                            // workload: 12.25 / 10.99 / 10.56 / 10.44 / 10.46 ms per step for 2 / 3 / 4 / 6 / 8
   std::vector<GemmArgs> pending_wgrad;
-  // A grouped launch is one workgroup per 128 x 128 tile with K = tokens unsplit (~70 K-steps each): what matters is how
-  // its tile count divides by the 256 CUs.  Six products of an encoder layer and a half are 288 tiles -- a full round
-  // plus a 12 % one that takes as long (70 us per launch); cutting at <= 256 tiles makes every launch one round (the
-  // layers' products are 16 ... 64 tiles each, so the cuts land on 256 exactly).  S2ST_WGRAD_TILES=0: count products only.
+  // S2ST_WGRAD_TILES=<n> (tuning aid, default 0 = off): cut a group when its 128 x 128 tiles would exceed n.  The idea --
+  // six products of an encoder layer and a half are 288 tiles, a full round of the 256 CUs plus a 12 % one; cuts at 256
+  // make every launch one round -- measured SLOWER on the step (8.22 vs 8.11 ms, profiles/r03_c_ab_switches.txt): the
+  // group runs beside the data-path stream, which takes the CUs the short second round leaves free.
   long pending_tiles = 0;
-  int group_tile_budget = 256;
+  int group_tile_budget = 0;
   static long wgrad_tiles(const GemmArgs& g) { return (long)((g.M + 127) / 128) * ((g.N + 127) / 128); }
   void push_wgrad(const GemmArgs& g) {
     for (const GemmArgs& p : pending_wgrad)
@@ -520,6 +524,12 @@ struct s2st_engine {
       chk(s2st_layernorm_bwd_fold(pending_lnfold, s));
     }
     pending_lnfold = s2st_lnfold_table{};
+  }
+  // out[c] += sum_b part[b][c] (b in order) joins the segment's batched fold
+  void add_fold(const float* part, int nblocks, int cols, float* out) {
+    if (!part || nblocks <= 0 || cols <= 0) return;
+    if (pending_lnfold.n == S2ST_LNFOLD_MAX) flush_lnfold();
+    chk(s2st_fold_add(pending_lnfold, part, nblocks, cols, 1, out, nullptr, nullptr));
   }
 
   // ------------------------------------------------------------------------------------
@@ -590,9 +600,12 @@ struct s2st_engine {
         // (bias sums in a fixed order: a bias whose gradient is mathematically zero -- key projections -- gets pure rounding
         // noise, which must repeat from run to run)
         float* part = (b >= 0 && ordered_sums) ? alloc(s2st_linear_bwd_prep_scratch_floats(M, N, ldp)) : nullptr;
-        if (live())
+        if (live()) {
+          int slabs = 0;
           chk(s2st_linear_bwd_prep(dy, y->d, y->d ? nullptr : y->h, mode, drop_p, sd, t, ldp, nullptr,
-                                   b >= 0 ? G + b : nullptr, M, N, st_, part));
+                                   b >= 0 ? G + b : nullptr, M, N, st_, part, part ? &slabs : nullptr));
+          if (part) add_fold(part, slabs, N, G + b);
+        }
         dph = t;
         bias_done = true;
       } else {
@@ -631,7 +644,11 @@ struct s2st_engine {
           g.ws = ws_for(ws_st); g.ws_floats = skws_n;
           chk(s2st_gemm(g, ws_st));
         }
-        if (b >= 0 && !bias_done) chk(s2st_colsum(dpre, N, M, N, G + b, 1, st_, cpart));
+        if (b >= 0 && !bias_done) {
+          int slabs = 0;
+          chk(s2st_colsum(dpre, N, M, N, G + b, 1, st_, cpart, cpart ? &slabs : nullptr));
+          if (cpart) add_fold(cpart, slabs, N, G + b);
+        }
       }
       if (x->needs_grad) {
         bool acc;
@@ -639,6 +656,7 @@ struct s2st_engine {
         if (fm && !acc && x->want_gh && x->hld() == x->cols) x->gh = alloc_h(x->n());
         const bool fuse_act = fm && !acc && x->act_mode == 1 && x->h && x->hld() == x->cols && use_act_fuse;
         if (fuse_act) x->gpre_h = alloc_h(x->n());
+        float* cs_part = (fuse_act && ordered_sums && x->act_bias >= 0) ? alloc((long)2 * ((M + 63) / 64) * K) : nullptr;
         if (live()) {
           GemmArgs g{};  // dx[M][K] (+)= dpre W
           g.A = fm ? gemm_rowmajor(dph, ldp) : gemm_rowmajor(dpre, N);
@@ -656,6 +674,15 @@ struct s2st_engine {
           g.ep.accumulate = acc ? 1 : 0;
           g.ws = ws_for(st_); g.ws_floats = skws_n;
           g.M = M; g.N = K; g.K = N; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
+          if (fuse_act && g.ep.colsum && ordered_sums) {
+            // the bias gradient of the masked layer as per-(row tile, wave row) partial rows (worst case: 64-row tiles)
+            g.ep.colsum_part = cs_part;
+            int tile = 0;
+            chk(s2st_gemm(g, st_, &tile));
+            const int bm = tile / 1000;
+            if (bm > 0) add_fold(cs_part, 2 * ((M + bm - 1) / bm), K, g.ep.colsum);
+            else if (!err) err = S2ST_ERR_LAUNCH;
+          } else
           chk(s2st_gemm(g, st_));
         }
       }
@@ -994,7 +1021,11 @@ struct s2st_engine {
         g.ws = ws_for(ws_st); g.ws_floats = skws_n;
         g.M = pp.O; g.N = pp.Kw * pp.I; g.K = M; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
         chk(s2st_gemm(g, ws_st));
-        chk(s2st_colsum(z->g, pp.O, M, pp.O, G + pp.b, 1, ws_st, cpart));
+        {
+          int slabs = 0;
+          chk(s2st_colsum(z->g, pp.O, M, pp.O, G + pp.b, 1, ws_st, cpart, cpart ? &slabs : nullptr));
+          if (cpart) add_fold(cpart, slabs, pp.O, G + pp.b);
+        }
         chk(s2st_conv_w_unpermute_acc(dwf, G + pp.w, pp.O, pp.I, pp.Kw, ws_st));
       }
       if (in2.src && in2.src->needs_grad) {
@@ -1067,8 +1098,12 @@ struct s2st_engine {
       if (!y->g) return;
       if (spk && !c.spk_frozen && live())
         chk(s2st_speaker_bwd(y->g, spk_ids, Bn, T, T, x->cols, c.n_speakers, drop_p, sd, G + spk_off, st_));
-      if (alpha_off >= 0 && live())
-        chk(s2st_pe_alpha_bwd(y->g, pos, table, x->rows, x->cols, drop_p, sd, G + alpha_off, st_));
+      float* apart = (alpha_off >= 0 && ordered_sums) ? alloc(1024) : nullptr;
+      if (alpha_off >= 0 && live()) {
+        int np = 0;
+        chk(s2st_pe_alpha_bwd(y->g, pos, table, x->rows, x->cols, drop_p, sd, G + alpha_off, st_, apart, apart ? &np : nullptr));
+        if (apart) add_fold(apart, np, 1, G + alpha_off);
+      }
       if (x->needs_grad) {
         bool acc;
         float* dx = gradbuf(x, acc);
@@ -1087,9 +1122,10 @@ struct s2st_engine {
     if (live()) chk(s2st_embed_fwd(prev_tok, P + a.embed, emb->d, B * L, a.in_dim, scale, st_));
     long embed_off = a.embed;
     int in_dim = a.in_dim;
+    const int vocab = a.V;
     tape.push_back([=]() {
       if (!emb->g) return;
-      if (live()) chk(s2st_embed_bwd(prev_tok, emb->g, G + embed_off, B * L, in_dim, scale, 1, st_));
+      if (live()) chk(s2st_embed_bwd(prev_tok, emb->g, G + embed_off, B * L, in_dim, scale, 1, st_, ordered_sums ? vocab : 0));
     });
     Ten* x = emb;
     if (a.proj_in >= 0) x = linear(x, a.proj_in, -1, a.d, a.in_dim);
@@ -1549,7 +1585,7 @@ struct s2st_engine {
       const long eoff = enc_embed;
       tape.push_back([=]() {
         if (!emb->g) return;
-        if (live()) chk(s2st_embed_bwd((const long*)bt.src_txt, emb->g, G + eoff, B * E, C, 1.f, 1, st_));
+        if (live()) chk(s2st_embed_bwd((const long*)bt.src_txt, emb->g, G + eoff, B * E, C, 1.f, 1, st_, ordered_sums ? c.src_vocab : 0));
       });
       Ten* pn = text_prenet(emb, B, E, tr, cst);
       Ten* pj = linear(pn, enc_prenet_proj.w, enc_prenet_proj.b, C, C);
@@ -1861,7 +1897,7 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->use_attn_gfuse = e->attn_gfuse_mode != 0;
   if (getenv("S2ST_WGRAD_TILES")) e->group_tile_budget = atoi(getenv("S2ST_WGRAD_TILES"));
   e->ln_bwd_split = getenv("S2ST_LN_BWD_SPLIT") && atoi(getenv("S2ST_LN_BWD_SPLIT")) != 0;
-  e->ordered_sums = getenv("S2ST_ORDERED_BIAS_SUMS") && atoi(getenv("S2ST_ORDERED_BIAS_SUMS")) != 0;
+  e->ordered_sums = !(getenv("S2ST_ORDERED_BIAS_SUMS") && atoi(getenv("S2ST_ORDERED_BIAS_SUMS")) == 0);
   e->build_params();
   if (!cfg->precise && (s2st_gemm_bf16_preload(nullptr) != 0 || s2st_flash_attn_preload(nullptr) != 0)) { delete e; return S2ST_ERR_LAUNCH; }
   if (!cfg->precise && !(getenv("S2ST_NO_SIDE_STREAM") && atoi(getenv("S2ST_NO_SIDE_STREAM")))) {

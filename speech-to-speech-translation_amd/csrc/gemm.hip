@@ -339,7 +339,8 @@ long s2st_profile_report_impl(char* out, long cap, int mode) {
   return o;
 }
 
-int s2st_gemm(GemmArgs g, hipStream_t st) {
+int s2st_gemm(GemmArgs g, hipStream_t st, int* tile_out) {
+  if (tile_out) *tile_out = 0;
   if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return 0;
   if (g.A.dtype != g.B.dtype) return S2ST_ERR_ARG;
   const bool bf16_in = g.A.dtype == S2ST_BF16;
@@ -348,7 +349,9 @@ int s2st_gemm(GemmArgs g, hipStream_t st) {
   if (g.zdiv <= 0) g.zdiv = 1;
   if (bf16_in) {
     int tile = 0;
-    return s2st_gemm_bf16(g, st, &tile);
+    const int rc = s2st_gemm_bf16(g, st, &tile);
+    if (tile_out) *tile_out = tile;
+    return rc;
   }
   g.avec = vec_ok(g.A, g.M, g.K) ? 1 : 0;
   g.bvec = vec_ok(g.B, g.N, g.K) ? 1 : 0;

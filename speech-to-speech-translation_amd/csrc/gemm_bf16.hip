@@ -947,7 +947,7 @@ void mark_fast_epilogue(GemmArgs& g) {
   // the bf16 copy is stored 16 bytes (8 columns) per lane
   const bool h16 = !g.C.h || ((uintptr_t)g.C.h % 16 == 0 && g.C.sp.ld % 8 == 0 && g.C.sp.bs % 8 == 0 && g.C.zo % 8 == 0 &&
                               g.C.zi % 8 == 0 && g.N % 8 == 0);
-  if (g.cvec && g.N >= 4 && g.N % 4 == 0 && g.M >= 1 && g.splitk == 1 && !g.slab && !g.ep.mask_y && !g.ep.colsum &&
+  if (g.cvec && g.N >= 4 && g.N % 4 == 0 && g.M >= 1 && g.splitk == 1 && !g.slab && !g.ep.mask_y && !g.ep.colsum && !g.ep.colsum_part &&
       g.ep.act != 2 && combo && h16 && (g.C.p || g.C.h) && (!accu || g.C.p))
     g.cvec |= 2;
   // bit 3: the masked data-gradient form (bf16 output only, nothing else in the epilogue but the column sums)
@@ -1323,7 +1323,9 @@ int s2st_gemm_skinny(const float* A, long lda, const bf16raw* W, long ldw, float
   if (M <= 0 || N <= 0) return 0;
   if (M > 16 || K <= 0 || K % 32 || lda % 4 || ldw % 8 || ((uintptr_t)A % 16) || ((uintptr_t)W % 16)) return S2ST_ERR_SHAPE;
   if (ln_g && (!ln_b || K % 64 || ((uintptr_t)ln_g % 16) || ((uintptr_t)ln_b % 16))) return S2ST_ERR_SHAPE;
-  S2ST_LAUNCH(gemm_skinny_kernel, dim3((N + 15) / 16), dim3(256), 0, st, A, lda, reinterpret_cast<const bf16_t*>(W),
-                     ldw, C, ldc, bias, act, drop_p, seed, resid, ldr, M, N, K, ln_g, ln_b, ln_eps);
+  // bytes the launch has to move: the bf16 weight rows once, the fp32 activation rows, the result (+ residual)
+  const double by = 2.0 * N * K + 4.0 * M * K + 4.0 * M * N * (resid ? 2 : 1);
+  s2st_launch("gemm_skinny_kernel", by, 2.0 * M * N * (double)K, gemm_skinny_kernel, dim3((N + 15) / 16), dim3(256), 0, st, A, lda,
+              reinterpret_cast<const bf16_t*>(W), ldw, C, ldc, bias, act, drop_p, seed, resid, ldr, M, N, K, ln_g, ln_b, ln_eps);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }

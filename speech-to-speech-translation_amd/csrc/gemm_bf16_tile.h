@@ -333,14 +333,21 @@ __device__ __forceinline__ void gemm_epilogue_fast_masky(const GemmArgs& g, f32x
       if (ok) *reinterpret_cast<uint4*>(hbase + ro + n) = make_uint4(ax, ay, bx, by);
     }
   }
-  if (g.ep.colsum) {
+  if (g.ep.colsum || g.ep.colsum_part) {
+    // column sums over the wave's rows (the 16 lanes of a DPP row hold 16 rows of a column group): DPP row sums, then
+    // either this (row tile, wave row)'s partial row -- folded in order by the caller, no atomics -- or atomic adds
+    float* prow = g.ep.colsum_part ? g.ep.colsum_part + ((long)(m0 / BM) * 2 + wm) * N : nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
+      float t[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float t = cs[j][r];
-        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
-        if ((lane & 15) == 0 && nok[j]) atomicAdd(g.ep.colsum + ncol[j] + r, t);
+      for (int r = 0; r < 4; ++r) t[r] = row16_sum(cs[j][r]);
+      if ((lane & 15) == 0 && nok[j]) {
+        if (prow) *reinterpret_cast<float4*>(prow + ncol[j]) = make_float4(t[0], t[1], t[2], t[3]);
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomicAdd(g.ep.colsum + ncol[j] + r, t[r]);
+        }
       }
     }
   }
@@ -494,15 +501,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
       }
     }
   }
-  if (g.ep.colsum && ybase) {
+  if ((g.ep.colsum || g.ep.colsum_part) && ybase) {
+    float* prow = g.ep.colsum_part ? g.ep.colsum_part + ((long)(m0 / BM) * 2 + wm) * g.N : nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * WN + j * 16 + (lane >> 4) * 4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float t = cs[j][r];
-        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
-        if ((lane & 15) == 0 && n + r < g.N) atomicAdd(g.ep.colsum + n + r, t);
+        const float t = row16_sum(cs[j][r]);
+        if ((lane & 15) == 0 && n + r < g.N) {
+          if (prow) prow[n + r] = t;
+          else atomicAdd(g.ep.colsum + n + r, t);
+        }
       }
     }
   }

@@ -134,19 +134,32 @@ __device__ __forceinline__ float lse3(float a, float b, float c) {
   return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
 }
 
-// One workgroup per utterance.  logits [B][E][V]; lp (log-softmax) [B][E][V];
-// alpha workspace [B][E][S_stride].
+// One workgroup per utterance.  logits [B][E][V]; lp (log-softmax) [B][E][V]; workspace alpha | beta, [B][E][ss] each.
+//
+// Round 3 structure (round 2: alpha sweep, then beta sweep with LDS-atomic occupancies and the gradient row inside the
+// sweep -- 2 T sequential steps of 2 - 3 barriers each: 0.3 - 0.6 ms with 40 - 180 of the 256 CUs busy):
+//   1. log-softmax of every frame (4 waves over the frames);
+//   2. alpha AND beta recursions in the SAME loop -- threads 0..127 step alpha forward (t = k) while threads 128..255
+//      step beta backward (t = T - 1 - k): T steps of one barrier; both keep their rows in HBM;
+//   3. the gradient, parallel over frames (one wave per frame): e[s] = exp(alpha_t(s) + beta_t(s) - lp_t(ext s) - ll)
+//      for all states at once into LDS, then lane v adds the e[s] of ITS label's states in state order (a CSR list built
+//      once per utterance) -- no atomics: the occupancies, hence the logits' gradient, repeat bit for bit.
 __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logits,
                                                   const long* __restrict__ targets, int Lmax,
                                                   const int* __restrict__ in_lens,
                                                   const int* __restrict__ tgt_lens, int E, int V,
                                                   float* __restrict__ lp_all,
-                                                  float* __restrict__ alpha_all, int s_stride,
+                                                  float* __restrict__ ws_all, int s_stride,
                                                   float* __restrict__ loss_out,
                                                   float* __restrict__ dlogits, float gscale) {
-  __shared__ float prev[2][CTC_MAXS];
-  __shared__ float occ[CTC_MAXV];
-  __shared__ int ext[CTC_MAXS];
+  HIP_DYNAMIC_SHARED(unsigned char, smem_raw)
+  const int ss = s_stride;
+  float* pA = reinterpret_cast<float*>(smem_raw);          // [2][ss] alpha rows
+  float* pB = pA + 2 * ss;                                  // [2][ss] beta rows
+  float* erow = pB + 2 * ss;                                // [4][ss] per-wave occupancy terms
+  int* ext = reinterpret_cast<int*>(erow + 4 * ss);         // [ss] extended label sequence
+  int* start = ext + ss;                                    // [V + 1] CSR: states of label v = idx[start[v] .. start[v+1])
+  unsigned short* idx = reinterpret_cast<unsigned short*>(start + V + 1);  // [ss]
   __shared__ float llsh;
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -155,7 +168,8 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
   const int S = 2 * L + 1;
   const float* x = logits + (long)b * E * V;
   float* lp = lp_all + (long)b * E * V;
-  float* alpha = alpha_all + (long)b * E * s_stride;
+  float* alpha = ws_all + (long)b * 2 * E * ss;
+  float* beta = alpha + (long)E * ss;
   float* dl = dlogits ? dlogits + (long)b * E * V : nullptr;
 
   // 1) log-softmax of every frame (also the get_normalized_probs output)
@@ -171,37 +185,83 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
     for (int c = lane; c < V; c += 64) lp[(long)t * V + c] = xr[c] - lse;
   }
   for (int s = tid; s < S; s += 256) ext[s] = (s & 1) ? (int)targets[(long)b * Lmax + (s >> 1)] : 0;
-  for (int v = tid; v < V; v += 256) occ[v] = 0.f;
   __syncthreads();
+  if (dl) {  // CSR of the states per label: counts, offsets (one thread: V <= 512), then each label lists its states in order
+    for (int v = tid; v < V; v += 256) {
+      int n = 0;
+      for (int s = 0; s < S; ++s) n += ext[s] == v ? 1 : 0;
+      start[v + 1] = n;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      start[0] = 0;
+      for (int v = 0; v < V; ++v) start[v + 1] += start[v];
+    }
+    __syncthreads();
+    for (int v = tid; v < V; v += 256) {
+      int q = start[v];
+      for (int s = 0; s < S; ++s)
+        if (ext[s] == v) idx[q++] = (unsigned short)s;
+    }
+  }
 
-  // 2) alpha recursion (previous row in LDS, every row also kept in HBM for step 4)
+  // 2) alpha (threads 0 .. 127, forward in time) and beta (threads 128 .. 255, backward) in one loop
+  const bool isA = tid < 128;
+  const int lt = isA ? tid : tid - 128;
   if (Tb > 0) {
-    for (int s = tid; s < S; s += 256) {
-      float a = s < 2 ? lp[ext[s]] : CTC_NEG;
-      prev[0][s] = a;
-      alpha[s] = a;
+    if (isA) {
+      for (int s = lt; s < S; s += 128) {
+        const float a = s < 2 ? lp[ext[s]] : CTC_NEG;
+        pA[s] = a;
+        alpha[s] = a;
+      }
+    } else {
+      const float* lpt = lp + (long)(Tb - 1) * V;
+      float* cu = pB + ((Tb - 1) & 1) * ss;
+      for (int s = lt; s < S; s += 128) {
+        const float bt = (s >= S - 2) ? lpt[ext[s]] : CTC_NEG;
+        cu[s] = bt;
+        beta[(long)(Tb - 1) * ss + s] = bt;
+      }
     }
   }
   __syncthreads();
-  for (int t = 1; t < Tb; ++t) {
-    const float* pr = prev[(t - 1) & 1];
-    float* cu = prev[t & 1];
-    const float* lpt = lp + (long)t * V;
-    for (int s = tid; s < S; s += 256) {
-      float a0 = pr[s];
-      float a1 = s >= 1 ? pr[s - 1] : CTC_NEG;
-      float a2 = (s >= 2 && (s & 1) && ext[s] != ext[s - 2]) ? pr[s - 2] : CTC_NEG;
-      float a = lse3(a0, a1, a2);
-      a = a < -1.0e29f ? CTC_NEG : a + lpt[ext[s]];
-      cu[s] = a;
-      alpha[(long)t * s_stride + s] = a;
+  for (int k = 1; k < Tb; ++k) {
+    if (isA) {
+      const int t = k;
+      const float* pr = pA + ((t - 1) & 1) * ss;
+      float* cu = pA + (t & 1) * ss;
+      const float* lpt = lp + (long)t * V;
+      for (int s = lt; s < S; s += 128) {
+        const float a0 = pr[s];
+        const float a1 = s >= 1 ? pr[s - 1] : CTC_NEG;
+        const float a2 = (s >= 2 && (s & 1) && ext[s] != ext[s - 2]) ? pr[s - 2] : CTC_NEG;
+        float a = lse3(a0, a1, a2);
+        a = a < -1.0e29f ? CTC_NEG : a + lpt[ext[s]];
+        cu[s] = a;
+        alpha[(long)t * ss + s] = a;
+      }
+    } else {
+      const int t = Tb - 1 - k;
+      const float* nx = pB + ((t + 1) & 1) * ss;
+      float* cu = pB + (t & 1) * ss;
+      const float* lpt = lp + (long)t * V;
+      for (int s = lt; s < S; s += 128) {
+        const float b0 = nx[s];
+        const float b1 = s + 1 < S ? nx[s + 1] : CTC_NEG;
+        const float b2 = (s + 2 < S && ((s + 2) & 1) && ext[s + 2] != ext[s]) ? nx[s + 2] : CTC_NEG;
+        float bt = lse3(b0, b1, b2);
+        bt = bt < -1.0e29f ? CTC_NEG : bt + lpt[ext[s]];
+        cu[s] = bt;
+        beta[(long)t * ss + s] = bt;
+      }
     }
     __syncthreads();
   }
   if (tid == 0) {
     float ll = CTC_NEG;
     if (Tb > 0) {
-      const float* last = prev[(Tb - 1) & 1];
+      const float* last = pA + ((Tb - 1) & 1) * ss;
       ll = lse3(last[S - 1], S >= 2 ? last[S - 2] : CTC_NEG, CTC_NEG);
     }
     llsh = ll;
@@ -220,30 +280,25 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
   }
   if (!feasible || Tb <= 0) return;
 
-  // 3+4) beta recursion fused with the occupancy accumulation and the gradient
-  for (int t = Tb - 1; t >= 0; --t) {
-    float* cu = prev[t & 1];
-    const float* nx = prev[(t + 1) & 1];
-    const float* lpt = lp + (long)t * V;
-    for (int s = tid; s < S; s += 256) {
-      float bt;
-      if (t == Tb - 1) {
-        bt = (s >= S - 2) ? lpt[ext[s]] : CTC_NEG;
-      } else {
-        float b0 = nx[s];
-        float b1 = s + 1 < S ? nx[s + 1] : CTC_NEG;
-        float b2 = (s + 2 < S && ((s + 2) & 1) && ext[s + 2] != ext[s]) ? nx[s + 2] : CTC_NEG;
-        bt = lse3(b0, b1, b2);
-        bt = bt < -1.0e29f ? CTC_NEG : bt + lpt[ext[s]];
+  // 3) gradient rows, one wave per frame (the loop is uniform over the workgroup: barriers inside)
+  float* er = erow + wave * ss;
+  for (int t0 = 0; t0 < Tb; t0 += 4) {
+    const int t = t0 + wave;
+    const bool on = t < Tb;
+    const float* lpt = lp + (long)(on ? t : 0) * V;
+    if (on) {
+      for (int s = lane; s < S; s += 64) {
+        const float al = alpha[(long)t * ss + s], be = beta[(long)t * ss + s];
+        er[s] = (al > -1.0e29f && be > -1.0e29f) ? expf(al + be - lpt[ext[s]] - ll) : 0.f;
       }
-      cu[s] = bt;
-      float al = alpha[(long)t * s_stride + s];
-      if (al > -1.0e29f && bt > -1.0e29f) atomicAdd(&occ[ext[s]], expf(al + bt - lpt[ext[s]] - ll));
     }
     __syncthreads();
-    for (int v = tid; v < V; v += 256) {
-      dl[(long)t * V + v] = sc * (expf(lpt[v]) - occ[v]);
-      occ[v] = 0.f;
+    if (on) {
+      for (int v = lane; v < V; v += 64) {
+        float o = 0.f;
+        for (int q = start[v]; q < start[v + 1]; ++q) o += er[idx[q]];
+        dl[(long)t * V + v] = sc * (expf(lpt[v]) - o);
+      }
     }
     __syncthreads();
   }
@@ -339,7 +394,7 @@ int s2st_ls_ce(const float* logits, const long* target, int rows, int V, long pa
 
 long s2st_ctc_workspace_floats(int B, int E, int Lmax) {
   long ss = ((2L * Lmax + 1 + 3) / 4) * 4;
-  return (long)B * E * ss;
+  return 2L * B * E * ss;  // alpha and beta rows
 }
 
 int s2st_ctc(const float* logits, const long* targets, int Lmax, const int* in_lens,
@@ -348,7 +403,17 @@ int s2st_ctc(const float* logits, const long* targets, int Lmax, const int* in_l
   if (B <= 0) return 0;
   if (2 * Lmax + 1 > CTC_MAXS || V > CTC_MAXV) return S2ST_ERR_SHAPE;
   int ss = ((2 * Lmax + 1 + 3) / 4) * 4;
-  S2ST_LAUNCH(ctc_kernel, dim3(B), dim3(256), 0, st, logits, targets, Lmax, in_lens, tgt_lens,
+  // LDS: alpha / beta row pairs, four per-wave term rows, the extended labels, the per-label state lists
+  const unsigned lds = (unsigned)(ss * (8 * 4 + 4 + 2) + (V + 1) * 4 + 16);
+  if (lds > 64 * 1024) {
+    static bool configured = false;
+    if (!configured) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess)
+        return S2ST_ERR_LAUNCH;
+      configured = true;
+    }
+  }
+  S2ST_LAUNCH(ctc_kernel, dim3(B), dim3(256), lds, st, logits, targets, Lmax, in_lens, tgt_lens,
                      E, V, lprobs, ws, ss, loss_per_utt, dlogits, gscale);
   return LAUNCH_OK();
 }

@@ -708,13 +708,15 @@ int s2st_colsum_fold(const float* part, int slabs, int cols, float* out, hipStre
 
 // part (s2st_colsum_scratch_floats floats) != null: fixed-order sums (slab partials + fold) instead of fp32 atomics
 int s2st_colsum(const float* x, long ld, int rows, int cols, float* out, int accumulate,
-                hipStream_t st, float* part) {
+                hipStream_t st, float* part, int* slabs_out) {
+  if (slabs_out) *slabs_out = 0;
   if (cols <= 0) return 0;
   if (!accumulate) hipMemsetAsync(out, 0, sizeof(float) * cols, st);
   if (rows <= 0) return 0;
   int cb, slabs, rpb;
   colsum_geometry(rows, cols, cb, slabs, rpb);
   S2ST_LAUNCH(colsum_kernel, dim3(cb, slabs), dim3(256), 0, st, x, ld, rows, cols, out, rpb, part);
+  if (part && slabs_out) { *slabs_out = slabs; return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH; }
   if (part) return s2st_colsum_fold(part, slabs, cols, out, st);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }

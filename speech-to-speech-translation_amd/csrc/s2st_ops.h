@@ -47,7 +47,7 @@ inline GemmEpilogue gemm_epi_default() {
   GemmEpilogue e;
   e.alpha = 1.f; e.bias = nullptr; e.act = 0; e.drop_p = 0.f; e.seed = 0; e.resid = nullptr;
   e.accumulate = 0;
-  e.mask_y = nullptr; e.mask_scale = 1.f; e.colsum = nullptr;
+  e.mask_y = nullptr; e.mask_scale = 1.f; e.colsum = nullptr; e.colsum_part = nullptr;
   return e;
 }
 
@@ -76,7 +76,7 @@ void s2st_gemm_streamk_unbind_all();
 // true if g can join a group (aligned bf16 operands, plain strides, batch 1, >= 128 x 128 of output)
 bool s2st_gemm_group_ok(const GemmArgs& g);
 int s2st_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t st);
-int s2st_gemm(GemmArgs g, hipStream_t st);
+int s2st_gemm(GemmArgs g, hipStream_t st, int* tile_out = nullptr /* bf16 path: tile rows * 1000 + tile columns */);
 int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* tile_out);
 // skinny-M (<= 16 rows) y = f(x W^T + b) (+ resid) with fp32 x converted in registers (AR decoding)
 int s2st_gemm_skinny(const float* A, long lda, const bf16raw* W, long ldw, float* C, long ldc, const float* bias, int act,
@@ -128,7 +128,8 @@ int s2st_softmax_bwd(const float* p, const float* dpd, float* ds, int B, int H, 
 
 // column sums: out[c] (+)= sum_r x[r][c]   (bias gradients)
 int s2st_colsum(const float* x, long ld, int rows, int cols, float* out, int accumulate,
-                hipStream_t st, float* part = nullptr /* fixed-order sums through this scratch (s2st_colsum_scratch_floats) */);
+                hipStream_t st, float* part = nullptr /* fixed-order sums through this scratch (s2st_colsum_scratch_floats) */,
+                int* slabs_out = nullptr /* with part: leave the fold to the caller (s2st_fold_add), return the partial rows */);
 long s2st_colsum_scratch_floats(int rows, int cols);
 int s2st_colsum_fold(const float* part, int slabs, int cols, float* out, hipStream_t st);  // out[c] += sum_s part[s][c], in order
 // out[c] += sum_r x[r][c] for a bf16 matrix (bias gradients of projections whose output gradient only exists in bf16)
@@ -178,11 +179,14 @@ int s2st_speaker_bwd(const float* dy, const long* ids, int B, int T, int T_sum, 
 int s2st_speaker_set_rows(const float* table, const long* ids, float* y, int B, int T, int C, hipStream_t st);
 // dalpha += sum dropmask * dy * table[pos]
 int s2st_pe_alpha_bwd(const float* dy, const int* pos, const float* table, int rows, int C,
-                      float drop_p, uint64_t seed, float* dalpha, hipStream_t st);
+                      float drop_p, uint64_t seed, float* dalpha, hipStream_t st,
+                      float* part = nullptr /* per-block partial sums instead of an atomic add (<= 1024 floats) */,
+                      int* nparts_out = nullptr);
 int s2st_embed_fwd(const long* tokens, const float* table, float* y, int rows, int C, float scale,
                    hipStream_t st);
 int s2st_embed_bwd(const long* tokens, const float* dy, float* dtable, int rows, int C, float scale,
-                   long pad, hipStream_t st);
+                   long pad, hipStream_t st, int V = 0 /* > 0: ordered form -- one thread per (table row, column) adds the
+                   matching rows of dy in index order: no atomics */);
 // y (+)= a * x * dropmask(p, seed)   (p == 0: plain scaled copy / accumulate)
 int s2st_dropout(const float* x, float* y, long n, float a, float p, uint64_t seed, int accumulate,
                  hipStream_t st);
@@ -194,7 +198,8 @@ int s2st_relu_drop_bwd(const float* dy, const float* y, float* dz, long n, float
 // 1: ReLU+dropout backward from the layer OUTPUT y ; 2: dropout(seed) backward.  N % 4 == 0.
 int s2st_linear_bwd_prep(const float* dy, const float* y, const uint16_t* yb /* bf16 y when y == null */, int mode,
                          float p, uint64_t seed, uint16_t* dph, long ldp, float* dpre, float* dbias, int M, int N,
-                         hipStream_t st, float* part = nullptr /* bias sums in a fixed order: s2st_linear_bwd_prep_scratch_floats */);
+                         hipStream_t st, float* part = nullptr /* bias sums in a fixed order: s2st_linear_bwd_prep_scratch_floats */,
+                         int* slabs_out = nullptr /* with part: leave the fold to the caller, return the partial rows */);
 long s2st_linear_bwd_prep_scratch_floats(int M, int N, long ldp);
 int s2st_axpy(const float* x, float* y, long n, float a, hipStream_t st);  // y += a * x
 int s2st_scale(float* x, long n, float a, hipStream_t st);

@@ -37,7 +37,8 @@ class GemmOut(C.Structure):
 class GemmEpilogue(C.Structure):
     _fields_ = [("alpha", C.c_float), ("act", C.c_int32), ("bias", C.c_void_p),
                 ("drop_p", C.c_float), ("accumulate", C.c_int32), ("seed", C.c_uint64),
-                ("resid", C.c_void_p), ("mask_y", C.c_void_p), ("mask_scale", C.c_float), ("colsum", C.c_void_p)]
+                ("resid", C.c_void_p), ("mask_y", C.c_void_p), ("mask_scale", C.c_float), ("colsum", C.c_void_p),
+                ("colsum_part", C.c_void_p)]
 
 
 class GemmArgs(C.Structure):

@@ -60,8 +60,8 @@ def _grad_close(g, ref, tol):
 
 def test_step_is_a_function_of_the_seed(backend, workload):
     """Same seed -> the same step: the forward sweep (every output and logged loss) is bit-identical -- all
-    of its reductions, BatchNorm statistics included, are fixed-order; the gradients agree to the fp32
-    rounding of the few leaf sums that use atomics (bias and embedding gradients)."""
+    of its reductions, BatchNorm statistics included, are fixed-order; so is every sum of the backward: the gradient
+    arena is bit-identical too (only the LOGGED loss sums still use atomics: last-bit noise in the printed numbers)."""
     _need_gpu(backend)
     corpus, b = workload
     a, e = _engine(backend, CONFIGS["base_recipe"])
@@ -82,7 +82,10 @@ def test_step_is_a_function_of_the_seed(backend, workload):
     for k, i in LOSS_KEYS:
         # (loss sums are folded with fp32 atomics: last-bit order noise, observed up to 1.1e-6 relative)
         assert abs(float(o0["stats"][i]) - float(o1["stats"][i])) <= 3e-6 * max(1.0, abs(float(o0["stats"][i]))), k
-    assert _rel(g1, g0) <= 1e-6, _rel(g1, g0)
+    # round 3: no sum of the backward uses atomics any more (bias / embedding / position-scale gradients, CTC occupancies,
+    # attention bias partials, layer-norm parameter partials are all folded in a fixed order): the whole gradient arena
+    # repeats BIT FOR BIT
+    assert torch.equal(g1, g0), (_rel(g1, g0), int((g1 != g0).sum()))
     assert not _grad_close(g2, g0, 5e-2)
 
 

@@ -338,6 +338,37 @@ def test_ctc(backend):
     assert torch.equal(lpo.argmax(-1).cpu(), lp.transpose(0, 1).argmax(-1))
 
 
+def test_ctc_long_labels_and_repeatability(backend):
+    """More than 128 extended states (the alpha / beta halves of the workgroup then walk the states in two strides), a
+    vocabulary beyond one wave, and the same launch twice: the gradient comes out of ordered per-label sums (no atomics),
+    so it repeats bit for bit."""
+    torch.manual_seed(1)
+    B, E, V, Lmax = 3, 170, 70, 72
+    logits = torch.randn(B, E, V)
+    tl = torch.tensor([72, 65, 2], dtype=torch.int32)
+    il = torch.tensor([170, 160, 5], dtype=torch.int32)
+    tg = torch.randint(1, V, (B, Lmax))
+    lr = logits.clone().requires_grad_()
+    lp = F.log_softmax(lr, -1).transpose(0, 1)
+    flat = torch.cat([tg[b, :tl[b]] for b in range(B)])
+    ref = F.ctc_loss(lp, flat, il.long(), tl.long(), reduction="mean", zero_infinity=True)
+    ref.backward()
+    ld_, tgd, ild, tld = dev(backend, logits, tg, il, tl)
+    nws = backend.bd._bind("s2st_ctc_workspace")(B, E, Lmax)
+    outs = []
+    for _ in range(2):
+        lpo = torch.zeros(B, E, V, device=backend.device)
+        per = torch.zeros(B, device=backend.device)
+        dl = torch.full((B, E, V), 7.0, device=backend.device)
+        ws = torch.zeros(nws, device=backend.device)
+        backend.bd.call("s2st_ctc_f32", ld_, tgd, Lmax, ild, tld, B, E, V, lpo, per, dl, 1.0 / B, ws)
+        backend.sync()
+        outs.append((per.clone(), dl.clone()))
+    close(outs[0][0].mean(), ref, 2e-5, 1e-6)
+    close(outs[0][1], lr.grad, 5e-4, 5e-6)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("parts", [False, True], ids=["scalar_sumsq", "partial_sums"])
 def test_sumsq_adam(backend, parts):
     """parts: the gradient norm as per-block partial sums folded in index order inside the Adam kernel (no atomics:
