@@ -218,8 +218,10 @@ int64_t s2st_sumsq_parts_count(int64_t n);
  * s2st_engine_bind_bf16 / s2st_engine_bf16_is_fresh).  skipped (optional, device int32): incremented when the
  * gradient norm is non-finite; parameters, moments and gradients are then left untouched (the reference raises
  * FloatingPointError at trainer.py:860-867 -- the host reads this counter at its logging interval and does the same).
- * sumsq_parts: 0 = sumsq is one float; > 0 = sumsq holds that many partial sums (s2st_sumsq_parts_f32) */
-int s2st_adam_f32(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float gmul, const float* gmul_dev, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int32_t step, float* gnorm_out, void* p_bf16, int32_t* skipped, int32_t sumsq_parts, void* stream);
+ * sumsq_parts: 0 = sumsq is one float; > 0 = sumsq holds that many partial sums (s2st_sumsq_parts_f32).
+ * zero_grad: 0 = g holds the scaled and clipped gradient afterwards; 1 = g is left all zero, also when the update is
+ * skipped (the write the kernel makes anyway: the next step's zero_grad() pass over the arena is not needed) */
+int s2st_adam_f32(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float gmul, const float* gmul_dev, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int32_t step, float* gnorm_out, void* p_bf16, int32_t* skipped, int32_t sumsq_parts, int32_t zero_grad, void* stream);
 
 /* floats of workspace s2st_ctc_f32 needs */
 int64_t s2st_ctc_workspace(int32_t B, int32_t E, int32_t Lmax);

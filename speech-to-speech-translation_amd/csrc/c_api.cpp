@@ -116,8 +116,8 @@ int s2st_sumsq_f32(const float* x, int64_t n, float* out, void* stream) {
   return s2st_sumsq(x, n, out, (hipStream_t)stream);
 }
 
-int s2st_adam_f32(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float gmul, const float* gmul_dev, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int32_t step, float* gnorm_out, void* p_bf16, int32_t* skipped, int32_t sumsq_parts, void* stream) {
-  return s2st_adam(p, g, m, v, n, sumsq, gmul, gmul_dev, max_norm, lr, beta1, beta2, eps, wd, step, gnorm_out, (hipStream_t)stream, (uint16_t*)p_bf16, skipped, sumsq_parts);
+int s2st_adam_f32(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float gmul, const float* gmul_dev, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int32_t step, float* gnorm_out, void* p_bf16, int32_t* skipped, int32_t sumsq_parts, int32_t zero_grad, void* stream) {
+  return s2st_adam(p, g, m, v, n, sumsq, gmul, gmul_dev, max_norm, lr, beta1, beta2, eps, wd, step, gnorm_out, (hipStream_t)stream, (uint16_t*)p_bf16, skipped, sumsq_parts, zero_grad);
 }
 
 int64_t s2st_layernorm_bwd_scratch(int32_t rows, int32_t cols) { return (int64_t)s2st_layernorm_bwd_blocks(rows, cols) * 2 * cols; }

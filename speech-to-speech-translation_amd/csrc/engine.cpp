@@ -1416,7 +1416,7 @@ struct s2st_engine {
     if (N < hc.conv_k[0] || Tin <= 0) return S2ST_ERR_SHAPE;
     // fast mode: conv1 only reads the bf16 copy, no fp32 activation is allocated or written
     Ten* a = newT(B * Tin, C0, nullptr, !fm);
-    float* stats = alloc(2 * (long)B * C0);
+    float* stats = alloc(s2st_hubert_conv0_stats_floats(B, Tin, C0));
     if (fm) a->h = alloc_h(a->n());
     if (live())
       chk(s2st_hubert_conv0_gn_gelu(wave, P + hp.conv_w[0], P + hp.gn_g, P + hp.gn_b, a->d, a->h, stats, B, N, Tin, C0,

@@ -25,6 +25,7 @@ constexpr int C0_TT = 128, CONV0_MAXK = 16, CONV0_CPT = 2;  // frames per block,
 template <int MODE>
 __global__ __launch_bounds__(256) void hubert_conv0_gn_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               float* __restrict__ csum, float* __restrict__ sq,
+                                                              float* __restrict__ part,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* __restrict__ y,
                                                               uint16_t* __restrict__ yh, int B, int N, int T, int C,
@@ -79,12 +80,22 @@ __global__ __launch_bounds__(256) void hubert_conv0_gn_kernel(const float* __res
         if (yh) *reinterpret_cast<unsigned*>(yh + o) = pack_bf16x4(o0, o1, 0.f, 0.f).x;
       }
     }
-    if (MODE < 2) {
-      float* dst = MODE == 0 ? csum : sq;
+    if (MODE < 2) {  // this block's share of the time sums: a plain store, folded in block order by conv0_fold_kernel
 #pragma unroll
-      for (int e = 0; e < CONV0_CPT; ++e) atomicAdd(dst + (long)b * C + c0 + e, acc[e]);
+      for (int e = 0; e < CONV0_CPT; ++e) part[((long)b * gridDim.x + blockIdx.x) * C + c0 + e] = acc[e];
     }
   }
+}
+
+// out[b][c] = sum over the nblk time blocks of part[b][blk][c], in block order (the same bits every run)
+__global__ __launch_bounds__(256) void conv0_fold_kernel(const float* __restrict__ part, float* __restrict__ out, int B,
+                                                         int nblk, int C) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i - b * C;
+  float s = 0.f;
+  for (int k = 0; k < nblk; ++k) s += part[((long)b * nblk + k) * C + c];
+  out[i] = s;
 }
 
 // x[b][t][:] = 0 for t >= lens[b] (in place), and the group-major, time-padded image
@@ -109,21 +120,26 @@ __global__ __launch_bounds__(256) void posconv_prep_kernel(float* __restrict__ x
 
 }  // namespace
 
-// conv0 -> GroupNorm(C, C) over time -> GELU (see the kernel).  stats: scratch of 2 * B * C floats; y (fp32) and yh
+long s2st_hubert_conv0_stats_floats(int B, int T, int C) { return (2 + (long)((T + C0_TT - 1) / C0_TT)) * B * C; }
+
+// conv0 -> GroupNorm(C, C) over time -> GELU (see the kernel).  stats: scratch of s2st_hubert_conv0_stats_floats(B, T, C)
+// floats (the two statistics + one partial row per time block: no atomics, nothing to zero); y (fp32) and yh
 // (bf16), each optional, receive the [B][T][C] result.
 int s2st_hubert_conv0_gn_gelu(const float* x, const float* w, const float* gamma, const float* beta, float* y,
                               uint16_t* yh, float* stats, int B, int N, int T, int C, int k, int stride, float eps,
                               hipStream_t st) {
   if (C % (2 * CONV0_CPT) || k > CONV0_MAXK || stride > 8 || stride < 1) return S2ST_ERR_SHAPE;
   if (B <= 0 || T <= 0) return 0;
-  float *csum = stats, *sq = stats + (long)B * C;
-  hipMemsetAsync(stats, 0, sizeof(float) * 2 * (size_t)B * C, st);
-  const dim3 grid((T + C0_TT - 1) / C0_TT, B);
-  S2ST_LAUNCH(hubert_conv0_gn_kernel<0>, grid, dim3(256), 0, st, x, w, csum, sq, gamma, beta, y, yh, B, N, T, C,
+  float *csum = stats, *sq = stats + (long)B * C, *part = stats + 2 * (long)B * C;
+  const int nblk = (T + C0_TT - 1) / C0_TT;
+  const dim3 grid(nblk, B), fgrid((B * C + 255) / 256);
+  S2ST_LAUNCH(hubert_conv0_gn_kernel<0>, grid, dim3(256), 0, st, x, w, csum, sq, part, gamma, beta, y, yh, B, N, T, C,
                      k, stride, eps);
-  S2ST_LAUNCH(hubert_conv0_gn_kernel<1>, grid, dim3(256), 0, st, x, w, csum, sq, gamma, beta, y, yh, B, N, T, C,
+  S2ST_LAUNCH(conv0_fold_kernel, fgrid, dim3(256), 0, st, part, csum, B, nblk, C);
+  S2ST_LAUNCH(hubert_conv0_gn_kernel<1>, grid, dim3(256), 0, st, x, w, csum, sq, part, gamma, beta, y, yh, B, N, T, C,
                      k, stride, eps);
-  S2ST_LAUNCH(hubert_conv0_gn_kernel<2>, grid, dim3(256), 0, st, x, w, csum, sq, gamma, beta, y, yh, B, N, T, C,
+  S2ST_LAUNCH(conv0_fold_kernel, fgrid, dim3(256), 0, st, part, sq, B, nblk, C);
+  S2ST_LAUNCH(hubert_conv0_gn_kernel<2>, grid, dim3(256), 0, st, x, w, csum, sq, part, gamma, beta, y, yh, B, N, T, C,
                      k, stride, eps);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }

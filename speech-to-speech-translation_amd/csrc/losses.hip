@@ -134,155 +134,168 @@ __device__ __forceinline__ float lse3(float a, float b, float c) {
   return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
 }
 
-// One workgroup per utterance.  logits [B][E][V]; lp (log-softmax) [B][E][V]; workspace alpha | beta, [B][E][ss] each.
-//
-// Round 3 structure (round 2: alpha sweep, then beta sweep with LDS-atomic occupancies and the gradient row inside the
-// sweep -- 2 T sequential steps of 2 - 3 barriers each: 0.3 - 0.6 ms with 40 - 180 of the 256 CUs busy):
-//   1. log-softmax of every frame (4 waves over the frames);
-//   2. alpha AND beta recursions in the SAME loop -- threads 0..127 step alpha forward (t = k) while threads 128..255
-//      step beta backward (t = T - 1 - k): T steps of one barrier; both keep their rows in HBM;
-//   3. the gradient, parallel over frames (one wave per frame): e[s] = exp(alpha_t(s) + beta_t(s) - lp_t(ext s) - ll)
-//      for all states at once into LDS, then lane v adds the e[s] of ITS label's states in state order (a CSR list built
-//      once per utterance) -- no atomics: the occupancies, hence the logits' gradient, repeat bit for bit.
-__global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logits,
-                                                  const long* __restrict__ targets, int Lmax,
-                                                  const int* __restrict__ in_lens,
-                                                  const int* __restrict__ tgt_lens, int E, int V,
-                                                  float* __restrict__ lp_all,
-                                                  float* __restrict__ ws_all, int s_stride,
-                                                  float* __restrict__ loss_out,
-                                                  float* __restrict__ dlogits, float gscale) {
+// CTC in three launches (round 2: one kernel, alpha sweep then beta sweep with LDS-atomic occupancies, 0.3 - 0.6 ms;
+// round 3 first form: one kernel with both sweeps in one loop, still 0.46 ms -- every sequential step waited for a
+// dependent global load behind a full __syncthreads, and the log-softmax and gradient phases ran on B of the 256 CUs):
+//   1. log-softmax of every frame: log_softmax_rows_kernel, one wave per frame over the whole chip;
+//   2. ctc_ab_kernel, one workgroup per utterance: alpha (waves 0, 1: forward in time) and beta (waves 2, 3: backward)
+//      recursions in the SAME loop.  A thread owns the same <= PER states at every step, so their labels and "may skip"
+//      flags sit in registers and the NEXT step's emissions lp_t(ext s) are fetched one step ahead; a step is LDS reads,
+//      three exp + one log, one LDS write, s_waitcnt lgkmcnt(0) and a raw s_barrier -- no wait for global memory (the
+//      alpha / beta rows go out as stores nobody waits for);
+//   3. ctc_grad_kernel, one workgroup per CTC_FR frames of an utterance (the whole chip again), one wave per frame:
+//      e[s] = exp(alpha_t(s) + beta_t(s) - lp_t(ext s) - ll) for all states into LDS, then lane v adds the e[s] of ITS
+//      label's states in state order (a CSR list built per workgroup) and the blank's as a fixed-shape wave reduction
+//      -- no atomics: the occupancies, hence the logits' gradient, repeat bit for bit.
+// Workspace per utterance: alpha | beta rows [2][E][ss]; behind all of them one log-likelihood per utterance.
+template <int PER>
+__global__ __launch_bounds__(256) void ctc_ab_kernel(const float* __restrict__ lp_all, const long* __restrict__ targets,
+                                                     int Lmax, const int* __restrict__ in_lens,
+                                                     const int* __restrict__ tgt_lens, int E, int V,
+                                                     float* __restrict__ ws_all, int ss, float* __restrict__ ll_all,
+                                                     float* __restrict__ loss_out) {
   HIP_DYNAMIC_SHARED(unsigned char, smem_raw)
-  const int ss = s_stride;
-  float* pA = reinterpret_cast<float*>(smem_raw);          // [2][ss] alpha rows
-  float* pB = pA + 2 * ss;                                  // [2][ss] beta rows
-  float* erow = pB + 2 * ss;                                // [4][ss] per-wave occupancy terms
-  int* ext = reinterpret_cast<int*>(erow + 4 * ss);         // [ss] extended label sequence
-  int* start = ext + ss;                                    // [V + 1] CSR: states of label v = idx[start[v] .. start[v+1])
-  unsigned short* idx = reinterpret_cast<unsigned short*>(start + V + 1);  // [ss]
-  __shared__ float llsh;
-  const int b = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int L = tgt_lens[b];
-  const int Tb = min(in_lens[b], E);
-  const int S = 2 * L + 1;
-  const float* x = logits + (long)b * E * V;
-  float* lp = lp_all + (long)b * E * V;
-  float* alpha = ws_all + (long)b * 2 * E * ss;
-  float* beta = alpha + (long)E * ss;
-  float* dl = dlogits ? dlogits + (long)b * E * V : nullptr;
-
-  // 1) log-softmax of every frame (also the get_normalized_probs output)
-  for (int t = wave; t < E; t += 4) {
-    const float* xr = x + (long)t * V;
-    float mx = -INFINITY;
-    for (int c = lane; c < V; c += 64) mx = fmaxf(mx, xr[c]);
-    mx = wave_max(mx);
-    float se = 0.f;
-    for (int c = lane; c < V; c += 64) se += expf(xr[c] - mx);
-    se = wave_sum(se);
-    float lse = logf(se) + mx;
-    for (int c = lane; c < V; c += 64) lp[(long)t * V + c] = xr[c] - lse;
-  }
+  float* rows = reinterpret_cast<float*>(smem_raw);  // alpha row pair [2][ss] | beta row pair [2][ss]
+  int* ext = reinterpret_cast<int*>(rows + 4 * ss);  // [ss] extended label sequence
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int L = tgt_lens[b], Tb = min(in_lens[b], E), S = 2 * L + 1;
+  const float* lp = lp_all + (long)b * E * V;
+  const bool isA = tid < 128;
+  const int lt = tid & 127, d = isA ? -1 : 1;
+  float* mine = rows + (isA ? 0 : 2 * ss);                                // this direction's row pair
+  float* out = ws_all + (long)b * 2 * E * ss + (isA ? 0 : (long)E * ss);  // this direction's rows in HBM
   for (int s = tid; s < S; s += 256) ext[s] = (s & 1) ? (int)targets[(long)b * Lmax + (s >> 1)] : 0;
   __syncthreads();
-  if (dl) {  // CSR of the states per label: counts, offsets (one thread: V <= 512), then each label lists its states in order
-    for (int v = tid; v < V; v += 256) {
-      int n = 0;
-      for (int s = 0; s < S; ++s) n += ext[s] == v ? 1 : 0;
-      start[v + 1] = n;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      start[0] = 0;
-      for (int v = 0; v < V; ++v) start[v + 1] += start[v];
-    }
-    __syncthreads();
-    for (int v = tid; v < V; v += 256) {
-      int q = start[v];
-      for (int s = 0; s < S; ++s)
-        if (ext[s] == v) idx[q++] = (unsigned short)s;
+  // A thread's states: s_i = lt + 128 i, clamped to the last state -- a thread past the end repeats state S - 1
+  // exactly (same reads, same value, same addresses written), which keeps the step free of branches
+  int sx[PER], es[PER];
+  bool has1[PER], has2[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int s = min(lt + 128 * i, S - 1);
+    sx[i] = s;
+    es[i] = ext[s];
+    const int s1 = s + d, s2 = s + 2 * d;  // the neighbours this state is reached from (alpha) / leads to (beta)
+    has1[i] = s1 >= 0 && s1 < S;
+    has2[i] = (s & 1) && s2 >= 0 && s2 < S && ext[s2] != ext[s];
+  }
+  float em0[PER], em1[PER];
+  if (Tb > 0) {  // first row: alpha_0 / beta_{T-1}
+    const int t = isA ? 0 : Tb - 1;
+    float* cu = mine + (t & 1) * ss;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int s = sx[i];
+      const bool open = isA ? s < 2 : s >= S - 2;
+      const float a = open ? lp[(long)t * V + es[i]] : CTC_NEG;
+      cu[s] = a;
+      out[(long)t * ss + s] = a;
     }
   }
-
-  // 2) alpha (threads 0 .. 127, forward in time) and beta (threads 128 .. 255, backward) in one loop
-  const bool isA = tid < 128;
-  const int lt = isA ? tid : tid - 128;
-  if (Tb > 0) {
-    if (isA) {
-      for (int s = lt; s < S; s += 128) {
-        const float a = s < 2 ? lp[ext[s]] : CTC_NEG;
-        pA[s] = a;
-        alpha[s] = a;
-      }
-    } else {
-      const float* lpt = lp + (long)(Tb - 1) * V;
-      float* cu = pB + ((Tb - 1) & 1) * ss;
-      for (int s = lt; s < S; s += 128) {
-        const float bt = (s >= S - 2) ? lpt[ext[s]] : CTC_NEG;
-        cu[s] = bt;
-        beta[(long)(Tb - 1) * ss + s] = bt;
-      }
-    }
+  if (Tb > 1) {
+    const int t = isA ? 1 : Tb - 2;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) em0[i] = lp[(long)t * V + es[i]];
   }
   __syncthreads();
-  for (int k = 1; k < Tb; ++k) {
-    if (isA) {
-      const int t = k;
-      const float* pr = pA + ((t - 1) & 1) * ss;
-      float* cu = pA + (t & 1) * ss;
-      const float* lpt = lp + (long)t * V;
-      for (int s = lt; s < S; s += 128) {
-        const float a0 = pr[s];
-        const float a1 = s >= 1 ? pr[s - 1] : CTC_NEG;
-        const float a2 = (s >= 2 && (s & 1) && ext[s] != ext[s - 2]) ? pr[s - 2] : CTC_NEG;
-        float a = lse3(a0, a1, a2);
-        a = a < -1.0e29f ? CTC_NEG : a + lpt[ext[s]];
-        cu[s] = a;
-        alpha[(long)t * ss + s] = a;
-      }
-    } else {
-      const int t = Tb - 1 - k;
-      const float* nx = pB + ((t + 1) & 1) * ss;
-      float* cu = pB + (t & 1) * ss;
-      const float* lpt = lp + (long)t * V;
-      for (int s = lt; s < S; s += 128) {
-        const float b0 = nx[s];
-        const float b1 = s + 1 < S ? nx[s + 1] : CTC_NEG;
-        const float b2 = (s + 2 < S && ((s + 2) & 1) && ext[s + 2] != ext[s]) ? nx[s + 2] : CTC_NEG;
-        float bt = lse3(b0, b1, b2);
-        bt = bt < -1.0e29f ? CTC_NEG : bt + lpt[ext[s]];
-        cu[s] = bt;
-        beta[(long)t * ss + s] = bt;
-      }
+  // one step: emc = this step's emissions (fetched one step ago), emx receives the next step's (the frame index is
+  // clamped at the last step: the loads are unconditional, the step is straight-line code)
+  auto step = [&](int k, const float (&emc)[PER], float (&emx)[PER]) {
+    const int t = isA ? k : Tb - 1 - k;
+    const long tn = isA ? min(k + 1, Tb - 1) : max(Tb - 2 - k, 0);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) emx[i] = lp[tn * V + es[i]];
+    const float* pr = mine + ((t & 1) ^ 1) * ss;
+    float* cu = mine + (t & 1) * ss;
+    float a[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int s = sx[i];
+      const float a0 = pr[s];
+      const float a1 = has1[i] ? pr[s + d] : CTC_NEG;
+      const float a2 = has2[i] ? pr[s + 2 * d] : CTC_NEG;
+      a[i] = lse3(a0, a1, a2);
     }
-    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const float v = a[i] < -1.0e29f ? CTC_NEG : a[i] + emc[i];
+      cu[sx[i]] = v;
+      out[(long)t * ss + sx[i]] = v;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): my LDS writes are done; global traffic stays in flight
+    __builtin_amdgcn_s_barrier();
+  };
+  int k = 1;
+  for (; k + 1 < Tb; k += 2) {
+    step(k, em0, em1);
+    step(k + 1, em1, em0);
   }
+  if (k < Tb) step(k, em0, em1);
   if (tid == 0) {
     float ll = CTC_NEG;
     if (Tb > 0) {
-      const float* last = pA + ((Tb - 1) & 1) * ss;
+      const float* last = rows + ((Tb - 1) & 1) * ss;
       ll = lse3(last[S - 1], S >= 2 ? last[S - 2] : CTC_NEG, CTC_NEG);
     }
-    llsh = ll;
-    float per = (ll < -1.0e29f) ? 0.f : -ll / (float)max(L, 1);  // zero_infinity
-    loss_out[b] = per;
+    ll_all[b] = ll;
+    loss_out[b] = (ll < -1.0e29f) ? 0.f : -ll / (float)max(L, 1);  // zero_infinity
+  }
+}
+
+constexpr int CTC_FR = 16;  // frames per workgroup of the gradient kernel
+__global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ lp_all, const long* __restrict__ targets,
+                                                       int Lmax, const int* __restrict__ in_lens,
+                                                       const int* __restrict__ tgt_lens, int E, int V,
+                                                       const float* __restrict__ ws_all, int ss,
+                                                       const float* __restrict__ ll_all, float* __restrict__ dlogits,
+                                                       float gscale) {
+  HIP_DYNAMIC_SHARED(unsigned char, smem_raw)
+  float* erow = reinterpret_cast<float*>(smem_raw);                        // [4][ss] per-wave occupancy terms
+  int* ext = reinterpret_cast<int*>(erow + 4 * ss);                        // [ss]
+  int* start = ext + ss;                                                   // [V + 1] states of label v: idx[start[v] .. start[v+1])
+  unsigned short* idx = reinterpret_cast<unsigned short*>(start + V + 1);  // [ss]
+  const int b = blockIdx.y, f0 = blockIdx.x * CTC_FR, f1 = min(f0 + CTC_FR, E);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = tgt_lens[b], Tb = min(in_lens[b], E), S = 2 * L + 1;
+  const float ll = ll_all[b];
+  float* dl = dlogits + (long)b * E * V;
+  if (!(ll > -1.0e29f) || f0 >= Tb) {  // infeasible utterance (zero_infinity) or frames past its input length
+    for (long i = (long)f0 * V + tid; i < (long)f1 * V; i += 256) dl[i] = 0.f;
+    return;
+  }
+  const float* lp = lp_all + (long)b * E * V;
+  const float* alpha = ws_all + (long)b * 2 * E * ss;
+  const float* beta = alpha + (long)E * ss;
+  const float sc = gscale / (float)max(L, 1);
+  for (int s = tid; s < S; s += 256) ext[s] = (s & 1) ? (int)targets[(long)b * Lmax + (s >> 1)] : 0;
+  for (int v = tid; v <= V; v += 256) start[v] = 0;
+  __syncthreads();
+  // the label states (odd s) per label, in state order: counts (integer LDS atomics), offsets (one wave scans), lists
+  for (int s = 2 * tid + 1; s < S; s += 512) atomicAdd(&start[ext[s] + 1], 1);
+  __syncthreads();
+  if (wave == 0) {
+    const int ch = (V + 63) / 64, v0 = lane * ch;
+    int own = 0;
+    for (int q = 0; q < ch; ++q) own += (v0 + q < V) ? start[v0 + q + 1] : 0;
+    int incl = own;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl(incl, max(lane - o, 0));
+      if (lane >= o) incl += up;
+    }
+    int run = incl - own;
+    for (int q = 0; q < ch; ++q)
+      if (v0 + q < V) { run += start[v0 + q + 1]; start[v0 + q + 1] = run; }
   }
   __syncthreads();
-  const float ll = llsh;
-  if (!dl) return;
-  const bool feasible = ll > -1.0e29f;
-  const float sc = gscale / (float)max(L, 1);
-  // frames past the utterance's input length (and infeasible utterances) get zero gradient
-  for (long i = tid; i < (long)E * V; i += 256) {
-    int t = (int)(i / V);
-    if (t >= Tb || !feasible) dl[i] = 0.f;
+  for (int s = 2 * tid + 1; s < S; s += 512) {
+    const int v = ext[s];
+    int rank = 0;
+    for (int q = 1; q < s; q += 2) rank += ext[q] == v ? 1 : 0;
+    idx[start[v] + rank] = (unsigned short)s;
   }
-  if (!feasible || Tb <= 0) return;
-
-  // 3) gradient rows, one wave per frame (the loop is uniform over the workgroup: barriers inside)
+  __syncthreads();
   float* er = erow + wave * ss;
-  for (int t0 = 0; t0 < Tb; t0 += 4) {
+  for (int t0 = f0; t0 < f1; t0 += 4) {  // uniform over the workgroup: barriers inside
     const int t = t0 + wave;
     const bool on = t < Tb;
     const float* lpt = lp + (long)(on ? t : 0) * V;
@@ -294,11 +307,16 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
     }
     __syncthreads();
     if (on) {
+      float blank = 0.f;
+      for (int s = 2 * lane; s < S; s += 128) blank += er[s];
+      blank = wave_sum(blank);
       for (int v = lane; v < V; v += 64) {
-        float o = 0.f;
+        float o = v == 0 ? blank : 0.f;
         for (int q = start[v]; q < start[v + 1]; ++q) o += er[idx[q]];
         dl[(long)t * V + v] = sc * (expf(lpt[v]) - o);
       }
+    } else if (t < f1) {
+      for (int v = lane; v < V; v += 64) dl[(long)t * V + v] = 0.f;
     }
     __syncthreads();
   }
@@ -394,27 +412,28 @@ int s2st_ls_ce(const float* logits, const long* target, int rows, int V, long pa
 
 long s2st_ctc_workspace_floats(int B, int E, int Lmax) {
   long ss = ((2L * Lmax + 1 + 3) / 4) * 4;
-  return 2L * B * E * ss;  // alpha and beta rows
+  return 2L * B * E * ss + B;  // alpha and beta rows; one log-likelihood per utterance
 }
 
 int s2st_ctc(const float* logits, const long* targets, int Lmax, const int* in_lens,
              const int* tgt_lens, int B, int E, int V, float* lprobs, float* loss_per_utt,
              float* dlogits, float gscale, float* ws, hipStream_t st) {
   if (B <= 0) return 0;
-  if (2 * Lmax + 1 > CTC_MAXS || V > CTC_MAXV) return S2ST_ERR_SHAPE;
-  int ss = ((2 * Lmax + 1 + 3) / 4) * 4;
-  // LDS: alpha / beta row pairs, four per-wave term rows, the extended labels, the per-label state lists
-  const unsigned lds = (unsigned)(ss * (8 * 4 + 4 + 2) + (V + 1) * 4 + 16);
-  if (lds > 64 * 1024) {
-    static bool configured = false;
-    if (!configured) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess)
-        return S2ST_ERR_LAUNCH;
-      configured = true;
-    }
+  if (2 * Lmax + 1 > CTC_MAXS || V > CTC_MAXV || E <= 0) return S2ST_ERR_SHAPE;
+  const int S = 2 * Lmax + 1, ss = ((S + 3) / 4) * 4;
+  float* ll = ws + 2L * B * E * ss;
+  S2ST_LAUNCH(log_softmax_rows_kernel, dim3((B * E + 3) / 4), dim3(256), 0, st, logits, (long)V, lprobs, (long)V, B * E, V, 1);
+  const unsigned lds_ab = (unsigned)(ss * 5 * 4);
+#define CTC_AB(PER) S2ST_LAUNCH(ctc_ab_kernel<PER>, dim3(B), dim3(256), lds_ab, st, lprobs, targets, Lmax, in_lens, tgt_lens, E, V, ws, ss, ll, loss_per_utt)
+  if (S <= 256) CTC_AB(2);
+  else if (S <= 512) CTC_AB(4);
+  else CTC_AB(16);
+#undef CTC_AB
+  if (dlogits) {
+    const unsigned lds_g = (unsigned)(ss * (4 * 4 + 4 + 2) + (V + 1) * 4 + 16);
+    S2ST_LAUNCH(ctc_grad_kernel, dim3((E + CTC_FR - 1) / CTC_FR, B), dim3(256), lds_g, st, lprobs, targets, Lmax, in_lens,
+                tgt_lens, E, V, ws, ss, ll, dlogits, gscale);
   }
-  S2ST_LAUNCH(ctc_kernel, dim3(B), dim3(256), lds, st, logits, targets, Lmax, in_lens, tgt_lens,
-                     E, V, lprobs, ws, ss, loss_per_utt, dlogits, gscale);
   return LAUNCH_OK();
 }
 

@@ -65,12 +65,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                                                           float max_norm, float lr, float b1, float b2, float eps,
                                                           float wd, float step_size,
                                                           float* __restrict__ gnorm_out, uint16_t* __restrict__ ph,
-                                                          int* __restrict__ skipped, int sumsq_parts) {
+                                                          int* __restrict__ skipped, int sumsq_parts, int zero_grad) {
   if (gmul_dev) gmul *= gmul_dev[0];
   const float gn = sqrtf(sumsq_parts > 0 ? fold_sumsq_parts(sumsq, sumsq_parts) : sumsq[0]) * gmul;
   if (gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) gnorm_out[0] = gn;
   if (!(gn < INFINITY)) {  // non-finite gradient norm: nothing is touched; the caller finds the count (trainer.py:860-867)
     if (skipped && blockIdx.x == 0 && threadIdx.x == 0) skipped[0] += 1;
+    if (zero_grad)  // ... except the gradients, which the caller asked to find cleared for the next step
+      for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) g[i] = 0.f;
     return;
   }
   float coef = gmul;
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     float gi = g[i], mi = m[i], vi = v[i];
     const float pi = adam_one(gi, mi, vi, p[i], coef, b1, b2, eps, wd_lr, step_size);
-    g[i] = gi; m[i] = mi; v[i] = vi; p[i] = pi;
+    g[i] = zero_grad ? 0.f : gi; m[i] = mi; v[i] = vi; p[i] = pi;
     if (ph) ph[i] = (uint16_t)(pack_bf16x4(pi, 0.f, 0.f, 0.f).x & 0xffffu);
   }
 }
@@ -108,7 +110,7 @@ long s2st_sumsq_nparts(long n) { return n <= 0 ? 0 : sumsq_blocks(n); }
 
 int s2st_adam(float* p, float* g, float* m, float* v, long n, const float* sumsq, float gmul,
               const float* gmul_dev, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step,
-              float* gnorm_out, hipStream_t st, uint16_t* ph, int* skipped, int sumsq_parts) {
+              float* gnorm_out, hipStream_t st, uint16_t* ph, int* skipped, int sumsq_parts, int zero_grad) {
   if (n <= 0) return 0;
   double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   float step_size = (float)((double)lr * sqrt(bc2) / bc1);
@@ -117,6 +119,6 @@ int s2st_adam(float* p, float* g, float* m, float* v, long n, const float* sumsq
   if (blocks > 1024) blocks = 1024;
   // bytes: p, g, m, v read and written (32 B per parameter) + the bf16 copy (2 B)
   s2st_launch("adam_kernel", (32.0 + (ph ? 2.0 : 0.0)) * n, 0.0, adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m,
-              v, n, sumsq, gmul, gmul_dev, max_norm, lr, beta1, beta2, eps, wd, step_size, gnorm_out, ph, skipped, sumsq_parts);
+              v, n, sumsq, gmul, gmul_dev, max_norm, lr, beta1, beta2, eps, wd, step_size, gnorm_out, ph, skipped, sumsq_parts, zero_grad);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }

@@ -241,8 +241,9 @@ int s2st_flash_attn_db_fold(const s2st_attn_args* p, const float* db_part, hipSt
 // HuBERT front end (hubert.hip): waveform conv, GroupNorm(C, C) + GELU, pos-conv input re-layout
 // ---------------------------------------------------------------------------------------
 int s2st_hubert_conv0_gn_gelu(const float* x, const float* w, const float* gamma, const float* beta, float* y,
-                              uint16_t* yh, float* stats /* 2 * B * C floats */, int B, int N, int T, int C, int k,
+                              uint16_t* yh, float* stats /* s2st_hubert_conv0_stats_floats(B, T, C) */, int B, int N, int T, int C, int k,
                               int stride, float eps, hipStream_t st);
+long s2st_hubert_conv0_stats_floats(int B, int T, int C);
 int s2st_posconv_prep(float* x, const int* lens, float* img, uint16_t* imgh, int B, int T, int E, int G, int pad,
                       int Tp, hipStream_t st);
 
@@ -322,4 +323,6 @@ int s2st_adam(float* p, float* g, float* m, float* v, long n, const float* sumsq
               const float* gmul_dev, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step,
               float* gnorm_out, hipStream_t st, uint16_t* p_bf16 = nullptr /* optional bf16 copy of the new p */,
               int* skipped = nullptr /* optional device counter: += 1 when the norm is non-finite and the update is skipped */,
-              int sumsq_parts = 0 /* > 0: sumsq points at that many partial sums (s2st_sumsq_parts) */);
+              int sumsq_parts = 0 /* > 0: sumsq points at that many partial sums (s2st_sumsq_parts) */,
+              int zero_grad = 0 /* 1: g is left all zero (also when the update is skipped) instead of holding the scaled
+                                   gradient: the next step needs no clearing pass over the arena */);

@@ -44,6 +44,7 @@ class Trainer:
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.gmul_dev = torch.ones(1, dtype=torch.float32, device=dev)
         self.skipped = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._grads_clean = False
         self.num_updates = 0
         self.lr = getattr(args, "lr", 1.5e-3)
         self.lr = self.lr[0] if isinstance(self.lr, (list, tuple)) else self.lr
@@ -76,7 +77,9 @@ class Trainer:
         eng = self.engine
         self.model.train()
         eng.step_seed = (self.seed + self.num_updates) * 1000003
-        eng.zero_grad()
+        if not self._grads_clean:  # the previous update's Adam kernel left the arena zeroed (zero_grad = 1 below)
+            eng.zero_grad()
+        self._grads_clean = False
         sample_size = 0
         logs = []
         hooks = self.reducer.on_segment if self.reducer is not None else None
@@ -124,7 +127,8 @@ class Trainer:
         lr = self.get_lr()
         bd.call("s2st_adam_f32", eng.params, eng.grads, self.exp_avg, self.exp_avg_sq, eng.n_params,
                 self.sumsq_parts, gmul, gmul_dev, float(self.clip_norm), lr, self.betas[0], self.betas[1],
-                self.eps, self.wd, self.num_updates + 1, self.gnorm, self._ph(), self.skipped, nparts)
+                self.eps, self.wd, self.num_updates + 1, self.gnorm, self._ph(), self.skipped, nparts, 1)
+        self._grads_clean = True
         if self._ph() is not None:
             eng.mark_bf16_fresh()
         self.num_updates += 1

@@ -338,15 +338,16 @@ def test_ctc(backend):
     assert torch.equal(lpo.argmax(-1).cpu(), lp.transpose(0, 1).argmax(-1))
 
 
-def test_ctc_long_labels_and_repeatability(backend):
-    """More than 128 extended states (the alpha / beta halves of the workgroup then walk the states in two strides), a
-    vocabulary beyond one wave, and the same launch twice: the gradient comes out of ordered per-label sums (no atomics),
-    so it repeats bit for bit."""
+@pytest.mark.parametrize("E,Lmax", [(170, 72), (300, 140), (540, 260)], ids=["S145", "S281", "S521"])
+def test_ctc_long_labels_and_repeatability(backend, E, Lmax):
+    """More than 128 extended states (a thread of the alpha / beta halves then owns 2, 4 or 16 states: the three
+    instantiations), a vocabulary beyond one wave, an empty target, and the same launch twice: the gradient comes out of
+    ordered per-label sums (no atomics), so it repeats bit for bit."""
     torch.manual_seed(1)
-    B, E, V, Lmax = 3, 170, 70, 72
+    B, V = 4, 70
     logits = torch.randn(B, E, V)
-    tl = torch.tensor([72, 65, 2], dtype=torch.int32)
-    il = torch.tensor([170, 160, 5], dtype=torch.int32)
+    tl = torch.tensor([Lmax, Lmax - 7, 2, 0], dtype=torch.int32)
+    il = torch.tensor([E, E - 10, 5, 9], dtype=torch.int32)
     tg = torch.randint(1, V, (B, Lmax))
     lr = logits.clone().requires_grad_()
     lp = F.log_softmax(lr, -1).transpose(0, 1)
@@ -403,9 +404,13 @@ def test_sumsq_adam(backend, parts):
         ph = torch.zeros(n, dtype=torch.bfloat16, device=backend.device)
         skipped = torch.zeros(1, dtype=torch.int32, device=backend.device)
         backend.bd.call("s2st_adam_f32", pd, gd, m, v, n, ss, 0.02, half, 0.5, 1e-2, 0.9, 0.999, 1e-8, 0.01,
-                        step, gno, ph, skipped, nparts)
+                        step, gno, ph, skipped, nparts, step % 2)
         backend.sync()
         assert int(skipped) == 0
+        if step % 2:  # zero_grad = 1: the arena is handed back cleared
+            assert not bool(gd.any())
+        else:  # the scaled and clipped gradient
+            close(gd, pr.grad, 1e-5, 1e-7)
         close(gno, gn_ref.view(1), 1e-5, 1e-6)
         close(pd, pr.detach(), 1e-5, 1e-6)
         assert torch.equal(ph, pd.to(torch.bfloat16))  # the fused bf16 copy == a cast of the new parameters
@@ -414,7 +419,12 @@ def test_sumsq_adam(backend, parts):
     gd[3] = float("inf")
     sumsq(gd, ss)
     backend.bd.call("s2st_adam_f32", pd, gd, m, v, n, ss, 0.02, half, 0.5, 1e-2, 0.9, 0.999, 1e-8, 0.01, 4, gno, ph,
-                    skipped, nparts)
+                    skipped, nparts, 0)
     backend.sync()
     assert int(skipped) == 1 and not bool(torch.isfinite(gno).all())
     assert torch.equal(pd, before[0]) and torch.equal(m, before[1]) and torch.equal(v, before[2])
+    assert bool(torch.isinf(gd[3]))
+    backend.bd.call("s2st_adam_f32", pd, gd, m, v, n, ss, 0.02, half, 0.5, 1e-2, 0.9, 0.999, 1e-8, 0.01, 4, gno, ph,
+                    skipped, nparts, 1)  # skipped again, but the gradients are cleared as asked
+    backend.sync()
+    assert int(skipped) == 2 and not bool(gd.any()) and torch.equal(pd, before[0])
