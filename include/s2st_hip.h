@@ -167,6 +167,9 @@ int s2st_embed_fwd_f32(const int64_t* tokens, const float* table, float* y, int3
 
 /* embedding gradient (pad row receives none) */
 int s2st_embed_bwd_f32(const int64_t* tokens, const float* dy, float* dtable, int32_t rows, int32_t C, float scale, int64_t pad, void* stream);
+/* the same gradient with the rows of every token id added in row order (no atomics: repeats bit for bit; what the engine
+ * uses); V = number of ids, C <= 1024 */
+int s2st_embed_bwd_ordered_f32(const int64_t* tokens, const float* dy, float* dtable, int32_t rows, int32_t C, int32_t V, float scale, int64_t pad, void* stream);
 
 /* fairseq_dropout.py:16-27: y (+)= a * x * mask(seed) */
 int s2st_dropout_f32(const float* x, float* y, int64_t n, float a, float p, uint64_t seed, int32_t accumulate, void* stream);

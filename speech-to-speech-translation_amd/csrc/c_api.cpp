@@ -68,6 +68,11 @@ int s2st_embed_bwd_f32(const int64_t* tokens, const float* dy, float* dtable, in
   return s2st_embed_bwd((const long*)tokens, dy, dtable, rows, C, scale, pad, (hipStream_t)stream);
 }
 
+int s2st_embed_bwd_ordered_f32(const int64_t* tokens, const float* dy, float* dtable, int32_t rows, int32_t C, int32_t V, float scale, int64_t pad, void* stream) {
+  if (V <= 0) return S2ST_ERR_ARG;
+  return s2st_embed_bwd((const long*)tokens, dy, dtable, rows, C, scale, (long)pad, (hipStream_t)stream, V);
+}
+
 int s2st_dropout_f32(const float* x, float* y, int64_t n, float a, float p, uint64_t seed, int32_t accumulate, void* stream) {
   return s2st_dropout(x, y, n, a, p, seed, accumulate, (hipStream_t)stream);
 }

@@ -703,17 +703,56 @@ int s2st_embed_fwd(const long* tokens, const float* table, float* y, int rows, i
   return LAUNCH_OK();
 }
 
-// dtable[v][c] += scale * sum over {r : tok[r] == v, v != pad} of dy[r][c], rows in index order: one thread per (v, c)
+// dtable[v][c] += scale * sum over {r : tok[r] == v, v != pad} of dy[r][c], rows in index order (no atomics: the same
+// bits every run).  One workgroup per token id: per window of EMB_WIN rows, every thread looks at EMB_WIN / 256
+// consecutive rows, the matches are compacted IN ORDER into an LDS list (counts -> offsets -> rows), and the threads --
+// one per column, EMB_CPT columns each -- add the listed rows.  Most ids have no row at all: those workgroups only scan.
+// (First form: one thread per (id, column) walking all rows -- 0.17 ms per launch at 4 k rows x 1 k ids.)
+constexpr int EMB_WIN = 4096, EMB_CPT = 4;
 __global__ __launch_bounds__(256) void embed_bwd_ordered_kernel(const long* __restrict__ tok, const float* __restrict__ dy,
                                                                 float* __restrict__ dtable, int rows, int C, int V,
                                                                 float scale, long pad) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  const int v = blockIdx.y;
-  if (c >= C || v >= V || v == pad) return;
-  float a = 0.f;
-  for (int r = 0; r < rows; ++r)
-    if (tok[r] == v) a += dy[(long)r * C + c];
-  dtable[(long)v * C + c] += scale * a;
+  __shared__ int cnt[256];
+  __shared__ int list[EMB_WIN];
+  __shared__ int total;
+  const int v = blockIdx.x, tid = threadIdx.x;
+  if (v >= V || v == pad) return;
+  float a[EMB_CPT] = {0.f, 0.f, 0.f, 0.f};
+  bool any = false;
+  constexpr int PT = EMB_WIN / 256;
+  for (int w0 = 0; w0 < rows; w0 += EMB_WIN) {
+    const int r0 = w0 + tid * PT;
+    unsigned hit = 0;
+#pragma unroll
+    for (int q = 0; q < PT; ++q)
+      if (r0 + q < rows && tok[r0 + q] == v) hit |= 1u << q;
+    cnt[tid] = __builtin_popcount(hit);
+    __syncthreads();
+    int off = 0;
+    for (int q = 0; q < tid; ++q) off += cnt[q];
+    if (tid == 255) total = off + cnt[255];
+    for (int q = 0; q < PT; ++q)
+      if (hit >> q & 1) list[off++] = r0 + q;
+    __syncthreads();
+    const int n = total;
+    if (n > 0) {
+      any = true;
+#pragma unroll
+      for (int e = 0; e < EMB_CPT; ++e) {
+        const int c = tid + 256 * e;
+        if (c < C)
+          for (int q = 0; q < n; ++q) a[e] += dy[(long)list[q] * C + c];
+      }
+    }
+    __syncthreads();
+  }
+  if (any) {
+#pragma unroll
+    for (int e = 0; e < EMB_CPT; ++e) {
+      const int c = tid + 256 * e;
+      if (c < C) dtable[(long)v * C + c] += scale * a[e];
+    }
+  }
 }
 
 int s2st_embed_bwd(const long* tokens, const float* dy, float* dtable, int rows, int C, float scale,
@@ -721,7 +760,8 @@ int s2st_embed_bwd(const long* tokens, const float* dy, float* dtable, int rows,
   long n = (long)rows * C;
   if (n <= 0) return 0;
   if (V > 0) {
-    S2ST_LAUNCH(embed_bwd_ordered_kernel, dim3((C + 255) / 256, V), dim3(256), 0, st, tokens, dy, dtable, rows, C, V, scale, pad);
+    if (C > 256 * EMB_CPT) return S2ST_ERR_SHAPE;
+    S2ST_LAUNCH(embed_bwd_ordered_kernel, dim3(V), dim3(256), 0, st, tokens, dy, dtable, rows, C, V, scale, pad);
     return LAUNCH_OK();
   }
   S2ST_LAUNCH(embed_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, tokens, dy, dtable, rows, C, scale, pad);

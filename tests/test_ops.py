@@ -170,6 +170,22 @@ def test_add_pe_embed_dropout(backend):
     ref = torch.zeros(12, Cc).index_add_(0, tok, 3.0 * dy)
     ref[1] = 0
     close(de, ref, 1e-5, 1e-5)
+    # ... and the ordered form (what the engine runs): more rows than one 4096-row window, ids without any row, twice
+    big = 4096 + 777
+    tokb = torch.randint(0, 9, (big,))
+    tokb[tokb == 5] = 6  # id 5 has no row
+    dyb = torch.randn(big, Cc)
+    tokbd, dybd = dev(backend, tokb, dyb)
+    refb = torch.zeros(12, Cc, dtype=torch.float64).index_add_(0, tokb, 3.0 * dyb.double())
+    refb[1] = 0
+    got = []
+    for _ in range(2):
+        de = torch.zeros(12, Cc, device=backend.device)
+        backend.bd.call("s2st_embed_bwd_ordered_f32", tokbd, dybd, de, big, Cc, 12, 3.0, 1)
+        backend.sync()
+        got.append(de.clone())
+    close(got[0], refb.float(), 1e-5, 1e-4)
+    assert torch.equal(got[0], got[1]) and not bool(got[0][5].any())
     # dropout: same seed same mask, scale a, accumulate
     y1 = torch.zeros(rows * Cc, device=backend.device)
     y2 = torch.ones(rows * Cc, device=backend.device)

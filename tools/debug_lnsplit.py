@@ -13,9 +13,13 @@ import conftest  # noqa: E402
 import test_engine as TE  # noqa: E402
 
 
+GLOBAL_ENV = dict(kv.split("=") for kv in sys.argv[2:])
+
+
 def run(backend, cfg, env, precise=False):
-    for k in ("S2ST_LN_BWD_SPLIT", "S2ST_NO_LN_FUSE"):
+    for k in ("S2ST_LN_BWD_SPLIT",):
         os.environ.pop(k, None)
+    os.environ.update(GLOBAL_ENV)
     os.environ.update(env)
     D = importlib.import_module(TE.DATA)
     c = D.SyntheticFisherCorpus(n_utts=4, seed=3, max_src=64, median_src=50, min_src=30)
@@ -44,7 +48,8 @@ def main():
                      float((a0[n] - p[n]).norm()) / nr, float((b[n] - p[n]).norm()) / nr, nr, n))
     rows.sort(reverse=True)
     print("%-10s %-10s %-10s %-10s %-10s %-10s name" % ("fused-split", "fused-rep", "split-rep", "fused-x3", "split-x3", "norm"))
-    for r in rows[:40]:
+    print('global env', GLOBAL_ENV)
+    for r in rows[:int(os.environ.get('DBG_ROWS', 12))]:
         print("%-10.2e %-10.2e %-10.2e %-10.2e %-10.2e %-10.2e %s" % r)
 
 
