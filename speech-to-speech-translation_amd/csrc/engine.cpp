@@ -728,6 +728,28 @@ struct s2st_engine {
       bf16raw* dph = nullptr;
       if (fuse) dph = x->gpre_h = alloc_h(x->n());
       float* dbias = fuse && x->drop2_bias >= 0 ? G + x->drop2_bias : nullptr;
+      // debugging aid (tools/debug_lnsplit3.py): S2ST_DEBUG_LN_DUMP=<dir> writes the inputs / outputs of every call
+      static const char* const dbg_dir = getenv("S2ST_DEBUG_LN_DUMP");
+      const char* dbg = live() ? dbg_dir : nullptr;
+      static int dbg_n = 0;
+      auto dump = [&](const char* what, const void* dptr, size_t bytes) {
+        std::vector<char> h(bytes);
+        hipStreamSynchronize(st_);
+        if (side_) hipStreamSynchronize(side_);
+        hipMemcpyAsync(h.data(), dptr, bytes, hipMemcpyDeviceToHost, st_);
+        hipStreamSynchronize(st_);
+        char path[512];
+        snprintf(path, sizeof path, "%s/ln%03d_%s.bin", dbg, dbg_n, what);
+        if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 1, bytes, f); fclose(f); }
+      };
+      if (dbg) {
+        fprintf(stderr, "[ln dump %d] rows %d cols %d acc %d fuse %d\n", dbg_n, x->rows, x->cols, (int)acc, (int)fuse);
+        dump("dy", y->g, sizeof(float) * x->n());
+        dump("x", x->d, sizeof(float) * x->n());
+        dump("mean", mean, sizeof(float) * x->rows);
+        dump("rstd", rstd, sizeof(float) * x->rows);
+        if (acc) dump("dx0", dx, sizeof(float) * x->n());
+      }
       if (live()) {
         if (!ln_bwd_split) {
           // one row kernel on the data path (dx, the fused bf16 operand, and the column-sum partials of dgamma / dbeta /
@@ -748,6 +770,10 @@ struct s2st_engine {
           chk(s2st_layernorm_bwd(y->g, x->d, P + pp.g, mean, rstd, dx, acc ? 1 : 0, G + pp.g, G + pp.b, scratch,
                                  x->rows, x->cols, st_, 2, dph, x->drop2_p, x->drop2_seed, dbias));
         }
+      }
+      if (dbg) {
+        dump("dx1", dx, sizeof(float) * x->n());
+        ++dbg_n;
       }
     });
     return y;

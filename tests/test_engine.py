@@ -343,7 +343,11 @@ def test_fused_backward_paths_equal_the_unfused_ones(backend, cfg, switch, monke
     # bias gradients are then summed from the rounded values instead of the fp32 ones)
     # (likewise the layer-norm backward's fused form: the bias gradient of the producing linear layer is the column sum
     # of the bf16 operand it emitted, not of the fp32 values)
-    tol = 50.0 if switch.startswith(("S2ST_ATTN_GFUSE", "S2ST_NO_LN_FUSE")) else 1.0
+    # (and the one-kernel layer-norm backward: on hardware its dx differs from the split kernel's in the last fp32 bit --
+    # the compiler contracts the two kernels' multiply-adds differently, the emulator build does not -- and ONE bf16
+    # operand of the 64-wide micro model rounding the other way moves the gradients behind it by ~5e-4:
+    # tools/debug_lnsplit3.py, profiles/r03_e_ln_schedules_dump_compare.txt)
+    tol = 50.0 if switch.startswith(("S2ST_ATTN_GFUSE", "S2ST_NO_LN_FUSE", "S2ST_LN_BWD_SPLIT")) else 1.0
     worst = sorted(((float((v0[n] - v1[n]).norm()), float(v0[n].norm()), n) for n in v0), reverse=True)[:5]
     assert float((g0 - g1).norm()) <= tol * 2e-5 * float(g0.norm()), worst
     gmax = max(float(v.norm()) for v in v0.values())
