@@ -1787,17 +1787,22 @@ struct s2st_engine {
     if (with_loss) {
       float* stats = outs.stats;
       const float nr = (float)bt.ntokens, nf = nr * c.out_dim;
+      float* loss_ws = alloc(3L * S2ST_LOSS_ORDERED_FLOATS);
       if (live()) {
         hipMemsetAsync(stats, 0, sizeof(float) * 32, st_);
+        // (stats[28 .. 30]: the arrival counters of the three loss kernels' ordered sums, zeroed with the rest)
+        unsigned* cnt = ordered_sums ? reinterpret_cast<unsigned*>(stats + 28) : nullptr;
         chk(s2st_mel_loss(feat->d, post->d, eos->d, bt.tgt, bt.tgt_lens, B, D, c.out_dim, c.bce_pos_weight,
-                          stats + S2ST_STAT_L1_SUM, 0, 0, 0, nullptr, nullptr, nullptr, st_));
+                          stats + S2ST_STAT_L1_SUM, 0, 0, 0, nullptr, nullptr, nullptr, st_, cnt ? loss_ws : nullptr, cnt));
         join_side();  // aux logits, CTC per-utterance losses
         if (asr_logits)
           chk(s2st_ls_ce(asr_logits->d, (const long*)bt.src_txt, B * bt.Ls, c.src_vocab, 1, c.label_smoothing,
-                         stats + S2ST_STAT_ASR_NLL, nullptr, 0.f, st_));
+                         stats + S2ST_STAT_ASR_NLL, nullptr, 0.f, st_, cnt ? loss_ws + S2ST_LOSS_ORDERED_FLOATS : nullptr,
+                         cnt ? cnt + 1 : nullptr));
         if (st_logits)
           chk(s2st_ls_ce(st_logits->d, (const long*)bt.tgt_txt, B * bt.Lt, c.tgt_vocab, 1, c.label_smoothing,
-                         stats + S2ST_STAT_ST_NLL, nullptr, 0.f, st_));
+                         stats + S2ST_STAT_ST_NLL, nullptr, 0.f, st_, cnt ? loss_ws + 2 * S2ST_LOSS_ORDERED_FLOATS : nullptr,
+                         cnt ? cnt + 2 : nullptr));
         chk(s2st_loss_finalize(stats, ctc_per, B, nf, nr, c.w_l1, c.w_mse, c.w_eos, c.ctc_weight,
                                c.asr_weight, c.st_weight, c.label_smoothing, c.src_vocab, c.tgt_vocab,
                                (float)bt.src_txt_ntokens, (float)bt.tgt_txt_ntokens, st_, ctc_tgt_per, c.ctc_tgt_weight));

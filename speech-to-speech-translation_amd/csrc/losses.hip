@@ -14,13 +14,42 @@ __device__ __forceinline__ float softplusf_(float x) {  // log(1 + exp(x)), stab
   return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
 }
 
+// stats[k] += the workgroups' sums, K <= 4 per workgroup.  ordered != null: every workgroup stores its sums, the LAST one to
+// arrive (a counter the caller zeroes with the stats) adds all of them in workgroup order -- the logged losses repeat
+// bit for bit; ordered == null (the stand-alone C-ABI calls): atomics.
+__device__ __forceinline__ void block_stats_out(float* __restrict__ stats, int K, const float (*red)[4],
+                                                float* __restrict__ ordered, unsigned* __restrict__ counter) {
+  __shared__ bool last;
+  const int tid = threadIdx.x;
+  if (!ordered) {
+    if (tid < K) atomicAdd(&stats[tid], red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3]);
+    return;
+  }
+  if (tid < K) ordered[(long)tid * gridDim.x + blockIdx.x] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) last = atomicAdd(counter, 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (tid == 0) *counter = 0;  // left as found
+  const int lane = tid & 63, k = tid >> 6;  // wave k sums output k
+  if (k < K) {
+    float v = 0.f;
+    for (unsigned b = lane; b < gridDim.x; b += 64) v += ordered[(long)k * gridDim.x + b];
+    v = wave_sum(v);
+    if (lane == 0) stats[k] += v;
+  }
+}
+
 // One thread per (row, f) element for the mel terms; thread f == 0 of each row also does the
 // stop-token term.  stats: [0] sum |fo-t| + |fp-t|, [1] sum (fo-t)^2 + (fp-t)^2, [2] sum bce
 __global__ __launch_bounds__(256) void mel_loss_kernel(
     const float* __restrict__ feat, const float* __restrict__ post, const float* __restrict__ eos,
     const float* __restrict__ tgt, const int* __restrict__ lens, int B, int D, int F,
     float pos_weight, float* __restrict__ stats, float c_l1, float c_mse, float c_eos,
-    float* __restrict__ dfeat, float* __restrict__ dpost, float* __restrict__ deos) {
+    float* __restrict__ dfeat, float* __restrict__ dpost, float* __restrict__ deos, float* __restrict__ ordered,
+    unsigned* __restrict__ counter) {
   __shared__ float red[3][4];
   const long n = (long)B * D * F;
   float a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -57,10 +86,7 @@ __global__ __launch_bounds__(256) void mel_loss_kernel(
     int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[0][w] = a1; red[1][w] = a2; red[2][w] = a3; }
     __syncthreads();
-    if (threadIdx.x < 3) {
-      int k = threadIdx.x;
-      atomicAdd(&stats[k], red[k][0] + red[k][1] + red[k][2] + red[k][3]);
-    }
+    block_stats_out(stats, 3, red, ordered, counter);
   }
 }
 
@@ -69,7 +95,8 @@ __global__ __launch_bounds__(256) void ls_ce_kernel(const float* __restrict__ lo
                                                     const long* __restrict__ target, int rows,
                                                     int V, long pad, float eps,
                                                     float* __restrict__ stats,
-                                                    float* __restrict__ dlogits, float gscale) {
+                                                    float* __restrict__ dlogits, float gscale,
+                                                    float* __restrict__ ordered, unsigned* __restrict__ counter) {
   __shared__ float red[4][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float nll_a = 0.f, sm_a = 0.f, cor_a = 0.f, tot_a = 0.f;
@@ -117,10 +144,7 @@ __global__ __launch_bounds__(256) void ls_ce_kernel(const float* __restrict__ lo
   if (stats) {
     if (lane == 0) { red[0][wave] = nll_a; red[1][wave] = sm_a; red[2][wave] = cor_a; red[3][wave] = tot_a; }
     __syncthreads();
-    if (threadIdx.x < 4) {
-      int k = threadIdx.x;
-      atomicAdd(&stats[k], red[k][0] + red[k][1] + red[k][2] + red[k][3]);
-    }
+    block_stats_out(stats, 4, red, ordered, counter);
   }
 }
 
@@ -390,23 +414,23 @@ __global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __re
 int s2st_mel_loss(const float* feat, const float* post, const float* eos, const float* tgt,
                   const int* lens, int B, int D, int F, float pos_weight, float* stats, float c_l1,
                   float c_mse, float c_eos, float* dfeat, float* dpost, float* deos,
-                  hipStream_t st) {
+                  hipStream_t st, float* ordered, unsigned* counter) {
   long n = (long)B * D * F;
   if (n <= 0) return 0;
   long blocks = (n + 256 * 4 - 1) / (256 * 4);
   if (blocks > 2048) blocks = 2048;
   S2ST_LAUNCH(mel_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, st, feat, post, eos, tgt,
-                     lens, B, D, F, pos_weight, stats, c_l1, c_mse, c_eos, dfeat, dpost, deos);
+                     lens, B, D, F, pos_weight, stats, c_l1, c_mse, c_eos, dfeat, dpost, deos, ordered, counter);
   return LAUNCH_OK();
 }
 
 int s2st_ls_ce(const float* logits, const long* target, int rows, int V, long pad, float eps,
-               float* stats, float* dlogits, float gscale, hipStream_t st) {
+               float* stats, float* dlogits, float gscale, hipStream_t st, float* ordered, unsigned* counter) {
   if (rows <= 0) return 0;
   int blocks = (rows + 3) / 4;
   if (blocks > 1024) blocks = 1024;
   S2ST_LAUNCH(ls_ce_kernel, dim3(blocks), dim3(256), 0, st, logits, target, rows, V, pad, eps,
-                     stats, dlogits, gscale);
+                     stats, dlogits, gscale, ordered, counter);
   return LAUNCH_OK();
 }
 

@@ -288,11 +288,16 @@ int s2st_log_offset(float* x, long n, float eps, hipStream_t st);
 int s2st_mel_loss(const float* feat, const float* post, const float* eos, const float* tgt,
                   const int* lens, int B, int D, int F, float pos_weight, float* stats, float c_l1,
                   float c_mse, float c_eos, float* dfeat, float* dpost, float* deos,
-                  hipStream_t st);
+                  hipStream_t st, float* ordered = nullptr, unsigned* counter = nullptr);
+// ordered / counter (both or neither; also s2st_ls_ce): scratch of S2ST_LOSS_ORDERED_FLOATS floats + a zeroed counter --
+// the workgroups' sums are then added in workgroup order by the last one to finish (no float atomics: the logged
+// sums repeat bit for bit)
+#define S2ST_LOSS_ORDERED_FLOATS (4 * 2048)
 // label-smoothed CE over logits [rows][V]; stats (optional) += {nll_sum, smooth_sum,
 // n_correct, total}; dlogits (optional) = gscale * d/dlogits[(1-eps-eps_i) nll + eps_i smooth]
 int s2st_ls_ce(const float* logits, const long* target, int rows, int V, long pad, float eps,
-               float* stats, float* dlogits, float gscale, hipStream_t st);
+               float* stats, float* dlogits, float gscale, hipStream_t st, float* ordered = nullptr,
+               unsigned* counter = nullptr);
 // log_softmax + CTC (blank 0, zero_infinity).  logits [B][E][V]; targets [B][Lmax];
 // lprobs [B][E][V] (required, also an output); loss_per_utt[b] = nll_b / max(L_b, 1);
 // dlogits (optional) = gscale / max(L_b,1) * (softmax - occupancy), 0 for t >= in_lens[b]
