@@ -327,7 +327,6 @@ enum {
   S2ST_STAT_ST_NLL = 7, S2ST_STAT_ST_SMOOTH = 8, S2ST_STAT_ST_CORRECT = 9, S2ST_STAT_ST_TOTAL = 10,
   S2ST_STAT_LOSS = 16, S2ST_STAT_L1 = 17, S2ST_STAT_MSE = 18, S2ST_STAT_EOS = 19,
   S2ST_STAT_CTC = 20, S2ST_STAT_ASR = 21, S2ST_STAT_ST = 22, S2ST_STAT_CTC_TGT = 23, S2ST_STAT_GNORM = 24
-  /* [28 .. 30]: scratch of the loss kernels (arrival counters of their ordered sums; zero before and after a step) */
 };
 
 typedef struct s2st_engine s2st_engine;

@@ -40,6 +40,41 @@ __global__ __launch_bounds__(256) void copy_rows_bf16_kernel(const uint16_t* __r
   reinterpret_cast<uint2*>(y + split_off(ysp, r))[c] = reinterpret_cast<const uint2*>(x + split_off(xsp, r))[c];
 }
 
+// The conv backward's operand image in ONE pass: y [B][Th][O] bf16 = x's rows at u = pad + stride * t, zeros everywhere
+// else (halos and, for stride 2, the stuffed rows) -- every 16-byte chunk of y is written exactly once (was: a memset of
+// the image + a row copy).  O % 8 == 0.
+__global__ __launch_bounds__(256) void halo_image_bf16_kernel(const uint16_t* __restrict__ x, long ldx,
+                                                              uint16_t* __restrict__ y, int B, int Tout, int Th, int O8,
+                                                              int pad, int stride) {
+  const long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  if (i >= (long)B * Th * O8) return;
+  const int c = (int)(i % O8);
+  const long bu = i / O8;
+  const int u = (int)(bu % Th), b = (int)(bu / Th);
+  const int d = u - pad;
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (d >= 0 && d % stride == 0 && d / stride < Tout)
+    v = reinterpret_cast<const uint4*>(x + ((long)b * Tout + d / stride) * ldx)[c];
+  reinterpret_cast<uint4*>(y)[i] = v;
+}
+
+// bf16 twin of a halo image [B][T + 2 pad][C]: interior rows converted from the fp32 image, halo rows written as zeros
+// WITHOUT reading the fp32 halos (fast mode never reads those, so the fp32 image is not cleared any more: one pass
+// instead of memset + cast).  C % 4 == 0.
+__global__ __launch_bounds__(256) void cast_bf16_halo_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int B,
+                                                             int T, int pad, int C4) {
+  const long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  const int Th = T + 2 * pad;
+  if (i >= (long)B * Th * C4) return;
+  const int u = (int)((i / C4) % Th);
+  uint2 v = make_uint2(0u, 0u);
+  if (u >= pad && u < pad + T) {
+    const float4 f = reinterpret_cast<const float4*>(x)[i];
+    v = pack_bf16x4(f.x, f.y, f.z, f.w);
+  }
+  reinterpret_cast<uint2*>(y)[i] = v;
+}
+
 // fp32 [rows][cols] (row stride ldx) -> bf16 [rows][ldy], columns [cols, ldy) zero-filled.
 // One thread per 4 output columns (ldy % 4 == 0); 16-byte loads when the source row allows.
 __global__ __launch_bounds__(256) void cast_bf16_rows_kernel(const float* __restrict__ x, long ldx,
@@ -616,6 +651,23 @@ int s2st_copy_rows_bf16(const uint16_t* x, Split xsp, uint16_t* y, Split ysp, in
     return S2ST_ERR_SHAPE;
   long n = (long)rows * (C / 4);
   S2ST_LAUNCH(copy_rows_bf16_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, xsp, y, ysp, rows, C / 4);
+  return LAUNCH_OK();
+}
+
+int s2st_halo_image_bf16(const uint16_t* x, long ldx, uint16_t* y, int B, int Tout, int Th, int O, int pad, int stride,
+                         hipStream_t st) {
+  if (B <= 0 || Th <= 0 || O <= 0) return 0;
+  if (O % 8 || ldx % 8 || stride < 1 || ((uintptr_t)x % 16) || ((uintptr_t)y % 16)) return S2ST_ERR_SHAPE;
+  const long n = (long)B * Th * (O / 8);
+  S2ST_LAUNCH(halo_image_bf16_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, ldx, y, B, Tout, Th, O / 8, pad, stride);
+  return LAUNCH_OK();
+}
+
+int s2st_cast_bf16_halo(const float* x, uint16_t* y, int B, int T, int pad, int C, hipStream_t st) {
+  if (B <= 0 || T + 2 * pad <= 0 || C <= 0) return 0;
+  if (C % 4 || ((uintptr_t)x % 16) || ((uintptr_t)y % 8)) return S2ST_ERR_SHAPE;
+  const long n = (long)B * (T + 2 * pad) * (C / 4);
+  S2ST_LAUNCH(cast_bf16_halo_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, y, B, T, pad, C / 4);
   return LAUNCH_OK();
 }
 

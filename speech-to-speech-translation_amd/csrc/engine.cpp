@@ -464,6 +464,13 @@ struct s2st_engine {
     if (live()) chk(s2st_cast_bf16_rows(x, n, y, (n + 7) / 8 * 8, 1, (int)n, st_));
     return y;
   }
+  // bf16 twin of a halo image [B][T + 2 pad][C] with zero halos; fast mode never reads the fp32 image's halos, so the
+  // callers do not clear it (alloc(n, !fast()))
+  bf16raw* cast_halo(const float* img, int B, int T, int pad, int C) {
+    bf16raw* y = alloc_h(((long)B * (T + 2 * pad) * C + 7) / 8 * 8);
+    if (live()) chk(s2st_cast_bf16_halo(img, y, B, T, pad, C, st_));
+    return y;
+  }
   void chk(int rc) { if (rc && !err) err = rc; }
   uint64_t next_seed() { return seed * 0x100000001B3ULL + (++site) * 0x9E3779B97F4A7C15ULL; }
   void mark() { marks.push_back(Mark{tape.size(), param_watermark}); }
@@ -1066,8 +1073,7 @@ struct s2st_engine {
           Split xs{(long)pp.O, 0, 0, 0};
           Split ys{(long)stride * pp.O, (long)Th * pp.O, Tout, 0};
           if (direct) {
-            hipMemsetAsync(upd, 0, sizeof(bf16raw) * (size_t)B * Th * pp.O, st_);
-            chk(s2st_copy_rows_bf16(dzh, xs, upd + (long)pad * pp.O, ys, M, pp.O, st_));
+            chk(s2st_halo_image_bf16(dzh, z->hld(), upd, B, Tout, Th, pp.O, pad, stride, st_));
           } else {
             chk(s2st_copy_rows(z->g, xs, up + (long)pad * pp.O, ys, M, pp.O, st_));
           }
@@ -1264,7 +1270,7 @@ struct s2st_engine {
     const bool fm = fast();
     Ten* cur = feat;  // plain holder of the current layer input
     const int pp = c.postnet_k / 2;
-    float* curh = alloc((long)B * (D + 2 * pp) * c.out_dim, true);
+    float* curh = alloc((long)B * (D + 2 * pp) * c.out_dim, !fm);
     if (live()) {
       Split xs{(long)c.out_dim, 0, 0, 0};
       Split ys{(long)c.out_dim, (long)(D + 2 * pp) * c.out_dim, D, 0};
@@ -1276,7 +1282,7 @@ struct s2st_engine {
       const ConvP& pc = post_conv[i];
       const BNP& bn = post_bn[i];
       const bool last = i == c.postnet_layers - 1;
-      const bf16raw* curhh = fm ? cast_buf(curh, (long)B * (D + 2 * pp) * pc.I) : nullptr;
+      const bf16raw* curhh = fm ? cast_halo(curh, B, D, pp, pc.I) : nullptr;
       Ten* z = conv(ConvIn{curh, cur, D, curhh}, pc, B, 1, csp[i]);
       float* mean = alloc(bn.C);
       float* var = alloc(bn.C);
@@ -1290,7 +1296,7 @@ struct s2st_engine {
         out = newT(B * D, bn.C, post_out);
         osp = Split{(long)bn.C, 0, 0, 0};
       } else {
-        nexth = alloc((long)B * (D + 2 * pp) * bn.C, true);
+        nexth = alloc((long)B * (D + 2 * pp) * bn.C, !fm);
         out = newT(B * D, bn.C, nexth + (long)pp * bn.C);
         osp = Split{(long)bn.C, (long)(D + 2 * pp) * bn.C, D, 0};
       }
@@ -1334,7 +1340,7 @@ struct s2st_engine {
     const bool fm = fast();
     const int C = c.enc_dim, pp = c.enc_conv_k / 2;
     Ten* cur = emb;
-    float* curh = alloc((long)B * (T + 2 * pp) * C, true);
+    float* curh = alloc((long)B * (T + 2 * pp) * C, !fm);
     if (live()) {
       Split xs{(long)C, 0, 0, 0};
       Split ys{(long)C, (long)(T + 2 * pp) * C, T, 0};
@@ -1346,7 +1352,7 @@ struct s2st_engine {
       const ConvP& pc = enc_conv[i];
       const BNP& bn = enc_bn[i];
       const bool last = i == n - 1;
-      const bf16raw* curhh = fm ? cast_buf(curh, (long)B * (T + 2 * pp) * C) : nullptr;
+      const bf16raw* curhh = fm ? cast_halo(curh, B, T, pp, C) : nullptr;
       Ten* z = conv(ConvIn{curh, cur, T, curhh}, pc, B, 1, csp[i]);
       float* mean = alloc(C);
       float* var = alloc(C);
@@ -1360,7 +1366,7 @@ struct s2st_engine {
         out = newT(B * T, C);
         osp = Split{(long)C, 0, 0, 0};
       } else {
-        nexth = alloc((long)B * (T + 2 * pp) * C, true);
+        nexth = alloc((long)B * (T + 2 * pp) * C, !fm);
         out = newT(B * T, C, nexth + (long)pp * C);
         osp = Split{(long)C, (long)(T + 2 * pp) * C, T, 0};
       }
@@ -1618,18 +1624,18 @@ struct s2st_engine {
       x = add_pe(pj, bt.enc_pos, pe_enc, 1.f, enc_pos_alpha, tr ? c.dropout : 0.f);
     } else {
     // ---- encoder front: 2 x (conv k s2 -> GLU), sqrt(C) scale + positions + dropout -------------
-    float* xh0 = alloc((long)B * (S + 2 * pad) * c.in_dim, true);
+    float* xh0 = alloc((long)B * (S + 2 * pad) * c.in_dim, !fm);
     if (live()) {
       Split xs{(long)c.in_dim, 0, 0, 0};
       Split ys{(long)c.in_dim, (long)(S + 2 * pad) * c.in_dim, S, 0};
       chk(s2st_copy_rows(bt.src, xs, xh0 + (long)pad * c.in_dim, ys, B * S, c.in_dim, st_));
     }
-    const bf16raw* xh0h = fm ? cast_buf(xh0, (long)B * (S + 2 * pad) * c.in_dim) : nullptr;
+    const bf16raw* xh0h = fm ? cast_halo(xh0, B, S, pad, c.in_dim) : nullptr;
     Ten* z1 = conv(ConvIn{xh0, nullptr, S, xh0h}, sub[0], B, 2, cs0);
     const int C1 = c.conv_channels / 2;
-    float* g1h = alloc((long)B * (T1 + 2 * pad) * C1, true);
+    float* g1h = alloc((long)B * (T1 + 2 * pad) * C1, !fm);
     Ten* g1 = glu_to(z1, g1h + (long)pad * C1, Split{(long)C1, (long)(T1 + 2 * pad) * C1, T1, 0}, C1);
-    const bf16raw* g1hh = fm ? cast_buf(g1h, (long)B * (T1 + 2 * pad) * C1) : nullptr;
+    const bf16raw* g1hh = fm ? cast_halo(g1h, B, T1, pad, C1) : nullptr;
     Ten* z2 = conv(ConvIn{g1h, g1, T1, g1hh}, sub[1], B, 2, cs1);
     float* x0d = alloc((long)B * E * C);
     Ten* x0 = glu_to(z2, x0d, Split{(long)C, 0, 0, 0}, C);
@@ -1790,22 +1796,24 @@ struct s2st_engine {
       float* loss_ws = alloc(3L * S2ST_LOSS_ORDERED_FLOATS);
       if (live()) {
         hipMemsetAsync(stats, 0, sizeof(float) * 32, st_);
-        // (stats[28 .. 30]: the arrival counters of the three loss kernels' ordered sums, zeroed with the rest)
-        unsigned* cnt = ordered_sums ? reinterpret_cast<unsigned*>(stats + 28) : nullptr;
+        // ordered sums: the loss kernels leave per-workgroup sums, the finalize kernel adds them in workgroup order
+        s2st_loss_parts lp{};
+        float* ow[3] = {nullptr, nullptr, nullptr};
+        if (ordered_sums)
+          for (int q = 0; q < 3; ++q) lp.part[q] = ow[q] = loss_ws + (long)q * S2ST_LOSS_ORDERED_FLOATS;
         chk(s2st_mel_loss(feat->d, post->d, eos->d, bt.tgt, bt.tgt_lens, B, D, c.out_dim, c.bce_pos_weight,
-                          stats + S2ST_STAT_L1_SUM, 0, 0, 0, nullptr, nullptr, nullptr, st_, cnt ? loss_ws : nullptr, cnt));
+                          stats + S2ST_STAT_L1_SUM, 0, 0, 0, nullptr, nullptr, nullptr, st_, ow[0], &lp.nblocks[0]));
         join_side();  // aux logits, CTC per-utterance losses
         if (asr_logits)
           chk(s2st_ls_ce(asr_logits->d, (const long*)bt.src_txt, B * bt.Ls, c.src_vocab, 1, c.label_smoothing,
-                         stats + S2ST_STAT_ASR_NLL, nullptr, 0.f, st_, cnt ? loss_ws + S2ST_LOSS_ORDERED_FLOATS : nullptr,
-                         cnt ? cnt + 1 : nullptr));
+                         stats + S2ST_STAT_ASR_NLL, nullptr, 0.f, st_, ow[1], &lp.nblocks[1]));
         if (st_logits)
           chk(s2st_ls_ce(st_logits->d, (const long*)bt.tgt_txt, B * bt.Lt, c.tgt_vocab, 1, c.label_smoothing,
-                         stats + S2ST_STAT_ST_NLL, nullptr, 0.f, st_, cnt ? loss_ws + 2 * S2ST_LOSS_ORDERED_FLOATS : nullptr,
-                         cnt ? cnt + 2 : nullptr));
+                         stats + S2ST_STAT_ST_NLL, nullptr, 0.f, st_, ow[2], &lp.nblocks[2]));
         chk(s2st_loss_finalize(stats, ctc_per, B, nf, nr, c.w_l1, c.w_mse, c.w_eos, c.ctc_weight,
                                c.asr_weight, c.st_weight, c.label_smoothing, c.src_vocab, c.tgt_vocab,
-                               (float)bt.src_txt_ntokens, (float)bt.tgt_txt_ntokens, st_, ctc_tgt_per, c.ctc_tgt_weight));
+                               (float)bt.src_txt_ntokens, (float)bt.tgt_txt_ntokens, st_, ctc_tgt_per, c.ctc_tgt_weight,
+                               ordered_sums ? &lp : nullptr));
       }
       tape.push_back([=]() {
         // roots of the backward: d loss / d {feat, post, eos, logits}

@@ -14,32 +14,17 @@ __device__ __forceinline__ float softplusf_(float x) {  // log(1 + exp(x)), stab
   return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
 }
 
-// stats[k] += the workgroups' sums, K <= 4 per workgroup.  ordered != null: every workgroup stores its sums, the LAST one to
-// arrive (a counter the caller zeroes with the stats) adds all of them in workgroup order -- the logged losses repeat
-// bit for bit; ordered == null (the stand-alone C-ABI calls): atomics.
+// The workgroups' sums of a loss kernel, K <= 4 per workgroup.  ordered != null: every workgroup stores its sums at
+// ordered[k][blockIdx.x]; loss_finalize_kernel adds them in workgroup order (the logged losses repeat bit for bit; a
+// first form -- the last workgroup to arrive adds them, found through a returning atomic counter -- cost 20 - 40 us per
+// launch: ~1 k returning atomics on one address).  ordered == null (the stand-alone C-ABI calls): float atomics.
 __device__ __forceinline__ void block_stats_out(float* __restrict__ stats, int K, const float (*red)[4],
-                                                float* __restrict__ ordered, unsigned* __restrict__ counter) {
-  __shared__ bool last;
+                                                float* __restrict__ ordered) {
   const int tid = threadIdx.x;
-  if (!ordered) {
-    if (tid < K) atomicAdd(&stats[tid], red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3]);
-    return;
-  }
-  if (tid < K) ordered[(long)tid * gridDim.x + blockIdx.x] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) last = atomicAdd(counter, 1u) == gridDim.x - 1;
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
-  if (tid == 0) *counter = 0;  // left as found
-  const int lane = tid & 63, k = tid >> 6;  // wave k sums output k
-  if (k < K) {
-    float v = 0.f;
-    for (unsigned b = lane; b < gridDim.x; b += 64) v += ordered[(long)k * gridDim.x + b];
-    v = wave_sum(v);
-    if (lane == 0) stats[k] += v;
-  }
+  if (tid >= K) return;
+  const float v = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+  if (ordered) ordered[(long)tid * gridDim.x + blockIdx.x] = v;
+  else atomicAdd(&stats[tid], v);
 }
 
 // One thread per (row, f) element for the mel terms; thread f == 0 of each row also does the
@@ -48,8 +33,7 @@ __global__ __launch_bounds__(256) void mel_loss_kernel(
     const float* __restrict__ feat, const float* __restrict__ post, const float* __restrict__ eos,
     const float* __restrict__ tgt, const int* __restrict__ lens, int B, int D, int F,
     float pos_weight, float* __restrict__ stats, float c_l1, float c_mse, float c_eos,
-    float* __restrict__ dfeat, float* __restrict__ dpost, float* __restrict__ deos, float* __restrict__ ordered,
-    unsigned* __restrict__ counter) {
+    float* __restrict__ dfeat, float* __restrict__ dpost, float* __restrict__ deos, float* __restrict__ ordered) {
   __shared__ float red[3][4];
   const long n = (long)B * D * F;
   float a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -86,7 +70,7 @@ __global__ __launch_bounds__(256) void mel_loss_kernel(
     int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[0][w] = a1; red[1][w] = a2; red[2][w] = a3; }
     __syncthreads();
-    block_stats_out(stats, 3, red, ordered, counter);
+    block_stats_out(stats, 3, red, ordered);
   }
 }
 
@@ -96,7 +80,7 @@ __global__ __launch_bounds__(256) void ls_ce_kernel(const float* __restrict__ lo
                                                     int V, long pad, float eps,
                                                     float* __restrict__ stats,
                                                     float* __restrict__ dlogits, float gscale,
-                                                    float* __restrict__ ordered, unsigned* __restrict__ counter) {
+                                                    float* __restrict__ ordered) {
   __shared__ float red[4][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float nll_a = 0.f, sm_a = 0.f, cor_a = 0.f, tot_a = 0.f;
@@ -144,7 +128,7 @@ __global__ __launch_bounds__(256) void ls_ce_kernel(const float* __restrict__ lo
   if (stats) {
     if (lane == 0) { red[0][wave] = nll_a; red[1][wave] = sm_a; red[2][wave] = cor_a; red[3][wave] = tot_a; }
     __syncthreads();
-    block_stats_out(stats, 4, red, ordered, counter);
+    block_stats_out(stats, 4, red, ordered);
   }
 }
 
@@ -351,7 +335,21 @@ __global__ void loss_finalize_kernel(float* __restrict__ stats, const float* __r
                                      float nf, float nr, float w_l1, float w_mse, float w_eos,
                                      float w_ctc, float w_asr, float w_st, float eps, int Vs, int Vt,
                                      float src_ntok, float tgt_ntok, const float* __restrict__ ctc_tgt_per,
-                                     float w_ctc_tgt) {
+                                     float w_ctc_tgt, s2st_loss_parts parts) {
+  if (parts.on) {  // the loss kernels' per-workgroup sums, added in workgroup order (wave-strided, fixed tree)
+    const int lane = threadIdx.x & 63;
+    for (int o = threadIdx.x >> 6; o < 11; o += blockDim.x >> 6) {
+      const int gi = o < 3 ? 0 : (o < 7 ? 1 : 2), k = o < 3 ? o : (o < 7 ? o - 3 : o - 7);
+      const float* p = parts.part[gi];
+      const int nb = parts.nblocks[gi];
+      if (!p || nb <= 0) continue;
+      float v = 0.f;
+      for (int b = lane; b < nb; b += 64) v += p[(long)k * nb + b];
+      v = wave_sum(v);
+      if (lane == 0) stats[o] = v;
+    }
+    __syncthreads();
+  }
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   float l1 = w_l1 * stats[S2ST_STAT_L1_SUM] / nf;
   float mse = w_mse * stats[S2ST_STAT_MSE_SUM] / nf;
@@ -414,23 +412,25 @@ __global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __re
 int s2st_mel_loss(const float* feat, const float* post, const float* eos, const float* tgt,
                   const int* lens, int B, int D, int F, float pos_weight, float* stats, float c_l1,
                   float c_mse, float c_eos, float* dfeat, float* dpost, float* deos,
-                  hipStream_t st, float* ordered, unsigned* counter) {
+                  hipStream_t st, float* ordered, int* nblocks_out) {
   long n = (long)B * D * F;
   if (n <= 0) return 0;
   long blocks = (n + 256 * 4 - 1) / (256 * 4);
   if (blocks > 2048) blocks = 2048;
   S2ST_LAUNCH(mel_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, st, feat, post, eos, tgt,
-                     lens, B, D, F, pos_weight, stats, c_l1, c_mse, c_eos, dfeat, dpost, deos, ordered, counter);
+                     lens, B, D, F, pos_weight, stats, c_l1, c_mse, c_eos, dfeat, dpost, deos, ordered);
+  if (nblocks_out) *nblocks_out = (int)blocks;
   return LAUNCH_OK();
 }
 
 int s2st_ls_ce(const float* logits, const long* target, int rows, int V, long pad, float eps,
-               float* stats, float* dlogits, float gscale, hipStream_t st, float* ordered, unsigned* counter) {
+               float* stats, float* dlogits, float gscale, hipStream_t st, float* ordered, int* nblocks_out) {
   if (rows <= 0) return 0;
   int blocks = (rows + 3) / 4;
   if (blocks > 1024) blocks = 1024;
   S2ST_LAUNCH(ls_ce_kernel, dim3(blocks), dim3(256), 0, st, logits, target, rows, V, pad, eps,
-                     stats, dlogits, gscale, ordered, counter);
+                     stats, dlogits, gscale, ordered);
+  if (nblocks_out) *nblocks_out = blocks;
   return LAUNCH_OK();
 }
 
@@ -463,9 +463,12 @@ int s2st_ctc(const float* logits, const long* targets, int Lmax, const int* in_l
 
 int s2st_loss_finalize(float* stats, const float* ctc_per, int B, float nf, float nr, float w_l1,
                        float w_mse, float w_eos, float w_ctc, float w_asr, float w_st, float eps, int Vs,
-                       int Vt, float src_ntok, float tgt_ntok, hipStream_t st, const float* ctc_tgt_per, float w_ctc_tgt) {
-  S2ST_LAUNCH(loss_finalize_kernel, dim3(1), dim3(64), 0, st, stats, ctc_per, B, nf, nr, w_l1, w_mse,
-                     w_eos, w_ctc, w_asr, w_st, eps, Vs, Vt, src_ntok, tgt_ntok, ctc_tgt_per, w_ctc_tgt);
+                       int Vt, float src_ntok, float tgt_ntok, hipStream_t st, const float* ctc_tgt_per, float w_ctc_tgt,
+                       const s2st_loss_parts* parts) {
+  s2st_loss_parts pt{};
+  if (parts) { pt = *parts; pt.on = 1; }
+  S2ST_LAUNCH(loss_finalize_kernel, dim3(1), dim3(parts ? 256 : 64), 0, st, stats, ctc_per, B, nf, nr, w_l1, w_mse,
+                     w_eos, w_ctc, w_asr, w_st, eps, Vs, Vt, src_ntok, tgt_ntok, ctc_tgt_per, w_ctc_tgt, pt);
   return LAUNCH_OK();
 }
 

@@ -160,6 +160,11 @@ struct s2st_transpose_table {
 int s2st_transpose_bf16_batched(const uint16_t* x_base, uint16_t* y_base, const s2st_transpose_table& t, hipStream_t st);
 // copy [rows][C] between split-addressed buffers (halo padding, zero-stuffing); C % 4 == 0
 int s2st_copy_rows_bf16(const uint16_t* x, Split xsp, uint16_t* y, Split ysp, int rows, int C, hipStream_t st);
+// bf16 twin of the fp32 halo image x [B][T + 2 pad][C]: interior converted, halos zero (x's halos are not read)
+int s2st_cast_bf16_halo(const float* x, uint16_t* y, int B, int T, int pad, int C, hipStream_t st);
+// y [B][Th][O] = rows of x [B * Tout][ldx] at u = pad + stride * t, zeros elsewhere (the whole image in one pass)
+int s2st_halo_image_bf16(const uint16_t* x, long ldx, uint16_t* y, int B, int Tout, int Th, int O, int pad, int stride,
+                         hipStream_t st);
 int s2st_copy_rows(const float* x, Split xsp, float* y, Split ysp, int rows, int C,
                    hipStream_t st);
 // y[r][c] = a[r][c] * sigmoid(a[r][c + C])   a: [rows][2C] plain ; y rows via split
@@ -288,16 +293,21 @@ int s2st_log_offset(float* x, long n, float eps, hipStream_t st);
 int s2st_mel_loss(const float* feat, const float* post, const float* eos, const float* tgt,
                   const int* lens, int B, int D, int F, float pos_weight, float* stats, float c_l1,
                   float c_mse, float c_eos, float* dfeat, float* dpost, float* deos,
-                  hipStream_t st, float* ordered = nullptr, unsigned* counter = nullptr);
-// ordered / counter (both or neither; also s2st_ls_ce): scratch of S2ST_LOSS_ORDERED_FLOATS floats + a zeroed counter --
-// the workgroups' sums are then added in workgroup order by the last one to finish (no float atomics: the logged
-// sums repeat bit for bit)
+                  hipStream_t st, float* ordered = nullptr, int* nblocks_out = nullptr);
+// ordered (also s2st_ls_ce): scratch of S2ST_LOSS_ORDERED_FLOATS floats -- the workgroups' sums go there instead of into
+// stats by float atomics ([k][nblocks], nblocks returned); s2st_loss_finalize(parts) adds them in workgroup order: the
+// logged sums repeat bit for bit
 #define S2ST_LOSS_ORDERED_FLOATS (4 * 2048)
+struct s2st_loss_parts {  // per loss kernel (mel, ASR CE, ST CE): its scratch and workgroup count (null / 0: not run)
+  const float* part[3];
+  int nblocks[3];
+  int on;
+};
 // label-smoothed CE over logits [rows][V]; stats (optional) += {nll_sum, smooth_sum,
 // n_correct, total}; dlogits (optional) = gscale * d/dlogits[(1-eps-eps_i) nll + eps_i smooth]
 int s2st_ls_ce(const float* logits, const long* target, int rows, int V, long pad, float eps,
                float* stats, float* dlogits, float gscale, hipStream_t st, float* ordered = nullptr,
-               unsigned* counter = nullptr);
+               int* nblocks_out = nullptr);
 // log_softmax + CTC (blank 0, zero_infinity).  logits [B][E][V]; targets [B][Lmax];
 // lprobs [B][E][V] (required, also an output); loss_per_utt[b] = nll_b / max(L_b, 1);
 // dlogits (optional) = gscale / max(L_b,1) * (softmax - occupancy), 0 for t >= in_lens[b]
@@ -310,7 +320,7 @@ int s2st_log_softmax_rows(const float* x, long ldx, float* y, long ldy, int rows
 int s2st_loss_finalize(float* stats, const float* ctc_per, int B, float nf, float nr, float w_l1,
                        float w_mse, float w_eos, float w_ctc, float w_asr, float w_st, float eps, int Vs,
                        int Vt, float src_ntok, float tgt_ntok, hipStream_t st, const float* ctc_tgt_per = nullptr,
-                       float w_ctc_tgt = 0.f);
+                       float w_ctc_tgt = 0.f, const s2st_loss_parts* parts = nullptr);
 
 // ---------------------------------------------------------------------------------------
 // optimizer (optim.hip)

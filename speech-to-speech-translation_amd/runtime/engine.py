@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
@@ -460,6 +461,8 @@ class Engine:
         if self.params_bf16 is not None and getattr(self, "_ph_version", None) == self.params._version:
             self.lib.s2st_engine_bf16_is_fresh(self.h)  # written by the optimizer kernel, parameters untouched since
         self._ph_version = None
+        if os.environ.get("S2ST_POISON_WORKSPACE"):  # debugging aid: a kernel that relies on a cleared workspace shows
+            self.workspace.fill_(float("nan"))
         rc = self.lib.s2st_engine_forward(self.h, C.byref(b), C.byref(out), self.workspace.data_ptr(),
                                           self.workspace.numel(), bd.stream_ptr())
         bd.check(rc, "s2st_engine_forward")

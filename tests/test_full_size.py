@@ -61,7 +61,7 @@ def _grad_close(g, ref, tol):
 def test_step_is_a_function_of_the_seed(backend, workload):
     """Same seed -> the same step: the forward sweep (every output and logged loss) is bit-identical -- all
     of its reductions, BatchNorm statistics included, are fixed-order (the loss sums too: per-workgroup sums added in
-    workgroup order by the last workgroup to finish); so is every sum of the backward: the gradient arena is bit-identical."""
+    workgroup order by the finalize kernel); so is every sum of the backward: the gradient arena is bit-identical."""
     _need_gpu(backend)
     corpus, b = workload
     a, e = _engine(backend, CONFIGS["base_recipe"])
@@ -80,7 +80,6 @@ def test_step_is_a_function_of_the_seed(backend, workload):
         assert torch.equal(o0[k], o1[k]), k
         assert not torch.equal(o0[k], o2[k]), k
     assert torch.equal(o0["stats"], o1["stats"]), (o0["stats"], o1["stats"])  # every logged sum and loss term
-    assert not bool(o0["stats"][28:31].any())  # (the loss kernels' arrival counters are left zero)
     # round 3: no sum of the backward uses atomics any more (bias / embedding / position-scale gradients, CTC occupancies,
     # attention bias partials, layer-norm parameter partials are all folded in a fixed order): the whole gradient arena
     # repeats BIT FOR BIT
