@@ -84,6 +84,36 @@ struct TileRegs {
   }
 };
 
+// sum over the 8 bf16 pairs of two 16-byte chunks (fp32 products and adds)
+__device__ __forceinline__ float dot_bf16x8(const uint4& a, const uint4& b) {
+  const unsigned aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    s += __uint_as_float(aw[i] << 16) * __uint_as_float(bw[i] << 16);
+    s += __uint_as_float(aw[i] & 0xffff0000u) * __uint_as_float(bw[i] & 0xffff0000u);
+  }
+  return s;
+}
+
+// out[row] = sum over the row of x * y for the 32 rows two staged tiles hold (the DH / 8 chunks of a row sit in
+// DH / 8 neighbouring lanes: a DPP row of 16 for DH = 128, half of one for DH = 64)
+template <int DH, int NT>
+__device__ __forceinline__ void tile_rowdots(const TileRegs<DH, NT>& x, const TileRegs<DH, NT>& y, float* out, int tid) {
+  constexpr int CH = DH / 8;
+#pragma unroll
+  for (int i = 0; i < TileRegs<DH, NT>::N; ++i) {
+    const int f = tid + NT * i, row = f / CH, ch = f - row * CH;
+    float s = dot_bf16x8(x.r[i], y.r[i]);
+    if (CH == 16) s = row16_sum(s);
+    else {
+#pragma unroll
+      for (int m = CH / 2; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    }
+    if (ch == 0) out[row] = s;
+  }
+}
+
 // register fragments of 16 rows (clamped) of a [rows][DH] bf16 matrix, A-style (== B-style of X^T)
 template <int DH>
 __device__ __forceinline__ void load_frags(const bf16_t* __restrict__ base, long ld, int r0, int nrows, int lane,
@@ -95,6 +125,7 @@ __device__ __forceinline__ void load_frags(const bf16_t* __restrict__ base, long
 }
 
 __device__ __forceinline__ unsigned pack2(float a, float b) { return pack_bf16x4(a, b, 0.f, 0.f).x; }
+
 
 __device__ __forceinline__ bf16x8 pack_frag(const float (&v)[8]) {
   union { uint4 u; bf16x8 f; } cv;
@@ -318,19 +349,28 @@ __device__ __forceinline__ void flash_bwd_kv_body(const AttnArgs& a, unsigned ch
   for (int d = 0; d < DT; ++d) dk[d] = dv[d] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
 
-  TileRegs<DH, 64 * NW> tq, td;
+  // D[q] = rowsum(dO * O) of the tile's 32 queries (a.dvec == null: no separate kernel ran): the O tile travels in
+  // registers beside the dO tile (same thread -> chunk map: the lanes that hold a row's chunks are neighbours), the
+  // row sums land in LDS with the tile images
+  __shared__ float dsh[32];
+  const bool own_d = a.dvec == nullptr;
+  const bf16_t* ob = own_d ? a.oh + (long)b * a.T * ((long)a.H * DH) + h * DH : nullptr;
+  TileRegs<DH, 64 * NW> tq, td, to;
   if (qbeg < a.T) {
     tq.fetch(qb, a.ldq, qbeg, a.T, tid);
     td.fetch(dob, (long)a.H * DH, qbeg, a.T, tid);
+    if (own_d) to.fetch(ob, (long)a.H * DH, qbeg, a.T, tid);
   }
   for (int qt = qbeg; qt < a.T; qt += 32) {
     __syncthreads();
     tq.commit(q_row, q_tr, tid);
     td.commit(do_row, do_tr, tid);
+    if (own_d) tile_rowdots<DH, 64 * NW>(td, to, dsh, tid);
     __syncthreads();
     if (qt + 32 < a.T) {
       tq.fetch(qb, a.ldq, qt + 32, a.T, tid);
       td.fetch(dob, (long)a.H * DH, qt + 32, a.T, tid);
+      if (own_d) to.fetch(ob, (long)a.H * DH, qt + 32, a.T, tid);
     }
     f32x4 x[2], dp[2];
 #pragma unroll
@@ -354,7 +394,7 @@ __device__ __forceinline__ void flash_bwd_kv_body(const AttnArgs& a, unsigned ch
         float keep = 1.f;
         if (a.drop_p > 0.f) keep = drop_scale(a.seed, (uint64_t)r * a.ld_drop + ki, a.drop_p, inv_keep);
         pdv = p * keep;
-        dsv = p * (keep * dp[e >> 2][e & 3] - a.dvec[r]);
+        dsv = p * (keep * dp[e >> 2][e & 3] - (own_d ? dsh[q - qt] : a.dvec[r]));
       }
       pd[e] = pdv;
       ds[e] = dsv;
@@ -410,7 +450,24 @@ __device__ __forceinline__ void flash_bwd_q_body(const AttnArgs& a, unsigned cha
   const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
   const bool q_ok = qi < a.T;
   const long r = (long)bh * a.T + min(qi, a.T - 1);
-  const float lse = a.lse[r], dvec = a.dvec[r];
+  const float lse = a.lse[r];
+  float dvec;
+  if (a.dvec) dvec = a.dvec[r];
+  else {  // D[q] from the bf16 dO fragments this lane already holds and the matching fragments of O
+    bf16x8 of[KS];
+    load_frags<DH>(a.oh + (long)b * a.T * ((long)a.H * DH) + h * DH, (long)a.H * DH, q0, a.T, lane, of);
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      union { bf16x8 f; uint4 u; } cx, cy;
+      cx.f = dof[ks];
+      cy.f = of[ks];
+      s += dot_bf16x8(cx.u, cy.u);
+    }
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    dvec = s;
+  }
   const uint64_t drow = (uint64_t)r * a.ld_drop;
 
   TileRegs<DH, 64 * NW> tk, tv;
@@ -578,10 +635,15 @@ void s2st_flash_attn_db_layout(const s2st_attn_args* p, int* slots_q, int* slots
 
 int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_scratch, hipStream_t st, int phase,
                         float* db_part) {
-  if (!p || !attn_args_ok(*p) || !p->doh || !dO || !dvec_scratch || (!p->dq && !p->dqh) || (!p->dk && !p->dkh) || (!p->dv && !p->dvh) || !p->lse || !p->o)
+  if (!p || !attn_args_ok(*p) || !p->doh || (!p->dq && !p->dqh) || (!p->dk && !p->dkh) || (!p->dv && !p->dvh) || !p->lse)
     return S2ST_ERR_ARG;
+  // D = rowsum(dO * O): inside the backward kernels from the bf16 copies when the forward left one of O (no separate
+  // launch; S2ST_ATTN_DVEC_KERNEL=1, the A/B switch (read per call: tests flip it), or no bf16 O: the fp32 row kernel first)
+  const bool dvec_kernel = getenv("S2ST_ATTN_DVEC_KERNEL") && atoi(getenv("S2ST_ATTN_DVEC_KERNEL")) != 0;
+  const bool own_d = p->oh && !dvec_kernel && phase == 0;
+  if (!own_d && (!dO || !dvec_scratch || !p->o)) return S2ST_ERR_ARG;
   AttnArgs a = to_args(*p);
-  a.dvec = dvec_scratch;
+  a.dvec = own_d ? nullptr : dvec_scratch;
   // bias gradients without atomics: the kernels write per-(block, wave) partial sums, folded in slot order below
   const int nwp = attn_nw();
   const long Cp = (long)p->H * p->dh;
@@ -594,7 +656,7 @@ int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_sc
     a.dbv = p->dbv ? db_part + (slots_q + slots_k) * Cp : nullptr;
   }
   const long rows = (long)p->B * p->T * p->H;
-  if (phase > 1) {
+  if (phase > 1 || own_d) {
   } else if (p->dh == 128)
     S2ST_LAUNCH(attn_dvec_kernel<128>, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, st, dO,
                        (const float*)p->o, dvec_scratch, p->B, p->H, p->T);

@@ -184,9 +184,12 @@ class AttnArgs(C.Structure):
                 ("dbv", C.c_void_p)]
 
 
-def flash_attention(q, k, v, H, *, klen=None, causal=False, scale=None, drop_p=0.0, seed=0, dO=None, bf16_grads=False):
+def flash_attention(q, k, v, H, *, klen=None, causal=False, scale=None, drop_p=0.0, seed=0, dO=None, bf16_grads=False,
+                    bf16_o=False):
     """Fused attention on bf16 [B, T, H*dh] / [B, S, H*dh] projections (s2st_flash_attn_*_bf16).
-    Returns (o fp32, lse) and, when dO (fp32 [B, T, H*dh]) is given, also (dq, dk, dv) fp32."""
+    Returns (o fp32, lse) and, when dO (fp32 [B, T, H*dh]) is given, also (dq, dk, dv) fp32.  ``bf16_o``: the forward also
+    leaves the bf16 copy of o (what the engine does); the backward then forms D = rowsum(dO * o) inside its kernels from
+    the bf16 copies instead of running the fp32 row kernel first."""
     require_device(q)
     B, T, Cm = q.shape
     S = k.shape[1]
@@ -196,7 +199,8 @@ def flash_attention(q, k, v, H, *, klen=None, causal=False, scale=None, drop_p=0
     a.ldq = a.ldk = a.ldv = Cm
     o = torch.zeros(B, T, Cm, dtype=torch.float32, device=q.device)
     lse = torch.zeros(B * H * T, dtype=torch.float32, device=q.device)
-    a.o, a.oh, a.lse, a.klen = o.data_ptr(), None, lse.data_ptr(), ptr(klen)
+    oh = torch.zeros(B, T, Cm, dtype=torch.bfloat16, device=q.device) if bf16_o else None
+    a.o, a.oh, a.lse, a.klen = o.data_ptr(), ptr(oh), lse.data_ptr(), ptr(klen)
     a.B, a.H, a.T, a.S, a.dh, a.causal = B, H, T, S, dh, 1 if causal else 0
     a.scale = scale if scale is not None else dh ** -0.5
     a.drop_p, a.seed, a.ld_drop = drop_p, seed, (S + 7) // 8 * 8

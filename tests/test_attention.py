@@ -36,7 +36,8 @@ def rel(x, y):
 
 @pytest.mark.parametrize("dh,H", [(64, 2), (128, 1)])
 @pytest.mark.parametrize("causal", [False, True])
-def test_flash_attention_fwd_bwd(backend, dh, H, causal):
+@pytest.mark.parametrize("bf16_o", [False, True], ids=["dvec_kernel", "d_in_kernel"])
+def test_flash_attention_fwd_bwd(backend, dh, H, causal, bf16_o):
     B, T, S = 2, 37, 37 if causal else 45
     Cm = H * dh
     g = torch.Generator().manual_seed(dh + 7 * causal)
@@ -47,7 +48,7 @@ def test_flash_attention_fwd_bwd(backend, dh, H, causal):
     klen = torch.tensor([S, S - 9], dtype=torch.int32)
     d = backend.device
     o, lse, dq, dk, dv = backend.bd.flash_attention(q.to(d), k.to(d), v.to(d), H, klen=klen.to(d), causal=causal,
-                                                    dO=dO.to(d))
+                                                    dO=dO.to(d), bf16_o=bf16_o)
     backend.sync()
     ro, rl, rq, rk, rv = reference(q.float(), k.float(), v.float(), H, klen.long(), causal,
                                    dO.to(torch.bfloat16).float())
@@ -58,7 +59,7 @@ def test_flash_attention_fwd_bwd(backend, dh, H, causal):
     assert float(dk[1, S - 9:].abs().max()) == 0.0 and float(dv[1, S - 9:].abs().max()) == 0.0
     # bf16 gradient copies + fused bias-gradient column sums
     _, _, dq2, dk2, dv2, (dqh, dkh, dvh, dbq, dbk, dbv) = backend.bd.flash_attention(
-        q.to(d), k.to(d), v.to(d), H, klen=klen.to(d), causal=causal, dO=dO.to(d), bf16_grads=True)
+        q.to(d), k.to(d), v.to(d), H, klen=klen.to(d), causal=causal, dO=dO.to(d), bf16_grads=True, bf16_o=bf16_o)
     backend.sync()
     for full, half, db in ((dq2, dqh, dbq), (dk2, dkh, dbk), (dv2, dvh, dbv)):
         assert torch.equal(half.cpu(), full.cpu().to(torch.bfloat16))

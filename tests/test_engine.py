@@ -315,7 +315,7 @@ def test_dropout_training_runs_and_is_seeded(backend):
 @pytest.mark.parametrize("switch", ["S2ST_NO_LN_FUSE", "S2ST_NO_KV_HOIST", "S2ST_NO_ACT_FUSE", "S2ST_ATTN_GFUSE=0", "S2ST_ATTN_GFUSE=2", "S2ST_ATTN_GFUSE=3",
                                     "S2ST_WGRAD_MAIN_EVERY=3", "S2ST_TRANSPOSE_EACH", "S2ST_NO_WGRAD_GROUP",
                                     "S2ST_GEMM_PERSIST=0", "S2ST_ATTN_BWD_SPLIT", "S2ST_ORDERED_BIAS_SUMS=0", "S2ST_LN_BWD_SPLIT",
-                                    "S2ST_GEMM_W4=2"])
+                                    "S2ST_GEMM_W4=2", "S2ST_ATTN_DVEC_KERNEL"])
 def test_fused_backward_paths_equal_the_unfused_ones(backend, cfg, switch, monkeypatch):
     """The oracle cannot reproduce the dropout masks, so fusions that only exist with dropout on are checked
     against the engine's own unfused schedule (A/B switch) with the same seed: the layer-norm backward that also
@@ -347,7 +347,8 @@ def test_fused_backward_paths_equal_the_unfused_ones(backend, cfg, switch, monke
     # the compiler contracts the two kernels' multiply-adds differently, the emulator build does not -- and ONE bf16
     # operand of the 64-wide micro model rounding the other way moves the gradients behind it by ~5e-4:
     # tools/debug_lnsplit3.py, profiles/r03_e_ln_schedules_dump_compare.txt)
-    tol = 50.0 if switch.startswith(("S2ST_ATTN_GFUSE", "S2ST_NO_LN_FUSE", "S2ST_LN_BWD_SPLIT")) else 1.0
+    # (and D = rowsum(dO * O) of the attention backward from the bf16 copies inside the kernels vs the fp32 row kernel)
+    tol = 50.0 if switch.startswith(("S2ST_ATTN_GFUSE", "S2ST_NO_LN_FUSE", "S2ST_LN_BWD_SPLIT", "S2ST_ATTN_DVEC_KERNEL")) else 1.0
     worst = sorted(((float((v0[n] - v1[n]).norm()), float(v0[n].norm()), n) for n in v0), reverse=True)[:5]
     assert float((g0 - g1).norm()) <= tol * 2e-5 * float(g0.norm()), worst
     gmax = max(float(v.norm()) for v in v0.values())
