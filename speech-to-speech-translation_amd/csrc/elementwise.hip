@@ -6,6 +6,8 @@
 // (scale + sinusoidal positions + dropout), fairseq/models/text_to_speech/tacotron2.py:101-126
 // (BatchNorm1d + tanh + dropout in the post-net), transformer_decoder.py:303-320 (token
 // embedding), fairseq/modules/fairseq_dropout.py:16-27.
+#include <cstdlib>
+
 #include "s2st_ops.h"
 #include "s2st_prof.h"
 
@@ -61,15 +63,18 @@ __global__ __launch_bounds__(256) void halo_image_bf16_kernel(const uint16_t* __
 // bf16 twin of a halo image [B][T + 2 pad][C]: interior rows converted from the fp32 image, halo rows written as zeros
 // WITHOUT reading the fp32 halos (fast mode never reads those, so the fp32 image is not cleared any more: one pass
 // instead of memset + cast).  C % 4 == 0.
+// (plain != 0: x is the plain rows [B * T][C] instead of the fp32 image -- the first convolution of a stack)
 __global__ __launch_bounds__(256) void cast_bf16_halo_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int B,
-                                                             int T, int pad, int C4) {
+                                                             int T, int pad, int C4, int plain) {
   const long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
   const int Th = T + 2 * pad;
   if (i >= (long)B * Th * C4) return;
-  const int u = (int)((i / C4) % Th);
+  const long bu = i / C4;
+  const int u = (int)(bu % Th);
   uint2 v = make_uint2(0u, 0u);
   if (u >= pad && u < pad + T) {
-    const float4 f = reinterpret_cast<const float4*>(x)[i];
+    const long src = plain ? ((bu / Th) * T + (u - pad)) * C4 + (i - bu * C4) : i;
+    const float4 f = reinterpret_cast<const float4*>(x)[src];
     v = pack_bf16x4(f.x, f.y, f.z, f.w);
   }
   reinterpret_cast<uint2*>(y)[i] = v;
@@ -544,6 +549,48 @@ struct SqDevF {
   }
 };
 
+// One pass over x: d = x - x[row 0] (a data sample of the column: |mean - shift| is a few standard deviations at most, so
+// var = E[d^2] - E[d]^2 loses ~10 ulp where the unshifted form can lose everything), returns {d, d^2}
+struct ShiftSqF {
+  const float* x; int C;
+  __device__ float2 operator()(int r, int c) const {
+    const float d = x[(long)r * C + c] - x[c];
+    return make_float2(d, d * d);
+  }
+};
+// part: the slab partials [slabs][2][C] of {d, d^2} (folded here, in slab order); x0 = row 0 of x (the shift)
+__global__ __launch_bounds__(256) void bn_finalize_shift_kernel(const float* __restrict__ x0, const float* __restrict__ part,
+                                                                int slabs, float* __restrict__ mean,
+                                                                float* __restrict__ var, float* __restrict__ run_mean,
+                                                                float* __restrict__ run_var, int C, int rows,
+                                                                float momentum) {
+  int c = blockIdx.x * EW_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int sb = 0; sb < slabs; sb += 16) {
+    float v1[16], v2[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const long s = min(sb + j, slabs - 1);
+      v1[j] = part[(s * 2 + 0) * C + c];
+      v2[j] = part[(s * 2 + 1) * C + c];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (sb + j < slabs) { s1 += v1[j]; s2 += v2[j]; }
+  }
+  const float d1 = s1 / rows;
+  const float m = x0[c] + d1;
+  const float v = fmaxf(s2 / rows - d1 * d1, 0.f);
+  mean[c] = m;
+  var[c] = v;
+  if (run_mean) {
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * m;
+    float unb = rows > 1 ? v * ((float)rows / (float)(rows - 1)) : v;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * unb;
+  }
+}
+
 // sq_part: the squared-deviation slab partials [slabs][2][C] (folded here, in slab order)
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sum,
                                                           const float* __restrict__ sq_part, int slabs,
@@ -589,6 +636,38 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
   if (drop_p > 0.f) u *= drop_scale(seed, (uint64_t)i, drop_p, 1.f / (1.f - drop_p));
   if (resid) u += resid[i];
   y[split_off(ysp, r) + c] = u;
+}
+
+// The same transform written as the NEXT convolution's operand: a bf16 halo image [B][T + 2 pad][C] (zero halos, one
+// 8-byte store per 4 channels) and, optionally, the fp32 result rows y [B * T][C] -- no fp32 image, no memset, no cast pass
+__global__ __launch_bounds__(256) void bn_apply_img_kernel(
+    const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ var,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y, uint16_t* __restrict__ img,
+    int B, int T, int pad, int C4, float eps, int tanh_, float drop_p, uint64_t seed) {
+  const long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
+  const int Th = T + 2 * pad;
+  if (i >= (long)B * Th * C4) return;
+  const int c = (int)(i % C4) * 4;
+  const long bu = i / C4;
+  const int u = (int)(bu % Th), b = (int)(bu / Th);
+  uint2 h = make_uint2(0u, 0u);
+  if (u >= pad && u < pad + T) {
+    const long e0 = ((long)b * T + (u - pad)) * (4L * C4) + c;  // element index in the plain [B * T][C] rows
+    const float4 xv = *reinterpret_cast<const float4*>(x + e0);
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float t = gamma[c + k] * (xs[k] - mean[c + k]) * rsqrtf(var[c + k] + eps) + beta[c + k];
+      if (tanh_ == 1) t = tanhf(t);
+      else if (tanh_ == 2) t = fmaxf(t, 0.f);
+      if (drop_p > 0.f) t *= drop_scale(seed, (uint64_t)(e0 + k), drop_p, 1.f / (1.f - drop_p));
+      o[k] = t;
+    }
+    if (y) *reinterpret_cast<float4*>(y + e0) = make_float4(o[0], o[1], o[2], o[3]);
+    h = pack_bf16x4(o[0], o[1], o[2], o[3]);
+  }
+  reinterpret_cast<uint2*>(img)[i] = h;
 }
 
 // du = dy * dropmask * (1 - tanh^2)   (recomputed from x);  returns {du, du * xhat}
@@ -663,11 +742,11 @@ int s2st_halo_image_bf16(const uint16_t* x, long ldx, uint16_t* y, int B, int To
   return LAUNCH_OK();
 }
 
-int s2st_cast_bf16_halo(const float* x, uint16_t* y, int B, int T, int pad, int C, hipStream_t st) {
+int s2st_cast_bf16_halo(const float* x, uint16_t* y, int B, int T, int pad, int C, hipStream_t st, int plain) {
   if (B <= 0 || T + 2 * pad <= 0 || C <= 0) return 0;
   if (C % 4 || ((uintptr_t)x % 16) || ((uintptr_t)y % 8)) return S2ST_ERR_SHAPE;
   const long n = (long)B * (T + 2 * pad) * (C / 4);
-  S2ST_LAUNCH(cast_bf16_halo_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, y, B, T, pad, C / 4);
+  S2ST_LAUNCH(cast_bf16_halo_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, y, B, T, pad, C / 4, plain);
   return LAUNCH_OK();
 }
 
@@ -905,9 +984,18 @@ int s2st_conv_w_unpermute_acc(const float* dwf, float* dw, int O, int I, int Kw,
 int s2st_bn_stats(const float* x, int rows, int C, float* mean, float* var, float* run_mean,
                   float* run_var, float momentum, float* tmp, hipStream_t st) {
   if (rows <= 0 || C <= 0) return 0;
+  // one pass (shifted sums; 2 launches) unless S2ST_BN_TWO_PASS=1 (round 1-2 form: mean, then squared deviations; 4)
+  static const bool two_pass = getenv("S2ST_BN_TWO_PASS") && atoi(getenv("S2ST_BN_TWO_PASS")) != 0;
+  int slabs = 0;
+  if (!two_pass) {
+    int rc = colreduce2(ShiftSqF{x, C}, rows, C, nullptr, nullptr, tmp + 2 * (long)C, st, nullptr, nullptr, &slabs);
+    if (rc) return rc;
+    S2ST_LAUNCH(bn_finalize_shift_kernel, dim3((C + EW_BLOCK - 1) / EW_BLOCK), dim3(EW_BLOCK), 0, st, x,
+                (const float*)(tmp + 2 * (long)C), slabs, mean, var, run_mean, run_var, C, rows, momentum);
+    return LAUNCH_OK();
+  }
   int rc = colreduce2(SumF{x, C}, rows, C, tmp, nullptr, tmp + 2 * (long)C, st);
   if (rc) return rc;
-  int slabs = 0;
   rc = colreduce2(SqDevF{x, tmp, C, 1.f / rows}, rows, C, nullptr, nullptr, tmp + 2 * (long)C, st, nullptr, nullptr, &slabs);
   if (rc) return rc;
   S2ST_LAUNCH(bn_finalize_kernel, dim3((C + EW_BLOCK - 1) / EW_BLOCK), dim3(EW_BLOCK), 0, st,
@@ -923,6 +1011,17 @@ int s2st_bn_apply(const float* x, const float* mean, const float* var, const flo
   if (n <= 0) return 0;
   S2ST_LAUNCH(bn_apply_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, mean, var, gamma,
                      beta, y, ysp, resid, rows, C, eps, tanh_, drop_p, seed);
+  return LAUNCH_OK();
+}
+
+int s2st_bn_apply_img(const float* x, const float* mean, const float* var, const float* gamma, const float* beta, float* y,
+                      uint16_t* img, int B, int T, int pad, int C, float eps, int tanh_, float drop_p, uint64_t seed,
+                      hipStream_t st) {
+  if (B <= 0 || T <= 0 || C <= 0) return 0;
+  if (C % 4 || ((uintptr_t)x % 16) || ((uintptr_t)img % 8) || (y && (uintptr_t)y % 16)) return S2ST_ERR_SHAPE;
+  const long n = (long)B * (T + 2 * pad) * (C / 4);
+  S2ST_LAUNCH(bn_apply_img_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, mean, var, gamma, beta, y, img, B, T, pad, C / 4,
+              eps, tanh_, drop_p, seed);
   return LAUNCH_OK();
 }
 

@@ -466,9 +466,10 @@ struct s2st_engine {
   }
   // bf16 twin of a halo image [B][T + 2 pad][C] with zero halos; fast mode never reads the fp32 image's halos, so the
   // callers do not clear it (alloc(n, !fast()))
-  bf16raw* cast_halo(const float* img, int B, int T, int pad, int C) {
+  // (plain: img is the plain rows [B * T][C] -- the first convolution of a stack needs no fp32 image at all)
+  bf16raw* cast_halo(const float* img, int B, int T, int pad, int C, bool plain = false) {
     bf16raw* y = alloc_h(((long)B * (T + 2 * pad) * C + 7) / 8 * 8);
-    if (live()) chk(s2st_cast_bf16_halo(img, y, B, T, pad, C, st_));
+    if (live()) chk(s2st_cast_bf16_halo(img, y, B, T, pad, C, st_, plain ? 1 : 0));
     return y;
   }
   void chk(int rc) { if (rc && !err) err = rc; }
@@ -1270,19 +1271,21 @@ struct s2st_engine {
     const bool fm = fast();
     Ten* cur = feat;  // plain holder of the current layer input
     const int pp = c.postnet_k / 2;
-    float* curh = alloc((long)B * (D + 2 * pp) * c.out_dim, !fm);
-    if (live()) {
+    // fast mode: the convolutions read bf16 halo images only -- the first one straight from feat's rows, the others
+    // written by the BatchNorm kernel of the layer before (no fp32 images, no memsets, no cast passes)
+    float* curh = fm ? nullptr : alloc((long)B * (D + 2 * pp) * c.out_dim, true);
+    if (live() && !fm) {
       Split xs{(long)c.out_dim, 0, 0, 0};
       Split ys{(long)c.out_dim, (long)(D + 2 * pp) * c.out_dim, D, 0};
       chk(s2st_copy_rows(feat->d, xs, curh + (long)pp * c.out_dim, ys, B * D, c.out_dim, st_));
     }
+    const bf16raw* curhh = fm ? cast_halo(feat->d, B, D, pp, c.out_dim, true) : nullptr;
     Ten* post = nullptr;
     float* bn_tmp = alloc(S2ST_BN_TMP_FLOATS(c.postnet_dim > c.out_dim ? c.postnet_dim : c.out_dim));
     for (int i = 0; i < c.postnet_layers; ++i) {
       const ConvP& pc = post_conv[i];
       const BNP& bn = post_bn[i];
       const bool last = i == c.postnet_layers - 1;
-      const bf16raw* curhh = fm ? cast_halo(curh, B, D, pp, pc.I) : nullptr;
       Ten* z = conv(ConvIn{curh, cur, D, curhh}, pc, B, 1, csp[i]);
       float* mean = alloc(bn.C);
       float* var = alloc(bn.C);
@@ -1290,13 +1293,18 @@ struct s2st_engine {
       const float pdrop = tr ? c.postnet_dropout : 0.f;
       const uint64_t sd = pdrop > 0.f ? next_seed() : 0;
       float* nexth = nullptr;
+      bf16raw* nexthh = nullptr;
       Ten* out;
       Split osp;
       if (last) {
         out = newT(B * D, bn.C, post_out);
         osp = Split{(long)bn.C, 0, 0, 0};
+      } else if (fm) {
+        nexthh = alloc_h(((long)B * (D + 2 * pp) * bn.C + 7) / 8 * 8);
+        out = newT(B * D, bn.C, nullptr, false);  // (only its gradient is ever used)
+        osp = Split{(long)bn.C, 0, 0, 0};
       } else {
-        nexth = alloc((long)B * (D + 2 * pp) * bn.C, !fm);
+        nexth = alloc((long)B * (D + 2 * pp) * bn.C, true);
         out = newT(B * D, bn.C, nexth + (long)pp * bn.C);
         osp = Split{(long)bn.C, (long)(D + 2 * pp) * bn.C, D, 0};
       }
@@ -1306,8 +1314,11 @@ struct s2st_engine {
           chk(s2st_bn_stats(z->d, B * D, bn.C, mean, var, BUF + bn.rm, BUF + bn.rv, 0.1f, bn_tmp, st_));
           m = mean; v = var;
         }
-        chk(s2st_bn_apply(z->d, m, v, P + bn.g, P + bn.b, out->d, osp, last ? feat->d : nullptr, B * D,
-                          bn.C, 1e-5f, last ? 0 : 1, pdrop, sd, st_));
+        if (nexthh)
+          chk(s2st_bn_apply_img(z->d, m, v, P + bn.g, P + bn.b, nullptr, nexthh, B, D, pp, bn.C, 1e-5f, 1, pdrop, sd, st_));
+        else
+          chk(s2st_bn_apply(z->d, m, v, P + bn.g, P + bn.b, out->d, osp, last ? feat->d : nullptr, B * D,
+                            bn.C, 1e-5f, last ? 0 : 1, pdrop, sd, st_));
       }
       BNP bnp = bn;
       tape.push_back([=]() {
@@ -1328,6 +1339,7 @@ struct s2st_engine {
       });
       cur = out;
       curh = nexth;
+      curhh = nexthh;
       if (last) post = out;
     }
     return post;
@@ -1340,19 +1352,19 @@ struct s2st_engine {
     const bool fm = fast();
     const int C = c.enc_dim, pp = c.enc_conv_k / 2;
     Ten* cur = emb;
-    float* curh = alloc((long)B * (T + 2 * pp) * C, !fm);
-    if (live()) {
+    float* curh = fm ? nullptr : alloc((long)B * (T + 2 * pp) * C, true);
+    if (live() && !fm) {
       Split xs{(long)C, 0, 0, 0};
       Split ys{(long)C, (long)(T + 2 * pp) * C, T, 0};
       chk(s2st_copy_rows(emb->d, xs, curh + (long)pp * C, ys, B * T, C, st_));
     }
+    const bf16raw* curhh = fm ? cast_halo(emb->d, B, T, pp, C, true) : nullptr;  // (as in postnet())
     float* bn_tmp = alloc(S2ST_BN_TMP_FLOATS(C));
     const int n = (int)enc_conv.size();
     for (int i = 0; i < n; ++i) {
       const ConvP& pc = enc_conv[i];
       const BNP& bn = enc_bn[i];
       const bool last = i == n - 1;
-      const bf16raw* curhh = fm ? cast_halo(curh, B, T, pp, C) : nullptr;
       Ten* z = conv(ConvIn{curh, cur, T, curhh}, pc, B, 1, csp[i]);
       float* mean = alloc(C);
       float* var = alloc(C);
@@ -1360,13 +1372,18 @@ struct s2st_engine {
       const float pdrop = tr ? c.enc_dropout : 0.f;
       const uint64_t sd = pdrop > 0.f ? next_seed() : 0;
       float* nexth = nullptr;
+      bf16raw* nexthh = nullptr;
       Ten* out;
       Split osp;
       if (last) {
         out = newT(B * T, C);
         osp = Split{(long)C, 0, 0, 0};
+      } else if (fm) {
+        nexthh = alloc_h(((long)B * (T + 2 * pp) * C + 7) / 8 * 8);
+        out = newT(B * T, C, nullptr, false);
+        osp = Split{(long)C, 0, 0, 0};
       } else {
-        nexth = alloc((long)B * (T + 2 * pp) * C, !fm);
+        nexth = alloc((long)B * (T + 2 * pp) * C, true);
         out = newT(B * T, C, nexth + (long)pp * C);
         osp = Split{(long)C, (long)(T + 2 * pp) * C, T, 0};
       }
@@ -1376,7 +1393,10 @@ struct s2st_engine {
           chk(s2st_bn_stats(z->d, B * T, C, mean, var, BUF + bn.rm, BUF + bn.rv, 0.1f, bn_tmp, st_));
           m = mean; v = var;
         }
-        chk(s2st_bn_apply(z->d, m, v, P + bn.g, P + bn.b, out->d, osp, nullptr, B * T, C, 1e-5f, 2 /* ReLU */, pdrop, sd, st_));
+        if (nexthh)
+          chk(s2st_bn_apply_img(z->d, m, v, P + bn.g, P + bn.b, nullptr, nexthh, B, T, pp, C, 1e-5f, 2 /* ReLU */, pdrop, sd, st_));
+        else
+          chk(s2st_bn_apply(z->d, m, v, P + bn.g, P + bn.b, out->d, osp, nullptr, B * T, C, 1e-5f, 2 /* ReLU */, pdrop, sd, st_));
       }
       BNP bnp = bn;
       tape.push_back([=]() {
@@ -1392,6 +1412,7 @@ struct s2st_engine {
       });
       cur = out;
       curh = nexth;
+      curhh = nexthh;
     }
     return cur;
   }
@@ -1624,13 +1645,13 @@ struct s2st_engine {
       x = add_pe(pj, bt.enc_pos, pe_enc, 1.f, enc_pos_alpha, tr ? c.dropout : 0.f);
     } else {
     // ---- encoder front: 2 x (conv k s2 -> GLU), sqrt(C) scale + positions + dropout -------------
-    float* xh0 = alloc((long)B * (S + 2 * pad) * c.in_dim, !fm);
-    if (live()) {
+    float* xh0 = fm ? nullptr : alloc((long)B * (S + 2 * pad) * c.in_dim, true);
+    if (live() && !fm) {
       Split xs{(long)c.in_dim, 0, 0, 0};
       Split ys{(long)c.in_dim, (long)(S + 2 * pad) * c.in_dim, S, 0};
       chk(s2st_copy_rows(bt.src, xs, xh0 + (long)pad * c.in_dim, ys, B * S, c.in_dim, st_));
     }
-    const bf16raw* xh0h = fm ? cast_halo(xh0, B, S, pad, c.in_dim) : nullptr;
+    const bf16raw* xh0h = fm ? cast_halo(bt.src, B, S, pad, c.in_dim, true) : nullptr;
     Ten* z1 = conv(ConvIn{xh0, nullptr, S, xh0h}, sub[0], B, 2, cs0);
     const int C1 = c.conv_channels / 2;
     float* g1h = alloc((long)B * (T1 + 2 * pad) * C1, !fm);

@@ -161,7 +161,8 @@ int s2st_transpose_bf16_batched(const uint16_t* x_base, uint16_t* y_base, const 
 // copy [rows][C] between split-addressed buffers (halo padding, zero-stuffing); C % 4 == 0
 int s2st_copy_rows_bf16(const uint16_t* x, Split xsp, uint16_t* y, Split ysp, int rows, int C, hipStream_t st);
 // bf16 twin of the fp32 halo image x [B][T + 2 pad][C]: interior converted, halos zero (x's halos are not read)
-int s2st_cast_bf16_halo(const float* x, uint16_t* y, int B, int T, int pad, int C, hipStream_t st);
+// plain != 0: x is the plain rows [B * T][C]
+int s2st_cast_bf16_halo(const float* x, uint16_t* y, int B, int T, int pad, int C, hipStream_t st, int plain = 0);
 // y [B][Th][O] = rows of x [B * Tout][ldx] at u = pad + stride * t, zeros elsewhere (the whole image in one pass)
 int s2st_halo_image_bf16(const uint16_t* x, long ldx, uint16_t* y, int B, int Tout, int Th, int O, int pad, int stride,
                          hipStream_t st);
@@ -222,6 +223,11 @@ int s2st_bn_stats(const float* x, int rows, int C, float* mean, float* var, floa
 int s2st_bn_apply(const float* x, const float* mean, const float* var, const float* gamma,
                   const float* beta, float* y, Split ysp, const float* resid, int rows, int C,
                   float eps, int tanh_, float drop_p, uint64_t seed, hipStream_t st);
+// the same transform as the next convolution's operand: bf16 halo image img [B][T + 2 pad][C] with zero halos, and
+// (y != null) the fp32 result rows [B * T][C]
+int s2st_bn_apply_img(const float* x, const float* mean, const float* var, const float* gamma, const float* beta, float* y,
+                      uint16_t* img, int B, int T, int pad, int C, float eps, int tanh_, float drop_p, uint64_t seed,
+                      hipStream_t st);
 // dx (via dxsp) = BN/tanh/dropout backward; dgamma/dbeta += ; tmp = 2*C floats
 int s2st_bn_bwd(const float* dy, Split dysp, const float* x, const float* mean, const float* var,
                 const float* gamma, const float* beta, float* dx, Split dxsp, float* dgamma,
