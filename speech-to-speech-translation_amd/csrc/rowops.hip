@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(
     const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx, int dx_accumulate, int rows,
     int cols, uint16_t* __restrict__ dph, float drop_p, float inv_keep, uint64_t seed, float* __restrict__ part) {
   constexpr int NOUT = FUSE ? 3 : 2;
-  __shared__ float4 red[3][64 * NV];
+  __shared__ float4 red[4][NOUT][64 * NV];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = cols >> 2;
   const float invc = 1.f / cols;
@@ -326,32 +326,28 @@ __global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(
       }
     }
   }
-  // the block's partial row of each output: waves 1 .. 3 hand their sums to wave 0 (added in wave order)
+  // the block's partial row of each output: every wave parks its column sums in LDS (one barrier), then the 256 threads
+  // add the four waves' values in wave order, one float4 column chunk each (first form: three serial hand-offs to
+  // wave 0, six barriers)
   float* p = part + (long)blockIdx.x * NOUT * cols;
-  auto fold = [&](float4 (&acc)[NV], int o) {
-    if (wave > 0) {
 #pragma unroll
-      for (int i = 0; i < NV; ++i) red[wave - 1][lane + 64 * i] = acc[i];
+  for (int i = 0; i < NV; ++i) {
+    red[wave][0][lane + 64 * i] = ag[i];
+    red[wave][1][lane + 64 * i] = ab[i];
+    if (FUSE) red[wave][2][lane + 64 * i] = ad[i];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < NOUT * 64 * NV; e += 256) {
+    const int o = e / (64 * NV), c4 = e - o * (64 * NV);
+    if (c4 >= nv) continue;
+    float4 v = red[0][o][c4];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float4 t = red[w][o][c4];
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const int c4 = lane + 64 * i;
-        float4 v = acc[i];
-#pragma unroll
-        for (int w = 0; w < 3; ++w) {
-          const float4 t = red[w][c4];
-          v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-        }
-        if (c4 < nv) reinterpret_cast<float4*>(p + (long)o * cols)[c4] = v;
-      }
-    }
-    __syncthreads();
-  };
-  fold(ag, 0);
-  fold(ab, 1);
-  if (FUSE) fold(ad, 2);
+    reinterpret_cast<float4*>(p + (long)o * cols)[c4] = v;
+  }
 }
 
 // the fold of layernorm_bwd_reduce_kernel for a whole table of layer norms in one launch
