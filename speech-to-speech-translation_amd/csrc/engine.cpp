@@ -138,6 +138,7 @@ struct s2st_engine {
   float* dec_crossKV(int l) const {
     return dec_st.base + (long)c.dec_layers * 2 * dec_st.B * dec_st.maxT * c.dec_dim + (long)l * dec_st.B * dec_st.E * 2 * c.dec_dim;
   }
+  bool conv_tail_on_main = true;  // S2ST_CONV_TAIL_MAIN=0 (A/B switch): the first convolution's weight gradient on the second stream too
   bool tail_share = false;   // set while the last tape closures run (see linear()'s weight-gradient GEMM)
   unsigned tail_count = 0, wgrad_count = 0;
   int wgrad_main_every = 0;  // S2ST_WGRAD_MAIN_EVERY=<n>: every n-th weight-gradient GEMM stays on the data-path stream
@@ -1050,14 +1051,18 @@ struct s2st_engine {
         g.C = gemm_out(dwf, (long)pp.Kw * pp.I);
         g.ep = gemm_epi_default();
         g.ep.accumulate = 1;
-        // parameter gradients only: on the second stream, next to the data-gradient chain
-        hipStream_t ws_st = fm ? fork_side() : st_;
+        // parameter gradients only: on the second stream, next to the data-gradient chain -- except for a convolution
+        // whose input needs no gradient (the model's first one = the LAST closure of the backward): no data-gradient
+        // chain is left, the data-path stream would only wait, so it takes the product and the second stream the bias sum
+        const bool no_dgrad = !(in2.src && in2.src->needs_grad);
+        hipStream_t side_st = fm ? fork_side() : st_;
+        hipStream_t ws_st = (fm && !(no_dgrad && conv_tail_on_main)) ? side_st : st_;
         g.ws = ws_for(ws_st); g.ws_floats = skws_n;
         g.M = pp.O; g.N = pp.Kw * pp.I; g.K = M; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
         chk(s2st_gemm(g, ws_st));
         {
           int slabs = 0;
-          chk(s2st_colsum(z->g, pp.O, M, pp.O, G + pp.b, 1, ws_st, cpart, cpart ? &slabs : nullptr));
+          chk(s2st_colsum(z->g, pp.O, M, pp.O, G + pp.b, 1, side_st, cpart, cpart ? &slabs : nullptr));
           if (cpart) add_fold(cpart, slabs, pp.O, G + pp.b);
         }
         chk(s2st_conv_w_unpermute_acc(dwf, G + pp.w, pp.O, pp.I, pp.Kw, ws_st));
@@ -1957,6 +1962,7 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->use_attn_gfuse = e->attn_gfuse_mode != 0;
   if (getenv("S2ST_WGRAD_TILES")) e->group_tile_budget = atoi(getenv("S2ST_WGRAD_TILES"));
   e->ln_bwd_split = getenv("S2ST_LN_BWD_SPLIT") && atoi(getenv("S2ST_LN_BWD_SPLIT")) != 0;
+  if (getenv("S2ST_CONV_TAIL_MAIN")) e->conv_tail_on_main = atoi(getenv("S2ST_CONV_TAIL_MAIN")) != 0;
   e->ordered_sums = !(getenv("S2ST_ORDERED_BIAS_SUMS") && atoi(getenv("S2ST_ORDERED_BIAS_SUMS")) == 0);
   e->build_params();
   if (!cfg->precise && (s2st_gemm_bf16_preload(nullptr) != 0 || s2st_flash_attn_preload(nullptr) != 0)) { delete e; return S2ST_ERR_LAUNCH; }
