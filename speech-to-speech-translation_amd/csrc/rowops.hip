@@ -564,6 +564,7 @@ static int ln_split_blocks(int rows) {
 // (S2ST_LN_RPW=2, tuning aid: 2 rows per wave also for narrow rows -- twice the blocks and partial rows)
 static int ln_rpw(int cols) {
   static const int ev = getenv("S2ST_LN_RPW") ? atoi(getenv("S2ST_LN_RPW")) : 4;
+  if (ev == 1) return 1;
   return (cols <= 512 && ev != 2) ? 4 : 2;
 }
 static int ln_fused_rows_per_block(int cols) { return 4 * ln_rpw(cols); }
@@ -623,6 +624,11 @@ int s2st_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
     s2st_launch("layernorm_bwd_fused_kernel<" #FUSE ">", by, 0.0, layernorm_bwd_fused_kernel<FUSE, NV, RPW>, dim3(blocks), \
                 dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, dx_accumulate, rows, cols, dph, drop_p, ik, seed, scratch)
     const int rpw = ln_rpw(cols);
+    if (rpw == 1) {
+      if (cols <= 256) { if (dph) LN_FUSED(true, 1, 1); else LN_FUSED(false, 1, 1); }
+      else if (cols <= 512) { if (dph) LN_FUSED(true, 2, 1); else LN_FUSED(false, 2, 1); }
+      else { if (dph) LN_FUSED(true, 4, 1); else LN_FUSED(false, 4, 1); }
+    } else
     if (cols <= 256) { if (rpw == 4) { if (dph) LN_FUSED(true, 1, 4); else LN_FUSED(false, 1, 4); } else { if (dph) LN_FUSED(true, 1, 2); else LN_FUSED(false, 1, 2); } }
     else if (cols <= 512) { if (rpw == 4) { if (dph) LN_FUSED(true, 2, 4); else LN_FUSED(false, 2, 4); } else { if (dph) LN_FUSED(true, 2, 2); else LN_FUSED(false, 2, 2); } }
     else { if (dph) LN_FUSED(true, 4, 2); else LN_FUSED(false, 4, 2); }
