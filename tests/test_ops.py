@@ -325,6 +325,23 @@ def test_label_smoothing_reference_kat(backend, golden_dir):
                                    z[f"eps{eps}"], rtol=1e-5)
 
 
+def test_batchnorm_statistics_with_a_large_mean(backend):
+    """One-pass statistics (shifted sums): columns whose mean is 100 standard deviations away from zero -- where
+    E[x^2] - E[x]^2 would lose every digit -- still give the variance of the two-pass formula."""
+    rows, Cc = 1537, 24
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(rows, Cc, generator=g) * torch.linspace(0.5, 2.0, Cc) + torch.linspace(-300.0, 300.0, Cc)
+    xd, = dev(backend, x)
+    mean, var = torch.zeros(Cc, device=backend.device), torch.zeros(Cc, device=backend.device)
+    rm, rv = torch.zeros(Cc, device=backend.device), torch.ones(Cc, device=backend.device)
+    tmp = torch.full((130 * Cc,), float("nan"), device=backend.device)
+    backend.bd.call("s2st_bn_stats_f32", xd, rows, Cc, mean, var, rm, rv, 0.1, tmp)
+    backend.sync()
+    xd64 = x.double()
+    close(mean, xd64.mean(0).float(), 1e-6, 1e-5)
+    close(var, xd64.var(0, unbiased=False).float(), 2e-5, 1e-7)
+
+
 def test_ctc(backend):
     torch.manual_seed(0)
     B, E, V, Lmax = 5, 40, 11, 30
