@@ -192,7 +192,7 @@ __device__ __forceinline__ void store_grad(const f32x4 (&t)[DT], float scale, bo
 // forward: grid (ceil(T / 64), B * H); 4 waves x 16 queries; key tiles of 32
 // ------------------------------------------------------------------------------------------------
 template <int DH, int NW>
-__global__ __launch_bounds__(64 * NW) void flash_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * NW, 3) void flash_fwd_kernel(AttnArgs a) {
   constexpr int KS = DH / 32, DT = DH / 16;
   if (a.T <= 0 || a.S <= 0) return;  // empty problem (kernel preload)
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * Img<DH>::BYTES];
@@ -217,20 +217,20 @@ __global__ __launch_bounds__(64 * NW) void flash_fwd_kernel(AttnArgs a) {
   const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
   const uint64_t drow = ((uint64_t)bh * a.T + qi) * (uint64_t)a.ld_drop;
 
-  TileRegs<DH, 64 * NW> tk, tv;
-  if (kmax > 0) {
-    tk.fetch(kb, a.ldk, 0, a.S, tid);
-    tv.fetch(vb, a.ldv, 0, a.S, tid);
-  }
-  for (int kt = 0; kt < kmax; kt += 32) {
+  // two register sets of staged tiles (even / odd): a tile's loads are issued two tiles ahead (see the backward)
+  struct Stage { TileRegs<DH, 64 * NW> k, v; } stg[2];
+  auto fetch = [&](Stage& st, int kt) {
+    st.k.fetch(kb, a.ldk, kt, a.S, tid);
+    st.v.fetch(vb, a.ldv, kt, a.S, tid);
+  };
+  if (kmax > 0) fetch(stg[0], 0);
+  if (kmax > 32) fetch(stg[1], 32);
+  auto tile = [&](Stage& st, const int kt) {
     __syncthreads();  // everyone is done with the previous tile's images
-    tk.commit(kimg, nullptr, tid);
-    tv.commit(nullptr, vimg, tid);
+    st.k.commit(kimg, nullptr, tid);
+    st.v.commit(nullptr, vimg, tid);
     __syncthreads();
-    if (kt + 32 < kmax) {  // next tile's loads fly during this tile's MFMAs
-      tk.fetch(kb, a.ldk, kt + 32, a.S, tid);
-      tv.fetch(vb, a.ldv, kt + 32, a.S, tid);
-    }
+    if (kt + 64 < kmax) fetch(st, kt + 64);  // flies during this tile's and the next tile's MFMAs
     // S^T tiles: rows = keys kt + 16 t2 + 4g + r, col = query
     f32x4 x[2];
 #pragma unroll
@@ -272,6 +272,10 @@ __global__ __launch_bounds__(64 * NW) void flash_fwd_kernel(AttnArgs a) {
       o[d] *= alpha;
       o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Img<DH>::tr_frag(vimg, d, lane), pf, o[d], 0, 0, 0);
     }
+  };
+  for (int kt = 0; kt < kmax; kt += 64) {
+    tile(stg[0], kt);
+    if (kt + 32 < kmax) tile(stg[1], kt + 32);
   }
   l += __shfl_xor(l, 16);
   l += __shfl_xor(l, 32);
@@ -353,25 +357,36 @@ __device__ __forceinline__ void flash_bwd_kv_body(const AttnArgs& a, unsigned ch
   // registers beside the dO tile (same thread -> chunk map: the lanes that hold a row's chunks are neighbours), the
   // row sums land in LDS with the tile images
   __shared__ float dsh[32];
+  // the tile's 32 log-sum-exp values travel the same way (one float per thread 0 .. 31, fetched a tile ahead): no
+  // scattered global loads between the score MFMAs and the exponentials
+  __shared__ float lsh[32];
+  const float* lseb = a.lse + (long)bh * a.T;
+  float lse_nx = 0.f;
   const bool own_d = a.dvec == nullptr;
   const bf16_t* ob = own_d ? a.oh + (long)b * a.T * ((long)a.H * DH) + h * DH : nullptr;
-  TileRegs<DH, 64 * NW> tq, td, to;
-  if (qbeg < a.T) {
-    tq.fetch(qb, a.ldq, qbeg, a.T, tid);
-    td.fetch(dob, (long)a.H * DH, qbeg, a.T, tid);
-    if (own_d) to.fetch(ob, (long)a.H * DH, qbeg, a.T, tid);
-  }
-  for (int qt = qbeg; qt < a.T; qt += 32) {
+  // Two register sets of staged tiles (even / odd tiles): a tile's global loads are issued TWO tiles ahead (right after the
+  // set's previous tile went to LDS), so they have a whole tile's MFMAs + the other set's commit to land -- with one set
+  // the loads issued after a commit were waited for one tile later (~1 us of work against 2 - 3 us of memory latency).
+  struct Stage {
+    TileRegs<DH, 64 * NW> q, d, o;
+    float lse;
+  } stg[2];
+  auto fetch = [&](Stage& st, int qt) {
+    st.q.fetch(qb, a.ldq, qt, a.T, tid);
+    st.d.fetch(dob, (long)a.H * DH, qt, a.T, tid);
+    if (own_d) st.o.fetch(ob, (long)a.H * DH, qt, a.T, tid);
+    if (tid < 32) st.lse = lseb[min(qt + tid, a.T - 1)];
+  };
+  if (qbeg < a.T) fetch(stg[0], qbeg);
+  if (qbeg + 32 < a.T) fetch(stg[1], qbeg + 32);
+  auto tile = [&](Stage& st, const int qt) {
     __syncthreads();
-    tq.commit(q_row, q_tr, tid);
-    td.commit(do_row, do_tr, tid);
-    if (own_d) tile_rowdots<DH, 64 * NW>(td, to, dsh, tid);
+    st.q.commit(q_row, q_tr, tid);
+    st.d.commit(do_row, do_tr, tid);
+    if (own_d) tile_rowdots<DH, 64 * NW>(st.d, st.o, dsh, tid);
+    if (tid < 32) lsh[tid] = st.lse;
     __syncthreads();
-    if (qt + 32 < a.T) {
-      tq.fetch(qb, a.ldq, qt + 32, a.T, tid);
-      td.fetch(dob, (long)a.H * DH, qt + 32, a.T, tid);
-      if (own_d) to.fetch(ob, (long)a.H * DH, qt + 32, a.T, tid);
-    }
+    if (qt + 64 < a.T) fetch(st, qt + 64);
     f32x4 x[2], dp[2];
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
@@ -390,7 +405,7 @@ __device__ __forceinline__ void flash_bwd_kv_body(const AttnArgs& a, unsigned ch
       float p = 0.f, dsv = 0.f, pdv = 0.f;
       if (ok) {
         const long r = (long)bh * a.T + q;
-        p = __expf(x[e >> 2][e & 3] * a.scale - a.lse[r]);
+        p = __expf(x[e >> 2][e & 3] * a.scale - lsh[q - qt]);
         float keep = 1.f;
         if (a.drop_p > 0.f) keep = drop_scale(a.seed, (uint64_t)r * a.ld_drop + ki, a.drop_p, inv_keep);
         pdv = p * keep;
@@ -405,6 +420,10 @@ __device__ __forceinline__ void flash_bwd_kv_body(const AttnArgs& a, unsigned ch
       dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Img<DH>::tr_frag(do_tr, d, lane), pf, dv[d], 0, 0, 0);
       dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Img<DH>::tr_frag(q_tr, d, lane), sf, dk[d], 0, 0, 0);
     }
+  };
+  for (int qt = qbeg; qt < a.T; qt += 64) {
+    tile(stg[0], qt);
+    if (qt + 32 < a.T) tile(stg[1], qt + 32);
   }
   {
     const bool on = ki < a.S;
@@ -470,20 +489,19 @@ __device__ __forceinline__ void flash_bwd_q_body(const AttnArgs& a, unsigned cha
   }
   const uint64_t drow = (uint64_t)r * a.ld_drop;
 
-  TileRegs<DH, 64 * NW> tk, tv;
-  if (kmax > 0) {
-    tk.fetch(kb, a.ldk, 0, a.S, tid);
-    tv.fetch(vb, a.ldv, 0, a.S, tid);
-  }
-  for (int kt = 0; kt < kmax; kt += 32) {
+  struct Stage { TileRegs<DH, 64 * NW> k, v; } stg[2];  // (two register sets, loads two tiles ahead: see the dK/dV body)
+  auto fetch = [&](Stage& st, int kt) {
+    st.k.fetch(kb, a.ldk, kt, a.S, tid);
+    st.v.fetch(vb, a.ldv, kt, a.S, tid);
+  };
+  if (kmax > 0) fetch(stg[0], 0);
+  if (kmax > 32) fetch(stg[1], 32);
+  auto tile = [&](Stage& st, const int kt) {
     __syncthreads();
-    tk.commit(k_row, k_tr, tid);
-    tv.commit(v_row, nullptr, tid);
+    st.k.commit(k_row, k_tr, tid);
+    st.v.commit(v_row, nullptr, tid);
     __syncthreads();
-    if (kt + 32 < kmax) {
-      tk.fetch(kb, a.ldk, kt + 32, a.S, tid);
-      tv.fetch(vb, a.ldv, kt + 32, a.S, tid);
-    }
+    if (kt + 64 < kmax) fetch(st, kt + 64);
     f32x4 x[2], dp[2];
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
@@ -512,6 +530,10 @@ __device__ __forceinline__ void flash_bwd_q_body(const AttnArgs& a, unsigned cha
 #pragma unroll
     for (int d = 0; d < DT; ++d)
       dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Img<DH>::tr_frag(k_tr, d, lane), sf, dq[d], 0, 0, 0);
+  };
+  for (int kt = 0; kt < kmax; kt += 64) {
+    tile(stg[0], kt);
+    if (kt + 32 < kmax) tile(stg[1], kt + 32);
   }
   {
     const long qo = ((long)b * a.T + min(qi, a.T - 1)) * a.ldq + h * DH;
@@ -522,14 +544,14 @@ __device__ __forceinline__ void flash_bwd_q_body(const AttnArgs& a, unsigned cha
 }
 
 template <int DH, int NW>
-__global__ __launch_bounds__(64 * NW) void flash_bwd_kv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * NW, 2) void flash_bwd_kv_kernel(AttnArgs a) {
   if (a.T <= 0 || a.S <= 0) return;  // empty problem (kernel preload)
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * Img<DH>::BYTES];
   flash_bwd_kv_body<DH, NW>(a, smem, (int)blockIdx.x);
 }
 
 template <int DH, int NW>
-__global__ __launch_bounds__(64 * NW) void flash_bwd_q_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * NW, 2) void flash_bwd_q_kernel(AttnArgs a) {
   if (a.T <= 0 || a.S <= 0) return;
   __shared__ __attribute__((aligned(16))) unsigned char smem[3 * Img<DH>::BYTES];
   flash_bwd_q_body<DH, NW>(a, smem, (int)blockIdx.x);
@@ -540,7 +562,7 @@ __global__ __launch_bounds__(64 * NW) void flash_bwd_q_kernel(AttnArgs a) {
 // two -- ~4 us each between dependent kernels, profiles/r02_b_timeline_summary_all_dispatches.txt) lets the short
 // query blocks fill the tail of the key blocks.
 template <int DH, int NW>
-__global__ __launch_bounds__(64 * NW) void flash_bwd_kernel(AttnArgs a, int nkx) {
+__global__ __launch_bounds__(64 * NW, 2) void flash_bwd_kernel(AttnArgs a, int nkx) {
   if (a.T <= 0 || a.S <= 0) return;
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * Img<DH>::BYTES];
   if ((int)blockIdx.x < nkx) flash_bwd_kv_body<DH, NW>(a, smem, (int)blockIdx.x);

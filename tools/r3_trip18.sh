@@ -1,0 +1,9 @@
+#!/bin/bash
+# round 3, trip 18: attention kernels with tile loads two tiles ahead + the tile's log-sum-exp through LDS
+cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -q -m gpu -k "attention or engine or full_size or hubert_train or base_size or inference" > gpurun_out/t18_pytest.log 2>&1
+echo "pytest rc $?" | tee -a gpurun_out/t18_pytest.log
+grep -E "passed|failed|FAILED|^E  " gpurun_out/t18_pytest.log | tail -8
+for i in 1 2; do S2ST_BENCH_VERBOSE=1 timeout 900 python bench.py --cpu-seconds 0 > gpurun_out/t18_bench_line.txt 2> gpurun_out/t18_bench_verbose.txt; grep -o '"ms_per_step": [0-9.]*' gpurun_out/t18_bench_line.txt | head -1; done
+grep -E "flash_|GPU time on" gpurun_out/t18_bench_verbose.txt | head
+echo DONE
