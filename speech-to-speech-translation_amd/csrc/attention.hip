@@ -148,6 +148,12 @@ struct AttnArgs {
   // backward
   const bf16_t* doh;              // bf16 dO [B*T][H*DH]
   const float* dvec;              // D[b,h,t] = rowsum(dO * O)
+#ifdef S2ST_ATTN_STAMP  // tools/attn_stamp.sh: a PRIVATE build that writes per-workgroup clock stamps (8 longs each)
+  long* stamp;
+#define ATTN_STAMP(k) do { if (threadIdx.x == 0) a.stamp[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = clock64(); } while (0)
+#else
+#define ATTN_STAMP(k) do { } while (0)
+#endif
   float *dq, *dk, *dv;            // fp32 gradients, addressed like q / k / v (ldq / ldk / ldv); may be null
   bf16_t *dqh, *dkh, *dvh;        // optional bf16 gradients (the operand of the projections' backward GEMMs)
   float *dbq, *dbk, *dbv;         // optional: projection bias gradients += column sums (head h at + h * DH)
@@ -345,6 +351,7 @@ __device__ __forceinline__ void flash_bwd_kv_body(const AttnArgs& a, unsigned ch
   const bool key_ok = ki < klim;
   const int qbeg = a.causal ? (bx * (16 * NW)) & ~31 : 0;  // queries < first key of the block see none of it
 
+  ATTN_STAMP(0);
   bf16x8 kf[KS], vf[KS];
   load_frags<DH>(kb, a.ldk, k0, a.S, lane, kf);
   load_frags<DH>(vb, a.ldv, k0, a.S, lane, vf);
@@ -386,6 +393,8 @@ __device__ __forceinline__ void flash_bwd_kv_body(const AttnArgs& a, unsigned ch
     if (own_d) tile_rowdots<DH, 64 * NW>(st.d, st.o, dsh, tid);
     if (tid < 32) lsh[tid] = st.lse;
     __syncthreads();
+    if (qt == qbeg) ATTN_STAMP(1);        // first tile in LDS
+    if (qt == qbeg + 32) ATTN_STAMP(2);   // second tile in LDS (= one full iteration later)
     if (qt + 64 < a.T) fetch(st, qt + 64);
     f32x4 x[2], dp[2];
 #pragma unroll
@@ -414,6 +423,7 @@ __device__ __forceinline__ void flash_bwd_kv_body(const AttnArgs& a, unsigned ch
       pd[e] = pdv;
       ds[e] = dsv;
     }
+    if (qt == qbeg + 32) ATTN_STAMP(3);   // scores, dP, exponentials, dropout of the second tile done
     const bf16x8 pf = pack_frag(pd), sf = pack_frag(ds);
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
@@ -425,6 +435,7 @@ __device__ __forceinline__ void flash_bwd_kv_body(const AttnArgs& a, unsigned ch
     tile(stg[0], qt);
     if (qt + 32 < a.T) tile(stg[1], qt + 32);
   }
+  ATTN_STAMP(4);  // loop done
   {
     const bool on = ki < a.S;
     const long ko = ((long)b * a.S + min(ki, a.S - 1)) * a.ldk + h * DH;
@@ -436,6 +447,7 @@ __device__ __forceinline__ void flash_bwd_kv_body(const AttnArgs& a, unsigned ch
     store_grad<DT>(dv, 1.f, on, a.dv ? a.dv + vo : nullptr, a.dvh ? a.dvh + vo : nullptr,
                    a.dbv ? a.dbv + slot + h * DH : nullptr, lane, a.db_part != 0);
   }
+  ATTN_STAMP(5);  // gradients stored
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -666,6 +678,9 @@ int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_sc
   if (!own_d && (!dO || !dvec_scratch || !p->o)) return S2ST_ERR_ARG;
   AttnArgs a = to_args(*p);
   a.dvec = own_d ? nullptr : dvec_scratch;
+#ifdef S2ST_ATTN_STAMP
+  a.stamp = reinterpret_cast<long*>(dvec_scratch);
+#endif
   // bias gradients without atomics: the kernels write per-(block, wave) partial sums, folded in slot order below
   const int nwp = attn_nw();
   const long Cp = (long)p->H * p->dh;

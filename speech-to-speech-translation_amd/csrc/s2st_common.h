@@ -62,17 +62,25 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + er
 
 // Counter-based dropout RNG: keep(element) is a pure function of (seed, element index), so
 // the backward pass regenerates the forward mask without storing it.
-__device__ __forceinline__ uint32_t mix64(uint64_t x) {
-  x ^= x >> 33;
-  x *= 0xff51afd7ed558ccdULL;
-  x ^= x >> 33;
-  x *= 0xc4ceb9fe1a85ec53ULL;
-  x ^= x >> 33;
-  return (uint32_t)x;
+// Round 3: a 32-bit mixer with TWO 32-bit multiplies (the "lowbias32" constants; the seed's halves enter before the first
+// and between the two rounds, so two sites' streams are not index-shifted copies of each other).  Rounds 1 - 2 used a
+// 64-bit finalizer: three 64 x 64 multiplies = ~12 quarter-rate v_mul per element, which clock stamps showed to be the
+// largest single cost of the attention kernels (8 elements per lane and key tile: ~1.6 k of the ~3.8 k cycles a wave
+// spent per tile) and of every GEMM epilogue with dropout (64 elements per lane of a 128 x 128 tile).
+__device__ __forceinline__ uint32_t mix32(uint64_t seed, uint64_t idx) {
+  const uint32_t hi = (uint32_t)(idx >> 32);
+  uint32_t h = (uint32_t)idx ^ (uint32_t)seed ^ ((hi << 16) | (hi >> 16));
+  h ^= h >> 16;
+  h *= 0x7feb352du;
+  h ^= h >> 15;
+  h ^= (uint32_t)(seed >> 32);
+  h *= 0x846ca68bu;
+  h ^= h >> 16;
+  return h;
 }
 __device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
   // returns 0 (dropped) or 1/(1-p) (kept)
-  uint32_t h = mix64(seed + idx * 0x9E3779B97F4A7C15ULL);
+  const uint32_t h = mix32(seed, idx);
   float u = (float)(h >> 8) * (1.0f / 16777216.0f);
   return u >= p ? inv_keep : 0.0f;
 }

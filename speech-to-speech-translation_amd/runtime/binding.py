@@ -185,7 +185,7 @@ class AttnArgs(C.Structure):
 
 
 def flash_attention(q, k, v, H, *, klen=None, causal=False, scale=None, drop_p=0.0, seed=0, dO=None, bf16_grads=False,
-                    bf16_o=False):
+                    bf16_o=False, scratch=None):
     """Fused attention on bf16 [B, T, H*dh] / [B, S, H*dh] projections (s2st_flash_attn_*_bf16).
     Returns (o fp32, lse) and, when dO (fp32 [B, T, H*dh]) is given, also (dq, dk, dv) fp32.  ``bf16_o``: the forward also
     leaves the bf16 copy of o (what the engine does); the backward then forms D = rowsum(dO * o) inside its kernels from
@@ -210,7 +210,8 @@ def flash_attention(q, k, v, H, *, klen=None, causal=False, scale=None, drop_p=0
         return o, lse.view(B, H, T)
     doh = dO.to(torch.bfloat16).contiguous()
     dq, dk, dv = (torch.zeros_like(x, dtype=torch.float32) for x in (q, k, v))
-    scratch = torch.zeros(B * H * T, dtype=torch.float32, device=q.device)
+    if scratch is None:  # (tools/attn_stamp.py passes a larger one: the private stamp build writes clock stamps there)
+        scratch = torch.zeros(B * H * T, dtype=torch.float32, device=q.device)
     a.doh, a.dq, a.dk, a.dv = doh.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
     extra = None
     if bf16_grads:  # also the bf16 copies + bias-gradient column sums
