@@ -265,10 +265,11 @@ __global__ __launch_bounds__(64 * NW, 3) void flash_fwd_kernel(AttnArgs a) {
     for (int e = 0; e < 8; ++e) {
       p[e] = __expf(s[e] - mu);
       ps += p[e];
-      if (a.drop_p > 0.f) {
-        const int key = kt + 16 * (e >> 2) + 4 * g + (e & 3);
-        p[e] *= drop_scale(a.seed, drow + key, a.drop_p, inv_keep);
-      }
+    }
+    if (a.drop_p > 0.f) {  // (one wave-uniform branch per tile, not one per element)
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        p[e] *= drop_scale(a.seed, drow + (uint64_t)(kt + 16 * (e >> 2) + 4 * g + (e & 3)), a.drop_p, inv_keep);
     }
     l = l * alpha + ps;
     m = mn;
@@ -406,22 +407,33 @@ __device__ __forceinline__ void flash_bwd_kv_body(const AttnArgs& a, unsigned ch
         dp[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Img<DH>::row_frag(do_row, 16 * t2, ks, lane), vf[ks], dp[t2], 0, 0, 0);
       }
     }
-    float pd[8], ds[8];
+    // Element work as straight-line code (selects, no per-element branches: the first form's `if (ok)` / `if (dropout)`
+    // per element were 16 exec-mask branches per tile): the two wave-uniform choices -- dropout on / off, D from LDS or
+    // from the row kernel's vector -- are made once per tile; masked elements compute on clamped indices and are zeroed.
+    float pd[8], ds[8], keep[8], dvl[8];
+    const uint64_t d0 = ((uint64_t)bh * a.T + qt + 4 * g) * (uint64_t)a.ld_drop + ki;  // dropout index of element 0
+    if (a.drop_p > 0.f) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        keep[e] = drop_scale(a.seed, d0 + (uint64_t)((16 * (e >> 2) + (e & 3)) * a.ld_drop), a.drop_p, inv_keep);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) keep[e] = 1.f;
+    }
+    if (own_d) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dvl[e] = dsh[16 * (e >> 2) + 4 * g + (e & 3)];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dvl[e] = a.dvec[(long)bh * a.T + min(qt + 16 * (e >> 2) + 4 * g + (e & 3), a.T - 1)];
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int q = qt + 16 * (e >> 2) + 4 * g + (e & 3);
+      const int qq = 16 * (e >> 2) + 4 * g + (e & 3), q = qt + qq;
       const bool ok = key_ok && q < a.T && (!a.causal || ki <= q);
-      float p = 0.f, dsv = 0.f, pdv = 0.f;
-      if (ok) {
-        const long r = (long)bh * a.T + q;
-        p = __expf(x[e >> 2][e & 3] * a.scale - lsh[q - qt]);
-        float keep = 1.f;
-        if (a.drop_p > 0.f) keep = drop_scale(a.seed, (uint64_t)r * a.ld_drop + ki, a.drop_p, inv_keep);
-        pdv = p * keep;
-        dsv = p * (keep * dp[e >> 2][e & 3] - (own_d ? dsh[q - qt] : a.dvec[r]));
-      }
-      pd[e] = pdv;
-      ds[e] = dsv;
+      const float p = ok ? __expf(x[e >> 2][e & 3] * a.scale - lsh[qq]) : 0.f;
+      pd[e] = p * keep[e];
+      ds[e] = p * (keep[e] * dp[e >> 2][e & 3] - dvl[e]);
     }
     if (qt == qbeg + 32) ATTN_STAMP(3);   // scores, dP, exponentials, dropout of the second tile done
     const bf16x8 pf = pack_frag(pd), sf = pack_frag(ds);
@@ -524,19 +536,21 @@ __device__ __forceinline__ void flash_bwd_q_body(const AttnArgs& a, unsigned cha
         dp[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Img<DH>::row_frag(v_row, 16 * t2, ks, lane), dof[ks], dp[t2], 0, 0, 0);
       }
     }
-    float ds[8];
+    float ds[8], keep[8];  // (straight-line element work: see the dK/dV body)
+    if (a.drop_p > 0.f) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        keep[e] = drop_scale(a.seed, drow + (uint64_t)(kt + 16 * (e >> 2) + 4 * g + (e & 3)), a.drop_p, inv_keep);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) keep[e] = 1.f;
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int key = kt + 16 * (e >> 2) + 4 * g + (e & 3);
       const bool ok = q_ok && key < klim && (!a.causal || key <= qi);
-      float dsv = 0.f;
-      if (ok) {
-        const float p = __expf(x[e >> 2][e & 3] * a.scale - lse);
-        float keep = 1.f;
-        if (a.drop_p > 0.f) keep = drop_scale(a.seed, drow + key, a.drop_p, inv_keep);
-        dsv = p * (keep * dp[e >> 2][e & 3] - dvec);
-      }
-      ds[e] = dsv;
+      const float p = ok ? __expf(x[e >> 2][e & 3] * a.scale - lse) : 0.f;
+      ds[e] = p * (keep[e] * dp[e >> 2][e & 3] - dvec);
     }
     const bf16x8 sf = pack_frag(ds);
 #pragma unroll
