@@ -70,8 +70,9 @@ struct TileRegs {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const int f = tid + NT * i, row = f / CH, ch = f - row * CH;
-      r[i] = make_uint4(0, 0, 0, 0);
-      if (r0 + row < nrows) r[i] = *reinterpret_cast<const uint4*>(base + (long)(r0 + row) * ld + ch * 8);
+      // (rows past the end: the load goes to the last row and is replaced by zeros -- a select, not a branch)
+      const uint4 v = *reinterpret_cast<const uint4*>(base + (long)min(r0 + row, nrows - 1) * ld + ch * 8);
+      r[i] = (r0 + row < nrows) ? v : make_uint4(0, 0, 0, 0);
     }
   }
   __device__ __forceinline__ void commit(unsigned char* rimg, unsigned char* timg, int tid) const {
@@ -372,13 +373,13 @@ __device__ __forceinline__ void flash_bwd_kv_body(const AttnArgs& a, unsigned ch
   float lse_nx = 0.f;
   const bool own_d = a.dvec == nullptr;
   const bf16_t* ob = own_d ? a.oh + (long)b * a.T * ((long)a.H * DH) + h * DH : nullptr;
-  // Two register sets of staged tiles (even / odd tiles): a tile's global loads are issued TWO tiles ahead (right after the
-  // set's previous tile went to LDS), so they have a whole tile's MFMAs + the other set's commit to land -- with one set
-  // the loads issued after a commit were waited for one tile later (~1 us of work against 2 - 3 us of memory latency).
+  // One register set of staged tiles: the next tile's global loads are issued right after this tile went to LDS.  (Two
+  // sets, loads two tiles ahead, were measured: -0.7 us per launch at +25 VGPRs -- with the straight-line element code
+  // below that spills past the 256 registers two waves per SIMD leave; the forward kernel keeps two sets.)
   struct Stage {
     TileRegs<DH, 64 * NW> q, d, o;
     float lse;
-  } stg[2];
+  } stg[1];
   auto fetch = [&](Stage& st, int qt) {
     st.q.fetch(qb, a.ldq, qt, a.T, tid);
     st.d.fetch(dob, (long)a.H * DH, qt, a.T, tid);
@@ -386,7 +387,6 @@ __device__ __forceinline__ void flash_bwd_kv_body(const AttnArgs& a, unsigned ch
     if (tid < 32) st.lse = lseb[min(qt + tid, a.T - 1)];
   };
   if (qbeg < a.T) fetch(stg[0], qbeg);
-  if (qbeg + 32 < a.T) fetch(stg[1], qbeg + 32);
   auto tile = [&](Stage& st, const int qt) {
     __syncthreads();
     st.q.commit(q_row, q_tr, tid);
@@ -396,7 +396,7 @@ __device__ __forceinline__ void flash_bwd_kv_body(const AttnArgs& a, unsigned ch
     __syncthreads();
     if (qt == qbeg) ATTN_STAMP(1);        // first tile in LDS
     if (qt == qbeg + 32) ATTN_STAMP(2);   // second tile in LDS (= one full iteration later)
-    if (qt + 64 < a.T) fetch(st, qt + 64);
+    if (qt + 32 < a.T) fetch(st, qt + 32);
     f32x4 x[2], dp[2];
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
@@ -443,10 +443,7 @@ __device__ __forceinline__ void flash_bwd_kv_body(const AttnArgs& a, unsigned ch
       dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Img<DH>::tr_frag(q_tr, d, lane), sf, dk[d], 0, 0, 0);
     }
   };
-  for (int qt = qbeg; qt < a.T; qt += 64) {
-    tile(stg[0], qt);
-    if (qt + 32 < a.T) tile(stg[1], qt + 32);
-  }
+  for (int qt = qbeg; qt < a.T; qt += 32) tile(stg[0], qt);
   ATTN_STAMP(4);  // loop done
   {
     const bool on = ki < a.S;
@@ -513,19 +510,18 @@ __device__ __forceinline__ void flash_bwd_q_body(const AttnArgs& a, unsigned cha
   }
   const uint64_t drow = (uint64_t)r * a.ld_drop;
 
-  struct Stage { TileRegs<DH, 64 * NW> k, v; } stg[2];  // (two register sets, loads two tiles ahead: see the dK/dV body)
+  struct Stage { TileRegs<DH, 64 * NW> k, v; } stg[1];  // (one register set: see the dK/dV body)
   auto fetch = [&](Stage& st, int kt) {
     st.k.fetch(kb, a.ldk, kt, a.S, tid);
     st.v.fetch(vb, a.ldv, kt, a.S, tid);
   };
   if (kmax > 0) fetch(stg[0], 0);
-  if (kmax > 32) fetch(stg[1], 32);
   auto tile = [&](Stage& st, const int kt) {
     __syncthreads();
     st.k.commit(k_row, k_tr, tid);
     st.v.commit(v_row, nullptr, tid);
     __syncthreads();
-    if (kt + 64 < kmax) fetch(st, kt + 64);
+    if (kt + 32 < kmax) fetch(st, kt + 32);
     f32x4 x[2], dp[2];
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
@@ -557,10 +553,7 @@ __device__ __forceinline__ void flash_bwd_q_body(const AttnArgs& a, unsigned cha
     for (int d = 0; d < DT; ++d)
       dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Img<DH>::tr_frag(k_tr, d, lane), sf, dq[d], 0, 0, 0);
   };
-  for (int kt = 0; kt < kmax; kt += 64) {
-    tile(stg[0], kt);
-    if (kt + 32 < kmax) tile(stg[1], kt + 32);
-  }
+  for (int kt = 0; kt < kmax; kt += 32) tile(stg[0], kt);
   {
     const long qo = ((long)b * a.T + min(qi, a.T - 1)) * a.ldq + h * DH;
     const long slot = a.db_part ? ((long)(b * (int)((a.T + 16 * NW - 1) / (16 * NW)) + bx) * NW + wave) * ((long)a.H * DH) : 0;
