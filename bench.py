@@ -485,7 +485,7 @@ def main():
         vlog('largest waveform batch', tuple(wb))
 
     def step(i):
-        return trainer.train_step([prepared[i]])
+        return trainer.train_step([prepared[i]], overlap_optimizer=True)  # (S2ST_ADAM_OVERLAP=0: the A/B switch)
 
     for i in range(args.warmup):
         step(i)
@@ -570,7 +570,7 @@ def main():
             torch.cuda.synchronize()
             th0 = time.perf_counter()
             for smp in src:
-                trainer.train_step([smp])
+                trainer.train_step([smp], overlap_optimizer=True)
             torch.cuda.synchronize()
             th = time.perf_counter() - th0
             vlog('host-fed (PCIe-inclusive), %s uploads: %.3f ms/step, %.0f mel-frames/s over %d steps' % (

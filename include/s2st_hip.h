@@ -368,6 +368,16 @@ int32_t s2st_engine_num_segments(const s2st_engine* e);
 void* s2st_engine_side_stream(const s2st_engine* e);
 /* after segment i has run, gradients in arena range [lo, hi) are final */
 int s2st_engine_segment_range(const s2st_engine* e, int32_t i, int64_t* lo, int64_t* hi);
+/* The optimizer update of the bound arenas (trainer.py:838-873 + adam.py:163-239, as s2st_adam_f32 with zero_grad = 1)
+ * OVERLAPPED with the next forward: the update runs in n_chunks pieces of the arena on the engine's second stream, behind
+ * everything enqueued on `stream` so far; the next s2st_engine_forward on the data-path stream waits for a piece right
+ * before the first op that reads parameters of it (the arena is in forward-use order), so the HBM-bound update hides behind
+ * the forward's first layers.  Anything ELSE that reads the parameters (host copies, a checkpoint, an all-reduce of
+ * parameters) first calls s2st_engine_wait_optimizer(e, its stream).  exp_avg / exp_avg_sq: the Adam moments, arena layout;
+ * sumsq_parts / n_parts: s2st_sumsq_parts_f32 of the gradient arena; write_bf16: refresh the bound bf16 arena as well.
+ * Without a second stream the update simply runs on `stream`. */
+int s2st_engine_adam_overlapped(s2st_engine* e, float* exp_avg, float* exp_avg_sq, const float* sumsq_parts, int32_t n_parts, float gmul, const float* gmul_dev, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int32_t step, float* gnorm_out, int32_t* skipped, int32_t write_bf16, int32_t n_chunks, void* stream);
+int s2st_engine_wait_optimizer(s2st_engine* e, void* stream);
 
 /* ---- AR inference (config 5): fairseq/speech_generator_for_s2st.py:46-110 drives these.
  * decode_begin runs the encoder on `b` (eval mode; out->enc_out / tap0 / tap1 receive the encoder

@@ -128,6 +128,8 @@ def state_dict(trainer, extra_state: Optional[Dict[str, Any]] = None) -> Dict[st
 
 def save_checkpoint(path: str, trainer, extra_state: Optional[Dict[str, Any]] = None) -> None:
     tmp = path + ".tmp"  # atomic like torch_persistent_save
+    if hasattr(trainer, "wait_optimizer"):
+        trainer.wait_optimizer()  # (an update overlapped with the next forward may still be in flight on the second stream)
     torch.save(state_dict(trainer, extra_state), tmp)
     os.replace(tmp, path)
 

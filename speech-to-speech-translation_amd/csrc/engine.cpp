@@ -476,7 +476,66 @@ struct s2st_engine {
   void chk(int rc) { if (rc && !err) err = rc; }
   uint64_t next_seed() { return seed * 0x100000001B3ULL + (++site) * 0x9E3779B97F4A7C15ULL; }
   void mark() { marks.push_back(Mark{tape.size(), param_watermark}); }
-  void touch(long off_end) { if (off_end > param_watermark) param_watermark = off_end; }
+  void touch(long off_end) {
+    if (off_end > param_watermark) param_watermark = off_end;
+    if (adam_pending && st_ != side_) adam_wait_upto(off_end);
+  }
+
+  // ---- optimizer update overlapped with the next forward (s2st_engine_adam_overlapped) ------------------------------
+  // The fused scale / clip / Adam kernel runs in chunks of the arena on the SECOND stream, one event per chunk.  The
+  // arena is laid out in forward-use order and every op announces the parameters it is about to read (touch()), so the
+  // next forward on the data-path stream waits for exactly the chunks it needs, when it needs them; work the forward
+  // puts on the second stream (weight transposes, post-net weight layouts, hoisted K|V projections, aux heads) is
+  // ordered behind the update by the stream itself.
+  std::vector<hipEvent_t> adam_ev;
+  std::vector<long> adam_lo;      // first element of chunk i
+  int adam_next = 0;              // chunks [0, adam_next) have been waited for by the data-path stream
+  bool adam_pending = false;
+  void adam_wait_upto(long off_end) {
+    if (!live()) return;
+    while (adam_next < (int)adam_lo.size() && adam_lo[adam_next] < off_end) {
+      hipStreamWaitEvent(st_, adam_ev[adam_next], 0);  // (st_ is the data-path stream here: touch() skips the second one)
+      ++adam_next;
+    }
+    if (adam_next >= (int)adam_lo.size()) adam_pending = false;
+  }
+  int adam_overlapped(float* m, float* v, const float* sumsq, int nparts, float gmul, const float* gmul_dev, float max_norm,
+                      float lr, float b1, float b2, float eps, float wd, int step, float* gnorm_out, int* skipped, int use_ph,
+                      int nchunks, hipStream_t main) {
+    if (!P || !G || n_params <= 0) return S2ST_ERR_ARG;
+    if (nchunks < 1) nchunks = 1;
+    if (nchunks > 64) nchunks = 64;
+    hipStream_t saved = st_;
+    st_ = main;
+    hipStream_t a = side_ ? fork_side() : main;  // behind the norm's partial sums (and everything else) on `main`
+    st_ = saved;
+    while ((int)adam_ev.size() < nchunks) {
+      hipEvent_t e;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return S2ST_ERR_LAUNCH;
+      adam_ev.push_back(e);
+    }
+    adam_lo.assign(nchunks, 0);
+    int rc = 0;
+    for (int c2 = 0; c2 < nchunks && !rc; ++c2) {
+      const long lo = (n_params * c2 / nchunks) / 64 * 64, hi = c2 + 1 == nchunks ? n_params : (n_params * (c2 + 1) / nchunks) / 64 * 64;
+      adam_lo[c2] = lo;
+      // (every chunk folds the norm's partials itself; only the first one reports the norm and counts a skipped update)
+      rc = s2st_adam(P + lo, G + lo, m + lo, v + lo, hi - lo, sumsq, gmul, gmul_dev, max_norm, lr, b1, b2, eps, wd, step,
+                     c2 == 0 ? gnorm_out : nullptr, a, (use_ph && PH) ? reinterpret_cast<uint16_t*>(PH) + lo : nullptr,
+                     c2 == 0 ? skipped : nullptr, nparts, 1);
+      if (side_) hipEventRecord(adam_ev[c2], a);
+    }
+    adam_next = 0;
+    adam_pending = side_ != nullptr && rc == 0;
+    return rc;
+  }
+  // `stream` waits for the whole update (callers that read parameters outside the engine)
+  void adam_wait_all(hipStream_t stream) {
+    if (!adam_pending) return;
+    for (int i = adam_next; i < (int)adam_lo.size(); ++i) hipStreamWaitEvent(stream, adam_ev[i], 0);
+    adam_next = (int)adam_lo.size();
+    adam_pending = false;
+  }
 
   // ------------------------------------------------------------------------------------
   // weight-gradient GEMMs waiting for their group launch (S2ST_NO_WGRAD_GROUP=1: A/B switch, one launch each)
@@ -1576,6 +1635,7 @@ struct s2st_engine {
     const bool fm = fast();
     if (fm && !PH && !dry) return S2ST_ERR_ARG;
     // bf16 copy of the whole parameter arena (292 MB read + 146 MB written: ~0.08 ms)
+    if (adam_pending && live() && (!fm || !ph_fresh)) adam_wait_all(st_);  // the whole arena is read right away
     if (fm && live()) {
       if (!ph_fresh) chk(s2st_cast_bf16_rows(P, n_params, PH, n_params, 1, (int)n_params, st_));
       ph_fresh = false;
@@ -1883,6 +1943,7 @@ struct s2st_engine {
         }
       });
     }
+    if (adam_pending && live()) adam_wait_all(st_);  // (parameters no op of this configuration reads)
     join_side();  // nothing of this forward is left running on the second stream when it returns in st_ order
     mark();
     return err;
@@ -2108,6 +2169,21 @@ int s2st_engine_backward(s2st_engine* e, float gscale, int32_t segment, void* st
     return 0;
   }
   return e->backward_segment(segment);
+}
+
+int s2st_engine_adam_overlapped(s2st_engine* e, float* exp_avg, float* exp_avg_sq, const float* sumsq_parts, int32_t n_parts,
+                                float gmul, const float* gmul_dev, float max_norm, float lr, float beta1, float beta2, float eps,
+                                float wd, int32_t step, float* gnorm_out, int32_t* skipped, int32_t write_bf16, int32_t n_chunks,
+                                void* stream) {
+  if (!e || !exp_avg || !exp_avg_sq || !sumsq_parts || n_parts <= 0) return S2ST_ERR_ARG;
+  return e->adam_overlapped(exp_avg, exp_avg_sq, sumsq_parts, n_parts, gmul, gmul_dev, max_norm, lr, beta1, beta2, eps, wd, step,
+                            gnorm_out, skipped, write_bf16, n_chunks, (hipStream_t)stream);
+}
+
+int s2st_engine_wait_optimizer(s2st_engine* e, void* stream) {
+  if (!e) return S2ST_ERR_ARG;
+  e->adam_wait_all((hipStream_t)stream);
+  return 0;
 }
 
 int32_t s2st_engine_num_segments(const s2st_engine* e) { return e->n_segments(); }

@@ -638,5 +638,26 @@ class Engine:
             if hi > lo:
                 on_segment(i, lo, hi)
 
+    def adam_overlapped(self, exp_avg, exp_avg_sq, sumsq_parts, n_parts, gmul, gmul_dev, max_norm, lr, beta1, beta2, eps, wd,
+                        step, gnorm_out, skipped, write_bf16: bool, n_chunks: int = 8):
+        """``s2st_engine_adam_overlapped``: the fused scale / clip / Adam update in chunks on the engine's second stream;
+        the next ``forward`` waits chunk by chunk.  Anything else that reads the parameters calls ``wait_optimizer``."""
+        f = self.lib.s2st_engine_adam_overlapped
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_float, C.c_float,
+                      C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                      C.c_void_p]
+        for t in (exp_avg, exp_avg_sq, sumsq_parts, gnorm_out, skipped):
+            bd.require_device(t)
+        bd.check(f(self.h, exp_avg.data_ptr(), exp_avg_sq.data_ptr(), sumsq_parts.data_ptr(), int(n_parts), float(gmul),
+                   bd.ptr(gmul_dev), float(max_norm), float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step),
+                   gnorm_out.data_ptr(), skipped.data_ptr(), 1 if write_bf16 else 0, int(n_chunks), bd.stream_ptr()),
+                 "s2st_engine_adam_overlapped")
+
+    def wait_optimizer(self):
+        """The current stream waits for an overlapped update still in flight (no-op otherwise)."""
+        f = self.lib.s2st_engine_wait_optimizer
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        bd.check(f(self.h, bd.stream_ptr()), "s2st_engine_wait_optimizer")
+
     def zero_grad(self):
         self.grads.zero_()

@@ -318,7 +318,9 @@ def main(argv: Optional[List[str]] = None, device: Optional[torch.device] = None
             pos["consumed"] += 1
             if len(group) < args.update_freq and pos["consumed"] < pos["total"]:
                 continue
-            r = trainer.train_step(group)  # forward, backward, gradient exchange, clip, Adam: no host sync
+            # forward, backward, gradient exchange, clip, Adam: no host sync; the update overlaps the next step's forward
+            # (every other reader of parameters / optimizer outputs below goes through trainer.wait_optimizer())
+            r = trainer.train_step(group, overlap_optimizer=True)
             group = []
             window.append(r)
             nu = trainer.num_updates

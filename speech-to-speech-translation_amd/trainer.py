@@ -70,10 +70,18 @@ class Trainer:
     def get_lr(self) -> float:
         return inverse_sqrt_lr(self.num_updates, self.lr, self.warmup)
 
-    def train_step(self, samples: List[Dict], fast: bool = True):
+    def wait_optimizer(self):
+        """After ``train_step(..., overlap_optimizer=True)``: make the current stream wait for the parameter update
+        before anything but the engine's own forward reads the parameters (checkpoints, host copies, broadcasts)."""
+        self.engine.wait_optimizer()
+
+    def train_step(self, samples: List[Dict], fast: bool = True, overlap_optimizer: bool = False):
         """One optimizer update over ``samples`` (the update_freq micro-batches of this rank).
         ``fast`` bypasses autograd (engine.backward is called directly); ``fast=False`` goes
-        through ``task.train_step`` / ``loss.backward()`` exactly like fairseq would."""
+        through ``task.train_step`` / ``loss.backward()`` exactly like fairseq would.
+        ``overlap_optimizer``: the caller's next call is another ``train_step`` (or an engine forward): the Adam kernel
+        runs in chunks on the engine's second stream and the next forward waits chunk by chunk (the update hides behind
+        the forward's first layers); any other reader of the parameters calls ``wait_optimizer()`` first."""
         eng = self.engine
         self.model.train()
         eng.step_seed = (self.seed + self.num_updates) * 1000003
@@ -125,9 +133,15 @@ class Trainer:
         nparts = self._sumsq_nparts
         bd.call("s2st_sumsq_parts_f32", eng.grads, eng.n_params, self.sumsq_parts)
         lr = self.get_lr()
-        bd.call("s2st_adam_f32", eng.params, eng.grads, self.exp_avg, self.exp_avg_sq, eng.n_params,
-                self.sumsq_parts, gmul, gmul_dev, float(self.clip_norm), lr, self.betas[0], self.betas[1],
-                self.eps, self.wd, self.num_updates + 1, self.gnorm, self._ph(), self.skipped, nparts, 1)
+        import os
+        if overlap_optimizer and os.environ.get("S2ST_ADAM_OVERLAP", "1") != "0":
+            eng.adam_overlapped(self.exp_avg, self.exp_avg_sq, self.sumsq_parts, nparts, gmul, gmul_dev, float(self.clip_norm),
+                                lr, self.betas[0], self.betas[1], self.eps, self.wd, self.num_updates + 1, self.gnorm,
+                                self.skipped, self._ph() is not None, int(os.environ.get("S2ST_ADAM_CHUNKS", "8")))
+        else:
+            bd.call("s2st_adam_f32", eng.params, eng.grads, self.exp_avg, self.exp_avg_sq, eng.n_params,
+                    self.sumsq_parts, gmul, gmul_dev, float(self.clip_norm), lr, self.betas[0], self.betas[1],
+                    self.eps, self.wd, self.num_updates + 1, self.gnorm, self._ph(), self.skipped, nparts, 1)
         self._grads_clean = True
         if self._ph() is not None:
             eng.mark_bf16_fresh()
@@ -139,6 +153,7 @@ class Trainer:
         """Raise FloatingPointError if any update since the last check met a non-finite gradient norm
         (fairseq/trainer.py:860-867 raises in the step itself; here the step stays asynchronous and the
         check is one small D2H read).  Such updates were not applied."""
+        self.engine.wait_optimizer()  # (an overlapped update writes the counter from the second stream)
         n = int(self.skipped.item())
         if n:
             self.skipped.zero_()

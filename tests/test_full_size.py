@@ -225,3 +225,44 @@ def test_longest_admissible_utterances(backend, precise):
     assert torch.allclose(o3["stats"], st2, rtol=1e-6, atol=0)  # (loss sums use atomics: last-bit order noise)
     # (the fp32-operand GEMM of the precise path splits K with atomics: order noise of a few 1e-6)
     assert _rel(f.grads, g2) <= (2e-5 if precise else 1e-6), _rel(f.grads, g2)
+
+
+def test_overlapped_optimizer_update_gives_the_same_trajectory(backend, workload):
+    """``train_step(overlap_optimizer=True)``: the Adam kernel runs in chunks on the engine's second stream and the next
+    forward waits chunk by chunk (s2st_engine_adam_overlapped).  Every sum of a step is ordered, so the trajectory is a
+    bit-exact function of (parameters, batches, seeds): five updates at base size with the recipe's dropouts end on the
+    SAME bits with and without the overlap -- a forward that read a parameter chunk before its update landed would not.
+    (On the emulator there is no second stream: the chunked update itself is what is compared.)"""
+    PKG = ENG.rsplit(".runtime", 1)[0]
+    tasks = importlib.import_module(PKG + ".tasks")
+    tr = importlib.import_module(PKG + ".trainer")
+    from synth_weights import load_synth
+    big = backend.kind == "hip"
+    corpus, b = workload
+    if big:
+        cfg = CONFIGS["base_recipe"]
+        batches = [corpus.collate_batch(x) for x in b]
+    else:
+        from test_engine import NANO, nano_batches
+        cfg = dict(NANO, dropout=0.1, attention_dropout=0.1)
+        batches = nano_batches()
+    runs = []
+    for overlap in (False, True, True):
+        a = O.make_args(**cfg)
+        a.precise_gemm, a.lr, a.warmup_updates, a.clip_norm = False, 1e-3, 2, 0.05
+        task = tasks.S2ST_TranslationTask.setup_task(a, device=backend.device)
+        model = task.build_model(a)
+        load_synth(model, 0)
+        t = tr.Trainer(a, task, model, task.build_criterion(a))
+        gn = []
+        for u in range(5):
+            r = t.train_step([batches[u % len(batches)]], overlap_optimizer=overlap)
+            gn.append(r["gnorm"])  # (read after the loop: no host sync between the updates)
+        t.wait_optimizer()
+        backend.sync()
+        runs.append((model.engine.params.clone(), t.exp_avg.clone(), float(gn[-1][0]), int(t.skipped)))
+        del t, model, task
+    (p0, m0, g0, s0), (p1, m1, g1, s1), (p2, m2, g2, s2) = runs
+    assert s0 == s1 == s2 == 0 and np.isfinite(g0)
+    assert torch.equal(p1, p2) and torch.equal(m1, m2)  # the overlapped schedule repeats itself ...
+    assert torch.equal(p0, p1) and torch.equal(m0, m1) and g0 == g1  # ... and equals the plain one
