@@ -389,6 +389,9 @@ def infer_main(args):
     print(json.dumps(line))
 
 
+ADAM_OVERLAP = os.environ.get("S2ST_ADAM_OVERLAP", "0") == "1"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -485,7 +488,9 @@ def main():
         vlog('largest waveform batch', tuple(wb))
 
     def step(i):
-        return trainer.train_step([prepared[i]], overlap_optimizer=True)  # (S2ST_ADAM_OVERLAP=0: the A/B switch)
+        # (S2ST_ADAM_OVERLAP=1: the update overlapped with the next forward -- measured 7.40 vs 7.43 ms/step, within
+        # noise: the HBM-bound update slows the forward's first layers by what it saves, so it stays off)
+        return trainer.train_step([prepared[i]], overlap_optimizer=ADAM_OVERLAP)
 
     for i in range(args.warmup):
         step(i)
@@ -570,7 +575,7 @@ def main():
             torch.cuda.synchronize()
             th0 = time.perf_counter()
             for smp in src:
-                trainer.train_step([smp], overlap_optimizer=True)
+                trainer.train_step([smp], overlap_optimizer=ADAM_OVERLAP)
             torch.cuda.synchronize()
             th = time.perf_counter() - th0
             vlog('host-fed (PCIe-inclusive), %s uploads: %.3f ms/step, %.0f mel-frames/s over %d steps' % (

@@ -2059,6 +2059,7 @@ void s2st_engine_destroy(s2st_engine* e) {
     if (e->ev_taps_) hipEventDestroy(e->ev_taps_);
     if (e->ev_auxb_) hipEventDestroy(e->ev_auxb_);
     if (e->ev_kv_) hipEventDestroy(e->ev_kv_);
+    for (hipEvent_t ev : e->adam_ev) hipEventDestroy(ev);
   }
   e->reset_call();
   delete e;

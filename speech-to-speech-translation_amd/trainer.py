@@ -134,7 +134,7 @@ class Trainer:
         bd.call("s2st_sumsq_parts_f32", eng.grads, eng.n_params, self.sumsq_parts)
         lr = self.get_lr()
         import os
-        if overlap_optimizer and os.environ.get("S2ST_ADAM_OVERLAP", "1") != "0":
+        if overlap_optimizer:
             eng.adam_overlapped(self.exp_avg, self.exp_avg_sq, self.sumsq_parts, nparts, gmul, gmul_dev, float(self.clip_norm),
                                 lr, self.betas[0], self.betas[1], self.eps, self.wd, self.num_updates + 1, self.gnorm,
                                 self.skipped, self._ph() is not None, int(os.environ.get("S2ST_ADAM_CHUNKS", "8")))
