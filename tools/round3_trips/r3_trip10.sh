@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, trip 10: whole GPU suite, the profile round (r03_f), one-step timeline
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out
 export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$PWD}
 timeout 2400 python -m pytest tests -q -m gpu > gpurun_out/t10_pytest.log 2>&1
 echo "pytest rc $?" | tee -a gpurun_out/t10_pytest.log

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, trip 11: loss sums folded by the finalize kernel, one-pass halo images; whole suite (+ engine tests with a
 # NaN-poisoned workspace), bench
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out
 timeout 2400 python -m pytest tests -q -m gpu > gpurun_out/t11_pytest.log 2>&1
 echo "pytest rc $?" | tee -a gpurun_out/t11_pytest.log
 grep -E "passed|failed|FAILED" gpurun_out/t11_pytest.log | tail -8

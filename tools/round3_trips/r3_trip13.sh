@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, trip 13: BatchNorm statistics in one pass, BatchNorm output written as the next convolution's bf16 halo image
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out
 timeout 2400 python -m pytest tests -q -m gpu > gpurun_out/t13_pytest.log 2>&1
 echo "pytest rc $?" | tee -a gpurun_out/t13_pytest.log
 grep -E "passed|failed|FAILED|^E  " gpurun_out/t13_pytest.log | tail -8

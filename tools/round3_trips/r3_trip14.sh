@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, trip 14: first convolution's weight gradient on the idle data-path stream; single-barrier layer-norm fold
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -q -m gpu -k "engine or full_size or layernorm or hubert_train or distributed" > gpurun_out/t14_pytest.log 2>&1
 echo "pytest rc $?" | tee -a gpurun_out/t14_pytest.log
 grep -E "passed|failed|FAILED|^E  " gpurun_out/t14_pytest.log | tail -8

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, trip 17: profile round r03_g (bench line, kernel stats, stream timelines, PMC passes, traffic JSON), one-step
 # timeline, other workloads' bench lines, determinism across fresh processes
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out
 export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$PWD}
 timeout 2400 bash tools/profile_round.sh r03_g > gpurun_out/t17_profile_round.log 2>&1
 tail -18 gpurun_out/t17_profile_round.log | cut -c1-300

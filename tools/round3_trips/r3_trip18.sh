@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, trip 18: attention kernels with tile loads two tiles ahead + the tile's log-sum-exp through LDS
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -q -m gpu -k "attention or engine or full_size or hubert_train or base_size or inference" > gpurun_out/t18_pytest.log 2>&1
 echo "pytest rc $?" | tee -a gpurun_out/t18_pytest.log
 grep -E "passed|failed|FAILED|^E  " gpurun_out/t18_pytest.log | tail -8

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, trip 20: 32-bit dropout mixer (two 32-bit multiplies instead of three 64-bit ones)
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out
 export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$PWD}
 timeout 2400 python -m pytest tests -q -m gpu > gpurun_out/t20_pytest.log 2>&1
 echo "pytest rc $?" | tee -a gpurun_out/t20_pytest.log

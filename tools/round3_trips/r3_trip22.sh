@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, trip 22: straight-line element work in the attention kernels
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out
 export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$PWD}
 timeout 1500 python -m pytest tests -q -m gpu -k "attention or engine or full_size or hubert_train or base_size or inference" > gpurun_out/t22_pytest.log 2>&1
 echo "pytest rc $?" | tee -a gpurun_out/t22_pytest.log

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, trip 25: optimizer update overlapped with the next forward
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out
 export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$PWD}
 timeout 2400 python -m pytest tests -q -m gpu > gpurun_out/t25_pytest.log 2>&1
 echo "pytest rc $?" | tee -a gpurun_out/t25_pytest.log

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, trip 7: where the fused and the split layer-norm backward part ways on hardware; ordered embedding backward
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out
 for v in "S2ST_NO_SIDE_STREAM=1" "S2ST_NO_LN_FUSE=1" "S2ST_JOIN_EVERY_SEGMENT=1" "S2ST_NO_WGRAD_GROUP=1" "S2ST_LN_RPW=1"; do
   timeout 300 python tools/debug_lnsplit.py hip $v 2>&1 | grep -v amdgpu.ids
 done > gpurun_out/t7_lnsplit.txt
