@@ -135,7 +135,7 @@ __device__ __forceinline__ void gemm_bf16_dma_tile(const GemmArgs& g, int id, co
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int wm = wave / WGN, wn = wave % WGN;
-  {
+  if (nwg > 0) {  // (nwg == 0: the caller already placed the tiles)
     const int x = id & 7, q = nwg >> 3, r = nwg & 7;
     id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
   }
@@ -349,9 +349,18 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_kernel(GemmArgs g) {
 template <int BM, int BN, bool AKM, bool BKM, int NS, int NW, bool IL = false>
 __global__ __launch_bounds__(64 * NW) void gemm_bf16_dma_group_kernel(GemmGroup grp) {
   int pi = 0;
-  const int t = blockIdx.x;
+  int t = blockIdx.x;
+  if (grp.xcd_global) {
+    // The workgroups of one XCD (blockIdx % 8) take ONE contiguous run of the concatenated tile list: ~G / 8 tiles of one
+    // or two products, i.e. a few whole tile rows -- they share far fewer operand panels in that XCD's L2 than one
+    // eighth of EVERY product's tiles (the per-product order below), which is what re-fetched every panel ~2x per launch.
+    const int G = grp.tile0[grp.n];
+    const int x = t & 7, q = G >> 3, r = G & 7;
+    t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (t >> 3);
+  }
   while (pi + 1 < grp.n && t >= grp.tile0[pi + 1]) ++pi;
-  gemm_bf16_dma_tile<BM, BN, AKM, BKM, NS, NW, IL>(grp.g[pi], t - grp.tile0[pi], grp.tile0[pi + 1] - grp.tile0[pi], 0);
+  gemm_bf16_dma_tile<BM, BN, AKM, BKM, NS, NW, IL>(grp.g[pi], t - grp.tile0[pi],
+                                                    grp.xcd_global ? 0 : grp.tile0[pi + 1] - grp.tile0[pi], 0);
 }
 
 // as-launched work of one GEMM (profiling records): FLOPs, and the bytes it has to move at least -- both bf16
@@ -1057,6 +1066,9 @@ int s2st_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t st) {
   bool sk_bound = false;
   for (int i = 0; i < g_sk_n; ++i) sk_bound = sk_bound || (g_sk[i].st == st && g_sk[i].p);
   if (!(os && atoi(os) == 0) && !(sk_bound && streamk_mode() > 0)) {
+    // S2ST_GROUP_XCD=0 (A/B switch): every product's tiles spread over all XCDs (the form up to round 3)
+    static const bool xcd_global = !(getenv("S2ST_GROUP_XCD") && atoi(getenv("S2ST_GROUP_XCD")) == 0);
+    grp.xcd_global = xcd_global ? 1 : 0;
     if (w4_mode() >= 2 ? s2st_gemm_bf16_w4_group(grp, st) : launch_dma_group<128, 128, 4, 8, true>(grp, st)) return S2ST_ERR_LAUNCH;
     return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
   }

@@ -63,6 +63,7 @@ struct GemmGroup {
   // that reaches the tile's last K-step adds them and runs the epilogue.  sk_ctr: 8 per-XCD ticket counters + a
   // completion counter (zero before the first launch; the last workgroup of a launch resets them).
   int sk, epoch;
+  int xcd_global;  // one-shot grouped form: each XCD owns one contiguous run of the CONCATENATED tile list
   int* sk_ctr;
   int* sk_flag;
   float* sk_part;
