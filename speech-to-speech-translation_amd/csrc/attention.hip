@@ -135,6 +135,23 @@ __device__ __forceinline__ bf16x8 pack_frag(const float (&v)[8]) {
   return cv.f;
 }
 
+// XCD-aware workgroup order: hardware deals consecutive workgroups (x fastest) to the 8 XCDs in turn, so the blocks of one
+// (batch, head) pair -- which all read the same Q / K / V / dO tiles -- used to land on 8 different L2s (PMC: the backward
+// fetched 68 MB per launch for 17 MB of operands).  The linear id is re-read as (XCD = id % 8, slot = id / 8): XCD x
+// owns pair 8 s + x of every group s of 8 pairs, for all of that pair's blocks.  Pairs beyond the last full group keep
+// the plain order.  (S2ST_ATTN_XCD=0 at launch: `plain` = 1, the A/B switch.)
+__device__ __forceinline__ void attn_block(int plain, int& bx, int& bh) {
+  const int nbx = gridDim.x, nbh = gridDim.y;
+  bx = blockIdx.x;
+  bh = blockIdx.y;
+  const int L = bh * nbx + bx, full = (nbh >> 3) << 3;
+  if (!plain && L < full * nbx) {
+    const int x = L & 7, j = L >> 3, s = j / nbx;
+    bh = 8 * s + x;
+    bx = j - s * nbx;
+  }
+}
+
 struct AttnArgs {
   const bf16_t *q, *k, *v;       // bf16 projections; row (b, t) at base + (b * rows + t) * ld + h * DH
   long ldq, ldk, ldv;
@@ -149,6 +166,7 @@ struct AttnArgs {
   // backward
   const bf16_t* doh;              // bf16 dO [B*T][H*DH]
   const float* dvec;              // D[b,h,t] = rowsum(dO * O)
+  int plain_order;                // 1: blocks in launch order (see attn_block)
 #ifdef S2ST_ATTN_STAMP  // tools/attn_stamp.sh: a PRIVATE build that writes per-workgroup clock stamps (8 longs each)
   long* stamp;
 #define ATTN_STAMP(k) do { if (threadIdx.x == 0) a.stamp[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = clock64(); } while (0)
@@ -206,14 +224,16 @@ __global__ __launch_bounds__(64 * NW, 3) void flash_fwd_kernel(AttnArgs a) {
   unsigned char* kimg = smem;                      // row image of the K tile
   unsigned char* vimg = smem + Img<DH>::BYTES;     // tr image of the V tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
-  const int q0 = blockIdx.x * (16 * NW) + wave * 16;
+  int bxr, bh;
+  attn_block(a.plain_order, bxr, bh);
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int q0 = bxr * (16 * NW) + wave * 16;
   const int qi = q0 + (lane & 15);                 // this lane's query (column)
   const bf16_t* qb = a.q + (long)b * a.T * a.ldq + h * DH;
   const bf16_t* kb = a.k + (long)b * a.S * a.ldk + h * DH;
   const bf16_t* vb = a.v + (long)b * a.S * a.ldv + h * DH;
   int klim = a.klen ? min((int)a.klen[b], a.S) : a.S;
-  const int kmax = a.causal ? min(klim, (int)(blockIdx.x + 1) * (16 * NW)) : klim;  // keys any query of the block sees
+  const int kmax = a.causal ? min(klim, (bxr + 1) * (16 * NW)) : klim;  // keys any query of the block sees
 
   bf16x8 qf[KS];
   load_frags<DH>(qb, a.ldq, q0, a.T, lane, qf);
@@ -335,14 +355,14 @@ __global__ __launch_bounds__(256) void attn_dvec_kernel(const float* __restrict_
 //   dK^T[d][key] += Q^T[d][q] dS[q][key]   (scaled at the end)
 // ------------------------------------------------------------------------------------------------
 template <int DH, int NW>
-__device__ __forceinline__ void flash_bwd_kv_body(const AttnArgs& a, unsigned char* smem, const int bx) {
+__device__ __forceinline__ void flash_bwd_kv_body(const AttnArgs& a, unsigned char* smem, const int bx, const int bh) {
   constexpr int KS = DH / 32, DT = DH / 16;
   unsigned char* q_row = smem;
   unsigned char* q_tr = smem + Img<DH>::BYTES;
   unsigned char* do_row = smem + 2 * Img<DH>::BYTES;
   unsigned char* do_tr = smem + 3 * Img<DH>::BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int b = bh / a.H, h = bh - b * a.H;
   const int k0 = bx * (16 * NW) + wave * 16;
   const int ki = k0 + (lane & 15);  // this lane's key (column)
   const bf16_t* qb = a.q + (long)b * a.T * a.ldq + h * DH;
@@ -465,13 +485,13 @@ __device__ __forceinline__ void flash_bwd_kv_body(const AttnArgs& a, unsigned ch
 //   dQ^T[d][q] += K^T[d][key] dS^T[key][q]
 // ------------------------------------------------------------------------------------------------
 template <int DH, int NW>
-__device__ __forceinline__ void flash_bwd_q_body(const AttnArgs& a, unsigned char* smem, const int bx) {
+__device__ __forceinline__ void flash_bwd_q_body(const AttnArgs& a, unsigned char* smem, const int bx, const int bh) {
   constexpr int KS = DH / 32, DT = DH / 16;
   unsigned char* k_row = smem;
   unsigned char* k_tr = smem + Img<DH>::BYTES;
   unsigned char* v_row = smem + 2 * Img<DH>::BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int b = bh / a.H, h = bh - b * a.H;
   const int q0 = bx * (16 * NW) + wave * 16;
   const int qi = q0 + (lane & 15);
   const bf16_t* qb = a.q + (long)b * a.T * a.ldq + h * DH;
@@ -566,14 +586,18 @@ template <int DH, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void flash_bwd_kv_kernel(AttnArgs a) {
   if (a.T <= 0 || a.S <= 0) return;  // empty problem (kernel preload)
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * Img<DH>::BYTES];
-  flash_bwd_kv_body<DH, NW>(a, smem, (int)blockIdx.x);
+  int bx, bh;
+  attn_block(a.plain_order, bx, bh);
+  flash_bwd_kv_body<DH, NW>(a, smem, bx, bh);
 }
 
 template <int DH, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void flash_bwd_q_kernel(AttnArgs a) {
   if (a.T <= 0 || a.S <= 0) return;
   __shared__ __attribute__((aligned(16))) unsigned char smem[3 * Img<DH>::BYTES];
-  flash_bwd_q_body<DH, NW>(a, smem, (int)blockIdx.x);
+  int bx, bh;
+  attn_block(a.plain_order, bx, bh);
+  flash_bwd_q_body<DH, NW>(a, smem, bx, bh);
 }
 
 // Both passes in ONE launch: workgroups [0, nkx) of a (b, h) row are key blocks (dK, dV), the rest query blocks (dQ).
@@ -584,8 +608,10 @@ template <int DH, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void flash_bwd_kernel(AttnArgs a, int nkx) {
   if (a.T <= 0 || a.S <= 0) return;
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * Img<DH>::BYTES];
-  if ((int)blockIdx.x < nkx) flash_bwd_kv_body<DH, NW>(a, smem, (int)blockIdx.x);
-  else flash_bwd_q_body<DH, NW>(a, smem, (int)blockIdx.x - nkx);
+  int bx, bh;
+  attn_block(a.plain_order, bx, bh);
+  if (bx < nkx) flash_bwd_kv_body<DH, NW>(a, smem, bx, bh);
+  else flash_bwd_q_body<DH, NW>(a, smem, bx - nkx, bh);
 }
 
 // waves per workgroup (16 columns each): 2 -> T/32 x B*H workgroups, several resident per CU, so the
@@ -611,6 +637,8 @@ AttnArgs to_args(const s2st_attn_args& p) {
   a.scale = p.scale; a.drop_p = p.drop_p; a.seed = p.seed; a.ld_drop = p.ld_drop;
   a.doh = p.doh; a.dq = p.dq; a.dk = p.dk; a.dv = p.dv;
   a.dqh = p.dqh; a.dkh = p.dkh; a.dvh = p.dvh; a.dbq = p.dbq; a.dbk = p.dbk; a.dbv = p.dbv;
+  static const int plain = (getenv("S2ST_ATTN_XCD") && atoi(getenv("S2ST_ATTN_XCD")) == 0) ? 1 : 0;
+  a.plain_order = plain;
   return a;
 }
 
