@@ -19,29 +19,41 @@ CSRC = os.path.join(ROOT, "speech-to-speech-translation_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
-def _asm(src, tmp_path):
-    out = os.path.join(str(tmp_path), os.path.basename(src) + ".s")
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", CSRC, "-I", os.path.join(ROOT, "include"),
-                           "-Wno-unused-value", "-Wno-unused-command-line-argument", "-S", "--cuda-device-only", "-x", "hip",
-                           os.path.join(CSRC, src), "-o", out])
-    return out
+SOURCES = ("gemm_bf16.hip", "gemm_bf16_w4.hip", "losses.hip")
+
+
+@pytest.fixture(scope="module")
+def asm(tmp_path_factory):
+    """The three sources compiled to gfx950 assembly, side by side (one hipcc process each)."""
+    d = str(tmp_path_factory.mktemp("isa"))
+    procs = {}
+    for src in SOURCES:
+        out = os.path.join(d, src + ".s")
+        procs[src] = (out, subprocess.Popen(
+            [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-Wno-unused-value",
+             "-Wno-unused-command-line-argument", "-S", "--cuda-device-only", "-x", "hip", os.path.join(CSRC, src), "-o", out]))
+    res = {}
+    for src, (out, pr) in procs.items():
+        assert pr.wait() == 0, "hipcc failed on " + src
+        res[src] = out
+    return res
 
 
 pytestmark = pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason="needs hipcc")
 
 
 @pytest.mark.parametrize("src", ["gemm_bf16.hip", "gemm_bf16_w4.hip"])
-def test_hand_issued_transposed_reads_are_waited_for(src, tmp_path):
+def test_hand_issued_transposed_reads_are_waited_for(src, asm):
     spec = importlib.util.spec_from_file_location("check_raw_reads", os.path.join(ROOT, "tools", "check_raw_reads.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    total, bad, msgs = mod.check(_asm(src, tmp_path))
+    total, bad, msgs = mod.check(asm[src])
     assert total > 0, "no hand-issued transposed read found: the check looks at the wrong thing"
     assert bad == 0, "\n".join(msgs)
 
 
-def test_ctc_step_keeps_its_prefetch_in_flight(tmp_path):
-    s = open(_asm("losses.hip", tmp_path)).read()
+def test_ctc_step_keeps_its_prefetch_in_flight(asm):
+    s = open(asm["losses.hip"]).read()
     m = re.search(r"^(_ZN\S*ctc_ab_kernelILi2E\S*):[^\n]*\n(.*?)s_endpgm", s, re.S | re.M)
     assert m, "ctc_ab_kernel<2> not found"
     body = m.group(2).splitlines()
