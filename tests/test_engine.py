@@ -322,6 +322,12 @@ def test_fused_backward_paths_equal_the_unfused_ones(backend, cfg, switch, monke
     emits the preceding linear layer's dropout-backward operand + bias gradient, the hoisted cross-attention
     K|V projections, the ReLU-dropout backward in the data-gradient GEMM epilogue.  Same masks, same bf16
     operands: the gradients agree to fp32 summation order."""
+    # (the emulator runs the switches that change kernels' ARITHMETIC paths; pure launch-structure switches are left to
+    # the GPU run, where every combination executes: the CPU suite stays within minutes)
+    if backend.kind == "emu" and switch not in ("S2ST_NO_LN_FUSE", "S2ST_NO_ACT_FUSE", "S2ST_ATTN_GFUSE=0", "S2ST_ATTN_GFUSE=3",
+                                                "S2ST_LN_BWD_SPLIT", "S2ST_NO_WGRAD_GROUP", "S2ST_ORDERED_BIAS_SUMS=0",
+                                                "S2ST_ATTN_DVEC_KERNEL"):
+        pytest.skip("launch-structure switch: covered by the GPU run")
     D = importlib.import_module(DATA)
     cfg = dict(cfg, dropout=0.1, attention_dropout=0.1, activation_dropout=0.05, prenet_dropout=0.5, postnet_dropout=0.5)
     c = D.SyntheticFisherCorpus(n_utts=4, seed=3, max_src=64, median_src=50, min_src=30)
