@@ -261,6 +261,12 @@ typedef struct {
    * [n_speakers, out_dim] -- the row replaces the first frame of prev_output_tokens.  spk_frozen: tables loaded with
    * Embedding.from_pretrained(freeze=True): no gradient is formed for them. */
   int32_t n_speakers, spk_frozen;
+  /* t2s_transformer with speakers (examples/s2s_trans/models/t2s_transformer.py:43-46, 107-111): the table is
+   * encoder.embed_speaker.weight [n_speakers, spk_dim] (--speaker-embed-dim) and the encoder output becomes
+   * encoder.spk_emb_proj(cat[x, row]) with weight [enc_dim, enc_dim + spk_dim]; unused (0) for speech input, where the
+   * rows are added and their widths are fixed by enc_dim / out_dim.  Frozen tables (spk_frozen) are reported as
+   * BUFFERS by s2st_engine_param_info: they live next to the BatchNorm statistics, outside the optimizer's arena. */
+  int32_t spk_dim;
   float dropout, attn_dropout, act_dropout, prenet_dropout, postnet_dropout;
   float ctc_weight, asr_weight, st_weight, w_l1, w_mse, w_eos, bce_pos_weight, label_smoothing;
   float ctc_tgt_weight;                   /* s2st_loss_mtl.py:171-185 */

@@ -241,6 +241,43 @@ __global__ __launch_bounds__(256) void speaker_set_rows_kernel(const float* __re
   y[(long)b * T * C + c] = table[ids[b] * C + c];
 }
 
+// t2s text encoder (t2s_transformer.py:107-111): columns [coff, coff + Sd) of every row of utterance b <- table[ids[b]]
+__global__ __launch_bounds__(256) void speaker_fill_cols_kernel(const float* __restrict__ table, const long* __restrict__ ids,
+                                                                float* __restrict__ y, int B, int T, int ld, int coff, int Sd) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * T * Sd) return;
+  const long r = i / Sd;
+  const int c = (int)(i - r * Sd);
+  y[r * ld + coff + c] = table[ids[r / T] * Sd + c];
+}
+
+// ... and its gradient: dtable[s][c] += sum over {b : ids[b] == s}, t < T of dy[b][t][coff + c] -- one thread per
+// (speaker, column), utterances and rows in index order (no atomics)
+__global__ __launch_bounds__(256) void speaker_cols_bwd_kernel(const float* __restrict__ dy, const long* __restrict__ ids, int B,
+                                                               int T, int ld, int coff, int Sd, int n_spk,
+                                                               float* __restrict__ dtable) {
+  const int c = blockIdx.x * 256 + threadIdx.x, sp = blockIdx.y;
+  if (c >= Sd || sp >= n_spk) return;
+  float a = 0.f;
+  for (int b = 0; b < B; ++b) {
+    if (ids[b] != sp) continue;
+    for (int t = 0; t < T; ++t) a += dy[((long)b * T + t) * ld + coff + c];
+  }
+  dtable[(long)sp * Sd + c] += a;
+}
+
+// dx[r][0..C) (+)= g[r][0..C) for g rows of stride ldg
+__global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict__ g, int ldg, float* __restrict__ dx, int ldx,
+                                                         int rows, int C, int acc) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)rows * C) return;
+  const long r = i / C;
+  const int c = (int)(i - r * C);
+  const float v = g[r * ldg + c];
+  float* d = dx + r * ldx + c;
+  *d = acc ? *d + v : v;
+}
+
 // dalpha += sum_i dy[i] * mask(i) * PE[pos(row)][c]
 __global__ __launch_bounds__(256) void pe_alpha_bwd_kernel(const float* __restrict__ dy,
                                                            const int* __restrict__ pos,
@@ -803,6 +840,29 @@ int s2st_speaker_bwd(const float* dy, const long* ids, int B, int T, int T_sum, 
   if (B <= 0 || C <= 0 || n_spk <= 0) return 0;
   S2ST_LAUNCH(speaker_bwd_kernel, dim3((C + 255) / 256, n_spk), dim3(256), 0, st, dy, ids, B, T, T_sum, C, n_spk, drop_p,
               seed, dtable);
+  return LAUNCH_OK();
+}
+
+int s2st_speaker_fill_cols(const float* table, const long* ids, float* y, int B, int T, int ld, int coff, int Sd, hipStream_t st) {
+  if (B <= 0 || T <= 0 || Sd <= 0) return 0;
+  if (!table || !ids || !y || coff < 0 || coff + Sd > ld) return S2ST_ERR_ARG;
+  S2ST_LAUNCH(speaker_fill_cols_kernel, dim3((unsigned)(((long)B * T * Sd + 255) / 256)), dim3(256), 0, st, table, ids, y, B, T,
+              ld, coff, Sd);
+  return LAUNCH_OK();
+}
+
+int s2st_speaker_cols_bwd(const float* dy, const long* ids, int B, int T, int ld, int coff, int Sd, int n_spk, float* dtable,
+                          hipStream_t st) {
+  if (B <= 0 || T <= 0 || Sd <= 0 || n_spk <= 0) return 0;
+  if (!dy || !ids || !dtable || coff < 0 || coff + Sd > ld) return S2ST_ERR_ARG;
+  S2ST_LAUNCH(speaker_cols_bwd_kernel, dim3((Sd + 255) / 256, n_spk), dim3(256), 0, st, dy, ids, B, T, ld, coff, Sd, n_spk, dtable);
+  return LAUNCH_OK();
+}
+
+int s2st_split_cols(const float* g, int ldg, float* dx, int ldx, int rows, int C, int acc, hipStream_t st) {
+  if (rows <= 0 || C <= 0) return 0;
+  if (!g || !dx || C > ldg || C > ldx) return S2ST_ERR_ARG;
+  S2ST_LAUNCH(split_cols_kernel, dim3((unsigned)(((long)rows * C + 255) / 256)), dim3(256), 0, st, g, ldg, dx, ldx, rows, C, acc);
   return LAUNCH_OK();
 }
 

@@ -327,6 +327,12 @@ struct s2st_engine {
   }
 
   long enc_spk = -1, dec_spk = -1;  // speaker-embedding tables (n_speakers > 0)
+  // frozen tables (Embedding.from_pretrained(freeze=True), tasks/s2s_translation.py:161-171) live in the BUFFER arena like
+  // the BatchNorm statistics: the reference leaves them out of the optimizer, so neither Adam's sweep over the
+  // parameter arena nor weight decay may touch them
+  const float* spk_tab(long off) const { return (c.spk_frozen ? BUF : P) + off; }
+  void touch_spk(long off_end) { if (!c.spk_frozen) touch(off_end); }
+  LinP enc_spk_proj{-1, -1, 0, 0};  // t2s text encoder: spk_emb_proj over cat[x, emb] (t2s_transformer.py:43-46, 107-111)
   // t2s text encoder front
   long enc_embed = -1, enc_pos_alpha = -1;
   std::vector<ConvP> enc_conv;
@@ -358,7 +364,7 @@ struct s2st_engine {
     sub[1] = ConvP{add("encoder.subsample.conv_layers.1.weight", {2 * C, c.conv_channels / 2, c.conv_k}),
                    add("encoder.subsample.conv_layers.1.bias", {2 * C}), 2 * C, c.conv_channels / 2,
                    c.conv_k};
-    if (c.n_speakers > 0) enc_spk = add("encoder.embed_speaker.weight", {c.n_speakers, C});
+    if (c.n_speakers > 0) enc_spk = add("encoder.embed_speaker.weight", {c.n_speakers, C}, c.spk_frozen ? 1 : 0);
     }
     for (int i = 0; i < c.enc_layers; ++i) {
       std::string pre = "encoder.transformer_layers." + std::to_string(i);
@@ -372,10 +378,16 @@ struct s2st_engine {
     }
     has_enc_ln = c.enc_pre_ln != 0;
     if (has_enc_ln) enc_ln = add_ln("encoder.layer_norm", C);
+    if (c.text_input && c.n_speakers > 0) {
+      // the table is spk_dim wide here (task.get_speaker_embeddings: Embedding(len(speaker_to_id), speaker_embed_dim))
+      enc_spk = add("encoder.embed_speaker.weight", {c.n_speakers, c.spk_dim}, c.spk_frozen ? 1 : 0);
+      enc_spk_proj = add_lin("encoder.spk_emb_proj", C, C + c.spk_dim);
+    }
     if (c.has_asr) asr_norm = add_ln("encoder.aux_asr_norm", C);
     if (c.has_st) st_norm = add_ln("encoder.aux_st_norm", C);
     pos_alpha = add("decoder.pos_emb_alpha", {1});
-    if (c.n_speakers > 0) dec_spk = add("decoder.embed_speaker.weight", {c.n_speakers, c.out_dim});
+    if (c.n_speakers > 0 && !c.text_input)  // (the t2s decoder takes `speaker` and ignores it: t2s_transformer.py:172-176)
+      dec_spk = add("decoder.embed_speaker.weight", {c.n_speakers, c.out_dim}, c.spk_frozen ? 1 : 0);
     for (int i = 0; i < c.prenet_layers; ++i)
       prenet.push_back(add_lin("decoder.prenet.0.layers." + std::to_string(i) + ".0",
                                c.prenet_dim, i == 0 ? c.out_dim : c.prenet_dim));
@@ -1185,12 +1197,12 @@ struct s2st_engine {
     const uint64_t sd = drop_p > 0.f ? next_seed() : 0;
     if (alpha_off >= 0) touch(alpha_off + 1);
     const bool spk = spk_off >= 0 && bt.speaker != nullptr;
-    if (spk) touch(spk_off + (long)c.n_speakers * x->cols);
+    if (spk) touch_spk(spk_off + (long)c.n_speakers * x->cols);
     const long* spk_ids = (const long*)bt.speaker;
     const int Bn = T > 0 ? x->rows / T : 0;
     if (live())
       chk(s2st_add_pe(x->d, y->d, pos, table, x->rows, x->cols, scale, alpha_off >= 0 ? P + alpha_off : nullptr,
-                      drop_p, sd, st_, spk ? P + spk_off : nullptr, spk ? spk_ids : nullptr, T));
+                      drop_p, sd, st_, spk ? spk_tab(spk_off) : nullptr, spk ? spk_ids : nullptr, T));
     tape.push_back([=]() {
       if (!y->g) return;
       if (spk && !c.spk_frozen && live())
@@ -1263,7 +1275,8 @@ struct s2st_engine {
       // so during incremental decoding EVERY step's input is the speaker row and the fed-back feature is dropped.
       // Reproduced as is (results identical to the reference's).
       Ten* sp = newT(B, c.out_dim);
-      if (live()) chk(s2st_embed_fwd((const long*)bt.speaker, P + dec_spk, sp->d, B, c.out_dim, 1.f, st_));
+      touch_spk(dec_spk + (long)c.n_speakers * c.out_dim);  // (an overlapped optimizer update may still be writing the table)
+      if (live()) chk(s2st_embed_fwd((const long*)bt.speaker, spk_tab(dec_spk), sp->d, B, c.out_dim, 1.f, st_));
       sp->needs_grad = false;
       x = sp;
     }
@@ -1737,9 +1750,38 @@ struct s2st_engine {
       if (i == c.tap_st) tap_st = x;
       if (i % 3 == 2) mark();
     }
-    Ten* enc_out = has_enc_ln ? layernorm(x, enc_ln, outs.enc_out) : x;
-    if (!has_enc_ln && outs.enc_out && live())  // post-LN encoder (t2s default): the last layer's output is the result
+    const bool t2s_spk = c.text_input && enc_spk >= 0 && bt.speaker != nullptr;
+    Ten* enc_out = has_enc_ln ? layernorm(x, enc_ln, t2s_spk ? nullptr : outs.enc_out) : x;
+    if (t2s_spk) {
+      // t2s_transformer.py:107-111: x = spk_emb_proj(cat[x, emb.expand(T)]) on EVERY position (padded ones included),
+      // after the final layer norm.  The concatenation is materialised so that forward, data gradient and weight
+      // gradient are the ordinary linear(); its backward splits the gradient into x's block and the table's rows.
+      const int Sd = c.spk_dim;
+      Ten* cat = newT(B * E, C + Sd);
+      Ten* xin = enc_out;
+      touch_spk(enc_spk + (long)c.n_speakers * Sd);
+      if (live()) {
+        chk(s2st_copy_rows(xin->d, Split{(long)C, 0, 0, 0}, cat->d, Split{(long)(C + Sd), 0, 0, 0}, B * E, C, st_));
+        chk(s2st_speaker_fill_cols(spk_tab(enc_spk), (const long*)bt.speaker, cat->d, B, E, C + Sd, C, Sd, st_));
+      }
+      const long soff = enc_spk;
+      tape.push_back([=]() {
+        if (!cat->g) return;
+        if (!c.spk_frozen && live())
+          chk(s2st_speaker_cols_bwd(cat->g, (const long*)bt.speaker, B, E, C + Sd, C, Sd, c.n_speakers, G + soff, st_));
+        if (xin->needs_grad) {
+          bool acc;
+          float* dx = gradbuf(xin, acc);
+          if (live()) chk(s2st_split_cols(cat->g, C + Sd, dx, C, B * E, C, acc ? 1 : 0, st_));
+        }
+      });
+      enc_out = linear(cat, enc_spk_proj.w, enc_spk_proj.b, C, C + Sd, 0, 0.f, nullptr, outs.enc_out);
+    } else if (!has_enc_ln && outs.enc_out && live())  // post-LN encoder (t2s default): the last layer's output is the result
       hipMemcpyAsync(outs.enc_out, x->d, sizeof(float) * (size_t)x->n(), hipMemcpyDeviceToDevice, st_);
+    // (mtl variant / CTC head without the aux ASR decoder: tap 0 is the RAW layer output -- no aux_asr_norm,
+    // s2st_transformer_mtl.py:150-153 -- handed out as is for greedy CTC decoding, speech_generator_for_s2st_mtl.py:66-69)
+    if (!c.has_asr && tap_asr && outs.tap0 && live())
+      hipMemcpyAsync(outs.tap0, tap_asr->d, sizeof(float) * (size_t)tap_asr->n(), hipMemcpyDeviceToDevice, st_);
     if (c.has_asr && tap_asr) tap_asr = layernorm(tap_asr, asr_norm, outs.tap0);
     if (c.has_st && tap_st) tap_st = layernorm(tap_st, st_norm, outs.tap1);
     // the CTC head and the aux text decoders only need the encoder taps: they are issued (below, in tape
@@ -1781,10 +1823,10 @@ struct s2st_engine {
       // the speaker's row replaces the first input frame (s2st_transformer.py:441-444): a copy of prev_output_tokens
       // with row (b, 0) overwritten; its gradient there is the table's gradient
       Ten* pv = newT(B * D, c.out_dim);
-      touch(dec_spk + (long)c.n_speakers * c.out_dim);
+      touch_spk(dec_spk + (long)c.n_speakers * c.out_dim);
       if (live()) {
         hipMemcpyAsync(pv->d, bt.prev, sizeof(float) * (size_t)pv->n(), hipMemcpyDeviceToDevice, st_);
-        chk(s2st_speaker_set_rows(P + dec_spk, (const long*)bt.speaker, pv->d, B, D, c.out_dim, st_));
+        chk(s2st_speaker_set_rows(spk_tab(dec_spk), (const long*)bt.speaker, pv->d, B, D, c.out_dim, st_));
       }
       pv->needs_grad = tr && !c.spk_frozen;
       const long doff = dec_spk;

@@ -182,6 +182,13 @@ int s2st_add_pe(const float* x, float* y, const int* pos, const float* table, in
 // fixed summation order (no atomics)
 int s2st_speaker_bwd(const float* dy, const long* ids, int B, int T, int T_sum, int C, int n_spk, float drop_p,
                      uint64_t seed, float* dtable, hipStream_t st);
+// t2s text encoder (t2s_transformer.py:107-111): y[(b,t)][coff .. coff + Sd) = table[ids[b]] for y rows of stride ld;
+// its gradient dtable[s] += sum_{b: ids[b] == s} sum_t dy[(b,t)][coff ..) in index order (no atomics); and
+// dx[r][0..C) (+)= g[r][0..C) (the other block of the concatenated gradient)
+int s2st_speaker_fill_cols(const float* table, const long* ids, float* y, int B, int T, int ld, int coff, int Sd, hipStream_t st);
+int s2st_speaker_cols_bwd(const float* dy, const long* ids, int B, int T, int ld, int coff, int Sd, int n_spk, float* dtable,
+                          hipStream_t st);
+int s2st_split_cols(const float* g, int ldg, float* dx, int ldx, int rows, int C, int acc, hipStream_t st);
 // y[b][0][:] = table[ids[b]] for y [B][T][C]
 int s2st_speaker_set_rows(const float* table, const long* ids, float* y, int B, int T, int C, hipStream_t st);
 // dalpha += sum dropmask * dy * table[pos]

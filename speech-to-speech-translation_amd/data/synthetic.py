@@ -56,7 +56,12 @@ class SyntheticFisherCorpus:
         median_src: float = 300.0,
         sigma: float = 0.6,
         with_audio: bool = False,
+        mtl: bool = False,
+        src_dict=None,
+        tgt_dict=None,
     ):
+        # mtl: batches in the format of the s2s_translation_mtl task's dataset (collate_mtl below)
+        self.mtl, self.src_dict, self.tgt_dict = mtl, src_dict, tgt_dict
         rs = np.random.RandomState(seed)
         self.seed = seed
         self.nfps = n_frames_per_step
@@ -109,9 +114,11 @@ class SyntheticFisherCorpus:
         return batch_by_size(idx, ntok, max_tokens, max_sentences, bsz_mult)
 
     def collate_batch(self, indices: Sequence[int]) -> Dict:
-        return collate([self[i] for i in indices])
+        return self.collater([self[i] for i in indices])
 
     def collater(self, items) -> Dict:
+        if self.mtl:
+            return collate_mtl(list(items), self.src_dict, self.tgt_dict)
         return collate(list(items))
 
 
@@ -213,3 +220,31 @@ def collate(items: List[Utterance]) -> Dict:
         "tgt_txt_ntokens": int(tgt_text_len.sum().item()),
         "nsentences": bsz,
     }
+
+
+def collate_mtl(items: List[Utterance], src_dict=None, tgt_dict=None) -> Dict:
+    """Batch dict with the schema of the mtl task's collater (examples/s2s_trans/data/s2st_dataset_mtl.py:242-347): the
+    source text WITHOUT its EOS (:192-195), ``source_texts``, no ``prev_src_text_tokens`` / ``src_txt_ntokens`` / HuBERT
+    keys, ``prev_tgt_text_tokens`` in sample (unsorted) order (:290-296)."""
+    unsorted = list(items)
+    b = collate(items)
+    order = torch.tensor([u.src_speech.shape[0] for u in unsorted], dtype=torch.long).sort(descending=True, stable=True)[1].tolist()
+    srt = [unsorted[i] for i in order]
+    src_text = _collate_tokens([u.src_text[:-1] for u in srt], False)
+    ni = b["net_input"]
+    out = {
+        "id": b["id"],
+        "net_input": {"src_speech": ni["src_speech"], "src_speech_lens": ni["src_speech_lens"],
+                      "prev_output_tokens": ni["prev_output_tokens"],
+                      "prev_tgt_text_tokens": _collate_tokens([u.tgt_text for u in unsorted], True)},
+        "speaker": None, "src_text": src_text,
+        "src_text_len": torch.tensor([len(u.src_text) - 1 for u in srt], dtype=torch.long),
+        "tgt_text": b["tgt_text"], "tgt_text_len": b["tgt_text_len"], "tgt_speech": b["tgt_speech"],
+        "target_lengths": b["target_lengths"], "durations": None, "pitches": None, "energies": None,
+        "ntokens": b["ntokens"], "tgt_txt_ntokens": b["tgt_txt_ntokens"], "nsentences": b["nsentences"],
+    }
+    if src_dict is not None:
+        out["source_texts"] = [src_dict.string(u.src_text[:-1]) for u in srt]
+    if tgt_dict is not None:
+        out["target_texts"] = [tgt_dict.string(u.tgt_text) for u in srt]
+    return out

@@ -128,9 +128,15 @@ def dump_result(args, vocoder_name: str, sample_rate: int, sample_id, hypo, writ
                  lambda p: write_wav(p, _to_np(hypo["targ_waveform"]), sample_rate))
 
 
-def main(argv: Optional[List[str]] = None, device: Optional[torch.device] = None, on_model_built=None) -> Dict:
-    args = make_parser().parse_args(argv)
-    if not (args.dump_features or args.dump_waveforms or args.dump_attentions or args.dump_eos_probs or args.dump_plots):
+def main(argv: Optional[List[str]] = None, device: Optional[torch.device] = None, on_model_built=None,
+         parser: Optional[argparse.ArgumentParser] = None, mtl: bool = False) -> Dict:
+    """``mtl``: the flow of generate_waveform_mtl.py (see generate_waveform_mtl.py in this package): the task's own
+    generator, source-transcript decoding + WER files, mel dumping only with --decode-target-mel."""
+    args = (parser or make_parser()).parse_args(argv)
+    decode_src = mtl and args.decode_source_text
+    decode_mel = (not mtl) or args.decode_target_mel
+    if not (args.dump_features or args.dump_waveforms or args.dump_attentions or args.dump_eos_probs or args.dump_plots
+            or decode_src):
         raise SystemExit("nothing to do: pass at least one --dump-* flag (generate_waveform.py:128-129)")
     if args.max_tokens is None and args.batch_size is None:
         args.max_tokens = 8000  # :130-131
@@ -166,7 +172,15 @@ def main(argv: Optional[List[str]] = None, device: Optional[torch.device] = None
     if args.output_sample_rate not in (None, sample_rate):
         raise SystemExit(f"--output-sample-rate {args.output_sample_rate}: resampling (torchaudio sox effects in the "
                          f"reference, generate_waveform.py:148-156) is not available here; the features are {sample_rate} Hz")
-    generator = task.build_generator_tts([model], margs)
+    # (generate_waveform.py:158 / generate_waveform_mtl.py:164: the mtl task's build_generator IS its speech generator)
+    generator = task.build_generator([model], margs) if mtl else task.build_generator_tts([model], margs)
+    wer = src_f = hyp_f = None
+    if decode_src:  # generate_waveform_mtl.py:183-185
+        from .scoring import build_scorer
+        wer = build_scorer(args.scoring, getattr(model, "src_dict", None))
+        Path(args.results_path).mkdir(exist_ok=True, parents=True)
+        src_f = open(os.path.join(args.results_path, "src_texts.txt"), "w")
+        hyp_f = open(os.path.join(args.results_path, "hyps_src_texts.txt"), "w")
     itr = task.get_batch_iterator(dataset, max_tokens=args.max_tokens, max_sentences=args.batch_size,
                                   max_positions=(sys.maxsize, sys.maxsize),
                                   required_batch_size_multiple=args.required_batch_size_multiple, seed=args.seed,
@@ -179,19 +193,36 @@ def main(argv: Optional[List[str]] = None, device: Optional[torch.device] = None
         if sample is None or len(sample) == 0:
             continue
         t0 = time.perf_counter()
-        hypos = generator.generate(model, sample, has_targ=args.dump_target)
+        if mtl:  # generate_waveform_mtl.py:195
+            hypos = generator.generate(model, sample, has_targ=args.dump_target and decode_mel,
+                                       decode_source_text=decode_src, decode_target_mel=decode_mel)
+        else:
+            hypos = generator.generate(model, sample, has_targ=args.dump_target)
         if device.type == "cuda":
             torch.cuda.synchronize(device)
         t_gen += time.perf_counter() - t0
+        if decode_src:  # :196-200
+            for hypo in hypos:
+                wer.add_string(hypo["src_texts"], hypo["hyps_src_texts"])
+                src_f.write(hypo["src_texts"] + "\n")
+                hyp_f.write(hypo["hyps_src_texts"] + "\n")
         for i, hypo in zip(sample["id"].tolist(), hypos):
-            dump_result(args, args.vocoder, sample_rate, ids[i] if ids is not None else i, hypo, written)
+            if decode_mel:
+                dump_result(args, args.vocoder, sample_rate, ids[i] if ids is not None else i, hypo, written)
+                n_frames += int(hypo["feature"].shape[0])
             n_utt += 1
-            n_frames += int(hypo["feature"].shape[0])
         n_batches += 1
         if args.max_batches and n_batches >= args.max_batches:
             break
-    return {"utterances": n_utt, "mel_frames": n_frames, "generate_seconds": t_gen, "batches": n_batches,
-            "files": written, "sample_rate": sample_rate}
+    out = {"utterances": n_utt, "mel_frames": n_frames, "generate_seconds": t_gen, "batches": n_batches,
+           "files": written, "sample_rate": sample_rate}
+    if decode_src:  # :207-210
+        src_f.close()
+        hyp_f.close()
+        out["wer"] = wer.score()
+        written += [src_f.name, hyp_f.name]
+        print(f"WER: {wer.score()}")
+    return out
 
 
 def cli_main():

@@ -96,6 +96,10 @@ class S2STTransformerModel(ModelBase):  # fairseq's BaseFairseqModel when fairse
             args.tgt_vocab_size = len(task.target_dictionary)
         device = getattr(task, "device", None) or torch.device("cuda", torch.cuda.current_device())
         model = cls(args, device=device, precise=bool(getattr(args, "precise_gemm", False)))
+        # (the reference's decoders keep the dictionaries: s2st_transformer_mtl.py:226-227 -- the mtl generator reads
+        # model.decoder.src_dict for its CTC hypotheses)
+        model.src_dict = getattr(task, "source_dictionary", None)
+        model.tgt_dict = getattr(task, "target_dictionary", None)
         cls.load_pretrained_components(model, args)
         return model
 
@@ -168,15 +172,17 @@ class S2STTransformerModel(ModelBase):  # fairseq's BaseFairseqModel when fairse
         # speaker tables from the data directory's speaker_emb_filename: Embedding.from_pretrained(freeze=True)
         # (tasks/s2s_translation.py:161-171) -- loaded, excluded from training
         if self.engine.cfg.spk_frozen:
+            # the engine keeps frozen tables in its BUFFER arena (outside the optimizer's sweep, weight decay included:
+            # the reference's optimizer never sees a requires_grad=False parameter); they are module buffers here and
+            # keep their state_dict key
             import numpy as np
             mat = torch.from_numpy(np.load(args.speaker_emb_path)).float()
-            for n_, p_ in self.named_parameters():
+            for n_, v_ in self._views.items():
                 if n_.endswith("embed_speaker.weight"):
-                    if tuple(mat.shape) != tuple(p_.shape):
-                        raise ValueError(f"{args.speaker_emb_path}: {tuple(mat.shape)} does not fit {n_} {tuple(p_.shape)}")
+                    if tuple(mat.shape) != tuple(v_.shape):
+                        raise ValueError(f"{args.speaker_emb_path}: {tuple(mat.shape)} does not fit {n_} {tuple(v_.shape)}")
                     with torch.no_grad():
-                        p_.copy_(mat)
-                    p_.requires_grad = False
+                        v_.copy_(mat)
 
     # -- initialisation: the reference's schemes ("Init") -----------------
     @torch.no_grad()

@@ -4,8 +4,10 @@ Host-side mirror of examples/s2s_trans/models/t2s_transformer.py:279-371 (Transf
 encoder -- token embedding, ``--encoder-conv-layers`` x (Conv1d k5 + BatchNorm1d + ReLU + dropout), a linear
 projection, ``pos_emb_alpha``-scaled sinusoidal positions, Transformer layers (post-LN by default) -- in front of the
 mel decoder of ``s2st_transformer``.  The engine's ``text_input`` switch builds that front (include/s2st_hip.h);
-decoder, losses and optimizer are the shared kernels.  The optional decoder-side CTC head of the reference
-(``ctc_proj`` over ``feature_out``, :161-163) is not built: ``--ctc-weight`` must be 0.
+decoder, losses and optimizer are the shared kernels.  The optional decoder-side CTC head (``ctc_proj`` over
+``feature_out``, :161-163, 258-263) and the speaker conditioning of the encoder (``spk_emb_proj(cat[x, embed_speaker(speaker)])``
+after the last layer, :43-46, 107-111; table ``Embedding(len(--speaker-to-id), --speaker-embed-dim)`` as the reference's
+``task.get_speaker_embeddings(args)`` builds it) are engine switches too.
 """
 from __future__ import annotations
 
@@ -36,7 +38,7 @@ class T2STransformerModel(S2STTransformerModel):
         """t2s_transformer.py (FairseqEncoderDecoderModel.forward): returns ``(post_feat_out, eos_out, extra)``."""
         sample = {"net_input": {"prev_output_tokens": prev_output_tokens}, "src_text": src_tokens,
                   "src_text_len": src_lengths, "target_lengths": kwargs["target_lengths"],
-                  "ntokens": int(kwargs["target_lengths"].sum())}
+                  "ntokens": int(kwargs["target_lengths"].sum()), "speaker": kwargs.get("speaker")}
         o = self.engine.forward(sample, training=self.training, want_attn=True, with_loss=False)
         return o["post_feat_out"], o["eos_out"], {"attn": o.get("attn"), "feature_out": o["feature_out"]}
 
@@ -44,7 +46,8 @@ class T2STransformerModel(S2STTransformerModel):
         import torch
         B = src_tokens.shape[0]
         sample = {"net_input": {"prev_output_tokens": torch.zeros(B, 1, self.engine.cfg.out_dim)}, "src_text": src_tokens,
-                  "src_text_len": src_lengths, "target_lengths": torch.ones(B, dtype=torch.long), "ntokens": B}
+                  "src_text_len": src_lengths, "target_lengths": torch.ones(B, dtype=torch.long), "ntokens": B,
+                  "speaker": speaker}
         o = self.engine.forward(sample, training=self.training, want_attn=False, with_loss=False)
         lens = o["encoder_lens"].long()
         E = o["encoder_out"].shape[1]

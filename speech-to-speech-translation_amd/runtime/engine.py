@@ -26,7 +26,7 @@ class ModelConfig(C.Structure):
         "prenet_layers", "prenet_dim", "postnet_layers", "postnet_dim", "postnet_k", "tap_asr",
         "tap_st", "has_asr", "has_st", "has_ctc", "asr_layers", "asr_dim", "st_layers", "st_dim",
         "src_vocab", "tgt_vocab", "no_scale_embedding", "precise", "tap_dec", "has_ctc_tgt", "text_input", "enc_conv_layers", "enc_conv_k",
-        "n_speakers", "spk_frozen")] + [(n, C.c_float) for n in (
+        "n_speakers", "spk_frozen", "spk_dim")] + [(n, C.c_float) for n in (
         "dropout", "attn_dropout", "act_dropout", "prenet_dropout", "postnet_dropout", "ctc_weight",
         "asr_weight", "st_weight", "w_l1", "w_mse", "w_eos", "bce_pos_weight", "label_smoothing", "ctc_tgt_weight", "enc_dropout")]
 
@@ -110,9 +110,12 @@ def config_from_args(a, precise: bool = False) -> ModelConfig:
     spk = getattr(a, "speaker_to_id", None)
     c.n_speakers = len(spk) if spk is not None else 0
     c.spk_frozen = int(c.n_speakers > 0 and getattr(a, "speaker_emb_path", None) is not None)
-    if c.n_speakers > 0:
-        if c.text_input:
-            raise NotImplementedError("speaker conditioning of the t2s text encoder is not built")
+    if c.n_speakers > 0 and c.text_input:
+        # t2s_transformer.py:43-46: Embedding(len(speaker_to_id), speaker_embed_dim) + spk_emb_proj(C + dim -> C)
+        c.spk_dim = int(getattr(a, "speaker_embed_dim", 64) or 64)
+        if c.spk_dim % 4:
+            raise ValueError("--speaker-embed-dim must be a multiple of 4 on this path")
+    elif c.n_speakers > 0:
         if getattr(a, "speaker_embed_dim", 64) != c.enc_dim:
             raise ValueError(f"--speaker-embed-dim {getattr(a, 'speaker_embed_dim', 64)} must equal --encoder-embed-dim "
                              f"{c.enc_dim}: the row is added to the encoder states (s2st_transformer.py:203-206)")
@@ -335,9 +338,7 @@ class Engine:
             if spk is None:
                 spk = ni.get("speaker")
             if spk is not None:  # [B, 1] ids (s2st_dataset.py:386-390)
-                keep["speaker"] = spk.reshape(-1).to(torch.int64).contiguous().to(dev)
-                if int(keep["speaker"].numel()) != B:
-                    raise ValueError("sample['speaker'] must hold one id per utterance")
+                keep["speaker"] = self._speaker_ids(spk, B)
                 b.speaker = keep["speaker"].data_ptr()
         b.ntokens = int(sample["ntokens"])
         b.src_txt_ntokens = int(sample.get("src_txt_ntokens", 0))
@@ -348,6 +349,19 @@ class Engine:
             self.step_seed += 1
         b.seed = seed
         return b, keep
+
+    def _speaker_ids(self, spk, B: int) -> Optional[torch.Tensor]:
+        """[B, 1] / [B] speaker ids -> device int64 [B], range-checked on the host like nn.Embedding would
+        (an id outside the table is an out-of-bounds row read in the kernels)."""
+        if spk is None:
+            return None
+        ids = spk.reshape(-1).to(torch.int64).cpu()
+        if int(ids.numel()) != B:
+            raise ValueError("sample['speaker'] must hold one id per utterance")
+        if B and (int(ids.min()) < 0 or int(ids.max()) >= self.cfg.n_speakers):
+            raise IndexError(f"speaker id out of range: ids span [{int(ids.min())}, {int(ids.max())}], the table has "
+                             f"{self.cfg.n_speakers} rows (tasks/s2s_translation.py:156-160 sizes it by len(--speaker-to-id))")
+        return ids.contiguous().to(self.device)
 
     def _prepare_text(self, sample, training, want_attn, with_loss, seed):
         """t2s_transformer: the encoder reads token ids -- ``sample["src_text"]`` / ``["src_text_len"]``, what the
@@ -380,6 +394,13 @@ class Engine:
         if with_loss:
             keep["tgt"] = sample["tgt_speech"].to(dev, torch.float32).contiguous()
             b.tgt = keep["tgt"].data_ptr()
+        if self.cfg.n_speakers > 0:
+            spk = sample.get("speaker")
+            if spk is None:
+                # t2s_transformer.py:107-109 calls self.embed_speaker(speaker) unconditionally once the table exists
+                raise ValueError("a t2s_transformer built with --speaker-to-id needs sample['speaker']")
+            keep["speaker"] = self._speaker_ids(spk, B)
+            b.speaker = keep["speaker"].data_ptr()
         b.ntokens = int(sample["ntokens"])
         b.training, b.want_attn = int(training), int(want_attn)
         if seed is None:
@@ -473,28 +494,46 @@ class Engine:
     # -- AR decoding (config 5): encoder once, then one decoder step per output frame -------------
     def decode_begin(self, src: torch.Tensor, src_lens: torch.Tensor, max_steps: int,
                      speaker: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
-        """Runs the encoder (eval mode) and fills the decoding caches for ``max_steps`` frames.  ``speaker``: [B, 1] ids
-        of a speaker-conditioned model (kept for the decoding steps)."""
+        """Runs the encoder (eval mode) and fills the decoding caches for ``max_steps`` frames.  ``src``: fbank / HuBERT
+        features [B, S, in_dim], or -- for a text-input model (t2s_transformer; speech_generator_for_s2st.py:60-64) -- the
+        token ids [B, S] of ``sample["src_text"]``.  ``speaker``: [B, 1] ids of a speaker-conditioned model (kept for the
+        decoding steps)."""
         dev, c = self.device, self.cfg
-        src = src.to(dev, torch.float32).contiguous()
-        B, S, _ = src.shape
-        k = c.conv_k
-        E = conv_out_len(conv_out_len(S, k), k)
-        enc_lens = src_lens.cpu().long().clone()
-        for _ in range(2):
-            enc_lens = ((enc_lens.float() - 1) / 2 + 1).floor().long()
+        b = Batch()
+        if c.text_input:
+            tok = src.cpu().long().contiguous()
+            if tok.dim() != 2:
+                raise ValueError("a text-input model decodes from token ids [B, S]")
+            B, S = tok.shape
+            E = S
+            enc_lens = src_lens.cpu().long().clone()
+            keep = {"src_txt": tok.to(dev), "src_txt_lens": enc_lens.to(torch.int32).to(dev)}
+            b.src_txt, b.src_txt_lens, b.Ls = keep["src_txt"].data_ptr(), keep["src_txt_lens"].data_ptr(), S
+        else:
+            src = src.to(dev, torch.float32).contiguous()
+            B, S, _ = src.shape
+            k = c.conv_k
+            E = conv_out_len(conv_out_len(S, k), k)
+            enc_lens = src_lens.cpu().long().clone()
+            for _ in range(2):
+                enc_lens = ((enc_lens.float() - 1) / 2 + 1).floor().long()
+            keep = {"src": src}
+            b.src = src.data_ptr()
         t = torch.arange(E).unsqueeze(0)
         enc_pos = torch.where(t < enc_lens.unsqueeze(1), t + PAD + 1, torch.full_like(t, PAD)).to(torch.int32)
-        keep = {"src": src, "enc_lens": enc_lens.to(torch.int32).to(dev), "enc_pos": enc_pos.contiguous().to(dev)}
-        b = Batch()
+        keep["enc_lens"] = enc_lens.to(torch.int32).to(dev)
+        keep["enc_pos"] = enc_pos.contiguous().to(dev)
         b.B, b.S, b.D, b.E = B, S, 1, E
-        b.src, b.enc_lens, b.enc_pos = src.data_ptr(), keep["enc_lens"].data_ptr(), keep["enc_pos"].data_ptr()
+        b.enc_lens, b.enc_pos = keep["enc_lens"].data_ptr(), keep["enc_pos"].data_ptr()
+        b.ctc_in_lens = keep["enc_lens"].data_ptr()
         b.pe_enc = self.pe(c.enc_dim, E + 2).data_ptr()
         b.pe_dec = self.pe(c.dec_dim, max_steps + 2).data_ptr()
         b.training, b.seed = 0, 0
         if c.n_speakers > 0 and speaker is not None:
-            keep["speaker"] = speaker.reshape(-1).to(torch.int64).contiguous().to(dev)
+            keep["speaker"] = self._speaker_ids(speaker, B)
             b.speaker = keep["speaker"].data_ptr()
+        elif c.n_speakers > 0 and c.text_input:
+            raise ValueError("a t2s_transformer built with --speaker-to-id needs sample['speaker']")
         # workspace: the encoder forward of this geometry (planned with the full schedule: a superset)
         geo = ("enc", B, S)
         need = self._plan.get(geo)

@@ -50,24 +50,40 @@ class AutoRegressiveSpeechGenerator(SpeechGenerator):
     def __init__(self, model, vocoder, data_cfg=None, max_iter: int = 6000, eos_prob_threshold: float = 0.5,
                  input_text: bool = False, seed: int = 1):
         super().__init__(model, vocoder, data_cfg)
-        if input_text:
-            raise NotImplementedError("text-input (t2s) variant is outside this path")
         self.max_iter, self.eos_prob_threshold, self.seed = max_iter, eos_prob_threshold, seed
+        self.input_text = bool(input_text)
+        if self.input_text != bool(model.engine.cfg.text_input):
+            # speech_generator_for_s2st.py:60-64 feeds token ids (--input-text true) or fbank frames to whatever encoder
+            # the model has; the mismatched pairs fail inside the reference's first encoder op -- say so up front
+            raise ValueError("--input-text true goes with a text-input model (--arch t2s_transformer), and only with one")
 
     @torch.no_grad()
     def generate(self, model, sample, has_targ: bool = False, **kwargs) -> List[Dict[str, Optional[torch.Tensor]]]:
         model.eval()
         eng = model.engine
         ni = sample["net_input"]
-        src, src_lens = model._front_end(ni.get("src_speech"), ni.get("src_speech_lens"),
-                                         ni.get("collated_audios_orig"), ni.get("padding_mask"))
+        if self.input_text:
+            # speech_generator_for_s2st.py:60-64: the encoder reads sample["src_text"] / ["src_text_len"]
+            src, src_lens = sample["src_text"], sample["src_text_len"]
+        else:
+            src, src_lens = model._front_end(ni.get("src_speech"), ni.get("src_speech_lens"),
+                                             ni.get("collated_audios_orig"), ni.get("padding_mask"))
         bsz = src.shape[0]
+        self._enc = eng.decode_begin(src, src_lens, self.max_iter, speaker=sample.get("speaker"))
+        finalized = [dict() for _ in range(bsz)]
+        self._decode_mel(model, sample, bsz, finalized)
+        if has_targ:
+            self._add_targets(model, sample, bsz, finalized)
+        return finalized
+
+    def _decode_mel(self, model, sample, bsz: int, finalized: List[Dict]) -> None:
+        """The AR loop + post-processing of speech_generator_for_s2st.py:70-122 over the caches ``decode_begin`` filled."""
+        eng = model.engine
         c = eng.cfg
         n_frames_per_step = model.args.n_frames_per_step
         out_dim = c.out_dim
         raw_dim = out_dim // n_frames_per_step
         dev = eng.device
-        eng.decode_begin(src, src_lens, self.max_iter, speaker=sample.get("speaker"))
         feat, attn, eos_prob = [], [], []
         finished = torch.zeros(bsz, dtype=torch.bool)
         out_lens = torch.full((bsz,), self.max_iter, dtype=torch.long)
@@ -99,14 +115,19 @@ class AutoRegressiveSpeechGenerator(SpeechGenerator):
         out_lens = out_lens * n_frames_per_step
         lens = out_lens.tolist()
         waves = self.get_waveforms([feat[b, :l] for b, l in enumerate(lens)])
-        finalized = [{"feature": feat[b, :l], "eos_prob": eos_prob[b, :l], "attn": attn[b, :, :l],
-                      "alignment": alignment[b, :l], "waveform": waves[b]}
-                     for b, l in enumerate(lens)]
-        if has_targ:
-            tgt = self.gcmvn_denormalize(sample["tgt_speech"].to(dev, torch.float32).reshape(bsz, -1, raw_dim))
-            tl = (sample["target_lengths"] * n_frames_per_step).tolist()
-            twaves = self.get_waveforms([tgt[b, :l] for b, l in enumerate(tl)])
-            for b, l in enumerate(tl):
-                finalized[b]["targ_feature"] = tgt[b, :l]
-                finalized[b]["targ_waveform"] = twaves[b]
-        return finalized
+        for b, l in enumerate(lens):
+            finalized[b].update({"feature": feat[b, :l], "eos_prob": eos_prob[b, :l], "attn": attn[b, :, :l],
+                                 "alignment": alignment[b, :l], "waveform": waves[b]})
+
+    def _add_targets(self, model, sample, bsz: int, finalized: List[Dict]) -> None:
+        """speech_generator_for_s2st.py:124-133."""
+        eng = model.engine
+        n_frames_per_step = model.args.n_frames_per_step
+        raw_dim = eng.cfg.out_dim // n_frames_per_step
+        assert sample["tgt_speech"].size(-1) == eng.cfg.out_dim
+        tgt = self.gcmvn_denormalize(sample["tgt_speech"].to(eng.device, torch.float32).reshape(bsz, -1, raw_dim))
+        tl = (sample["target_lengths"] * n_frames_per_step).tolist()
+        twaves = self.get_waveforms([tgt[b, :l] for b, l in enumerate(tl)])
+        for b, l in enumerate(tl):
+            finalized[b]["targ_feature"] = tgt[b, :l]
+            finalized[b]["targ_waveform"] = twaves[b]

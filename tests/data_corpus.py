@@ -107,6 +107,30 @@ sample_rate: 16000
     return root
 
 
+def make_mtl_extras(root: str) -> str:
+    """A manifest with the FastSpeech-style columns the mtl task's dataset still reads (duration / pitch / energy,
+    s2st_dataset_mtl.py:389-405): ``dev_fs.tsv`` over the dev utterances.  The reference appends a 0 "for EOS" to each
+    of the three (:206-219) and asserts their collated width equals ``src_text``'s -- whose EOS it has REMOVED (:195) --
+    so a manifest that passes has one value fewer than the source text has words."""
+    import csv
+    rs = np.random.RandomState(31)
+    with open(os.path.join(root, "dev_tiny.tsv")) as f:
+        rows = list(csv.DictReader(f, delimiter="\t", quotechar=None, doublequote=False, lineterminator="\n",
+                                   quoting=csv.QUOTE_NONE))
+    cols = list(rows[0].keys()) + ["duration", "pitch", "energy"]
+    with open(os.path.join(root, "dev_fs.tsv"), "w") as f:
+        f.write("\t".join(cols) + "\n")
+        for k, r in enumerate(rows):
+            n = len(r["src_text"].split(" ")) - 1
+            r = dict(r)
+            r["duration"] = " ".join(str(int(v)) for v in rs.randint(1, 9, size=n))
+            for name in ("pitch", "energy"):
+                np.save(os.path.join(root, f"{name}_{k}.npy"), rs.standard_normal(n).astype(np.float32))
+                r[name] = f"{name}_{k}.npy"
+            f.write("\t".join(r[c] for c in cols) + "\n")
+    return root
+
+
 def flatten_batch(b, prefix=""):
     """Collated sample -> {name: ndarray} (tensors only; strings / None recorded as such)."""
     import torch
