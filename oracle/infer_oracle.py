@@ -70,7 +70,9 @@ def ar_generate(m, src, src_lens, max_iter: int, eos_prob_threshold: float, n_fr
         cur_out_lens.masked_fill_(cur_out_lens.eq(max_iter), step + 1)
         # with a speaker the reference's incremental decoder replaces its ONE input frame by the speaker row at every step
         # (s2st_transformer.py:441-444 on the [B, 1, C] tensor the generator hands over): the whole prefix is speaker rows
-        px = prefix if speaker is None else m.decoder.embed_speaker(speaker).expand(-1, prefix.shape[1], -1)
+        # (the t2s decoder has no table: its speaker enters through the encoder's projection only)
+        px = (prefix if speaker is None or m.decoder.embed_speaker is None
+              else m.decoder.embed_speaker(speaker).expand(-1, prefix.shape[1], -1))
         f_all, eos, a_all = _decoder_prefix(m.decoder, px, enc, cur_out_lens)
         cur_feat = f_all[:, -1:, :]
         cur_eos = torch.sigmoid(eos[:, -1:, :]).squeeze(2)

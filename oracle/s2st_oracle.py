@@ -411,8 +411,13 @@ class T2SEncoder(nn.Module):
             for _ in range(a.encoder_transformer_layers))
         self.layer_norm = nn.LayerNorm(C) if a.encoder_normalize_before else None
         self.embed_positions = _PositionalEmbeddingState()
+        # t2s_transformer.py:40-46 (+ tasks/s2s_translation_mtl.py:133-150: Embedding(len(speaker_to_id), speaker_embed_dim),
+        # the length of the flag's STRING)
+        n_spk = len(a.speaker_to_id) if getattr(a, "speaker_to_id", None) is not None else 0
+        self.embed_speaker = nn.Embedding(n_spk, a.speaker_embed_dim) if n_spk else None
+        self.spk_emb_proj = nn.Linear(C + a.speaker_embed_dim, C) if n_spk else None
 
-    def forward(self, src_tokens, src_lens):
+    def forward(self, src_tokens, src_lens, speaker=None):
         x = self.embed_tokens(src_tokens).transpose(1, 2).contiguous()
         for conv in self.prenet:
             x = conv(x)
@@ -424,6 +429,9 @@ class T2SEncoder(nn.Module):
             x = layer(x, pad)
         if self.layer_norm is not None:
             x = self.layer_norm(x)
+        if self.embed_speaker is not None:  # t2s_transformer.py:107-111: every position, padded ones included
+            emb = self.embed_speaker(speaker).transpose(0, 1).expand(x.shape[0], x.shape[1], -1)
+            x = self.spk_emb_proj(torch.cat([x, emb], dim=2))
         return {"encoder_out": x, "encoder_padding_mask": pad, "out_middle_layers": [],
                 "encoder_lens": (~pad).long().sum(1)}
 
@@ -459,10 +467,12 @@ class S2STDecoder(nn.Module):
         self.middle_layers_decoder = [int(k) for k in str(getattr(a, "middle_layers_decoder", "6")).split(",")]
         self.embed_positions = _PositionalEmbeddingState()
         n_spk = len(a.speaker_to_id) if getattr(a, "speaker_to_id", None) is not None else 0
+        if getattr(a, "text_encoder", False):
+            n_spk = 0  # T2STransformerDecoder has no speaker table; its `speaker` argument is unused (t2s_transformer.py:172-176)
         self.embed_speaker = nn.Embedding(n_spk, a.speaker_embed_dim_dec) if n_spk else None
 
     def forward(self, prev, enc, target_lengths, speaker=None):
-        if speaker is not None:  # s2st_transformer.py:441-444: the speaker row replaces the first input frame
+        if speaker is not None and self.embed_speaker is not None:  # s2st_transformer.py:441-444: the speaker row replaces the first input frame
             prev = torch.cat([self.embed_speaker(speaker), prev[:, 1:, :]], 1)
         pad = lengths_to_padding_mask(target_lengths, prev.shape[1])
         pos = positional_embedding(pad, self.a.decoder_embed_dim)

@@ -52,16 +52,16 @@ class AutoRegressiveSpeechGenerator(SpeechGenerator):
         super().__init__(model, vocoder, data_cfg)
         self.max_iter, self.eos_prob_threshold, self.seed = max_iter, eos_prob_threshold, seed
         self.input_text = bool(input_text)
-        if self.input_text != bool(model.engine.cfg.text_input):
-            # speech_generator_for_s2st.py:60-64 feeds token ids (--input-text true) or fbank frames to whatever encoder
-            # the model has; the mismatched pairs fail inside the reference's first encoder op -- say so up front
-            raise ValueError("--input-text true goes with a text-input model (--arch t2s_transformer), and only with one")
 
     @torch.no_grad()
     def generate(self, model, sample, has_targ: bool = False, **kwargs) -> List[Dict[str, Optional[torch.Tensor]]]:
         model.eval()
         eng = model.engine
         ni = sample["net_input"]
+        if self.input_text != bool(eng.cfg.text_input):
+            # speech_generator_for_s2st.py:60-64 feeds token ids (--input-text true) or fbank frames to whatever encoder
+            # the model has; the mismatched pairs fail inside the reference's first encoder op -- say so
+            raise ValueError("--input-text true goes with a text-input model (--arch t2s_transformer), and only with one")
         if self.input_text:
             # speech_generator_for_s2st.py:60-64: the encoder reads sample["src_text"] / ["src_text_len"]
             src, src_lens = sample["src_text"], sample["src_text_len"]

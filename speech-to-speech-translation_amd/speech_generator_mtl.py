@@ -55,6 +55,7 @@ class AutoRegressiveSpeechGenerator(_BaseARGenerator):
             if not eng.cfg.has_ctc:
                 raise ValueError("decode_source_text needs the model's source-text CTC head (--ctc-weight > 0)")
             src_texts = sample["source_texts"]
+            self._last_tap = enc["tap0"]
             best = self.greedy_ctc_paths(model, enc["tap0"]).cpu()
             lens = enc["encoder_lens"].cpu().tolist()
             hyps = []

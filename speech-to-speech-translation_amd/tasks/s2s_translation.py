@@ -180,6 +180,8 @@ class S2ST_TranslationTask(TaskBase):  # fairseq's LegacyFairseqTask when fairse
         from ..speech_generator import AutoRegressiveSpeechGenerator
         if vocoder is None:
             vocoder = self.build_default_vocoder()
+        elif vocoder is False:  # (tests: features only)
+            vocoder = None
         return AutoRegressiveSpeechGenerator(
             models[0], vocoder, self.data_cfg, max_iter=self.args.max_target_positions,
             eos_prob_threshold=getattr(self.args, "eos_prob_threshold", 0.5),

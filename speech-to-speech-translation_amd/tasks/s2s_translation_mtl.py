@@ -56,6 +56,8 @@ class S2ST_TranslationMTLTask(S2ST_TranslationTask):
         from ..speech_generator_mtl import AutoRegressiveSpeechGenerator
         if vocoder is None:
             vocoder = self.build_default_vocoder()
+        elif vocoder is False:  # (tests: features only)
+            vocoder = None
         return AutoRegressiveSpeechGenerator(
             models[0], vocoder, self.data_cfg, max_iter=self.args.max_target_positions,
             eos_prob_threshold=getattr(self.args, "eos_prob_threshold", 0.5))

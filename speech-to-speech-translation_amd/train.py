@@ -21,6 +21,7 @@ import sys
 import time
 from typing import Dict, List, Optional
 
+import numpy as np
 import torch
 
 from . import checkpoint_utils
@@ -74,6 +75,7 @@ def get_parser() -> argparse.ArgumentParser:
     a("--restore-file", default="checkpoint_last.pt")
     a("--reset-optimizer", action="store_true")
     a("--reset-lr-scheduler", action="store_true")
+    a("--reset-meters", action="store_true")
     a("--save-interval", type=int, default=1)
     a("--save-interval-updates", type=int, default=0)
     a("--no-save", action="store_true")
@@ -177,6 +179,34 @@ def validate(args, trainer: Trainer, task, subsets: List[str], world: int, rank:
     return out
 
 
+def best_checkpoint_files(existing: List[str], metric: str, keep_best: int, maximize: bool, v: float, best: Optional[float],
+                          epoch: int, updates: int):
+    """Which "best" files a validation score writes -- fairseq/checkpoint_utils.py:41-44, 65-104.  Returns (updated best,
+    file names).  ``is_better`` counts a tie as better; ``best`` is updated FIRST and the conditions compare against the
+    updated value.  ``checkpoint.best_<metric>_<v:.3f><d>.pt`` (d = a digit in [0, keep_best) drawn under
+    ``numpy_seed(epoch, updates, v)`` so that equal scores do not overwrite each other) is written only when the score is
+    at least as good as the WORST kept one -- whose value the reference parses back from its file name, tie-break digit
+    included (reproduced) -- or, with none kept yet, as the best so far."""
+    import re
+    from .data.iterators import numpy_seed
+    is_better = (lambda a_, b_: a_ >= b_) if maximize else (lambda a_, b_: a_ <= b_)
+    best = v if best is None else (max(v, best) if maximize else min(v, best))
+    names = []
+    if is_better(v, best):
+        names.append("checkpoint_best.pt")
+    if keep_best > 0:
+        rx = re.compile(r"checkpoint\.best_%s_(\d+\.?\d*)\.pt" % metric)  # (the reference does not escape the metric either)
+        kept = sorted((float(m.group(1)) for m in (rx.fullmatch(fn) for fn in existing) if m), reverse=True)
+        worst_best = best
+        if kept:
+            worst_best = kept[-1] if maximize else kept[0]
+        with numpy_seed(epoch, updates, v):
+            rand_sfx = np.random.randint(0, keep_best)
+        if worst_best is None or is_better(v, worst_best):
+            names.append("checkpoint.best_{}_{:.3f}{}.pt".format(metric, v, rand_sfx))
+    return best, names
+
+
 def main(argv: Optional[List[str]] = None, device: Optional[torch.device] = None, args: Optional[argparse.Namespace] = None,
          on_model_built=None) -> Dict:
     args = args or parse_args(argv)
@@ -225,7 +255,8 @@ def main(argv: Optional[List[str]] = None, device: Optional[torch.device] = None
     summary = {"train_loss": [], "valid": [], "saved": []}
     # fairseq/checkpoint_utils.py:41-46, 262-264: the best validation score survives a resume (a worse first validation
     # after it must not overwrite checkpoint_best.pt)
-    best = extra.get("best") if extra else None
+    # (restored only when neither --reset-optimizer nor --reset-meters is given: checkpoint_utils.py:256-262)
+    best = extra.get("best") if (extra and not args.reset_optimizer and not getattr(args, "reset_meters", False)) else None
 
     # position of the TRAINER inside the epoch (the background stager runs ahead of it inside epoch_itr's own iterator,
     # so the iterator's counter is not the resume point)
@@ -270,12 +301,9 @@ def main(argv: Optional[List[str]] = None, device: Optional[torch.device] = None
         files = list(tag_files)
         if val and args.best_checkpoint_metric in val:
             v = val[args.best_checkpoint_metric]
-            better = best is None or (v > best if args.maximize_best_checkpoint_metric else v < best)
-            if better:
-                best = v
-                files.append("checkpoint_best.pt")
-            if args.keep_best_checkpoints > 0:  # checkpoint_utils.py:95-104
-                files.append("checkpoint.best_%s_%.2f.pt" % (args.best_checkpoint_metric, v))
+            best, names = best_checkpoint_files(os.listdir(args.save_dir), args.best_checkpoint_metric, args.keep_best_checkpoints,
+                                                args.maximize_best_checkpoint_metric, v, best, epoch_itr.epoch, trainer.num_updates)
+            files += names
         state_extra["best"] = best
         for fn in files:
             path = os.path.join(args.save_dir, fn)

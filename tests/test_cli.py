@@ -50,8 +50,8 @@ def test_flags_of_other_variants_are_rejected():
 
 
 def test_eval_inference_builds_the_speech_generator_from_parsed_flags():
-    """``--input-text`` is ``type=str, default="false"``; passed on unconverted, the string is truthy and the
-    generator refuses to build.  The task converts at the use site."""
+    """``--input-text`` is ``type=str, default="false"``; passed on unconverted, the string is truthy and every
+    model would be decoded as a text-input one.  The task converts at the use site."""
     tasks = importlib.import_module(PKG + ".tasks")
     gen_mod = importlib.import_module(PKG + ".speech_generator")
     a = _train().parse_args(["synthetic", "--eval-inference", "--n-frames-per-step", "4"])
@@ -65,7 +65,35 @@ def test_eval_inference_builds_the_speech_generator_from_parsed_flags():
         pass
 
     gen = task.build_generator_tts([_Model()], a, vocoder=_Vocoder())
-    assert isinstance(gen, gen_mod.AutoRegressiveSpeechGenerator)
-    a.input_text = "true"
-    with pytest.raises(NotImplementedError):
-        task.build_generator_tts([_Model()], a, vocoder=_Vocoder())
+    assert isinstance(gen, gen_mod.AutoRegressiveSpeechGenerator) and gen.input_text is False
+    a.input_text = "true"  # round 4: text-input generation is built (speech_generator_for_s2st.py:60-64)
+    assert task.build_generator_tts([_Model()], a, vocoder=_Vocoder()).input_text is True
+
+
+def test_best_checkpoint_file_names_equal_the_reference(golden_dir, tmp_path):
+    """``--keep-best-checkpoints``.  The sequence of validation scores of oracle/gen_golden_ckpt_names.py through
+    ``train.best_checkpoint_files`` + the pruning rule, against the files the reference's own ``save_checkpoint``
+    (fairseq/checkpoint_utils.py:34-187) wrote and kept: 3 decimals + a seeded tie-break digit, written only when at least as
+    good as the worst kept one, ties included."""
+    import os
+    import re
+    import numpy as np
+    train = importlib.import_module(PKG + ".train")
+    z = np.load(os.path.join(golden_dir, "ckpt_names.npz"))
+    scores = z["scores"].tolist()
+    for maximize in (False, True):
+        for keep in (2, 3):
+            tag = f"{'max' if maximize else 'min'}.keep{keep}"
+            listing, best = ["checkpoint_last.pt"] if False else [], None
+            for k, v in enumerate(scores):
+                best, names = train.best_checkpoint_files(listing, "loss", keep, maximize, v, best, k + 1, 10 * (k + 1))
+                written = sorted(set(names + ["checkpoint_last.pt"]))
+                assert written == z[f"{tag}.{k}.written"].tolist(), (tag, k, written, z[f"{tag}.{k}.written"].tolist())
+                listing = sorted(set(listing) | set(written))
+                rx = re.compile(r"checkpoint\.best_loss_(\d+\.?\d*)\.pt")
+                kept = [fn for _, fn in sorted(((float(rx.fullmatch(f).group(1)), f) for f in listing if rx.fullmatch(f)), reverse=True)]
+                if not maximize:
+                    kept = kept[::-1]
+                listing = [f for f in listing if f not in kept[keep:]]
+                assert listing == z[f"{tag}.{k}.listing"].tolist(), (tag, k)
+                assert best == float(z[f"{tag}.{k}.best"])

@@ -111,3 +111,46 @@ def test_flag_checks(backend):
     task = tasks.S2ST_TranslationTask.setup_task(a, device=backend.device)
     with pytest.raises(ValueError, match="speaker-embed-dim"):
         task.build_model(a)
+
+
+def test_frozen_tables_stay_out_of_the_optimizer(backend, tmp_path):
+    """tables from ``speaker_emb_path`` are ``Embedding.from_pretrained(freeze=True)`` in the reference
+    (tasks/s2s_translation.py:161-171) -- requires_grad False, hence never handed to the optimizer.  Here they live in the
+    engine's BUFFER arena: not a module parameter, no gradient, and Adam updates with weight decay leave them bit for
+    bit -- while trainable tables of the same geometry move.  (One file serves both tables in the reference, so the
+    encoder is as wide as a packed output frame here.)"""
+    tasks = importlib.import_module(PKG + ".tasks")
+    trainer_mod = importlib.import_module(PKG + ".trainer")
+    from test_engine import MICRO
+    D = importlib.import_module(PKG + ".data")
+    spk = '{"a": 0, "b": 1}'
+    c = D.SyntheticFisherCorpus(n_utts=4, seed=3, max_src=64, median_src=50, min_src=30)
+    s = c.collate_batch(range(4))
+    s["speaker"] = torch.tensor([3, 0, 3, 7]).view(-1, 1)
+    s["net_input"]["speaker"] = s["speaker"]
+    moved = {}
+    for frozen in (True, False):
+        cfg = dict(MICRO, encoder_embed_dim=320, speaker_to_id=spk, speaker_embed_dim=320, speaker_embed_dim_dec=320)
+        a = O.make_args(**cfg)
+        a.precise_gemm = True
+        a.weight_decay, a.lr, a.warmup_updates, a.clip_norm = 0.1, [1e-2], 1, 1.0
+        task = tasks.S2ST_TranslationTask.setup_task(a, device=backend.device)
+        if frozen:
+            path = str(tmp_path / "spk.npy")
+            np.save(path, np.random.RandomState(0).standard_normal((len(spk), 320)).astype(np.float32))
+            task.get_speaker_embeddings_path = lambda: path
+        model = task.build_model(a)
+        load_synth(model, 0)
+        names_p = {n for n, _ in model.named_parameters()}
+        names_b = {n for n, _ in model.named_buffers()}
+        tabs = ["encoder.embed_speaker.weight", "decoder.embed_speaker.weight"]
+        assert all((t in names_b) == frozen and (t in names_p) == (not frozen) for t in tabs)
+        assert all(t in model.state_dict() for t in tabs)  # the checkpoint key stays either way
+        before = {t: model._views[t].clone() for t in tabs}
+        tr = trainer_mod.Trainer(a, task, model, task.build_criterion(a))
+        tr.train_step([s])
+        tr.train_step([s])
+        backend.sync()
+        moved[frozen] = {t: float((model._views[t] - before[t]).abs().max()) for t in tabs}
+    assert all(v > 0 for v in moved[False].values()), moved
+    assert all(v == 0.0 for v in moved[True].values()), moved
