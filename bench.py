@@ -17,6 +17,7 @@ import argparse
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -392,6 +393,36 @@ def infer_main(args):
 ADAM_OVERLAP = os.environ.get("S2ST_ADAM_OVERLAP", "0") == "1"
 
 
+def spawn_ranks(args) -> None:
+    """One rank per GPU through `python -m torch.distributed.run` (RCCL rendezvous on 127.0.0.1, a free port), with this
+    command line.  Refuses -- non-zero exit, no JSON line -- when the node shows fewer than N devices, unless
+    S2ST_BENCH_SHARE_GPU=1 asks for the one-GPU control-flow check (all ranks on cuda:0, gloo carries the bytes)."""
+    import socket
+    n = args.gpus
+    share = os.environ.get("S2ST_BENCH_SHARE_GPU") == "1"
+    have = torch.cuda.device_count()  # (counts devices without initialising the runtime in this process)
+    if have < n and not share:
+        raise SystemExit(f"[bench] --gpus {n} but only {have} HIP device(s) are visible: refusing to report an N={n} line "
+                         f"(S2ST_BENCH_SHARE_GPU=1 runs the {n}-rank code path on one device as a control-flow check)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if r.returncode != 0 or len(lines) != 1:
+        sys.stdout.write(r.stdout)
+        raise SystemExit(f"[bench] the {n}-rank run failed (exit code {r.returncode}, {len(lines)} result lines)")
+    line = json.loads(lines[0])
+    if line.get("n_gpus") != n or line.get("n_ranks_seen") != n:
+        raise SystemExit(f"[bench] asked for {n} ranks, the run reports n_gpus={line.get('n_gpus')} / "
+                         f"n_ranks_seen={line.get('n_ranks_seen')}")
+    print(lines[0])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -416,12 +447,18 @@ def main():
             args.steps = 8  # (default: two passes over the four batches)
         return infer_main(args)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks here, as fresh child processes BEFORE this
+        # process touches the GPU (the reference spawns its ranks itself too: fairseq/distributed/utils.py:334-369
+        # `torch.multiprocessing.spawn` from `call_main`); the parent only relays the JSON line and the exit code.
+        return spawn_ranks(args)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
-        print(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}: launch N>1 with torch.distributed.run", file=sys.stderr)
-        args.gpus = world
+        # never an N = 1 line under an N = 8 label (or the reverse)
+        raise SystemExit(f"[bench] WORLD_SIZE={world} contradicts --gpus {args.gpus}: launch with `--nproc-per-node "
+                         f"{args.gpus}` (or run `python bench.py --gpus {args.gpus}` without a launcher)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
     # S2ST_BENCH_SHARE_GPU=1 (a check of the N > 1 code path on a one-GPU box, never a measurement): every rank drives
@@ -443,6 +480,18 @@ def main():
     tasks = importlib.import_module(PKG + ".tasks")
     trainer_mod = importlib.import_module(PKG + ".trainer")
     bd = importlib.import_module(PKG + ".runtime.binding")
+    if os.environ.get("S2ST_MAIN_CU_MASK"):
+        # tuning instrument (tools/cu_partition.sh): the data path on a CU-masked stream (S2ST_SIDE_CU_MASK masks the
+        # engine's second stream; S2ST_DATA_CUS tells the tile picker how many CUs the data path has)
+        import ctypes as _C
+        words = [int(w, 16) for w in os.environ["S2ST_MAIN_CU_MASK"].split(",")]
+        arr = (_C.c_uint32 * len(words))(*words)
+        sp = _C.c_void_p()
+        fn = bd.lib().s2st_stream_create_cu_mask
+        fn.argtypes = [_C.c_void_p, _C.c_int32, _C.POINTER(_C.c_void_p)]
+        bd.check(fn(arr, len(words), _C.byref(sp)), "s2st_stream_create_cu_mask")
+        torch.cuda.set_stream(torch.cuda.ExternalStream(sp.value, device=dev))
+        vlog("data path on a CU-masked stream", os.environ["S2ST_MAIN_CU_MASK"])
     prefetch = importlib.import_module(PKG + ".runtime.prefetch")
 
     a = C_.recipe_args(args.config)  # named configurations live in the package (configs.py)
@@ -583,6 +632,12 @@ def main():
     if step_ev:
         vlog('per-step GPU ms (mel frames):', ' '.join('%.2f(%d)' % (step_ev[j - 1].elapsed_time(step_ev[j]), frames[args.warmup + j])
                                                      for j in range(1, len(step_ev))))
+    # how many ranks the communicator really joined (a SUM of ones over it), reported next to n_gpus
+    n_ranks_seen = 1
+    if world > 1:
+        ones = torch.ones(1, dtype=torch.float64, device="cpu" if share else dev)
+        torch.distributed.all_reduce(ones, op=torch.distributed.ReduceOp.SUM)
+        n_ranks_seen = int(round(float(ones[0])))
     my_frames = float(sum(frames[args.warmup:]))
     my_flops = 3.0 * 2.0 * sum(macs[args.warmup:])  # fwd + bwd = 3 x fwd, 2 FLOP per MAC
     stat = torch.tensor([dt, my_frames, my_flops], dtype=torch.float64, device="cpu" if share else dev)
@@ -725,7 +780,7 @@ def main():
         value = total_frames / dt
         line = {
             "metric": "mel-frames/sec (fwd+bwd+opt) on Fisher-shaped fbank80->mel80", "value": round(value, 1),
-            "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "mel-frames/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("s2st_transformer base 12enc/6dec d512 nfps4 + aux ASR/ST(1x64) + CTC, "

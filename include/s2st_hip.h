@@ -514,6 +514,12 @@ int64_t s2st_profile_timeline(char* out, int64_t cap);
 int s2st_version(void);
 /* number of HIP devices visible (0 = none: every compute entry point then fails) */
 int s2st_device_count(void);
+/* A stream restricted to the CUs named by `words` (bit i of word j = CU 32 j + i, hipExtStreamCreateWithCUMask); the
+ * caller drives the engine on it to keep the data path and the engine's second stream (S2ST_SIDE_CU_MASK) on disjoint
+ * parts of the chip.  A tuning instrument (tools/cu_partition.sh): the reference has no counterpart.  *out owns the
+ * stream until s2st_stream_destroy. */
+int s2st_stream_create_cu_mask(const uint32_t* words, int32_t n_words, void** out);
+int s2st_stream_destroy(void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,4 +1,5 @@
 // extern "C" surface of libs2st_hip.so (see include/s2st_hip.h).
+#include <hip/hip_ext.h>
 #include "s2st_ops.h"
 
 extern "C" {
@@ -9,6 +10,19 @@ int s2st_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+
+int s2st_stream_create_cu_mask(const uint32_t* words, int32_t n_words, void** out) {
+  if (!words || n_words <= 0 || !out) return S2ST_ERR_ARG;
+  hipStream_t st = nullptr;
+  if (hipExtStreamCreateWithCUMask(&st, (unsigned)n_words, words) != hipSuccess) return S2ST_ERR_LAUNCH;
+  *out = (void*)st;
+  return 0;
+}
+
+int s2st_stream_destroy(void* stream) {
+  if (!stream) return S2ST_ERR_ARG;
+  return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
 int s2st_gemm_f32(const s2st_gemm_args* a, void* stream) {

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "s2st_ops.h"
+#include <hip/hip_ext.h>
 
 namespace {
 
@@ -2076,7 +2077,23 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
     int pr_least = 0, pr_greatest = 0;
     const bool low = !(getenv("S2ST_SIDE_PRIORITY") && atoi(getenv("S2ST_SIDE_PRIORITY")) == 0);
     if (!low || hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest) != hipSuccess) pr_least = 0;
-    if (hipStreamCreateWithPriority(&e->side_, hipStreamNonBlocking, pr_least) != hipSuccess) e->side_ = nullptr;
+    // S2ST_SIDE_CU_MASK="w0,w1,...,w7" (hex words, bit i of word j = CU 32 j + i as hipExtStreamCreateWithCUMask counts
+    // them): the second stream only runs on those CUs -- an experiment of round 4 (keep the
+    // weight-gradient groups off part of the chip so that the data path's kernels do not share their CUs)
+    bool masked = false;
+    if (const char* mk = getenv("S2ST_SIDE_CU_MASK")) {
+      std::vector<unsigned> words;
+      for (const char* p = mk; *p;) {
+        char* end = nullptr;
+        const unsigned long v = strtoul(p, &end, 16);
+        if (end == p) break;
+        words.push_back((unsigned)v);
+        p = *end == ',' ? end + 1 : end;
+      }
+      if (!words.empty() && hipExtStreamCreateWithCUMask(&e->side_, (unsigned)words.size(), words.data()) == hipSuccess) masked = true;
+      else { e->side_ = nullptr; fprintf(stderr, "[s2st] S2ST_SIDE_CU_MASK: masked stream not created, falling back\n"); }
+    }
+    if (!masked && hipStreamCreateWithPriority(&e->side_, hipStreamNonBlocking, pr_least) != hipSuccess) e->side_ = nullptr;
     e->overlap_aux = !(getenv("S2ST_NO_AUX_OVERLAP") && atoi(getenv("S2ST_NO_AUX_OVERLAP")) != 0);
     if (e->side_ && hipEventCreateWithFlags(&e->ev_kv_, hipEventDisableTiming) != hipSuccess) e->ev_kv_ = nullptr;
     if (e->side_ && (hipEventCreateWithFlags(&e->ev_fork_, hipEventDisableTiming) != hipSuccess ||

@@ -969,6 +969,16 @@ void mark_fast_epilogue(GemmArgs& g) {
 // with more tiles than CUs the hardware dispatcher back-fills CUs as one-shot workgroups retire, which balances better
 // than a fixed walk of 2.25 tiles per workgroup -- 10.05 vs 10.58 ms per training step, profiles/r02_ab_switches.txt),
 // 2 = every 128-row launch persistent, 3 = grouped launches and single products with more tiles than CUs
+// CUs the data path's single products can count on: the whole chip, or -- S2ST_DATA_CUS=<n>, with the caller's stream
+// restricted by a CU mask (s2st_stream_create_cu_mask) -- that many; the tile choice prices rounds over this number
+int data_cus() {
+  static const int n = [] {
+    const char* ev = getenv("S2ST_DATA_CUS");
+    return ev && atoi(ev) > 0 ? atoi(ev) : 0;
+  }();
+  return n > 0 ? n : num_cus();
+}
+
 int persist_mode() {
   const char* ev = getenv("S2ST_GEMM_PERSIST");  // read per call: an A/B switch the tests flip
   return ev ? atoi(ev) : 1;
@@ -995,8 +1005,8 @@ int w4_pick(const GemmArgs& g, bool dma_ok) {
   if (mode == 0 || !dma_ok || g.M < 128) return 0;
   const long tm = (g.M + 127) / 128;
   const long t128 = tm * ((g.N + 127) / 128) * g.batch, t64 = tm * ((g.N + 63) / 64) * g.batch;
-  if (mode < 0 && t128 < num_cus()) return 0;
-  const long s128 = 2L * num_cus(), s64 = 3L * num_cus();
+  if (mode < 0 && t128 < data_cus()) return 0;
+  const long s128 = 2L * data_cus(), s64 = 3L * data_cus();
   const double e128 = (double)t128 / (double)(((t128 + s128 - 1) / s128) * s128);
   const double e64 = (double)t64 / (double)(((t64 + s64 - 1) / s64) * s64);
   return (g.N > 64 && e128 >= e64) ? 128 : 64;
@@ -1126,7 +1136,8 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
     double best = 1e300;
     for (const Cand& c : cands) {
       long tiles = (long)((g.M + c.bm - 1) / c.bm) * ((g.N + c.bn - 1) / c.bn) * g.batch;
-      long rounds = (tiles + 255) / 256;
+      const long ncu = data_cus();
+      long rounds = (tiles + ncu - 1) / ncu;
       // split-K candidates fill the chip anyway: cost by work / efficiency only
       double cost = (double)rounds * c.bm * c.bn / c.eff;
       if (cost < best) { best = cost; bm = c.bm; bn = c.bn; }

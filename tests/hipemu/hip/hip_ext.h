@@ -6,3 +6,4 @@ static inline void hipExtLaunchKernelGGL(K kernel, dim3 grid, dim3 block, unsign
                                          hipEvent_t, unsigned, A... a) {
   hipLaunchKernelGGL(kernel, grid, block, lds, st, a...);
 }
+static inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, unsigned, const unsigned*) { *s = nullptr; return hipErrorInvalidValue; }

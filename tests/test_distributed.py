@@ -258,3 +258,37 @@ def test_bench_two_ranks_share_the_gpu_control_flow():
     assert len(ex["buckets_mib"]) >= 3 and min(ex["buckets_mib"][:-1]) >= 16.0  # >= 16 MiB ranges (the tail may be smaller)
     assert abs(rec["ms_per_step"] * rec["steps"] * rec["value"] / 1e3 - rec["config"]["global_batch_mel_frames"] * rec["steps"]) \
         < 1e-3 * rec["config"]["global_batch_mel_frames"] * rec["steps"]
+    assert rec["n_ranks_seen"] == 2
+    # the driver's command shape is `python bench.py --gpus N` WITHOUT a launcher -- bench.py starts the
+    # N ranks itself (fresh children, before the parent touches the GPU) and relays their one line ...
+    bare = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-roofline",
+            "--cpu-seconds", "0", "--n-utts", "512"]
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run(bare, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec2 = json.loads(lines[0])
+    assert rec2["n_gpus"] == 2 and rec2["n_ranks_seen"] == 2 and "gradient_exchange" in rec2
+    assert rec2["config"]["global_batch_mel_frames"] == rec["config"]["global_batch_mel_frames"]  # same batches, same ranks
+    # ... and refuses loudly -- non-zero exit, no result line -- when the node has fewer devices than ranks asked for
+    if torch.cuda.device_count() < 2:
+        env2 = {k: v for k, v in env.items() if k != "S2ST_BENCH_SHARE_GPU"}
+        r = subprocess.run(bare, capture_output=True, text=True, timeout=300, env=env2, cwd=ROOT)
+        assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert "refusing" in r.stderr
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """(CPU) ``python bench.py --gpus 2`` on a box without two devices exits non-zero and prints no JSON line; so does a
+    launcher whose WORLD_SIZE contradicts --gpus."""
+    import subprocess
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than two devices")
+    env = {k: v for k, v in os.environ.items() if k not in ("S2ST_BENCH_SHARE_GPU", "WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "refusing" in r.stderr and "{" not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
+    assert r.returncode != 0 and "contradicts" in r.stderr and "{" not in r.stdout

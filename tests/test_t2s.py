@@ -284,6 +284,8 @@ def test_tiny_t2s_with_speakers_against_reference_golden(backend, golden_dir, pr
     for n in ("encoder.embed_speaker.weight", "encoder.spk_emb_proj.weight", "encoder.spk_emb_proj.bias"):
         assert rel(grads[n], torch.from_numpy(z["grad." + n])) < (2e-3 if precise else 8e-2), (n, rel(grads[n], torch.from_numpy(z["grad." + n])))
     if precise:  # text-input generation WITH speakers (the table enters through the encoder only)
+        # (a fresh model, as in the golden: the training forward above moved the BatchNorm running statistics)
+        a, task, model = _t2s_task_model(backend, SPK_CFG, precise)
         gen = task.build_generator_tts([model], a, vocoder=False)
         gen.max_iter, gen.eos_prob_threshold = int(z["max_iter"]), float(z["thr"])
         fin = gen.generate(model, s)
