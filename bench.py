@@ -165,7 +165,9 @@ def cpu_leg(args):
 # --config infer_base (BASELINE.json configs[4]): AR mel decode + Griffin-Lim (64 iterations) on Fisher-shaped inputs,
 # base geometry, 1 GPU: utterances / s, and the MCD of the GPU path's waveforms against the CPU path's on the same inputs
 # ================================================================================================
-INFER_B = 16          # utterances per generator call (the reference's generate_waveform batches by --max-tokens)
+INFER_MAX_TOKENS = 100000  # the recipe's generate_waveform batches by --max-tokens 100000 (run_baseline.sh:143-147):
+                           # utterances x longest source of a length-ordered batch; the 64 utterances below are ONE batch
+                           # (rounds 1 - 3 decoded them 16 at a time: four times the sequential decoding steps)
 INFER_N_UTTS = 64     # 64 utterances of the synthetic Fisher-shaped distribution
 INFER_GL_ITERS = 64   # --spec-bwd-max-iter 64
 
@@ -235,7 +237,8 @@ def infer_main(args):
     voc = V.GriffinLimVocoder(spec_bwd_max_iter=INFER_GL_ITERS, device=dev, **voc_kw)
     corpus = D.SyntheticFisherCorpus(n_utts=INFER_N_UTTS, seed=1234)
     order = np.argsort(-corpus.src_n_frames, kind="stable")  # length-ordered batches, like the task's iterator
-    groups = [order[i:i + INFER_B].tolist() for i in range(0, INFER_N_UTTS, INFER_B)]
+    groups = [g.tolist() for g in D.batch_by_size(order, corpus.src_n_frames[order], INFER_MAX_TOKENS, -1, 1)]
+    vlog("batches", [len(g) for g in groups])
     samples, iters = [], []
     for ix in groups:
         s_ = corpus.collate_batch(ix)
@@ -322,8 +325,11 @@ def infer_main(args):
     if args.cpu_seconds > 0:
         import subprocess
         import tempfile
-        n_cpu = args.cpu_utts or 2
-        ids = groups[1][:n_cpu]  # utterances of the second batch: close to the corpus' mean decode length
+        n_cpu = args.cpu_utts or 8
+        # utterances around the corpus' median length (the CPU oracle re-runs its decoder on the whole prefix every step:
+        # ~1 s per utterance here; `--cpu-utts 64` = all of them, the run committed under profiles/)
+        mid = len(order) // 2
+        ids = order[max(0, mid - n_cpu // 2): max(0, mid - n_cpu // 2) + n_cpu].tolist() if n_cpu < len(order) else order.tolist()
         sub = corpus.collate_batch(ids)
         sub["net_input"]["collated_audios_orig"] = None
         sub["net_input"]["padding_mask"] = None
@@ -373,11 +379,12 @@ def infer_main(args):
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "generate_waveform-shaped inference: s2st_transformer base 12enc/6dec d512 nfps4 (random-init), "
-                                   "%d Fisher-shaped utterances in length-ordered batches of %d, key/value-cached AR decode for the "
-                                   "batch's longest teacher length (stop threshold never reached: fixed work), Prenet dropout "
-                                   "0.5 on, post-net, Griffin-Lim %d iterations (n_fft 2048, hop 300) batched over the "
-                                   "utterances" % (INFER_N_UTTS, INFER_B, INFER_GL_ITERS),
-                       "name": "infer_base", "utterances_per_step": INFER_B, "mel_frames_per_s": round(n_frames / dt, 1),
+                                   "%d Fisher-shaped utterances in length-ordered --max-tokens %d batches (%s utterances), key/value-cached "
+                                   "AR decode for the batch's longest teacher length (stop threshold never reached: fixed work), "
+                                   "Prenet dropout 0.5 on, post-net, Griffin-Lim %d iterations (n_fft 2048, hop 300: real FFTs in "
+                                   "LDS) batched over the utterances" % (INFER_N_UTTS, INFER_MAX_TOKENS,
+                                                                        "+".join(str(len(g)) for g in groups), INFER_GL_ITERS),
+                       "name": "infer_base", "utterances_per_step": len(groups[0]), "mel_frames_per_s": round(n_frames / dt, 1),
                        "decode_steps_per_batch": iters, "batch0_decode_ms": round(t_dec * 1e3, 2),
                        "batch0_vocoder_ms": round(t_voc * 1e3, 2)}}
     if roofline:
@@ -436,6 +443,7 @@ def main():
                     "whole batch; default 8 for the HuBERT configuration, whose CPU front end is ~10x the model)")
     ap.add_argument("--cpu-whole", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (PCIe-inclusive) leg")
     ap.add_argument("--timeline", default=None, help="write the per-dispatch timeline (stream, start, duration on the GPU "
                     "clock) of ONE replayed step to this file; tools/timeline.py summarises it")
     ap.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)
@@ -444,7 +452,7 @@ def main():
         return infer_cpu_leg(args) if args.cpu_leg.startswith("infer:") else cpu_leg(args)
     if args.config == "infer_base":
         if args.steps == 100:
-            args.steps = 8  # (default: two passes over the four batches)
+            args.steps = 4  # (default: four passes over the corpus' batch(es))
         return infer_main(args)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -589,6 +597,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     vlog('timed region', dt, 'host issue time', t_issue)
+    last_loss = float(trainer.criterion.last_outputs["stats"][16])  # (of the last TIMED step: the legs below run more)
     # N > 1: what the gradient exchange cost beyond what the backward hid (the compute stream's wait in
     # GradReducer.finish(), GPU clock), and the ranges it was issued in
     exchange = None
@@ -614,21 +623,44 @@ def main():
         step(args.warmup + 1)
         torch.cuda.synchronize()
         vlog('cross-stream waits of one step on the data-path stream: %d us in total' % fn(eng.h, 1))
+    # PCIe-inclusive rate: the same steps fed from HOST batches (the collater's output), i.e. with the feature upload and the
+    # per-batch index preparation of Engine.prepare inside the timed region -- through runtime/prefetch.DevicePrefetcher
+    # (background thread, own stream, 3 batches ahead: what fairseq's BufferedIterator + pinned DataLoader do for the
+    # reference).  Steady state: the clock starts once the prefetcher's queue is full.  Reported in `config`
+    # (host_fed_ms_per_step), never as `value`.
+    host_fed = None
+    if not args.no_host_fed and world == 1:
+        n_h = args.steps
+        feed = [samples[i] for i in range(args.warmup, args.warmup + n_h)]
+        pf = prefetch.DevicePrefetcher(feed, eng, depth=3, model=model if hub else None)
+        t_fill = time.perf_counter()
+        while not pf.q.full() and time.perf_counter() - t_fill < 5.0:
+            time.sleep(0.001)
+        torch.cuda.synchronize()
+        th0 = time.perf_counter()
+        for smp in pf:
+            trainer.train_step([smp], overlap_optimizer=ADAM_OVERLAP)
+        torch.cuda.synchronize()
+        th = time.perf_counter() - th0
+        host_fed = th / n_h * 1e3
+        vlog('host-fed (PCIe-inclusive), prefetched uploads: %.3f ms/step, %.0f mel-frames/s over %d steps' % (
+            host_fed, sum(frames[args.warmup:args.warmup + n_h]) / th, n_h))
     if os.environ.get('S2ST_BENCH_VERBOSE'):
-        # PCIe-inclusive rate: the same steps fed from HOST batches (the collater's output), i.e. with the feature
-        # upload and the per-batch index preparation inside the timed region (reported in DESIGN.md, never as `value`)
         n_h = min(args.steps, 10)
-        for mode in ("in-line", "prefetched"):
-            feed = [samples[i] for i in range(args.warmup, args.warmup + n_h)]
-            src = iter(feed) if mode == "in-line" else prefetch.DevicePrefetcher(feed, eng, depth=3, model=model if hub else None)
-            torch.cuda.synchronize()
-            th0 = time.perf_counter()
-            for smp in src:
-                trainer.train_step([smp], overlap_optimizer=ADAM_OVERLAP)
-            torch.cuda.synchronize()
-            th = time.perf_counter() - th0
-            vlog('host-fed (PCIe-inclusive), %s uploads: %.3f ms/step, %.0f mel-frames/s over %d steps' % (
-                mode, th / n_h * 1e3, sum(frames[args.warmup:args.warmup + n_h]) / th, n_h))
+        feed = [samples[i] for i in range(args.warmup, args.warmup + n_h)]
+        torch.cuda.synchronize()
+        th0 = time.perf_counter()
+        for smp in feed:
+            trainer.train_step([smp], overlap_optimizer=ADAM_OVERLAP)
+        torch.cuda.synchronize()
+        th = time.perf_counter() - th0
+        vlog('host-fed (PCIe-inclusive), in-line uploads: %.3f ms/step over %d steps' % (th / n_h * 1e3, n_h))
+        # host cost of preparing one batch (Engine.prepare: index vectors + uploads), main thread, idle GPU
+        tp0 = time.perf_counter()
+        for smp in feed:
+            eng.prepare(smp, training=True, seed=0)
+        torch.cuda.synchronize()
+        vlog('Engine.prepare alone: %.3f ms per batch' % ((time.perf_counter() - tp0) / n_h * 1e3))
     if step_ev:
         vlog('per-step GPU ms (mel frames):', ' '.join('%.2f(%d)' % (step_ev[j - 1].elapsed_time(step_ev[j]), frames[args.warmup + j])
                                                      for j in range(1, len(step_ev))))
@@ -649,7 +681,6 @@ def main():
         dt, total_frames, total_flops = float(tmax[0]), float(tot[0]), float(tot[1])
     else:
         total_frames, total_flops = my_frames, my_flops
-    last_loss = float(trainer.criterion.last_outputs["stats"][16])
 
     # ---- roofline leg: replay the timed steps with per-DISPATCH timing (include/s2st_hip.h s2st_profile_*) ------
     # Every launch of the dominant kernels carries its own start / stop event (hipExtLaunchKernelGGL): the elapsed
@@ -794,7 +825,11 @@ def main():
                        "global_batch_mel_frames": round(total_frames / args.steps, 1),
                        "parallelism": f"dp{world}", "gemm": "bf16 MFMA operands (bf16 copies of fp32 tensors), fp32 accumulate, fp32 master weights / residual stream / softmax / losses",
                        "final_loss": round(last_loss, 4),
-                       "model_tflops": round(total_flops / dt / 1e12, 2)},
+                       "model_tflops": round(total_flops / dt / 1e12, 2),
+                       **({"host_fed_ms_per_step": round(host_fed, 3),
+                           "host_fed_note": "the same steps fed from host batches through DevicePrefetcher (feature upload + "
+                                            "Engine.prepare per batch inside the timed region, steady state); never `value`"}
+                          if host_fed is not None else {})},
         }
         if roofline:
             line["roofline"] = roofline

@@ -423,6 +423,18 @@ int s2st_gl_overlap_add_f32(const float* frames, const float* wsq, float* wave, 
  *   frame_split: As[rows][3][n_fft] = split(frames of the reflect-padded waves [U][Lw]) */
 int s2st_gl_polar_split_f32(const float* mag, const float* aux, int32_t from_spectrum, const int32_t* tl, void* Xs, int32_t U, int32_t F, int32_t Fp, int32_t Tmax, void* stream);
 int s2st_gl_frame_split_f32(const float* wave, const int32_t* tl, void* As, int32_t U, int32_t Tmax, int32_t hop, int32_t n_fft, int32_t Lw, void* stream);
+/* Griffin-Lim with FFTs (round 4; replaces, for n_fft a power of two in 256 ... 4096, the dense Fourier-basis contractions
+ * above).  The reference's analysis basis [Re; Im] fft(eye(n_fft)) * window is rfft(window * frame)
+ * (fairseq/data/audio/audio_utils.py:226-231, 259-271) and its synthesis basis pinverse(n_fft / hop * basis)^T * window is
+ * window * (hop / n_fft) * irfft (fairseq/models/text_to_speech/vocoder.py:59-62, 82-86).  X: complex spectra
+ * [U * Tmax][n_fft / 2 + 1] (re, im interleaved); tl [U] frames per utterance; win [n_fft]; tw [n_fft] complex exp(-2 pi i j / n_fft).
+ * s2st_gl_polar_c_f32: X = mag * exp(i ang) (vocoder.py:101-103).  s2st_gl_stft_project_f32: reflect-pad + frame + window +
+ * rfft of wave [U][Lw], then X = mag * Y / |Y| (vocoder.py:104-107).  s2st_gl_istft_frames_f32: synthesis frames
+ * [U * Tmax][n_fft] for s2st_gl_overlap_add_b_f32. */
+int s2st_gl_fft_supported_i32(int32_t n_fft);
+int s2st_gl_polar_c_f32(const float* mag, const float* ang, const int32_t* tl, float* X, int32_t U, int32_t F, int32_t Tmax, void* stream);
+int s2st_gl_stft_project_f32(const float* wave, const int32_t* tl, const float* win, const float* tw, const float* mag, float* X, int32_t U, int32_t Tmax, int32_t n_fft, int32_t hop, int32_t Lw, void* stream);
+int s2st_gl_istft_frames_f32(const float* X, const int32_t* tl, const float* win, const float* tw, float* frames, int32_t U, int32_t Tmax, int32_t n_fft, int32_t hop, void* stream);
 int s2st_gl_overlap_add_b_f32(const float* frames, const float* wsq_all, const int64_t* wsq_off, const int32_t* tl, float* wave, int32_t U, int32_t Tmax, int32_t n_fft, int32_t hop, int32_t Lw, void* stream);
 
 /* AR decoding (speech_generator_for_s2st.py:76-110: one decoder step for the B utterances of a batch): skinny
@@ -512,6 +524,10 @@ int64_t s2st_profile_report(char* out, int64_t cap);
 int64_t s2st_profile_timeline(char* out, int64_t cap);
 
 int s2st_version(void);
+/* 1 when the library was built with -DS2ST_EXPERIMENTAL: the measured-and-not-chosen GEMM forms (persistent tile walk,
+ * stream-K, 256 x 128 tiles: S2ST_GEMM_PERSIST=2/3, S2ST_GROUP_ONESHOT=0, S2ST_GROUP_TILE=256, S2ST_GEMM_STREAMK) and the
+ * timing-only switch S2ST_TIMING_SKIP_WGRAD exist only there; the product build (0) ignores those switches */
+int s2st_experimental_build(void);
 /* number of HIP devices visible (0 = none: every compute entry point then fails) */
 int s2st_device_count(void);
 /* A stream restricted to the CUs named by `words` (bit i of word j = CU 32 j + i, hipExtStreamCreateWithCUMask); the

@@ -6,6 +6,14 @@ extern "C" {
 
 int s2st_version(void) { return 100; }
 
+int s2st_experimental_build(void) {
+#ifdef S2ST_EXPERIMENTAL
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 int s2st_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -184,6 +192,16 @@ int s2st_gl_polar_split_f32(const float* mag, const float* aux, int32_t from_spe
 }
 int s2st_gl_frame_split_f32(const float* wave, const int32_t* tl, void* As, int32_t U, int32_t Tmax, int32_t hop, int32_t n_fft, int32_t Lw, void* stream) {
   return s2st_gl_frame_split(wave, tl, (uint16_t*)As, U, Tmax, hop, n_fft, Lw, (hipStream_t)stream);
+}
+int s2st_gl_fft_supported_i32(int32_t n_fft) { return s2st_gl_fft_supported(n_fft) ? 1 : 0; }
+int s2st_gl_polar_c_f32(const float* mag, const float* ang, const int32_t* tl, float* X, int32_t U, int32_t F, int32_t Tmax, void* stream) {
+  return s2st_gl_polar_c(mag, ang, tl, X, U, F, Tmax, (hipStream_t)stream);
+}
+int s2st_gl_stft_project_f32(const float* wave, const int32_t* tl, const float* win, const float* tw, const float* mag, float* X, int32_t U, int32_t Tmax, int32_t n_fft, int32_t hop, int32_t Lw, void* stream) {
+  return s2st_gl_stft_project(wave, tl, win, tw, mag, X, U, Tmax, n_fft, hop, Lw, (hipStream_t)stream);
+}
+int s2st_gl_istft_frames_f32(const float* X, const int32_t* tl, const float* win, const float* tw, float* frames, int32_t U, int32_t Tmax, int32_t n_fft, int32_t hop, void* stream) {
+  return s2st_gl_istft_frames(X, tl, win, tw, frames, U, Tmax, n_fft, hop, (hipStream_t)stream);
 }
 int s2st_gl_overlap_add_b_f32(const float* frames, const float* wsq_all, const int64_t* wsq_off, const int32_t* tl, float* wave, int32_t U, int32_t Tmax, int32_t n_fft, int32_t hop, int32_t Lw, void* stream) {
   return s2st_gl_overlap_add_b(frames, wsq_all, (const long*)wsq_off, tl, wave, U, Tmax, n_fft, hop, Lw, (hipStream_t)stream);

@@ -133,6 +133,7 @@ struct s2st_engine {
   Ten* enc_out_keep = nullptr;
   struct Dec {
     float* base = nullptr; int B = 0, E = 0, maxT = 0; const int* enc_lens = nullptr; const float* pe_dec = nullptr;
+    float* pe_alpha = nullptr;  // [maxT + 2][dec_dim]: pos_emb_alpha * PE rows (tail of the caller's state buffer)
   } dec_st;
   float* dec_selfK(int l) const { return dec_st.base + (long)l * 2 * dec_st.B * dec_st.maxT * c.dec_dim; }
   float* dec_selfV(int l) const { return dec_selfK(l) + (long)dec_st.B * dec_st.maxT * c.dec_dim; }
@@ -553,6 +554,7 @@ struct s2st_engine {
   // ------------------------------------------------------------------------------------
   // weight-gradient GEMMs waiting for their group launch (S2ST_NO_WGRAD_GROUP=1: A/B switch, one launch each)
   bool group_wgrad = true;
+  int wgrad_kchunk = 0;    // S2ST_WGRAD_KCHUNK (see flush_wgrad)
   int group_flush_at = 6;  // S2ST_WGRAD_GROUP=<n>: problems per launch (<= S2ST_GROUP_MAX); measured 2 .. 8 on the bench
                            // workload: 12.25 / 10.99 / 10.56 / 10.44 / 10.46 ms per step for 2 / 3 / 4 / 6 / 8
   std::vector<GemmArgs> pending_wgrad;
@@ -579,14 +581,42 @@ struct s2st_engine {
     if (live()) {
       // everything the products read was enqueued on st_ before this point
       hipStream_t s = (side_ && st_ != side_) ? fork_side() : st_;
-      // S2ST_TIMING_SKIP_WGRAD=1: a TIMING experiment only (wrong gradients): how much of the step is the weight-gradient
-      // products' share of the chip
+      // S2ST_TIMING_SKIP_WGRAD=1 (-DS2ST_EXPERIMENTAL builds only: it makes the gradients WRONG): a timing experiment --
+      // how much of the step is the weight-gradient products' share of the chip
+#ifdef S2ST_EXPERIMENTAL
       static const bool skip = [] {
         const bool on = getenv("S2ST_TIMING_SKIP_WGRAD") && atoi(getenv("S2ST_TIMING_SKIP_WGRAD")) != 0;
         if (on) fprintf(stderr, "[s2st] S2ST_TIMING_SKIP_WGRAD=1: weight-gradient products are SKIPPED -- gradients are WRONG, "
                                 "timing experiments only\n");
         return on;
       }();
+#else
+      constexpr bool skip = false;
+#endif
+      if (!skip && wgrad_kchunk > 0) {
+        // S2ST_WGRAD_KCHUNK=<tokens> (round 4): the group as SEVERAL launches over consecutive token ranges, each
+        // accumulating into the same gradient tiles (stream order keeps the sums in a fixed order).  A launch's
+        // workgroups then live K / chunks as long: the data path's kernels, which share the chip with them, find free
+        // CUs sooner -- at the price of one more read-modify-write of the gradient tiles per chunk on the second stream.
+        int kmax = 0;
+        for (const GemmArgs& g : pending_wgrad) kmax = g.K > kmax ? g.K : kmax;
+        const int nch = (kmax + wgrad_kchunk - 1) / wgrad_kchunk;
+        const int step = (((kmax + nch - 1) / nch) + 63) / 64 * 64;  // equal chunks, multiples of the K-step
+        std::vector<GemmArgs> part;
+        for (int k0 = 0; k0 < kmax; k0 += step) {
+          part.clear();
+          for (const GemmArgs& g : pending_wgrad) {
+            if (k0 >= g.K) continue;
+            GemmArgs q = g;
+            q.K = (g.K - k0 < step) ? g.K - k0 : step;
+            // both operands are stored [k][rows] (rows contiguous): K index k0 is k0 rows further down
+            q.A.p = reinterpret_cast<const bf16raw*>(g.A.p) + (long)k0 * g.A.sp.ld;
+            q.B.p = reinterpret_cast<const bf16raw*>(g.B.p) + (long)k0 * g.B.sp.ld;
+            part.push_back(q);
+          }
+          if (!part.empty()) chk(s2st_gemm_bf16_group(part.data(), (int)part.size(), s));
+        }
+      } else
       if (!skip) chk(s2st_gemm_bf16_group(pending_wgrad.data(), (int)pending_wgrad.size(), s));
     }
     pending_wgrad.clear();
@@ -617,14 +647,15 @@ struct s2st_engine {
   // op: y = [resid +] dropout(act(x W^T + b))
   // only_h: the caller guarantees every consumer reads the bf16 copy (fast mode): no fp32 result is
   // allocated or written
+  // resid_row (AR decoding only, skinny path): ONE row added to every output row (the step's alpha-scaled position)
   Ten* linear(Ten* x, long w, long b, int N, int K, int act = 0, float drop_p = 0.f,
-              Ten* resid = nullptr, float* ext_out = nullptr, bool only_h = false) {
+              Ten* resid = nullptr, float* ext_out = nullptr, bool only_h = false, const float* resid_row = nullptr) {
     const int M = x->rows;
     const bool fm = fast();
     // AR decoding: a handful of rows (one per utterance) -- the skinny kernel converts x in registers, so neither
     // a bf16 copy of the input nor one of the output is made (fp32 in, fp32 out)
-    const bool skinny = fm && !bt.training && use_skinny && M <= 16 && K % 32 == 0 && x->d && x->cols == K &&
-                        (act == 0 || act == 1);
+    const bool skinny = fm && !bt.training && use_skinny && M <= 64 && K % 32 == 0 && x->d && x->cols == K &&
+                        (act == 0 || act == 1 || act == 3);
     only_h = only_h && fast() && use_only_h && N % 8 == 0 && !ext_out && !resid && !skinny;
     Ten* y = newT(M, N, ext_out, !only_h);
     touch(w + (long)N * K);
@@ -632,8 +663,8 @@ struct s2st_engine {
     const uint64_t sd = drop_p > 0.f ? next_seed() : 0;
     if (skinny) {
       if (live())
-        chk(s2st_gemm_skinny(x->d, K, PH + w, K, y->d, N, b >= 0 ? P + b : nullptr, act, drop_p, sd, resid ? resid->d : nullptr,
-                             N, M, N, K, st_));
+        chk(s2st_gemm_skinny(x->d, K, PH + w, K, y->d, N, b >= 0 ? P + b : nullptr, act, drop_p, sd,
+                             resid ? resid->d : resid_row, resid ? N : 0, M, N, K, st_));
       return y;  // inference only: no tape entry
     }
     const bf16raw* xh = fm ? half_of(x) : nullptr;
@@ -774,8 +805,8 @@ struct s2st_engine {
   // inference with a handful of rows (AR decoding): y = act(LayerNorm(x) W^T + b) in ONE skinny launch (the
   // normalisation is applied while the rows are converted to bf16); otherwise layernorm() + linear()
   Ten* ln_linear(Ten* x, const LNP& ln, long w, long b, int N, int K, int act = 0, float* ext_out = nullptr) {
-    const bool fused = fast() && !bt.training && use_skinny && use_ln_skinny && x->rows <= 16 && K % 64 == 0 &&
-                       x->d && x->cols == K && (act == 0 || act == 1);
+    const bool fused = fast() && !bt.training && use_skinny && use_ln_skinny && x->rows <= 64 && K % 64 == 0 &&
+                       x->d && x->cols == K && (act == 0 || act == 1 || act == 3);
     if (!fused) return linear(layernorm(x, ln), w, b, N, K, act, 0.f, nullptr, ext_out);
     Ten* y = newT(x->rows, N, ext_out);
     touch(w + (long)N * K);
@@ -1251,13 +1282,16 @@ struct s2st_engine {
   // ------------------------------------------------------------------------------------
   // incremental decoding (fairseq/speech_generator_for_s2st.py:46-110; s2st_transformer.py:369-456 with
   // incremental_state; transformer_layer.py:301-446; multihead_attention.py:194-385 incremental path)
-  Ten* dec_attn(Ten* qt, int qoff, const float* K, const float* V, long ldk, long kbs, const int* klen, int nkeys,
-                int H, float* attn_mean, int S) {
+  // k_new / v_new (self-attention): this step's key / value rows [B][ld_new]; every (b, h) workgroup writes its head slice
+  // to row `pos_new` of the caches before it attends (the two copy launches per layer of rounds 1 - 3 are gone)
+  Ten* dec_attn(Ten* qt, int qoff, float* K, float* V, long ldk, long kbs, const int* klen, int nkeys,
+                int H, float* attn_mean, int S, const float* k_new = nullptr, const float* v_new = nullptr, long ld_new = 0,
+                int pos_new = 0) {
     const int Cd = c.dec_dim, B = dec_st.B;
     Ten* o = newT(B, Cd);
     if (live())
       chk(s2st_decode_attn(qt->d + qoff, qt->cols, K, V, ldk, kbs, klen, nkeys, B, H, Cd / H,
-                           1.0f / sqrtf((float)(Cd / H)), o->d, Cd, attn_mean, S, st_));
+                           1.0f / sqrtf((float)(Cd / H)), o->d, Cd, attn_mean, S, st_, k_new, v_new, ld_new, pos_new));
     return o;
   }
 
@@ -1284,20 +1318,21 @@ struct s2st_engine {
     // Prenet: dropout is ALWAYS on (tacotron2.py:95-98), also at inference
     for (int i = 0; i < c.prenet_layers; ++i)
       x = linear(x, prenet[i].w, prenet[i].b, prenet[i].N, prenet[i].K, 1, c.prenet_dropout);
-    x = linear(x, prenet.back().w, prenet.back().b, Cd, c.prenet_dim);
-    x = add_pe(x, pos, dec_st.pe_dec, 1.f, pos_alpha, 0.f);
+    // (every utterance is at position step + 2 in the incremental path: x + alpha * PE[pos] is ONE row for the whole
+    // batch, taken from the alpha-scaled table decode_begin prepared -- added in the projection's epilogue on the skinny
+    // path, by the position kernel otherwise)
+    const float* pe_row = dec_st.pe_alpha ? dec_st.pe_alpha + (long)(step + 2) * Cd : nullptr;
+    const bool pe_fused = pe_row && fast() && use_skinny && B <= 64 && c.prenet_dim % 32 == 0;
+    x = linear(x, prenet.back().w, prenet.back().b, Cd, c.prenet_dim, 0, 0.f, nullptr, nullptr, false, pe_fused ? pe_row : nullptr);
+    if (!pe_fused) x = add_pe(x, pos, dec_st.pe_dec, 1.f, pos_alpha, 0.f);
     for (int l = 0; l < c.dec_layers; ++l) {
       const DecLayerP& L = dec[l];
       // self-attention over the cached keys / values 0..step
       Ten* kvq = pre ? ln_linear(x, L.ln1, L.sa.kvq_w, L.sa.kvq_b, 3 * Cd, Cd) : linear(x, L.sa.kvq_w, L.sa.kvq_b, 3 * Cd, Cd);
-      if (live()) {
-        Split xs{(long)3 * Cd, 0, 0, 0}, ys{(long)maxT * Cd, 0, 0, 0};
-        chk(s2st_copy_rows(kvq->d, xs, dec_selfK(l) + (long)step * Cd, ys, B, Cd, st_));
-        chk(s2st_copy_rows(kvq->d + Cd, xs, dec_selfV(l) + (long)step * Cd, ys, B, Cd, st_));
-      }
       // keys >= self_klen[b] are masked: a finished utterance keeps its final length (the reference's
       // cached key padding mask, speech_generator_for_s2st.py:88-89 + multihead_attention.py:268-277)
-      Ten* o = dec_attn(kvq, 2 * Cd, dec_selfK(l), dec_selfV(l), Cd, (long)maxT * Cd, self_klen, step + 1, H, nullptr, 0);
+      Ten* o = dec_attn(kvq, 2 * Cd, dec_selfK(l), dec_selfV(l), Cd, (long)maxT * Cd, self_klen, step + 1, H, nullptr, 0,
+                        kvq->d, kvq->d + Cd, 3 * Cd, step);
       x = linear(o, L.sa.out_w, L.sa.out_b, Cd, Cd, 0, 0.f, x);
       if (!pre) x = layernorm(x, L.ln1);
       // encoder attention (static keys / values precomputed by decode_begin)
@@ -1314,15 +1349,17 @@ struct s2st_engine {
         x = layernorm(ffn_block(x, L.fc1, L.fc2, x), L.ln3);
       }
     }
+    // the stop head's logistic rides in its projection's epilogue on the skinny path (act 3)
+    const bool sig_fused = fast() && use_skinny && B <= 64 && Cd % 64 == 0 && (!has_dec_ln || use_ln_skinny);
     Ten* eos;
     if (has_dec_ln) {  // both heads read the normalised state
       ln_linear(x, dec_ln, feat_proj.w, feat_proj.b, c.out_dim, Cd, 0, feat_out);
-      eos = ln_linear(x, dec_ln, eos_proj.w, eos_proj.b, 1, Cd);
+      eos = ln_linear(x, dec_ln, eos_proj.w, eos_proj.b, 1, Cd, sig_fused ? 3 : 0, sig_fused ? eos_prob : nullptr);
     } else {
       linear(x, feat_proj.w, feat_proj.b, c.out_dim, Cd, 0, 0.f, nullptr, feat_out);
-      eos = linear(x, eos_proj.w, eos_proj.b, 1, Cd);
+      eos = linear(x, eos_proj.w, eos_proj.b, 1, Cd, sig_fused ? 3 : 0, 0.f, nullptr, sig_fused ? eos_prob : nullptr);
     }
-    if (live()) chk(s2st_sigmoid(eos->d, eos_prob, B, st_));
+    if (!sig_fused && live()) chk(s2st_sigmoid(eos->d, eos_prob, B, st_));
     return err;
   }
 
@@ -2065,6 +2102,7 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->attn_gfuse_mode = getenv("S2ST_ATTN_GFUSE") ? atoi(getenv("S2ST_ATTN_GFUSE")) : 1;
   e->use_attn_gfuse = e->attn_gfuse_mode != 0;
   if (getenv("S2ST_WGRAD_TILES")) e->group_tile_budget = atoi(getenv("S2ST_WGRAD_TILES"));
+  if (getenv("S2ST_WGRAD_KCHUNK")) e->wgrad_kchunk = atoi(getenv("S2ST_WGRAD_KCHUNK"));
   e->ln_bwd_split = getenv("S2ST_LN_BWD_SPLIT") && atoi(getenv("S2ST_LN_BWD_SPLIT")) != 0;
   if (getenv("S2ST_CONV_TAIL_MAIN")) e->conv_tail_on_main = atoi(getenv("S2ST_CONV_TAIL_MAIN")) != 0;
   e->ordered_sums = !(getenv("S2ST_ORDERED_BIAS_SUMS") && atoi(getenv("S2ST_ORDERED_BIAS_SUMS")) == 0);
@@ -2261,7 +2299,7 @@ int s2st_engine_segment_range(const s2st_engine* e, int32_t i, int64_t* lo, int6
 // ---- AR decoding + eval post-net (config 5) ---------------------------------------------------
 int64_t s2st_engine_decode_state_floats(const s2st_engine* e, int32_t B, int32_t E, int32_t max_steps) {
   const long Cd = e->c.dec_dim, L = e->c.dec_layers;
-  return L * 2 * B * (long)max_steps * Cd + L * (long)B * E * 2 * Cd + 64;
+  return L * 2 * B * (long)max_steps * Cd + L * (long)B * E * 2 * Cd + 64 + ((long)max_steps + 2) * Cd;
 }
 
 int s2st_engine_decode_begin(s2st_engine* e, const s2st_batch* b, const s2st_outputs* out, float* state,
@@ -2286,6 +2324,14 @@ int s2st_engine_decode_begin(s2st_engine* e, const s2st_batch* b, const s2st_out
   e->dec_st.B = b->B; e->dec_st.E = b->E; e->dec_st.maxT = max_steps;
   e->dec_st.enc_lens = b->enc_lens;
   e->dec_st.pe_dec = b->pe_dec;
+  // alpha-scaled position rows 0 .. max_steps + 1 (one small launch per utterance batch instead of one per step)
+  {
+    const long Cd = e->c.dec_dim, L = e->c.dec_layers;
+    e->dec_st.pe_alpha = state + L * 2 * b->B * (long)max_steps * Cd + L * (long)b->B * b->E * 2 * Cd + 64;
+    e->touch(e->pos_alpha + 1);
+    if (e->live())
+      e->chk(s2st_scale_rows(b->pe_dec, e->P + e->pos_alpha, e->dec_st.pe_alpha, ((long)max_steps + 2) * Cd, e->st_));
+  }
   // static cross-attention keys / values of every decoder layer (static_kv=True)
   for (int l = 0; l < e->c.dec_layers; ++l) {
     const XAttnP& xa = e->dec[l].xa;

@@ -437,6 +437,11 @@ int launch_dma_group(const GemmGroup& grp, hipStream_t st) {
   return go(gemm_bf16_dma_group_kernel<BM, BN, false, false, NS, NW, IL>, tag(0));
 }
 
+// The persistent tile walk, its stream-K form and the 256 x 128 tile were built and measured in rounds 2 - 3 (DESIGN.md
+// section 4 / 5: none of them is what the launcher picks for this step's products).  They are compiled only into
+// -DS2ST_EXPERIMENTAL builds (tools/build_experimental.sh: the A/B tools, the emulator's test build), so that the product
+// library carries -- and preloads -- only the instantiations its pickers can select.
+#ifdef S2ST_EXPERIMENTAL
 // ------------------------------------------------------------------------------------------------
 // Persistent, grouped form of the ring kernel.  One workgroup per CU walks tiles t = id, id + G, id + 2G, ... of the
 // concatenated tile list of up to S2ST_GROUP_MAX problems (same operand layouts, batch 1, no split-K), and the DMA
@@ -793,6 +798,8 @@ const char* streamk_tag() {
   return buf;
 }
 
+#endif  // S2ST_EXPERIMENTAL
+
 int num_cus() {
   static int n = 0;
   if (!n) {
@@ -818,6 +825,7 @@ int g_sk_epoch = 0;
 // with S2ST_GEMM_STREAMK=1 in the environment: measured on MI355X (tools/streamk_probe.py) the
 // hand-off -- L2 write-back behind the release, invalidate + 64 KB read behind the acquire -- costs 12-20 us per launch,
 // more than the idle last round of the 25-45 us products of a training step; it pays from ~2 rounds of long-K tiles on.
+#ifdef S2ST_EXPERIMENTAL
 int streamk_mode() {
   const char* ev = getenv("S2ST_GEMM_STREAMK");
   return ev ? atoi(ev) : 1;
@@ -879,6 +887,12 @@ int launch_persistent(const GemmGroup& grp_in, hipStream_t st) {
   if (!akm && bkm) return go(gemm_bf16_dma_persistent_kernel<BM, BN, false, true, NS, NW>, persistent_tag<BM, BN, false, true, NS, NW>());
   return go(gemm_bf16_dma_persistent_kernel<BM, BN, false, false, NS, NW>, persistent_tag<BM, BN, false, false, NS, NW>());
 }
+
+#else
+int streamk_mode() { return 0; }
+template <int BM, int BN, int NS, int NW>
+int launch_persistent(const GemmGroup&, hipStream_t) { return S2ST_ERR_ARG; }  // (not built: never reached, see persist_mode())
+#endif  // S2ST_EXPERIMENTAL
 
 // C(m, n) (+)= sum_s slab[z][s][m][n]
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, GemmOut C, int M, int N,
@@ -981,8 +995,20 @@ int data_cus() {
 
 int persist_mode() {
   const char* ev = getenv("S2ST_GEMM_PERSIST");  // read per call: an A/B switch the tests flip
-  return ev ? atoi(ev) : 1;
+  const int v = ev ? atoi(ev) : 1;
+#ifdef S2ST_EXPERIMENTAL
+  return v;
+#else
+  return v > 1 ? 1 : v;  // (2 / 3 need the persistent kernels: experimental builds only)
+#endif
 }
+
+constexpr bool kExperimental =
+#ifdef S2ST_EXPERIMENTAL
+    true;
+#else
+    false;
+#endif
 
 // S2ST_GEMM_W4 (read per call: an A/B switch): 0 = the 8-wave ring kernels only (one workgroup per CU); -1 (default) =
 // the 4-wave early-release form (gemm_bf16_w4.hip, 2 - 3 workgroups per CU) for single products with at least one
@@ -1057,7 +1083,7 @@ int s2st_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t st) {
   // S2ST_GROUP_TILE=256: 256 x 128 tiles (48 KB of operands per K-step for twice the FLOPs: half the workgroups, which
   // leaves CUs to the data-path stream the group runs beside)
   const char* gt = getenv("S2ST_GROUP_TILE");
-  bool big = gt && atoi(gt) == 256;
+  bool big = kExperimental && gt && atoi(gt) == 256;
   for (int i = 0; i < n && big; ++i) big = list[i].M >= 256;
   if (big) {
     GemmGroup g2{};
@@ -1067,7 +1093,9 @@ int s2st_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t st) {
       prep_flags(g);
       add_to_group<128, 256>(g2, g);
     }
-    if (launch_persistent<256, 128, 3, 8>(g2, st)) return S2ST_ERR_LAUNCH;
+    if constexpr (kExperimental) {
+      if (launch_persistent<256, 128, 3, 8>(g2, st)) return S2ST_ERR_LAUNCH;
+    }
     return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
   }
   // default: one workgroup per tile of the concatenated list (plain K-loop: 9.65 vs 9.76 ms/step);
@@ -1075,7 +1103,7 @@ int s2st_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t st) {
   const char* os = getenv("S2ST_GROUP_ONESHOT");
   bool sk_bound = false;
   for (int i = 0; i < g_sk_n; ++i) sk_bound = sk_bound || (g_sk[i].st == st && g_sk[i].p);
-  if (!(os && atoi(os) == 0) && !(sk_bound && streamk_mode() > 0)) {
+  if (!kExperimental || (!(os && atoi(os) == 0) && !(sk_bound && streamk_mode() > 0))) {
     // S2ST_GROUP_XCD=0 (A/B switch): every product's tiles spread over all XCDs (the form up to round 3)
     static const bool xcd_global = !(getenv("S2ST_GROUP_XCD") && atoi(getenv("S2ST_GROUP_XCD")) == 0);
     grp.xcd_global = xcd_global ? 1 : 0;
@@ -1104,14 +1132,16 @@ int s2st_gemm_bf16_preload(hipStream_t st) {
     rc |= launch_dma<128, 128, 4, 8, true>(g, grid, st);
     rc |= launch_dma<128, 64, 4, 8, true>(g, grid, st);
     rc |= launch_dma<64, 64, 4, 4, true>(g, grid, st);
-    GemmGroup grp{};  // no tiles: the persistent kernels fall straight through
+    GemmGroup grp{};  // no tiles: the kernels fall straight through
     grp.n = 1;
     grp.g[0] = g;
-    rc |= launch_persistent<128, 128, 4, 8>(grp, st);
-    rc |= launch_persistent<128, 64, 4, 8>(grp, st);
-    rc |= launch_persistent<256, 128, 3, 8>(grp, st);
+    if constexpr (kExperimental) {
+      rc |= launch_persistent<128, 128, 4, 8>(grp, st);
+      rc |= launch_persistent<128, 64, 4, 8>(grp, st);
+      rc |= launch_persistent<256, 128, 3, 8>(grp, st);
+      rc |= launch_dma<256, 128, 3, 8>(g, grid, st);
+    }
     { GemmGroup g0 = grp; g0.total = 0; g0.n = 1; rc |= launch_dma_group<128, 128, 4, 8, true>(g0, st); }
-    rc |= launch_dma<256, 128, 3, 8>(g, grid, st);
   }
   rc |= s2st_gemm_bf16_w4_preload(st);
   return rc || hipGetLastError() != hipSuccess ? -1 : 0;
@@ -1147,7 +1177,7 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
     const char* force = getenv("S2ST_GEMM_TILE");  // (read per call: the tests switch it)
     if (force && sscanf(force, "%dx%d", &bm, &bn) != 2) { bm = 64; bn = 64; }
   }
-  if (bm == 256 && !(vec && dma_layout_ok(g) && g.batch == 1)) { bm = 128; bn = 128; }  // 256-row tiles: ring kernels only
+  if (bm == 256 && !(kExperimental && vec && dma_layout_ok(g) && g.batch == 1)) { bm = 128; bn = 128; }  // 256-row tiles: ring kernels of experimental builds only
   const bool can_split_ = g.ep.accumulate && linear_epi && g.C.p && !g.C.h && !g.ep.bias && !g.ep.resid && g.K >= 8 * BK;
   if (vec && can_split_ && (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch < 256) { bm = 128; bn = 128; }
   // the 4-wave early-release form (w4_pick above): a forced tile is honoured (S2ST_GEMM_W4 >= 1 puts it on that form)
@@ -1214,7 +1244,7 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
     // (one instantiation per tile shape: the interleaved steady state, 8 waves for 128-row tiles; the round-2 A/B forms
     // -- plain loop, 4 waves, 2 / 3 / 5 ring stages, 64 x 128 -- were measured then and are no longer built)
     if (w4bn && g.splitk == 1) rc = s2st_gemm_bf16_w4(g, bm, bn, grid, st);
-    else if (bm == 256 && bn == 128) rc = launch_dma<256, 128, 3, 8>(g, grid, st);
+    else if (kExperimental && bm == 256 && bn == 128) { if constexpr (kExperimental) rc = launch_dma<256, 128, 3, 8>(g, grid, st); else rc = -1; }
     else if (bm == 128 && bn == 128) rc = launch_dma<128, 128, 4, 8, true>(g, grid, st);
     else if (bm == 128) rc = launch_dma<128, 64, 4, 8, true>(g, grid, st);
     else rc = launch_dma<64, 64, 4, 4, true>(g, grid, st);
@@ -1243,6 +1273,10 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
 // the tiled path forms; only the fp32 summation order over K differs.  Partial accumulators meet in LDS.
 // MFMA roles: a = weight rows (-> accumulator rows n), b = activation rows (-> accumulator columns m), i.e. lane l
 // holds y[m = l & 15][n0 + 4 (l >> 4) + r], the layout of gemm_epilogue above (float4 stores along n).
+// MT = row blocks of 16 (M <= 16 MT): round 4 decodes up to 64 utterances per step (the reference's generate_waveform
+// batches by --max-tokens 100000, run_baseline.sh:147), so a lane keeps MT accumulators and the weight fragment it
+// fetched is used MT times.  act: 0 none, 1 ReLU, 2 GELU, 3 logistic (the stop head: sigmoid fused, speech_generator_for_s2st.py:91).
+template <int MT>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restrict__ A, long lda,
                                                           const bf16_t* __restrict__ W, long ldw,
                                                           float* __restrict__ C, long ldc,
@@ -1250,105 +1284,148 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
                                                           uint64_t seed, const float* __restrict__ resid, long ldr,
                                                           int M, int N, int K, const float* __restrict__ ln_g,
                                                           const float* __restrict__ ln_b, float ln_eps) {
-  __shared__ __attribute__((aligned(16))) float part[3][64 * 4];
-  __shared__ float ln_mean[16], ln_rstd[16];
+  __shared__ __attribute__((aligned(16))) float part[3][MT * 64 * 4];
+  __shared__ float ln_mean[16 * MT], ln_rstd[16 * MT];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n0 = blockIdx.x * 16;
   const int kc = (lane >> 4) * 8;
   if (ln_g) {
     // fused LayerNorm of the activation rows (the decoder's pre-LN in front of a projection): every workgroup
-    // recomputes the 16 row statistics (32 KB of L2-resident input) instead of a separate kernel + round trip.
+    // recomputes the row statistics (L2-resident input) instead of a separate kernel + round trip.
     // 16 threads per row, two passes (mean, then squared deviations) like layernorm_fwd_kernel.
-    const int row = min(tid >> 4, M - 1), j = tid & 15;
-    const float* xr = A + (long)row * lda;
-    float s = 0.f;
-    for (int c = 4 * j; c < K; c += 64) {
-      const float4 v = *reinterpret_cast<const float4*>(xr + c);
-      s += v.x + v.y + v.z + v.w;
+    const int j = tid & 15;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = min(16 * mt + (tid >> 4), M - 1);
+      const float* xr = A + (long)row * lda;
+      float s = 0.f;
+      for (int c = 4 * j; c < K; c += 64) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + c);
+        s += v.x + v.y + v.z + v.w;
+      }
+      s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
+      const float mean = s / K;
+      float q = 0.f;
+      for (int c = 4 * j; c < K; c += 64) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + c);
+        const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
+        q += a * a + b * b + cc * cc + d * d;
+      }
+      q += __shfl_xor(q, 8); q += __shfl_xor(q, 4); q += __shfl_xor(q, 2); q += __shfl_xor(q, 1);
+      if (j == 0) { ln_mean[16 * mt + (tid >> 4)] = mean; ln_rstd[16 * mt + (tid >> 4)] = rsqrtf(q / K + ln_eps); }
     }
-    s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
-    const float mean = s / K;
-    float q = 0.f;
-    for (int c = 4 * j; c < K; c += 64) {
-      const float4 v = *reinterpret_cast<const float4*>(xr + c);
-      const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
-      q += a * a + b * b + cc * cc + d * d;
-    }
-    q += __shfl_xor(q, 8); q += __shfl_xor(q, 4); q += __shfl_xor(q, 2); q += __shfl_xor(q, 1);
-    if (j == 0) { ln_mean[tid >> 4] = mean; ln_rstd[tid >> 4] = rsqrtf(q / K + ln_eps); }
     __syncthreads();
   }
-  const float mu = ln_g ? ln_mean[lane & 15] : 0.f, rs = ln_g ? ln_rstd[lane & 15] : 1.f;
-  const float* arow = A + (long)min(lane & 15, M - 1) * lda + kc;
-  const bf16_t* wrow = W + (long)min(n0 + (lane & 15), N - 1) * ldw + kc;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const int steps = K >> 5;
-  for (int s0 = wave; s0 < steps; s0 += 16) {
-    float4 a0[4], a1[4];
-    uint4 w[4];
+  float mu[MT], rs[MT];
+  const float* arow[MT];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+  for (int mt = 0; mt < MT; ++mt) {
+    mu[mt] = ln_g ? ln_mean[16 * mt + (lane & 15)] : 0.f;
+    rs[mt] = ln_g ? ln_rstd[16 * mt + (lane & 15)] : 1.f;
+    arow[mt] = A + (long)min(16 * mt + (lane & 15), M - 1) * lda + kc;
+  }
+  const bf16_t* wrow = W + (long)min(n0 + (lane & 15), N - 1) * ldw + kc;
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int steps = K >> 5;
+  constexpr int U = MT == 1 ? 4 : 2;  // K-steps in flight per wave and pass (registers: 2 float4 per row block and step)
+  for (int s0 = wave; s0 < steps; s0 += 4 * U) {
+    float4 a0[U][MT], a1[U][MT];
+    uint4 w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
       const int s = min(s0 + 4 * u, steps - 1);  // clamped: loads stay unconditional (issued back to back)
-      a0[u] = *reinterpret_cast<const float4*>(arow + 32 * s);
-      a1[u] = *reinterpret_cast<const float4*>(arow + 32 * s + 4);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        a0[u][mt] = *reinterpret_cast<const float4*>(arow[mt] + 32 * s);
+        a1[u][mt] = *reinterpret_cast<const float4*>(arow[mt] + 32 * s + 4);
+      }
       w[u] = *reinterpret_cast<const uint4*>(wrow + 32 * s);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       if (s0 + 4 * u >= steps) break;
       union { uint4 q; bf16x8 v; } xa, wb;
+      wb.q = w[u];
+      float4 g0, g1, b0, b1;
       if (ln_g) {
         const int k = 32 * (s0 + 4 * u) + kc;
-        const float4 g0 = *reinterpret_cast<const float4*>(ln_g + k), g1 = *reinterpret_cast<const float4*>(ln_g + k + 4);
-        const float4 b0 = *reinterpret_cast<const float4*>(ln_b + k), b1 = *reinterpret_cast<const float4*>(ln_b + k + 4);
-        a0[u].x = (a0[u].x - mu) * rs * g0.x + b0.x; a0[u].y = (a0[u].y - mu) * rs * g0.y + b0.y;
-        a0[u].z = (a0[u].z - mu) * rs * g0.z + b0.z; a0[u].w = (a0[u].w - mu) * rs * g0.w + b0.w;
-        a1[u].x = (a1[u].x - mu) * rs * g1.x + b1.x; a1[u].y = (a1[u].y - mu) * rs * g1.y + b1.y;
-        a1[u].z = (a1[u].z - mu) * rs * g1.z + b1.z; a1[u].w = (a1[u].w - mu) * rs * g1.w + b1.w;
+        g0 = *reinterpret_cast<const float4*>(ln_g + k); g1 = *reinterpret_cast<const float4*>(ln_g + k + 4);
+        b0 = *reinterpret_cast<const float4*>(ln_b + k); b1 = *reinterpret_cast<const float4*>(ln_b + k + 4);
       }
-      const uint2 lo = pack_bf16x4(a0[u].x, a0[u].y, a0[u].z, a0[u].w), hi = pack_bf16x4(a1[u].x, a1[u].y, a1[u].z, a1[u].w);
-      xa.q = make_uint4(lo.x, lo.y, hi.x, hi.y);
-      wb.q = w[u];
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb.v, xa.v, acc, 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        float4 p0 = a0[u][mt], p1 = a1[u][mt];
+        if (ln_g) {
+          const float m_ = mu[mt], r_ = rs[mt];
+          p0.x = (p0.x - m_) * r_ * g0.x + b0.x; p0.y = (p0.y - m_) * r_ * g0.y + b0.y;
+          p0.z = (p0.z - m_) * r_ * g0.z + b0.z; p0.w = (p0.w - m_) * r_ * g0.w + b0.w;
+          p1.x = (p1.x - m_) * r_ * g1.x + b1.x; p1.y = (p1.y - m_) * r_ * g1.y + b1.y;
+          p1.z = (p1.z - m_) * r_ * g1.z + b1.z; p1.w = (p1.w - m_) * r_ * g1.w + b1.w;
+        }
+        const uint2 lo = pack_bf16x4(p0.x, p0.y, p0.z, p0.w), hi = pack_bf16x4(p1.x, p1.y, p1.z, p1.w);
+        xa.q = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb.v, xa.v, acc[mt], 0, 0, 0);
+      }
     }
   }
-  if (wave > 0) *reinterpret_cast<f32x4*>(&part[wave - 1][lane * 4]) = acc;
+  if (wave > 0) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4*>(&part[wave - 1][(mt * 64 + lane) * 4]) = acc[mt];
+  }
   __syncthreads();
   if (wave > 0) return;
-#pragma unroll
-  for (int w = 0; w < 3; ++w) {
-    const f32x4 p = *reinterpret_cast<const f32x4*>(&part[w][lane * 4]);
-    acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2]; acc[3] += p[3];
-  }
-  const int m = lane & 15, n = n0 + (lane >> 4) * 4;
-  if (m >= M || n >= N) return;
+  const int n = n0 + (lane >> 4) * 4;
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  float v[4] = {acc[0], acc[1], acc[2], acc[3]};
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    if (n + r >= N) break;
-    float x = v[r];
-    if (bias) x += bias[n + r];
-    if (act == 1) x = fmaxf(x, 0.f);
-    else if (act == 2) x = gelu_erf(x);
-    if (drop_p > 0.f) x *= drop_scale(seed, (uint64_t)m * (uint64_t)N + n + r, drop_p, inv_keep);
-    if (resid) x += resid[(long)m * ldr + n + r];
-    C[(long)m * ldc + n + r] = x;
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+      const f32x4 p = *reinterpret_cast<const f32x4*>(&part[w][(mt * 64 + lane) * 4]);
+      acc[mt][0] += p[0]; acc[mt][1] += p[1]; acc[mt][2] += p[2]; acc[mt][3] += p[3];
+    }
+    const int m = 16 * mt + (lane & 15);
+    if (m >= M || n >= N) continue;
+    float v[4] = {acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (n + r >= N) break;
+      float x = v[r];
+      if (bias) x += bias[n + r];
+      if (act == 1) x = fmaxf(x, 0.f);
+      else if (act == 2) x = gelu_erf(x);
+      else if (act == 3) x = 1.f / (1.f + __expf(-x));
+      if (drop_p > 0.f) x *= drop_scale(seed, (uint64_t)m * (uint64_t)N + n + r, drop_p, inv_keep);
+      if (resid) x += resid[(long)m * ldr + n + r];
+      C[(long)m * ldc + n + r] = x;
+    }
   }
 }
 
-// A fp32 [M][K] (row stride lda), W bf16 [N][K] (row stride ldw): M <= 16, K % 32 == 0, 16-byte aligned rows
+// A fp32 [M][K] (row stride lda), W bf16 [N][K] (row stride ldw): M <= 64, K % 32 == 0, 16-byte aligned rows
 // ln_g / ln_b (optional, K floats each): y = f(LayerNorm(x) W^T + b) -- the normalisation is applied to the rows
-// while they are converted (K % 64 == 0 then)
+// while they are converted (K % 64 == 0 then).  resid rows may all be the same one (ldr = 0: a positional row).
 int s2st_gemm_skinny(const float* A, long lda, const bf16raw* W, long ldw, float* C, long ldc, const float* bias, int act,
                      float drop_p, uint64_t seed, const float* resid, long ldr, int M, int N, int K, hipStream_t st,
                      const float* ln_g, const float* ln_b, float ln_eps) {
   if (M <= 0 || N <= 0) return 0;
-  if (M > 16 || K <= 0 || K % 32 || lda % 4 || ldw % 8 || ((uintptr_t)A % 16) || ((uintptr_t)W % 16)) return S2ST_ERR_SHAPE;
+  if (M > 64 || K <= 0 || K % 32 || lda % 4 || ldw % 8 || ((uintptr_t)A % 16) || ((uintptr_t)W % 16)) return S2ST_ERR_SHAPE;
   if (ln_g && (!ln_b || K % 64 || ((uintptr_t)ln_g % 16) || ((uintptr_t)ln_b % 16))) return S2ST_ERR_SHAPE;
   // bytes the launch has to move: the bf16 weight rows once, the fp32 activation rows, the result (+ residual)
   const double by = 2.0 * N * K + 4.0 * M * K + 4.0 * M * N * (resid ? 2 : 1);
-  s2st_launch("gemm_skinny_kernel", by, 2.0 * M * N * (double)K, gemm_skinny_kernel, dim3((N + 15) / 16), dim3(256), 0, st, A, lda,
-              reinterpret_cast<const bf16_t*>(W), ldw, C, ldc, bias, act, drop_p, seed, resid, ldr, M, N, K, ln_g, ln_b, ln_eps);
+  const double fl = 2.0 * M * N * (double)K;
+  const dim3 grid((N + 15) / 16), block(256);
+  const bf16_t* Wp = reinterpret_cast<const bf16_t*>(W);
+  const int mt = (M + 15) / 16;
+  if (mt == 1)
+    s2st_launch("gemm_skinny_kernel", by, fl, gemm_skinny_kernel<1>, grid, block, 0, st, A, lda, Wp, ldw, C, ldc, bias, act, drop_p,
+                seed, resid, ldr, M, N, K, ln_g, ln_b, ln_eps);
+  else if (mt == 2)
+    s2st_launch("gemm_skinny_kernel", by, fl, gemm_skinny_kernel<2>, grid, block, 0, st, A, lda, Wp, ldw, C, ldc, bias, act, drop_p,
+                seed, resid, ldr, M, N, K, ln_g, ln_b, ln_eps);
+  else
+    s2st_launch("gemm_skinny_kernel", by, fl, gemm_skinny_kernel<4>, grid, block, 0, st, A, lda, Wp, ldw, C, ldc, bias, act, drop_p,
+                seed, resid, ldr, M, N, K, ln_g, ln_b, ln_eps);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }

@@ -30,11 +30,15 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 // one query per (b, h): o[b][h*dh + d] = sum_s softmax_s(scale q.k_s) v_s[d]; optional
 // attn_mean[b][s] += p_s / H (zero-initialised by the launcher)
+// k_new / v_new (self-attention of a decoding step): the step's key / value rows [B][ld_new]; the workgroup first stores its
+// (b, h) slice as row pos_new of the caches (no other workgroup reads or writes that slice), then attends over the cache
 __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restrict__ q, long ldq,
-                                                          const float* __restrict__ kc, const float* __restrict__ vc,
+                                                          float* __restrict__ kc, float* __restrict__ vc,
                                                           long ldk, long kbs, const int* __restrict__ klen, int nkeys,
                                                           int H, int dh, float scale, float* __restrict__ o, long ldo,
-                                                          float* __restrict__ attn_mean, int S) {
+                                                          float* __restrict__ attn_mean, int S,
+                                                          const float* __restrict__ k_new, const float* __restrict__ v_new,
+                                                          long ld_new, int pos_new) {
   __shared__ float p[DA_MAXS];
   __shared__ __attribute__((aligned(16))) float qs[256];
   __shared__ float red[4];
@@ -42,7 +46,11 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
   const int b = blockIdx.x / H, h = blockIdx.x - b * H, tid = threadIdx.x;
   const int n = klen ? min((int)klen[b], nkeys) : nkeys;
   if (tid < dh) qs[tid] = q[(long)b * ldq + h * dh + tid] * scale;
-  __syncthreads();
+  if (k_new && tid < dh) {
+    kc[(long)b * kbs + (long)pos_new * ldk + h * dh + tid] = k_new[(long)b * ld_new + h * dh + tid];
+    vc[(long)b * kbs + (long)pos_new * ldk + h * dh + tid] = v_new[(long)b * ld_new + h * dh + tid];
+  }
+  __syncthreads();  // (workgroup-scope: the stores above are visible to this workgroup's loads below)
   const float* kb = kc + (long)b * kbs + h * dh;
   const float* vb = vc + (long)b * kbs + h * dh;
   // 16 lanes per key, one float4 each: a 64-wide head row is one coalesced 256-byte read; 16 keys per pass
@@ -271,6 +279,208 @@ __global__ __launch_bounds__(256) void gl_overlap_add_b_kernel(const float* __re
   wave[i] = out;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Griffin-Lim with FFTs (round 4).  The reference's STFT / inverse STFT are dense Fourier-basis convolutions
+// (audio_utils.py:226-271: basis = [Re; Im] of fft(eye(n_fft)) * window; vocoder.py:56-98: pinverse(n_fft / hop * basis)):
+//   * the analysis is exactly rfft(window * frame);
+//   * the synthesis basis pinverse(s B)^T equals the plain inverse real FFT / s: B^T B = (N/2) I + E with E[n][m] = 1 for
+//     n - m even, whose inverse turns B^T X = Re sum_{k <= N/2} X_k W^{kn} into (1/N) [X_0 + X_{N/2} (-1)^n + 2 sum_{0<k<N/2}
+//     Re X_k W^{kn}] (imaginary parts of the DC and Nyquist bins dropped) -- checked numerically against numpy's pinv to 1e-16.
+// So both directions are N-point real FFTs: O(N log N) per frame instead of the 2 N (N + 2) multiply-adds of the dense
+// contraction (x 3 in the bf16x3 GEMM form that rounds 1 - 3 used: 137 ms of the 237 ms one 16-utterance batch took).
+// One workgroup transforms TWO frames at once as the real and imaginary part of one complex N-point FFT (Stockham
+// autosort, radix 4 with a final radix 2 when log2 N is odd, in LDS: 8 N bytes + the twiddle table) and separates /
+// merges the two spectra through the Hermitian symmetry.  N = 256 ... 4096 (powers of two); other n_fft keep the GEMM path.
+// ------------------------------------------------------------------------------------------------
+struct cplx { float x, y; };
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return cplx{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return cplx{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return cplx{a.x - b.x, a.y - b.y}; }
+
+// in-place complex FFT of buf[0 .. N) (LDS), 256 threads; tw[j] = exp(-2 pi i j / N); INV: conjugate transform (unscaled)
+template <int N, bool INV>
+__device__ void fft_lds(cplx* buf, const cplx* tw, int tid) {
+  constexpr int Q = N / 4, PER4 = (Q + 255) / 256;
+  int Ns = 1;
+  for (; Ns * 4 <= N; Ns *= 4) {
+    cplx v[PER4][4];
+    const int tstride = N / (4 * Ns);
+#pragma unroll
+    for (int i = 0; i < PER4; ++i) {
+      const int j = tid + 256 * i;
+      if (j < Q) {
+        const int k = j & (Ns - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          cplx x = buf[j + r * Q];
+          if (r > 0 && k > 0) {
+            cplx w = tw[r * k * tstride];
+            if (INV) w.y = -w.y;
+            x = cmul(x, w);
+          }
+          v[i][r] = x;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER4; ++i) {
+      const int j = tid + 256 * i;
+      if (j < Q) {
+        const int k = j & (Ns - 1);
+        const cplx a0 = cadd(v[i][0], v[i][2]), a1 = csub(v[i][0], v[i][2]), a2 = cadd(v[i][1], v[i][3]);
+        const cplx d = csub(v[i][1], v[i][3]);
+        const cplx a3 = INV ? cplx{-d.y, d.x} : cplx{d.y, -d.x};  // (+-) i (v1 - v3)
+        const int j0 = ((j - k) << 2) + k;
+        buf[j0] = cadd(a0, a2);
+        buf[j0 + Ns] = cadd(a1, a3);
+        buf[j0 + 2 * Ns] = csub(a0, a2);
+        buf[j0 + 3 * Ns] = csub(a1, a3);
+      }
+    }
+    __syncthreads();
+  }
+  if (Ns < N) {  // one radix-2 stage left (log2 N odd): Ns = N / 2
+    constexpr int H = N / 2, PER2 = (H + 255) / 256;
+    cplx v0[PER2], v1[PER2];
+#pragma unroll
+    for (int i = 0; i < PER2; ++i) {
+      const int j = tid + 256 * i;
+      if (j < H) {
+        cplx w = tw[j];
+        if (INV) w.y = -w.y;
+        v0[i] = buf[j];
+        v1[i] = cmul(buf[j + H], w);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER2; ++i) {
+      const int j = tid + 256 * i;
+      if (j < H) {
+        buf[j] = cadd(v0[i], v1[i]);
+        buf[j + H] = csub(v0[i], v1[i]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// STFT of the reflect-padded waveforms + phase projection, per PAIR of frames (rows m0 = 2 * pair, m0 + 1 of the
+// flattened [U][Tmax] frame index): X[m][k] = mag[m][k] * Y_k / |Y_k| with Y = rfft(window * frame) -- the reference's
+// mag * (cos, sin)(atan2(Im Y, Re Y)) (audio_utils.py:259-271, vocoder.py:104-107; |Y| = 0: angle 0).  Rows t >= T_u: zeros.
+template <int N>
+__global__ __launch_bounds__(256) void gl_stft_project_kernel(const float* __restrict__ wave, const int* __restrict__ tl,
+                                                              const float* __restrict__ win, const cplx* __restrict__ twg,
+                                                              const float* __restrict__ mag, cplx* __restrict__ X, int U,
+                                                              int Tmax, int hop, int Lw, long npairs) {
+  __shared__ cplx buf[N];
+  __shared__ cplx tw[N];
+  const int tid = threadIdx.x;
+  constexpr int F = N / 2 + 1;
+  for (int j = tid; j < N; j += 256) tw[j] = twg[j];
+  for (long pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+    const long m0 = 2 * pair, M = (long)U * Tmax;
+    int tt[2], uu[2], TT[2];
+    bool on[2];
+    for (int h = 0; h < 2; ++h) {
+      const long m = m0 + h;
+      uu[h] = m < M ? (int)(m / Tmax) : 0;
+      tt[h] = m < M ? (int)(m - (long)uu[h] * Tmax) : 0;
+      TT[h] = tl[uu[h]];
+      on[h] = m < M && tt[h] < TT[h] && hop * (TT[h] - 1) > N / 2;
+    }
+    __syncthreads();  // (the previous pair's readers are done with buf)
+    for (int n = tid; n < N; n += 256) {
+      float v[2] = {0.f, 0.f};
+      for (int h = 0; h < 2; ++h) {
+        if (!on[h]) continue;
+        const int len = hop * (TT[h] - 1);
+        int j = tt[h] * hop + n - N / 2;
+        if (j < 0) j = -j;
+        if (j >= len) j = 2 * (len - 1) - j;
+        v[h] = wave[(long)uu[h] * Lw + j] * win[n];
+      }
+      buf[n] = cplx{v[0], v[1]};
+    }
+    __syncthreads();
+    fft_lds<N, false>(buf, tw, tid);
+    for (int k = tid; k < F; k += 256) {
+      const cplx zk = buf[k], zn = buf[(N - k) & (N - 1)];
+      // Y1 = (Z_k + conj Z_{N-k}) / 2 ; Y2 = (Z_k - conj Z_{N-k}) / (2 i)
+      const cplx y[2] = {cplx{0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)}, cplx{0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x)}};
+      for (int h = 0; h < 2; ++h) {
+        const long m = m0 + h;
+        if (m >= M) continue;
+        cplx o{0.f, 0.f};
+        if (on[h]) {
+          const float mg = mag[m * F + k];
+          const float a2 = y[h].x * y[h].x + y[h].y * y[h].y;
+          if (a2 > 0.f) {
+            const float r = mg * rsqrtf(a2);
+            o = cplx{y[h].x * r, y[h].y * r};
+          } else {
+            o = cplx{mg, 0.f};
+          }
+        }
+        X[m * F + k] = o;
+      }
+    }
+  }
+}
+
+// inverse: frames[m][n] = window[n] * (hop / N) * irfft(X[m])[n] for the two rows of a pair (rows t >= T_u: zeros);
+// the overlap-add kernel above turns the frames into the waveforms
+template <int N>
+__global__ __launch_bounds__(256) void gl_istft_frames_kernel(const cplx* __restrict__ X, const int* __restrict__ tl,
+                                                              const float* __restrict__ win, const cplx* __restrict__ twg,
+                                                              float* __restrict__ frames, int U, int Tmax, int hop, long npairs) {
+  __shared__ cplx buf[N];
+  __shared__ cplx tw[N];
+  const int tid = threadIdx.x;
+  constexpr int F = N / 2 + 1;
+  for (int j = tid; j < N; j += 256) tw[j] = twg[j];
+  const float sc = (float)hop / ((float)N * (float)N);
+  for (long pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+    const long m0 = 2 * pair, M = (long)U * Tmax;
+    bool on[2];
+    for (int h = 0; h < 2; ++h) {
+      const long m = m0 + h;
+      const int u = m < M ? (int)(m / Tmax) : 0, t = m < M ? (int)(m - (long)u * Tmax) : 0;
+      on[h] = m < M && t < tl[u];
+    }
+    __syncthreads();
+    for (int k = tid; k < F; k += 256) {
+      cplx a = on[0] ? X[m0 * F + k] : cplx{0.f, 0.f}, b = on[1] ? X[(m0 + 1) * F + k] : cplx{0.f, 0.f};
+      if (k == 0 || k == N / 2) a.y = b.y = 0.f;  // (the basis' sine rows of DC / Nyquist are zero)
+      buf[k] = cplx{a.x - b.y, a.y + b.x};                       // Z_k     = X1_k + i X2_k
+      if (k > 0 && k < N / 2) buf[N - k] = cplx{a.x + b.y, b.x - a.y};  // Z_{N-k} = conj X1_k + i conj X2_k
+    }
+    __syncthreads();
+    fft_lds<N, true>(buf, tw, tid);
+    for (int n = tid; n < N; n += 256) {
+      const float w = win[n] * sc;
+      if (m0 < M) frames[m0 * N + n] = on[0] ? buf[n].x * w : 0.f;
+      if (m0 + 1 < M) frames[(m0 + 1) * N + n] = on[1] ? buf[n].y * w : 0.f;
+    }
+  }
+}
+
+// X[m][k] = mag[m][k] * (cos, sin)(ang[m][k]) (the initial phases, vocoder.py:101-103); rows t >= T_u: zeros
+__global__ __launch_bounds__(256) void gl_polar_c_kernel(const float* __restrict__ mag, const float* __restrict__ ang,
+                                                         const int* __restrict__ tl, cplx* __restrict__ X, int U, int F, int Tmax) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)U * Tmax * F) return;
+  const long row = i / F;
+  const int t = (int)(row % Tmax), u = (int)(row / Tmax);
+  cplx o{0.f, 0.f};
+  if (t < tl[u]) {
+    const float m = mag[i], a = ang[i];
+    o = cplx{m * cosf(a), m * sinf(a)};
+  }
+  X[i] = o;
+}
+
 // reflect-pad a waveform by `pad` on both sides: y[i] = x[reflect(i - pad)]
 __global__ __launch_bounds__(256) void reflect_pad_kernel(const float* __restrict__ x, float* __restrict__ y, int n,
                                                           int pad) {
@@ -303,14 +513,30 @@ __global__ __launch_bounds__(256) void gl_overlap_add_kernel(const float* __rest
 
 }  // namespace
 
-int s2st_decode_attn(const float* q, long ldq, const float* kc, const float* vc, long ldk, long kbs, const int* klen,
+int s2st_decode_attn(const float* q, long ldq, float* kc, float* vc, long ldk, long kbs, const int* klen,
                      int nkeys, int B, int H, int dh, float scale, float* o, long ldo, float* attn_mean, int S,
-                     hipStream_t st) {
+                     hipStream_t st, const float* k_new, const float* v_new, long ld_new, int pos_new) {
   if (B <= 0) return 0;
   if (nkeys > DA_MAXS || dh > 256 || dh % 4 || 256 % dh) return S2ST_ERR_SHAPE;
+  if ((k_new != nullptr) != (v_new != nullptr) || (k_new && (pos_new < 0 || pos_new >= nkeys))) return S2ST_ERR_ARG;
   if (attn_mean) hipMemsetAsync(attn_mean, 0, sizeof(float) * (size_t)B * S, st);
   S2ST_LAUNCH(decode_attn_kernel, dim3(B * H), dim3(256), 0, st, q, ldq, kc, vc, ldk, kbs, klen, nkeys, H, dh,
-                     scale, o, ldo, attn_mean, S);
+                     scale, o, ldo, attn_mean, S, k_new, v_new, ld_new, pos_new);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                                         float* __restrict__ y, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = a[0] * x[i];
+}
+}  // namespace
+
+// y = a[0] * x (a: one device scalar): the alpha-scaled position table of a decoding run
+int s2st_scale_rows(const float* x, const float* a, float* y, long n, hipStream_t st) {
+  if (n <= 0) return 0;
+  S2ST_LAUNCH(scale_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, a, y, n);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
@@ -405,4 +631,58 @@ int s2st_gl_overlap_add_b(const float* frames, const float* wsq_all, const long*
   S2ST_LAUNCH(gl_overlap_add_b_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, frames, wsq_all,
                      wsq_off, tl, wave, U, Tmax, n_fft, hop, Lw, 1.1754944e-38f);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+
+// ---- FFT-based Griffin-Lim launchers (n_fft a power of two in 256 ... 4096) ------------------------------------------
+bool s2st_gl_fft_supported(int n_fft) { return n_fft == 256 || n_fft == 512 || n_fft == 1024 || n_fft == 2048 || n_fft == 4096; }
+
+int s2st_gl_polar_c(const float* mag, const float* ang, const int* tl, float* X, int U, int F, int Tmax, hipStream_t st) {
+  const long n = (long)U * Tmax * F;
+  if (n <= 0) return 0;
+  S2ST_LAUNCH(gl_polar_c_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mag, ang, tl, reinterpret_cast<cplx*>(X), U, F, Tmax);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+
+namespace {
+template <int N>
+int gl_fft_launch(int inverse, const float* wave_or_frames, const int* tl, const float* win, const float* tw, const float* mag,
+                  float* X, float* frames, int U, int Tmax, int hop, int Lw, hipStream_t st) {
+  const long npairs = ((long)U * Tmax + 1) / 2;
+  if (npairs <= 0) return 0;
+  // (4 k workgroups at most: a workgroup keeps its twiddle table over the pairs it walks)
+  const unsigned grid = (unsigned)(npairs < 4096 ? npairs : 4096);
+  if (!inverse)
+    S2ST_LAUNCH(gl_stft_project_kernel<N>, dim3(grid), dim3(256), 0, st, wave_or_frames, tl, win, reinterpret_cast<const cplx*>(tw),
+                mag, reinterpret_cast<cplx*>(X), U, Tmax, hop, Lw, npairs);
+  else
+    S2ST_LAUNCH(gl_istft_frames_kernel<N>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const cplx*>(X), tl, win,
+                reinterpret_cast<const cplx*>(tw), frames, U, Tmax, hop, npairs);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+}  // namespace
+
+// wave [U][Lw] -> X [U * Tmax][n_fft / 2 + 1] complex (re, im interleaved), projected onto the magnitudes mag [U * Tmax][F]
+int s2st_gl_stft_project(const float* wave, const int* tl, const float* win, const float* tw, const float* mag, float* X, int U,
+                         int Tmax, int n_fft, int hop, int Lw, hipStream_t st) {
+  switch (n_fft) {
+    case 256: return gl_fft_launch<256>(0, wave, tl, win, tw, mag, X, nullptr, U, Tmax, hop, Lw, st);
+    case 512: return gl_fft_launch<512>(0, wave, tl, win, tw, mag, X, nullptr, U, Tmax, hop, Lw, st);
+    case 1024: return gl_fft_launch<1024>(0, wave, tl, win, tw, mag, X, nullptr, U, Tmax, hop, Lw, st);
+    case 2048: return gl_fft_launch<2048>(0, wave, tl, win, tw, mag, X, nullptr, U, Tmax, hop, Lw, st);
+    case 4096: return gl_fft_launch<4096>(0, wave, tl, win, tw, mag, X, nullptr, U, Tmax, hop, Lw, st);
+  }
+  return S2ST_ERR_SHAPE;
+}
+
+// X [U * Tmax][F] complex -> frames [U * Tmax][n_fft] (windowed synthesis frames; s2st_gl_overlap_add_b finishes)
+int s2st_gl_istft_frames(const float* X, const int* tl, const float* win, const float* tw, float* frames, int U, int Tmax,
+                         int n_fft, int hop, hipStream_t st) {
+  switch (n_fft) {
+    case 256: return gl_fft_launch<256>(1, nullptr, tl, win, tw, nullptr, const_cast<float*>(X), frames, U, Tmax, hop, 0, st);
+    case 512: return gl_fft_launch<512>(1, nullptr, tl, win, tw, nullptr, const_cast<float*>(X), frames, U, Tmax, hop, 0, st);
+    case 1024: return gl_fft_launch<1024>(1, nullptr, tl, win, tw, nullptr, const_cast<float*>(X), frames, U, Tmax, hop, 0, st);
+    case 2048: return gl_fft_launch<2048>(1, nullptr, tl, win, tw, nullptr, const_cast<float*>(X), frames, U, Tmax, hop, 0, st);
+    case 4096: return gl_fft_launch<4096>(1, nullptr, tl, win, tw, nullptr, const_cast<float*>(X), frames, U, Tmax, hop, 0, st);
+  }
+  return S2ST_ERR_SHAPE;
 }

@@ -67,13 +67,20 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + er
 // 64-bit finalizer: three 64 x 64 multiplies = ~12 quarter-rate v_mul per element, which clock stamps showed to be the
 // largest single cost of the attention kernels (8 elements per lane and key tile: ~1.6 k of the ~3.8 k cycles a wave
 // spent per tile) and of every GEMM epilogue with dropout (64 elements per lane of a 128 x 128 tile).
+// Round 4: the seed is whitened first (one 64-bit multiply + xor-shift on a wave-uniform value: scalar instructions, hoisted
+// out of the element loops), so that BOTH words the rounds consume depend on every bit of the seed.  Without it two seeds
+// that differ only in their low word gave XOR-permuted copies of one mask (mask_s'(i) = mask_s(i ^ (s ^ s')): found by
+// tests/test_ops.py::test_dropout_mask_independence, phi = 0.5 at lag 1 for seed + 1); the engine's own site seeds always
+// differ in both words, so no training run was affected.
 __device__ __forceinline__ uint32_t mix32(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed * 0x9E3779B97F4A7C15ull;
+  z ^= z >> 32;
   const uint32_t hi = (uint32_t)(idx >> 32);
-  uint32_t h = (uint32_t)idx ^ (uint32_t)seed ^ ((hi << 16) | (hi >> 16));
+  uint32_t h = (uint32_t)idx ^ (uint32_t)z ^ ((hi << 16) | (hi >> 16));
   h ^= h >> 16;
   h *= 0x7feb352du;
   h ^= h >> 15;
-  h ^= (uint32_t)(seed >> 32);
+  h ^= (uint32_t)(z >> 32);
   h *= 0x846ca68bu;
   h ^= h >> 16;
   return h;

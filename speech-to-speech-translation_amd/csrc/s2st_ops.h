@@ -269,9 +269,11 @@ int s2st_posconv_prep(float* x, const int* lens, float* img, uint16_t* imgh, int
 // ---------------------------------------------------------------------------------------
 // inference (infer.hip): incremental-decoding attention, stop / alignment / de-CMVN helpers, Griffin-Lim
 // ---------------------------------------------------------------------------------------
-int s2st_decode_attn(const float* q, long ldq, const float* kc, const float* vc, long ldk, long kbs, const int* klen,
+int s2st_decode_attn(const float* q, long ldq, float* kc, float* vc, long ldk, long kbs, const int* klen,
                      int nkeys, int B, int H, int dh, float scale, float* o, long ldo, float* attn_mean, int S,
-                     hipStream_t st);
+                     hipStream_t st, const float* k_new = nullptr, const float* v_new = nullptr, long ld_new = 0,
+                     int pos_new = 0);
+int s2st_scale_rows(const float* x, const float* a, float* y, long n, hipStream_t st);
 int s2st_sigmoid(const float* x, float* y, long n, hipStream_t st);
 int s2st_argmax_dim1(const float* x, long* idx, int B, int E, int D, hipStream_t st);
 int s2st_affine_cols(const float* x, const float* scale, const float* shift, float* y, long rows, int C, hipStream_t st);
@@ -286,6 +288,14 @@ int s2st_gl_frame_split(const float* wave, const int* tl, uint16_t* As, int U, i
                         hipStream_t st);
 int s2st_gl_overlap_add_b(const float* frames, const float* wsq_all, const long* wsq_off, const int* tl, float* wave,
                           int U, int Tmax, int n_fft, int hop, int Lw, hipStream_t st);
+// FFT-based Griffin-Lim (infer.hip): n_fft a power of two in 256 ... 4096; X is complex [U * Tmax][n_fft / 2 + 1] (re, im
+// interleaved); win [n_fft]; tw [n_fft] complex = exp(-2 pi i j / n_fft)
+bool s2st_gl_fft_supported(int n_fft);
+int s2st_gl_polar_c(const float* mag, const float* ang, const int* tl, float* X, int U, int F, int Tmax, hipStream_t st);
+int s2st_gl_stft_project(const float* wave, const int* tl, const float* win, const float* tw, const float* mag, float* X, int U,
+                         int Tmax, int n_fft, int hop, int Lw, hipStream_t st);
+int s2st_gl_istft_frames(const float* X, const int* tl, const float* win, const float* tw, float* frames, int U, int Tmax,
+                         int n_fft, int hop, hipStream_t st);
 int s2st_gl_overlap_add(const float* frames, const float* wsq, float* wave, int T, int n_fft, int hop, int n_out,
                         hipStream_t st);
 

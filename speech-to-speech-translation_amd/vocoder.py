@@ -2,10 +2,12 @@
 ``fairseq/models/text_to_speech/vocoder.py:24-158`` (PseudoInverseMelScale, GriffinLim,
 GriffinLimVocoder) with the same constructor arguments.
 
-Like the reference, the STFT / inverse STFT are dense-DFT contractions (the reference uses conv1d /
-conv_transpose1d with Fourier bases, audio_utils.py:259-271, vocoder.py:56-98): here they are GEMMs on
-the matrix cores (bf16x3 "precise" mode: phase retrieval is precision-sensitive) around small HIP
-kernels for polar <-> rectangular conversion, reflect padding and overlap-add.  The constant tables
+The reference's STFT / inverse STFT are dense-DFT contractions (conv1d / conv_transpose1d with Fourier bases,
+audio_utils.py:259-271, vocoder.py:56-98).  Round 4: for power-of-two n_fft (256 ... 4096) they run as real FFTs in LDS
+(csrc/infer.hip: the analysis basis is rfft(window * frame), the pseudo-inverse synthesis basis is window * hop / n_fft *
+irfft -- exactly); other n_fft (and S2ST_GL_FFT=0) keep the dense form of rounds 1 - 3: GEMMs on the matrix cores (bf16x3
+"precise" mode: phase retrieval is precision-sensitive) around small HIP kernels for polar <-> rectangular conversion,
+reflect padding and overlap-add.  The constant tables
 (window, Fourier bases and their pseudo-inverses, mel filterbank pseudo-inverse) are built once on
 the host at construction, as the reference does in its ``register_buffer`` calls.
 
@@ -70,14 +72,40 @@ class GriffinLim:
         self.n_fft, self.win_length, self.hop_length, self.n_iter, self.device = n_fft, win_length, hop_length, n_iter, device
         win = get_window(n_fft, win_length, window_fn)
         self.F = n_fft // 2 + 1
-        # forward basis [2F][n_fft] (TTSSpectrogram) and inverse basis [2F][n_fft] (GriffinLim.__init__)
-        self.fwd = (get_fourier_basis(n_fft) * win).contiguous().to(device)
-        inv = torch.pinverse(n_fft / hop_length * get_fourier_basis(n_fft)).T * win
-        self.inv_t = inv.t().contiguous().to(device)  # [n_fft][2F]: rows-of-output x K layout for the GEMM
+        self._dense = None  # the dense bases of the GEMM path: built on first use (a 2050 x 2048 pseudo-inverse at n_fft 2048)
         self.win_sq = win ** 2
         self._wss = {}
         self.Fp = (self.F + 15) // 16 * 16
         self._bb = None
+        self._win = win
+        self._ft = None
+        # FFT path for power-of-two n_fft (S2ST_GL_FFT=0: the dense-basis GEMMs of rounds 1 - 3, an A/B switch)
+        import os
+        fn = bd.lib().s2st_gl_fft_supported_i32
+        self.use_fft = bool(fn(int(n_fft))) and os.environ.get("S2ST_GL_FFT", "1") != "0"
+
+    @property
+    def fwd(self):
+        return self._dense_bases()[0]
+
+    @property
+    def inv_t(self):
+        return self._dense_bases()[1]
+
+    def _dense_bases(self):
+        """forward basis [2F][n_fft] (TTSSpectrogram) and inverse basis [n_fft][2F] (GriffinLim.__init__: pinverse)."""
+        if self._dense is None:
+            fwd = (get_fourier_basis(self.n_fft) * self._win).contiguous().to(self.device)
+            inv = torch.pinverse(self.n_fft / self.hop_length * get_fourier_basis(self.n_fft)).T * self._win
+            self._dense = (fwd, inv.t().contiguous().to(self.device))
+        return self._dense
+
+    def _fft_tables(self):
+        if self._ft is None:
+            j = np.arange(self.n_fft, dtype=np.float64)
+            tw = np.stack([np.cos(2 * np.pi * j / self.n_fft), -np.sin(2 * np.pi * j / self.n_fft)], axis=1).astype(np.float32)
+            self._ft = (self._win.to(self.device, torch.float32).contiguous(), torch.from_numpy(tw).contiguous().to(self.device))
+        return self._ft
 
     def _window_sum_square(self, n_frames: int) -> torch.Tensor:
         w = self._wss.get(n_frames)
@@ -115,6 +143,8 @@ class GriffinLim:
         assert Fq == self.F
         if angles is None:
             angles = random_phases(Fq, T)
+        if self.use_fft:
+            return self.batch([specgram], [angles])[0]
         mag = specgram.to(self.device, torch.float32).contiguous()
         ang = torch.from_numpy(np.ascontiguousarray(angles, dtype=np.float32)).to(self.device)
         X = torch.empty(T, 2 * Fq, device=self.device)
@@ -179,8 +209,27 @@ class GriffinLim:
             o += w.numel()
         wsq_all = torch.cat(tabs)
         wsq_off = torch.tensor(offs, dtype=torch.int64).to(dev)
-        fwd3, inv3 = self._bases_bf16()
         M, Lw = U * Tmax, hop * (Tmax - 1)
+        if self.use_fft:
+            # round 4: both transforms as N-point real FFTs in LDS (csrc/infer.hip: the reference's analysis basis IS
+            # rfft(window * frame), its pseudo-inverse synthesis basis IS window * hop / n_fft * irfft): three launches per
+            # iteration, O(N log N) per frame instead of the dense contraction's 2 N (N + 2) multiply-adds x 3 (bf16x3)
+            win, tw = self._fft_tables()
+            Xc = torch.empty(M, Fq, 2, device=dev)
+            frames = torch.empty(M, n_fft, device=dev)
+            wave = torch.empty(U, max(Lw, 1), device=dev)
+
+            def inverse_fft():
+                bd.call("s2st_gl_istft_frames_f32", Xc, tl, win, tw, frames, U, Tmax, n_fft, hop)
+                bd.call("s2st_gl_overlap_add_b_f32", frames, wsq_all, wsq_off, tl, wave, U, Tmax, n_fft, hop, Lw)
+
+            bd.call("s2st_gl_polar_c_f32", mag, ang, tl, Xc, U, Fq, Tmax)
+            inverse_fft()
+            for _ in range(self.n_iter):
+                bd.call("s2st_gl_stft_project_f32", wave, tl, win, tw, mag, Xc, U, Tmax, n_fft, hop, Lw)
+                inverse_fft()
+            return [wave[u, :hop * (Ts[u] - 1)].clone() for u in range(U)]
+        fwd3, inv3 = self._bases_bf16()
         Xs = torch.empty(M, 6 * Fp, dtype=torch.bfloat16, device=dev)
         As = torch.empty(M, 3 * n_fft, dtype=torch.bfloat16, device=dev)
         Y = torch.empty(M, 2 * Fp, device=dev)

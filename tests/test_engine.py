@@ -66,16 +66,28 @@ def gsub(x):
     return x.astype(np.float64) if x.size <= 4096 else x.reshape(-1)[::GRAD_STRIDE].astype(np.float64)
 
 
-def BF16_TENSOR_TOL(name):
-    """bf16-operand mode, base size, per-tensor Frobenius-relative gradient error against the reference.  Measured on
-    the 8-utterance base golden: 4.9e-2 for the worst tensor (first decoder layer's cross-attention projections, first
-    encoder layer's fc1) and 6.3e-2 for the first prenet layer at the very end of the longest backward path (decoder
-    stack -> prenet); bf16x3 mode: 4.3e-3 everywhere.  The bounds leave ~20 % head-room over the measured values (the
-    bias-gradient sums use atomics: a few 1e-3 of run-to-run spread on the small tensors)."""
-    return 8e-2 if name.startswith("decoder.prenet.0.layers.") else 6e-2
+def bf16_tensor_bounds(golden_dir, fname="s2st_base_autocast.npz"):
+    """Gradient-error bounds of the benchmarked bf16 mode at base size: not "what this path was measured
+    at plus head-room" but what the REFERENCE's own mixed precision does to the same gradients.
+    oracle/gen_golden_autocast.py runs the reference model + criterion on the golden batch under ``torch.autocast("cpu",
+    bfloat16)`` and records, per tensor, the same Frobenius-relative error against the fp32 golden that
+    check_gradient_direction computes (base batch: whole gradient 1.6e-2, worst tensors 8e-2 ... 1.1e-1, median 3.2e-2).
+    The HIP path keeps fp32 results, residual stream and softmax where autocast rounds to bf16, so it is held to 1.5 x the
+    reference-autocast figures:
+      * the whole gradient, the median and the maximum over the tensors: 1.5 x the autocast run's;
+      * every tensor: 1.5 x max(its own autocast error, the 90th percentile of the autocast errors).  A tensor's autocast
+        error is ONE realisation of rounding noise, not a constant of the tensor -- the same tensor (first decoder layer's
+        cross-attention k_proj.weight) measures 8.0e-2 on the base batch and 2.6e-2 on the HuBERT batch, while this path
+        measures 4.9e-2 / 5.7e-2 on the two -- so a tensor is allowed what autocast does to its typically-worst tensors;
+      * the floor is the bf16x3 (fp32-accurate) mode's own bound, 5e-3.
+    Returns (per-tensor bound, whole-gradient bound, the per-tensor autocast errors)."""
+    z = np.load(os.path.join(golden_dir, fname))
+    ac = dict(zip(z["names"].tolist(), z["err"].tolist()))
+    p90 = float(np.quantile(z["err"], 0.9))
+    return (lambda n: max(1.5 * max(ac[n], p90), 5e-3)), 1.5 * float(z["whole"]), ac
 
 
-def check_gradient_direction(named_grads, z, per_tensor_tol, whole_tol, tag=""):
+def check_gradient_direction(named_grads, z, per_tensor_tol, whole_tol, tag="", yardstick=None):
     """Every gradient tensor against the reference's sampled gradient (``gsub.<name>``): Frobenius-relative
     difference of the samples per tensor (a gradient with the right norm and the wrong direction fails), and of the
     concatenation of all samples.  The floor (1e-3 of the largest tensor norm, spread over the sample) covers
@@ -97,6 +109,15 @@ def check_gradient_direction(named_grads, z, per_tensor_tol, whole_tol, tag=""):
     whole = math.sqrt(num / den)
     print(f"[gradient direction {tag}] whole {whole:.2e}; worst tensors " +
           ", ".join(f"{n} {v:.2e}" for v, n in worst[:4]))
+    if yardstick is not None:  # error relative to the reference-autocast error of the same tensor
+        ratios = sorted(((v / max(yardstick[n], 1e-12), v, yardstick[n], n) for v, n in worst), reverse=True)
+        mine_v, ac_v = np.asarray([v for v, _ in worst]), np.asarray([yardstick[n] for _, n in worst])
+        print(f"[gradient direction {tag}] error / reference-autocast error: " +
+              ", ".join(f"{n} {r:.2f} ({v:.1e} vs {y:.1e})" for r, v, y, n in ratios[:6]) +
+              f"; median ratio {ratios[len(ratios) // 2][0]:.2f}; median {np.median(mine_v):.2e} vs {np.median(ac_v):.2e}, "
+              f"max {mine_v.max():.2e} vs {ac_v.max():.2e}")
+        assert np.median(mine_v) <= 1.5 * np.median(ac_v), (tag, "median tensor error vs reference autocast")
+        assert mine_v.max() <= 1.5 * ac_v.max(), (tag, "worst tensor error vs reference autocast")
     tol_of = per_tensor_tol if callable(per_tensor_tol) else (lambda n: per_tensor_tol)
     bad = [(v, n) for v, n in worst if v >= tol_of(n)]
     assert not bad, (tag, "per-tensor gradient direction", bad[:5])
@@ -282,8 +303,9 @@ def test_base_golden(backend, golden_dir):
         # gradient DIRECTION of every tensor against the reference's sampled gradients: the
         # benchmarked bf16 mode is held to 5e-2 per tensor / 2e-2 for the whole gradient
         grads = {n: gv for n, pv, gv, isb in e.named_views() if not isb}
-        w, whole = check_gradient_direction(grads, z, 5e-3 if precise else BF16_TENSOR_TOL, 2e-3 if precise else 2e-2,
-                                            tag="bf16x3" if precise else "bf16")
+        tol_of, whole_tol, ac = bf16_tensor_bounds(golden_dir)
+        w, whole = check_gradient_direction(grads, z, 5e-3 if precise else tol_of, 2e-3 if precise else whole_tol,
+                                            tag="bf16x3" if precise else "bf16", yardstick=None if precise else ac)
         print(f"[base golden {'bf16x3' if precise else 'bf16'}] worst tensor {w[1]} {w[0]:.2e}, whole gradient {whole:.2e}")
         if precise:
             assert np.array_equal(O.stop_indices(o["eos_out"].cpu()).numpy(), z["int.stop_idx"])

@@ -287,7 +287,10 @@ def test_bf16_tiles_splitk_conv_batched(backend):
 
 
 @pytest.mark.parametrize("M,N,K,act,resid", [(16, 512, 512, 0, False), (16, 2048, 512, 1, False), (16, 512, 2048, 0, True),
-                                             (5, 80, 256, 0, False), (1, 1, 32, 2, True), (16, 1536, 512, 0, False)])
+                                             (5, 80, 256, 0, False), (1, 1, 32, 2, True), (16, 1536, 512, 0, False),
+                                             # round 4: up to 64 rows (2 / 4 row blocks per lane), logistic epilogue
+                                             (17, 512, 512, 0, True), (32, 1536, 512, 1, False), (49, 80, 256, 0, False),
+                                             (64, 512, 2048, 0, True), (64, 1, 512, 3, False), (16, 1, 512, 3, False)])
 def test_skinny_gemm(backend, M, N, K, act, resid):
     """AR-decoding product (s2st_gemm_skinny_f32): bf16-rounded operands, fp32 accumulation, bias / activation /
     residual -- against the same product formed in double from the rounded operands."""
@@ -308,6 +311,8 @@ def test_skinny_gemm(backend, M, N, K, act, resid):
         ref = ref.clamp_min(0)
     elif act == 2:
         ref = torch.nn.functional.gelu(ref)
+    elif act == 3:
+        ref = torch.sigmoid(ref)
     if resid:
         ref = ref + r.double()
     got = y[:, :N].cpu().double()
@@ -323,7 +328,8 @@ def test_skinny_gemm(backend, M, N, K, act, resid):
         assert torch.equal(y2 == 0, y3 == 0) and float((y2 - y3).abs().max()) <= 1e-4 * (float(y3.abs().max()) + 1.0)
 
 
-@pytest.mark.parametrize("M,N,K,act", [(16, 1536, 512, 0), (16, 2048, 512, 1), (3, 80, 256, 0), (16, 1, 512, 0)])
+@pytest.mark.parametrize("M,N,K,act", [(16, 1536, 512, 0), (16, 2048, 512, 1), (3, 80, 256, 0), (16, 1, 512, 0),
+                                       (64, 1536, 512, 0), (40, 320, 512, 1), (64, 1, 512, 3), (23, 2048, 512, 1)])
 def test_skinny_gemm_with_fused_layernorm(backend, M, N, K, act):
     """s2st_ln_gemm_skinny_f32 == LayerNorm (fp32) -> bf16 rounding -> product, formed in double."""
     g = torch.Generator().manual_seed(N + K)
@@ -338,9 +344,20 @@ def test_skinny_gemm_with_fused_layernorm(backend, M, N, K, act):
     ref = ln.to(torch.bfloat16).double() @ w.double().t() + b.double()
     if act == 1:
         ref = ref.clamp_min(0)
+    elif act == 3:
+        ref = torch.sigmoid(ref)
     # a last-bit difference in the statistics can flip the bf16 rounding of single inputs: 2^-9 of one product term
     assert float((y.cpu().double() - ref).abs().max()) <= 2e-3 * (float(ref.abs().max()) + 1.0)
     assert float((y.cpu().double() - ref).abs().mean()) <= 1e-4 * (float(ref.abs().max()) + 1.0)
+
+
+def _needs_experimental(backend):
+    """The persistent tile walk / stream-K / 256 x 128 forms are compiled only into -DS2ST_EXPERIMENTAL builds (the
+    emulator's test build, tools/build_experimental.sh); the product library ignores their switches."""
+    fn = backend.bd.lib().s2st_experimental_build
+    fn.restype = __import__("ctypes").c_int
+    if not fn():
+        pytest.skip("forms of -DS2ST_EXPERIMENTAL builds only")
 
 
 @pytest.mark.parametrize("akm,bkm", [(True, True), (True, False), (False, False), (False, True)])
@@ -349,6 +366,7 @@ def test_bf16_persistent_kernel(backend, monkeypatch, akm, bkm, K):
     """The persistent ring kernel (more tiles than workgroups: every workgroup walks several tiles with the DMA ring
     running across tile boundaries -- K = 64 makes the prologue itself span tiles, K = 200 has a K tail) against the
     exact product; epilogue variants with both output copies."""
+    _needs_experimental(backend)
     monkeypatch.setenv("S2ST_GEMM_PERSIST", "2")
     monkeypatch.setenv("S2ST_GEMM_TILE", "128x128")  # (the small emulator shape would get 64 x 64 tiles: one-shot kernel)
     M, N = (640, 256) if backend.kind == "emu" else (4584, 2048)
@@ -423,6 +441,7 @@ def test_bf16_group_of_weight_gradients(backend, monkeypatch, tile):
         monkeypatch.setenv("S2ST_GROUP_ONESHOT", "1")
         monkeypatch.setenv("S2ST_GEMM_W4", "2" if tile == "w4" else "0")  # w4: the 4-wave early-release form of it
     else:                  # the persistent tile walk
+        _needs_experimental(backend)
         monkeypatch.setenv("S2ST_GROUP_ONESHOT", "0")
         monkeypatch.setenv("S2ST_GROUP_TILE", str(tile))
     d = backend.device
@@ -455,6 +474,7 @@ def test_bf16_stream_k(backend, monkeypatch, akm, bkm, shape):
     against the unsplit launch (same products, different fp32 summation order); two launches in a row (the ticket
     counters re-arm themselves)."""
     import ctypes as C
+    _needs_experimental(backend)
     monkeypatch.setenv("S2ST_GEMM_PERSIST", "1")
     monkeypatch.setenv("S2ST_STREAMK_MIN_STEPS", "2")
     monkeypatch.setenv("S2ST_GEMM_TILE", "128x128")

@@ -273,3 +273,97 @@ def test_generate_waveform_harness_on_disk_corpus(backend, tmp_path):
     with pytest.raises(SystemExit):
         GW.main([corpus, "--gen-subset", "dev_tiny", "--path", ckpt, "--results-path", str(out), "--dump-features",
                  "--output-sample-rate", str(sr + 1)], device=backend.device)
+
+
+def _gl_numpy_fft(spec, angles, n_fft, win_length, hop, n_iter):
+    """Griffin-Lim in float64 with numpy's real FFTs -- the form csrc/infer.hip computes.  That this IS the reference's
+    arithmetic (dense Fourier-basis convolutions, audio_utils.py:226-271 / vocoder.py:56-98) is what
+    test_fourier_bases_are_real_ffts pins; the reference golden at n_fft 256 pins the kernels themselves."""
+    Fq, T = spec.shape
+    pad = n_fft - win_length
+    win = np.pad(torch.hann_window(win_length).double().numpy(), (pad // 2, pad - pad // 2))
+    n = n_fft + hop * (T - 1)
+    wss = np.zeros(n)
+    for i in range(T):
+        wss[i * hop: i * hop + n_fft] += (win ** 2)[: max(0, min(n_fft, n - i * hop))]
+
+    def inverse(X):
+        fr = np.fft.irfft(X.T, n=n_fft, axis=1) * (hop / n_fft) * win  # [T][n_fft]
+        y = np.zeros(n)
+        for t in range(T):
+            y[t * hop: t * hop + n_fft] += fr[t]
+        nz = wss > 1.1754944e-38
+        y[nz] /= wss[nz]
+        y *= n_fft / hop
+        return y[n_fft // 2: -(n_fft // 2)]
+
+    def transform(w):
+        p = np.pad(w, (n_fft // 2, n_fft // 2), mode="reflect")
+        fr = np.stack([p[t * hop: t * hop + n_fft] * win for t in range(T)])
+        return np.fft.rfft(fr, axis=1).T  # [F][T]
+
+    mag = spec.astype(np.float64)
+    X = mag * np.exp(1j * angles.astype(np.float64))
+    w = inverse(X)
+    for _ in range(n_iter):
+        Y = transform(w)
+        X = mag * np.exp(1j * np.angle(Y))
+        w = inverse(X)
+    return w
+
+
+def test_fourier_bases_are_real_ffts():
+    """The identity behind the FFT path (round 4): the reference's analysis basis applied to a frame is rfft(window * frame),
+    and its synthesis basis pinverse(n_fft / hop * basis)^T * window is window * (hop / n_fft) * irfft -- imaginary parts of
+    the DC and Nyquist bins dropped, as numpy's irfft does."""
+    V = importlib.import_module(PKG + ".vocoder")
+    for n_fft, hop in ((64, 16), (256, 64)):
+        basis = np.fft.fft(np.eye(n_fft))  # the reference's get_fourier_basis (audio_utils.py:226-231), kept in float64
+        Fq = n_fft // 2 + 1
+        B = np.vstack([basis.real[:Fq], basis.imag[:Fq]])
+        assert np.abs(V.get_fourier_basis(n_fft).double().numpy() - B).max() < 1e-6
+        rs = np.random.RandomState(n_fft)
+        fr = rs.randn(n_fft)
+        Y = B @ fr
+        ref = np.fft.rfft(fr)
+        assert np.abs(Y[:Fq] - ref.real).max() < 1e-10 and np.abs(Y[Fq:] - ref.imag).max() < 1e-10
+        P = np.linalg.pinv(n_fft / hop * B).T  # [2F][n_fft] (vocoder.py:59-60)
+        X = rs.randn(Fq) + 1j * rs.randn(Fq)
+        syn = np.concatenate([X.real, X.imag]) @ P
+        assert np.abs(syn - np.fft.irfft(X, n=n_fft) * hop / n_fft).max() < 1e-12
+
+
+@pytest.mark.parametrize("n_fft,win,hop,T", [(256, 200, 64, 23), (2048, 1200, 300, 19), (1024, 1024, 256, 12)])
+def test_fft_griffin_lim_kernels(backend, golden_dir, monkeypatch, n_fft, win, hop, T):
+    """The LDS FFT kernels (radix-4 Stockham + a radix-2 stage for odd log2 n_fft, two frames per complex transform):
+    the benchmark geometry (n_fft 2048 / window 1200 / hop 300), one with log2 n_fft even, and the golden's -- against
+    the float64 numpy form to 2e-4 of the waveform scale (fp32 butterflies), ragged batches included; at the golden's
+    geometry also against the REFERENCE's GriffinLim output, where the FFT form must be at least as close as the dense
+    bf16x3 GEMM form it replaces."""
+    if backend.kind == "emu" and n_fft > 1024:
+        T = 9
+    V = importlib.import_module(PKG + ".vocoder")
+    rs = np.random.RandomState(n_fft + T)
+    Fq = n_fft // 2 + 1
+    specs = [np.abs(rs.randn(Fq, t)).astype(np.float32) for t in (T, max(T // 2, 5))]
+    angs = [IO.initial_angles((Fq, s.shape[1]), rs) for s in specs]
+    gl = V.GriffinLim(n_fft, win, hop, 3, backend.device)
+    assert gl.use_fft
+    out = gl.batch([torch.from_numpy(s) for s in specs], angs)
+    backend.sync()
+    for s, a, w in zip(specs, angs, out):
+        ref = _gl_numpy_fft(s, a, n_fft, win, hop, 3)
+        assert w.shape[0] == ref.shape[0]
+        assert float(np.abs(w.cpu().numpy() - ref).max()) < 2e-4 * float(np.abs(ref).max()), (n_fft, s.shape)
+    if n_fft == 256:
+        z = np.load(os.path.join(golden_dir, "infer_gl.npz"))
+        ref = z["wave.4"]
+        g4 = V.GriffinLim(256, 200, 64, 4, backend.device)
+        e_fft = float(np.abs(g4(torch.from_numpy(z["spec"]), z["angles"]).cpu().numpy() - ref).max())
+        monkeypatch.setenv("S2ST_GL_FFT", "0")
+        g4d = V.GriffinLim(256, 200, 64, 4, backend.device)
+        assert not g4d.use_fft
+        e_dense = float(np.abs(g4d(torch.from_numpy(z["spec"]), z["angles"]).cpu().numpy() - ref).max())
+        backend.sync()
+        scale = float(np.abs(ref).max())
+        assert e_fft < 2e-4 * scale and e_dense < 2e-3 * scale, (e_fft / scale, e_dense / scale)

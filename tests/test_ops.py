@@ -461,3 +461,53 @@ def test_sumsq_adam(backend, parts):
                     skipped, nparts, 1)  # skipped again, but the gradients are cleared as asked
     backend.sync()
     assert int(skipped) == 2 and not bool(gd.any()) and torch.equal(pd, before[0])
+
+
+def test_dropout_mask_independence(backend):
+    """the 2-multiply 32-bit dropout hash (csrc/s2st_common.h: mix32) was only checked for its keep
+    RATE.  Here the masks themselves: (1) neighbouring elements of one site, at lags 1, 2, 64 and the row width (what a
+    correlated mask would hit first: the lanes of a wave and the rows of a tile), (2) the SAME elements at two sites of one
+    step -- seeds as the engine derives them, seed * 0x100000001B3 + site * 0x9E3779B97F4A7C15 -- and at the same site of
+    two consecutive steps, (3) the two seed words separately (a seed differing only in its high word must give an
+    unrelated mask).  Statistic: the phi coefficient of the two keep indicators, |phi| < 4.5 / sqrt(n) (a 4.5-sigma bound
+    under independence: ~7e-6 false-alarm rate per comparison), and each mask's keep rate within 4.5 sigma of 1 - p."""
+    n = 1 << 20 if backend.kind == "hip" else 1 << 17
+    p = 0.3
+    x = torch.ones(n, device=backend.device)
+
+    def mask(seed):
+        y = torch.empty_like(x)
+        backend.bd.call("s2st_dropout_f32", x, y, n, 1.0, p, seed & ((1 << 64) - 1), 0)
+        backend.sync()
+        return (y.cpu() != 0).double()
+
+    def phi(a, b):
+        a, b = a - a.mean(), b - b.mean()
+        return float((a * b).mean() / (a.std(unbiased=False) * b.std(unbiased=False)))
+
+    def site_seed(step_seed, site):
+        return (step_seed * 0x100000001B3 + site * 0x9E3779B97F4A7C15) & ((1 << 64) - 1)
+
+    bound = 4.5 / n ** 0.5
+    rate_bound = 4.5 * (p * (1 - p) / n) ** 0.5
+    m0 = mask(site_seed(1000003, 1))
+    assert abs(float(m0.mean()) - (1 - p)) < rate_bound
+    for lag in (1, 2, 3, 64, 512, 2048):
+        assert abs(phi(m0[:-lag], m0[lag:])) < 4.5 / (n - lag) ** 0.5, lag
+    others = {"next site": site_seed(1000003, 2), "site 40": site_seed(1000003, 40), "next step": site_seed(2000006, 1),
+              "low word + 1": site_seed(1000003, 1) + 1, "high word + 1": site_seed(1000003, 1) + (1 << 32),
+              "seed 0": 0, "seed 1": 1}
+    masks = {k: mask(v) for k, v in others.items()}
+    for k, m in masks.items():
+        assert abs(float(m.mean()) - (1 - p)) < rate_bound, k
+        assert abs(phi(m0, m)) < bound, (k, phi(m0, m))
+        assert abs(phi(m0[1:], m[:-1])) < bound, (k, "shifted")  # not an index-shifted copy either
+    assert abs(phi(masks["seed 0"], masks["seed 1"])) < bound
+    # a 2 x 2 x 2 check over three sites: every one of the 8 joint outcomes at its product probability
+    a, b, c = m0, masks["next site"], masks["site 40"]
+    for va in (0.0, 1.0):
+        for vb in (0.0, 1.0):
+            for vc in (0.0, 1.0):
+                q = (p if va == 0 else 1 - p) * (p if vb == 0 else 1 - p) * (p if vc == 0 else 1 - p)
+                got = float(((a == va) & (b == vb) & (c == vc)).double().mean())
+                assert abs(got - q) < 4.5 * (q * (1 - q) / n) ** 0.5, (va, vb, vc, got, q)
