@@ -264,6 +264,19 @@ def infer_main(args):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     vlog("timed region", dt, "s for", n_utt, "utterances")
+    # the same pass with the initial phases drawn by the device's generator instead of numpy's (GriffinLim(phase_rng="device"):
+    # same distribution, no host-side generator run) -- reported next to `value`, never as it
+    voc_d = V.GriffinLimVocoder(spec_bwd_max_iter=INFER_GL_ITERS, device=dev, phase_rng="device", **voc_kw)
+    gens_d = [G.AutoRegressiveSpeechGenerator(model, voc_d, None, max_iter=it, eos_prob_threshold=2.0) for it in iters]
+    for k in range(len(samples)):
+        gens_d[k].generate(model, samples[k])
+    torch.cuda.synchronize()
+    t0d = time.perf_counter()
+    nd = 0
+    for i in range(args.steps):
+        nd += len(gens_d[i % len(samples)].generate(model, samples[i % len(samples)]))
+    torch.cuda.synchronize()
+    value_device_rng = nd / (time.perf_counter() - t0d)
     # decode / vocoder split of one batch (un-timed above)
     tA = time.perf_counter()
     g0 = G.AutoRegressiveSpeechGenerator(model, None, None, max_iter=iters[0], eos_prob_threshold=2.0)
@@ -385,6 +398,8 @@ def infer_main(args):
                                    "LDS) batched over the utterances" % (INFER_N_UTTS, INFER_MAX_TOKENS,
                                                                         "+".join(str(len(g)) for g in groups), INFER_GL_ITERS),
                        "name": "infer_base", "utterances_per_step": len(groups[0]), "mel_frames_per_s": round(n_frames / dt, 1),
+                       "initial_phases": "numpy global generator on the host (the reference's draws, vocoder.py:101-102)",
+                       "value_with_device_phase_rng": round(value_device_rng, 2),
                        "decode_steps_per_batch": iters, "batch0_decode_ms": round(t_dec * 1e3, 2),
                        "batch0_vocoder_ms": round(t_voc * 1e3, 2)}}
     if roofline:
@@ -728,17 +743,23 @@ def main():
         # process); the committed measurement is reported, with its source
         traffic, traffic_src = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
-                tj = json.load(f)
+            import glob
             hb = C.create_string_buffer(32)
             lib.s2st_source_hash.argtypes = [C.c_char_p, C.c_int32]
             lib.s2st_source_hash(hb, 32)
-            if tj.get("source_hash") != hb.value.decode():
+            # the newest committed measurement taken on the sources the loaded library was built from
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True)
+            for fn in cands:
+                with open(fn) as f:
+                    tj = json.load(f)
+                if tj.get("source_hash") == hb.value.decode() and tj.get("config", "base_recipe") == args.config:
+                    traffic, traffic_src = round(tj["kernels"][dom_tag]["hbm_bytes_per_launch"]), tj["source"]
+                    break
+            else:
                 # measured on other sources than the loaded library was built from: not this kernel's figure any more
-                traffic_src = ("stale: profiles/r03_pmc_traffic.json was measured on sources %s, the loaded library is %s "
-                               "(tools/profile_round.sh re-measures)" % (tj.get("source_hash"), hb.value.decode()))
-            elif tj.get("config", "base_recipe") == args.config:
-                traffic, traffic_src = round(tj["kernels"][dom_tag]["hbm_bytes_per_launch"]), tj["source"]
+                traffic_src = ("stale: no profiles/r*_pmc_traffic.json was measured on the sources the loaded library was built "
+                               "from (%s; newest file: %s) -- tools/profile_round.sh re-measures" % (
+                                   hb.value.decode(), os.path.basename(cands[0]) if cands else "none"))
         except Exception:
             pass
         gemm_us = sum(r["us"] for r in gemm.values())

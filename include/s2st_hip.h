@@ -423,7 +423,7 @@ int s2st_gl_overlap_add_f32(const float* frames, const float* wsq, float* wave, 
  *   frame_split: As[rows][3][n_fft] = split(frames of the reflect-padded waves [U][Lw]) */
 int s2st_gl_polar_split_f32(const float* mag, const float* aux, int32_t from_spectrum, const int32_t* tl, void* Xs, int32_t U, int32_t F, int32_t Fp, int32_t Tmax, void* stream);
 int s2st_gl_frame_split_f32(const float* wave, const int32_t* tl, void* As, int32_t U, int32_t Tmax, int32_t hop, int32_t n_fft, int32_t Lw, void* stream);
-/* Griffin-Lim with FFTs (round 4; replaces, for n_fft a power of two in 256 ... 4096, the dense Fourier-basis contractions
+/* Griffin-Lim with FFTs (round 4; replaces, for n_fft a power of two in 256 ... 2048, the dense Fourier-basis contractions
  * above).  The reference's analysis basis [Re; Im] fft(eye(n_fft)) * window is rfft(window * frame)
  * (fairseq/data/audio/audio_utils.py:226-231, 259-271) and its synthesis basis pinverse(n_fft / hop * basis)^T * window is
  * window * (hop / n_fft) * irfft (fairseq/models/text_to_speech/vocoder.py:59-62, 82-86).  X: complex spectra
@@ -433,6 +433,12 @@ int s2st_gl_frame_split_f32(const float* wave, const int32_t* tl, void* As, int3
  * [U * Tmax][n_fft] for s2st_gl_overlap_add_b_f32. */
 int s2st_gl_fft_supported_i32(int32_t n_fft);
 int s2st_gl_polar_c_f32(const float* mag, const float* ang, const int32_t* tl, float* X, int32_t U, int32_t F, int32_t Tmax, void* stream);
+/* initial phases (vocoder.py:101-102) from the uniform draws themselves: uniform = the doubles numpy's generator produced, utterance
+ * u's [F][T_u] block at uniform + offsets[u]; X = mag * exp(i wrap(2 pi u)).  uniform == NULL: the draws come from the device's
+ * counter-based generator (seed): same distribution, not numpy's stream. */
+/* x <- exp(x) in place (vocoder.py:139 for a padded batch of log-mel frames) */
+int s2st_exp_inplace_f32(float* x, int64_t n, void* stream);
+int s2st_gl_polar_u_f32(const float* mag, const double* uniform, const int64_t* offsets, const int32_t* tl, uint64_t seed, float* X, int32_t U, int32_t F, int32_t Tmax, void* stream);
 int s2st_gl_stft_project_f32(const float* wave, const int32_t* tl, const float* win, const float* tw, const float* mag, float* X, int32_t U, int32_t Tmax, int32_t n_fft, int32_t hop, int32_t Lw, void* stream);
 int s2st_gl_istft_frames_f32(const float* X, const int32_t* tl, const float* win, const float* tw, float* frames, int32_t U, int32_t Tmax, int32_t n_fft, int32_t hop, void* stream);
 int s2st_gl_overlap_add_b_f32(const float* frames, const float* wsq_all, const int64_t* wsq_off, const int32_t* tl, float* wave, int32_t U, int32_t Tmax, int32_t n_fft, int32_t hop, int32_t Lw, void* stream);

@@ -197,6 +197,10 @@ int s2st_gl_fft_supported_i32(int32_t n_fft) { return s2st_gl_fft_supported(n_ff
 int s2st_gl_polar_c_f32(const float* mag, const float* ang, const int32_t* tl, float* X, int32_t U, int32_t F, int32_t Tmax, void* stream) {
   return s2st_gl_polar_c(mag, ang, tl, X, U, F, Tmax, (hipStream_t)stream);
 }
+int s2st_exp_inplace_f32(float* x, int64_t n, void* stream) { return s2st_exp_inplace(x, n, (hipStream_t)stream); }
+int s2st_gl_polar_u_f32(const float* mag, const double* uniform, const int64_t* offsets, const int32_t* tl, uint64_t seed, float* X, int32_t U, int32_t F, int32_t Tmax, void* stream) {
+  return s2st_gl_polar_u(mag, uniform, (const long*)offsets, tl, seed, X, U, F, Tmax, (hipStream_t)stream);
+}
 int s2st_gl_stft_project_f32(const float* wave, const int32_t* tl, const float* win, const float* tw, const float* mag, float* X, int32_t U, int32_t Tmax, int32_t n_fft, int32_t hop, int32_t Lw, void* stream) {
   return s2st_gl_stft_project(wave, tl, win, tw, mag, X, U, Tmax, n_fft, hop, Lw, (hipStream_t)stream);
 }

@@ -1293,26 +1293,41 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
     // fused LayerNorm of the activation rows (the decoder's pre-LN in front of a projection): every workgroup
     // recomputes the row statistics (L2-resident input) instead of a separate kernel + round trip.
     // 16 threads per row, two passes (mean, then squared deviations) like layernorm_fwd_kernel.
+    // (the MT row blocks advance together: their loads are independent, so a pass costs one memory round trip, not MT)
     const int j = tid & 15;
+    const float* xr[MT];
+    float s[MT], q[MT], mean[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const int row = min(16 * mt + (tid >> 4), M - 1);
-      const float* xr = A + (long)row * lda;
-      float s = 0.f;
-      for (int c = 4 * j; c < K; c += 64) {
-        const float4 v = *reinterpret_cast<const float4*>(xr + c);
-        s += v.x + v.y + v.z + v.w;
+      xr[mt] = A + (long)min(16 * mt + (tid >> 4), M - 1) * lda;
+      s[mt] = q[mt] = 0.f;
+    }
+    for (int c = 4 * j; c < K; c += 64) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float4 v = *reinterpret_cast<const float4*>(xr[mt] + c);
+        s[mt] += v.x + v.y + v.z + v.w;
       }
-      s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
-      const float mean = s / K;
-      float q = 0.f;
-      for (int c = 4 * j; c < K; c += 64) {
-        const float4 v = *reinterpret_cast<const float4*>(xr + c);
-        const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
-        q += a * a + b * b + cc * cc + d * d;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      float t = s[mt];
+      t += __shfl_xor(t, 8); t += __shfl_xor(t, 4); t += __shfl_xor(t, 2); t += __shfl_xor(t, 1);
+      mean[mt] = t / K;
+    }
+    for (int c = 4 * j; c < K; c += 64) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float4 v = *reinterpret_cast<const float4*>(xr[mt] + c);
+        const float a = v.x - mean[mt], b = v.y - mean[mt], cc = v.z - mean[mt], d = v.w - mean[mt];
+        q[mt] += a * a + b * b + cc * cc + d * d;
       }
-      q += __shfl_xor(q, 8); q += __shfl_xor(q, 4); q += __shfl_xor(q, 2); q += __shfl_xor(q, 1);
-      if (j == 0) { ln_mean[16 * mt + (tid >> 4)] = mean; ln_rstd[16 * mt + (tid >> 4)] = rsqrtf(q / K + ln_eps); }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      float t = q[mt];
+      t += __shfl_xor(t, 8); t += __shfl_xor(t, 4); t += __shfl_xor(t, 2); t += __shfl_xor(t, 1);
+      if (j == 0) { ln_mean[16 * mt + (tid >> 4)] = mean[mt]; ln_rstd[16 * mt + (tid >> 4)] = rsqrtf(t / K + ln_eps); }
     }
     __syncthreads();
   }

@@ -160,6 +160,10 @@ __global__ __launch_bounds__(256) void exp_transpose_kernel(const float* __restr
   const int c = (int)(i / T), t = (int)(i - (long)c * T);
   y[i] = expf(x[(long)t * C + c]);
 }
+__global__ __launch_bounds__(256) void exp_kernel(float* __restrict__ x, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) x[i] = expf(x[i]);
+}
 __global__ __launch_bounds__(256) void clamp_min_kernel(float* __restrict__ x, long n, float lo) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) x[i] = fmaxf(x[i], lo);
@@ -290,14 +294,25 @@ __global__ __launch_bounds__(256) void gl_overlap_add_b_kernel(const float* __re
 // contraction (x 3 in the bf16x3 GEMM form that rounds 1 - 3 used: 137 ms of the 237 ms one 16-utterance batch took).
 // One workgroup transforms TWO frames at once as the real and imaginary part of one complex N-point FFT (Stockham
 // autosort, radix 4 with a final radix 2 when log2 N is odd, in LDS: 8 N bytes + the twiddle table) and separates /
-// merges the two spectra through the Hermitian symmetry.  N = 256 ... 4096 (powers of two); other n_fft keep the GEMM path.
+// merges the two spectra through the Hermitian symmetry.  N = 256 ... 2048 (powers of two); other n_fft keep the GEMM path.
 // ------------------------------------------------------------------------------------------------
 struct cplx { float x, y; };
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return cplx{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return cplx{a.x + b.x, a.y + b.y}; }
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return cplx{a.x - b.x, a.y - b.y}; }
 
-// in-place complex FFT of buf[0 .. N) (LDS), 256 threads; tw[j] = exp(-2 pi i j / N); INV: conjugate transform (unscaled)
+// LDS arrays are PADDED: logical element i lives at P(i) = i + (i >> 5).  The Stockham passes scatter their results with
+// power-of-two strides (4, 16, 64 elements of 8 bytes) and read twiddles at strides of N / (4 Ns): without the pad 8 - 16
+// lanes of a wave hit one bank (the first measurement of these kernels on MI355X: 390 us per 44.5 k-frame STFT, ~10 k cycles
+// of a CU per frame pair against ~2 k of LDS traffic).
+__device__ __forceinline__ int fpad(int i) { return i + (i >> 5); }
+template <int N>
+struct FftLds {
+  static constexpr int SIZE = N + N / 32 + 1;
+};
+
+// in-place complex FFT of the padded LDS array buf (logical 0 .. N), 256 threads; tw (padded) logical j = exp(-2 pi i j / N);
+// INV: conjugate transform (unscaled)
 template <int N, bool INV>
 __device__ void fft_lds(cplx* buf, const cplx* tw, int tid) {
   constexpr int Q = N / 4, PER4 = (Q + 255) / 256;
@@ -312,9 +327,9 @@ __device__ void fft_lds(cplx* buf, const cplx* tw, int tid) {
         const int k = j & (Ns - 1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          cplx x = buf[j + r * Q];
+          cplx x = buf[fpad(j + r * Q)];
           if (r > 0 && k > 0) {
-            cplx w = tw[r * k * tstride];
+            cplx w = tw[fpad(r * k * tstride)];
             if (INV) w.y = -w.y;
             x = cmul(x, w);
           }
@@ -332,10 +347,10 @@ __device__ void fft_lds(cplx* buf, const cplx* tw, int tid) {
         const cplx d = csub(v[i][1], v[i][3]);
         const cplx a3 = INV ? cplx{-d.y, d.x} : cplx{d.y, -d.x};  // (+-) i (v1 - v3)
         const int j0 = ((j - k) << 2) + k;
-        buf[j0] = cadd(a0, a2);
-        buf[j0 + Ns] = cadd(a1, a3);
-        buf[j0 + 2 * Ns] = csub(a0, a2);
-        buf[j0 + 3 * Ns] = csub(a1, a3);
+        buf[fpad(j0)] = cadd(a0, a2);
+        buf[fpad(j0 + Ns)] = cadd(a1, a3);
+        buf[fpad(j0 + 2 * Ns)] = csub(a0, a2);
+        buf[fpad(j0 + 3 * Ns)] = csub(a1, a3);
       }
     }
     __syncthreads();
@@ -347,10 +362,10 @@ __device__ void fft_lds(cplx* buf, const cplx* tw, int tid) {
     for (int i = 0; i < PER2; ++i) {
       const int j = tid + 256 * i;
       if (j < H) {
-        cplx w = tw[j];
+        cplx w = tw[fpad(j)];
         if (INV) w.y = -w.y;
-        v0[i] = buf[j];
-        v1[i] = cmul(buf[j + H], w);
+        v0[i] = buf[fpad(j)];
+        v1[i] = cmul(buf[fpad(j + H)], w);
       }
     }
     __syncthreads();
@@ -358,8 +373,8 @@ __device__ void fft_lds(cplx* buf, const cplx* tw, int tid) {
     for (int i = 0; i < PER2; ++i) {
       const int j = tid + 256 * i;
       if (j < H) {
-        buf[j] = cadd(v0[i], v1[i]);
-        buf[j + H] = csub(v0[i], v1[i]);
+        buf[fpad(j)] = cadd(v0[i], v1[i]);
+        buf[fpad(j + H)] = csub(v0[i], v1[i]);
       }
     }
     __syncthreads();
@@ -369,101 +384,195 @@ __device__ void fft_lds(cplx* buf, const cplx* tw, int tid) {
 // STFT of the reflect-padded waveforms + phase projection, per PAIR of frames (rows m0 = 2 * pair, m0 + 1 of the
 // flattened [U][Tmax] frame index): X[m][k] = mag[m][k] * Y_k / |Y_k| with Y = rfft(window * frame) -- the reference's
 // mag * (cos, sin)(atan2(Im Y, Re Y)) (audio_utils.py:259-271, vocoder.py:104-107; |Y| = 0: angle 0).  Rows t >= T_u: zeros.
+// A workgroup walks several pairs; the NEXT pair's samples and this pair's magnitudes are fetched into registers before
+// the transform starts, so the memory round trips run under the butterflies (first version: load -> transform -> load ->
+// store in sequence, ~18 us per pair and workgroup with four workgroups per CU).
+template <int N>
+struct PairInfo {
+  int tt[2], uu[2], TT[2];
+  bool on[2];
+  __device__ __forceinline__ void set(long pair, long M, int Tmax, const int* tl, int hop, bool need_len) {
+    for (int h = 0; h < 2; ++h) {
+      const long m = 2 * pair + h;
+      uu[h] = m < M ? (int)(m / Tmax) : 0;
+      tt[h] = m < M ? (int)(m - (long)uu[h] * Tmax) : 0;
+      TT[h] = tl[uu[h]];
+      on[h] = m < M && tt[h] < TT[h] && (!need_len || hop * (TT[h] - 1) > N / 2);
+    }
+  }
+};
+
 template <int N>
 __global__ __launch_bounds__(256) void gl_stft_project_kernel(const float* __restrict__ wave, const int* __restrict__ tl,
                                                               const float* __restrict__ win, const cplx* __restrict__ twg,
                                                               const float* __restrict__ mag, cplx* __restrict__ X, int U,
                                                               int Tmax, int hop, int Lw, long npairs) {
-  __shared__ cplx buf[N];
-  __shared__ cplx tw[N];
+  __shared__ cplx buf[FftLds<N>::SIZE];
+  __shared__ cplx tw[FftLds<N>::SIZE];
   const int tid = threadIdx.x;
-  constexpr int F = N / 2 + 1;
-  for (int j = tid; j < N; j += 256) tw[j] = twg[j];
-  for (long pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
-    const long m0 = 2 * pair, M = (long)U * Tmax;
-    int tt[2], uu[2], TT[2];
-    bool on[2];
-    for (int h = 0; h < 2; ++h) {
-      const long m = m0 + h;
-      uu[h] = m < M ? (int)(m / Tmax) : 0;
-      tt[h] = m < M ? (int)(m - (long)uu[h] * Tmax) : 0;
-      TT[h] = tl[uu[h]];
-      on[h] = m < M && tt[h] < TT[h] && hop * (TT[h] - 1) > N / 2;
-    }
-    __syncthreads();  // (the previous pair's readers are done with buf)
-    for (int n = tid; n < N; n += 256) {
+  constexpr int F = N / 2 + 1, PN = N / 256, PF = (F + 255) / 256;
+  for (int j = tid; j < N; j += 256) tw[fpad(j)] = twg[j];
+  const long M = (long)U * Tmax;
+  float wn[PN];
+#pragma unroll
+  for (int i = 0; i < PN; ++i) wn[i] = win[tid + 256 * i];
+  cplx xr[PN];
+  auto fetch = [&](const PairInfo<N>& pi) {
+#pragma unroll
+    for (int i = 0; i < PN; ++i) {
+      const int n = tid + 256 * i;
       float v[2] = {0.f, 0.f};
       for (int h = 0; h < 2; ++h) {
-        if (!on[h]) continue;
-        const int len = hop * (TT[h] - 1);
-        int j = tt[h] * hop + n - N / 2;
+        if (!pi.on[h]) continue;
+        const int len = hop * (pi.TT[h] - 1);
+        int j = pi.tt[h] * hop + n - N / 2;
         if (j < 0) j = -j;
         if (j >= len) j = 2 * (len - 1) - j;
-        v[h] = wave[(long)uu[h] * Lw + j] * win[n];
+        v[h] = wave[(long)pi.uu[h] * Lw + j];
       }
-      buf[n] = cplx{v[0], v[1]};
+      xr[i] = cplx{v[0] * wn[i], v[1] * wn[i]};
+    }
+  };
+  PairInfo<N> cur, nxt;
+  long pair = blockIdx.x;
+  if (pair < npairs) {
+    cur.set(pair, M, Tmax, tl, hop, true);
+    fetch(cur);
+  }
+  for (; pair < npairs; pair += gridDim.x) {
+    const long m0 = 2 * pair;
+    __syncthreads();  // (the previous pair's readers are done with buf)
+#pragma unroll
+    for (int i = 0; i < PN; ++i) buf[fpad(tid + 256 * i)] = xr[i];
+    // this pair's magnitudes and the next pair's samples: in flight during the transform
+    float mg[PF][2];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int k = tid + 256 * i;
+      for (int h = 0; h < 2; ++h) mg[i][h] = (k < F && cur.on[h]) ? mag[(m0 + h) * F + k] : 0.f;
+    }
+    const long np_ = pair + gridDim.x;
+    if (np_ < npairs) {
+      nxt.set(np_, M, Tmax, tl, hop, true);
+      fetch(nxt);
     }
     __syncthreads();
     fft_lds<N, false>(buf, tw, tid);
-    for (int k = tid; k < F; k += 256) {
-      const cplx zk = buf[k], zn = buf[(N - k) & (N - 1)];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int k = tid + 256 * i;
+      if (k >= F) continue;
+      const cplx zk = buf[fpad(k)], zn = buf[fpad((N - k) & (N - 1))];
       // Y1 = (Z_k + conj Z_{N-k}) / 2 ; Y2 = (Z_k - conj Z_{N-k}) / (2 i)
       const cplx y[2] = {cplx{0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)}, cplx{0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x)}};
       for (int h = 0; h < 2; ++h) {
         const long m = m0 + h;
         if (m >= M) continue;
         cplx o{0.f, 0.f};
-        if (on[h]) {
-          const float mg = mag[m * F + k];
+        if (cur.on[h]) {
           const float a2 = y[h].x * y[h].x + y[h].y * y[h].y;
           if (a2 > 0.f) {
-            const float r = mg * rsqrtf(a2);
+            const float r = mg[i][h] * rsqrtf(a2);
             o = cplx{y[h].x * r, y[h].y * r};
           } else {
-            o = cplx{mg, 0.f};
+            o = cplx{mg[i][h], 0.f};
           }
         }
         X[m * F + k] = o;
       }
     }
+    cur = nxt;
   }
 }
 
 // inverse: frames[m][n] = window[n] * (hop / N) * irfft(X[m])[n] for the two rows of a pair (rows t >= T_u: zeros);
-// the overlap-add kernel above turns the frames into the waveforms
+// the overlap-add kernel above turns the frames into the waveforms.  The next pair's spectra are fetched ahead likewise.
 template <int N>
 __global__ __launch_bounds__(256) void gl_istft_frames_kernel(const cplx* __restrict__ X, const int* __restrict__ tl,
                                                               const float* __restrict__ win, const cplx* __restrict__ twg,
                                                               float* __restrict__ frames, int U, int Tmax, int hop, long npairs) {
-  __shared__ cplx buf[N];
-  __shared__ cplx tw[N];
+  __shared__ cplx buf[FftLds<N>::SIZE];
+  __shared__ cplx tw[FftLds<N>::SIZE];
   const int tid = threadIdx.x;
-  constexpr int F = N / 2 + 1;
-  for (int j = tid; j < N; j += 256) tw[j] = twg[j];
+  constexpr int F = N / 2 + 1, PN = N / 256, PF = (F + 255) / 256;
+  for (int j = tid; j < N; j += 256) tw[fpad(j)] = twg[j];
   const float sc = (float)hop / ((float)N * (float)N);
-  for (long pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
-    const long m0 = 2 * pair, M = (long)U * Tmax;
-    bool on[2];
-    for (int h = 0; h < 2; ++h) {
-      const long m = m0 + h;
-      const int u = m < M ? (int)(m / Tmax) : 0, t = m < M ? (int)(m - (long)u * Tmax) : 0;
-      on[h] = m < M && t < tl[u];
+  const long M = (long)U * Tmax;
+  float wn[PN];
+#pragma unroll
+  for (int i = 0; i < PN; ++i) wn[i] = win[tid + 256 * i] * sc;
+  cplx xa[PF], xb[PF];
+  auto fetch = [&](const PairInfo<N>& pi, long m0) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int k = tid + 256 * i;
+      xa[i] = (k < F && pi.on[0]) ? X[m0 * F + k] : cplx{0.f, 0.f};
+      xb[i] = (k < F && pi.on[1]) ? X[(m0 + 1) * F + k] : cplx{0.f, 0.f};
     }
+  };
+  PairInfo<N> cur, nxt;
+  long pair = blockIdx.x;
+  if (pair < npairs) {
+    cur.set(pair, M, Tmax, tl, hop, false);
+    fetch(cur, 2 * pair);
+  }
+  for (; pair < npairs; pair += gridDim.x) {
+    const long m0 = 2 * pair;
     __syncthreads();
-    for (int k = tid; k < F; k += 256) {
-      cplx a = on[0] ? X[m0 * F + k] : cplx{0.f, 0.f}, b = on[1] ? X[(m0 + 1) * F + k] : cplx{0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int k = tid + 256 * i;
+      if (k >= F) continue;
+      cplx a = xa[i], b = xb[i];
       if (k == 0 || k == N / 2) a.y = b.y = 0.f;  // (the basis' sine rows of DC / Nyquist are zero)
-      buf[k] = cplx{a.x - b.y, a.y + b.x};                       // Z_k     = X1_k + i X2_k
-      if (k > 0 && k < N / 2) buf[N - k] = cplx{a.x + b.y, b.x - a.y};  // Z_{N-k} = conj X1_k + i conj X2_k
+      buf[fpad(k)] = cplx{a.x - b.y, a.y + b.x};                             // Z_k     = X1_k + i X2_k
+      if (k > 0 && k < N / 2) buf[fpad(N - k)] = cplx{a.x + b.y, b.x - a.y};  // Z_{N-k} = conj X1_k + i conj X2_k
+    }
+    const long np_ = pair + gridDim.x;
+    if (np_ < npairs) {
+      nxt.set(np_, M, Tmax, tl, hop, false);
+      fetch(nxt, 2 * np_);
     }
     __syncthreads();
     fft_lds<N, true>(buf, tw, tid);
-    for (int n = tid; n < N; n += 256) {
-      const float w = win[n] * sc;
-      if (m0 < M) frames[m0 * N + n] = on[0] ? buf[n].x * w : 0.f;
-      if (m0 + 1 < M) frames[(m0 + 1) * N + n] = on[1] ? buf[n].y * w : 0.f;
+#pragma unroll
+    for (int i = 0; i < PN; ++i) {
+      const int n = tid + 256 * i;
+      const cplx z = buf[fpad(n)];
+      if (m0 < M) frames[m0 * N + n] = cur.on[0] ? z.x * wn[i] : 0.f;
+      if (m0 + 1 < M) frames[(m0 + 1) * N + n] = cur.on[1] ? z.y * wn[i] : 0.f;
     }
+    cur = nxt;
   }
+}
+
+// The initial phases on the device.  The reference draws np.random.rand(F, T_u) per utterance from numpy's global generator and
+// takes np.angle(np.exp(2j pi u)) (vocoder.py:101-102) = 2 pi u wrapped into (-pi, pi], in double, then casts to the
+// spectrogram's dtype.  `uni`: those uniform draws, as drawn (utterance u's [F][T_u] block at uni + uoff[u]): the wrap, the
+// cast, the transposition to frame-major and mag * (cos, sin) happen here (the host only runs the generator -- rounds 1 - 3
+// also wrapped, cast and transposed 45 M numbers per 64 utterances there: 2/3 of the vocoder's wall time).  uni == nullptr:
+// the draws themselves come from the counter-based hash of (seed, utterance, bin, frame) -- same distribution, not numpy's
+// stream (GriffinLim(phase_rng="device")).  One thread per (u, k, t), t fastest: coalesced reads of uni.
+__global__ __launch_bounds__(256) void gl_polar_u_kernel(const float* __restrict__ mag, const double* __restrict__ uni,
+                                                         const long* __restrict__ uoff, const int* __restrict__ tl,
+                                                         uint64_t seed, cplx* __restrict__ X, int U, int F, int Tmax) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)U * F * Tmax) return;
+  const int t = (int)(i % Tmax);
+  const long r = i / Tmax;
+  const int k = (int)(r % F), u = (int)(r / F);
+  const int T = tl[u];
+  cplx o{0.f, 0.f};
+  if (t < T) {
+    double un;
+    if (uni) un = uni[uoff[u] + (long)k * T + t];
+    else un = (double)(mix32(seed + (uint64_t)u, (uint64_t)k * (uint64_t)Tmax + (uint64_t)t) >> 8) * (1.0 / 16777216.0);
+    double a = 6.283185307179586476925286766559 * un;
+    if (a > 3.141592653589793238462643383279) a -= 6.283185307179586476925286766559;
+    const float af = (float)a, m = mag[((long)u * Tmax + t) * F + k];
+    o = cplx{m * cosf(af), m * sinf(af)};
+  }
+  X[((long)u * Tmax + t) * F + k] = o;
 }
 
 // X[m][k] = mag[m][k] * (cos, sin)(ang[m][k]) (the initial phases, vocoder.py:101-103); rows t >= T_u: zeros
@@ -633,13 +742,30 @@ int s2st_gl_overlap_add_b(const float* frames, const float* wsq_all, const long*
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
-// ---- FFT-based Griffin-Lim launchers (n_fft a power of two in 256 ... 4096) ------------------------------------------
-bool s2st_gl_fft_supported(int n_fft) { return n_fft == 256 || n_fft == 512 || n_fft == 1024 || n_fft == 2048 || n_fft == 4096; }
+// ---- FFT-based Griffin-Lim launchers (n_fft a power of two in 256 ... 2048) ------------------------------------------
+bool s2st_gl_fft_supported(int n_fft) { return n_fft == 256 || n_fft == 512 || n_fft == 1024 || n_fft == 2048; }
 
 int s2st_gl_polar_c(const float* mag, const float* ang, const int* tl, float* X, int U, int F, int Tmax, hipStream_t st) {
   const long n = (long)U * Tmax * F;
   if (n <= 0) return 0;
   S2ST_LAUNCH(gl_polar_c_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mag, ang, tl, reinterpret_cast<cplx*>(X), U, F, Tmax);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+
+// x <- exp(x) in place (the vocoder's log-mel -> mel step, vocoder.py:139, for a whole padded batch at once)
+int s2st_exp_inplace(float* x, long n, hipStream_t st) {
+  if (n <= 0) return 0;
+  S2ST_LAUNCH(exp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+
+int s2st_gl_polar_u(const float* mag, const double* uni, const long* uoff, const int* tl, uint64_t seed, float* X, int U, int F,
+                    int Tmax, hipStream_t st) {
+  const long n = (long)U * F * Tmax;
+  if (n <= 0) return 0;
+  if (uni && !uoff) return S2ST_ERR_ARG;
+  S2ST_LAUNCH(gl_polar_u_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mag, uni, uoff, tl, seed,
+              reinterpret_cast<cplx*>(X), U, F, Tmax);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
@@ -669,7 +795,6 @@ int s2st_gl_stft_project(const float* wave, const int* tl, const float* win, con
     case 512: return gl_fft_launch<512>(0, wave, tl, win, tw, mag, X, nullptr, U, Tmax, hop, Lw, st);
     case 1024: return gl_fft_launch<1024>(0, wave, tl, win, tw, mag, X, nullptr, U, Tmax, hop, Lw, st);
     case 2048: return gl_fft_launch<2048>(0, wave, tl, win, tw, mag, X, nullptr, U, Tmax, hop, Lw, st);
-    case 4096: return gl_fft_launch<4096>(0, wave, tl, win, tw, mag, X, nullptr, U, Tmax, hop, Lw, st);
   }
   return S2ST_ERR_SHAPE;
 }
@@ -682,7 +807,6 @@ int s2st_gl_istft_frames(const float* X, const int* tl, const float* win, const 
     case 512: return gl_fft_launch<512>(1, nullptr, tl, win, tw, nullptr, const_cast<float*>(X), frames, U, Tmax, hop, 0, st);
     case 1024: return gl_fft_launch<1024>(1, nullptr, tl, win, tw, nullptr, const_cast<float*>(X), frames, U, Tmax, hop, 0, st);
     case 2048: return gl_fft_launch<2048>(1, nullptr, tl, win, tw, nullptr, const_cast<float*>(X), frames, U, Tmax, hop, 0, st);
-    case 4096: return gl_fft_launch<4096>(1, nullptr, tl, win, tw, nullptr, const_cast<float*>(X), frames, U, Tmax, hop, 0, st);
   }
   return S2ST_ERR_SHAPE;
 }

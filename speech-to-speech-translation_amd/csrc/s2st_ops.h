@@ -288,10 +288,15 @@ int s2st_gl_frame_split(const float* wave, const int* tl, uint16_t* As, int U, i
                         hipStream_t st);
 int s2st_gl_overlap_add_b(const float* frames, const float* wsq_all, const long* wsq_off, const int* tl, float* wave,
                           int U, int Tmax, int n_fft, int hop, int Lw, hipStream_t st);
-// FFT-based Griffin-Lim (infer.hip): n_fft a power of two in 256 ... 4096; X is complex [U * Tmax][n_fft / 2 + 1] (re, im
+// FFT-based Griffin-Lim (infer.hip): n_fft a power of two in 256 ... 2048; X is complex [U * Tmax][n_fft / 2 + 1] (re, im
 // interleaved); win [n_fft]; tw [n_fft] complex = exp(-2 pi i j / n_fft)
 bool s2st_gl_fft_supported(int n_fft);
 int s2st_gl_polar_c(const float* mag, const float* ang, const int* tl, float* X, int U, int F, int Tmax, hipStream_t st);
+// initial phases from uniform draws (uni: utterance u's [F][T_u] block at uni + uoff[u], doubles as numpy drew them) or, uni ==
+// nullptr, from the device's counter-based generator
+int s2st_exp_inplace(float* x, long n, hipStream_t st);
+int s2st_gl_polar_u(const float* mag, const double* uni, const long* uoff, const int* tl, uint64_t seed, float* X, int U, int F,
+                    int Tmax, hipStream_t st);
 int s2st_gl_stft_project(const float* wave, const int* tl, const float* win, const float* tw, const float* mag, float* X, int U,
                          int Tmax, int n_fft, int hop, int Lw, hipStream_t st);
 int s2st_gl_istft_frames(const float* X, const int* tl, const float* win, const float* tw, float* frames, int U, int Tmax,

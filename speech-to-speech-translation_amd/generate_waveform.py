@@ -55,6 +55,9 @@ def make_parser() -> argparse.ArgumentParser:
     a("--eos-prob-threshold", type=float, default=0.5)
     a("--vocoder", default="griffin_lim", choices=["griffin_lim"])
     a("--spec-bwd-max-iter", type=int, default=8)
+    a("--gl-phase-rng", default="numpy", choices=["numpy", "device"],
+      help="initial Griffin-Lim phases: numpy's global generator (the reference's draws, vocoder.py:101-102) or the device's "
+           "counter-based generator (same distribution, no host work)")
     a("--dump-features", action="store_true")
     a("--dump-waveforms", action="store_true")
     a("--dump-attentions", action="store_true")
@@ -153,6 +156,7 @@ def main(argv: Optional[List[str]] = None, device: Optional[torch.device] = None
     margs.data, margs.config_yaml = args.data, args.config_yaml
     margs.eos_prob_threshold = args.eos_prob_threshold
     margs.spec_bwd_max_iter = args.spec_bwd_max_iter
+    margs.gl_phase_rng = args.gl_phase_rng
     margs.precise_gemm = bool(args.precise_gemm)
     margs.eval_inference = False
     margs.train_subset = None

@@ -173,7 +173,8 @@ class S2ST_TranslationTask(TaskBase):  # fairseq's LegacyFairseqTask when fairse
             sample_rate=self.sr, win_size=int(getattr(a, "win_size", 1200)), hop_size=int(getattr(a, "hop_size", 300)),
             n_fft=int(getattr(a, "n_fft", 2048)), n_mels=int(getattr(a, "output_frame_dim", 80)),
             f_min=float(getattr(a, "f_min", 20.0)), f_max=float(getattr(a, "f_max", 8000.0)),
-            spec_bwd_max_iter=int(getattr(a, "spec_bwd_max_iter", 32)), device=self.device)
+            spec_bwd_max_iter=int(getattr(a, "spec_bwd_max_iter", 32)), device=self.device,
+            phase_rng=getattr(a, "gl_phase_rng", "numpy") or "numpy", seed=int(getattr(a, "seed", 1) or 1))
 
     def build_generator_tts(self, models, cfg, vocoder=None, **unused):
         """s2s_translation.py:186-204."""

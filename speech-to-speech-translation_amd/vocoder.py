@@ -3,7 +3,7 @@
 GriffinLimVocoder) with the same constructor arguments.
 
 The reference's STFT / inverse STFT are dense-DFT contractions (conv1d / conv_transpose1d with Fourier bases,
-audio_utils.py:259-271, vocoder.py:56-98).  Round 4: for power-of-two n_fft (256 ... 4096) they run as real FFTs in LDS
+audio_utils.py:259-271, vocoder.py:56-98).  Round 4: for power-of-two n_fft (256 ... 2048) they run as real FFTs in LDS
 (csrc/infer.hip: the analysis basis is rfft(window * frame), the pseudo-inverse synthesis basis is window * hop / n_fft *
 irfft -- exactly); other n_fft (and S2ST_GL_FFT=0) keep the dense form of rounds 1 - 3: GEMMs on the matrix cores (bf16x3
 "precise" mode: phase retrieval is precision-sensitive) around small HIP kernels for polar <-> rectangular conversion,
@@ -68,8 +68,18 @@ def random_phases(n_freq: int, n_frames: int) -> np.ndarray:
 
 
 class GriffinLim:
-    def __init__(self, n_fft: int, win_length: int, hop_length: int, n_iter: int, device, window_fn=torch.hann_window):
+    def __init__(self, n_fft: int, win_length: int, hop_length: int, n_iter: int, device, window_fn=torch.hann_window,
+                 phase_rng: str = "numpy", seed: int = 1):
+        """``phase_rng``: where the initial phases' uniform draws come from when the caller passes no ``angles`` --
+        "numpy" (default): numpy's global generator, one ``np.random.rand(F, T_u)`` per utterance in order, exactly the
+        reference's draws (vocoder.py:101-102: a seeded run reproduces the reference's waveform); "device": the counter-based
+        generator of the HIP library (``seed``, utterance, bin, frame) -- the same distribution without the ~1 ms per
+        utterance-second the host generator costs, for callers that do not need numpy's stream."""
         self.n_fft, self.win_length, self.hop_length, self.n_iter, self.device = n_fft, win_length, hop_length, n_iter, device
+        if phase_rng not in ("numpy", "device"):
+            raise ValueError("phase_rng must be 'numpy' or 'device'")
+        self.phase_rng, self.seed, self._calls = phase_rng, int(seed), 0
+        self._pin = None
         win = get_window(n_fft, win_length, window_fn)
         self.F = n_fft // 2 + 1
         self._dense = None  # the dense bases of the GEMM path: built on first use (a 2050 x 2048 pseudo-inverse at n_fft 2048)
@@ -141,10 +151,10 @@ class GriffinLim:
         np.angle(np.exp(2j*pi*np.random.rand(F, T))) from numpy's global RNG (vocoder.py:101-102)."""
         Fq, T = specgram.shape
         assert Fq == self.F
+        if self.use_fft:
+            return self.batch([specgram], None if angles is None else [angles])[0]
         if angles is None:
             angles = random_phases(Fq, T)
-        if self.use_fft:
-            return self.batch([specgram], [angles])[0]
         mag = specgram.to(self.device, torch.float32).contiguous()
         ang = torch.from_numpy(np.ascontiguousarray(angles, dtype=np.float32)).to(self.device)
         X = torch.empty(T, 2 * Fq, device=self.device)
@@ -179,28 +189,54 @@ class GriffinLim:
             self._bb = (fwd3, inv3)
         return self._bb
 
-    def batch(self, specgrams, angles=None):
+    def batch(self, specgrams, angles=None, mag_tm=None):
         """Several utterances at once: ``specgrams`` is a list of [F, T_u] magnitudes, the result the list
         of waveforms.  Griffin-Lim is sequential in its iterations but independent across utterances, so
         every STFT / inverse STFT is ONE GEMM over all utterances' frames (rows beyond an utterance's T_u
         are zero padding); the reference loops utterances (speech_generator.py:81-94 ->
         vocoder.py:100-123).  The GEMMs run on the bf16 kernel with the hi/lo split folded into K."""
-        U = len(specgrams)
+        Fq, Fp, hop, n_fft, dev = self.F, self.Fp, self.hop_length, self.n_fft, self.device
+        if mag_tm is not None:
+            # (the vocoder hands over the whole batch frame-major already: ``specgrams`` is then the list of frame counts)
+            Ts = [int(t) for t in specgrams]
+            U, Tmax = len(Ts), int(mag_tm.shape[1])
+            mag = mag_tm
+        else:
+            U = len(specgrams)
+            if U == 0:
+                return []
+            Ts = [int(s.shape[1]) for s in specgrams]
+            Tmax = max(Ts)
+            mag = torch.zeros(U, Tmax, Fq, device=dev)  # time-major: the kernels walk rows = frames
+            for u, s_ in enumerate(specgrams):
+                mag[u, :Ts[u]] = s_.to(dev, torch.float32).t()
         if U == 0:
             return []
-        Fq, Fp, hop, n_fft, dev = self.F, self.Fp, self.hop_length, self.n_fft, self.device
-        Ts = [int(s.shape[1]) for s in specgrams]
-        Tmax = max(Ts)
-        if angles is None:  # the reference's per-utterance draws from numpy's global RNG, in order
-            angles = [random_phases(Fq, T) for T in Ts]
-        ang_h = torch.zeros(U, Tmax, Fq, dtype=torch.float32)
-        for u, a_ in enumerate(angles):
-            ang_h[u, :Ts[u]] = torch.from_numpy(np.ascontiguousarray(a_, dtype=np.float32)).t()
-        ang = ang_h.to(dev)
-        mag = torch.zeros(U, Tmax, Fq, device=dev)  # time-major: the kernels walk rows = frames
-        for u, s_ in enumerate(specgrams):
-            mag[u, :Ts[u]] = s_.to(dev, torch.float32).t()
         tl = torch.tensor(Ts, dtype=torch.int32).to(dev)
+        uni = uoff = ang = None
+        if angles is None and self.use_fft:
+            # FFT path: the HOST only runs the generator (the reference's per-utterance draws from numpy's global RNG, in
+            # order, into one pinned buffer); wrapping to (-pi, pi], the cast, the transposition and mag * (cos, sin) are
+            # one kernel.  phase_rng="device": no host work at all.
+            if self.phase_rng == "numpy":
+                n_all = sum(Fq * T for T in Ts)
+                if self._pin is None or self._pin.numel() < n_all:
+                    self._pin = torch.empty(n_all, dtype=torch.float64, pin_memory=dev.type == "cuda")
+                host = self._pin.numpy()
+                offs, o = [], 0
+                for T in Ts:
+                    host[o:o + Fq * T] = np.random.rand(Fq, T).reshape(-1)
+                    offs.append(o)
+                    o += Fq * T
+                uni = self._pin[:n_all].to(dev, non_blocking=True)
+                uoff = torch.tensor(offs, dtype=torch.int64).to(dev)
+        else:
+            if angles is None:  # the reference's per-utterance draws from numpy's global RNG, in order
+                angles = [random_phases(Fq, T) for T in Ts]
+            ang_h = torch.zeros(U, Tmax, Fq, dtype=torch.float32)
+            for u, a_ in enumerate(angles):
+                ang_h[u, :Ts[u]] = torch.from_numpy(np.ascontiguousarray(a_, dtype=np.float32)).t()
+            ang = ang_h.to(dev)
         offs, tabs, o = [], [], 0
         for T in Ts:
             w = self._window_sum_square(T)
@@ -223,7 +259,11 @@ class GriffinLim:
                 bd.call("s2st_gl_istft_frames_f32", Xc, tl, win, tw, frames, U, Tmax, n_fft, hop)
                 bd.call("s2st_gl_overlap_add_b_f32", frames, wsq_all, wsq_off, tl, wave, U, Tmax, n_fft, hop, Lw)
 
-            bd.call("s2st_gl_polar_c_f32", mag, ang, tl, Xc, U, Fq, Tmax)
+            if ang is not None:
+                bd.call("s2st_gl_polar_c_f32", mag, ang, tl, Xc, U, Fq, Tmax)
+            else:
+                self._calls += 1
+                bd.call("s2st_gl_polar_u_f32", mag, uni, uoff, tl, (self.seed * 1000003 + self._calls) & ((1 << 63) - 1), Xc, U, Fq, Tmax)
             inverse_fft()
             for _ in range(self.n_iter):
                 bd.call("s2st_gl_stft_project_f32", wave, tl, win, tw, mag, Xc, U, Tmax, n_fft, hop, Lw)
@@ -252,12 +292,12 @@ class GriffinLim:
 
 class GriffinLimVocoder:
     def __init__(self, sample_rate, win_size, hop_size, n_fft, n_mels, f_min, f_max, window_fn=torch.hann_window,
-                 spec_bwd_max_iter=32, device=None):
+                 spec_bwd_max_iter=32, device=None, phase_rng: str = "numpy", seed: int = 1):
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.n_mels, self.F = n_mels, n_fft // 2 + 1
         basis = torch.pinverse(slaney_mel_filters(sample_rate, n_fft, n_mels, f_min, f_max))  # F x n_mels
         self.inv_mel = basis.contiguous().to(self.device)
-        self.gl = GriffinLim(n_fft, win_size, hop_size, spec_bwd_max_iter, self.device, window_fn)
+        self.gl = GriffinLim(n_fft, win_size, hop_size, spec_bwd_max_iter, self.device, window_fn, phase_rng=phase_rng, seed=seed)
 
     def __call__(self, x: torch.Tensor, angles: np.ndarray = None) -> torch.Tensor:
         """x [T, n_mels] log-mel -> waveform [1, N] (vocoder.py:136-144)."""
@@ -270,7 +310,20 @@ class GriffinLimVocoder:
         return self.gl(spec, angles).unsqueeze(0)
 
     def batch(self, xs, angles=None):
-        """List of [T_u, n_mels] log-mels -> list of [1, N_u] waveforms, all utterances per GEMM."""
+        """List of [T_u, n_mels] log-mels -> list of [1, N_u] waveforms, all utterances per launch."""
+        if self.gl.use_fft and len(xs) > 0:
+            # the whole padded batch at once: exp -> pseudo-inverse mel (one bf16x3 GEMM, frame-major result = the layout
+            # the Griffin-Lim kernels walk) -> clamp; rounds 1 - 3 ran three launches and two copies per utterance
+            Ts = [int(x.shape[0]) for x in xs]
+            U, Tmax, C_ = len(xs), max(Ts), int(xs[0].shape[1])
+            pad = torch.zeros(U, Tmax, C_, device=self.device)
+            for u, x in enumerate(xs):
+                pad[u, :Ts[u]] = x.to(self.device, torch.float32)
+            bd.call("s2st_exp_inplace_f32", pad, U * Tmax * C_)
+            mag = torch.empty(U, Tmax, self.F, device=self.device)
+            bd.gemm(pad.view(U * Tmax, C_), self.inv_mel, mag.view(U * Tmax, self.F), U * Tmax, self.F, C_, precise=True)
+            bd.call("s2st_clamp_min_f32", mag, U * Tmax * self.F, 0.0)
+            return [w.unsqueeze(0) for w in self.gl.batch(Ts, angles, mag_tm=mag)]
         specs = []
         for x in xs:
             T, C_ = x.shape
@@ -289,4 +342,5 @@ class GriffinLimVocoder:
                    hop_size=int(feat_cfg["hop_len_t"] * feat_cfg["sample_rate"]), n_fft=feat_cfg["n_fft"],
                    n_mels=feat_cfg["n_mels"], f_min=feat_cfg["f_min"], f_max=feat_cfg["f_max"],
                    window_fn=getattr(torch, feat_cfg["window_fn"] + "_window"),
-                   spec_bwd_max_iter=getattr(args, "spec_bwd_max_iter", 32), device=device)
+                   spec_bwd_max_iter=getattr(args, "spec_bwd_max_iter", 32), device=device,
+                   phase_rng=getattr(args, "gl_phase_rng", "numpy") or "numpy", seed=int(getattr(args, "seed", 1) or 1))

@@ -367,3 +367,43 @@ def test_fft_griffin_lim_kernels(backend, golden_dir, monkeypatch, n_fft, win, h
         backend.sync()
         scale = float(np.abs(ref).max())
         assert e_fft < 2e-4 * scale and e_dense < 2e-3 * scale, (e_fft / scale, e_dense / scale)
+
+
+def test_initial_phases_numpy_stream_and_device_generator(backend):
+    """Round 4: the host only RUNS numpy's generator; wrap / cast / transposition / mag * (cos, sin) are one kernel.  (1) The
+    default (phase_rng="numpy") path with a seeded global RNG == passing the reference's angles explicitly (same draws, same
+    double-precision wrap: waveforms equal to fp32 rounding); (2) phase_rng="device": reproducible per (seed, call), another
+    waveform than numpy's stream, and its phases are uniform on (-pi, pi] (mean resultant length ~ 0, all four quadrants)."""
+    V = importlib.import_module(PKG + ".vocoder")
+    rs = np.random.RandomState(1)
+    specs = [torch.from_numpy(np.abs(rs.randn(129, t)).astype(np.float32)) for t in (21, 12)]
+    gl = V.GriffinLim(256, 200, 64, 2, backend.device)
+    np.random.seed(9)
+    a = gl.batch(specs)
+    np.random.seed(9)
+    angles = [V.random_phases(129, int(s.shape[1])) for s in specs]
+    b = gl.batch(specs, angles)
+    backend.sync()
+    for x, y in zip(a, b):
+        assert float((x - y).abs().max()) <= 1e-6 * float(y.abs().max())
+    gd = V.GriffinLim(256, 200, 64, 0, backend.device, phase_rng="device", seed=5)
+    w1 = gd.batch(specs)
+    gd2 = V.GriffinLim(256, 200, 64, 0, backend.device, phase_rng="device", seed=5)
+    w2 = gd2.batch(specs)
+    w3 = gd2.batch(specs)  # the next call of the same object draws new phases
+    backend.sync()
+    assert all(torch.equal(x, y) for x, y in zip(w1, w2)) and not torch.equal(w2[0], w3[0])
+    assert not torch.equal(w1[0].cpu(), a[0].cpu())
+    # the phases themselves: X = mag * exp(i phase) with mag = 1
+    ones = torch.ones(1, 64, 129, device=backend.device)
+    X = torch.empty(64, 129, 2, device=backend.device)
+    tl = torch.tensor([64], dtype=torch.int32).to(backend.device)
+    backend.bd.call("s2st_gl_polar_u_f32", ones, None, None, tl, 1234, X, 1, 129, 64)
+    backend.sync()
+    z = X.cpu().double()
+    ph = torch.atan2(z[..., 1], z[..., 0]).reshape(-1)
+    n = ph.numel()
+    assert float((z[..., 0] ** 2 + z[..., 1] ** 2 - 1).abs().max()) < 1e-5
+    assert abs(float(torch.cos(ph).mean())) < 4.5 / (2 * n) ** 0.5 and abs(float(torch.sin(ph).mean())) < 4.5 / (2 * n) ** 0.5
+    for lo in (-np.pi, -np.pi / 2, 0.0, np.pi / 2):
+        assert abs(float(((ph > lo) & (ph <= lo + np.pi / 2)).double().mean()) - 0.25) < 4.5 * (0.25 * 0.75 / n) ** 0.5
