@@ -1302,12 +1302,20 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
       xr[mt] = A + (long)min(16 * mt + (tid >> 4), M - 1) * lda;
       s[mt] = q[mt] = 0.f;
     }
-    for (int c = 4 * j; c < K; c += 64) {
+    // (UL chunks of 64 columns per trip, all their loads issued before the first add: a pass is K / (64 UL) memory round
+    // trips -- two at K = 512 -- instead of K / 64; the summation order over c is unchanged)
+    constexpr int UL = MT >= 4 ? 4 : 8;
+    for (int c0 = 4 * j; c0 < K; c0 += 64 * UL) {
+      float4 v[UL][MT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const float4 v = *reinterpret_cast<const float4*>(xr[mt] + c);
-        s[mt] += v.x + v.y + v.z + v.w;
-      }
+      for (int u = 0; u < UL; ++u)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) v[u][mt] = *reinterpret_cast<const float4*>(xr[mt] + min(c0 + 64 * u, K - 4));
+#pragma unroll
+      for (int u = 0; u < UL; ++u)
+        if (c0 + 64 * u < K)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) s[mt] += v[u][mt].x + v[u][mt].y + v[u][mt].z + v[u][mt].w;
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -1315,13 +1323,20 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
       t += __shfl_xor(t, 8); t += __shfl_xor(t, 4); t += __shfl_xor(t, 2); t += __shfl_xor(t, 1);
       mean[mt] = t / K;
     }
-    for (int c = 4 * j; c < K; c += 64) {
+    for (int c0 = 4 * j; c0 < K; c0 += 64 * UL) {
+      float4 v[UL][MT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const float4 v = *reinterpret_cast<const float4*>(xr[mt] + c);
-        const float a = v.x - mean[mt], b = v.y - mean[mt], cc = v.z - mean[mt], d = v.w - mean[mt];
-        q[mt] += a * a + b * b + cc * cc + d * d;
-      }
+      for (int u = 0; u < UL; ++u)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) v[u][mt] = *reinterpret_cast<const float4*>(xr[mt] + min(c0 + 64 * u, K - 4));
+#pragma unroll
+      for (int u = 0; u < UL; ++u)
+        if (c0 + 64 * u < K)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const float a = v[u][mt].x - mean[mt], b = v[u][mt].y - mean[mt], cc = v[u][mt].z - mean[mt], d = v[u][mt].w - mean[mt];
+            q[mt] += a * a + b * b + cc * cc + d * d;
+          }
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {

@@ -57,7 +57,44 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
   const int g = tid >> 4, l4 = (tid & 15) * 4;
   // (4 keys per thread and pass, loads clamped instead of predicated so that they issue back to back:
   // the kernel is a chain of memory latencies otherwise)
+  // (round 4: 8 keys per thread and pass -- 128 keys per workgroup and pass, every load of a pass issued before the first
+  // multiply: the ~350 encoder positions of a cross-attention are 3 memory round trips instead of 6 x 2)
+  constexpr int KP = 8;
   float mx = -INFINITY;
+  if (dh <= 128 && dh % 64 == 0) {
+    const int nd = dh / 64;  // 1 or 2 float4 chunks per lane
+    for (int s0 = 0; s0 < n; s0 += 16 * KP) {
+      float4 kv[2][KP];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < KP; ++i)
+          kv[c][i] = *reinterpret_cast<const float4*>(kb + (long)min(s0 + g + 16 * i, n - 1) * ldk + min(l4 + 64 * c, dh - 4));
+      float a[KP];
+#pragma unroll
+      for (int i = 0; i < KP; ++i) a[i] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (c >= nd) break;
+        const float4 qv = *reinterpret_cast<const float4*>(qs + l4 + 64 * c);
+#pragma unroll
+        for (int i = 0; i < KP; ++i) a[i] += qv.x * kv[c][i].x + qv.y * kv[c][i].y + qv.z * kv[c][i].z + qv.w * kv[c][i].w;
+      }
+#pragma unroll
+      for (int i = 0; i < KP; ++i) {
+        float v = a[i];
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 1);
+        const int s = s0 + g + 16 * i;
+        if (s < n) {
+          if (l4 == 0) p[s] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+    }
+  } else
   for (int s0 = 0; s0 < n; s0 += 64) {
     float a[4] = {0.f, 0.f, 0.f, 0.f};
     for (int d = l4; d < dh; d += 64) {
@@ -95,17 +132,17 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
   // o: 16 key slices x (16 lanes x float4) per 64 head columns, slices combined in a fixed order
   for (int d = l4; d < dh; d += 64) {
     float4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int s0 = 0; s0 < n; s0 += 64) {
-      float4 vv[4];
-      float w[4];
+    for (int s0 = 0; s0 < n; s0 += 16 * KP) {  // (8 value rows per thread in flight; same accumulation order as before)
+      float4 vv[KP];
+      float w[KP];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < KP; ++i) {
         const int s = s0 + g + 16 * i;
         vv[i] = *reinterpret_cast<const float4*>(vb + (long)min(s, n - 1) * ldk + d);
         w[i] = s < n ? p[s] : 0.f;
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < KP; ++i) {
         acc.x += w[i] * vv[i].x; acc.y += w[i] * vv[i].y; acc.z += w[i] * vv[i].z; acc.w += w[i] * vv[i].w;
       }
     }

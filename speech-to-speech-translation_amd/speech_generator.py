@@ -88,6 +88,9 @@ class AutoRegressiveSpeechGenerator(SpeechGenerator):
         finished = torch.zeros(bsz, dtype=torch.bool)
         out_lens = torch.full((bsz,), self.max_iter, dtype=torch.long)
         prev = torch.zeros(bsz, out_dim, device=dev)  # bos frame
+        if self.vocoder is not None and hasattr(self.vocoder, "prefetch_phases"):
+            # the vocoder's random initial phases: numpy's generator starts running ahead while the GPU decodes
+            self.vocoder.prefetch_phases(bsz * self.max_iter * n_frames_per_step)
         for step in range(self.max_iter):
             cur_out_lens = out_lens.clone()
             cur_out_lens.masked_fill_(cur_out_lens.eq(self.max_iter), step + 1)

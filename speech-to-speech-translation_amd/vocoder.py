@@ -67,6 +67,58 @@ def random_phases(n_freq: int, n_frames: int) -> np.ndarray:
     return np.where(th > np.pi, th - 2.0 * np.pi, th)
 
 
+class _UniformStream:
+    """numpy's global generator, run AHEAD on a background thread.  ``np.random.rand(F, T_u)`` per utterance -- what the
+    reference's GriffinLim draws (vocoder.py:101-102) -- is just the next F * T_u doubles of one stream, whatever the shapes;
+    only their number is unknown until the decoder has stopped.  So while the GPU decodes, a private generator started from
+    the global one's state fills a pinned buffer with an upper bound of draws (numpy releases the GIL inside the fill),
+    keeping a state snapshot every chunk.  ``take(n)`` hands out the first n and leaves the GLOBAL generator exactly where
+    n sequential draws would have left it (nearest snapshot + the remainder drawn for real) -- provided nobody else used
+    the global generator in between, else it returns None and the caller draws the ordinary way."""
+    CHUNK = 1 << 20
+
+    def __init__(self, n_upper: int, pin: bool):
+        import threading
+        self.state0 = np.random.get_state()
+        self.n = int(n_upper)
+        self.buf = torch.empty(max(self.n, 1), dtype=torch.float64, pin_memory=pin)
+        self.host = self.buf.numpy()
+        self.snaps = []
+        self.produced = 0
+        self.cv = threading.Condition()
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        rs = np.random.RandomState()
+        rs.set_state(self.state0)
+        pos = 0
+        while pos < self.n:
+            m = min(self.CHUNK, self.n - pos)
+            snap = rs.get_state()
+            self.host[pos:pos + m] = rs.random_sample(m)
+            with self.cv:
+                self.snaps.append((pos, snap))
+                self.produced = pos + m
+                self.cv.notify_all()
+            pos += m
+
+    def take(self, n: int):
+        cur = np.random.get_state()
+        same = cur[0] == self.state0[0] and cur[2] == self.state0[2] and np.array_equal(cur[1], self.state0[1]) \
+            and cur[3] == self.state0[3] and cur[4] == self.state0[4]
+        if n > self.n or not same:
+            return None
+        with self.cv:
+            while self.produced < n:
+                self.cv.wait(0.05)
+            pos, snap = max((ps for ps in self.snaps if ps[0] <= n), key=lambda ps: ps[0]) if n > 0 else (0, self.state0)
+        np.random.set_state(snap)
+        if n > pos:
+            np.random.random_sample(n - pos)  # (advance the global generator by the remainder: < one chunk)
+        return self.buf[:n]
+
+
 class GriffinLim:
     def __init__(self, n_fft: int, win_length: int, hop_length: int, n_iter: int, device, window_fn=torch.hann_window,
                  phase_rng: str = "numpy", seed: int = 1):
@@ -80,6 +132,8 @@ class GriffinLim:
             raise ValueError("phase_rng must be 'numpy' or 'device'")
         self.phase_rng, self.seed, self._calls = phase_rng, int(seed), 0
         self._pin = None
+        self._stream = None
+
         win = get_window(n_fft, win_length, window_fn)
         self.F = n_fft // 2 + 1
         self._dense = None  # the dense bases of the GEMM path: built on first use (a 2050 x 2048 pseudo-inverse at n_fft 2048)
@@ -93,6 +147,14 @@ class GriffinLim:
         import os
         fn = bd.lib().s2st_gl_fft_supported_i32
         self.use_fft = bool(fn(int(n_fft))) and os.environ.get("S2ST_GL_FFT", "1") != "0"
+
+    def prefetch_phases(self, n_frames_upper: int):
+        """Called by the speech generator BEFORE it decodes (``n_frames_upper``: an upper bound of the frames the batch
+        will vocode): with phase_rng="numpy" and the FFT path, numpy's generator starts running ahead on a background
+        thread (``_UniformStream``) so that its ~3 ns per draw -- 45 M draws for 64 utterances -- hide under the decode."""
+        self._stream = None
+        if self.phase_rng == "numpy" and self.use_fft and n_frames_upper > 0:
+            self._stream = _UniformStream(self.F * int(n_frames_upper), self.device.type == "cuda")
 
     @property
     def fwd(self):
@@ -220,15 +282,20 @@ class GriffinLim:
             # one kernel.  phase_rng="device": no host work at all.
             if self.phase_rng == "numpy":
                 n_all = sum(Fq * T for T in Ts)
-                if self._pin is None or self._pin.numel() < n_all:
-                    self._pin = torch.empty(n_all, dtype=torch.float64, pin_memory=dev.type == "cuda")
-                host = self._pin.numpy()
                 offs, o = [], 0
                 for T in Ts:
-                    host[o:o + Fq * T] = np.random.rand(Fq, T).reshape(-1)
                     offs.append(o)
                     o += Fq * T
-                uni = self._pin[:n_all].to(dev, non_blocking=True)
+                ahead, self._stream = (self._stream.take(n_all) if self._stream is not None else None), None
+                if ahead is not None:  # drawn while the decoder ran (prefetch_phases)
+                    uni = ahead.to(dev, non_blocking=True)
+                else:
+                    if self._pin is None or self._pin.numel() < n_all:
+                        self._pin = torch.empty(n_all, dtype=torch.float64, pin_memory=dev.type == "cuda")
+                    host = self._pin.numpy()
+                    for T, o in zip(Ts, offs):
+                        host[o:o + Fq * T] = np.random.rand(Fq, T).reshape(-1)
+                    uni = self._pin[:n_all].to(dev, non_blocking=True)
                 uoff = torch.tensor(offs, dtype=torch.int64).to(dev)
         else:
             if angles is None:  # the reference's per-utterance draws from numpy's global RNG, in order
@@ -308,6 +375,9 @@ class GriffinLimVocoder:
         bd.gemm(self.inv_mel, xt, spec, self.F, T, C_, b_kmajor=False, b_ld=T, precise=True)
         bd.call("s2st_clamp_min_f32", spec, self.F * T, 0.0)
         return self.gl(spec, angles).unsqueeze(0)
+
+    def prefetch_phases(self, n_frames_upper: int):
+        self.gl.prefetch_phases(n_frames_upper)
 
     def batch(self, xs, angles=None):
         """List of [T_u, n_mels] log-mels -> list of [1, N_u] waveforms, all utterances per launch."""

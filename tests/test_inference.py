@@ -407,3 +407,36 @@ def test_initial_phases_numpy_stream_and_device_generator(backend):
     assert abs(float(torch.cos(ph).mean())) < 4.5 / (2 * n) ** 0.5 and abs(float(torch.sin(ph).mean())) < 4.5 / (2 * n) ** 0.5
     for lo in (-np.pi, -np.pi / 2, 0.0, np.pi / 2):
         assert abs(float(((ph > lo) & (ph <= lo + np.pi / 2)).double().mean()) - 0.25) < 4.5 * (0.25 * 0.75 / n) ** 0.5
+
+
+def test_uniform_stream_runs_numpy_ahead_and_leaves_its_state_exact(backend):
+    """Round 4: numpy's global generator run ahead on a background thread while the GPU decodes (vocoder._UniformStream).
+    The draws handed out are the ones sequential ``np.random.rand`` calls would have produced, the global generator ends
+    where they would have left it (the next draw agrees), and a stream whose generator somebody else touched declines."""
+    V = importlib.import_module(PKG + ".vocoder")
+    np.random.seed(21)
+    ref = [np.random.rand(129, t) for t in (7, 13, 5)]
+    nxt = np.random.rand(4)
+    np.random.seed(21)
+    st = V._UniformStream(129 * 40 + (3 << 20), False)  # (upper bound beyond three chunks: snapshots are exercised)
+    n = sum(r.size for r in ref)
+    got = st.take(n).numpy()
+    assert np.array_equal(got, np.concatenate([r.reshape(-1) for r in ref]))
+    assert np.array_equal(np.random.rand(4), nxt)
+    np.random.seed(21)
+    st2 = V._UniformStream(1000, False)
+    np.random.rand(1)  # someone else draws in between
+    assert st2.take(10) is None
+    # through the vocoder: prefetch + batch == plain batch, same seed
+    gl = V.GriffinLim(256, 200, 64, 1, backend.device)
+    rs = np.random.RandomState(1)
+    specs = [torch.from_numpy(np.abs(rs.randn(129, t)).astype(np.float32)) for t in (21, 12)]
+    np.random.seed(4)
+    a = gl.batch(specs)
+    tail_a = np.random.rand(2)
+    np.random.seed(4)
+    gl.prefetch_phases(100)
+    b = gl.batch(specs)
+    tail_b = np.random.rand(2)
+    backend.sync()
+    assert all(torch.equal(x, y) for x, y in zip(a, b)) and np.array_equal(tail_a, tail_b)
