@@ -431,6 +431,11 @@ int s2st_gl_frame_split_f32(const float* wave, const int32_t* tl, void* As, int3
  * s2st_gl_polar_c_f32: X = mag * exp(i ang) (vocoder.py:101-103).  s2st_gl_stft_project_f32: reflect-pad + frame + window +
  * rfft of wave [U][Lw], then X = mag * Y / |Y| (vocoder.py:104-107).  s2st_gl_istft_frames_f32: synthesis frames
  * [U * Tmax][n_fft] for s2st_gl_overlap_add_b_f32. */
+/* The AR generator's stop rule on the device (fairseq/speech_generator_for_s2st.py:84-99): after decoding step `step`,
+ * finished |= eos_prob > thr, out_lens of the utterances that just finished = step + 1 (initial value max_iter = "still
+ * running"), klen_next = the key lengths the NEXT step's self-attention masks with (:84-85), n_done[step] = how many are
+ * finished.  The host reads n_done a few steps late and drops the steps it ran past the stop: no synchronisation per step. */
+int s2st_decode_stop_update_i32(const float* eos_prob, float thr, int32_t step, int32_t max_iter, int32_t B, int32_t* finished, int32_t* out_lens, int32_t* klen_next, int32_t* n_done, void* stream);
 int s2st_gl_fft_supported_i32(int32_t n_fft);
 int s2st_gl_polar_c_f32(const float* mag, const float* ang, const int32_t* tl, float* X, int32_t U, int32_t F, int32_t Tmax, void* stream);
 /* initial phases (vocoder.py:101-102) from the uniform draws themselves: uniform = the doubles numpy's generator produced, utterance

@@ -193,6 +193,9 @@ int s2st_gl_polar_split_f32(const float* mag, const float* aux, int32_t from_spe
 int s2st_gl_frame_split_f32(const float* wave, const int32_t* tl, void* As, int32_t U, int32_t Tmax, int32_t hop, int32_t n_fft, int32_t Lw, void* stream) {
   return s2st_gl_frame_split(wave, tl, (uint16_t*)As, U, Tmax, hop, n_fft, Lw, (hipStream_t)stream);
 }
+int s2st_decode_stop_update_i32(const float* eos_prob, float thr, int32_t step, int32_t max_iter, int32_t B, int32_t* finished, int32_t* out_lens, int32_t* klen_next, int32_t* n_done, void* stream) {
+  return s2st_decode_stop_update(eos_prob, thr, step, max_iter, B, finished, out_lens, klen_next, n_done, (hipStream_t)stream);
+}
 int s2st_gl_fft_supported_i32(int32_t n_fft) { return s2st_gl_fft_supported(n_fft) ? 1 : 0; }
 int s2st_gl_polar_c_f32(const float* mag, const float* ang, const int32_t* tl, float* X, int32_t U, int32_t F, int32_t Tmax, void* stream) {
   return s2st_gl_polar_c(mag, ang, tl, X, U, F, Tmax, (hipStream_t)stream);

@@ -1289,6 +1289,18 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n0 = blockIdx.x * 16;
   const int kc = (lane >> 4) * 8;
+  {
+    // blockIdx.y: the block of 16 MT rows this workgroup owns.  More than 16 rows (round 4: up to 64 utterances per
+    // decoding step) are split over workgroups rather than looped over inside one: a workgroup that owns ALL rows reads
+    // all of A through one CU's load path (~30 B / clk measured: fc2 at 64 rows 19.3 us against 7.7 us at 16,
+    // profiles/r04_skinny_bench.txt), while its 16 weight columns are an L2 hit for the other row blocks anyway.
+    const int mb = blockIdx.y * 16 * MT;
+    A += (long)mb * lda;
+    C += (long)mb * ldc;
+    if (resid) resid += (long)mb * ldr;
+    M -= mb;
+  }
+  const int m_glob0 = blockIdx.y * 16 * MT;
   if (ln_g) {
     // fused LayerNorm of the activation rows (the decoder's pre-LN in front of a projection): every workgroup
     // recomputes the row statistics (L2-resident input) instead of a separate kernel + round trip.
@@ -1304,7 +1316,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
     }
     // (UL chunks of 64 columns per trip, all their loads issued before the first add: a pass is K / (64 UL) memory round
     // trips -- two at K = 512 -- instead of K / 64; the summation order over c is unchanged)
-    constexpr int UL = MT >= 4 ? 4 : 8;
+    constexpr int UL = 8;
     for (int c0 = 4 * j; c0 < K; c0 += 64 * UL) {
       float4 v[UL][MT];
 #pragma unroll
@@ -1359,9 +1371,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int steps = K >> 5;
-  constexpr int U = MT == 1 ? 4 : 2;  // K-steps in flight per wave and pass (registers: 2 float4 per row block and step)
+  constexpr int U = 4;  // K-steps in flight per wave and pass (2 float4 per row block and step; a decoding launch has at most
+                        // one workgroup per CU, so the 512-register budget of one wave per SIMD is there to be used)
   for (int s0 = wave; s0 < steps; s0 += 4 * U) {
-    float4 a0[U][MT], a1[U][MT];
+    float4 a0[U][MT], a1[U][MT], lg0[U], lg1[U], lb0[U], lb1[U];
     uint4 w[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -1372,18 +1385,18 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
         a1[u][mt] = *reinterpret_cast<const float4*>(arow[mt] + 32 * s + 4);
       }
       w[u] = *reinterpret_cast<const uint4*>(wrow + 32 * s);
+      if (ln_g) {  // (the step's gamma / beta chunks ride with its operand loads)
+        const int k = 32 * s + kc;
+        lg0[u] = *reinterpret_cast<const float4*>(ln_g + k); lg1[u] = *reinterpret_cast<const float4*>(ln_g + k + 4);
+        lb0[u] = *reinterpret_cast<const float4*>(ln_b + k); lb1[u] = *reinterpret_cast<const float4*>(ln_b + k + 4);
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (s0 + 4 * u >= steps) break;
       union { uint4 q; bf16x8 v; } xa, wb;
       wb.q = w[u];
-      float4 g0, g1, b0, b1;
-      if (ln_g) {
-        const int k = 32 * (s0 + 4 * u) + kc;
-        g0 = *reinterpret_cast<const float4*>(ln_g + k); g1 = *reinterpret_cast<const float4*>(ln_g + k + 4);
-        b0 = *reinterpret_cast<const float4*>(ln_b + k); b1 = *reinterpret_cast<const float4*>(ln_b + k + 4);
-      }
+      const float4 g0 = lg0[u], g1 = lg1[u], b0 = lb0[u], b1 = lb1[u];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         float4 p0 = a0[u][mt], p1 = a1[u][mt];
@@ -1408,6 +1421,44 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
   if (wave > 0) return;
   const int n = n0 + (lane >> 4) * 4;
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  // Four whole columns per lane and 16-byte aligned rows (every product of a decoding step but the 1-wide stop head): the
+  // bias and ALL row blocks' residual rows are fetched as float4 before the first use.  The first form loaded them
+  // element by element behind the `n + r < N` test: 4 MT dependent round trips, ~0.55 us each -- the whole difference
+  // between 16 and 64 rows (out-proj + residual 4.4 -> 11.1 us, profiles/r04_skinny_bench.txt).
+  const bool vec4 = n + 3 < N && (ldc & 3) == 0 && (ldr & 3) == 0 && ((uintptr_t)C & 15) == 0 &&
+                    (!resid || ((uintptr_t)resid & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0) && (n0 & 3) == 0;
+  if (vec4) {
+    float4 bv = {0.f, 0.f, 0.f, 0.f}, rv[MT];
+    if (bias) bv = *reinterpret_cast<const float4*>(bias + n);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = min(16 * mt + (lane & 15), M - 1);
+      rv[mt] = resid ? *reinterpret_cast<const float4*>(resid + (long)m * ldr + n) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int w = 0; w < 3; ++w) {
+        const f32x4 p = *reinterpret_cast<const f32x4*>(&part[w][(mt * 64 + lane) * 4]);
+        acc[mt][0] += p[0]; acc[mt][1] += p[1]; acc[mt][2] += p[2]; acc[mt][3] += p[3];
+      }
+      const int m = 16 * mt + (lane & 15);
+      if (m >= M) continue;
+      float v[4] = {acc[mt][0] + bv.x, acc[mt][1] + bv.y, acc[mt][2] + bv.z, acc[mt][3] + bv.w};
+      const float rr[4] = {rv[mt].x, rv[mt].y, rv[mt].z, rv[mt].w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x = v[r];
+        if (act == 1) x = fmaxf(x, 0.f);
+        else if (act == 2) x = gelu_erf(x);
+        else if (act == 3) x = 1.f / (1.f + __expf(-x));
+        if (drop_p > 0.f) x *= drop_scale(seed, (uint64_t)(m_glob0 + m) * (uint64_t)N + n + r, drop_p, inv_keep);
+        v[r] = x + rr[r];
+      }
+      *reinterpret_cast<float4*>(C + (long)m * ldc + n) = float4{v[0], v[1], v[2], v[3]};
+    }
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -1426,7 +1477,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
       if (act == 1) x = fmaxf(x, 0.f);
       else if (act == 2) x = gelu_erf(x);
       else if (act == 3) x = 1.f / (1.f + __expf(-x));
-      if (drop_p > 0.f) x *= drop_scale(seed, (uint64_t)m * (uint64_t)N + n + r, drop_p, inv_keep);
+      if (drop_p > 0.f) x *= drop_scale(seed, (uint64_t)(m_glob0 + m) * (uint64_t)N + n + r, drop_p, inv_keep);
       if (resid) x += resid[(long)m * ldr + n + r];
       C[(long)m * ldc + n + r] = x;
     }
@@ -1445,17 +1496,9 @@ int s2st_gemm_skinny(const float* A, long lda, const bf16raw* W, long ldw, float
   // bytes the launch has to move: the bf16 weight rows once, the fp32 activation rows, the result (+ residual)
   const double by = 2.0 * N * K + 4.0 * M * K + 4.0 * M * N * (resid ? 2 : 1);
   const double fl = 2.0 * M * N * (double)K;
-  const dim3 grid((N + 15) / 16), block(256);
+  const dim3 grid((N + 15) / 16, (M + 15) / 16), block(256);  // (16 columns) x (16 rows) per workgroup
   const bf16_t* Wp = reinterpret_cast<const bf16_t*>(W);
-  const int mt = (M + 15) / 16;
-  if (mt == 1)
-    s2st_launch("gemm_skinny_kernel", by, fl, gemm_skinny_kernel<1>, grid, block, 0, st, A, lda, Wp, ldw, C, ldc, bias, act, drop_p,
-                seed, resid, ldr, M, N, K, ln_g, ln_b, ln_eps);
-  else if (mt == 2)
-    s2st_launch("gemm_skinny_kernel", by, fl, gemm_skinny_kernel<2>, grid, block, 0, st, A, lda, Wp, ldw, C, ldc, bias, act, drop_p,
-                seed, resid, ldr, M, N, K, ln_g, ln_b, ln_eps);
-  else
-    s2st_launch("gemm_skinny_kernel", by, fl, gemm_skinny_kernel<4>, grid, block, 0, st, A, lda, Wp, ldw, C, ldc, bias, act, drop_p,
-                seed, resid, ldr, M, N, K, ln_g, ln_b, ln_eps);
+  s2st_launch("gemm_skinny_kernel", by, fl, gemm_skinny_kernel<1>, grid, block, 0, st, A, lda, Wp, ldw, C, ldc, bias, act, drop_p,
+              seed, resid, ldr, M, N, K, ln_g, ln_b, ln_eps);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }

@@ -686,6 +686,44 @@ int s2st_scale_rows(const float* x, const float* a, float* y, long n, hipStream_
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
+namespace {
+// The generator's stop rule on the device (speech_generator_for_s2st.py:88-99), one workgroup: after step `step`
+//   cur_finished = eos_prob > thr ; out_lens[~finished & cur_finished] = step + 1 ; finished |= cur_finished
+// and the key lengths of the NEXT step's self-attention, cur_out_lens of :84-85 (out_lens with the "still running" value
+// max_iter replaced by step + 2).  n_done[step] = number of finished utterances after this step: the host reads it a few
+// steps late (no synchronisation inside the loop) and discards the steps it ran past the stop.
+__global__ __launch_bounds__(256) void decode_stop_update_kernel(const float* __restrict__ eos_prob, float thr, int step,
+                                                                 int max_iter, int B, int* __restrict__ finished,
+                                                                 int* __restrict__ out_lens, int* __restrict__ klen_next,
+                                                                 int* __restrict__ n_done) {
+  __shared__ int cnt[4];
+  int c = 0;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const int cur = eos_prob[b] > thr ? 1 : 0;
+    int f = finished[b], ol = out_lens[b];
+    if (!f && cur) ol = step + 1;
+    f |= cur;
+    finished[b] = f;
+    out_lens[b] = ol;
+    klen_next[b] = ol == max_iter ? step + 2 : ol;
+    c += f;
+  }
+  c = (int)wave_sum((float)c);
+  if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) n_done[step] = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+}
+}  // namespace
+
+int s2st_decode_stop_update(const float* eos_prob, float thr, int step, int max_iter, int B, int* finished, int* out_lens,
+                            int* klen_next, int* n_done, hipStream_t st) {
+  if (B <= 0) return 0;
+  if (!eos_prob || !finished || !out_lens || !klen_next || !n_done || step < 0) return S2ST_ERR_ARG;
+  S2ST_LAUNCH(decode_stop_update_kernel, dim3(1), dim3(256), 0, st, eos_prob, thr, step, max_iter, B, finished, out_lens, klen_next,
+              n_done);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+
 int s2st_sigmoid(const float* x, float* y, long n, hipStream_t st) {
   if (n <= 0) return 0;
   S2ST_LAUNCH(sigmoid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n);

@@ -274,6 +274,8 @@ int s2st_decode_attn(const float* q, long ldq, float* kc, float* vc, long ldk, l
                      hipStream_t st, const float* k_new = nullptr, const float* v_new = nullptr, long ld_new = 0,
                      int pos_new = 0);
 int s2st_scale_rows(const float* x, const float* a, float* y, long n, hipStream_t st);
+int s2st_decode_stop_update(const float* eos_prob, float thr, int step, int max_iter, int B, int* finished, int* out_lens,
+                            int* klen_next, int* n_done, hipStream_t st);
 int s2st_sigmoid(const float* x, float* y, long n, hipStream_t st);
 int s2st_argmax_dim1(const float* x, long* idx, int B, int E, int D, hipStream_t st);
 int s2st_affine_cols(const float* x, const float* scale, const float* shift, float* y, long rows, int C, hipStream_t st);

@@ -569,6 +569,39 @@ class Engine:
         o["encoder_lens"] = keep["enc_lens"]
         return o
 
+    def decode_buffers(self, max_steps: int):
+        """Whole-run buffers of an AR decode (round 4: nothing is allocated, filled or uploaded per step): outputs
+        ``feat`` [steps, B, out_dim] / ``eos`` [steps, B] / ``attn`` [steps, B, E], the positions of every step, and the stop
+        rule's device state (``finished``, ``out_lens`` = max_steps while running, ``klen`` = key lengths of the next step's
+        self-attention, ``n_done`` [steps])."""
+        d, dev, c = self._dec, self.device, self.cfg
+        B, E = d["B"], d["E"]
+        pos = (torch.arange(max_steps, dtype=torch.int32) + PAD + 1).view(-1, 1).expand(-1, B).contiguous().to(dev)
+        bufs = dict(feat=torch.empty(max_steps, B, c.out_dim, device=dev), eos=torch.empty(max_steps, B, device=dev),
+                    attn=torch.empty(max_steps, B, E, device=dev), pos=pos,
+                    finished=torch.zeros(B, dtype=torch.int32, device=dev),
+                    out_lens=torch.full((B,), max_steps, dtype=torch.int32, device=dev),
+                    klen=torch.ones(B, dtype=torch.int32, device=dev),  # step 0: one key
+                    n_done=torch.zeros(max_steps, dtype=torch.int32, device=dev),
+                    bos=torch.zeros(B, c.out_dim, device=dev))
+        d["bufs"] = bufs
+        return bufs
+
+    def decode_step_into(self, step: int, seed: int, thr: float, max_iter: int):
+        """Step ``step`` of a buffered decode: input = the previous step's feature row block (the zero frame at step 0),
+        outputs into the run's buffers, then the stop rule's update -- all stream-ordered, no host round trip."""
+        d, c = self._dec, self.cfg
+        b = d["bufs"]
+        prev = b["bos"] if step == 0 else b["feat"][step - 1]
+        f = self.lib.s2st_engine_decode_step
+        f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                      C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        bd.check(f(self.h, step, prev.data_ptr(), b["pos"][step].data_ptr(), b["klen"].data_ptr(), seed,
+                   b["feat"][step].data_ptr(), b["eos"][step].data_ptr(), b["attn"][step].data_ptr(),
+                   self.workspace.data_ptr(), self.workspace.numel(), bd.stream_ptr()), "s2st_engine_decode_step")
+        bd.call("s2st_decode_stop_update_i32", b["eos"][step], float(thr), step, int(max_iter), d["B"], b["finished"],
+                b["out_lens"], b["klen"], b["n_done"])
+
     def decode_step(self, step: int, prev: torch.Tensor, seed: int, want_attn: bool = True,
                     self_klen: Optional[torch.Tensor] = None):
         """prev [B, out_dim] -> (feature_out [B, out_dim], eos_prob [B], attn [B, E] | None)."""

@@ -84,31 +84,48 @@ class AutoRegressiveSpeechGenerator(SpeechGenerator):
         out_dim = c.out_dim
         raw_dim = out_dim // n_frames_per_step
         dev = eng.device
-        feat, attn, eos_prob = [], [], []
-        finished = torch.zeros(bsz, dtype=torch.bool)
-        out_lens = torch.full((bsz,), self.max_iter, dtype=torch.long)
-        prev = torch.zeros(bsz, out_dim, device=dev)  # bos frame
         if self.vocoder is not None and hasattr(self.vocoder, "prefetch_phases"):
             # the vocoder's random initial phases: numpy's generator starts running ahead while the GPU decodes
             self.vocoder.prefetch_phases(bsz * self.max_iter * n_frames_per_step)
+        # The loop of speech_generator_for_s2st.py:83-103 without a host round trip per step (round 4): the stop rule --
+        # finished flags, out_lens, the next step's key lengths -- is a one-workgroup kernel behind every step
+        # (s2st_decode_stop_update_i32), outputs land in whole-run buffers, and the host learns the number of finished
+        # utterances LAG steps late through pinned memory: it may enqueue up to LAG steps past the stop, which are then
+        # dropped (they only wrote rows nobody reads).  Same outputs as the step-by-step form (tests/test_inference.py).
+        LAG = 4
+        bufs = eng.decode_buffers(self.max_iter)
+        on_gpu = dev.type == "cuda"
+        pinned = torch.zeros(self.max_iter, dtype=torch.int32, pin_memory=on_gpu)
+        events = []
+        n_steps = self.max_iter
         for step in range(self.max_iter):
-            cur_out_lens = out_lens.clone()
-            cur_out_lens.masked_fill_(cur_out_lens.eq(self.max_iter), step + 1)
-            cur_feat, cur_eos, cur_attn = eng.decode_step(step, prev, self.seed * 1000003 + step,
-                                                          self_klen=cur_out_lens)
-            feat.append(cur_feat.unsqueeze(1))
-            attn.append(cur_attn.unsqueeze(2))
-            eos_prob.append(cur_eos.unsqueeze(1))
-            cur_finished = cur_eos.cpu() > self.eos_prob_threshold  # the stop rule needs the host every step
-            out_lens.masked_fill_((~finished) & cur_finished, step + 1)
-            finished = finished | cur_finished
-            if int(finished.sum()) == bsz:
-                break
-            prev = cur_feat
-        feat = torch.cat(feat, dim=1)
+            eng.decode_step_into(step, self.seed * 1000003 + step, self.eos_prob_threshold, self.max_iter)
+            pinned[step:step + 1].copy_(bufs["n_done"][step:step + 1], non_blocking=True)
+            if on_gpu:
+                ev = torch.cuda.Event()
+                ev.record()
+                events.append(ev)
+            look = step - LAG if on_gpu else step
+            if look >= 0:
+                if on_gpu:
+                    events[look].synchronize()
+                if int(pinned[look]) == bsz:
+                    n_steps = look + 1
+                    break
+        else:
+            if on_gpu:
+                torch.cuda.current_stream().synchronize()
+            done = (pinned == bsz).nonzero()
+            if done.numel():
+                n_steps = int(done[0]) + 1
+        # (the reference's out_lens after its loop: steps at which the utterances stopped, max_iter for those still running;
+        # an utterance that would have stopped only in a dropped run-ahead step is still running at the real stop)
+        out_lens = bufs["out_lens"].cpu().long()
+        out_lens = torch.where(out_lens > n_steps, torch.full_like(out_lens, self.max_iter), out_lens)
+        feat = bufs["feat"][:n_steps].transpose(0, 1).contiguous()          # [B, steps, out_dim]
+        eos_prob = bufs["eos"][:n_steps].transpose(0, 1).contiguous()        # [B, steps]
+        attn = bufs["attn"][:n_steps].permute(1, 2, 0).contiguous()          # [B, E, steps]
         feat = eng.postnet_eval(feat)  # postnet(feat) + feat, BatchNorm in eval mode
-        eos_prob = torch.cat(eos_prob, dim=1)
-        attn = torch.cat(attn, dim=2).contiguous()  # [B, E, D]
         alignment = torch.empty(bsz, attn.shape[2], dtype=torch.long, device=dev)
         bd.call("s2st_argmax_dim1_f32", attn, alignment, bsz, attn.shape[1], attn.shape[2])
         feat = self.gcmvn_denormalize(feat.reshape(bsz, -1, raw_dim))
