@@ -441,6 +441,14 @@ int s2st_gl_polar_c_f32(const float* mag, const float* ang, const int32_t* tl, f
 /* initial phases (vocoder.py:101-102) from the uniform draws themselves: uniform = the doubles numpy's generator produced, utterance
  * u's [F][T_u] block at uniform + offsets[u]; X = mag * exp(i wrap(2 pi u)).  uniform == NULL: the draws come from the device's
  * counter-based generator (seed): same distribution, not numpy's stream. */
+/* numpy's legacy generator (MT19937, np.random.random_sample / rand: one double per two 32-bit outputs) on the device: n
+ * doubles continuing from `state` -- S2ST_MT_STATE_WORDS (640) uint32: the 624 key words and the position of
+ * np.random.get_state(), then have_carry / carry (0 for a state taken from numpy; set in snapshot records) -- and the state
+ * numpy would be left in (same layout) -- what the reference's GriffinLim draws on the host (vocoder.py:101-102), draw
+ * for draw.  out == NULL: only the successor state.  snaps (optional, max_snaps records of 640 words): a resumable record
+ * after every snap_every regenerated 624-word blocks, for callers that generate ahead of knowing how many draws they need. */
+#define S2ST_MT_STATE_WORDS 640
+int s2st_mt19937_doubles_f64(const uint32_t* state, int64_t n, double* out, uint32_t* state_out, int32_t snap_every, uint32_t* snaps, int32_t max_snaps, void* stream);
 /* x <- exp(x) in place (vocoder.py:139 for a padded batch of log-mel frames) */
 int s2st_exp_inplace_f32(float* x, int64_t n, void* stream);
 int s2st_gl_polar_u_f32(const float* mag, const double* uniform, const int64_t* offsets, const int32_t* tl, uint64_t seed, float* X, int32_t U, int32_t F, int32_t Tmax, void* stream);

@@ -200,6 +200,9 @@ int s2st_gl_fft_supported_i32(int32_t n_fft) { return s2st_gl_fft_supported(n_ff
 int s2st_gl_polar_c_f32(const float* mag, const float* ang, const int32_t* tl, float* X, int32_t U, int32_t F, int32_t Tmax, void* stream) {
   return s2st_gl_polar_c(mag, ang, tl, X, U, F, Tmax, (hipStream_t)stream);
 }
+int s2st_mt19937_doubles_f64(const uint32_t* state, int64_t n, double* out, uint32_t* state_out, int32_t snap_every, uint32_t* snaps, int32_t max_snaps, void* stream) {
+  return s2st_mt19937_doubles(state, n, out, state_out, snap_every, snaps, max_snaps, (hipStream_t)stream);
+}
 int s2st_exp_inplace_f32(float* x, int64_t n, void* stream) { return s2st_exp_inplace(x, n, (hipStream_t)stream); }
 int s2st_gl_polar_u_f32(const float* mag, const double* uniform, const int64_t* offsets, const int32_t* tl, uint64_t seed, float* X, int32_t U, int32_t F, int32_t Tmax, void* stream) {
   return s2st_gl_polar_u(mag, uniform, (const long*)offsets, tl, seed, X, U, F, Tmax, (hipStream_t)stream);

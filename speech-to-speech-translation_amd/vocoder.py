@@ -119,6 +119,77 @@ class _UniformStream:
         return self.buf[:n]
 
 
+class _DeviceMTStream:
+    """numpy's global generator continued ON THE DEVICE (``s2st_mt19937_doubles_f64``: MT19937 + numpy's two-words-per-double
+    conversion, draw for draw -- tests/test_inference.py::test_device_mt19937_is_numpys_stream).  Started by
+    ``prefetch_phases`` on a side stream while the decoder runs: an upper bound of draws goes straight into device memory
+    (no host generator run, no upload), with a resumable snapshot every ``SNAP`` blocks.  ``take(n)`` returns the first n,
+    and puts the GLOBAL numpy generator into the state n sequential draws would have left it in (nearest snapshot + a short
+    output-less run on the device, one 2.5 KB read-back) -- unless somebody used the global generator in between (None)."""
+    SNAP = 256          # blocks of 624 words between snapshots (80 k doubles)
+    CAP = 1 << 26       # doubles generated ahead at most (512 MB); a longer request draws the rest afterwards
+
+    def __init__(self, n_upper: int, device):
+        self.dev = device
+        self.state0 = np.random.get_state()
+        self.n = int(min(n_upper, self.CAP))
+        w = np.zeros(640, dtype=np.uint32)
+        w[:624] = self.state0[1]
+        w[624] = self.state0[2]
+        self.first_words = 624 - int(self.state0[2])
+        self.state_dev = torch.from_numpy(w.view(np.int32)).to(device)
+        self.buf = torch.empty(max(self.n, 1), dtype=torch.float64, device=device)
+        n_blocks = (2 * self.n) // 624 + 2
+        self.max_snaps = n_blocks // self.SNAP + 1
+        self.snaps = torch.zeros(self.max_snaps * 640, dtype=torch.int32, device=device)
+        self.end_state = torch.zeros(640, dtype=torch.int32, device=device)
+        self.stream = torch.cuda.Stream(device=device) if device.type == "cuda" else None
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self._launch(self.state_dev, self.n, self.buf, self.end_state, self.SNAP, self.snaps, self.max_snaps)
+        else:
+            self._launch(self.state_dev, self.n, self.buf, self.end_state, self.SNAP, self.snaps, self.max_snaps)
+
+    @staticmethod
+    def _launch(state, n, out, state_out, snap_every, snaps, max_snaps):
+        bd.call("s2st_mt19937_doubles_f64", state, int(n), out, state_out, int(snap_every), snaps, int(max_snaps))
+
+    def take(self, n: int):
+        cur = np.random.get_state()
+        same = cur[0] == self.state0[0] and cur[2] == self.state0[2] and np.array_equal(cur[1], self.state0[1]) \
+            and cur[3] == self.state0[3] and cur[4] == self.state0[4]
+        if not same or n > self.n:
+            if self.stream is not None:
+                self.stream.synchronize()
+            return None
+        ctx = torch.cuda.stream(self.stream) if self.stream is not None else None
+        if ctx is not None:
+            ctx.__enter__()
+        try:
+            if n == self.n:
+                final = self.end_state
+            else:
+                # snapshot k is taken in front of regenerated block (k + 1) * SNAP: 624 ((k + 1) SNAP - 1) + first_words
+                # words -- whole doubles plus perhaps half a one (the record's carry) -- were consumed before it
+                k = (2 * n - self.first_words) // (624 * self.SNAP) - 1 if 2 * n >= self.first_words else -1
+                k = min(k, self.max_snaps - 1)
+                final = torch.zeros(640, dtype=torch.int32, device=self.dev)
+                if k >= 0:
+                    words = self.first_words + 624 * ((k + 1) * self.SNAP - 1)
+                    self._launch(self.snaps[k * 640:(k + 1) * 640], n - words // 2, None, final, 0, None, 0)
+                else:
+                    self._launch(self.state_dev, n, None, final, 0, None, 0)
+            so = final.cpu().numpy().view(np.uint32)  # (waits for the side stream only)
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+        np.random.set_state((self.state0[0], so[:624].copy(), int(so[624]), self.state0[3], self.state0[4]))
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        return self.buf[:n]
+
+
 class GriffinLim:
     def __init__(self, n_fft: int, win_length: int, hop_length: int, n_iter: int, device, window_fn=torch.hann_window,
                  phase_rng: str = "numpy", seed: int = 1):
@@ -150,11 +221,16 @@ class GriffinLim:
 
     def prefetch_phases(self, n_frames_upper: int):
         """Called by the speech generator BEFORE it decodes (``n_frames_upper``: an upper bound of the frames the batch
-        will vocode): with phase_rng="numpy" and the FFT path, numpy's generator starts running ahead on a background
-        thread (``_UniformStream``) so that its ~3 ns per draw -- 45 M draws for 64 utterances -- hide under the decode."""
+        will vocode): with phase_rng="numpy" and the FFT path, numpy's generator is continued on the device, on a side
+        stream, while the decoder runs (``_DeviceMTStream``; ``S2ST_GL_HOST_RNG=1``: on a host thread, ``_UniformStream``):
+        the ~3 ns per draw of the host generator -- 45 M draws for 64 utterances, more than the decode itself -- are gone."""
         self._stream = None
         if self.phase_rng == "numpy" and self.use_fft and n_frames_upper > 0:
-            self._stream = _UniformStream(self.F * int(n_frames_upper), self.device.type == "cuda")
+            import os
+            if os.environ.get("S2ST_GL_HOST_RNG", "0") == "1":  # (A/B switch: numpy itself, run ahead on a host thread)
+                self._stream = _UniformStream(self.F * int(n_frames_upper), self.device.type == "cuda")
+            else:
+                self._stream = _DeviceMTStream(self.F * int(n_frames_upper), self.device)
 
     @property
     def fwd(self):
@@ -288,7 +364,7 @@ class GriffinLim:
                     o += Fq * T
                 ahead, self._stream = (self._stream.take(n_all) if self._stream is not None else None), None
                 if ahead is not None:  # drawn while the decoder ran (prefetch_phases)
-                    uni = ahead.to(dev, non_blocking=True)
+                    uni = ahead if ahead.device == dev else ahead.to(dev, non_blocking=True)
                 else:
                     if self._pin is None or self._pin.numel() < n_all:
                         self._pin = torch.empty(n_all, dtype=torch.float64, pin_memory=dev.type == "cuda")

@@ -130,7 +130,9 @@ def test_frozen_tables_stay_out_of_the_optimizer(backend, tmp_path):
     s["net_input"]["speaker"] = s["speaker"]
     moved = {}
     for frozen in (True, False):
-        cfg = dict(MICRO, encoder_embed_dim=320, speaker_to_id=spk, speaker_embed_dim=320, speaker_embed_dim_dec=320)
+        cfg = dict(MICRO, encoder_embed_dim=320, speaker_to_id=spk, speaker_embed_dim=320, speaker_embed_dim_dec=320,
+                   encoder_transformer_layers=1, decoder_transformer_layers=1, encoder_ffn_embed_dim=64,
+                   decoder_ffn_embed_dim=64, middle_layers="0,0", asr_ce_weight=0.0, st_ce_weight=0.0, ctc_weight=0.0)
         a = O.make_args(**cfg)
         a.precise_gemm = True
         a.weight_decay, a.lr, a.warmup_updates, a.clip_norm = 0.1, [1e-2], 1, 1.0
@@ -148,7 +150,7 @@ def test_frozen_tables_stay_out_of_the_optimizer(backend, tmp_path):
         assert all(t in model.state_dict() for t in tabs)  # the checkpoint key stays either way
         before = {t: model._views[t].clone() for t in tabs}
         tr = trainer_mod.Trainer(a, task, model, task.build_criterion(a))
-        tr.train_step([s])
+        tr.train_step([s])  # (the first update runs at lr 0: linear warm-up from 0)
         tr.train_step([s])
         backend.sync()
         moved[frozen] = {t: float((model._views[t] - before[t]).abs().max()) for t in tabs}
