@@ -449,6 +449,11 @@ int s2st_gl_polar_c_f32(const float* mag, const float* ang, const int32_t* tl, f
  * after every snap_every regenerated 624-word blocks, for callers that generate ahead of knowing how many draws they need. */
 #define S2ST_MT_STATE_WORDS 640
 int s2st_mt19937_doubles_f64(const uint32_t* state, int64_t n, double* out, uint32_t* state_out, int32_t snap_every, uint32_t* snaps, int32_t max_snaps, void* stream);
+/* The same stream on the HOST, several threads (csrc/mt19937_host.cpp): `state` = 624 key words + position (625 uint32),
+ * out = n doubles in host memory (NULL: states only), bounds_out (optional) = (threads + 1) records of 625 words: the state
+ * in front of double n * t / threads, t = 0 .. threads.  Thread t reaches its share by running the recurrence alone. No GPU
+ * work: replaces the host-side np.random.rand of vocoder.py:101-102 (0.37 G draws/s on one core) draw for draw. */
+int s2st_mt19937_host_doubles(const uint32_t* state, int64_t n, double* out, uint32_t* bounds_out, int32_t threads);
 /* x <- exp(x) in place (vocoder.py:139 for a padded batch of log-mel frames) */
 int s2st_exp_inplace_f32(float* x, int64_t n, void* stream);
 int s2st_gl_polar_u_f32(const float* mag, const double* uniform, const int64_t* offsets, const int32_t* tl, uint64_t seed, float* X, int32_t U, int32_t F, int32_t Tmax, void* stream);

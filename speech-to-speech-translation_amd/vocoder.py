@@ -119,6 +119,60 @@ class _UniformStream:
         return self.buf[:n]
 
 
+class _HostMTStream:
+    """numpy's global generator continued by the library's own HOST generator (``s2st_mt19937_host_doubles``, csrc/
+    mt19937_host.cpp: MT19937 + numpy's two-words-per-double conversion, several threads -- each skips to its share by running
+    the recurrence alone, an order of magnitude faster than drawing), on a background thread (ctypes drops the GIL) into a
+    pinned buffer while the GPU decodes.  ``take(n)``: the first n draws, and the GLOBAL numpy generator left where n
+    sequential draws would have left it (the share boundary in front of n + a short output-less run) -- or None when somebody
+    used the global generator in between."""
+
+    def __init__(self, n_upper: int, pin: bool, threads: int = 0):
+        import os
+        import threading
+        self.state0 = np.random.get_state()
+        self.n = int(n_upper)
+        self.threads = int(threads) or max(1, min(8, (os.cpu_count() or 2) - 1))
+        self.buf = torch.empty(max(self.n, 1), dtype=torch.float64, pin_memory=pin)
+        w = np.zeros(625, dtype=np.uint32)
+        w[:624] = self.state0[1]
+        w[624] = self.state0[2]
+        self.state_w = w
+        self.bounds = np.zeros((self.threads + 1, 625), dtype=np.uint32)
+        self.rc = None
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        self.rc = _mt_host(self.state_w, self.n, self.buf.data_ptr(), self.bounds, self.threads)
+
+    def take(self, n: int):
+        self.thread.join()
+        cur = np.random.get_state()
+        same = cur[0] == self.state0[0] and cur[2] == self.state0[2] and np.array_equal(cur[1], self.state0[1]) \
+            and cur[3] == self.state0[3] and cur[4] == self.state0[4]
+        if n > self.n or not same or self.rc != 0:
+            return None
+        t = min(self.threads, (n * self.threads) // self.n) if self.n else 0
+        while t > 0 and self.n * t // self.threads > n:
+            t -= 1
+        d0 = self.n * t // self.threads
+        end = np.zeros((2, 625), dtype=np.uint32)
+        if _mt_host(self.bounds[t], n - d0, None, end, 1) != 0:
+            return None
+        np.random.set_state((self.state0[0], end[1, :624].copy(), int(end[1, 624]), self.state0[3], self.state0[4]))
+        return self.buf[:n]
+
+
+def _mt_host(state: np.ndarray, n: int, out_ptr, bounds: np.ndarray, threads: int) -> int:
+    import ctypes
+    fn = bd.lib().s2st_mt19937_host_doubles
+    state = np.ascontiguousarray(state, dtype=np.uint32)
+    assert bounds.flags["C_CONTIGUOUS"] and bounds.dtype == np.uint32 and bounds.shape == (threads + 1, 625)
+    return int(fn(ctypes.c_void_p(state.ctypes.data), int(n), ctypes.c_void_p(out_ptr) if out_ptr else None,
+                  ctypes.c_void_p(bounds.ctypes.data), int(threads)))
+
+
 class _DeviceMTStream:
     """numpy's global generator continued ON THE DEVICE (``s2st_mt19937_doubles_f64``: MT19937 + numpy's two-words-per-double
     conversion, draw for draw -- tests/test_inference.py::test_device_mt19937_is_numpys_stream).  Started by
@@ -221,16 +275,24 @@ class GriffinLim:
 
     def prefetch_phases(self, n_frames_upper: int):
         """Called by the speech generator BEFORE it decodes (``n_frames_upper``: an upper bound of the frames the batch
-        will vocode): with phase_rng="numpy" and the FFT path, numpy's generator is continued on the device, on a side
-        stream, while the decoder runs (``_DeviceMTStream``; ``S2ST_GL_HOST_RNG=1``: on a host thread, ``_UniformStream``):
-        the ~3 ns per draw of the host generator -- 45 M draws for 64 utterances, more than the decode itself -- are gone."""
+        will vocode): with phase_rng="numpy" and the FFT path, numpy's generator is continued while the decoder runs -- by the
+        library's multi-threaded host generator into pinned memory (``_HostMTStream``, default), ``S2ST_GL_PHASE_STREAM=
+        numpy``: by numpy itself on one background thread (``_UniformStream``), ``=device``: by the one-workgroup device kernel
+        (``_DeviceMTStream``; 160 ms for 64 utterances: slower than either host form, kept for hosts without spare cores),
+        ``=off``: drawn after the decode, the ordinary way.  All four hand out the same doubles."""
         self._stream = None
         if self.phase_rng == "numpy" and self.use_fft and n_frames_upper > 0:
             import os
-            if os.environ.get("S2ST_GL_HOST_RNG", "0") == "1":  # (A/B switch: numpy itself, run ahead on a host thread)
-                self._stream = _UniformStream(self.F * int(n_frames_upper), self.device.type == "cuda")
-            else:
-                self._stream = _DeviceMTStream(self.F * int(n_frames_upper), self.device)
+            how = os.environ.get("S2ST_GL_PHASE_STREAM", "host")
+            n = self.F * int(n_frames_upper)
+            if how == "numpy":
+                self._stream = _UniformStream(n, self.device.type == "cuda")
+            elif how == "device":
+                self._stream = _DeviceMTStream(n, self.device)
+            elif how == "host":
+                self._stream = _HostMTStream(n, self.device.type == "cuda")
+            elif how != "off":
+                raise ValueError("S2ST_GL_PHASE_STREAM must be host, numpy, device or off")
 
     @property
     def fwd(self):

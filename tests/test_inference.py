@@ -427,14 +427,14 @@ def test_uniform_stream_runs_numpy_ahead_and_leaves_its_state_exact(backend):
     st2 = V._UniformStream(1000, False)
     np.random.rand(1)  # someone else draws in between
     assert st2.take(10) is None
-    # through the vocoder: prefetch + batch == plain batch, same seed -- with numpy on a host thread and (the default)
-    # with numpy's generator continued on the device
-    for host_rng in ("1", "0"):
-        os.environ["S2ST_GL_HOST_RNG"] = host_rng
+    # through the vocoder: prefetch + batch == plain batch, same seed -- with the library's threaded host generator (the
+    # default), numpy on a host thread, and numpy's generator continued on the device
+    for how in ("host", "numpy", "device", "off"):
+        os.environ["S2ST_GL_PHASE_STREAM"] = how
         try:
             _prefetch_equals_plain(backend, V)
         finally:
-            os.environ.pop("S2ST_GL_HOST_RNG", None)
+            os.environ.pop("S2ST_GL_PHASE_STREAM", None)
 
 
 def _prefetch_equals_plain(backend, V):
@@ -510,3 +510,34 @@ def test_device_mt19937_is_numpys_stream(backend, warm, n):
         backend.sync()
         s2 = so2.cpu().numpy().view(np.uint32)
         assert np.array_equal(s2[:624], after[1]) and int(s2[624]) == after[2], j
+
+
+def test_host_mt19937_is_numpys_stream():
+    """csrc/mt19937_host.cpp (no GPU involved): the threaded host generator hands out numpy's own doubles from numpy's own
+    state -- every start position inside a block, share boundaries that split blocks and doubles, fewer draws taken than
+    generated -- and leaves numpy's GLOBAL generator where the same number of np.random.rand draws would have
+    (the reference: vocoder.py:101-102 draws from the global generator)."""
+    import importlib
+    V = importlib.import_module("speech-to-speech-translation_amd.vocoder")
+    for pos0 in (624, 0, 1, 623, 311):
+        np.random.seed(5)
+        np.random.random_sample(1)
+        st = list(np.random.get_state())
+        st[2] = pos0
+        st0 = tuple(st)
+        for n, T in ((100003, 5), (7, 3), (0, 2), (1000, 1), (3 * 312 + 1, 4)):
+            np.random.set_state(st0)
+            stream = V._HostMTStream(n, False, threads=T)
+            nt = n - n // 3
+            got = stream.take(nt)
+            after = np.random.random_sample(5)
+            np.random.set_state(st0)
+            want = np.random.random_sample(nt)
+            after_w = np.random.random_sample(5)
+            assert np.array_equal(got.numpy(), want), (pos0, n, T)
+            assert np.array_equal(after, after_w), (pos0, n, T)
+    np.random.seed(21)
+    s2 = V._HostMTStream(1000, False)
+    np.random.rand(1)  # someone else draws in between
+    assert s2.take(10) is None
+    assert s2.take(2000) is None  # more than was generated ahead
