@@ -401,7 +401,9 @@ def infer_main(args):
                        "initial_phases": "numpy global generator on the host (the reference's draws, vocoder.py:101-102)",
                        "value_with_device_phase_rng": round(value_device_rng, 2),
                        "decode_steps_per_batch": iters, "batch0_decode_ms": round(t_dec * 1e3, 2),
-                       "batch0_vocoder_ms": round(t_voc * 1e3, 2)}}
+                       "batch0_vocoder_alone_ms": round(t_voc * 1e3, 2),
+                       "batch0_note": "vocoder alone = called by itself, its phase draws NOT run ahead under the decode as they "
+                                      "are inside generate() (vocoder.GriffinLim.prefetch_phases)"}}
     if roofline:
         line["roofline"] = roofline
     if cpu:
