@@ -460,6 +460,10 @@ int s2st_gl_polar_u_f32(const float* mag, const double* uniform, const int64_t* 
 int s2st_gl_stft_project_f32(const float* wave, const int32_t* tl, const float* win, const float* tw, const float* mag, float* X, int32_t U, int32_t Tmax, int32_t n_fft, int32_t hop, int32_t Lw, void* stream);
 int s2st_gl_istft_frames_f32(const float* X, const int32_t* tl, const float* win, const float* tw, float* frames, int32_t U, int32_t Tmax, int32_t n_fft, int32_t hop, void* stream);
 int s2st_gl_overlap_add_b_f32(const float* frames, const float* wsq_all, const int64_t* wsq_off, const int32_t* tl, float* wave, int32_t U, int32_t Tmax, int32_t n_fft, int32_t hop, int32_t Lw, void* stream);
+/* s2st_gl_istft_frames_f32 + s2st_gl_overlap_add_b_f32 as ONE launch (the synthesis frames stay in LDS): X [U * Tmax][F]
+ * complex -> wave [U][Lw], vocoder.py:84-98 (conv_transpose1d with the pseudo-inverse basis, window-sum-square division
+ * above `tiny`, * n_fft / hop, n_fft / 2 trimmed at both ends); equal to the two calls to fp32 rounding. */
+int s2st_gl_istft_ola_f32(const float* X, const int32_t* tl, const float* win, const float* tw, const float* wsq_all, const int64_t* wsq_off, float* wave, int32_t U, int32_t Tmax, int32_t n_fft, int32_t hop, int32_t Lw, void* stream);
 
 /* AR decoding (speech_generator_for_s2st.py:76-110: one decoder step for the B utterances of a batch): skinny
  * y[M][N] = f(x[M][K] W[N][K]^T + bias) (+ resid), M <= 16, K % 32 == 0; x fp32 (rounded to bf16 in registers like the

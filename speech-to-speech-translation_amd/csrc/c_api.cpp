@@ -213,6 +213,9 @@ int s2st_gl_stft_project_f32(const float* wave, const int32_t* tl, const float* 
 int s2st_gl_istft_frames_f32(const float* X, const int32_t* tl, const float* win, const float* tw, float* frames, int32_t U, int32_t Tmax, int32_t n_fft, int32_t hop, void* stream) {
   return s2st_gl_istft_frames(X, tl, win, tw, frames, U, Tmax, n_fft, hop, (hipStream_t)stream);
 }
+int s2st_gl_istft_ola_f32(const float* X, const int32_t* tl, const float* win, const float* tw, const float* wsq_all, const int64_t* wsq_off, float* wave, int32_t U, int32_t Tmax, int32_t n_fft, int32_t hop, int32_t Lw, void* stream) {
+  return s2st_gl_istft_ola(X, tl, win, tw, wsq_all, (const long*)wsq_off, wave, U, Tmax, n_fft, hop, Lw, (hipStream_t)stream);
+}
 int s2st_gl_overlap_add_b_f32(const float* frames, const float* wsq_all, const int64_t* wsq_off, const int32_t* tl, float* wave, int32_t U, int32_t Tmax, int32_t n_fft, int32_t hop, int32_t Lw, void* stream) {
   return s2st_gl_overlap_add_b(frames, wsq_all, (const long*)wsq_off, tl, wave, U, Tmax, n_fft, hop, Lw, (hipStream_t)stream);
 }

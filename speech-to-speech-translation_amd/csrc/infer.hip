@@ -349,73 +349,93 @@ struct FftLds {
 };
 
 // in-place complex FFT of the padded LDS array buf (logical 0 .. N), 256 threads; tw (padded) logical j = exp(-2 pi i j / N);
-// INV: conjugate transform (unscaled)
+// INV: conjugate transform (unscaled).  Stockham autosort passes of radix 8 while a factor 8 is left, then one radix-4 or
+// radix-2 pass (2048 = 8 * 8 * 8 * 4: FOUR LDS round trips; the first form of this kernel ran five radix-4 passes and a
+// radix-2 one with run-time strides).  Pass with Ns done: butterfly j (0 .. N / R) reads x_r = buf[j + r N / R] * w^(r k)
+// with k = j mod Ns, w = exp(-+2 pi i / (R Ns)), and writes its R outputs to (j - k) R + k + s Ns.
+template <bool INV>
+__device__ __forceinline__ cplx mul_mi(cplx d) { return INV ? cplx{-d.y, d.x} : cplx{d.y, -d.x}; }  // d * (-+ i)
+template <bool INV>
+__device__ __forceinline__ cplx mul_w8(cplx d) {  // d * exp(-+ i pi / 4)
+  constexpr float h = 0.70710678118654752440f;
+  return INV ? cplx{h * (d.x - d.y), h * (d.x + d.y)} : cplx{h * (d.x + d.y), h * (d.y - d.x)};
+}
+template <bool INV>
+__device__ __forceinline__ cplx mul_w83(cplx d) {  // d * exp(-+ 3 i pi / 4)
+  constexpr float h = 0.70710678118654752440f;
+  return INV ? cplx{-h * (d.x + d.y), h * (d.x - d.y)} : cplx{h * (d.y - d.x), -h * (d.x + d.y)};
+}
+template <int R, bool INV>
+__device__ __forceinline__ void dft_small(cplx* v) {
+  if constexpr (R == 2) {
+    const cplx a = v[0], b = v[1];
+    v[0] = cadd(a, b);
+    v[1] = csub(a, b);
+  } else if constexpr (R == 4) {
+    const cplx e0 = cadd(v[0], v[2]), e1 = csub(v[0], v[2]), e2 = cadd(v[1], v[3]), e3 = mul_mi<INV>(csub(v[1], v[3]));
+    v[0] = cadd(e0, e2);
+    v[1] = cadd(e1, e3);
+    v[2] = csub(e0, e2);
+    v[3] = csub(e1, e3);
+  } else {
+    // even outputs: 4-point transform of x_n + x_{n+4}; odd outputs: of (x_n - x_{n+4}) * w8^n
+    cplx c[4] = {cadd(v[0], v[4]), cadd(v[1], v[5]), cadd(v[2], v[6]), cadd(v[3], v[7])};
+    cplx d[4] = {csub(v[0], v[4]), mul_w8<INV>(csub(v[1], v[5])), mul_mi<INV>(csub(v[2], v[6])), mul_w83<INV>(csub(v[3], v[7]))};
+    dft_small<4, INV>(c);
+    dft_small<4, INV>(d);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      v[2 * q] = c[q];
+      v[2 * q + 1] = d[q];
+    }
+  }
+}
+template <int N, int NS, int R, bool INV>
+__device__ __forceinline__ void fft_pass(cplx* buf, const cplx* tw, int tid) {
+  constexpr int NB = N / R, PER = (NB + 255) / 256, TS = N / (R * NS);
+  cplx v[PER][R];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int j = tid + 256 * i;
+    if (NB % 256 == 0 || j < NB) {
+      const int k = j & (NS - 1);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        cplx x = buf[fpad(j + r * NB)];
+        if (NS > 1 && r > 0) {
+          cplx w = tw[fpad(r * k * TS)];
+          if (INV) w.y = -w.y;
+          x = cmul(x, w);
+        }
+        v[i][r] = x;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int j = tid + 256 * i;
+    if (NB % 256 == 0 || j < NB) {
+      const int k = j & (NS - 1);
+      dft_small<R, INV>(v[i]);
+      const int j0 = (j - k) * R + k;
+#pragma unroll
+      for (int r = 0; r < R; ++r) buf[fpad(j0 + r * NS)] = v[i][r];
+    }
+  }
+  __syncthreads();
+}
+template <int N, int NS, bool INV>
+__device__ __forceinline__ void fft_passes(cplx* buf, const cplx* tw, int tid) {
+  if constexpr (NS < N) {
+    constexpr int R = N / NS >= 8 ? 8 : N / NS;
+    fft_pass<N, NS, R, INV>(buf, tw, tid);
+    fft_passes<N, NS * R, INV>(buf, tw, tid);
+  }
+}
 template <int N, bool INV>
 __device__ void fft_lds(cplx* buf, const cplx* tw, int tid) {
-  constexpr int Q = N / 4, PER4 = (Q + 255) / 256;
-  int Ns = 1;
-  for (; Ns * 4 <= N; Ns *= 4) {
-    cplx v[PER4][4];
-    const int tstride = N / (4 * Ns);
-#pragma unroll
-    for (int i = 0; i < PER4; ++i) {
-      const int j = tid + 256 * i;
-      if (j < Q) {
-        const int k = j & (Ns - 1);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          cplx x = buf[fpad(j + r * Q)];
-          if (r > 0 && k > 0) {
-            cplx w = tw[fpad(r * k * tstride)];
-            if (INV) w.y = -w.y;
-            x = cmul(x, w);
-          }
-          v[i][r] = x;
-        }
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < PER4; ++i) {
-      const int j = tid + 256 * i;
-      if (j < Q) {
-        const int k = j & (Ns - 1);
-        const cplx a0 = cadd(v[i][0], v[i][2]), a1 = csub(v[i][0], v[i][2]), a2 = cadd(v[i][1], v[i][3]);
-        const cplx d = csub(v[i][1], v[i][3]);
-        const cplx a3 = INV ? cplx{-d.y, d.x} : cplx{d.y, -d.x};  // (+-) i (v1 - v3)
-        const int j0 = ((j - k) << 2) + k;
-        buf[fpad(j0)] = cadd(a0, a2);
-        buf[fpad(j0 + Ns)] = cadd(a1, a3);
-        buf[fpad(j0 + 2 * Ns)] = csub(a0, a2);
-        buf[fpad(j0 + 3 * Ns)] = csub(a1, a3);
-      }
-    }
-    __syncthreads();
-  }
-  if (Ns < N) {  // one radix-2 stage left (log2 N odd): Ns = N / 2
-    constexpr int H = N / 2, PER2 = (H + 255) / 256;
-    cplx v0[PER2], v1[PER2];
-#pragma unroll
-    for (int i = 0; i < PER2; ++i) {
-      const int j = tid + 256 * i;
-      if (j < H) {
-        cplx w = tw[fpad(j)];
-        if (INV) w.y = -w.y;
-        v0[i] = buf[fpad(j)];
-        v1[i] = cmul(buf[fpad(j + H)], w);
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < PER2; ++i) {
-      const int j = tid + 256 * i;
-      if (j < H) {
-        buf[fpad(j)] = cadd(v0[i], v1[i]);
-        buf[fpad(j + H)] = csub(v0[i], v1[i]);
-      }
-    }
-    __syncthreads();
-  }
+  fft_passes<N, 1, INV>(buf, tw, tid);
 }
 
 // STFT of the reflect-padded waveforms + phase projection, per PAIR of frames (rows m0 = 2 * pair, m0 + 1 of the
@@ -580,6 +600,116 @@ __global__ __launch_bounds__(256) void gl_istft_frames_kernel(const cplx* __rest
       if (m0 + 1 < M) frames[(m0 + 1) * N + n] = cur.on[1] ? z.y * wn[i] : 0.f;
     }
     cur = nxt;
+  }
+}
+
+// inverse transform AND overlap-add in one launch (the 367 MB of synthesis frames per iteration -- written by the kernel
+// above, read back by gl_overlap_add_b -- never exist).  Workgroup (b, u) owns the output samples q in [b S, (b + 1) S) of
+// utterance u (S = R hops) and inverse-transforms every frame that touches them in ascending order: its own R frames plus
+// the ceil(N / hop) in front whose tails reach in (recomputed by the neighbouring workgroup too: +11 % transforms at R = 64
+// for n_fft 2048 / hop 300).  The accumulator is a CIRCULAR LDS array of C >= N + 2 hop floats (a power of two): once a pair
+// (t, t + 1) is added, the samples in front of (t + 2) hop are final -- they are normalised, written out and their slots
+// cleared for the samples C further on.  (First form: an S-float accumulator, 72 KB of LDS per workgroup, two workgroups per
+// CU: 329 us per launch against 136 + 164 for the two-kernel form; the transforms are latency-bound and want 3 - 4
+// workgroups per CU.)  Frames are added in ascending order with a barrier between the two frames of a pair, so every sample
+// sees the additions the stand-alone overlap-add makes, in its order (which two frames share a complex transform differs
+// from the kernel above, so a frame's last bits can: 1e-8 relative, tests/test_inference.py).
+template <int N>
+__global__ __launch_bounds__(256) void gl_istft_ola_kernel(const cplx* __restrict__ X, const int* __restrict__ tl,
+                                                           const float* __restrict__ win, const cplx* __restrict__ twg,
+                                                           const float* __restrict__ wsq_all, const long* __restrict__ wsq_off,
+                                                           float* __restrict__ wave, int Tmax, int hop, int Lw, int S, int C,
+                                                           float tiny) {
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+  cplx* buf = reinterpret_cast<cplx*>(smem);
+  cplx* tw = buf + FftLds<N>::SIZE;
+  float* acc = reinterpret_cast<float*>(tw + FftLds<N>::SIZE);
+  const int tid = threadIdx.x, u = blockIdx.y;
+  constexpr int F = N / 2 + 1, PN = N / 256, PF = (F + 255) / 256;
+  const int T = tl[u];
+  const int q0 = blockIdx.x * S, q1 = min(q0 + S, Lw);
+  const int len = hop * (T - 1);  // samples of this utterance (vocoder.py:95-97: the n_fft / 2 borders are trimmed)
+  float* out = wave + (long)u * Lw;
+  if (q0 >= len) {
+    for (int q = q0 + tid; q < q1; q += 256) out[q] = 0.f;
+    return;
+  }
+  for (int q = max(q0, len) + tid; q < q1; q += 256) out[q] = 0.f;  // (behind the utterance's end)
+  for (int j = tid; j < N; j += 256) tw[fpad(j)] = twg[j];
+  for (int i = tid; i < C; i += 256) acc[i] = 0.f;
+  const int cm = C - 1;
+  const float sc = (float)hop / ((float)N * (float)N);
+  float wn[PN];
+#pragma unroll
+  for (int i = 0; i < PN; ++i) wn[i] = win[tid + 256 * i] * sc;
+  const int P0 = q0 + N / 2, P1 = min(q1, len) + N / 2;  // owned positions of the untrimmed signal
+  const int t_lo = P0 - N + 1 <= 0 ? 0 : (P0 - N + hop) / hop;
+  const int t_hi = min(T - 1, (P1 - 1) / hop);
+  const cplx* Xu = X + (long)u * Tmax * F;
+  const float* wsq = wsq_all + wsq_off[u];
+  const float gain = (float)N / (float)hop;
+  cplx xa[PF], xb[PF];
+  auto fetch = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int k = tid + 256 * i;
+      xa[i] = (k < F && t <= t_hi) ? Xu[(long)t * F + k] : cplx{0.f, 0.f};
+      xb[i] = (k < F && t + 1 <= t_hi) ? Xu[(long)(t + 1) * F + k] : cplx{0.f, 0.f};
+    }
+  };
+  fetch(t_lo);
+  int done = t_lo * hop;  // positions in front of `done` are final and flushed
+  for (int t = t_lo; t <= t_hi; t += 2) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int k = tid + 256 * i;
+      if (k >= F) continue;
+      cplx a = xa[i], b = xb[i];
+      if (k == 0 || k == N / 2) a.y = b.y = 0.f;
+      buf[fpad(k)] = cplx{a.x - b.y, a.y + b.x};
+      if (k > 0 && k < N / 2) buf[fpad(N - k)] = cplx{a.x + b.y, b.x - a.y};
+    }
+    if (t + 2 <= t_hi) fetch(t + 2);
+    __syncthreads();
+    fft_lds<N, true>(buf, tw, tid);
+    float zx[PN], zy[PN];
+    {
+#pragma clang fp contract(off)  // (product rounded, then added: what the frames-through-HBM form does; no fused multiply-add)
+#pragma unroll
+      for (int i = 0; i < PN; ++i) {
+        const cplx z = buf[fpad(tid + 256 * i)];
+        zx[i] = z.x * wn[i];
+        zy[i] = z.y * wn[i];
+      }
+#pragma unroll
+      for (int i = 0; i < PN; ++i) {
+        const int sl = (t * hop + tid + 256 * i) & cm;
+        acc[sl] = acc[sl] + zx[i];
+      }
+    }
+    __syncthreads();
+    if (t + 1 <= t_hi) {
+#pragma unroll
+      for (int i = 0; i < PN; ++i) {
+        const int sl = ((t + 1) * hop + tid + 256 * i) & cm;
+        acc[sl] = acc[sl] + zy[i];
+      }
+    }
+    __syncthreads();
+    // final now: everything in front of the next pair's first position (after the last pair: up to the block's end)
+    const int upto = t + 2 <= t_hi ? (t + 2) * hop : P1;
+    for (int p = done + tid; p < upto; p += 256) {
+      const int sl = p & cm;
+      if (p >= P0 && p < P1) {
+        float a = acc[sl];
+        const float w = wsq[p];
+        if (w > tiny) a /= w;
+        out[p - N / 2] = a * gain;
+      }
+      acc[sl] = 0.f;
+    }
+    done = upto;
   }
 }
 
@@ -975,6 +1105,47 @@ int s2st_gl_stft_project(const float* wave, const int* tl, const float* win, con
   return S2ST_ERR_SHAPE;
 }
 
+template <int N>
+int gl_istft_ola_launch(const float* X, const int* tl, const float* win, const float* tw, const float* wsq_all, const long* wsq_off,
+                        float* wave, int U, int Tmax, int hop, int Lw, hipStream_t st) {
+  if (U <= 0 || Lw <= 0) return 0;
+  if (hop < 1 || hop > N) return S2ST_ERR_ARG;
+  // R frames per workgroup: about three workgroups per CU over the batch (S2ST_GL_OLA_FRAMES overrides), at least 16 so that
+  // the ceil(N / hop) frames recomputed in front of each block stay a small share
+  static const int r_env = [] {
+    const char* e = getenv("S2ST_GL_OLA_FRAMES");
+    return e ? atoi(e) : 0;
+  }();
+  int R = r_env > 0 ? r_env : (int)(((long)U * Tmax + 3 * 256 - 1) / (3 * 256));  // (256 CUs)
+  if (R < 16 && r_env <= 0) R = 16;
+  if (R > Tmax) R = Tmax;
+  if (R < 1) R = 1;
+  const int S = R * hop;
+  const int C = N + 2 * hop <= 2 * N ? 2 * N : 4 * N;
+  const int lds = 2 * FftLds<N>::SIZE * (int)sizeof(cplx) + C * (int)sizeof(float);
+  static int configured = 0;  // (per instantiation)
+  if (lds > configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gl_istft_ola_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+        hipSuccess)
+      return S2ST_ERR_LAUNCH;
+    configured = lds;
+  }
+  const float tiny = 1.1754944e-38f;
+  S2ST_LAUNCH(gl_istft_ola_kernel<N>, dim3((unsigned)((Lw + S - 1) / S), (unsigned)U), dim3(256), lds, st, reinterpret_cast<const cplx*>(X),
+              tl, win, reinterpret_cast<const cplx*>(tw), wsq_all, wsq_off, wave, Tmax, hop, Lw, S, C, tiny);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+// X [U * Tmax][F] complex -> wave [U][Lw]: inverse transforms, overlap-add, window-sum-square normalisation, trim (one launch)
+int s2st_gl_istft_ola(const float* X, const int* tl, const float* win, const float* tw, const float* wsq_all, const long* wsq_off,
+                      float* wave, int U, int Tmax, int n_fft, int hop, int Lw, hipStream_t st) {
+  switch (n_fft) {
+    case 256: return gl_istft_ola_launch<256>(X, tl, win, tw, wsq_all, wsq_off, wave, U, Tmax, hop, Lw, st);
+    case 512: return gl_istft_ola_launch<512>(X, tl, win, tw, wsq_all, wsq_off, wave, U, Tmax, hop, Lw, st);
+    case 1024: return gl_istft_ola_launch<1024>(X, tl, win, tw, wsq_all, wsq_off, wave, U, Tmax, hop, Lw, st);
+    case 2048: return gl_istft_ola_launch<2048>(X, tl, win, tw, wsq_all, wsq_off, wave, U, Tmax, hop, Lw, st);
+  }
+  return S2ST_ERR_ARG;
+}
 // X [U * Tmax][F] complex -> frames [U * Tmax][n_fft] (windowed synthesis frames; s2st_gl_overlap_add_b finishes)
 int s2st_gl_istft_frames(const float* X, const int* tl, const float* win, const float* tw, float* frames, int U, int Tmax,
                          int n_fft, int hop, hipStream_t st) {

@@ -304,6 +304,8 @@ int s2st_gl_polar_u(const float* mag, const double* uni, const long* uoff, const
                     int Tmax, hipStream_t st);
 int s2st_gl_stft_project(const float* wave, const int* tl, const float* win, const float* tw, const float* mag, float* X, int U,
                          int Tmax, int n_fft, int hop, int Lw, hipStream_t st);
+int s2st_gl_istft_ola(const float* X, const int* tl, const float* win, const float* tw, const float* wsq_all, const long* wsq_off,
+                      float* wave, int U, int Tmax, int n_fft, int hop, int Lw, hipStream_t st);
 int s2st_gl_istft_frames(const float* X, const int* tl, const float* win, const float* tw, float* frames, int U, int Tmax,
                          int n_fft, int hop, hipStream_t st);
 int s2st_gl_overlap_add(const float* frames, const float* wsq, float* wave, int T, int n_fft, int hop, int n_out,

@@ -453,16 +453,21 @@ class GriffinLim:
         M, Lw = U * Tmax, hop * (Tmax - 1)
         if self.use_fft:
             # round 4: both transforms as N-point real FFTs in LDS (csrc/infer.hip: the reference's analysis basis IS
-            # rfft(window * frame), its pseudo-inverse synthesis basis IS window * hop / n_fft * irfft): three launches per
+            # rfft(window * frame), its pseudo-inverse synthesis basis IS window * hop / n_fft * irfft): two launches per
             # iteration, O(N log N) per frame instead of the dense contraction's 2 N (N + 2) multiply-adds x 3 (bf16x3)
             win, tw = self._fft_tables()
             Xc = torch.empty(M, Fq, 2, device=dev)
-            frames = torch.empty(M, n_fft, device=dev)
             wave = torch.empty(U, max(Lw, 1), device=dev)
+            import os
+            two_kernels = os.environ.get("S2ST_GL_OLA_FUSE", "1") == "0"  # (A/B switch: frames through HBM, as first built)
+            frames = torch.empty(M, n_fft, device=dev) if two_kernels else None
 
             def inverse_fft():
-                bd.call("s2st_gl_istft_frames_f32", Xc, tl, win, tw, frames, U, Tmax, n_fft, hop)
-                bd.call("s2st_gl_overlap_add_b_f32", frames, wsq_all, wsq_off, tl, wave, U, Tmax, n_fft, hop, Lw)
+                if two_kernels:
+                    bd.call("s2st_gl_istft_frames_f32", Xc, tl, win, tw, frames, U, Tmax, n_fft, hop)
+                    bd.call("s2st_gl_overlap_add_b_f32", frames, wsq_all, wsq_off, tl, wave, U, Tmax, n_fft, hop, Lw)
+                else:
+                    bd.call("s2st_gl_istft_ola_f32", Xc, tl, win, tw, wsq_all, wsq_off, wave, U, Tmax, n_fft, hop, Lw)
 
             if ang is not None:
                 bd.call("s2st_gl_polar_c_f32", mag, ang, tl, Xc, U, Fq, Tmax)

@@ -333,9 +333,9 @@ def test_fourier_bases_are_real_ffts():
         assert np.abs(syn - np.fft.irfft(X, n=n_fft) * hop / n_fft).max() < 1e-12
 
 
-@pytest.mark.parametrize("n_fft,win,hop,T", [(256, 200, 64, 23), (2048, 1200, 300, 19), (1024, 1024, 256, 12)])
+@pytest.mark.parametrize("n_fft,win,hop,T", [(256, 200, 64, 23), (2048, 1200, 300, 19), (1024, 1024, 256, 12), (512, 400, 128, 9)])
 def test_fft_griffin_lim_kernels(backend, golden_dir, monkeypatch, n_fft, win, hop, T):
-    """The LDS FFT kernels (radix-4 Stockham + a radix-2 stage for odd log2 n_fft, two frames per complex transform):
+    """The LDS FFT kernels (Stockham passes of radix 8 + a last radix-4 or radix-2 one, two frames per complex transform):
     the benchmark geometry (n_fft 2048 / window 1200 / hop 300), one with log2 n_fft even, and the golden's -- against
     the float64 numpy form to 2e-4 of the waveform scale (fp32 butterflies), ragged batches included; at the golden's
     geometry also against the REFERENCE's GriffinLim output, where the FFT form must be at least as close as the dense
@@ -355,6 +355,28 @@ def test_fft_griffin_lim_kernels(backend, golden_dir, monkeypatch, n_fft, win, h
         ref = _gl_numpy_fft(s, a, n_fft, win, hop, 3)
         assert w.shape[0] == ref.shape[0]
         assert float(np.abs(w.cpu().numpy() - ref).max()) < 2e-4 * float(np.abs(ref).max()), (n_fft, s.shape)
+    # the inverse transform with the overlap-add inside the launch (default) == frames through HBM + stand-alone overlap-add
+    # to the last bits (same additions in the same order; only which two frames share a complex transform differs, and a
+    # frame's rounding depends on its partner at the 1e-8 level), also where an utterance spans several accumulator blocks
+    def same(xs, ys):
+        return all(float((a_ - b_).abs().max()) <= 2e-5 * float(b_.abs().max()) for a_, b_ in zip(xs, ys))  # (3 iterations amplify)
+
+    monkeypatch.setenv("S2ST_GL_OLA_FUSE", "0")
+    out2 = V.GriffinLim(n_fft, win, hop, 3, backend.device).batch([torch.from_numpy(s) for s in specs], angs)
+    monkeypatch.delenv("S2ST_GL_OLA_FUSE")
+    backend.sync()
+    assert same(out, out2)
+    if n_fft == 256:
+        long_specs = [np.abs(rs.randn(Fq, t)).astype(np.float32) for t in (9600 // hop * 2 + 7, 9600 // hop + 1, 3)]
+        long_angs = [IO.initial_angles((Fq, s.shape[1]), rs) for s in long_specs]
+        a1 = V.GriffinLim(n_fft, win, hop, 1, backend.device).batch([torch.from_numpy(s) for s in long_specs], long_angs)
+        monkeypatch.setenv("S2ST_GL_OLA_FUSE", "0")
+        a2 = V.GriffinLim(n_fft, win, hop, 1, backend.device).batch([torch.from_numpy(s) for s in long_specs], long_angs)
+        monkeypatch.delenv("S2ST_GL_OLA_FUSE")
+        backend.sync()
+        assert same(a1, a2)
+        r0 = _gl_numpy_fft(long_specs[0], long_angs[0], n_fft, win, hop, 1)
+        assert float(np.abs(a1[0].cpu().numpy() - r0).max()) < 2e-4 * float(np.abs(r0).max())
     if n_fft == 256:
         z = np.load(os.path.join(golden_dir, "infer_gl.npz"))
         ref = z["wave.4"]
