@@ -388,7 +388,8 @@ int s2st_engine_wait_optimizer(s2st_engine* e, void* stream);
 /* ---- AR inference (config 5): fairseq/speech_generator_for_s2st.py:46-110 drives these.
  * decode_begin runs the encoder on `b` (eval mode; out->enc_out / tap0 / tap1 receive the encoder
  * outputs) and fills the caller-owned `state` (self-attention K/V caches for max_steps frames + the
- * static cross-attention K/V of every decoder layer).  decode_step consumes the previous output
+ * static cross-attention K/V of every decoder layer; with S2ST_DECODE_KV_BF16=1 in the bf16 mode also bf16 copies of
+ * those rows, which the steps' cross-attention then reads).  decode_step consumes the previous output
  * frame prev [B][out_dim] (zeros at step 0), appends to the caches and returns feat_out [B][out_dim]
  * (pre-post-net features), eos_prob [B] = sigmoid(stop logit) and, optionally, the head-averaged
  * cross-attention of the last layer attn_out [B][E].  `pos` [B] = positional-table row of this step
@@ -431,6 +432,13 @@ int s2st_gl_frame_split_f32(const float* wave, const int32_t* tl, void* As, int3
  * s2st_gl_polar_c_f32: X = mag * exp(i ang) (vocoder.py:101-103).  s2st_gl_stft_project_f32: reflect-pad + frame + window +
  * rfft of wave [U][Lw], then X = mag * Y / |Y| (vocoder.py:104-107).  s2st_gl_istft_frames_f32: synthesis frames
  * [U * Tmax][n_fft] for s2st_gl_overlap_add_b_f32. */
+/* One decoding step's attention (fairseq/modules/multihead_attention.py:194-385 with incremental_state: one query per
+ * utterance against the cached keys / values, key padding mask = klen, softmax, weighted values; head-averaged weights of the
+ * alignment layer into attn_mean [B][S], zeroed here).  q [B][ldq] (head h at columns h * dh); caches: row s of utterance b at
+ * cache + b * kbs + s * ldk (elements), fp32 or -- kv_bf16 = 1, head widths 64 / 128, static rows only -- bf16.  k_new / v_new
+ * [B][ld_new] (optional, fp32 caches): this step's rows, stored as row pos_new of the caches before attending (saved-state
+ * update, :300-318). */
+int s2st_decode_attn_f32(const float* q, int64_t ldq, void* k_cache, void* v_cache, int64_t ldk, int64_t kbs, const int32_t* klen, int32_t nkeys, int32_t B, int32_t H, int32_t dh, float scale, float* o, int64_t ldo, float* attn_mean, int32_t S, const float* k_new, const float* v_new, int64_t ld_new, int32_t pos_new, int32_t kv_bf16, void* stream);
 /* The AR generator's stop rule on the device (fairseq/speech_generator_for_s2st.py:84-99): after decoding step `step`,
  * finished |= eos_prob > thr, out_lens of the utterances that just finished = step + 1 (initial value max_iter = "still
  * running"), klen_next = the key lengths the NEXT step's self-attention masks with (:84-85), n_done[step] = how many are

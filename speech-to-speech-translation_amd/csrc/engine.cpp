@@ -134,6 +134,7 @@ struct s2st_engine {
   struct Dec {
     float* base = nullptr; int B = 0, E = 0, maxT = 0; const int* enc_lens = nullptr; const float* pe_dec = nullptr;
     float* pe_alpha = nullptr;  // [maxT + 2][dec_dim]: pos_emb_alpha * PE rows (tail of the caller's state buffer)
+    bf16raw* cross_h = nullptr; // fast mode: bf16 copies of the static cross-attention keys | values, [L][B * E][2 dec_dim]
   } dec_st;
   float* dec_selfK(int l) const { return dec_st.base + (long)l * 2 * dec_st.B * dec_st.maxT * c.dec_dim; }
   float* dec_selfV(int l) const { return dec_selfK(l) + (long)dec_st.B * dec_st.maxT * c.dec_dim; }
@@ -1286,12 +1287,12 @@ struct s2st_engine {
   // to row `pos_new` of the caches before it attends (the two copy launches per layer of rounds 1 - 3 are gone)
   Ten* dec_attn(Ten* qt, int qoff, float* K, float* V, long ldk, long kbs, const int* klen, int nkeys,
                 int H, float* attn_mean, int S, const float* k_new = nullptr, const float* v_new = nullptr, long ld_new = 0,
-                int pos_new = 0) {
+                int pos_new = 0, int kv_bf16 = 0) {
     const int Cd = c.dec_dim, B = dec_st.B;
     Ten* o = newT(B, Cd);
     if (live())
       chk(s2st_decode_attn(qt->d + qoff, qt->cols, K, V, ldk, kbs, klen, nkeys, B, H, Cd / H,
-                           1.0f / sqrtf((float)(Cd / H)), o->d, Cd, attn_mean, S, st_, k_new, v_new, ld_new, pos_new));
+                           1.0f / sqrtf((float)(Cd / H)), o->d, Cd, attn_mean, S, st_, k_new, v_new, ld_new, pos_new, kv_bf16));
     return o;
   }
 
@@ -1338,6 +1339,11 @@ struct s2st_engine {
       // encoder attention (static keys / values precomputed by decode_begin)
       Ten* q = pre ? ln_linear(x, L.ln2, L.xa.q_w, L.xa.q_b, Cd, Cd) : linear(x, L.xa.q_w, L.xa.q_b, Cd, Cd);
       const bool align = l == c.dec_layers - 1;
+      if (dec_st.cross_h) {  // fast mode: the static rows as bf16 (what the training path's attention kernels read too)
+        bf16raw* kvh = dec_st.cross_h + (long)l * B * E * 2 * Cd;
+        o = dec_attn(q, 0, reinterpret_cast<float*>(kvh), reinterpret_cast<float*>(kvh + Cd), 2 * Cd, (long)E * 2 * Cd,
+                     dec_st.enc_lens, E, H, align ? attn_out : nullptr, E, nullptr, nullptr, 0, 0, 1);
+      } else
       o = dec_attn(q, 0, dec_crossKV(l), dec_crossKV(l) + Cd, 2 * Cd, (long)E * 2 * Cd, dec_st.enc_lens, E, H,
                    align ? attn_out : nullptr, E);
       x = linear(o, L.xa.out_w, L.xa.out_b, Cd, Cd, 0, 0.f, x);
@@ -2299,7 +2305,9 @@ int s2st_engine_segment_range(const s2st_engine* e, int32_t i, int64_t* lo, int6
 // ---- AR decoding + eval post-net (config 5) ---------------------------------------------------
 int64_t s2st_engine_decode_state_floats(const s2st_engine* e, int32_t B, int32_t E, int32_t max_steps) {
   const long Cd = e->c.dec_dim, L = e->c.dec_layers;
-  return L * 2 * B * (long)max_steps * Cd + L * (long)B * E * 2 * Cd + 64 + ((long)max_steps + 2) * Cd;
+  // self-attention caches | static cross-attention keys and values | pad | alpha-scaled position rows | bf16 copies of the
+  // cross-attention rows (fast mode)
+  return L * 2 * B * (long)max_steps * Cd + L * (long)B * E * 2 * Cd + 64 + ((long)max_steps + 2) * Cd + L * (long)B * E * Cd + 8;
 }
 
 int s2st_engine_decode_begin(s2st_engine* e, const s2st_batch* b, const s2st_outputs* out, float* state,
@@ -2333,9 +2341,24 @@ int s2st_engine_decode_begin(s2st_engine* e, const s2st_batch* b, const s2st_out
       e->chk(s2st_scale_rows(b->pe_dec, e->P + e->pos_alpha, e->dec_st.pe_alpha, ((long)max_steps + 2) * Cd, e->st_));
   }
   // static cross-attention keys / values of every decoder layer (static_kv=True)
+  // S2ST_DECODE_KV_BF16=1 (fast mode, head width 64 / 128): the decode steps' cross-attention reads bf16 copies of the static
+  // rows.  Built for the bandwidth (a step's six launches read every row of the batch), measured slower than the fp32 rows
+  // on the bench batch (csrc/infer.hip: decode_attn_fast_kernel), so off by default.
+  const char* kv_env = getenv("S2ST_DECODE_KV_BF16");  // (per call: the tests run both forms in one process)
+  const bool kv_bf16 = kv_env && kv_env[0] == '1';
+  const int dhd = e->c.dec_dim / e->c.dec_heads;
+  e->dec_st.cross_h = nullptr;
+  if (e->fast() && kv_bf16 && (dhd == 64 || dhd == 128)) {
+    float* tail = e->dec_st.pe_alpha + ((long)max_steps + 2) * e->c.dec_dim;
+    tail += (8 - ((tail - state) & 7)) & 7;  // (16-byte rows for the 8-byte loads)
+    e->dec_st.cross_h = reinterpret_cast<bf16raw*>(tail);
+  }
   for (int l = 0; l < e->c.dec_layers; ++l) {
     const XAttnP& xa = e->dec[l].xa;
     e->linear(e->enc_out_keep, xa.kv_w, xa.kv_b, 2 * e->c.dec_dim, e->c.enc_dim, 0, 0.f, nullptr, e->dec_crossKV(l));
+    if (e->dec_st.cross_h && e->live())
+      e->chk(s2st_cast_bf16_rows(e->dec_crossKV(l), 2 * e->c.dec_dim, e->dec_st.cross_h + (long)l * b->B * b->E * 2 * e->c.dec_dim,
+                                 2 * e->c.dec_dim, (long)b->B * b->E, 2 * e->c.dec_dim, e->st_));
   }
   e->tape.clear();
   return e->err;

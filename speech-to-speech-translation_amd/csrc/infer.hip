@@ -320,6 +320,175 @@ __global__ __launch_bounds__(256) void gl_overlap_add_b_kernel(const float* __re
   wave[i] = out;
 }
 
+// The same attention for head widths 64 / 128 (round 4, second form).  The kernel above is a chain of memory round trips:
+// key lengths and the query (-> LDS, barrier), key passes, two block-wide reductions, then value passes (x 2 column halves
+// at width 128): 5.3 us for ONE key, 18 us for 315, and a batch's launch lasts as long as its longest utterance's
+// workgroup (tools/decode_attn_bench.py, profiles/r04_t_decode_attn_bench.txt).  Here
+//   * every 16-lane group keeps a RUNNING softmax over its own keys (s = g mod G): keys AND values of a pass are loaded
+//     together, scores -> running maximum -> rescale -> accumulate; the G groups are merged once at the end through LDS in
+//     group order (no block-wide reduction inside the loop, no atomics);
+//   * the first pass's loads wait for the utterance's key count only: the query comes straight from global memory, and the
+//     step's own key / value row is taken from k_new / v_new in registers (and stored to the cache for the later steps)
+//     instead of being stored, fenced by a barrier and read back.  (Clamping the rows to the cache's extent instead of
+//     the utterance's length, so that not even the key count is waited for, was tried: every workgroup then fetches a full
+//     pass of distinct rows -- 67 MB per launch instead of 23 MB for the bench batch -- and the launch takes 20 us);
+//   * NT = 1024 threads (64 groups: 256 keys per pass in fp32, 512 with bf16 rows) and KT = bf16raw (the static
+//     cross-attention rows as bf16) are built and tested but NOT the default: measured on the bench batch (64 utterances x 4
+//     heads of width 128, 8 - 315 keys, tools/decode_attn_bench.py) 16.3 us and 13.9 us against 13.3 us for 256 threads on
+//     fp32 rows -- a launch lasts as long as its longest utterance's workgroup, which pulls its rows at ~20 B/clk whatever
+//     their type, and the wider forms start later (5.8 us for one key with 256 threads on fp32, 8.4 with bf16, 9.3 with
+//     1024 threads).
+template <typename KT>
+struct RawRow;
+template <>
+struct RawRow<float> {
+  typedef float4 T;
+  static __device__ __forceinline__ float4 cvt(const float4& r) { return r; }
+};
+template <>
+struct RawRow<bf16raw> {
+  typedef uint2 T;
+  static __device__ __forceinline__ float4 cvt(const uint2& u) {
+    return float4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                  __uint_as_float(u.y & 0xffff0000u)};
+  }
+};
+
+template <typename KT, int ND, int NT>
+__global__ __launch_bounds__(NT) void decode_attn_fast_kernel(const float* __restrict__ q, long ldq, KT* __restrict__ kc,
+                                                              KT* __restrict__ vc, long ldk, long kbs,
+                                                              const int* __restrict__ klen, int nkeys, int H, float scale,
+                                                              float* __restrict__ o, long ldo, float* __restrict__ attn_mean,
+                                                              int S, const float* __restrict__ k_new,
+                                                              const float* __restrict__ v_new, long ld_new, int pos_new) {
+  constexpr int dh = 64 * ND, G = NT / 16;
+  constexpr int KP = (sizeof(KT) == 2 ? 16 : 8) / (NT / 256 > 2 ? 2 : 1);
+  typedef typename RawRow<KT>::T Raw;
+  __shared__ float p[DA_MAXS];
+  __shared__ float gm[G], gl[G];
+  __shared__ __attribute__((aligned(16))) float part[G * dh];
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H, tid = threadIdx.x;
+  const int g = tid >> 4, l4 = (tid & 15) * 4;
+  const KT* kb = kc + (long)b * kbs + h * dh;
+  const KT* vb = vc + (long)b * kbs + h * dh;
+  const int row_new = (sizeof(KT) == 4 && k_new) ? pos_new : -1;
+  // ---- everything below up to the first use is independent loads ----
+  const int n = klen ? min((int)klen[b], nkeys) : nkeys;
+  float4 qv[ND], kn[ND], vn[ND];
+#pragma unroll
+  for (int c = 0; c < ND; ++c) {
+    qv[c] = *reinterpret_cast<const float4*>(q + (long)b * ldq + h * dh + l4 + 64 * c);
+    if (row_new >= 0) {
+      kn[c] = *reinterpret_cast<const float4*>(k_new + (long)b * ld_new + h * dh + l4 + 64 * c);
+      vn[c] = *reinterpret_cast<const float4*>(v_new + (long)b * ld_new + h * dh + l4 + 64 * c);
+    } else {
+      kn[c] = vn[c] = float4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  float m_run = -INFINITY, l_run = 0.f;
+  float4 acc[ND];
+#pragma unroll
+  for (int c = 0; c < ND; ++c) acc[c] = float4{0.f, 0.f, 0.f, 0.f};
+  for (int s0 = 0; s0 < n; s0 += G * KP) {
+    Raw kr[ND][KP], vr[ND][KP];
+#pragma unroll
+    for (int c = 0; c < ND; ++c)
+#pragma unroll
+      for (int i = 0; i < KP; ++i)
+        kr[c][i] = *reinterpret_cast<const Raw*>(kb + (long)min(s0 + g + G * i, n - 1) * ldk + l4 + 64 * c);
+#pragma unroll
+    for (int c = 0; c < ND; ++c)
+#pragma unroll
+      for (int i = 0; i < KP; ++i)
+        vr[c][i] = *reinterpret_cast<const Raw*>(vb + (long)min(s0 + g + G * i, n - 1) * ldk + l4 + 64 * c);
+    if (s0 == 0) {
+#pragma unroll
+      for (int c = 0; c < ND; ++c) {
+        qv[c].x *= scale; qv[c].y *= scale; qv[c].z *= scale; qv[c].w *= scale;
+      }
+    }
+    float a[KP];
+#pragma unroll
+    for (int i = 0; i < KP; ++i) a[i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < ND; ++c)
+#pragma unroll
+      for (int i = 0; i < KP; ++i) {
+        float4 k4 = RawRow<KT>::cvt(kr[c][i]);
+        if (s0 + g + G * i == row_new) k4 = kn[c];
+        a[i] += qv[c].x * k4.x + qv[c].y * k4.y + qv[c].z * k4.z + qv[c].w * k4.w;
+      }
+    float pm = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+      float v = a[i];
+      v += __shfl_xor(v, 8);
+      v += __shfl_xor(v, 4);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 1);
+      const int s = s0 + g + G * i;
+      if (s < n) {
+        if (attn_mean && l4 == 0) p[s] = v;
+        pm = fmaxf(pm, v);
+      } else {
+        v = -INFINITY;
+      }
+      a[i] = v;
+    }
+    if (pm == -INFINITY) continue;  // (none of this group's keys of the pass exists)
+    const float m_new = fmaxf(m_run, pm);
+    const float sc = __expf(m_run - m_new);  // (first pass: exp(-inf) = 0)
+    l_run *= sc;
+#pragma unroll
+    for (int c = 0; c < ND; ++c) {
+      acc[c].x *= sc; acc[c].y *= sc; acc[c].z *= sc; acc[c].w *= sc;
+    }
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+      const bool on = a[i] != -INFINITY;
+      const float e = on ? __expf(a[i] - m_new) : 0.f;
+      l_run += e;
+#pragma unroll
+      for (int c = 0; c < ND; ++c) {
+        float4 v4 = RawRow<KT>::cvt(vr[c][i]);
+        if (s0 + g + G * i == row_new) v4 = vn[c];
+        if (!on) v4 = float4{0.f, 0.f, 0.f, 0.f};  // (a row behind the utterance's end may hold anything)
+        acc[c].x += e * v4.x; acc[c].y += e * v4.y; acc[c].z += e * v4.z; acc[c].w += e * v4.w;
+      }
+    }
+    m_run = m_new;
+  }
+  if constexpr (sizeof(KT) == 4) {
+    if (row_new >= 0 && g == 0) {  // this step's rows into the caches (read by the later steps' launches)
+#pragma unroll
+      for (int c = 0; c < ND; ++c) {
+        *reinterpret_cast<float4*>(kc + (long)b * kbs + (long)row_new * ldk + h * dh + l4 + 64 * c) = kn[c];
+        *reinterpret_cast<float4*>(vc + (long)b * kbs + (long)row_new * ldk + h * dh + l4 + 64 * c) = vn[c];
+      }
+    }
+  }
+  if (l4 == 0) {
+    gm[g] = m_run;
+    gl[g] = l_run;
+  }
+#pragma unroll
+  for (int c = 0; c < ND; ++c) *reinterpret_cast<float4*>(part + g * dh + l4 + 64 * c) = acc[c];
+  __syncthreads();
+  // merge of the G groups, in group order
+  float M = gm[0];
+  for (int i = 1; i < G; ++i) M = fmaxf(M, gm[i]);
+  float Lsum = 0.f;
+  for (int i = 0; i < G; ++i) Lsum += gm[i] == -INFINITY ? 0.f : gl[i] * __expf(gm[i] - M);
+  const float inv = Lsum > 0.f ? 1.f / Lsum : 0.f;
+  if (tid < dh) {
+    float a = 0.f;
+    for (int i = 0; i < G; ++i) a += gm[i] == -INFINITY ? 0.f : part[i * dh + tid] * __expf(gm[i] - M);
+    o[(long)b * ldo + h * dh + tid] = a * inv;
+  }
+  if (attn_mean)
+    for (int s = tid; s < n; s += NT) atomicAdd(attn_mean + (long)b * S + s, __expf(p[s] - M) * inv / H);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Griffin-Lim with FFTs (round 4).  The reference's STFT / inverse STFT are dense Fourier-basis convolutions
 // (audio_utils.py:226-271: basis = [Re; Im] of fft(eye(n_fft)) * window; vocoder.py:56-98: pinverse(n_fft / hop * basis)):
@@ -791,13 +960,50 @@ __global__ __launch_bounds__(256) void gl_overlap_add_kernel(const float* __rest
 
 int s2st_decode_attn(const float* q, long ldq, float* kc, float* vc, long ldk, long kbs, const int* klen,
                      int nkeys, int B, int H, int dh, float scale, float* o, long ldo, float* attn_mean, int S,
-                     hipStream_t st, const float* k_new, const float* v_new, long ld_new, int pos_new) {
+                     hipStream_t st, const float* k_new, const float* v_new, long ld_new, int pos_new, int kv_bf16) {
   if (B <= 0) return 0;
   if (nkeys > DA_MAXS || dh > 256 || dh % 4 || 256 % dh) return S2ST_ERR_SHAPE;
   if ((k_new != nullptr) != (v_new != nullptr) || (k_new && (pos_new < 0 || pos_new >= nkeys))) return S2ST_ERR_ARG;
+  if (kv_bf16 && (k_new || (dh != 64 && dh != 128) || ldk % 4)) return S2ST_ERR_ARG;  // (bf16 caches: static rows only)
+  if (nkeys < 1) return S2ST_ERR_ARG;
   if (attn_mean) hipMemsetAsync(attn_mean, 0, sizeof(float) * (size_t)B * S, st);
-  S2ST_LAUNCH(decode_attn_kernel, dim3(B * H), dim3(256), 0, st, q, ldq, kc, vc, ldk, kbs, klen, nkeys, H, dh,
-                     scale, o, ldo, attn_mean, S, k_new, v_new, ld_new, pos_new);
+  static const bool old_form = [] {
+    const char* e = getenv("S2ST_DECODE_ATTN_V1");  // A/B switch: the first form of the kernel
+    return e && e[0] == '1';
+  }();
+  const bool fast_ok = (dh == 64 || dh == 128) && ldk % 4 == 0 && ldq % 4 == 0 && (!k_new || ld_new % 4 == 0) &&
+                       (!old_form || kv_bf16);
+  if (kv_bf16 && !fast_ok) return S2ST_ERR_ARG;
+  // S2ST_DECODE_ATTN_NT=1024: 64 key groups per workgroup (an experiment kept for small batches)
+  const char* nt_e = getenv("S2ST_DECODE_ATTN_NT");  // (read per call: the tests run both forms in one process)
+  const int nt_env = nt_e ? atoi(nt_e) : 0;
+  const bool big = nt_env == 1024;  // (measured slower at B * H = 256: 9.3 us against 5.8 us for one key, 16.3 against 13.3 for the bench batch)
+#define S2ST_DA_LAUNCH(KT_, ND_, NT_, kp, vp)                                                                               \
+  S2ST_LAUNCH((decode_attn_fast_kernel<KT_, ND_, NT_>), dim3(B * H), dim3(NT_), 0, st, q, ldq, kp, vp, ldk, kbs, klen, nkeys, H, \
+              scale, o, ldo, attn_mean, S, k_new, v_new, ld_new, pos_new)
+  if (!fast_ok) {
+    S2ST_LAUNCH(decode_attn_kernel, dim3(B * H), dim3(256), 0, st, q, ldq, kc, vc, ldk, kbs, klen, nkeys, H, dh,
+                scale, o, ldo, attn_mean, S, k_new, v_new, ld_new, pos_new);
+  } else if (kv_bf16) {
+    bf16raw* kh = reinterpret_cast<bf16raw*>(kc);
+    bf16raw* vh = reinterpret_cast<bf16raw*>(vc);
+    if (dh == 64) {
+      if (big) S2ST_DA_LAUNCH(bf16raw, 1, 1024, kh, vh);
+      else S2ST_DA_LAUNCH(bf16raw, 1, 256, kh, vh);
+    } else {
+      if (big) S2ST_DA_LAUNCH(bf16raw, 2, 1024, kh, vh);
+      else S2ST_DA_LAUNCH(bf16raw, 2, 256, kh, vh);
+    }
+  } else {
+    if (dh == 64) {
+      if (big) S2ST_DA_LAUNCH(float, 1, 1024, kc, vc);
+      else S2ST_DA_LAUNCH(float, 1, 256, kc, vc);
+    } else {
+      if (big) S2ST_DA_LAUNCH(float, 2, 1024, kc, vc);
+      else S2ST_DA_LAUNCH(float, 2, 256, kc, vc);
+    }
+  }
+#undef S2ST_DA_LAUNCH
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 

@@ -272,7 +272,7 @@ int s2st_posconv_prep(float* x, const int* lens, float* img, uint16_t* imgh, int
 int s2st_decode_attn(const float* q, long ldq, float* kc, float* vc, long ldk, long kbs, const int* klen,
                      int nkeys, int B, int H, int dh, float scale, float* o, long ldo, float* attn_mean, int S,
                      hipStream_t st, const float* k_new = nullptr, const float* v_new = nullptr, long ld_new = 0,
-                     int pos_new = 0);
+                     int pos_new = 0, int kv_bf16 = 0);  // kv_bf16: kc / vc point at bf16 rows (ldk, kbs in elements)
 int s2st_scale_rows(const float* x, const float* a, float* y, long n, hipStream_t st);
 int s2st_decode_stop_update(const float* eos_prob, float thr, int step, int max_iter, int B, int* finished, int* out_lens,
                             int* klen_next, int* n_done, hipStream_t st);
