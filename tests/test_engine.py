@@ -350,6 +350,9 @@ def test_fused_backward_paths_equal_the_unfused_ones(backend, cfg, switch, monke
                                                 "S2ST_LN_BWD_SPLIT", "S2ST_NO_WGRAD_GROUP", "S2ST_ORDERED_BIAS_SUMS=0",
                                                 "S2ST_ATTN_DVEC_KERNEL"):
         pytest.skip("launch-structure switch: covered by the GPU run")
+    if backend.kind == "emu" and cfg is MICRO_POSTLN and switch not in ("S2ST_NO_LN_FUSE", "S2ST_LN_BWD_SPLIT"):
+        pytest.skip("post-LN layers differ from pre-LN ones in where the layer norms sit: their two switches run here, "
+                    "the others on the pre-LN model (and all of them on the GPU)")
     D = importlib.import_module(DATA)
     cfg = dict(cfg, dropout=0.1, attention_dropout=0.1, activation_dropout=0.05, prenet_dropout=0.5, postnet_dropout=0.5)
     c = D.SyntheticFisherCorpus(n_utts=4, seed=3, max_src=64, median_src=50, min_src=30)
