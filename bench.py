@@ -540,7 +540,7 @@ def main():
     # deterministic shuffle of the (length-sorted) batches, then deal round-robin to ranks
     import numpy as np
     order = np.random.RandomState(7).permutation(len(batches))
-    need = (args.steps + args.warmup)
+    need = (args.steps + args.warmup) + (1 if hub else 0)  # (+1: the batch whose front end the last timed step launches ahead)
     mine = [batches[order[(i * world + rank) % len(batches)]] for i in range(need)]
     samples = [corpus.collate_batch(ix) for ix in mine]
     if hub:
@@ -564,6 +564,10 @@ def main():
     def step(i):
         # (S2ST_ADAM_OVERLAP=1: the update overlapped with the next forward -- measured 7.40 vs 7.43 ms/step, within
         # noise: the HBM-bound update slows the forward's first layers by what it saves, so it stays off)
+        if hub and i + 1 < len(prepared):
+            # frozen HuBERT of the NEXT batch beside this step (it does not depend on the update): every timed step launches
+            # exactly one front-end forward, as before -- for the batch after it instead of its own
+            model.front_end_ahead(prepared[i + 1])
         return trainer.train_step([prepared[i]], overlap_optimizer=ADAM_OVERLAP)
 
     for i in range(args.warmup):
@@ -672,12 +676,13 @@ def main():
         torch.cuda.synchronize()
         th = time.perf_counter() - th0
         vlog('host-fed (PCIe-inclusive), in-line uploads: %.3f ms/step over %d steps' % (th / n_h * 1e3, n_h))
-        # host cost of preparing one batch (Engine.prepare: index vectors + uploads), main thread, idle GPU
+        # host cost of preparing one batch (Engine.prepare: index vectors + uploads; --use-hubert: waveform staging + frame
+        # mask too), main thread, idle GPU
         tp0 = time.perf_counter()
         for smp in feed:
-            eng.prepare(smp, training=True, seed=0)
+            model.prepare_sample(smp, training=True) if hub else eng.prepare(smp, training=True, seed=0)
         torch.cuda.synchronize()
-        vlog('Engine.prepare alone: %.3f ms per batch' % ((time.perf_counter() - tp0) / n_h * 1e3))
+        vlog('batch preparation alone: %.3f ms per batch' % ((time.perf_counter() - tp0) / n_h * 1e3))
     if step_ev:
         vlog('per-step GPU ms (mel frames):', ' '.join('%.2f(%d)' % (step_ev[j - 1].elapsed_time(step_ev[j]), frames[args.warmup + j])
                                                      for j in range(1, len(step_ev))))
@@ -687,8 +692,8 @@ def main():
         ones = torch.ones(1, dtype=torch.float64, device="cpu" if share else dev)
         torch.distributed.all_reduce(ones, op=torch.distributed.ReduceOp.SUM)
         n_ranks_seen = int(round(float(ones[0])))
-    my_frames = float(sum(frames[args.warmup:]))
-    my_flops = 3.0 * 2.0 * sum(macs[args.warmup:])  # fwd + bwd = 3 x fwd, 2 FLOP per MAC
+    my_frames = float(sum(frames[args.warmup:args.warmup + args.steps]))
+    my_flops = 3.0 * 2.0 * sum(macs[args.warmup:args.warmup + args.steps])  # fwd + bwd = 3 x fwd, 2 FLOP per MAC
     stat = torch.tensor([dt, my_frames, my_flops], dtype=torch.float64, device="cpu" if share else dev)
     if world > 1:
         tmax = stat[:1].clone()

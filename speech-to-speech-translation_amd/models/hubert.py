@@ -184,6 +184,25 @@ class HubertFrontend:
             padding_mask = padding_mask[:, :-extra]
         return padding_mask.view(padding_mask.size(0), n_frames, -1).all(-1)
 
+    @staticmethod
+    def _suffix_frame_mask(padding_mask: torch.Tensor, n_frames: int):
+        """``frame_padding_mask`` for the masks a collater produces (padding = a suffix of every row) without the
+        [B][T][chunk] boolean reduction over millions of samples (20 - 50 ms per 24 x 8 s batch on the host: it made the
+        host-fed --use-hubert step twice as long as the device-resident one): with n_b valid samples, frame f's chunk
+        [f c, (f + 1) c) is all padding iff f c >= n_b.  None when some row's padding is not a suffix."""
+        import numpy as np
+        pm = padding_mask.detach().cpu().numpy()
+        B, N = pm.shape
+        chunk = (N - N % n_frames) // n_frames
+        if chunk <= 0 or pm.dtype != np.bool_:
+            return None
+        n_pad = np.count_nonzero(pm, axis=1)
+        first = np.where(n_pad > 0, pm.argmax(axis=1), N)
+        if not np.array_equal(first + n_pad, np.full(B, N)):
+            return None
+        pad_from = -(-first // chunk)  # ceil(n_b / chunk)
+        return torch.from_numpy(np.arange(n_frames)[None, :] >= pad_from[:, None])
+
     def stage(self, source: torch.Tensor, padding_mask: Optional[torch.Tensor] = None):
         """Host side of a call, done once per batch: upload the waveform, turn the sample-level padding mask into
         frame counts (hubert.py:400-410).  Returns ``(wave_dev, frame_lens_dev int32, frame_pad_mask_host, T)``;
@@ -196,7 +215,9 @@ class HubertFrontend:
             raise ValueError(f"{N} samples are shorter than the conv stack's receptive field")
         if padding_mask is None:
             padding_mask = torch.zeros(B, N, dtype=torch.bool)
-        fpm = self.frame_padding_mask(padding_mask.cpu(), T)
+        fpm = self._suffix_frame_mask(padding_mask, T)
+        if fpm is None:  # (not a suffix mask at the sample level: the general reduction decides)
+            fpm = self.frame_padding_mask(padding_mask.cpu(), T)
         if not bool(((~fpm).long().cumsum(1)[:, -1:] == (~fpm).long().sum(1, keepdim=True)).all()) or \
                 bool((fpm[:, :-1] & ~fpm[:, 1:]).any()):
             raise ValueError("padding must be a suffix of every utterance")

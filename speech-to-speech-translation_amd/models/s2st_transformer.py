@@ -127,6 +127,7 @@ class S2STTransformerModel(ModelBase):  # fairseq's BaseFairseqModel when fairse
         # frozen HuBERT front end (s2st_transformer.py:685-703): hubert_base geometry unless the
         # caller passes ``hubert_geometry`` (tests); weights from --load-pretrained-hubert-from
         self.hubert = None
+        self._fe_stream = None  # front_end_ahead's stream
         if str(getattr(args, "use_hubert", "false")) == "true":
             from .hubert import HubertFrontend
             geo = dict(getattr(args, "hubert_geometry", None) or {})
@@ -304,8 +305,45 @@ class S2STTransformerModel(ModelBase):  # fairseq's BaseFairseqModel when fairse
         io = getattr(sample, "hubert_io", None)
         if io is None:
             raise ValueError("a batch prepared without the HuBERT front end was given to a --use-hubert model")
+        ev = getattr(sample, "fe_ready", None)
+        if ev is not None:  # computed ahead (front_end_ahead): the step only waits for it
+            torch.cuda.current_stream().wait_event(ev)
+            sample.fe_ready = None
+            return sample
+        if self._fe_stream is not None:  # (one front-end call at a time: they share the front end's workspace)
+            torch.cuda.current_stream().wait_stream(self._fe_stream)
         self.hubert.eval()
         self.hubert.forward_into(*io)
+        return sample
+
+    def front_end_ahead(self, sample, after=None):
+        """The frozen front end of an UPCOMING prepared batch, launched now on a second stream: HuBERT does not depend on the
+        update in flight, so its forward for batch i + 1 runs beside the training step of batch i (whose small dependent
+        kernels leave most of the chip idle) instead of in front of step i + 1.  Same kernels, same results; the step then
+        only waits for the event (``front_end_sample``).  Call it right before ``train_step`` of the CURRENT batch: the
+        second stream first waits for everything enqueued so far (earlier readers of this batch's feature buffer) and for
+        ``after`` (the upload event of a prefetched batch).  No-op without --use-hubert, on CPU, or with
+        S2ST_HUBERT_AHEAD=0 (A/B switch)."""
+        import os
+        io = getattr(sample, "hubert_io", None) if sample is not None else None
+        if self.hubert is None or io is None or not io[0].is_cuda or getattr(sample, "fe_ready", None) is not None \
+                or os.environ.get("S2ST_HUBERT_AHEAD", "1") == "0":
+            return sample
+        if self._fe_stream is None:
+            self._fe_stream = torch.cuda.Stream(device=self.engine.device)
+        fe = self._fe_stream
+        fe.wait_stream(torch.cuda.current_stream())
+        if after is not None:
+            fe.wait_event(after)
+        self.hubert.eval()
+        with torch.cuda.stream(fe):
+            self.hubert.forward_into(*io)
+            ev = torch.cuda.Event()
+            ev.record(fe)
+        for t in io:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(fe)
+        sample.fe_ready = ev
         return sample
 
     def forward(self, src_tokens, src_lengths, collated_audios, padding_mask, prev_output_tokens,

@@ -54,6 +54,7 @@ class DevicePrefetcher:
         self.cuda = engine.device.type == "cuda"
         self.stream = torch.cuda.Stream(device=engine.device) if self.cuda else None
         self._stop = False
+        self._held = None  # (the look-ahead item of a --use-hubert run)
         self.thread = threading.Thread(target=self._run, args=(iter(batches),), daemon=True)
         self.thread.start()
 
@@ -89,11 +90,22 @@ class DevicePrefetcher:
         return self
 
     def __next__(self):
-        item = self.q.get()
+        # --use-hubert: one batch of look-ahead -- when batch k is handed out, the frozen front end of batch k + 1 is
+        # launched on the model's second stream (``front_end_ahead``), to run beside training step k
+        ahead = self.model is not None and getattr(self.model, "hubert", None) is not None and self.cuda
+        if self._held is not None:
+            item, self._held = self._held, None
+        else:
+            item = self.q.get()
         if item is StopIteration:
             raise StopIteration
         if isinstance(item, BaseException):
             raise item
+        if ahead and isinstance(item, PreparedBatch):
+            nxt = self.q.get()
+            self._held = nxt
+            if isinstance(nxt, PreparedBatch):
+                self.model.front_end_ahead(nxt, after=nxt.ready)
         return item.wait() if isinstance(item, PreparedBatch) else item
 
     def close(self):

@@ -268,6 +268,38 @@ def test_use_hubert_training_steps_against_oracle(backend):
     assert ss == batches[0]["ntokens"] and math.isfinite(float(log["loss"]))
 
 
+def test_hubert_front_end_ahead_of_the_step_gives_the_same_updates(backend):
+    """--use-hubert: the frozen front end of batch i + 1 launched beside step i (model.front_end_ahead: second stream, the
+    step only waits for an event; DevicePrefetcher does it with one batch of look-ahead) == the front end inside each step:
+    same losses, same parameters -- HuBERT does not depend on the update.  On the CPU emulator the call is a pass-through
+    (nothing to overlap), so the three loops are the same code path there; on the GPU they differ."""
+    P = importlib.import_module(PKG + ".runtime.prefetch")
+    res = []
+    for mode in ("inline", "ahead", "prefetcher"):
+        geo, cfg, a, task, model, crit, trainer, batches = _hubert_nano_setup(backend)
+        feed = batches + [batches[0], batches[1]]
+        losses = []
+        if mode == "prefetcher":
+            for s in P.DevicePrefetcher(feed, model.engine, depth=2, model=model):
+                losses.append(float(trainer.train_step([s])["logs"][0]["loss"]))
+        else:
+            prepared = [model.prepare_sample(s, training=True) for s in feed]
+            for i, pb in enumerate(prepared):
+                if mode == "ahead" and i + 1 < len(prepared):
+                    model.front_end_ahead(prepared[i + 1])
+                    if backend.kind == "hip":
+                        assert prepared[i + 1].fe_ready is not None
+                losses.append(float(trainer.train_step([pb])["logs"][0]["loss"]))
+                assert getattr(pb, "fe_ready", None) is None  # (consumed by the step)
+        backend.sync()
+        res.append((losses, {n: p.detach().clone() for n, p in model.named_parameters()}))
+    for other in res[1:]:
+        assert all(abs(x - y) <= 1e-6 * abs(x) for x, y in zip(res[0][0], other[0])), (res[0][0], other[0])
+        for n, p in res[0][1].items():
+            if not (n.endswith("k_proj.bias") or (".postnet.convolutions." in n and n.endswith(".0.bias"))):
+                assert float((p - other[1][n]).abs().max()) <= 1e-6, n
+
+
 def test_use_hubert_with_ctc_fails_like_the_reference(backend):
     """s2st_loss.py:231-232 derives the CTC input lengths from the fbank lengths (100 fps) although the
     encoder ran on HuBERT frames (50 fps); F.ctc_loss then raises 'Expected input_lengths to have value at most E'

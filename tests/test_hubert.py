@@ -90,3 +90,24 @@ def test_base_hubert_golden(backend, golden_dir, precise):
     ref = torch.from_numpy(z["sample"])
     err = ((y.cpu()[:, ::5, ::16] - ref).abs() * valid).max() / ref.abs().max()
     assert float(err) < (3e-4 if precise else 4e-2), float(err)
+
+
+def test_frame_padding_mask_fast_path_equals_the_reduction():
+    """hubert.py:400-410 (a frame is padding iff all samples of its chunk are) for suffix masks from the row's valid-sample
+    count (HubertFrontend._suffix_frame_mask, the staging path of every --use-hubert batch) == the [B][T][chunk] reduction
+    the reference does, over random lengths / frame counts incl. rows without padding, fully padded rows and lengths that
+    are not a multiple of the frame count; a mask whose padding is not a suffix is left to the general path."""
+    F = importlib.import_module("speech-to-speech-translation_amd.models.hubert").HubertFrontend
+    rs = np.random.RandomState(0)
+    for trial in range(300):
+        B, N = rs.randint(1, 5), rs.randint(50, 4000)
+        T = rs.randint(1, min(N, 60))
+        pm = torch.zeros(B, N, dtype=torch.bool)
+        for b in range(B):
+            k = N if rs.rand() < 0.2 else rs.randint(0, N + 1)
+            pm[b, k:] = True
+        fast = F._suffix_frame_mask(pm, T)
+        assert fast is not None and torch.equal(F.frame_padding_mask(pm, T), fast), (trial, B, N, T)
+    pm = torch.zeros(2, 100, dtype=torch.bool)
+    pm[0, 10:20] = True
+    assert F._suffix_frame_mask(pm, 7) is None

@@ -1,5 +1,2 @@
-python -m pytest tests/test_inference.py tests/test_inference_mtl.py tests/test_speaker.py tests/test_t2s.py -m gpu -x -q 2>&1 | tail -3 > gpurun_out/r04_t_tests.txt
-python tools/decode_attn_bench.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" > gpurun_out/r04_t_attn_bench.txt
-for f in "S2ST_DECODE_ATTN_V1=1" "S2ST_DECODE_ATTN_NT=1024"; do echo "== $f" >> gpurun_out/r04_t_attn_bench.txt; env $f python tools/decode_attn_bench.py 2>&1 | grep "fp32\|bf16" >> gpurun_out/r04_t_attn_bench.txt; done
-for f in "" "S2ST_DECODE_KV_BF16=1"; do echo "== $f"; env $f S2ST_BENCH_VERBOSE=1 python bench.py --config infer_base 2>gpurun_out/r04_t.err | tail -1 ; grep "decode_attn\|skinny\|gl_" gpurun_out/r04_t.err; done > gpurun_out/r04_t_infer.txt
-cat gpurun_out/r04_t_tests.txt;  grep -o '"value": [0-9.]*\|"batch0_decode_ms": [0-9.]*\|"mcd_gpu_vs_cpu": [0-9.]*\|== .*\|.*launches.*' gpurun_out/r04_t_infer.txt
+for f in "S2ST_HUBERT_AHEAD=1" "S2ST_HUBERT_AHEAD=0"; do echo "== $f"; env $f python bench.py --config base_recipe_hubert --steps 40 --cpu-seconds 0 2>gpurun_out/r04_w_$f.err | tail -1 | cut -c1-2000; done > gpurun_out/r04_w_hubert.txt
+grep -o '== .*\|"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"host_fed_ms_per_step": [0-9.]*\|"final_loss": [0-9.]*' gpurun_out/r04_w_hubert.txt; 
