@@ -248,19 +248,31 @@ def infer_main(args):
         iters.append(int(s_["target_lengths"].max()))  # teacher length of the batch: deterministic work
     gens = [G.AutoRegressiveSpeechGenerator(model, voc, None, max_iter=it, eos_prob_threshold=2.0) for it in iters]
 
-    def step(i):
-        k = i % len(samples)
-        return gens[k].generate(model, samples[k])
+    # As generate_waveform.py drives it: batch k's hypotheses are collected after batch k + 1 has been enqueued, its vocoder
+    # launches on the generator's second stream -- Griffin-Lim of one batch beside the decoding steps of the next
+    # (S2ST_DEFER_VOCODER=0: strictly one after the other).  Every timed step decodes AND vocodes one batch; the last
+    # batch's vocoder is waited for inside the timed region.
+    DEFER = os.environ.get("S2ST_DEFER_VOCODER", "1") != "0"
 
-    for i in range(max(args.warmup, len(samples))):  # every batch geometry once: workspace sizes, code objects
-        step(i)
+    def run(gen_list, n_steps, first=0):
+        held, n_u, n_f = None, 0, 0
+        for i in range(first, first + n_steps):
+            k = i % len(samples)
+            fin = gen_list[k].generate(model, samples[k], defer_vocoder=DEFER)
+            if held is not None:
+                held.wait()
+                n_u += len(held)
+                n_f += sum(int(f["feature"].shape[0]) for f in held)
+            held = fin
+        held.wait()
+        n_u += len(held)
+        n_f += sum(int(f["feature"].shape[0]) for f in held)
+        return n_u, n_f
+
+    run(gens, max(args.warmup, len(samples)))  # every batch geometry once: workspace sizes, code objects
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n_utt = n_frames = 0
-    for i in range(args.steps):
-        fin = step(i)
-        n_utt += len(fin)
-        n_frames += sum(int(f["feature"].shape[0]) for f in fin)
+    n_utt, n_frames = run(gens, args.steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     vlog("timed region", dt, "s for", n_utt, "utterances")
@@ -268,15 +280,18 @@ def infer_main(args):
     # same distribution, no host-side generator run) -- reported next to `value`, never as it
     voc_d = V.GriffinLimVocoder(spec_bwd_max_iter=INFER_GL_ITERS, device=dev, phase_rng="device", **voc_kw)
     gens_d = [G.AutoRegressiveSpeechGenerator(model, voc_d, None, max_iter=it, eos_prob_threshold=2.0) for it in iters]
-    for k in range(len(samples)):
-        gens_d[k].generate(model, samples[k])
+    run(gens_d, len(samples))
     torch.cuda.synchronize()
     t0d = time.perf_counter()
-    nd = 0
-    for i in range(args.steps):
-        nd += len(gens_d[i % len(samples)].generate(model, samples[i % len(samples)]))
+    nd, _ = run(gens_d, args.steps)
     torch.cuda.synchronize()
     value_device_rng = nd / (time.perf_counter() - t0d)
+    # ... and strictly one after the other (the vocoder on the decoder's stream), for the record
+    t0s = time.perf_counter()
+    for i in range(args.steps):
+        gens[i % len(samples)].generate(model, samples[i % len(samples)])
+    torch.cuda.synchronize()
+    value_serial = args.steps * len(samples[0]["id"]) / (time.perf_counter() - t0s) if len(samples) == 1 else None
     # decode / vocoder split of one batch (un-timed above)
     tA = time.perf_counter()
     g0 = G.AutoRegressiveSpeechGenerator(model, None, None, max_iter=iters[0], eos_prob_threshold=2.0)
@@ -297,8 +312,8 @@ def infer_main(args):
         lib.s2st_profile_report.argtypes = [C.c_char_p, C.c_int64]
         lib.s2st_profile_report.restype = C.c_int64
         lib.s2st_profile_enable(1)
-        for i in range(len(samples)):
-            step(i)
+        for i in range(len(samples)):  # (one stream: the per-dispatch events belong to one queue)
+            gens[i].generate(model, samples[i])
         torch.cuda.synchronize()
         lib.s2st_profile_enable(0)
         buf = C.create_string_buffer(1 << 16)
@@ -400,6 +415,9 @@ def infer_main(args):
                        "name": "infer_base", "utterances_per_step": len(groups[0]), "mel_frames_per_s": round(n_frames / dt, 1),
                        "initial_phases": "numpy global generator on the host (the reference's draws, vocoder.py:101-102)",
                        "value_with_device_phase_rng": round(value_device_rng, 2),
+                       "vocoder_overlap": ("batch k's Griffin-Lim on a second stream beside batch k + 1's decoding steps"
+                                           if DEFER else "off"),
+                       "value_without_vocoder_overlap": round(value_serial, 2) if value_serial else None,
                        "decode_steps_per_batch": iters, "batch0_decode_ms": round(t_dec * 1e3, 2),
                        "batch0_vocoder_alone_ms": round(t_voc * 1e3, 2),
                        "batch0_note": "vocoder alone = called by itself, its phase draws NOT run ahead under the decode as they "

@@ -193,18 +193,11 @@ def main(argv: Optional[List[str]] = None, device: Optional[torch.device] = None
     ids = getattr(dataset, "ids", None)
     written: List[str] = []
     n_utt, n_frames, t_gen, n_batches = 0, 0, 0.0, 0
-    for sample in itr:
-        if sample is None or len(sample) == 0:
-            continue
-        t0 = time.perf_counter()
-        if mtl:  # generate_waveform_mtl.py:195
-            hypos = generator.generate(model, sample, has_targ=args.dump_target and decode_mel,
-                                       decode_source_text=decode_src, decode_target_mel=decode_mel)
-        else:
-            hypos = generator.generate(model, sample, has_targ=args.dump_target)
-        if device.type == "cuda":
-            torch.cuda.synchronize(device)
-        t_gen += time.perf_counter() - t0
+    def finish(sample, hypos):
+        """What the reference's loop does with a batch's hypotheses (generate_waveform.py:172-183 / _mtl.py:196-205)."""
+        nonlocal n_utt, n_frames
+        if hasattr(hypos, "wait"):
+            hypos.wait()  # (the vocoder ran on the generator's second stream, beside the next batch's decoding)
         if decode_src:  # :196-200
             for hypo in hypos:
                 wer.add_string(hypo["src_texts"], hypo["hyps_src_texts"])
@@ -215,9 +208,38 @@ def main(argv: Optional[List[str]] = None, device: Optional[torch.device] = None
                 dump_result(args, args.vocoder, sample_rate, ids[i] if ids is not None else i, hypo, written)
                 n_frames += int(hypo["feature"].shape[0])
             n_utt += 1
+
+    # one batch of overlap on the GPU: batch k's files are written after batch k + 1 has been enqueued, so that its
+    # Griffin-Lim iterations run beside that batch's decoding steps (S2ST_DEFER_VOCODER=0: strictly one after the other)
+    defer = device.type == "cuda" and os.environ.get("S2ST_DEFER_VOCODER", "1") != "0"
+    held = None
+    t_all = time.perf_counter()
+    for sample in itr:
+        if sample is None or len(sample) == 0:
+            continue
+        t0 = time.perf_counter()
+        if mtl:  # generate_waveform_mtl.py:195
+            hypos = generator.generate(model, sample, has_targ=args.dump_target and decode_mel,
+                                       decode_source_text=decode_src, decode_target_mel=decode_mel, defer_vocoder=defer)
+        else:
+            hypos = generator.generate(model, sample, has_targ=args.dump_target, defer_vocoder=defer)
+        if device.type == "cuda" and not defer:
+            torch.cuda.synchronize(device)
+        t_gen += time.perf_counter() - t0
+        if held is not None:
+            finish(*held)
+        held = (sample, hypos)
+        if not defer:
+            finish(*held)
+            held = None
         n_batches += 1
         if args.max_batches and n_batches >= args.max_batches:
             break
+    if held is not None:
+        finish(*held)
+    if defer:  # (generator time cannot be told from file writing when the two overlap: the loop's wall time)
+        torch.cuda.synchronize(device)
+        t_gen = time.perf_counter() - t_all
     out = {"utterances": n_utt, "mel_frames": n_frames, "generate_seconds": t_gen, "batches": n_batches,
            "files": written, "sample_rate": sample_rate}
     if decode_src:  # :207-210

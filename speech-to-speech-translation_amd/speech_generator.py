@@ -12,6 +12,25 @@ import torch
 from .runtime import binding as bd
 
 
+class PendingHypos(list):
+    """Finalized hypotheses whose vocoder outputs are still being computed on the generator's second stream."""
+    _events = ()
+
+    def wait(self):
+        """Make the current stream wait for the vocoder launches; afterwards the list is an ordinary result."""
+        if self._events:
+            cur = torch.cuda.current_stream()
+            for ev in self._events:
+                cur.wait_event(ev)
+            for h in self:
+                for k in ("waveform", "targ_waveform"):
+                    w = h.get(k)
+                    if torch.is_tensor(w) and w.is_cuda:
+                        w.record_stream(cur)
+            self._events = ()
+        return self
+
+
 class SpeechGenerator:
     def __init__(self, model, vocoder, data_cfg=None):
         self.model, self.vocoder = model, vocoder
@@ -35,6 +54,36 @@ class SpeechGenerator:
 
     def get_waveform(self, feat):
         return None if self.vocoder is None else self.vocoder(feat).squeeze(0)
+
+    # ``generate(..., defer_vocoder=True)``: the batch's vocoder launches go to a SECOND stream and the call returns a
+    # ``PendingHypos`` -- the same list, whose "waveform" tensors are complete only after ``.wait()``.  A driver that calls
+    # ``generate`` for the next batch before it waits (generate_waveform.py, bench.py) gets the Griffin-Lim iterations of
+    # batch k -- few large launches -- beside the decoding steps of batch k + 1 -- thousands of small dependent ones that
+    # leave most of the chip idle.  Host-side order is unchanged (batch k's phase draws precede batch k + 1's), so are
+    # the results.  Measured on the bench batch: 118.7 -> 111.7 ms per batch only -- the decoding steps under a running
+    # Griffin-Lim kernel take 17 us instead of 8 (shared HBM / L2, not queue arbitration: a high-priority decode queue,
+    # fewer Griffin-Lim workgroups per CU and shorter-lived ones changed nothing; profiles/r04_z_*).
+    defer_vocoder = False
+
+    def _vocode(self, feats):
+        if not (self.defer_vocoder and self.vocoder is not None and feats and feats[0].is_cuda):
+            return self.get_waveforms(feats), None
+        vs = getattr(self.vocoder, "_defer_stream", None)  # (one per vocoder: generators that share it share the stream)
+        if vs is None:
+            vs = torch.cuda.Stream(device=feats[0].device)
+            try:
+                self.vocoder._defer_stream = vs
+            except AttributeError:
+                pass
+        cur = torch.cuda.current_stream()
+        vs.wait_stream(cur)
+        with torch.cuda.stream(vs):
+            waves = self.get_waveforms(feats)
+            ev = torch.cuda.Event()
+            ev.record(vs)
+        for f in feats:
+            f.record_stream(vs)
+        return waves, ev
 
     def get_waveforms(self, feats):
         """All utterances of a batch through the vocoder together (same random-phase draws, in the same
@@ -70,10 +119,14 @@ class AutoRegressiveSpeechGenerator(SpeechGenerator):
                                              ni.get("collated_audios_orig"), ni.get("padding_mask"))
         bsz = src.shape[0]
         self._enc = eng.decode_begin(src, src_lens, self.max_iter, speaker=sample.get("speaker"))
-        finalized = [dict() for _ in range(bsz)]
-        self._decode_mel(model, sample, bsz, finalized)
-        if has_targ:
-            self._add_targets(model, sample, bsz, finalized)
+        self.defer_vocoder = bool(kwargs.get("defer_vocoder", False))
+        finalized = PendingHypos(dict() for _ in range(bsz))
+        try:
+            self._decode_mel(model, sample, bsz, finalized)
+            if has_targ:
+                self._add_targets(model, sample, bsz, finalized)
+        finally:
+            self.defer_vocoder = False
         return finalized
 
     def _decode_mel(self, model, sample, bsz: int, finalized: List[Dict]) -> None:
@@ -95,7 +148,12 @@ class AutoRegressiveSpeechGenerator(SpeechGenerator):
         LAG = 4
         bufs = eng.decode_buffers(self.max_iter)
         on_gpu = dev.type == "cuda"
-        pinned = torch.zeros(self.max_iter, dtype=torch.int32, pin_memory=on_gpu)
+        # (a persistent pinned buffer: a fresh pinned allocation waits for the whole device, i.e. for a deferred vocoder)
+        pinned = self.__dict__.get("_pinned_done")
+        if pinned is None or pinned.numel() < self.max_iter:
+            pinned = self._pinned_done = torch.zeros(self.max_iter, dtype=torch.int32, pin_memory=on_gpu)
+        pinned = pinned[:self.max_iter]
+        pinned.zero_()
         events = []
         n_steps = self.max_iter
         for step in range(self.max_iter):
@@ -134,7 +192,9 @@ class AutoRegressiveSpeechGenerator(SpeechGenerator):
         alignment = alignment.repeat_interleave(n_frames_per_step, dim=1)
         out_lens = out_lens * n_frames_per_step
         lens = out_lens.tolist()
-        waves = self.get_waveforms([feat[b, :l] for b, l in enumerate(lens)])
+        waves, ev = self._vocode([feat[b, :l] for b, l in enumerate(lens)])
+        if ev is not None:
+            finalized._events = tuple(finalized._events) + (ev,)
         for b, l in enumerate(lens):
             finalized[b].update({"feature": feat[b, :l], "eos_prob": eos_prob[b, :l], "attn": attn[b, :, :l],
                                  "alignment": alignment[b, :l], "waveform": waves[b]})
@@ -147,7 +207,9 @@ class AutoRegressiveSpeechGenerator(SpeechGenerator):
         assert sample["tgt_speech"].size(-1) == eng.cfg.out_dim
         tgt = self.gcmvn_denormalize(sample["tgt_speech"].to(eng.device, torch.float32).reshape(bsz, -1, raw_dim))
         tl = (sample["target_lengths"] * n_frames_per_step).tolist()
-        twaves = self.get_waveforms([tgt[b, :l] for b, l in enumerate(tl)])
+        twaves, ev = self._vocode([tgt[b, :l] for b, l in enumerate(tl)])
+        if ev is not None:
+            finalized._events = tuple(finalized._events) + (ev,)
         for b, l in enumerate(tl):
             finalized[b]["targ_feature"] = tgt[b, :l]
             finalized[b]["targ_waveform"] = twaves[b]

@@ -23,7 +23,7 @@ import torch
 
 from .runtime import binding as bd
 from .scoring import build_scorer
-from .speech_generator import AutoRegressiveSpeechGenerator as _BaseARGenerator
+from .speech_generator import AutoRegressiveSpeechGenerator as _BaseARGenerator, PendingHypos
 
 
 class AutoRegressiveSpeechGenerator(_BaseARGenerator):
@@ -50,7 +50,7 @@ class AutoRegressiveSpeechGenerator(_BaseARGenerator):
         src, src_lens = ni["src_speech"], ni["src_speech_lens"]
         bsz = src.shape[0]
         enc = eng.decode_begin(src, src_lens, self.max_iter, speaker=sample.get("speaker"))
-        finalized: List[Dict] = [dict() for _ in range(bsz)]
+        finalized: List[Dict] = PendingHypos(dict() for _ in range(bsz))
         if kwargs.get("decode_source_text"):
             if not eng.cfg.has_ctc:
                 raise ValueError("decode_source_text needs the model's source-text CTC head (--ctc-weight > 0)")
@@ -70,8 +70,12 @@ class AutoRegressiveSpeechGenerator(_BaseARGenerator):
                 finalized[b]["src_texts"] = src_texts[b]
                 finalized[b]["hyps_src_texts"] = hyp_texts[b]
                 finalized[b]["hyps_src_tokens"] = hyps[b]
-        if kwargs.get("decode_target_mel"):
-            self._decode_mel(model, sample, bsz, finalized)
-        if has_targ:
-            self._add_targets(model, sample, bsz, finalized)
+        self.defer_vocoder = bool(kwargs.get("defer_vocoder", False))
+        try:
+            if kwargs.get("decode_target_mel"):
+                self._decode_mel(model, sample, bsz, finalized)
+            if has_targ:
+                self._add_targets(model, sample, bsz, finalized)
+        finally:
+            self.defer_vocoder = False
         return finalized

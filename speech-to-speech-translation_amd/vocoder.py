@@ -16,6 +16,8 @@ The mel filterbank comes from librosa in the reference (absent in this image, ve
 """
 from __future__ import annotations
 
+from typing import Optional
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -127,13 +129,16 @@ class _HostMTStream:
     sequential draws would have left it (the share boundary in front of n + a short output-less run) -- or None when somebody
     used the global generator in between."""
 
-    def __init__(self, n_upper: int, pin: bool, threads: int = 0):
+    def __init__(self, n_upper: int, pin: bool, threads: int = 0, buf: Optional[torch.Tensor] = None):
         import os
         import threading
         self.state0 = np.random.get_state()
         self.n = int(n_upper)
         self.threads = int(threads) or max(1, min(8, (os.cpu_count() or 2) - 1))
-        self.buf = torch.empty(max(self.n, 1), dtype=torch.float64, pin_memory=pin)
+        # (``buf``: a caller-owned pinned buffer -- a fresh pinned allocation of this size is a hipHostMalloc, which waits
+        # for the whole device: it serialised a deferred vocoder with the next batch's decode)
+        self.buf = buf if buf is not None and buf.numel() >= max(self.n, 1) else \
+            torch.empty(max(self.n, 1), dtype=torch.float64, pin_memory=pin)
         w = np.zeros(625, dtype=np.uint32)
         w[:624] = self.state0[1]
         w[624] = self.state0[2]
@@ -290,9 +295,33 @@ class GriffinLim:
             elif how == "device":
                 self._stream = _DeviceMTStream(n, self.device)
             elif how == "host":
-                self._stream = _HostMTStream(n, self.device.type == "cuda")
+                self._stream = _HostMTStream(n, self.device.type == "cuda", buf=self._ring_buffer(n))
             elif how != "off":
                 raise ValueError("S2ST_GL_PHASE_STREAM must be host, numpy, device or off")
+
+    def _ring_buffer(self, n: int):
+        """One of two persistent pinned staging buffers for the run-ahead draws, alternating, each guarded by the event of
+        the upload that last read it (two: batch k's upload may still be in flight on the vocoder's stream when batch
+        k + 1's generator starts filling)."""
+        if self.device.type != "cuda":
+            return None
+        ring = self.__dict__.setdefault("_pin_ring", [[None, None], [None, None]])
+        self._ring_i = (self.__dict__.get("_ring_i", -1) + 1) % 2
+        slot = ring[self._ring_i]
+        if slot[1] is not None:
+            slot[1].synchronize()  # (two batches old: long complete)
+            slot[1] = None
+        if slot[0] is None or slot[0].numel() < n:
+            slot[0] = torch.empty(int(n * 1.05) + 1, dtype=torch.float64, pin_memory=True)
+        return slot[0]
+
+    def _ring_uploaded(self, host: torch.Tensor):
+        """Record, on the current stream, that the asynchronous upload of a ring buffer was just enqueued."""
+        for slot in self.__dict__.get("_pin_ring", ()):
+            if slot[0] is not None and slot[0].data_ptr() == host.data_ptr():
+                ev = torch.cuda.Event()
+                ev.record()
+                slot[1] = ev
 
     @property
     def fwd(self):
@@ -427,6 +456,8 @@ class GriffinLim:
                 ahead, self._stream = (self._stream.take(n_all) if self._stream is not None else None), None
                 if ahead is not None:  # drawn while the decoder ran (prefetch_phases)
                     uni = ahead if ahead.device == dev else ahead.to(dev, non_blocking=True)
+                    if ahead.device != dev and dev.type == "cuda":
+                        self._ring_uploaded(ahead)
                 else:
                     if self._pin is None or self._pin.numel() < n_all:
                         self._pin = torch.empty(n_all, dtype=torch.float64, pin_memory=dev.type == "cuda")

@@ -638,3 +638,41 @@ def test_decode_attention_kernels(backend, monkeypatch, dh, H, kv_bf16, nt):
             backend.bd.call("s2st_decode_attn_f32", torch.zeros(1, 32, device=dev), 32, torch.zeros(4, 32, device=dev),
                             torch.zeros(4, 32, device=dev), 32, 128, None, 4, 1, 1, 32, 1.0, torch.zeros(1, 32, device=dev), 32,
                             None, 0, None, None, 0, 0, 1)
+
+
+def test_deferred_vocoder_gives_the_same_hypotheses(backend):
+    """generate(..., defer_vocoder=True): the vocoder launches of batch k go to a second stream and the caller collects them
+    (PendingHypos.wait) after it has enqueued batch k + 1 -- as generate_waveform.py and bench.py drive it.  Same features,
+    same waveforms (numpy's phase stream is consumed in batch order either way) as one batch after the other; on the CPU
+    emulator the deferral is a pass-through."""
+    gen_mod = importlib.import_module(PKG + ".speech_generator")
+    V = importlib.import_module(PKG + ".vocoder")
+    a, model = _build_model(backend, AR_CFG)
+    nm = AR_CFG["out_dim"] // AR_CFG["n_frames_per_step"] if "out_dim" in AR_CFG else 80
+    voc = V.GriffinLimVocoder(spec_bwd_max_iter=2, device=backend.device, sample_rate=16000, win_size=200, hop_size=64, n_fft=256,
+                              n_mels=nm, f_min=20, f_max=8000)
+    gen = gen_mod.AutoRegressiveSpeechGenerator(model, voc, None, max_iter=6, eos_prob_threshold=0.6)
+    batches = []
+    for i in (0, 1, 0):
+        s = golden_sample("tiny", i)
+        s["net_input"]["collated_audios_orig"] = None
+        s["net_input"]["padding_mask"] = None
+        batches.append(s)
+    np.random.seed(11)
+    plain = [gen.generate(model, s, has_targ=True) for s in batches]
+    backend.sync()
+    np.random.seed(11)
+    piped, held = [], None
+    for s in batches:
+        fin = gen.generate(model, s, has_targ=True, defer_vocoder=True)
+        assert hasattr(fin, "wait")
+        if held is not None:
+            piped.append(held.wait())
+        held = fin
+    piped.append(held.wait())
+    backend.sync()
+    for x, y in zip(plain, piped):
+        assert len(x) == len(y)
+        for hx, hy in zip(x, y):
+            for k in ("feature", "waveform", "targ_waveform", "alignment"):
+                assert torch.equal(hx[k], hy[k]), k
