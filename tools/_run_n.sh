@@ -1,2 +1,4 @@
-for f in "S2ST_DECODE_PRIORITY=high" "S2ST_DECODE_PRIORITY=high S2ST_GL_LDS_FREE_KB=64" "S2ST_DECODE_PRIORITY=high S2ST_GL_OLA_FRAMES=16"; do echo "== $f"; env $f python bench.py --config infer_base --cpu-utts 2 --no-roofline 2>gpurun_out/r04_y.err | tail -1 ; done > gpurun_out/r04_y_infer.txt
-grep -o '"value": [0-9.]*\|"value_with[a-z_]*": [0-9.]*\|== .*' gpurun_out/r04_y_infer.txt; tail -3 gpurun_out/r04_y.err
+python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -6 > gpurun_out/r04_aa_gputests.txt
+python bench.py > gpurun_out/r04_aa_bench.txt 2>gpurun_out/r04_aa_bench.err
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r04_aa_smoke.txt 2>&1
+tail -4 gpurun_out/r04_aa_gputests.txt; cut -c1-400 gpurun_out/r04_aa_bench.txt; tail -2 gpurun_out/r04_aa_smoke.txt
