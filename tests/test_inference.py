@@ -676,3 +676,33 @@ def test_deferred_vocoder_gives_the_same_hypotheses(backend):
         for hx, hy in zip(x, y):
             for k in ("feature", "waveform", "targ_waveform", "alignment"):
                 assert torch.equal(hx[k], hy[k]), k
+
+
+@pytest.mark.parametrize("n_fft,win,hop", [(256, 256, 160), (256, 256, 256), (512, 400, 300), (256, 200, 8)])
+def test_fft_griffin_lim_edge_geometries(backend, monkeypatch, n_fft, win, hop):
+    """The one-launch inverse transform's circular accumulator at its limits: hop > n_fft / 2 (accumulator of 4 n_fft),
+    hop = n_fft (no overlap at all), a tiny hop (32 frames under every sample), and batches that mix one-frame utterances
+    (no output samples: vocoder.py:95-97 trims n_fft / 2 at both ends) with long ones -- against the float64 numpy form and
+    the two-kernel form."""
+    V = importlib.import_module(PKG + ".vocoder")
+    rs = np.random.RandomState(n_fft + hop)
+    Fq = n_fft // 2 + 1
+    Ts = (1, 37, 2, 90 if hop >= 64 else 300)
+    specs = [np.abs(rs.randn(Fq, t)).astype(np.float32) for t in Ts]
+    angs = [IO.initial_angles((Fq, t), rs) for t in Ts]
+    gl = V.GriffinLim(n_fft, win, hop, 1, backend.device)
+    assert gl.use_fft
+    out = gl.batch([torch.from_numpy(s) for s in specs], angs)
+    monkeypatch.setenv("S2ST_GL_OLA_FUSE", "0")
+    out2 = V.GriffinLim(n_fft, win, hop, 1, backend.device).batch([torch.from_numpy(s) for s in specs], angs)
+    monkeypatch.delenv("S2ST_GL_OLA_FUSE")
+    backend.sync()
+    for s, a_, w, w2 in zip(specs, angs, out, out2):
+        assert w.shape == w2.shape == (hop * (s.shape[1] - 1),)
+        if w.numel() == 0:
+            continue
+        scale = float(w2.abs().max())
+        assert float((w - w2).abs().max()) <= 2e-5 * scale
+        if hop * (s.shape[1] - 1) > n_fft // 2:  # (shorter signals cannot be reflect-padded: the reference fails there too)
+            ref = _gl_numpy_fft(s, a_, n_fft, win, hop, 1)
+            assert float(np.abs(w.cpu().numpy() - ref).max()) < 2e-4 * float(np.abs(ref).max())
