@@ -432,6 +432,12 @@ int s2st_gl_frame_split_f32(const float* wave, const int32_t* tl, void* As, int3
  * s2st_gl_polar_c_f32: X = mag * exp(i ang) (vocoder.py:101-103).  s2st_gl_stft_project_f32: reflect-pad + frame + window +
  * rfft of wave [U][Lw], then X = mag * Y / |Y| (vocoder.py:104-107).  s2st_gl_istft_frames_f32: synthesis frames
  * [U * Tmax][n_fft] for s2st_gl_overlap_add_b_f32. */
+/* First block of the HuBERT / wav2vec 2.0 feature extractor (fairseq/models/wav2vec/wav2vec2.py:777-783, 806-814:
+ * Conv1d(1, C, k, stride, bias=False) -> Fp32GroupNorm(C, C) -> GELU) on wave [B][N]: y / y_bf16 [B][T][C] (channel-last;
+ * either may be NULL), T = (N - k) / stride + 1, statistics over the T frames of each (utterance, channel).  stats: scratch
+ * of s2st_hubert_conv0_stats_floats_i64(B, T, C) floats.  k <= 16, stride <= 8, C % 4 == 0. */
+int64_t s2st_hubert_conv0_stats_floats_i64(int32_t B, int32_t T, int32_t C);
+int s2st_hubert_conv0_gn_gelu_f32(const float* wave, const float* w, const float* gamma, const float* beta, float* y, uint16_t* y_bf16, float* stats, int32_t B, int32_t N, int32_t T, int32_t C, int32_t k, int32_t stride, float eps, void* stream);
 /* One decoding step's attention (fairseq/modules/multihead_attention.py:194-385 with incremental_state: one query per
  * utterance against the cached keys / values, key padding mask = klen, softmax, weighted values; head-averaged weights of the
  * alignment layer into attn_mean [B][S], zeroed here).  q [B][ldq] (head h at columns h * dh); caches: row s of utterance b at

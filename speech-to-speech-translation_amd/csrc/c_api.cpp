@@ -193,6 +193,10 @@ int s2st_gl_polar_split_f32(const float* mag, const float* aux, int32_t from_spe
 int s2st_gl_frame_split_f32(const float* wave, const int32_t* tl, void* As, int32_t U, int32_t Tmax, int32_t hop, int32_t n_fft, int32_t Lw, void* stream) {
   return s2st_gl_frame_split(wave, tl, (uint16_t*)As, U, Tmax, hop, n_fft, Lw, (hipStream_t)stream);
 }
+int64_t s2st_hubert_conv0_stats_floats_i64(int32_t B, int32_t T, int32_t C) { return s2st_hubert_conv0_stats_floats(B, T, C); }
+int s2st_hubert_conv0_gn_gelu_f32(const float* wave, const float* w, const float* gamma, const float* beta, float* y, uint16_t* y_bf16, float* stats, int32_t B, int32_t N, int32_t T, int32_t C, int32_t k, int32_t stride, float eps, void* stream) {
+  return s2st_hubert_conv0_gn_gelu(wave, w, gamma, beta, y, y_bf16, stats, B, N, T, C, k, stride, eps, (hipStream_t)stream);
+}
 int s2st_decode_attn_f32(const float* q, int64_t ldq, void* k_cache, void* v_cache, int64_t ldk, int64_t kbs, const int32_t* klen, int32_t nkeys, int32_t B, int32_t H, int32_t dh, float scale, float* o, int64_t ldo, float* attn_mean, int32_t S, const float* k_new, const float* v_new, int64_t ld_new, int32_t pos_new, int32_t kv_bf16, void* stream) {
   return s2st_decode_attn(q, ldq, (float*)k_cache, (float*)v_cache, ldk, kbs, klen, nkeys, B, H, dh, scale, o, ldo, attn_mean, S, (hipStream_t)stream, k_new, v_new, ld_new, pos_new, kv_bf16);
 }

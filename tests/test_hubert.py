@@ -111,3 +111,38 @@ def test_frame_padding_mask_fast_path_equals_the_reduction():
     pm = torch.zeros(2, 100, dtype=torch.bool)
     pm[0, 10:20] = True
     assert F._suffix_frame_mask(pm, 7) is None
+
+
+@pytest.mark.parametrize("k,stride,C,T", [(10, 5, 32, 300), (7, 3, 8, 130), (3, 1, 4, 1), (16, 8, 64, 129)])
+def test_first_block_kernels(backend, k, stride, C, T):
+    """Conv1d(1, C, k, stride, bias=False) -> GroupNorm(C, C) -> GELU (wav2vec2.py:777-783, 806-814) through the C ABI against
+    float64 numpy: the 10-tap form HuBERT uses and the general one (zero-weight taps, clamped reads), several time blocks of
+    128 frames, a single frame (variance 0), a waveform with a large offset (the one-pass statistics work on deviations
+    from the channel's first frame), fp32 and bf16 outputs."""
+    import ctypes as C_
+    from math import erf
+    rs = np.random.RandomState(k * 100 + stride)
+    B = 3
+    N = (T - 1) * stride + k
+    wave = (rs.randn(B, N) + np.array([0.0, 40.0, -3.0])[:, None]).astype(np.float32)
+    w = (rs.randn(C, k) / np.sqrt(k)).astype(np.float32)
+    g = (1.0 + 0.2 * rs.randn(C)).astype(np.float32)
+    b_ = (0.1 * rs.randn(C)).astype(np.float32)
+    idx = np.arange(T)[:, None] * stride + np.arange(k)[None, :]
+    conv = np.einsum("btk,ck->btc", wave.astype(np.float64)[:, idx], w.astype(np.float64))
+    mu, var = conv.mean(1, keepdims=True), conv.var(1, keepdims=True)
+    z = (conv - mu) / np.sqrt(var + 1e-5) * g + b_
+    ref = 0.5 * z * (1.0 + np.vectorize(erf)(z / np.sqrt(2.0)))
+    dev = backend.device
+    lib = backend.bd.lib()
+    lib.s2st_hubert_conv0_stats_floats_i64.restype = C_.c_int64
+    lib.s2st_hubert_conv0_stats_floats_i64.argtypes = [C_.c_int32] * 3
+    stats = torch.empty(int(lib.s2st_hubert_conv0_stats_floats_i64(B, T, C)), device=dev)
+    y = torch.empty(B, T, C, device=dev)
+    yh = torch.empty(B, T, C, dtype=torch.bfloat16, device=dev)
+    backend.bd.call("s2st_hubert_conv0_gn_gelu_f32", torch.from_numpy(wave).to(dev), torch.from_numpy(w).to(dev),
+                    torch.from_numpy(g).to(dev), torch.from_numpy(b_).to(dev), y, yh, stats, B, N, T, C, k, stride, 1e-5)
+    backend.sync()
+    # (an utterance with offset 40: conv values ~ 40 * sum(w) with unit spread; the statistics must not lose the spread)
+    assert float(np.abs(y.cpu().numpy() - ref).max()) < 2e-4 * max(1.0, float(np.abs(ref).max()))
+    assert float(np.abs(yh.float().cpu().numpy() - ref).max()) < 1e-2 * max(1.0, float(np.abs(ref).max()))
