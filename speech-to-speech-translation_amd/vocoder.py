@@ -129,9 +129,13 @@ class _HostMTStream:
     sequential draws would have left it (the share boundary in front of n + a short output-less run) -- or None when somebody
     used the global generator in between."""
 
-    def __init__(self, n_upper: int, pin: bool, threads: int = 0, buf: Optional[torch.Tensor] = None):
+    def __init__(self, n_upper: int, pin: bool, threads: int = 0, buf: Optional[torch.Tensor] = None, upload=None):
+        """``upload``: (device, copy stream, ring slot) -- the generator thread then also uploads the WHOLE upper bound of
+        draws on that stream as soon as they exist (the decoder is still running: the PCIe link is idle), and ``take``
+        hands out a slice of the device copy; without it the caller uploads the n it takes, after the decode."""
         import os
         import threading
+        self.upload, self.dev_buf, self.up_ev = upload, None, None
         self.state0 = np.random.get_state()
         self.n = int(n_upper)
         self.threads = int(threads) or max(1, min(8, (os.cpu_count() or 2) - 1))
@@ -150,6 +154,16 @@ class _HostMTStream:
 
     def _run(self):
         self.rc = _mt_host(self.state_w, self.n, self.buf.data_ptr(), self.bounds, self.threads)
+        if self.upload is not None and self.rc == 0 and self.n > 0:
+            dev, stream, slot = self.upload
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(stream):
+                self.dev_buf = self.buf[:self.n].to(dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+            self.up_ev = ev
+            if slot is not None:
+                slot[1] = ev  # (the ring buffer is free again once this upload has read it)
 
     def take(self, n: int):
         self.thread.join()
@@ -166,6 +180,11 @@ class _HostMTStream:
         if _mt_host(self.bounds[t], n - d0, None, end, 1) != 0:
             return None
         np.random.set_state((self.state0[0], end[1, :624].copy(), int(end[1, 624]), self.state0[3], self.state0[4]))
+        if self.dev_buf is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(self.up_ev)
+            self.dev_buf.record_stream(cur)
+            return self.dev_buf[:n]
         return self.buf[:n]
 
 
@@ -295,7 +314,14 @@ class GriffinLim:
             elif how == "device":
                 self._stream = _DeviceMTStream(n, self.device)
             elif how == "host":
-                self._stream = _HostMTStream(n, self.device.type == "cuda", buf=self._ring_buffer(n))
+                up = None
+                buf = self._ring_buffer(n)
+                if self.device.type == "cuda" and os.environ.get("S2ST_GL_EARLY_UPLOAD", "1") != "0":
+                    # the draws go to the device as soon as the host has them, under the decode (a copy stream of their own)
+                    if self.__dict__.get("_copy_stream") is None:
+                        self._copy_stream = torch.cuda.Stream(device=self.device)
+                    up = (self.device, self._copy_stream, self._pin_ring[self._ring_i])
+                self._stream = _HostMTStream(n, self.device.type == "cuda", buf=buf, upload=up)
             elif how != "off":
                 raise ValueError("S2ST_GL_PHASE_STREAM must be host, numpy, device or off")
 
