@@ -254,19 +254,35 @@ def infer_main(args):
     # batch's vocoder is waited for inside the timed region.
     DEFER = os.environ.get("S2ST_DEFER_VOCODER", "1") != "0"
 
+    # S2ST_DECODE_CHAINS=2 (default): consecutive batches are decoded two at a time (generate_two: the second on a twin
+    # engine and a second stream, the step loops alternated) -- one batch's decoding steps leave most of the chip idle, the
+    # next batch's do not depend on them.  Same hypotheses as one batch after the other (tests/test_inference.py).
+    CHAINS = int(os.environ.get("S2ST_DECODE_CHAINS", "2"))
+
     def run(gen_list, n_steps, first=0):
-        held, n_u, n_f = None, 0, 0
-        for i in range(first, first + n_steps):
+        held, n_u, n_f = [], 0, 0
+
+        def collect():
+            nonlocal n_u, n_f
+            for h in held:
+                h.wait()
+                n_u += len(h)
+                n_f += sum(int(f["feature"].shape[0]) for f in h)
+            held.clear()
+
+        i = first
+        while i < first + n_steps:
             k = i % len(samples)
-            fin = gen_list[k].generate(model, samples[k], defer_vocoder=DEFER)
-            if held is not None:
-                held.wait()
-                n_u += len(held)
-                n_f += sum(int(f["feature"].shape[0]) for f in held)
-            held = fin
-        held.wait()
-        n_u += len(held)
-        n_f += sum(int(f["feature"].shape[0]) for f in held)
+            if CHAINS >= 2 and i + 1 < first + n_steps and gen_list[k] is gen_list[(i + 1) % len(samples)]:
+                k2 = (i + 1) % len(samples)
+                fins = list(gen_list[k].generate_two(model, samples[k], samples[k2], defer_vocoder=DEFER))
+                i += 2
+            else:
+                fins = [gen_list[k].generate(model, samples[k], defer_vocoder=DEFER)]
+                i += 1
+            collect()
+            held.extend(fins)
+        collect()
         return n_u, n_f
 
     run(gens, max(args.warmup, len(samples)))  # every batch geometry once: workspace sizes, code objects
@@ -280,7 +296,7 @@ def infer_main(args):
     # same distribution, no host-side generator run) -- reported next to `value`, never as it
     voc_d = V.GriffinLimVocoder(spec_bwd_max_iter=INFER_GL_ITERS, device=dev, phase_rng="device", **voc_kw)
     gens_d = [G.AutoRegressiveSpeechGenerator(model, voc_d, None, max_iter=it, eos_prob_threshold=2.0) for it in iters]
-    run(gens_d, len(samples))
+    run(gens_d, max(4, len(samples)))  # (its vocoder's buffers and second stream exist before the clock starts)
     torch.cuda.synchronize()
     t0d = time.perf_counter()
     nd, _ = run(gens_d, args.steps)
@@ -417,6 +433,7 @@ def infer_main(args):
                        "value_with_device_phase_rng": round(value_device_rng, 2),
                        "vocoder_overlap": ("batch k's Griffin-Lim on a second stream beside batch k + 1's decoding steps"
                                            if DEFER else "off"),
+                       "decode_chains": CHAINS,
                        "value_without_vocoder_overlap": round(value_serial, 2) if value_serial else None,
                        "decode_steps_per_batch": iters, "batch0_decode_ms": round(t_dec * 1e3, 2),
                        "batch0_vocoder_alone_ms": round(t_voc * 1e3, 2),

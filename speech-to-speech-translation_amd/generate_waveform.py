@@ -212,31 +212,51 @@ def main(argv: Optional[List[str]] = None, device: Optional[torch.device] = None
     # one batch of overlap on the GPU: batch k's files are written after batch k + 1 has been enqueued, so that its
     # Griffin-Lim iterations run beside that batch's decoding steps (S2ST_DEFER_VOCODER=0: strictly one after the other)
     defer = device.type == "cuda" and os.environ.get("S2ST_DEFER_VOCODER", "1") != "0"
-    held = None
+    # ... and two batches are DECODED at once (generate_two: the second on a twin engine and a second stream) where the
+    # generator has that form: the decoding steps of one batch leave most of the chip idle (S2ST_DECODE_CHAINS=1: one by one)
+    chains = 2 if (defer and not mtl and hasattr(generator, "generate_two")
+                   and os.environ.get("S2ST_DECODE_CHAINS", "2") != "1") else 1
+
+    def groups():
+        buf, n = [], 0
+        for sample in itr:
+            if sample is None or len(sample) == 0:
+                continue
+            buf.append(sample)
+            n += 1
+            last = bool(args.max_batches and n >= args.max_batches)
+            if len(buf) == chains or last:
+                yield buf
+                buf = []
+            if last:
+                return
+        if buf:
+            yield buf
+
+    held = []
     t_all = time.perf_counter()
-    for sample in itr:
-        if sample is None or len(sample) == 0:
-            continue
+    for group in groups():
         t0 = time.perf_counter()
-        if mtl:  # generate_waveform_mtl.py:195
-            hypos = generator.generate(model, sample, has_targ=args.dump_target and decode_mel,
-                                       decode_source_text=decode_src, decode_target_mel=decode_mel, defer_vocoder=defer)
+        if len(group) == 2:
+            hyps = list(generator.generate_two(model, group[0], group[1], has_targ=args.dump_target, defer_vocoder=defer))
+        elif mtl:  # generate_waveform_mtl.py:195
+            hyps = [generator.generate(model, group[0], has_targ=args.dump_target and decode_mel,
+                                       decode_source_text=decode_src, decode_target_mel=decode_mel, defer_vocoder=defer)]
         else:
-            hypos = generator.generate(model, sample, has_targ=args.dump_target, defer_vocoder=defer)
+            hyps = [generator.generate(model, group[0], has_targ=args.dump_target, defer_vocoder=defer)]
         if device.type == "cuda" and not defer:
             torch.cuda.synchronize(device)
         t_gen += time.perf_counter() - t0
-        if held is not None:
-            finish(*held)
-        held = (sample, hypos)
+        for h in held:
+            finish(*h)
+        held = list(zip(group, hyps))
         if not defer:
-            finish(*held)
-            held = None
-        n_batches += 1
-        if args.max_batches and n_batches >= args.max_batches:
-            break
-    if held is not None:
-        finish(*held)
+            for h in held:
+                finish(*h)
+            held = []
+        n_batches += len(group)
+    for h in held:
+        finish(*h)
     if defer:  # (generator time cannot be told from file writing when the two overlap: the loop's wall time)
         torch.cuda.synchronize(device)
         t_gen = time.perf_counter() - t_all

@@ -150,7 +150,10 @@ def conv_out_len(n: int, k: int, stride: int = 2) -> int:
 class Engine:
     """Owns the arenas and the native engine handle."""
 
-    def __init__(self, args, device: torch.device, precise: bool = False):
+    def __init__(self, args, device: torch.device, precise: bool = False, share_with: Optional["Engine"] = None):
+        """``share_with``: an INFERENCE twin of another engine -- the same fp32 parameter / gradient / buffer arenas (read-only
+        there), its own bf16 copies, workspace, caches and streams: a second, independent decode chain over the same
+        weights (``Engine.inference_twin``)."""
         self.args = args
         self.device = device
         self.lib = bd.lib()
@@ -184,9 +187,13 @@ class Engine:
             bd.check(self.lib.s2st_engine_param_info(h, i, C.byref(pi)), "param_info")
             self.infos.append((pi.name.decode(), int(pi.offset), int(pi.numel),
                                tuple(pi.shape[:pi.ndim]), bool(pi.is_buffer)))
-        self.params = torch.zeros(self.n_params, dtype=torch.float32, device=device)
-        self.grads = torch.zeros(self.n_params, dtype=torch.float32, device=device)
-        self.buffers = torch.zeros(max(self.n_buffers, 4), dtype=torch.float32, device=device)
+        if share_with is not None:
+            assert share_with.n_params == self.n_params and share_with.n_buffers == self.n_buffers
+            self.params, self.grads, self.buffers = share_with.params, share_with.grads, share_with.buffers
+        else:
+            self.params = torch.zeros(self.n_params, dtype=torch.float32, device=device)
+            self.grads = torch.zeros(self.n_params, dtype=torch.float32, device=device)
+            self.buffers = torch.zeros(max(self.n_buffers, 4), dtype=torch.float32, device=device)
         self.lib.s2st_engine_bind(h, self.params.data_ptr(), self.grads.data_ptr(), self.buffers.data_ptr())
         # fast mode: bf16 copy of the parameter arena (refreshed by the engine every forward)
         self.params_bf16 = None
@@ -216,6 +223,13 @@ class Engine:
         self._plan: Dict[tuple, int] = {}
         self._keep = None
         self.step_seed = 1
+
+    def inference_twin(self) -> "Engine":
+        """A second engine over the same weights (created once, kept): for decoding two batches as two interleaved chains."""
+        tw = self.__dict__.get("_twin")
+        if tw is None:
+            tw = self._twin = Engine(self.args, self.device, precise=bool(self.cfg.precise), share_with=self)
+        return tw
 
     def __del__(self):
         try:

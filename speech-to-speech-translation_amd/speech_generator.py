@@ -22,9 +22,8 @@ class PendingHypos(list):
             cur = torch.cuda.current_stream()
             for ev in self._events:
                 cur.wait_event(ev)
-            for h in self:
-                for k in ("waveform", "targ_waveform"):
-                    w = h.get(k)
+            for h in self:  # (everything a second stream produced is read on this one from now on)
+                for w in h.values():
                     if torch.is_tensor(w) and w.is_cuda:
                         w.record_stream(cur)
             self._events = ()
@@ -129,9 +128,75 @@ class AutoRegressiveSpeechGenerator(SpeechGenerator):
             self.defer_vocoder = False
         return finalized
 
+    @torch.no_grad()
+    def generate_two(self, model, sample_a, sample_b, has_targ: bool = False, **kwargs):
+        """Two batches decoded AT ONCE: the decoding steps of one batch are thousands of small dependent launches that leave
+        most of the chip idle, and the other batch's steps do not depend on them.  Batch b runs on a second engine object
+        over the same weights (``Engine.inference_twin``: own caches, workspace, bf16 copies) and a second stream; the host
+        alternates the two step loops.  Results and their order are those of ``generate(sample_a)`` followed by
+        ``generate(sample_b)``: numpy's phase stream is consumed in that order (batch b's run-ahead draws assume batch a
+        uses all of its upper bound and are discarded otherwise).  Returns the two hypothesis lists (``PendingHypos``)."""
+        model.eval()
+        engs = (model.engine, model.engine.inference_twin())
+        dev = engs[0].device
+        if dev.type != "cuda":
+            return self.generate(model, sample_a, has_targ, **kwargs), self.generate(model, sample_b, has_targ, **kwargs)
+        if self.__dict__.get("_chain_stream") is None:
+            self._chain_stream = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream()
+        streams = (cur, self._chain_stream)
+        self._chain_stream.wait_stream(cur)
+        self.defer_vocoder = bool(kwargs.get("defer_vocoder", False))
+        runs = []
+        try:
+            for eng, st, sample in zip(engs, streams, (sample_a, sample_b)):
+                with torch.cuda.stream(st):
+                    ni = sample["net_input"]
+                    if self.input_text != bool(eng.cfg.text_input):
+                        raise ValueError("--input-text true goes with a text-input model (--arch t2s_transformer), and only with one")
+                    if self.input_text:
+                        src, src_lens = sample["src_text"], sample["src_text_len"]
+                    else:
+                        src, src_lens = model._front_end(ni.get("src_speech"), ni.get("src_speech_lens"),
+                                                         ni.get("collated_audios_orig"), ni.get("padding_mask"))
+                    bsz = src.shape[0]
+                    eng.decode_begin(src, src_lens, self.max_iter, speaker=sample.get("speaker"))
+                    fin = PendingHypos(dict() for _ in range(bsz))
+                    runs.append([self._decode_mel_steps(model, sample, bsz, fin, eng), st, fin, sample, bsz, True])
+            alive, held_b = 2, False
+            while alive:
+                for r in runs:
+                    if not r[5]:
+                        continue
+                    if r is runs[1] and held_b:
+                        if runs[0][5]:
+                            continue  # batch b's post-processing (its phase draws) comes after batch a's
+                        held_b = False
+                    with torch.cuda.stream(r[1]):
+                        try:
+                            if next(r[0]) == "post" and r is runs[1]:
+                                held_b = True
+                        except StopIteration:
+                            r[5] = False
+                            alive -= 1
+                            if has_targ:
+                                self._add_targets(model, r[3], r[4], r[2])
+            # the caller's stream takes in what the second chain produced
+            ev = torch.cuda.Event()
+            ev.record(self._chain_stream)
+            runs[1][2]._events = tuple(runs[1][2]._events) + (ev,)
+        finally:
+            self.defer_vocoder = False
+        return runs[0][2], runs[1][2]
+
     def _decode_mel(self, model, sample, bsz: int, finalized: List[Dict]) -> None:
         """The AR loop + post-processing of speech_generator_for_s2st.py:70-122 over the caches ``decode_begin`` filled."""
-        eng = model.engine
+        for _ in self._decode_mel_steps(model, sample, bsz, finalized, model.engine):
+            pass
+
+    def _decode_mel_steps(self, model, sample, bsz: int, finalized: List[Dict], eng):
+        """``_decode_mel`` as a generator that yields after every enqueued decoding step: ``generate_two`` alternates two of
+        them (two batches on two engines / streams), ``_decode_mel`` just runs one to its end."""
         c = eng.cfg
         n_frames_per_step = model.args.n_frames_per_step
         out_dim = c.out_dim
@@ -149,9 +214,9 @@ class AutoRegressiveSpeechGenerator(SpeechGenerator):
         bufs = eng.decode_buffers(self.max_iter)
         on_gpu = dev.type == "cuda"
         # (a persistent pinned buffer: a fresh pinned allocation waits for the whole device, i.e. for a deferred vocoder)
-        pinned = self.__dict__.get("_pinned_done")
+        pinned = eng.__dict__.get("_pinned_done")  # (per engine: two chains decode at once in generate_two)
         if pinned is None or pinned.numel() < self.max_iter:
-            pinned = self._pinned_done = torch.zeros(self.max_iter, dtype=torch.int32, pin_memory=on_gpu)
+            pinned = eng._pinned_done = torch.zeros(self.max_iter, dtype=torch.int32, pin_memory=on_gpu)
         pinned = pinned[:self.max_iter]
         pinned.zero_()
         events = []
@@ -170,12 +235,14 @@ class AutoRegressiveSpeechGenerator(SpeechGenerator):
                 if int(pinned[look]) == bsz:
                     n_steps = look + 1
                     break
+            yield step
         else:
             if on_gpu:
                 torch.cuda.current_stream().synchronize()
             done = (pinned == bsz).nonzero()
             if done.numel():
                 n_steps = int(done[0]) + 1
+        yield "post"  # (generate_two holds the second batch here until the first one's post-processing is done)
         # (the reference's out_lens after its loop: steps at which the utterances stopped, max_iter for those still running;
         # an utterance that would have stopped only in a dropped run-ahead step is still running at the real stop)
         out_lens = bufs["out_lens"].cpu().long()

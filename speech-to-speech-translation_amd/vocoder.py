@@ -129,14 +129,19 @@ class _HostMTStream:
     sequential draws would have left it (the share boundary in front of n + a short output-less run) -- or None when somebody
     used the global generator in between."""
 
-    def __init__(self, n_upper: int, pin: bool, threads: int = 0, buf: Optional[torch.Tensor] = None, upload=None):
+    def __init__(self, n_upper: int, pin: bool, threads: int = 0, buf: Optional[torch.Tensor] = None, upload=None,
+                 start_after: Optional["_HostMTStream"] = None):
         """``upload``: (device, copy stream, ring slot) -- the generator thread then also uploads the WHOLE upper bound of
         draws on that stream as soon as they exist (the decoder is still running: the PCIe link is idle), and ``take``
-        hands out a slice of the device copy; without it the caller uploads the n it takes, after the decode."""
+        hands out a slice of the device copy; without it the caller uploads the n it takes, after the decode.
+        ``start_after``: an earlier, still pending stream (two batches decoded at once): this one starts where that one
+        ends IF all of its upper bound gets drawn -- a guess that ``take`` checks against numpy's real state (a batch
+        that stopped early leaves numpy elsewhere: None, and the caller draws the ordinary way)."""
         import os
         import threading
         self.upload, self.dev_buf, self.up_ev = upload, None, None
-        self.state0 = np.random.get_state()
+        self.start_after = start_after
+        self.state0 = np.random.get_state()  # (with start_after: only its constant fields are used)
         self.n = int(n_upper)
         self.threads = int(threads) or max(1, min(8, (os.cpu_count() or 2) - 1))
         # (``buf``: a caller-owned pinned buffer -- a fresh pinned allocation of this size is a hipHostMalloc, which waits
@@ -153,6 +158,13 @@ class _HostMTStream:
         self.thread.start()
 
     def _run(self):
+        if self.start_after is not None:
+            prev = self.start_after
+            prev.thread.join()
+            if prev.rc != 0:
+                self.rc = -1
+                return
+            self.state_w = prev.bounds[prev.threads].copy()  # the state behind all of the earlier stream's draws
         self.rc = _mt_host(self.state_w, self.n, self.buf.data_ptr(), self.bounds, self.threads)
         if self.upload is not None and self.rc == 0 and self.n > 0:
             dev, stream, slot = self.upload
@@ -168,9 +180,11 @@ class _HostMTStream:
     def take(self, n: int):
         self.thread.join()
         cur = np.random.get_state()
-        same = cur[0] == self.state0[0] and cur[2] == self.state0[2] and np.array_equal(cur[1], self.state0[1]) \
+        if self.rc != 0:
+            return None
+        same = cur[0] == self.state0[0] and cur[2] == int(self.state_w[624]) and np.array_equal(cur[1], self.state_w[:624]) \
             and cur[3] == self.state0[3] and cur[4] == self.state0[4]
-        if n > self.n or not same or self.rc != 0:
+        if n > self.n or not same:
             return None
         t = min(self.threads, (n * self.threads) // self.n) if self.n else 0
         while t > 0 and self.n * t // self.threads > n:
@@ -281,7 +295,7 @@ class GriffinLim:
             raise ValueError("phase_rng must be 'numpy' or 'device'")
         self.phase_rng, self.seed, self._calls = phase_rng, int(seed), 0
         self._pin = None
-        self._stream = None
+        self._streams = []  # run-ahead phase streams of the batches being decoded, oldest first (prefetch_phases / batch)
 
         win = get_window(n_fft, win_length, window_fn)
         self.F = n_fft // 2 + 1
@@ -304,15 +318,18 @@ class GriffinLim:
         numpy``: by numpy itself on one background thread (``_UniformStream``), ``=device``: by the one-workgroup device kernel
         (``_DeviceMTStream``; 160 ms for 64 utterances: slower than either host form, kept for hosts without spare cores),
         ``=off``: drawn after the decode, the ordinary way.  All four hand out the same doubles."""
-        self._stream = None
+        obj = None
+        pending = [x for x in self._streams if x is not None]
         if self.phase_rng == "numpy" and self.use_fft and n_frames_upper > 0:
             import os
             how = os.environ.get("S2ST_GL_PHASE_STREAM", "host")
             n = self.F * int(n_frames_upper)
+            if pending and not (how == "host" and isinstance(pending[-1], _HostMTStream)):
+                how = "off"  # (a second batch in flight: only the host generator can be chained behind a pending one)
             if how == "numpy":
-                self._stream = _UniformStream(n, self.device.type == "cuda")
+                obj = _UniformStream(n, self.device.type == "cuda")
             elif how == "device":
-                self._stream = _DeviceMTStream(n, self.device)
+                obj = _DeviceMTStream(n, self.device)
             elif how == "host":
                 up = None
                 buf = self._ring_buffer(n)
@@ -321,9 +338,12 @@ class GriffinLim:
                     if self.__dict__.get("_copy_stream") is None:
                         self._copy_stream = torch.cuda.Stream(device=self.device)
                     up = (self.device, self._copy_stream, self._pin_ring[self._ring_i])
-                self._stream = _HostMTStream(n, self.device.type == "cuda", buf=buf, upload=up)
+                obj = _HostMTStream(n, self.device.type == "cuda", buf=buf, upload=up,
+                                    start_after=pending[-1] if pending else None)
             elif how != "off":
                 raise ValueError("S2ST_GL_PHASE_STREAM must be host, numpy, device or off")
+        self._streams.append(obj)
+        del self._streams[:-2]  # (at most two batches are in flight; an entry nobody took is dropped)
 
     def _ring_buffer(self, n: int):
         """One of two persistent pinned staging buffers for the run-ahead draws, alternating, each guarded by the event of
@@ -479,7 +499,8 @@ class GriffinLim:
                 for T in Ts:
                     offs.append(o)
                     o += Fq * T
-                ahead, self._stream = (self._stream.take(n_all) if self._stream is not None else None), None
+                obj = self._streams.pop(0) if self._streams else None
+                ahead = obj.take(n_all) if obj is not None else None
                 if ahead is not None:  # drawn while the decoder ran (prefetch_phases)
                     uni = ahead if ahead.device == dev else ahead.to(dev, non_blocking=True)
                     if ahead.device != dev and dev.type == "cuda":

@@ -708,3 +708,45 @@ def test_fft_griffin_lim_edge_geometries(backend, monkeypatch, n_fft, win, hop):
         if hop * (s.shape[1] - 1) > n_fft // 2:  # (shorter signals cannot be reflect-padded: the reference fails there too)
             ref = _gl_numpy_fft(s, a_, n_fft, win, hop, 1)
             assert float(np.abs(w.cpu().numpy() - ref).max()) < 2e-4 * float(np.abs(ref).max())
+
+
+@pytest.mark.parametrize("has_targ", [False, True])
+def test_two_batches_decoded_at_once_give_the_sequential_results(backend, has_targ):
+    """generate_two(a, b): batch b on a second engine over the same weights and a second stream, the two step loops alternated
+    by the host == generate(a) then generate(b): every field of every hypothesis, incl. the waveforms (numpy's phase draws
+    are consumed in batch order; batch b's run-ahead stream is a guess that is checked) -- with early stops in batch a (its
+    upper bound of draws is then NOT used up: b's guess fails and it draws the ordinary way) and without."""
+    if backend.kind == "emu":
+        pytest.skip("no second stream on the emulator: generate_two is two generate() calls")
+    gen_mod = importlib.import_module(PKG + ".speech_generator")
+    V = importlib.import_module(PKG + ".vocoder")
+    a, model = _build_model(backend, AR_CFG)
+    voc = V.GriffinLimVocoder(spec_bwd_max_iter=2, device=backend.device, sample_rate=16000, win_size=200, hop_size=64, n_fft=256,
+                              n_mels=80, f_min=20, f_max=8000)
+    batches = []
+    for i in (0, 1):
+        s = golden_sample("tiny", i)
+        s["net_input"]["collated_audios_orig"] = None
+        s["net_input"]["padding_mask"] = None
+        batches.append(s)
+    for thr in (0.6, 2.0):  # early stops / every utterance runs to max_iter
+        gen = gen_mod.AutoRegressiveSpeechGenerator(model, voc, None, max_iter=6, eos_prob_threshold=thr)
+        np.random.seed(5)
+        plain = [gen.generate(model, s, has_targ=has_targ) for s in batches]
+        tail_p = np.random.rand(3)
+        backend.sync()
+        for defer in (False, True):
+            np.random.seed(5)
+            two = gen.generate_two(model, batches[0], batches[1], has_targ=has_targ, defer_vocoder=defer)
+            for h in two:
+                h.wait()
+            tail_t = np.random.rand(3)
+            backend.sync()
+            assert np.array_equal(tail_p, tail_t)
+            for x, y in zip(plain, two):
+                assert len(x) == len(y)
+                for hx, hy in zip(x, y):
+                    for k in ("feature", "eos_prob", "alignment", "waveform") + (("targ_waveform",) if has_targ else ()):
+                        assert torch.equal(hx[k], hy[k]), (thr, defer, k)
+                    # (the alignment layer's head mean is summed by atomics: last-bit differences between any two runs)
+                    assert float((hx["attn"] - hy["attn"]).abs().max()) < 1e-6
