@@ -139,7 +139,8 @@ class AutoRegressiveSpeechGenerator(SpeechGenerator):
         model.eval()
         engs = (model.engine, model.engine.inference_twin())
         dev = engs[0].device
-        if dev.type != "cuda":
+        if dev.type != "cuda" or getattr(model, "hubert", None) is not None:
+            # (no second stream; or a frozen front end whose one workspace the two chains would share)
             return self.generate(model, sample_a, has_targ, **kwargs), self.generate(model, sample_b, has_targ, **kwargs)
         if self.__dict__.get("_chain_stream") is None:
             self._chain_stream = torch.cuda.Stream(device=dev)
