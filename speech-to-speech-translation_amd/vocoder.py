@@ -506,12 +506,19 @@ class GriffinLim:
                     if ahead.device != dev and dev.type == "cuda":
                         self._ring_uploaded(ahead)
                 else:
+                    ev = self.__dict__.get("_pin_ev")
+                    if ev is not None:  # (the previous call's upload of this staging buffer: it may still be queued on
+                        ev.synchronize()  # another stream when two batches are in flight)
+                        self._pin_ev = None
                     if self._pin is None or self._pin.numel() < n_all:
                         self._pin = torch.empty(n_all, dtype=torch.float64, pin_memory=dev.type == "cuda")
                     host = self._pin.numpy()
                     for T, o in zip(Ts, offs):
                         host[o:o + Fq * T] = np.random.rand(Fq, T).reshape(-1)
                     uni = self._pin[:n_all].to(dev, non_blocking=True)
+                    if dev.type == "cuda":
+                        self._pin_ev = torch.cuda.Event()
+                        self._pin_ev.record()
                 uoff = torch.tensor(offs, dtype=torch.int64).to(dev)
         else:
             if angles is None:  # the reference's per-utterance draws from numpy's global RNG, in order
