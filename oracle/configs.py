@@ -1,6 +1,7 @@
 """Named model/criterion configurations shared by the golden generator, the oracle tests,
 the HIP parity tests and bench.py (flag names are the reference's, see
 examples/s2s_trans/models/s2st_transformer.py:586-664 and run_baseline.sh:96-124)."""
+import numpy as np
 
 TINY = dict(  # BASELINE.json configs[0]: 2+2 layers, d=128, no HuBERT
     encoder_transformer_layers=2, decoder_transformer_layers=2,
@@ -104,3 +105,16 @@ def golden_sample(cfg_name, which=0):
         c = D.SyntheticFisherCorpus(n_utts=64, seed=7)
     idx = list(range(8)) if which == 0 else list(range(8, 16))
     return c.collate_batch(idx)
+
+
+def smooth_logmel(seed: int, T: int, n_mels: int = 80) -> np.ndarray:
+    """A speech-like log-mel track [T, n_mels] from a seed: a few moving formant bumps over a tilted floor (so that the
+    mel inversion and Griffin-Lim see structured magnitudes, not white noise)."""
+    rs = np.random.RandomState(seed)
+    t = np.arange(T)[:, None] / 80.0
+    m = np.arange(n_mels)[None, :]
+    x = -4.0 - 0.03 * m + 0.3 * rs.randn(T, n_mels)
+    for k in range(4):
+        centre = 8 + 16 * k + 5 * np.sin(2 * np.pi * (0.7 + 0.3 * k) * t + rs.rand() * 6.28)
+        x += (2.5 - 0.4 * k) * np.exp(-0.5 * ((m - centre) / (2.0 + k)) ** 2) * (0.6 + 0.4 * np.sin(2 * np.pi * 3.1 * t + k))
+    return x.astype(np.float32)

@@ -233,6 +233,131 @@ def test_mcd_against_oracle(backend):
         assert float((rets[b][1][0].cpu() - x1).abs().max()) < 2e-3 * float(x1.abs().max())
 
 
+# ---- round 5: the reference's own vocoder / MCD code at config 5's geometry (oracle/gen_golden_vocoder.py) ---------------
+# Tolerance of a 64-iteration Griffin-Lim run.  Every iteration re-derives the phase from the previous waveform, so a
+# rounding difference is amplified from one iteration to the next.  Measured in the build container on this golden's
+# input: EXACT arithmetic (float64, numpy FFTs) differs from the reference's own fp32 result by 6.7e-6 / 1.9e-5 / 3.4e-4 of
+# the waveform scale (max norm) after 1 / 8 / 64 iterations -- a growth of ~1.07 x per iteration; the fp32 reference is
+# therefore itself only defined to that margin, and an fp32 implementation with a different summation order (FFT
+# butterflies instead of 2048-term dot products) is held to 3 x it.
+GL_2048_TOL = {1: 2e-5, 8: 6e-5, 64: 1e-3}
+
+
+@pytest.mark.parametrize("n_iter", [1, 8, 64])
+def test_griffin_lim_at_config5_geometry_against_reference(backend, golden_dir, n_iter):
+    """The benchmarked kernels (`gl_stft_project<2048>`, radix-8 passes, circular-LDS overlap-add) against the reference
+    `GriffinLim` (vocoder.py:84-110) at n_fft 2048 / window 1200 / hop 300, 224 frames, 1 / 8 / 64 iterations, the
+    reference's own random phases (numpy's global generator seeded)."""
+    if backend.kind == "emu":
+        pytest.skip("224 frames x 64 iterations of 2048-point transforms: GPU only (the emulator covers 2048 in test_fft_griffin_lim_kernels)")
+    z = np.load(os.path.join(golden_dir, "infer_gl_2048.npz"))
+    V = importlib.import_module(PKG + ".vocoder")
+    n_fft, win, hop, T = int(z["n_fft"]), int(z["win"]), int(z["hop"]), int(z["T"])
+    Fq = n_fft // 2 + 1
+    spec = np.abs(np.random.RandomState(int(z["spec_seed"])).randn(Fq, T)).astype(np.float32)
+    gl = V.GriffinLim(n_fft, win, hop, n_iter, backend.device)
+    assert gl.use_fft
+    ref = z[f"wave.{n_iter}"]
+    # (a) the generator's own draws: the default path takes the phases from numpy's global stream like the reference
+    np.random.seed(int(z["phase_seed"]))
+    w = gl(torch.from_numpy(spec)).cpu().numpy()
+    backend.sync()
+    assert w.shape == ref.shape
+    err = float(np.abs(w - ref).max()) / float(np.abs(ref).max())
+    assert err < GL_2048_TOL[n_iter], (n_iter, err)
+    # (b) the batched launch form the bench runs (explicit angles), with a shorter neighbour in the batch
+    ang = IO.initial_angles((Fq, T), np.random.RandomState(int(z["phase_seed"])))
+    both = gl.batch([torch.from_numpy(spec[:, :97].copy()), torch.from_numpy(spec)], [ang[:, :97].copy(), ang])
+    backend.sync()
+    err_b = float(np.abs(both[1].cpu().numpy() - ref).max()) / float(np.abs(ref).max())
+    assert err_b < GL_2048_TOL[n_iter], (n_iter, err_b)
+    # (c) spectral convergence || |STFT(w)| - spec || / || spec || -- independent of which near-equivalent phase
+    # trajectory rounding selects -- equals the reference's
+    mag, _ = IO.gl_transform(torch.from_numpy(w).unsqueeze(0), n_fft, win, hop)
+    sc = float((mag[0] - torch.from_numpy(spec)).norm() / torch.from_numpy(spec).norm())
+    assert abs(sc - float(z[f"sc.{n_iter}"])) < 1e-4, (sc, float(z[f"sc.{n_iter}"]))
+
+
+def test_vocoder_against_reference_wrapper(backend, golden_dir):
+    """`GriffinLimVocoder.forward` (vocoder.py:113-144) as the REFERENCE runs it -- exp, `PseudoInverseMelScale` (pinverse of
+    the mel basis, clamp at 0), Griffin-Lim -- at config 5's geometry.  The reference ran on `oracle/ref_shims_tables`'
+    librosa stand-in, i.e. on this repository's Slaney table: everything but that table is pinned here."""
+    if backend.kind == "emu":
+        pytest.skip("config 5 geometry: GPU only")
+    from configs import smooth_logmel
+    z = np.load(os.path.join(golden_dir, "infer_vocoder_ref.npz"))
+    V = importlib.import_module(PKG + ".vocoder")
+    kw = {k: (float(z[k]) if k in ("f_min", "f_max") else int(z[k])) for k in
+          ("sample_rate", "win_size", "hop_size", "n_fft", "n_mels", "f_min", "f_max")}
+    lens = [int(t) for t in z["lens"]]
+    feats = [torch.from_numpy(smooth_logmel(int(z["feat_seed0"]) + u, T)) for u, T in enumerate(lens)]
+    for n_iter, tol in ((2, 3e-5), (64, 1e-3)):
+        voc = V.GriffinLimVocoder(spec_bwd_max_iter=n_iter, device=backend.device, **kw)
+        basis = voc.inv_mel.cpu().numpy()[::16]
+        ref_b = z["pinv_basis_sample"]
+        assert float(np.abs(basis - ref_b).max()) < 1e-5 * float(np.abs(ref_b).max())  # same pinverse of the same table
+        for u, feat in enumerate(feats):
+            np.random.seed(40 + u)
+            w = voc(feat)[0].cpu().numpy()
+            ref = z[f"wave.{n_iter}.{u}"]
+            assert w.shape == ref.shape
+            err = float(np.abs(w - ref).max()) / float(np.abs(ref).max())
+            assert err < tol, (n_iter, u, err)
+        # the padded-batch form (one exp / GEMM / clamp for all utterances)
+        angs = [IO.initial_angles((kw["n_fft"] // 2 + 1, T), np.random.RandomState(40 + u)) for u, T in enumerate(lens)]
+        ws = voc.batch(feats, angs)
+        backend.sync()
+        for u, w in enumerate(ws):
+            ref = z[f"wave.{n_iter}.{u}"]
+            err = float(np.abs(w[0].cpu().numpy() - ref).max()) / float(np.abs(ref).max())
+            assert err < tol, (n_iter, u, err)
+    # the mel inversion alone: spec = clamp(pinv(mel) @ exp(feat)^T, 0)
+    for u, feat in enumerate(feats):
+        T = feat.shape[0]
+        xt = torch.empty(kw["n_mels"], T, device=backend.device)
+        voc_bd = importlib.import_module(PKG + ".runtime.binding")
+        voc_bd.call("s2st_exp_transpose_f32", feat.to(backend.device).contiguous(), xt, T, kw["n_mels"])
+        spec = torch.empty(voc.F, T, device=backend.device)
+        voc_bd.gemm(voc.inv_mel, xt, spec, voc.F, T, kw["n_mels"], b_kmajor=False, b_ld=T, precise=True)
+        voc_bd.call("s2st_clamp_min_f32", spec, voc.F * T, 0.0)
+        backend.sync()
+        ref = z[f"spec.{u}"]
+        assert float(np.abs(spec.cpu().numpy() - ref).max()) < 2e-5 * float(np.abs(ref).max())
+        assert float(spec.min()) >= 0.0
+
+
+def test_mcd_against_reference_wrapper(backend, golden_dir):
+    """`batch_mel_cepstral_distortion` / `batch_compute_distortion` (s2s_translation.py:465-552) as the REFERENCE runs them
+    (on `oracle/ref_shims_tables`' MFCC stand-in = this repository's MFCC restatement): features, RMS distance, padding of
+    the distance batch, DTW, the path normaliser.  Distortions to 1e-3 relative (fp32 GEMM features against float64 ones),
+    path lengths equal."""
+    if backend.kind == "emu":
+        pytest.skip("1200-point frames of 24 kHz audio: GPU only (test_mcd_against_oracle covers the emulator)")
+    z = np.load(os.path.join(golden_dir, "infer_mcd_ref.npz"))
+    M = importlib.import_module(PKG + ".metrics")
+    n, sr = int(z["n"]), int(z["sr"])
+    y1 = [torch.from_numpy(z[f"y1.{i}"]) for i in range(n)]
+    y2 = [torch.from_numpy(z[f"y2.{i}"]) for i in range(n)]
+    rets = M.batch_mel_cepstral_distortion(y1, y2, sr, device=backend.device)
+    backend.sync()
+    for i, (dist, (x1, x2, d, cum, bp, pm)) in enumerate(rets):
+        r1, r2 = z[f"x1.{i}"], z[f"x2.{i}"]
+        assert tuple(x1.shape) == r1.shape and tuple(x2.shape) == r2.shape
+        assert float(np.abs(x1.cpu().numpy() - r1).max()) < 2e-3 * float(np.abs(r1).max())
+        assert float(np.abs(x2.cpu().numpy() - r2).max()) < 2e-3 * float(np.abs(r2).max())
+        ref = float(z[f"distortion.{i}"])
+        assert abs(float(dist) - ref) < 1e-3 * max(ref, 0.05), (i, float(dist), ref)
+        assert tuple(pm.shape) == tuple(int(v) for v in z[f"shape.{i}"])
+        if i < 2:  # (the identical pair's off-diagonal distances are rounding noise: its path may wander, its length not by much)
+            assert int(pm.sum()) == int(z[f"path_len.{i}"]), (i, int(pm.sum()), int(z[f"path_len.{i}"]))
+            ref_pm = np.unpackbits(z[f"pathmap.{i}"])[: pm.numel()].reshape(tuple(pm.shape))
+            assert np.array_equal(pm.cpu().numpy().astype(np.uint8), ref_pm)
+    for nt in ("len1", "len2", None):
+        r = M.batch_mel_cepstral_distortion(y1[:1], y2[:1], sr, normalize_type=nt, device=backend.device)
+        ref = float(z[f"distortion0.{nt}"])
+        assert abs(float(r[0][0]) - ref) < 1e-3 * ref, (nt, float(r[0][0]), ref)
+
+
 def test_generate_waveform_harness_on_disk_corpus(backend, tmp_path):
     """The counterpart of examples/s2s_trans/generate_waveform.py:127-183 end to end on the miniature on-disk corpus: a
     checkpoint written by the train harness (reference .pt layout) -> task / model from its cfg -> AR decode + Griffin-Lim
