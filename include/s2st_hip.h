@@ -271,6 +271,16 @@ typedef struct {
   float ctc_weight, asr_weight, st_weight, w_l1, w_mse, w_eos, bce_pos_weight, label_smoothing;
   float ctc_tgt_weight;                   /* s2st_loss_mtl.py:171-185 */
   float enc_dropout;                      /* t2s encoder prenet dropout (nn.Dropout: training only) */
+  /* s2t_transformer_hubert (fairseq/models/speech_to_text/s2t_transformer_me.py:82-330): the ST / ASR pre-training stage of
+   * the mix- / prompt-tuning recipes (run_mix_tuning.sh:100) -- the SAME speech encoder, and in place of the mel decoder
+   * ONE full-width text decoder (fairseq TransformerDecoder: dec_layers x dec_dim, embedding and output projection over
+   * tgt_vocab, parameter names decoder.embed_tokens / decoder.layers.N / decoder.layer_norm / decoder.output_projection)
+   * reading the encoder output.  The batch's prev_src_txt / src_txt / src_txt_lens / src_txt_pos / pe_asr (width dec_dim)
+   * slots carry the decoder's tokens -- the host picks source or target text by the criterion's --test-type
+   * (criterions/s2t_loss.py:88-92) -- and the loss is s2t_loss.py:36-56's label-smoothed NLL SUMMED over the non-pad
+   * tokens: stats[S2ST_STAT_LOSS] = that sum, S2ST_STAT_ASR_NLL / _SMOOTH / _CORRECT / _TOTAL its parts and the accuracy
+   * counts; outputs.asr_logits = [B, Ls, tgt_vocab].  No mel decoder, post-net, CTC or aux heads exist in this mode. */
+  int32_t s2t_mode;
 } s2st_model_config;
 
 typedef struct {

@@ -70,6 +70,13 @@ TINY_T2S = dict(TINY, asr_ce_weight=0.0, st_ce_weight=0.0, ctc_weight=0.0, text_
                 encoder_conv_kernel_size=5, encoder_dropout=0.0, encoder_normalize_before=False,
                 decoder_normalize_before=False)
 
+# s2t_transformer_hubert (the ST / ASR pre-training stage) at tiny size: 2 encoder + 2 decoder layers, d = 128, heads 4,
+# dropouts 0 (the model's own flag names: --encoder-layers / --decoder-layers)
+S2T_TINY = dict(encoder_layers=2, decoder_layers=2, encoder_embed_dim=128, decoder_embed_dim=128,
+                encoder_ffn_embed_dim=256, decoder_ffn_embed_dim=256, encoder_attention_heads=4,
+                decoder_attention_heads=4, encoder_normalize_before=True, decoder_normalize_before=True,
+                dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, label_smoothing=0.1)
+
 CONFIGS = {"tiny_t2s": TINY_T2S, "tiny_mtl": TINY_MTL, "tiny": TINY, "tiny_postln": TINY_POSTLN, "base": BASE_PARITY,
            "base_recipe": BASE_RECIPE, "hubert_train": HUBERT_TRAIN, "base_recipe_hubert": HUBERT_RECIPE}
 

@@ -513,7 +513,9 @@ class AuxTextDecoder(nn.Module):
     final LN if normalize_before, project_out (512, d) no bias when d != 512,
     output_projection (V, 512) no bias."""
 
-    def __init__(self, a, vocab, in_dim, d, n_layers, tap):
+    def __init__(self, a, vocab, in_dim, d, n_layers, tap, out_dim=512):
+        """``tap`` None / ``out_dim`` = d: the s2t model's own decoder (oracle/s2t_oracle.py) -- it reads the encoder's final
+        output and projects at its own width (s2t_transformer_me.py:527-529)."""
         super().__init__()
         self.a, self.d, self.tap = a, d, tap
         self.embed_tokens = nn.Embedding(vocab, in_dim, padding_idx=PAD)
@@ -525,7 +527,7 @@ class AuxTextDecoder(nn.Module):
                                     a.dropout, a.attention_dropout, a.activation_dropout)
             for _ in range(n_layers))
         self.layer_norm = nn.LayerNorm(d) if a.decoder_normalize_before else None
-        out_dim = 512  # DecoderConfig.output_dim default (transformer_config.py:63-68)
+        # (aux heads: DecoderConfig.output_dim default 512, transformer_config.py:63-68)
         self.out_dim = out_dim
         self.project_out_dim = nn.Linear(d, out_dim, bias=False) if d != out_dim else None
         self.output_projection = nn.Linear(out_dim, vocab, bias=False)
@@ -544,7 +546,7 @@ class AuxTextDecoder(nn.Module):
         enc_pad = enc["encoder_padding_mask"] if bool(enc["encoder_padding_mask"].any()) else None
         fm = future_mask(x.shape[0])
         for layer in self.layers:
-            x, _ = layer(x, enc["out_middle_layers"][self.tap], enc_pad, fm, self_pad)
+            x, _ = layer(x, enc["encoder_out"] if self.tap is None else enc["out_middle_layers"][self.tap], enc_pad, fm, self_pad)
         if self.layer_norm is not None:
             x = self.layer_norm(x)
         x = x.transpose(0, 1)

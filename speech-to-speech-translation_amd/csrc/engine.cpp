@@ -71,7 +71,7 @@ struct DecLayerP { AttnP sa; LNP ln1; XAttnP xa; LNP ln2; LinP fc1, fc2; LNP ln3
 struct ConvP { long w, b; int O, I, Kw; };
 struct BNP { long g, b, rm, rv; int C; };
 struct AuxP {
-  long embed; int V, in_dim, d, layers;
+  long embed; int V, in_dim, d, layers, out_dim;
   long proj_in;  // -1 if none
   std::vector<DecLayerP> L;
   LNP ln; bool has_ln;
@@ -227,6 +227,7 @@ struct s2st_engine {
   std::vector<BNP> post_bn;
   LinP ctc_proj, ctc_proj_tgt;
   AuxP asr, st;
+  AuxP s2t;  // s2t_mode: the model's own text decoder ("decoder.*")
 
   // per-call state
   float* ws = nullptr;
@@ -315,17 +316,19 @@ struct s2st_engine {
     l.ln3 = add_ln(pre + ".final_layer_norm", C);
     return l;
   }
-  AuxP add_aux(const std::string& pre, int V, int in_dim, int d, int layers) {
+  // out_dim: the decoder's output width (DecoderConfig.output_dim: 512 for the aux heads whatever their width,
+  // transformer_config.py:63-68; decoder_embed_dim for the s2t model's own decoder, s2t_transformer_me.py:527-529)
+  AuxP add_aux(const std::string& pre, int V, int in_dim, int d, int layers, int out_dim = 512) {
     AuxP a;
-    a.V = V; a.in_dim = in_dim; a.d = d; a.layers = layers;
+    a.V = V; a.in_dim = in_dim; a.d = d; a.layers = layers; a.out_dim = out_dim;
     a.embed = add(pre + ".embed_tokens.weight", {V, in_dim});
     a.proj_in = d != in_dim ? add(pre + ".project_in_dim.weight", {d, in_dim}) : -1;
     for (int i = 0; i < layers; ++i)
       a.L.push_back(add_dec_layer(pre + ".layers." + std::to_string(i), d, c.dec_ffn, c.enc_dim));
     a.has_ln = c.dec_pre_ln != 0;
     if (a.has_ln) a.ln = add_ln(pre + ".layer_norm", d);
-    a.proj_out = d != 512 ? add(pre + ".project_out_dim.weight", {512, d}) : -1;
-    a.out_proj = add(pre + ".output_projection.weight", {V, 512});
+    a.proj_out = d != out_dim ? add(pre + ".project_out_dim.weight", {out_dim, d}) : -1;
+    a.out_proj = add(pre + ".output_projection.weight", {V, out_dim});
     return a;
   }
 
@@ -385,6 +388,11 @@ struct s2st_engine {
       // the table is spk_dim wide here (task.get_speaker_embeddings: Embedding(len(speaker_to_id), speaker_embed_dim))
       enc_spk = add("encoder.embed_speaker.weight", {c.n_speakers, c.spk_dim}, c.spk_frozen ? 1 : 0);
       enc_spk_proj = add_lin("encoder.spk_emb_proj", C, C + c.spk_dim);
+    }
+    if (c.s2t_mode) {
+      // s2t_transformer_hubert: speech encoder + ONE full-width text decoder (s2t_transformer_me.py:266-283, 473-492)
+      s2t = add_aux("decoder", c.tgt_vocab, Cd, Cd, c.dec_layers, Cd);
+      return;
     }
     if (c.has_asr) asr_norm = add_ln("encoder.aux_asr_norm", C);
     if (c.has_st) st_norm = add_ln("encoder.aux_st_norm", C);
@@ -1275,8 +1283,8 @@ struct s2st_engine {
     for (int i = 0; i < a.layers; ++i)
       x = dec_layer(x, tap, a.L[i], B, L, E, c.dec_heads, c.dec_pre_ln != 0, lens, nullptr);
     if (a.has_ln) x = layernorm(x, a.ln);
-    if (a.proj_out >= 0) x = linear(x, a.proj_out, -1, 512, a.d);
-    return linear(x, a.out_proj, -1, a.V, 512, 0, 0.f, nullptr, logits_out);
+    if (a.proj_out >= 0) x = linear(x, a.proj_out, -1, a.out_dim, a.d);
+    return linear(x, a.out_proj, -1, a.V, a.out_dim, 0, 0.f, nullptr, logits_out);
   }
 
 
@@ -1841,6 +1849,7 @@ struct s2st_engine {
       enc_out_keep = enc_out;
       return err;
     }
+    if (c.s2t_mode) return forward_s2t(enc_out, with_loss);
     // The cross-attention K|V projections of every decoder layer only need the encoder output: they are
     // issued here, on the second stream, and run under the prenet and the first self-attention block (their
     // backward -- data gradients into the encoder output, weight gradients -- then runs after the layers').
@@ -2031,6 +2040,44 @@ struct s2st_engine {
     }
     if (adam_pending && live()) adam_wait_all(st_);  // (parameters no op of this configuration reads)
     join_side();  // nothing of this forward is left running on the second stream when it returns in st_ order
+    mark();
+    return err;
+  }
+
+  // s2t_transformer_hubert + s2t_loss (s2t_transformer_me.py:308-330; criterions/s2t_loss.py:80-160): text decoder over the
+  // encoder output, label-smoothed NLL summed over the non-pad tokens, accuracy counts.  The decoder's tokens ride in the
+  // batch's source-text slots (the host chose them by --test-type); the dictionary is the TARGET one for both types
+  // (s2t_transformer_me.py:268-283 builds embedding and output projection from task.target_dictionary).
+  int forward_s2t(Ten* enc_out, bool with_loss) {
+    const int B = bt.B;
+    if (!bt.prev_src_txt || bt.Ls <= 0) return err;  // encoder only (forward_encoder)
+    Ten* logits = aux_decoder(s2t, enc_out, (const long*)bt.prev_src_txt, bt.src_txt_pos, bt.src_txt_lens, B, bt.Ls,
+                              bt.pe_asr, outs.asr_logits);
+    mark();
+    if (with_loss && bt.src_txt) {
+      float* stats = outs.stats;
+      float* loss_ws = alloc(3L * S2ST_LOSS_ORDERED_FLOATS);
+      if (live()) {
+        hipMemsetAsync(stats, 0, sizeof(float) * 32, st_);
+        s2st_loss_parts lp{};
+        float* ow = nullptr;
+        if (ordered_sums) lp.part[1] = ow = loss_ws + S2ST_LOSS_ORDERED_FLOATS;
+        chk(s2st_ls_ce(logits->d, (const long*)bt.src_txt, B * bt.Ls, c.tgt_vocab, 1, c.label_smoothing,
+                       stats + S2ST_STAT_ASR_NLL, nullptr, 0.f, st_, ow, &lp.nblocks[1]));
+        // (w_asr = 1 over "1 token": the SUM (1 - eps - eps_i) nll + eps_i smooth, eps_i = eps / (V - 1), s2t_loss.py:52-55)
+        chk(s2st_loss_finalize(stats, nullptr, B, 1.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, c.label_smoothing, c.tgt_vocab,
+                               c.tgt_vocab, 1.f, 1.f, st_, nullptr, 0.f, ordered_sums ? &lp : nullptr));
+      }
+      tape.push_back([=]() {
+        bool a;
+        float* dl = gradbuf(logits, a);
+        if (live())
+          chk(s2st_ls_ce(logits->d, (const long*)bt.src_txt, B * bt.Ls, c.tgt_vocab, 1, c.label_smoothing, nullptr, dl,
+                         gscale, st_));
+      });
+    }
+    if (adam_pending && live()) adam_wait_all(st_);
+    join_side();
     mark();
     return err;
   }

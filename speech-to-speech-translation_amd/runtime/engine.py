@@ -28,7 +28,8 @@ class ModelConfig(C.Structure):
         "src_vocab", "tgt_vocab", "no_scale_embedding", "precise", "tap_dec", "has_ctc_tgt", "text_input", "enc_conv_layers", "enc_conv_k",
         "n_speakers", "spk_frozen", "spk_dim")] + [(n, C.c_float) for n in (
         "dropout", "attn_dropout", "act_dropout", "prenet_dropout", "postnet_dropout", "ctc_weight",
-        "asr_weight", "st_weight", "w_l1", "w_mse", "w_eos", "bce_pos_weight", "label_smoothing", "ctc_tgt_weight", "enc_dropout")]
+        "asr_weight", "st_weight", "w_l1", "w_mse", "w_eos", "bce_pos_weight", "label_smoothing", "ctc_tgt_weight", "enc_dropout")] + \
+        [("s2t_mode", C.c_int32)]
 
 
 class ParamInfo(C.Structure):
@@ -122,6 +123,10 @@ def config_from_args(a, precise: bool = False) -> ModelConfig:
         if getattr(a, "speaker_embed_dim_dec", 64) != c.out_dim:
             raise ValueError(f"--speaker-embed-dim-dec {getattr(a, 'speaker_embed_dim_dec', 64)} must equal output_frame_dim * "
                              f"n_frames_per_step = {c.out_dim}: the row replaces the first input frame (:441-444)")
+    # s2t_transformer_hubert: speech encoder + ONE full-width text decoder, no mel decoder (models/s2t_transformer.py)
+    c.s2t_mode = int(bool(getattr(a, "s2t_mode", False)))
+    if c.s2t_mode and (c.has_asr or c.has_st or c.has_ctc or c.has_ctc_tgt or c.text_input or c.n_speakers):
+        raise ValueError("s2t_transformer_hubert has no aux heads, CTC heads, text encoder or speaker tables")
     if c.text_input and (c.has_asr or c.has_st or c.has_ctc_tgt or c.enc_conv_k % 2 != 1):
         raise ValueError("t2s_transformer: no aux heads / target-text CTC head; --encoder-conv-kernel-size must be odd")
     if c.has_ctc_tgt and not (0 <= c.tap_dec < c.dec_layers):
@@ -346,6 +351,24 @@ class Engine:
             keep["tgt_txt_pos"] = token_pos(pt).contiguous().to(dev)
             b.prev_tgt_txt, b.tgt_txt_pos = keep["prev_tgt_txt"].data_ptr(), keep["tgt_txt_pos"].data_ptr()
             b.pe_st = self.pe(self.cfg.st_dim, Lt + 2).data_ptr()
+        if self.cfg.s2t_mode:
+            # the model's own text decoder reads the SOURCE text (--test-type asr) or the TARGET text (st):
+            # criterions/s2t_loss.py:88-92, s2t_transformer_me.py:300-305; the tokens ride in the source-text slots
+            key = "src" if getattr(self, "s2t_test_type", "asr") == "asr" else "tgt"
+            pt = ni.get(f"prev_{key}_text_tokens")
+            if pt is not None:
+                pt = pt.cpu().long().contiguous()
+                Ls = pt.shape[1]
+                keep["prev_src_txt"] = pt.to(dev)
+                keep["src_txt_pos"] = token_pos(pt).contiguous().to(dev)
+                b.prev_src_txt, b.src_txt_pos = keep["prev_src_txt"].data_ptr(), keep["src_txt_pos"].data_ptr()
+                b.pe_asr = self.pe(self.cfg.dec_dim, Ls + 2).data_ptr()
+                keep["src_txt_lens"] = sample[f"{key}_text_len"].to(torch.int32).to(dev)
+                b.src_txt_lens = keep["src_txt_lens"].data_ptr()
+                if sample.get(f"{key}_text") is not None:
+                    keep["src_txt"] = sample[f"{key}_text"].cpu().long().contiguous().to(dev)
+                    b.src_txt = keep["src_txt"].data_ptr()
+            Lt = 0
         b.Ls, b.Lt = Ls, Lt
         if self.cfg.n_speakers > 0:
             spk = sample.get("speaker")
@@ -486,6 +509,9 @@ class Engine:
             out.tap1 = o["tap1"].data_ptr()
         if c.has_asr:
             o["asr_logits"] = buf(B, b.Ls, c.src_vocab)
+            out.asr_logits = o["asr_logits"].data_ptr()
+        if c.s2t_mode and b.Ls > 0:  # the text decoder's logits over the TARGET dictionary
+            o["asr_logits"] = buf(B, b.Ls, c.tgt_vocab)
             out.asr_logits = o["asr_logits"].data_ptr()
         if c.has_st:
             o["st_logits"] = buf(B, b.Lt, c.tgt_vocab)

@@ -102,10 +102,16 @@ class DevicePrefetcher:
         if isinstance(item, BaseException):
             raise item
         if ahead and isinstance(item, PreparedBatch):
-            nxt = self.q.get()
-            self._held = nxt
-            if isinstance(nxt, PreparedBatch):
-                self.model.front_end_ahead(nxt, after=nxt.ready)
+            # (only when batch k + 1 is ALREADY staged: a step that is ready must not wait for a slow stager -- first
+            # batches, validation, epoch tails; the front end of a batch that was not looked ahead runs in its own step)
+            try:
+                nxt = self.q.get_nowait()
+            except queue.Empty:
+                nxt = None
+            if nxt is not None:
+                self._held = nxt
+                if isinstance(nxt, PreparedBatch):
+                    self.model.front_end_ahead(nxt, after=nxt.ready)
         return item.wait() if isinstance(item, PreparedBatch) else item
 
     def close(self):

@@ -137,11 +137,12 @@ class AutoRegressiveSpeechGenerator(SpeechGenerator):
         ``generate(sample_b)``: numpy's phase stream is consumed in that order (batch b's run-ahead draws assume batch a
         uses all of its upper bound and are discarded otherwise).  Returns the two hypothesis lists (``PendingHypos``)."""
         model.eval()
-        engs = (model.engine, model.engine.inference_twin())
-        dev = engs[0].device
+        dev = model.engine.device
         if dev.type != "cuda" or getattr(model, "hubert", None) is not None:
-            # (no second stream; or a frozen front end whose one workspace the two chains would share)
+            # (no second stream; or a frozen front end whose one workspace the two chains would share -- checked BEFORE the
+            # twin engine, with its own bf16 arena, is built: ADVICE r4)
             return self.generate(model, sample_a, has_targ, **kwargs), self.generate(model, sample_b, has_targ, **kwargs)
+        engs = (model.engine, model.engine.inference_twin())
         if self.__dict__.get("_chain_stream") is None:
             self._chain_stream = torch.cuda.Stream(device=dev)
         cur = torch.cuda.current_stream()

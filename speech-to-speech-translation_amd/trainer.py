@@ -161,6 +161,9 @@ class Trainer:
                                      f"(num_updates={self.num_updates}); those updates were skipped")
 
     def _fast_micro_step(self, sample, hooks, gscale: float = 1.0):
+        fs = getattr(self.criterion, "fast_step", None)
+        if fs is not None:  # a criterion with its own sample size / logging output (s2t_loss: text tokens, not mel frames)
+            return fs(self.model, sample, hooks, gscale)
         eng = self.engine
         sample = self.model.front_end_sample(sample)  # --use-hubert: frozen front end inside the step
         out = eng.forward(sample, training=True, want_attn=False, with_loss=True)

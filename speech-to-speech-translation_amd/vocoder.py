@@ -134,13 +134,17 @@ class _HostMTStream:
         """``upload``: (device, copy stream, ring slot) -- the generator thread then also uploads the WHOLE upper bound of
         draws on that stream as soon as they exist (the decoder is still running: the PCIe link is idle), and ``take``
         hands out a slice of the device copy; without it the caller uploads the n it takes, after the decode.
-        ``start_after``: an earlier, still pending stream (two batches decoded at once): this one starts where that one
-        ends IF all of its upper bound gets drawn -- a guess that ``take`` checks against numpy's real state (a batch
-        that stopped early leaves numpy elsewhere: None, and the caller draws the ordinary way)."""
+        ``start_after``: an earlier, still pending stream (two batches decoded at once): this one starts from the state
+        the earlier one's ``take(n)`` leaves numpy in -- its REAL end, wherever the earlier batch stopped (round 4 guessed
+        "all of its upper bound", which only holds when no utterance stops early: ADVICE r4) -- so its generator thread
+        waits for that ``take``; the second batch's post-processing is held behind the first one's anyway
+        (``generate_two``), and the run is hidden under the first batch's vocoder."""
         import os
         import threading
         self.upload, self.dev_buf, self.up_ev = upload, None, None
         self.start_after = start_after
+        self.taken = threading.Event()  # set by take() / abandon(); end_words: numpy's state behind the draws handed out
+        self.end_words = None
         self.state0 = np.random.get_state()  # (with start_after: only its constant fields are used)
         self.n = int(n_upper)
         self.threads = int(threads) or max(1, min(8, (os.cpu_count() or 2) - 1))
@@ -157,14 +161,21 @@ class _HostMTStream:
         self.thread = threading.Thread(target=self._run, daemon=True)
         self.thread.start()
 
+    def abandon(self):
+        """Nobody will ``take`` from this stream (its batch failed, or it was dropped): release a stream chained behind it
+        (which then reports failure: its caller draws the ordinary way) and wait for the generator thread, which may still
+        be writing the staging buffer."""
+        self.taken.set()
+        self.thread.join()
+
     def _run(self):
         if self.start_after is not None:
             prev = self.start_after
-            prev.thread.join()
-            if prev.rc != 0:
+            prev.taken.wait()
+            if prev.end_words is None:  # (not taken from, or its take failed: numpy's state is not ours to predict)
                 self.rc = -1
                 return
-            self.state_w = prev.bounds[prev.threads].copy()  # the state behind all of the earlier stream's draws
+            self.state_w = prev.end_words.copy()  # the state behind the draws the earlier batch REALLY used
         self.rc = _mt_host(self.state_w, self.n, self.buf.data_ptr(), self.bounds, self.threads)
         if self.upload is not None and self.rc == 0 and self.n > 0:
             dev, stream, slot = self.upload
@@ -173,11 +184,17 @@ class _HostMTStream:
                 self.dev_buf = self.buf[:self.n].to(dev, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(stream)
-            self.up_ev = ev
-            if slot is not None:
-                slot[1] = ev  # (the ring buffer is free again once this upload has read it)
+            self.up_ev = ev  # (published through this object only; whoever reuses the ring slot reads it after thread.join())
 
     def take(self, n: int):
+        try:
+            return self._take(n)
+        finally:
+            self.taken.set()  # (a stream chained behind this one starts now -- or learns that it cannot)
+
+    def _take(self, n: int):
+        if self.start_after is not None and not self.start_after.taken.is_set():
+            self.start_after.abandon()  # (out of order: the earlier batch never took its draws)
         self.thread.join()
         cur = np.random.get_state()
         if self.rc != 0:
@@ -194,6 +211,7 @@ class _HostMTStream:
         if _mt_host(self.bounds[t], n - d0, None, end, 1) != 0:
             return None
         np.random.set_state((self.state0[0], end[1, :624].copy(), int(end[1, 624]), self.state0[3], self.state0[4]))
+        self.end_words = end[1].copy()
         if self.dev_buf is not None:
             cur = torch.cuda.current_stream()
             cur.wait_event(self.up_ev)
@@ -283,6 +301,8 @@ class _DeviceMTStream:
 
 
 class GriffinLim:
+    PHASE_CAP = 1 << 26  # doubles drawn ahead of the decode at most (512 MB of pinned memory per ring slot)
+
     def __init__(self, n_fft: int, win_length: int, hop_length: int, n_iter: int, device, window_fn=torch.hann_window,
                  phase_rng: str = "numpy", seed: int = 1):
         """``phase_rng``: where the initial phases' uniform draws come from when the caller passes no ``angles`` --
@@ -323,7 +343,10 @@ class GriffinLim:
         if self.phase_rng == "numpy" and self.use_fft and n_frames_upper > 0:
             import os
             how = os.environ.get("S2ST_GL_PHASE_STREAM", "host")
-            n = self.F * int(n_frames_upper)
+            # (the run-ahead is capped like the device generator's: the speech generator's upper bound is bsz x max_iter
+            # frames, and max_iter defaults to 6000 -- 12 GB of doubles for a batch of 64 at n_fft 2048; a batch that
+            # really vocodes more than the cap draws the ordinary way, after the decode: ADVICE r4)
+            n = min(self.F * int(n_frames_upper), self.PHASE_CAP)
             if pending and not (how == "host" and isinstance(pending[-1], _HostMTStream)):
                 how = "off"  # (a second batch in flight: only the host generator can be chained behind a pending one)
             if how == "numpy":
@@ -332,18 +355,29 @@ class GriffinLim:
                 obj = _DeviceMTStream(n, self.device)
             elif how == "host":
                 up = None
-                buf = self._ring_buffer(n)
-                if self.device.type == "cuda" and os.environ.get("S2ST_GL_EARLY_UPLOAD", "1") != "0":
-                    # the draws go to the device as soon as the host has them, under the decode (a copy stream of their own)
-                    if self.__dict__.get("_copy_stream") is None:
-                        self._copy_stream = torch.cuda.Stream(device=self.device)
-                    up = (self.device, self._copy_stream, self._pin_ring[self._ring_i])
-                obj = _HostMTStream(n, self.device.type == "cuda", buf=buf, upload=up,
-                                    start_after=pending[-1] if pending else None)
+                try:
+                    buf = self._ring_buffer(n)
+                except RuntimeError:  # (no pinned memory of that size: draw after the decode, the ordinary way)
+                    buf, how = None, "off"
+                if how == "host":
+                    if self.device.type == "cuda" and os.environ.get("S2ST_GL_EARLY_UPLOAD", "1") != "0":
+                        # the draws go to the device as soon as the host has them, under the decode (a copy stream of their own)
+                        if self.__dict__.get("_copy_stream") is None:
+                            self._copy_stream = torch.cuda.Stream(device=self.device)
+                        up = (self.device, self._copy_stream, None)
+                    obj = _HostMTStream(n, self.device.type == "cuda", buf=buf, upload=up,
+                                        start_after=pending[-1] if pending else None)
+                    if self.device.type == "cuda":
+                        self._pin_ring[self._ring_i][2] = obj  # the stream OWNS its slot until it has been joined
             elif how != "off":
                 raise ValueError("S2ST_GL_PHASE_STREAM must be host, numpy, device or off")
         self._streams.append(obj)
-        del self._streams[:-2]  # (at most two batches are in flight; an entry nobody took is dropped)
+        # at most two batches are in flight; an entry nobody took (its batch failed, or the vocoder was called with explicit
+        # angles) is dropped -- after its generator thread has been joined: it may still be filling / uploading its slot
+        for old in self._streams[:-2]:
+            if isinstance(old, _HostMTStream):
+                old.abandon()
+        del self._streams[:-2]
 
     def _ring_buffer(self, n: int):
         """One of two persistent pinned staging buffers for the run-ahead draws, alternating, each guarded by the event of
@@ -351,9 +385,14 @@ class GriffinLim:
         k + 1's generator starts filling)."""
         if self.device.type != "cuda":
             return None
-        ring = self.__dict__.setdefault("_pin_ring", [[None, None], [None, None]])
+        ring = self.__dict__.setdefault("_pin_ring", [[None, None, None], [None, None, None]])  # [buffer, upload event, owner]
         self._ring_i = (self.__dict__.get("_ring_i", -1) + 1) % 2
         slot = ring[self._ring_i]
+        if slot[2] is not None:  # the stream that last filled the slot: its thread is joined before anything is reused
+            slot[2].abandon() if not slot[2].taken.is_set() else slot[2].thread.join()
+            if slot[2].up_ev is not None:
+                slot[2].up_ev.synchronize()  # (its early upload has read the buffer)
+            slot[2] = None
         if slot[1] is not None:
             slot[1].synchronize()  # (two batches old: long complete)
             slot[1] = None

@@ -295,6 +295,10 @@ def test_base_golden(backend, golden_dir):
             ref = z[f"sum.{k}"]
             assert abs(float(t.abs().sum()) - ref[1]) < otol * ref[1], (precise, k)
             assert abs(float((t ** 2).sum().sqrt()) - ref[2]) < otol * ref[2], (precise, k)
+            # the reference's first 256 values of the tensor (its own layout), element by element -- not only checksums
+            head = z[f"head.{k}"].astype(np.float64)
+            err = float(np.abs(t.reshape(-1)[:256].numpy() - head).max())
+            assert err < otol * max(float(np.abs(head).max()), 1e-2 * float(t.abs().max())), (precise, k, err)
         gn = dict(zip(z["grad_norm_names"].tolist(), z["grad_norms"].tolist()))
         gmax = max(gn.values())
         for n, pv, gv, isb in e.named_views():

@@ -60,9 +60,10 @@ def test_names_resolve_through_fairseq_registries():
     assert out["criterion"] == pkg + ".criterions.s2st_loss"
     assert out["bases"] == [True, True, True]
     assert out["registered"] == {"task": ["s2s_translation", "s2s_translation_mtl"],
-                                 "model": ["s2st_transformer", "s2st_transformer_mtl", "t2s_transformer"],
-                                 "arch": ["s2st_transformer", "s2st_transformer_mtl", "t2s_transformer"],
-                                 "criterion": ["s2st_loss", "s2st_loss_mtl", "t2s_loss"]}
+                                 "model": ["s2st_transformer", "s2st_transformer_mtl", "t2s_transformer", "s2t_transformer_hubert"],
+                                 "arch": ["s2st_transformer", "s2st_transformer_mtl", "t2s_transformer", "s2t_transformer_hubert",
+                                          "s2t_transformer_hubert_s"],
+                                 "criterion": ["s2st_loss", "s2st_loss_mtl", "t2s_loss", "s2t_loss"]}
     assert out["mtl"] == [pkg + ".tasks.s2s_translation_mtl", pkg + ".models.s2st_transformer_mtl",
                           pkg + ".criterions.s2st_loss_mtl"]
     assert out["arch_defaults"] == [12, 6, 512, 256]  # base_architecture, s2st_transformer.py:792-830

@@ -156,6 +156,82 @@ def test_fast_path_within_north_star_tolerance_of_precise(backend, workload):
     assert _grad_close(gf, gp, 5e-2)
 
 
+class _SampledGrads:
+    """The oracle's gradients in the layout of a golden file's ``gsub.*`` entries (test_engine.check_gradient_direction)."""
+    def __init__(self, named):
+        from test_engine import gsub
+        self.d = {"gsub." + n: gsub(g.detach().numpy()) for n, g in named.items()}
+        self.files = list(self.d)
+
+    def __getitem__(self, k):
+        return self.d[k]
+
+
+@pytest.fixture(scope="module")
+def oracle_full_batch(workload):
+    """The CPU oracle (torch fp32) on ALL utterances of the bench's first max-tokens 20000 batch, dropouts 0, training mode
+    (BatchNorm batch statistics): forward, criterion, backward -- ~3 - 6 s on the GPU host's cores, once per module."""
+    from test_engine import make_oracle
+    corpus, b = workload
+    s = corpus.collate_batch(b[0])
+    _, m = make_oracle(dict(CONFIGS["base_recipe"], **NO_DROP))
+    loss, ss, log, outs = O.criterion_forward(m, s)
+    loss.backward()
+    grads = {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
+    outs = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in outs.items()}
+    return s, log, outs, grads
+
+
+@pytest.mark.parametrize("precise", [True, False], ids=["bf16x3", "bf16"])
+def test_full_batch_against_oracle(backend, workload, oracle_full_batch, golden_dir, precise):
+    """at the BENCHMARKED batch size (40 utterances, ~4.6 k decoder / 3.4 k encoder rows) the tile
+    picker's 4-wave forms, the one-round 128 x 128 rule, the grouped weight-gradient launch with one XCD run per tile range
+    and the XCD-aware attention block order engage -- and were only ever compared with the precise mode of the same
+    library.  Here the whole path is held against the ORACLE on the bench's first batch: every loss term (bf16x3 5e-5,
+    bf16 1e-3 = north-star), sampled outputs (flat[::127], not checksums), the direction of every gradient tensor (bf16x3:
+    5e-3 per tensor / 2e-3 whole; bf16: the bounds derived from the reference under autocast, test_engine.bf16_tensor_bounds),
+    and in bf16x3 mode the integer outputs bit for bit (stop indices, greedy CTC path, encoder lengths)."""
+    _need_gpu(backend)
+    from test_engine import bf16_tensor_bounds, check_gradient_direction, gsub
+    s, log, outs, ograds = oracle_full_batch
+    a, e = _engine(backend, dict(CONFIGS["base_recipe"], **NO_DROP), precise=precise)
+    o = e.forward(s, training=True, want_attn=True, seed=1)
+    e.zero_grad()
+    e.backward(1.0)
+    backend.sync()
+    st = o["stats"].double().cpu()
+    ltol = 5e-5 if precise else 1e-3
+    for k, i in LOSS_KEYS:
+        ref = float(log[k])
+        assert abs(float(st[i]) - ref) < ltol * max(1.0, abs(ref)), (k, float(st[i]), ref)
+    assert int(st[5]) == log["asr_n_correct"] or not precise
+    otol = 5e-4 if precise else 3e-2
+    pairs = [("encoder_out", outs["encoder_out"].transpose(0, 1)), ("feature_out", outs["feature_out"]),
+             ("eos_out", outs["eos_out"]), ("post_feat_out", outs["post_feat_out"]), ("attn", outs["attn"]),
+             ("asr_logits", outs["asr_logits"]), ("st_logits", outs["st_logits"]),
+             ("ctc_lprobs", outs["ctc_lprobs"].transpose(0, 1))]
+    for k, ref in pairs:
+        mine = gsub(o[k].detach().cpu().contiguous().numpy())
+        r = gsub(ref.contiguous().numpy())
+        assert mine.shape == r.shape, (k, mine.shape, r.shape)
+        if k == "ctc_lprobs":  # (log-probabilities: padded frames hold -inf-like fill on neither side, compare finite ones)
+            ok = np.isfinite(r) & np.isfinite(mine)
+            mine, r = mine[ok], r[ok]
+        err = float(np.abs(mine - r).max()) / float(np.abs(r).max())
+        assert err < otol, (k, err)
+    assert torch.equal(o["encoder_lens"].cpu().long(), outs["encoder_lens"])
+    if precise:
+        assert torch.equal(O.stop_indices(o["eos_out"].cpu()), O.stop_indices(outs["eos_out"]))
+        il = O.ctc_input_lengths(s["net_input"]["src_speech_lens"], [5, 5])
+        assert torch.equal(O.ctc_greedy_path(o["ctc_lprobs"].cpu().transpose(0, 1), il), O.ctc_greedy_path(outs["ctc_lprobs"], il))
+    grads = {n: gv for n, pv, gv, isb in e.named_views() if not isb}
+    z = _SampledGrads(ograds)
+    tol_of, whole_tol, ac = bf16_tensor_bounds(golden_dir)
+    w, whole = check_gradient_direction(grads, z, 5e-3 if precise else tol_of, 2e-3 if precise else whole_tol,
+                                        tag="full batch " + ("bf16x3" if precise else "bf16"))
+    print(f"[full batch vs oracle {'bf16x3' if precise else 'bf16'}] worst tensor {w[1]} {w[0]:.2e}, whole gradient {whole:.2e}")
+
+
 @pytest.mark.parametrize("precise,tol", [(True, 1e-4), (False, 2e-2)])
 def test_valid_frames_do_not_see_batch_padding(backend, workload, precise, tol):
     """(bf16 mode: a different padded length changes tile counts, hence fp32 summation order in the last bit,

@@ -1,0 +1,184 @@
+"""``s2t_transformer_hubert`` / ``s2t_loss`` -- the ST / ASR pre-training stage of the mix- / prompt-tuning recipes (SURVEY
+section 2.1 #29): the speech encoder + ONE full-width text decoder, label-smoothed CE over
+``--test-type`` asr / st.  Golden from the reference's own model and criterion (oracle/gen_golden_s2t.py): oracle pinned on
+CPU; the HIP path through task -> model -> criterion on the emulator and the GPU against the golden; three updates through
+the package's trainer against the reference's Adam; and the stage's checkpoint feeding ``--load-pretrained-encoder-from`` of
+the s2st stage (run_mix_tuning.sh:100, 143)."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import s2st_oracle as O
+import s2t_oracle as SO
+from configs import CONFIGS, S2T_TINY, golden_sample
+from synth_weights import load_synth
+from test_engine import gsub, rel
+
+PKG = "speech-to-speech-translation_amd"
+
+
+def _sample(which=0):
+    s = golden_sample("tiny", which)
+    s["net_input"]["collated_audios_orig"], s["net_input"]["padding_mask"] = None, None
+    return s
+
+
+def _check_grads(named_grads, z, tt, tensor_tol, whole_tol):
+    names = [k[len(tt) + 6:] for k in z.files if k.startswith(tt + ".gsub.")]
+    assert len(names) > 50
+    gmax = max(float(np.linalg.norm(z[f"{tt}.gsub.{n}"])) for n in names)
+    num = den = 0.0
+    for n in names:
+        ref = z[f"{tt}.gsub.{n}"].astype(np.float64).reshape(-1)
+        mine = gsub(named_grads[n].detach().cpu().numpy()).reshape(-1)
+        d, r = float(np.linalg.norm(mine - ref)), float(np.linalg.norm(ref))
+        assert d < tensor_tol * (r + 1e-3 * gmax), (tt, n, d, r)
+        num += d * d
+        den += r * r
+    assert (num / den) ** 0.5 < whole_tol, (tt, (num / den) ** 0.5)
+
+
+@pytest.mark.parametrize("tt", ["asr", "st"])
+def test_oracle_against_reference_golden(golden_dir, tt):
+    z = np.load(os.path.join(golden_dir, "s2t_tiny.npz"))
+    a = SO.make_args(**S2T_TINY)
+    m = SO.S2TModel(a)
+    assert set(m.state_dict().keys()) == set(z["sd_names"].tolist())
+    ref_shapes = dict(zip(z["sd_names"].tolist(), z["sd_shapes"].tolist()))
+    for k, v in m.state_dict().items():
+        assert ",".join(str(int(s)) for s in v.shape) == ref_shapes[k], k
+    load_synth(m, 0)
+    m.train()
+    loss, ss, log, outs = SO.criterion_forward(m, _sample(), tt, a.label_smoothing)
+    loss.backward()
+    for k in ("loss", "nll_loss"):
+        np.testing.assert_allclose(float(log[k]), float(z[f"{tt}.log.{k}"]), rtol=2e-5, err_msg=k)
+    for k in ("ntokens", "nsentences", "sample_size", "n_correct", "total"):
+        assert int(log[k]) == int(z[f"{tt}.log.{k}"]), k
+    assert rel(outs["logits"], torch.from_numpy(z[f"{tt}.logits"])) < 3e-5
+    _check_grads({n: p.grad for n, p in m.named_parameters() if p.grad is not None}, z, tt, 2e-3, 5e-4)
+
+
+def _build(backend, precise, tt, **extra):
+    tasks = importlib.import_module(PKG + ".tasks")
+    a = SO.make_args(**S2T_TINY)
+    for k in ("encoder_layers", "decoder_layers"):
+        setattr(a, k, S2T_TINY[k])
+    a.precise_gemm, a.arch, a.criterion, a.test_type, a.report_accuracy = precise, "s2t_transformer_hubert", "s2t_loss", tt, True
+    for k, v in extra.items():
+        setattr(a, k, v)
+    task = tasks.S2ST_TranslationTask.setup_task(a, device=backend.device)
+    model = task.build_model(a)
+    return a, task, model, task.build_criterion(a)
+
+
+@pytest.mark.parametrize("tt", ["asr", "st"])
+@pytest.mark.parametrize("precise", [True, False], ids=["bf16x3", "bf16"])
+def test_task_model_criterion_against_reference_golden(backend, golden_dir, precise, tt):
+    if backend.kind == "emu" and not precise:
+        pytest.skip("the emulator runs the precise form of this golden (the bf16 form: GPU)")
+    z = np.load(os.path.join(golden_dir, "s2t_tiny.npz"))
+    a, task, model, crit = _build(backend, precise, tt)
+    assert type(model).__name__ == "S2TTransformerModel" and type(crit).__name__ == "LabelSmoothedCrossEntropyCriterion"
+    assert set(model.state_dict().keys()) == set(z["sd_names"].tolist())
+    ref_shapes = dict(zip(z["sd_names"].tolist(), z["sd_shapes"].tolist()))
+    for k, v in model.state_dict().items():
+        assert ",".join(str(int(s)) for s in v.shape) == ref_shapes[k], k
+    load_synth(model, 0)
+    model.train()
+    s = _sample()
+    loss, ss, log = crit(model, s)
+    model.engine.zero_grad()
+    loss.backward()
+    backend.sync()
+    ltol = 5e-5 if precise else 1e-3
+    for k in ("loss", "nll_loss"):
+        r = float(z[f"{tt}.log.{k}"])
+        assert abs(float(log[k]) - r) < ltol * abs(r), (k, float(log[k]), r)
+    for k in ("ntokens", "nsentences", "sample_size"):
+        assert int(log[k]) == int(z[f"{tt}.log.{k}"]), k
+    assert int(ss) == int(z[f"{tt}.sample_size"])
+    assert int(log["total"]) == int(z[f"{tt}.log.total"])
+    if precise:
+        assert int(log["n_correct"]) == int(z[f"{tt}.log.n_correct"])
+    o = crit.last_outputs
+    assert rel(o["asr_logits"], torch.from_numpy(z[f"{tt}.logits"])) < (3e-4 if precise else 3e-2)
+    grads = {n: gv for n, pv, gv, isb in model.engine.named_views() if not isb}
+    _check_grads(grads, z, tt, 1.5e-2 if precise else 1.5e-1, 5e-3 if precise else 5e-2)
+    # the reference's own entry points: model(...) -> (logits, None); get_normalized_probs; get_targets
+    model.eval()
+    key = "src" if tt == "asr" else "tgt"
+    ni = s["net_input"]
+    logits, extra = model(ni["src_speech"], ni["src_speech_lens"], None, None, ni[f"prev_{key}_text_tokens"])
+    backend.sync()
+    assert extra is None and rel(logits, torch.from_numpy(z[f"{tt}.logits"])) < (3e-4 if precise else 3e-2)
+    lp = model.get_normalized_probs((logits, None), log_probs=True)
+    assert lp.batch_first and float((lp.exp().sum(-1) - 1).abs().max()) < 1e-4
+    assert torch.equal(model.get_targets(s, tt, None), s[f"{key}_text"])
+    red = type(crit).reduce_metrics([dict(log.items())])
+    assert abs(red["loss"] - float(log["loss"]) / int(ss) / np.log(2)) < 1e-6 and "accuracy" in red and "ppl" in red
+    assert type(crit).logging_outputs_can_be_summed()
+
+
+def test_three_updates_against_the_references_adam(backend, golden_dir):
+    """--test-type st, lr 1e-3 / warm-up 2 / clip 1.0: losses and gradient norms of three updates, parameter norms after them
+    (the reference's own Adam and clip_grad_norm_ wrote the golden)."""
+    z = np.load(os.path.join(golden_dir, "s2t_tiny.npz"))
+    tr = importlib.import_module(PKG + ".trainer")
+    lr0, warm, clip = (float(v) for v in z["train.hparams"])
+    a, task, model, crit = _build(backend, True, "st", lr=lr0, warmup_updates=int(warm), clip_norm=clip)
+    load_synth(model, 0)
+    t = tr.Trainer(a, task, model, crit)
+    losses, gnorms = [], []
+    for s in (_sample(0), _sample(1), _sample(0)):
+        r = t.train_step([s])
+        losses.append(float(crit.last_outputs["stats"][16]))
+        gnorms.append(float(r["gnorm"]))
+    backend.sync()
+    np.testing.assert_allclose(losses, z["train.loss"], rtol=2e-4)
+    np.testing.assert_allclose(gnorms, z["train.gnorm"], rtol=2e-3)
+    mine = {n: pv for n, pv, gv, isb in model.engine.named_views() if not isb}
+    for n, r in zip(z["train.param_norm_names"].tolist(), z["train.param_norms"].tolist()):
+        assert abs(float(mine[n].norm()) - r) < 2e-4 * max(r, 1e-3), n
+    for k in z.files:
+        if k.startswith("train.param."):
+            ref = z[k].astype(np.float64).reshape(-1)
+            x = mine[k[len("train.param."):]].detach().cpu().numpy()
+            x = x if x.size <= 40000 else x.reshape(-1)[::61]
+            assert np.linalg.norm(x.reshape(-1) - ref) < 2e-3 * np.linalg.norm(ref), k
+
+
+def test_pretraining_checkpoint_feeds_the_s2st_stage(backend, tmp_path):
+    """run_mix_tuning.sh:100 -> :143: the ST pre-training stage's checkpoint is what the s2st stage's
+    --load-pretrained-encoder-from reads; every encoder tensor must arrive, the rest keeps its initialisation."""
+    tasks = importlib.import_module(PKG + ".tasks")
+    ck = importlib.import_module(PKG + ".checkpoint_utils")
+    a, task, model, crit = _build(backend, True, "st")
+    load_synth(model, 3)
+    path = str(tmp_path / "st_pretraining_last.pt")
+    torch.save({"model": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, "args": None,
+                "cfg": {"model": None}}, path)
+    b = O.make_args(**dict(CONFIGS["tiny"], encoder_attention_heads=4))
+    b.precise_gemm = True
+
+    def build(**flags):
+        for k, v in flags.items():
+            setattr(b, k, v)
+        torch.manual_seed(5)
+        return tasks.S2ST_TranslationTask.setup_task(b, device=backend.device).build_model(b)
+
+    plain = {k: v.detach().cpu().clone() for k, v in build().state_dict().items()}
+    got = {k: v.detach().cpu() for k, v in build(load_pretrained_encoder_from=path).state_dict().items()}
+    src = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    n_enc = 0
+    for k, v in got.items():
+        if k.startswith("encoder.") and k in src and not k.endswith("_float_tensor"):
+            assert torch.equal(v, src[k]), k
+            n_enc += 1
+        elif v.dtype.is_floating_point and not k.startswith("encoder."):
+            assert torch.equal(v, plain[k]), k
+    assert n_enc > 20
+    del ck
