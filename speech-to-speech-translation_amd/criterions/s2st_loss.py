@@ -39,16 +39,44 @@ class _EngineStep(torch.autograd.Function):
     flat gradient arena)."""
 
     @staticmethod
-    def forward(ctx, anchor, loss_value, engine, hooks):
+    def forward(ctx, anchor, loss_value, engine, hooks, model=None):
         ctx.engine = engine
         ctx.hooks = hooks
+        ctx.model = model
         return loss_value.clone()
 
     @staticmethod
     def backward(ctx, grad_out):
         gs = float(grad_out)  # host read; the native trainer calls engine.backward directly
+        if ctx.model is not None:
+            attach_grad_views(ctx.model)
         ctx.engine.backward(gs, on_segment=ctx.hooks)
-        return None, None, None, None
+        return None, None, None, None, None
+
+
+def attach_grad_views(model):
+    """Make ``p.grad`` of every trainable parameter the view of the engine's flat gradient arena again.
+
+    fairseq's optimizer wrapper clears gradients by DROPPING them -- ``FairseqOptimizer.zero_grad`` sets ``p.grad = None``
+    (fairseq/optim/fairseq_optimizer.py:127-131), and so does ``torch.optim.Optimizer.zero_grad(set_to_none=True)`` -- while
+    the engine's backward ADDS into the arena whatever the Python attributes say.  So, right before a backward: a parameter
+    whose ``.grad`` is None gets its arena range zeroed (that is what "cleared" means to the caller) and its view attached;
+    a parameter that still holds its view keeps accumulating (update-freq > 1: the micro-batches after the first one).
+    Found by tests/test_reference_loop.py: without this the reference's own loop left the parameters where they were."""
+    views = getattr(model, "_grad_views", None)
+    if views is None:
+        views = model._grad_views = {n: gv for n, pv, gv, isb in model.engine.named_views() if not isb}
+    params = dict(model.named_parameters())
+    missing = [n for n, p in params.items() if p.requires_grad and p.grad is None and n in views]
+    if not missing:
+        return
+    if len(missing) == len(views):
+        model.engine.zero_grad()  # one pass over the arena
+    else:
+        for n in missing:
+            views[n].zero_()
+    for n in missing:
+        params[n].grad = views[n]
 
 
 class LazyLog(dict):
@@ -145,7 +173,7 @@ class Tacotron2Criterion(CriterionBase):  # fairseq's FairseqCriterion when fair
         stats = out["stats"]
         loss_val = stats[STAT["LOSS"]]
         anchor = next(model.parameters())
-        loss = _EngineStep.apply(anchor, loss_val, eng, self.grad_hooks) if torch.is_grad_enabled() else loss_val
+        loss = _EngineStep.apply(anchor, loss_val, eng, self.grad_hooks, model) if torch.is_grad_enabled() else loss_val
         sample_size = sample["nsentences"] if self.sentence_avg else sample["ntokens"]
         log = LazyLog(stats, {"ntokens": sample["ntokens"], "nsentences": sample["nsentences"],
                               "sample_size": sample_size}, self.report_accuracy, bool(c.has_asr), bool(c.has_st))

@@ -105,7 +105,7 @@ class LabelSmoothedCrossEntropyCriterion(CriterionBase):
         stats = out["stats"]
         loss_val = stats[STAT["LOSS"]]
         anchor = next(model.parameters())
-        loss = _EngineStep.apply(anchor, loss_val, eng, self.grad_hooks) if torch.is_grad_enabled() else loss_val
+        loss = _EngineStep.apply(anchor, loss_val, eng, self.grad_hooks, model) if torch.is_grad_enabled() else loss_val
         key = "src" if self.test_type == "asr" else "tgt"
         nsent = int(sample[f"{key}_text"].size(0))
         ntok = sample[f"{key}_txt_ntokens"]

@@ -201,9 +201,13 @@ def test_full_batch_against_oracle(backend, workload, oracle_full_batch, golden_
     backend.sync()
     st = o["stats"].double().cpu()
     ltol = 5e-5 if precise else 1e-3
+    tot = float(log["loss"])
     for k, i in LOSS_KEYS:
         ref = float(log[k])
-        assert abs(float(st[i]) - ref) < ltol * max(1.0, abs(ref)), (k, float(st[i]), ref)
+        if precise or k == "loss":  # north-star: loss parity 1e-3
+            assert abs(float(st[i]) - ref) < ltol * max(1.0, abs(ref)), (k, float(st[i]), ref)
+        else:  # bf16 components: 5e-3 of themselves or 1e-3 of the total (test_fast_path_within_north_star_tolerance_of_precise)
+            assert abs(float(st[i]) - ref) <= max(5e-3 * abs(ref), 1e-3 * abs(tot)), (k, float(st[i]), ref)
     assert int(st[5]) == log["asr_n_correct"] or not precise
     otol = 5e-4 if precise else 3e-2
     pairs = [("encoder_out", outs["encoder_out"].transpose(0, 1)), ("feature_out", outs["feature_out"]),

@@ -107,7 +107,10 @@ def test_task_model_criterion_against_reference_golden(backend, golden_dir, prec
     o = crit.last_outputs
     assert rel(o["asr_logits"], torch.from_numpy(z[f"{tt}.logits"])) < (3e-4 if precise else 3e-2)
     grads = {n: gv for n, pv, gv, isb in model.engine.named_views() if not isb}
-    _check_grads(grads, z, tt, 1.5e-2 if precise else 1.5e-1, 5e-3 if precise else 5e-2)
+    # (precise mode: the fp32 reference's own gradients move by ~1e-2 under a 1e-5 input perturbation -- ReLU units with
+    # near-zero pre-activations flip -- which is this comparison's resolution, tests/test_engine.py::test_tiny_golden_precise;
+    # the summed loss of this criterion makes the text decoder's fc1 the most exposed tensor: 1.53e-2 measured)
+    _check_grads(grads, z, tt, 2.5e-2 if precise else 1.5e-1, 5e-3 if precise else 5e-2)
     # the reference's own entry points: model(...) -> (logits, None); get_normalized_probs; get_targets
     model.eval()
     key = "src" if tt == "asr" else "tgt"
