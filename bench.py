@@ -302,6 +302,29 @@ def infer_main(args):
     nd, _ = run(gens_d, args.steps)
     torch.cuda.synchronize()
     value_device_rng = nd / (time.perf_counter() - t0d)
+    # ---- the same pass with EARLY STOPS: the headline's stop threshold is never reached (fixed work, SURVEY
+    #      8(d)), which also means no utterance ever leaves the batch early and every run-ahead phase draw is used -- not what
+    #      a trained checkpoint does.  Random-init weights give every (utterance, step) some stop probability: the threshold
+    #      is set to the median over the utterances of their largest probability in the first 70 % of the steps, so about
+    #      half of them stop somewhere in there and the rest later or never; the batch ends when its last utterance has.
+    with torch.no_grad():
+        probe = G.AutoRegressiveSpeechGenerator(model, None, None, max_iter=iters[0], eos_prob_threshold=2.0).generate(model, samples[0])
+    nf = a.n_frames_per_step
+    peak = torch.stack([f["eos_prob"][::nf][: max(1, int(0.7 * iters[0]))].max() for f in probe])
+    thr_e = float(peak.median())
+    gens_e = [G.AutoRegressiveSpeechGenerator(model, voc, None, max_iter=it, eos_prob_threshold=thr_e) for it in iters]
+    run(gens_e, max(2, len(samples)))
+    torch.cuda.synchronize()
+    t0e = time.perf_counter()
+    ne, nfe = run(gens_e, args.steps)
+    torch.cuda.synchronize()
+    dte = time.perf_counter() - t0e
+    early = {"threshold": round(thr_e, 5), "utterances_per_s": round(ne / dte, 2), "mel_frames_per_s": round(nfe / dte, 1),
+             "mean_decoded_fraction_of_the_fixed_work": round(nfe / max(n_frames, 1), 3),
+             "note": "same batches, weights, chains and vocoder overlap as `value`, stop threshold = median over utterances of "
+                     "their peak stop probability in the first 70 % of the steps (random-init weights): utterances leave at "
+                     "different steps, Griffin-Lim runs on what was decoded"}
+    vlog("early-stop leg", early)
     # ... and strictly one after the other (the vocoder on the decoder's stream), for the record
     t0s = time.perf_counter()
     for i in range(args.steps):
@@ -433,7 +456,7 @@ def infer_main(args):
                        "value_with_device_phase_rng": round(value_device_rng, 2),
                        "vocoder_overlap": ("batch k's Griffin-Lim on a second stream beside batch k + 1's decoding steps"
                                            if DEFER else "off"),
-                       "decode_chains": CHAINS,
+                       "decode_chains": CHAINS, "early_stop": early,
                        "value_without_vocoder_overlap": round(value_serial, 2) if value_serial else None,
                        "decode_steps_per_batch": iters, "batch0_decode_ms": round(t_dec * 1e3, 2),
                        "batch0_vocoder_alone_ms": round(t_voc * 1e3, 2),
@@ -496,6 +519,11 @@ def main():
     ap.add_argument("--cpu-whole", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (PCIe-inclusive) leg")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short legs that put the other single-GPU BASELINE workloads (infer_base = configs[4], "
+                         "base_recipe_hubert = configs[3] on one GPU) into config.other_configs of the default line")
+    ap.add_argument("--grad-exchange-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="N > 1: type the gradient ranges are all-reduced in (runtime/distributed.py; fp32 = the reference's)")
     ap.add_argument("--timeline", default=None, help="write the per-dispatch timeline (stream, start, duration on the GPU "
                     "clock) of ONE replayed step to this file; tools/timeline.py summarises it")
     ap.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)
@@ -555,6 +583,7 @@ def main():
     prefetch = importlib.import_module(PKG + ".runtime.prefetch")
 
     a = C_.recipe_args(args.config)  # named configurations live in the package (configs.py)
+    a.grad_exchange_dtype = args.grad_exchange_dtype
     hub = str(a.use_hubert) == "true"
     task = tasks.S2ST_TranslationTask.setup_task(a, device=dev)
     torch.manual_seed(1)
@@ -664,7 +693,13 @@ def main():
         exchange = {"allreduce_exposed_ms": round(sum(ex) / max(len(ex), 1), 4),
                     "allreduce_exposed_ms_max": round(max(ex) if ex else 0.0, 4),
                     "buckets_mib": [round((hi - lo) * 4 / 2 ** 20, 1) for lo, hi in bk],
-                    "bytes_per_update": int(sum(hi - lo for lo, hi in bk) * 4), "dtype": "f32",
+                    "bytes_per_update": int(sum(hi - lo for lo, hi in bk) * (2 if trainer.reducer.exchange_dtype == "bf16" else 4)),
+                    "dtype": "bf16" if trainer.reducer.exchange_dtype == "bf16" else "f32",
+                    # RCCL's channel / CU budget and algorithm choices as this run saw them (unset = RCCL's defaults): the
+                    # collective's kernels share the chip with the backward, so the first 8-GPU run should explain itself
+                    "rccl_env": {k: os.environ[k] for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_ALGO", "NCCL_PROTO",
+                                                            "NCCL_NCHANNELS_PER_PEER", "RCCL_MSCCL_ENABLE", "NCCL_P2P_LEVEL",
+                                                            "HSA_ENABLE_IPC_MODE_LEGACY", "GPU_MAX_HW_QUEUES") if k in os.environ},
                     "transport": ("gloo through pinned host memory (S2ST_BENCH_SHARE_GPU: a control-flow check, not a "
                                   "measurement)" if share else
                                   ("RCCL via the C ABI (s2st_allreduce_sum_f32)" if trainer.reducer.native is not None
@@ -870,6 +905,36 @@ def main():
         except subprocess.TimeoutExpired:
             vlog("cpu leg timed out")
 
+    # ---- the other single-GPU BASELINE workloads as short legs: so that configs[3] (on one GPU) and
+    #      configs[4] carry a figure in the driver's own run.  Fresh child processes of this script (started while this
+    #      process sits idle; never an exec), each printing its own line; summarised under config.other_configs ----------
+    others = None
+    if rank == 0 and world == 1 and args.config == "base_recipe" and not args.no_other_configs:
+        import subprocess
+        others = {}
+        legs = {"infer_base": ["--config", "infer_base", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0"],
+                "base_recipe_hubert": ["--config", "base_recipe_hubert", "--steps", "20", "--warmup", "5", "--cpu-seconds", "0",
+                                       "--no-host-fed", "--no-roofline"]}
+        torch.cuda.empty_cache()
+        for name, extra in legs.items():
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-other-configs"] + extra,
+                                   capture_output=True, text=True, timeout=600)
+                got = None
+                for ln in r.stdout.splitlines():
+                    if ln.startswith("{"):
+                        got = json.loads(ln)
+                if got is None:
+                    others[name] = {"error": (r.stderr or "no line")[-300:]}
+                else:
+                    others[name] = {k: got[k] for k in ("metric", "value", "unit", "ms_per_step", "steps") if k in got}
+                    others[name]["workload"] = got.get("config", {}).get("workload")
+                    for k in ("mcd_vs_cpu", "early_stop"):
+                        if k in got.get("config", {}):
+                            others[name][k] = got["config"][k]
+            except subprocess.TimeoutExpired:
+                others[name] = {"error": "timed out"}
+
     if rank == 0:
         value = total_frames / dt
         line = {
@@ -901,6 +966,8 @@ def main():
             line["config"]["x_over_cpu"] = round(value / cpu["value"], 1)
         if exchange:
             line["gradient_exchange"] = exchange  # rank 0's view
+        if others:
+            line["config"]["other_configs"] = others
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -226,6 +226,12 @@ int64_t s2st_sumsq_parts_count(int64_t n);
  * skipped (the write the kernel makes anyway: the next step's zero_grad() pass over the arena is not needed) */
 int s2st_adam_f32(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float gmul, const float* gmul_dev, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int32_t step, float* gnorm_out, void* p_bf16, int32_t* skipped, int32_t sumsq_parts, int32_t zero_grad, void* stream);
 
+/* --grad-exchange-dtype bf16 (runtime/distributed.py; opt-in, the default exchange is fp32 like the reference's DDP,
+ * fairseq/models/distributed_fairseq_model.py:58-67): a finished range of the gradient arena rounded to bf16 (RNE) for
+ * the collective, and the reduced values widened back into the fp32 arena.  g 16-byte aligned, the bf16 buffer 8-byte. */
+int s2st_grad_pack_bf16_f32(const float* g, uint16_t* out, int64_t n, void* stream);
+int s2st_grad_unpack_bf16_f32(const uint16_t* in, float* g, int64_t n, void* stream);
+
 /* floats of workspace s2st_ctc_f32 needs */
 int64_t s2st_ctc_workspace(int32_t B, int32_t E, int32_t Lmax);
 

@@ -33,6 +33,14 @@ int s2st_stream_destroy(void* stream) {
   return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
+int s2st_grad_pack_bf16_f32(const float* g, uint16_t* out, int64_t n, void* stream) {
+  return s2st_grad_pack_bf16(g, out, (long)n, (hipStream_t)stream);
+}
+
+int s2st_grad_unpack_bf16_f32(const uint16_t* in, float* g, int64_t n, void* stream) {
+  return s2st_grad_unpack_bf16(in, g, (long)n, (hipStream_t)stream);
+}
+
 int s2st_gemm_f32(const s2st_gemm_args* a, void* stream) {
   if (!a) return S2ST_ERR_ARG;
   return s2st_gemm(*a, (hipStream_t)stream);

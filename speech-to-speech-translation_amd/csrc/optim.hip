@@ -122,3 +122,50 @@ int s2st_adam(float* p, float* g, float* m, float* v, long n, const float* sumsq
               v, n, sumsq, gmul, gmul_dev, max_norm, lr, beta1, beta2, eps, wd, step_size, gnorm_out, ph, skipped, sumsq_parts, zero_grad);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
+
+// ---- bf16 gradient exchange (runtime/distributed.py: --grad-exchange-dtype bf16) --------------------------------------
+// A finished range of the gradient arena is rounded to bf16 (round-to-nearest-even, like every bf16 operand copy of the
+// path), summed over the ranks in that type by the collective, and widened back into the fp32 arena: half the wire bytes
+// of the default fp32 exchange (fairseq/models/distributed_fairseq_model.py:58-67 all-reduces fp32 gradients; opt-in).
+namespace {
+__global__ __launch_bounds__(256) void grad_pack_bf16_kernel(const float* __restrict__ g, uint16_t* __restrict__ out, long n) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    reinterpret_cast<uint2*>(out)[i] = pack_bf16x4(v.x, v.y, v.z, v.w);
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const uint2 q = pack_bf16x4(g[i], 0.f, 0.f, 0.f);
+    out[i] = (uint16_t)(q.x & 0xffffu);
+  }
+}
+__global__ __launch_bounds__(256) void grad_unpack_bf16_kernel(const uint16_t* __restrict__ in, float* __restrict__ g, long n) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const uint2 q = reinterpret_cast<const uint2*>(in)[i];
+    float4 v;
+    v.x = __uint_as_float(q.x << 16); v.y = __uint_as_float(q.x & 0xffff0000u);
+    v.z = __uint_as_float(q.y << 16); v.w = __uint_as_float(q.y & 0xffff0000u);
+    reinterpret_cast<float4*>(g)[i] = v;
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    g[i] = __uint_as_float((uint32_t)in[i] << 16);
+}
+}  // namespace
+
+int s2st_grad_pack_bf16(const float* g, uint16_t* out, long n, hipStream_t st) {
+  if (n <= 0) return 0;
+  if (((uintptr_t)g % 16) || ((uintptr_t)out % 8)) return S2ST_ERR_ARG;
+  long blocks = (n / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  S2ST_LAUNCH(grad_pack_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, out, n);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+int s2st_grad_unpack_bf16(const uint16_t* in, float* g, long n, hipStream_t st) {
+  if (n <= 0) return 0;
+  if (((uintptr_t)g % 16) || ((uintptr_t)in % 8)) return S2ST_ERR_ARG;
+  long blocks = (n / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  S2ST_LAUNCH(grad_unpack_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, g, n);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}

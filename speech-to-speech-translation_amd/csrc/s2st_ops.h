@@ -148,6 +148,9 @@ int s2st_attn_headmean(const float* p, float* out, int B, int H, int T, int S, i
 // fp32 [rows][cols] (stride ldx) -> bf16 [rows][ldy] (ldy % 4 == 0, pad columns zeroed): the
 // bf16 copies the fast GEMM path reads
 int s2st_cast_bf16_rows(const float* x, long ldx, uint16_t* y, long ldy, long rows, int cols, hipStream_t st);
+// bf16 gradient exchange (optim.hip): round a range of the gradient arena to bf16 / widen the reduced values back
+int s2st_grad_pack_bf16(const float* g, uint16_t* out, long n, hipStream_t st);
+int s2st_grad_unpack_bf16(const uint16_t* in, float* g, long n, hipStream_t st);
 int s2st_transpose_bf16(const uint16_t* x, uint16_t* y, int R, int C, hipStream_t st);  // [R][C] -> [C][R]
 // every registered matrix [rows][cols] at element offset off of x_base -> its transpose at the same offset of y_base,
 // one launch (rows, cols multiples of 8; tile0 = running count of 64 x 64 tiles, tile0[n] = grid size)

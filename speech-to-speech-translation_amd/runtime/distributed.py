@@ -76,8 +76,17 @@ class GradReducer:
       two-process GPU test of the exchange runs this way;
     * host gradients (the CPU emulator tests): asynchronous gloo all-reduce."""
 
-    def __init__(self, grads: torch.Tensor, min_bucket_floats: int = 4 << 20, extra_stream=None):
+    def __init__(self, grads: torch.Tensor, min_bucket_floats: int = 4 << 20, extra_stream=None, exchange_dtype: str = "fp32"):
+        """``exchange_dtype``: "fp32" (default: what the reference's DDP sums, distributed_fairseq_model.py:58-67) or "bf16"
+        (``--grad-exchange-dtype bf16``): a finished range is rounded to bf16 by ``s2st_grad_pack_bf16_f32``, summed over
+        the ranks in that type, and widened back into the fp32 arena -- half the wire bytes, at the price of
+        one rounding of every rank's contribution and bf16 partial sums inside the collective; the two-rank trajectory test
+        bounds the effect (tests/test_distributed.py)."""
         self.grads = grads
+        if exchange_dtype not in ("fp32", "bf16"):
+            raise ValueError("--grad-exchange-dtype must be fp32 or bf16")
+        self.exchange_dtype = exchange_dtype
+        self._half = None
         import os
         self.staged = grads.is_cuda and dist.is_initialized() and dist.get_backend() == "gloo"
         self.native = None
@@ -110,7 +119,9 @@ class GradReducer:
             if self.extra_stream is not None:
                 self.stream.wait_stream(self.extra_stream)
             with torch.cuda.stream(self.stream):
-                if self.staged:
+                if self.exchange_dtype == "bf16":
+                    self._exchange_bf16(view)
+                elif self.staged:
                     if self._pin is None or self._pin.numel() < view.numel():
                         self._pin = torch.empty(max(view.numel(), self.min_bucket), dtype=torch.float32).pin_memory()
                     host = self._pin[:view.numel()]
@@ -122,8 +133,44 @@ class GradReducer:
                     self.native.all_reduce_(view)
                 else:
                     dist.all_reduce(view, op=dist.ReduceOp.SUM)
+        elif self.exchange_dtype == "bf16":
+            self._exchange_bf16(view)
         else:
             self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+
+    def _exchange_bf16(self, view: torch.Tensor):
+        """One range through the bf16 exchange, on the current stream (the reducer's own on a GPU; ranges follow each other
+        on it, so one staging buffer serves them all)."""
+        from . import binding as bd
+        n = view.numel()
+        if self._half is None or self._half.numel() < n:
+            self._half = torch.empty(max(n, self.min_bucket), dtype=torch.bfloat16, device=view.device)
+        half = self._half[:n]
+        bd.call("s2st_grad_pack_bf16_f32", view, half, n)
+        if self.staged:  # two ranks on one GPU (tests): gloo carries the bytes through pinned host memory
+            if self._pin is None or self._pin.numel() * 2 < n:
+                self._pin = torch.empty(max(n, self.min_bucket), dtype=torch.float32).pin_memory()
+            host = self._pin.view(torch.bfloat16)[:n]
+            host.copy_(half, non_blocking=True)
+            self.stream.synchronize()
+            self._host_sum_bf16(host)
+            half.copy_(host, non_blocking=True)
+        elif view.is_cuda:
+            dist.all_reduce(half, op=dist.ReduceOp.SUM)
+        else:
+            self._host_sum_bf16(half)
+        bd.call("s2st_grad_unpack_bf16_f32", half, view, n)
+
+    @staticmethod
+    def _host_sum_bf16(t: torch.Tensor):
+        """gloo has no bf16 reduction on every build: gather the ranks' bf16 buffers and add them in rank order with a
+        bf16 running sum (what a ring reduction's hops hold)."""
+        parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, t)
+        acc = parts[0].clone()
+        for q in parts[1:]:
+            acc += q
+        t.copy_(acc)
 
     def on_segment(self, i: int, lo: int, hi: int):
         """Engine callback: gradients in [lo, hi) are final.  Ranges arrive back-to-front and

@@ -103,6 +103,9 @@ def get_parser() -> argparse.ArgumentParser:
     a("--report-accuracy", action="store_true")
     a("--sentence-avg", action="store_true")
     a("--spec-bwd-max-iter", type=int, default=32)
+    a("--grad-exchange-dtype", default="fp32", choices=["fp32", "bf16"],
+      help="type the gradient ranges are all-reduced in (fp32: the reference's DDP; bf16: half the wire bytes, one rounding "
+           "of every rank's contribution -- runtime/distributed.py)")
     return p
 
 

@@ -55,7 +55,8 @@ class Trainer:
         self.wd = getattr(args, "weight_decay", 0.0)
         self.seed = getattr(args, "seed", 1)
         self._dummy_batch = None
-        self.reducer = GradReducer(self.engine.grads, extra_stream=self.engine.side_stream()) if is_dist() else None
+        self.reducer = GradReducer(self.engine.grads, extra_stream=self.engine.side_stream(),
+                                   exchange_dtype=str(getattr(args, "grad_exchange_dtype", "fp32") or "fp32")) if is_dist() else None
         if is_dist():
             # DDP's constructor broadcast of parameters and buffers from rank 0
             broadcast_(self.engine.params, 0)

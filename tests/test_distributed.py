@@ -49,12 +49,14 @@ def _worker_body(rank, world, port, q, on_gpu, fast):
                                      decoder_attention_heads=2)
     a = O.make_args(**cfg)
     a.precise_gemm, a.lr, a.warmup_updates, a.clip_norm = not fast, 1e-3, 1, 0.05
+    a.grad_exchange_dtype = os.environ.get("S2ST_TEST_EXCHANGE", "fp32")
     task = tasks.S2ST_TranslationTask.setup_task(a, device=torch.device("cuda", 0) if on_gpu else torch.device("cpu"))
     model = task.build_model(a)
     load_synth(model, rank)  # deliberately different per rank: the Trainer must broadcast rank 0's
     crit = task.build_criterion(a)
     trainer = tr.Trainer(a, task, model, crit)
     trainer.reducer.min_bucket = 50_000  # several buckets even on the nano model
+    assert trainer.reducer.exchange_dtype == a.grad_exchange_dtype
     mine = nano_batches()[rank]
     gnorms = []
     for u in range(3):
@@ -74,7 +76,24 @@ def _worker_body(rank, world, port, q, on_gpu, fast):
 
 
 @pytest.mark.parametrize("where", ["emu", pytest.param("hip", marks=pytest.mark.gpu)])
+def test_two_rank_bf16_gradient_exchange_is_bounded(where, monkeypatch):
+    """``--grad-exchange-dtype bf16`` (SURVEY 8(e) prices it at half the wire time): every finished range
+    is rounded to bf16 (``s2st_grad_pack_bf16_f32``), summed over the ranks in that type and widened back.  Same scenario as
+    the fp32 test below, against the same single-process oracle: each rank's contribution carries one bf16 rounding (2^-9
+    relative per element): the clipped gradient norm stays within 5e-3, and the parameters after three Adam updates within
+    1.5e-2 of their scale -- measured 6.3e-3 on the emulator (the subsampler's second convolution: Adam divides by sqrt(v),
+    so elements whose gradient is small against its rounding step move by whole learning-rate steps); the fp32 exchange is
+    held to 2e-3 / 1e-3.  fp32 stays the default: it is what the reference exchanges."""
+    monkeypatch.setenv("S2ST_TEST_EXCHANGE", "bf16")
+    _two_rank_vs_oracle(where, gnorm_tol=5e-3, param_tol=1.5e-2)
+
+
+@pytest.mark.parametrize("where", ["emu", pytest.param("hip", marks=pytest.mark.gpu)])
 def test_two_rank_update_equals_single_process(where):
+    _two_rank_vs_oracle(where, gnorm_tol=2e-3, param_tol=1e-3)
+
+
+def _two_rank_vs_oracle(where, gnorm_tol, param_tol):
     """Two processes, three updates (the third with an exhausted shard on rank 1), against the ORACLE's single-process
     update over both batches.  ``emu``: host gradients, emulator build.  ``hip``: both ranks drive the product library on
     the one GPU the test box has -- device gradients, the engine's two streams, the reducer's stream and events, the
@@ -125,10 +144,12 @@ def test_two_rank_update_equals_single_process(where):
                     p.grad.mul_(1.0 / ss)  # world / sum(sample_size) on gradients summed over ranks / world ...
         gn = O.clip_grad_norm_(list(m.parameters()), 0.05)
         opt.step(O.inverse_sqrt_lr(u, 1e-3, 1))
-    assert abs(gnorm - float(gn)) < 2e-3 * float(gn)
-    for n, p in m.named_parameters():
-        ref = p.detach()
-        assert float((torch.from_numpy(params[n]) - ref).abs().max()) < 1e-3 * (float(ref.abs().max()) + 1e-6), n
+    assert abs(gnorm - float(gn)) < gnorm_tol * float(gn), (gnorm, float(gn))
+    worst = max((float((torch.from_numpy(params[n]) - p.detach()).abs().max()) / (float(p.detach().abs().max()) + 1e-6), n)
+                for n, p in m.named_parameters())
+    print(f"[two ranks vs oracle, exchange {os.environ.get('S2ST_TEST_EXCHANGE', 'fp32')}] gnorm {gnorm:.6f} vs {float(gn):.6f}, "
+          f"worst parameter {worst[1]} {worst[0]:.2e}")
+    assert worst[0] < param_tol, worst
 
 
 @pytest.mark.gpu
