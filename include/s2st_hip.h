@@ -88,6 +88,10 @@ typedef struct {
  * fairseq/modules/multihead_attention.py:170-192,332,367, transformer_layer.py:158-162,
  * examples/s2s_trans/models/s2st_transformer.py:135-139,452-455, tacotron2.py:95-126. */
 int s2st_gemm_f32(const s2st_gemm_args* args, void* stream);
+/* the same launch; *tile = 1000 * tile rows + tile columns of the kernel form the launcher picked for a bf16 product (0 for
+ * the fp32-operand path): lets a caller -- the tests, a tuning tool -- see which form ran (128 x 128 / 128 x 64 / 64 x 64
+ * ring or 4-wave forms, the 256 x 256 four-phase form of gemm_bf16_p4.hip) */
+int s2st_gemm_tile_f32(const s2st_gemm_args* args, int32_t* tile, void* stream);
 
 /* Stream-K for the bf16 products launched on `stream` (s2st_gemm_f32 / s2st_gemm_group_f32): with a scratch buffer of
  * s2st_gemm_streamk_scratch_floats() floats bound to the stream (first 4 KiB zero at bind time; NULL unbinds), launches

@@ -46,6 +46,14 @@ int s2st_gemm_f32(const s2st_gemm_args* a, void* stream) {
   return s2st_gemm(*a, (hipStream_t)stream);
 }
 
+int s2st_gemm_tile_f32(const s2st_gemm_args* a, int32_t* tile, void* stream) {
+  if (!a || !tile) return S2ST_ERR_ARG;
+  int t = 0;
+  const int rc = s2st_gemm(*a, (hipStream_t)stream, &t);
+  *tile = t;
+  return rc;
+}
+
 int s2st_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int32_t rows, int32_t cols, float eps, void* stream) {
   return s2st_layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, cols, eps, (hipStream_t)stream);
 }

@@ -1038,6 +1038,36 @@ int w4_pick(const GemmArgs& g, bool dma_ok) {
   return (g.N > 64 && e128 >= e64) ? 128 : 64;
 }
 
+// S2ST_GEMM_P4 (read per call: an A/B switch): 0 = never; -1 (default) = the 256 x 256 four-phase form (gemm_bf16_p4.hip)
+// where p4_pick() says so; 1 = every product it can run.  It can run: both operands K-contiguous with plain row strides,
+// 16-byte aligned, batch 1, no split-K, no masked epilogue.  The pick is a two-line cost model fitted to
+// tools/gemm_p4_bench.py (profiles/r05_gemm_p4_bench.txt, random operands, kernel time from events on the dispatch):
+//   four-phase form : rounds of 256-row tiles over the CUs x (2.0 us per 64-deep K-tile + 7 us of prologue / epilogue)
+//   128-row forms   : ~650 TFLOP/s on products of this size (577 - 693 measured; 870 on 4096^3)
+// It takes 4096^3 (126 vs 159 us: 1.09 PFLOP/s), HuBERT's FFN-in products (9600 x 3072 x 768: 64 vs 78 us; 19200 rows: 119 vs
+// 148) and leaves the K = 512 products of the training step (one round of 8 K-tiles: 21 vs 14 - 19 us) and the short-N
+// ones (768 columns: a third of the CUs) where they were.
+int p4_mode() {
+  const char* ev = getenv("S2ST_GEMM_P4");
+  return ev ? atoi(ev) : -1;
+}
+bool p4_can(const GemmArgs& g, bool dma_ok) {
+  return dma_ok && g.A.kmajor && g.B.kmajor && g.batch == 1 && g.A.sp.per <= 0 && g.B.sp.per <= 0 && !g.ep.mask_y &&
+         !g.ep.colsum && !g.ep.colsum_part;
+}
+bool p4_pick(const GemmArgs& g, bool dma_ok) {
+  const int mode = p4_mode();
+  if (mode == 0 || !p4_can(g, dma_ok)) return false;
+  if (mode >= 1) return true;
+  if (g.M < 512 || g.N < 512 || g.K < 8 * BK) return false;
+  const long tiles = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
+  const long ncu = data_cus();
+  const long rounds = (tiles + ncu - 1) / ncu;
+  const double t_p4 = (double)rounds * (2.0 * ((g.K + BK - 1) / BK) + 7.0);          // us
+  const double t_ring = 2.0 * g.M * (double)g.N * g.K / 650e6;                        // us at 650 TFLOP/s
+  return t_p4 < 0.92 * t_ring;
+}
+
 template <int BN, int BM = 128>
 void add_to_group(GemmGroup& grp, GemmArgs g) {
   g.splitk = 1;
@@ -1144,6 +1174,7 @@ int s2st_gemm_bf16_preload(hipStream_t st) {
     { GemmGroup g0 = grp; g0.total = 0; g0.n = 1; rc |= launch_dma_group<128, 128, 4, 8, true>(g0, st); }
   }
   rc |= s2st_gemm_bf16_w4_preload(st);
+  rc |= s2st_gemm_bf16_p4_preload(st);
   return rc || hipGetLastError() != hipSuccess ? -1 : 0;
 }
 
@@ -1177,7 +1208,8 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
     const char* force = getenv("S2ST_GEMM_TILE");  // (read per call: the tests switch it)
     if (force && sscanf(force, "%dx%d", &bm, &bn) != 2) { bm = 64; bn = 64; }
   }
-  if (bm == 256 && !(kExperimental && vec && dma_layout_ok(g) && g.batch == 1)) { bm = 128; bn = 128; }  // 256-row tiles: ring kernels of experimental builds only
+  const bool forced_p4 = vec && bm == 256 && bn == 256;  // S2ST_GEMM_TILE=256x256: the four-phase form where it can run
+  if (bm == 256 && !forced_p4 && !(kExperimental && vec && dma_layout_ok(g) && g.batch == 1)) { bm = 128; bn = 128; }  // 256-row tiles: ring kernels of experimental builds only
   const bool can_split_ = g.ep.accumulate && linear_epi && g.C.p && !g.C.h && !g.ep.bias && !g.ep.resid && g.K >= 8 * BK;
   if (vec && can_split_ && (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch < 256) { bm = 128; bn = 128; }
   // the 4-wave early-release form (w4_pick above): a forced tile is honoured (S2ST_GEMM_W4 >= 1 puts it on that form)
@@ -1190,6 +1222,17 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
       else w4bn = w4_pick(g, true);
       if (w4bn) { bm = 128; bn = w4bn; }
     }
+  }
+  // the 256 x 256 four-phase form (p4_pick above); a forced tile is honoured where the form can run at all
+  bool p4 = false;
+  {
+    static const int use_dma_p4 = getenv("S2ST_GEMM_DMA") ? atoi(getenv("S2ST_GEMM_DMA")) : 1;
+    const bool split_like = can_split_ && (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch < 256;
+    const bool can = vec && use_dma_p4 && !split_like && persist_mode() != 2 && p4_can(g, dma_layout_ok(g));
+    if (getenv("S2ST_GEMM_TILE")) p4 = forced_p4 && can && p4_mode() != 0;
+    else p4 = can && p4_pick(g, true);
+    if (forced_p4 && !p4) { bm = 128; bn = 128; }
+    if (p4) { bm = 256; bn = 256; w4bn = 0; }
   }
   const int tm = (g.M + bm - 1) / bm, tn = (g.N + bn - 1) / bn;
   const long nt = (long)tm * tn * g.batch;
@@ -1243,7 +1286,8 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
     int rc;
     // (one instantiation per tile shape: the interleaved steady state, 8 waves for 128-row tiles; the round-2 A/B forms
     // -- plain loop, 4 waves, 2 / 3 / 5 ring stages, 64 x 128 -- were measured then and are no longer built)
-    if (w4bn && g.splitk == 1) rc = s2st_gemm_bf16_w4(g, bm, bn, grid, st);
+    if (p4 && g.splitk == 1) rc = s2st_gemm_bf16_p4(g, grid, st);
+    else if (w4bn && g.splitk == 1) rc = s2st_gemm_bf16_w4(g, bm, bn, grid, st);
     else if (kExperimental && bm == 256 && bn == 128) { if constexpr (kExperimental) rc = launch_dma<256, 128, 3, 8>(g, grid, st); else rc = -1; }
     else if (bm == 128 && bn == 128) rc = launch_dma<128, 128, 4, 8, true>(g, grid, st);
     else if (bm == 128) rc = launch_dma<128, 64, 4, 8, true>(g, grid, st);

@@ -24,6 +24,12 @@ __device__ __forceinline__ s16x4 lds_read_tr16_raw(const unsigned char* p) {
 __device__ __forceinline__ void lds_raw_wait() { asm volatile("s_waitcnt lgkmcnt(0)"); }
 __device__ __forceinline__ void lds_raw_fence(s16x4& x) { asm volatile("" : "+v"(x)); }
 
+// Opaque copies: the value is unchanged, but the compiler may not look through the statement -- work that depends on it
+// cannot be hoisted above it (gemm_bf16_p4.hip pins epilogue address arithmetic behind its K-loop and keeps loop-invariant
+// DMA row addresses from being materialised in registers the accumulators need).
+__device__ __forceinline__ void opaque_v(int& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void opaque_s(int& x) { asm volatile("" : "+s"(x)); }
+
 // v_permlane16_swap_b32 (gfx950): the odd 16-lane rows of `a` trade places with the even rows of `b` --
 //   a' = {a row 0, b row 0, a row 2, b row 2},  b' = {a row 1, b row 1, a row 3, b row 3}
 // (lane map checked on hardware: tools/ubench/permlane16_swap.hip).  One VALU instruction, no LDS crossbar.

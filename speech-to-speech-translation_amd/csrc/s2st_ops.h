@@ -88,6 +88,9 @@ int s2st_gemm_skinny(const float* A, long lda, const bf16raw* W, long ldw, float
 int s2st_gemm_bf16_w4(const GemmArgs& g, int bm, int bn, dim3 grid, hipStream_t st);
 int s2st_gemm_bf16_w4_group(const GemmGroup& grp, hipStream_t st);
 int s2st_gemm_bf16_w4_preload(hipStream_t st);
+// 256 x 256 four-phase form (gemm_bf16_p4.hip): both operands K-contiguous, chosen by p4_pick() in gemm_bf16.hip
+int s2st_gemm_bf16_p4(const GemmArgs& g, dim3 grid, hipStream_t st);
+int s2st_gemm_bf16_p4_preload(hipStream_t st);
 int s2st_gemm_bf16_preload(hipStream_t st);  // load every instantiation (empty launches)  // gemm_bf16.hip (both operands bf16)
 void s2st_profile_enable_impl(int on);                 // per-dispatch timing registry (s2st_prof.h, gemm.hip)
 long s2st_profile_report_impl(char* out, long cap, int mode = 0);

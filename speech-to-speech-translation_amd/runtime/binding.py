@@ -111,7 +111,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
          c_ld=None, c_per=0, c_bs=0, c_zo=0, c_zi=0,
          batch=1, zdiv=1, alpha=1.0, bias=None, act=0, drop_p=0.0, seed=0, resid=None,
          accumulate=False, precise=False, a_off=0, b_off=0, c_off=0, c_bf16=None, ws=None,
-         mask_y=None, mask_scale=1.0, colsum=None):
+         mask_y=None, mask_scale=1.0, colsum=None, return_tile=False):
     """Raw GEMM entry (s2st_gemm_f32). Offsets are in elements.  A and B are both fp32 or both
     torch.bfloat16 tensors; ``Cout`` (fp32) may be None when only ``c_bf16`` is wanted."""
     require_device(A)
@@ -151,6 +151,10 @@ def _gemm_bf16(A, B, Cout, M, N, K, kw):
     g.M, g.N, g.K, g.batch, g.zdiv, g.precise = M, N, K, kw["batch"], kw["zdiv"], 0
     if kw["ws"] is not None:
         g.ws, g.ws_floats = kw["ws"].data_ptr(), kw["ws"].numel()
+    if kw.get("return_tile"):
+        t = C.c_int32(0)
+        check(lib().s2st_gemm_tile_f32(C.byref(g), C.byref(t), C.c_void_p(stream_ptr())), "s2st_gemm_tile_f32")
+        return (t.value // 1000, t.value % 1000)
     check(lib().s2st_gemm_f32(C.byref(g), C.c_void_p(stream_ptr())), "s2st_gemm_f32")
 
 

@@ -3,6 +3,8 @@
 static inline s16x4 lds_read_tr16_raw(const unsigned char* p) { return lds_read_tr16(p); }
 static inline void lds_raw_wait() {}
 static inline void lds_raw_fence(s16x4&) {}
+static inline void opaque_v(int&) {}
+static inline void opaque_s(int&) {}
 static inline void lane16_swap(unsigned& a, unsigned& b) {
   const int l = emu_lane();
   const unsigned pa = emu_shfl_idx(a, l ^ 16), pb = emu_shfl_idx(b, l ^ 16);

@@ -432,6 +432,60 @@ def test_bf16_w4_early_release_kernel(backend, monkeypatch, akm, bkm, K, tile):
     assert torch.equal(C3, C)
 
 
+@pytest.mark.parametrize("K", [64, 200, 512, 776])
+def test_bf16_p4_four_phase_kernel(backend, monkeypatch, K):
+    """The 256 x 256 four-phase form (gemm_bf16_p4.hip; forced by S2ST_GEMM_TILE=256x256): K = 64 is a single K-tile (no
+    second buffer), K = 200 / 776 end in a K tail (an even and an odd number of K-tiles: both buffers hold the tail once), K =
+    512 is the steady state; ragged M and N (partial tiles on both edges); epilogue variants with both output copies;
+    bit-equal to the 8-wave ring kernel (same products, same summation order over K); falls back to the 128-row forms for
+    operands it cannot take (a rows-contiguous B) and when switched off."""
+    monkeypatch.setenv("S2ST_GEMM_PERSIST", "0")
+    monkeypatch.setenv("S2ST_GEMM_TILE", "256x256")
+    M, N = (300, 520) if backend.kind == "emu" else (4584, 1544)
+    g = torch.Generator().manual_seed(K)
+    A, B = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g))
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    Am, a_ld = _pad_cols(A)
+    Bm, b_ld = _pad_cols(B)
+    d = backend.device
+    R = A.double() @ B.double().t()
+    C = torch.full((M, N), 7.0, device=d)
+    Ch = torch.zeros(M, N, dtype=torch.bfloat16, device=d)
+    tile = backend.bd.gemm(Am.to(d), Bm.to(d), C, M, N, K, a_kmajor=True, b_kmajor=True, a_ld=a_ld, b_ld=b_ld, c_bf16=Ch,
+                           return_tile=True)
+    backend.sync()
+    assert tile == (256, 256), tile
+    assert _relerr(C, R) < 2e-6
+    assert torch.equal(Ch.cpu(), C.cpu().to(torch.bfloat16))
+    C2 = torch.zeros(M, N, device=d)
+    backend.bd.gemm(Am.to(d), Bm.to(d), C2, M, N, K, a_kmajor=True, b_kmajor=True, a_ld=a_ld, b_ld=b_ld, alpha=0.5,
+                    bias=bias.to(d), act=1, resid=res.to(d))
+    backend.sync()
+    assert _relerr(C2, torch.relu(0.5 * R + bias.double()) + res.double()) < 2e-6
+    # bf16-only output with dropout (the FFN's hidden activation): the mask is the one the 128-row forms apply
+    H1 = torch.zeros(M, N, dtype=torch.bfloat16, device=d)
+    backend.bd.gemm(Am.to(d), Bm.to(d), None, M, N, K, a_kmajor=True, b_kmajor=True, a_ld=a_ld, b_ld=b_ld, bias=bias.to(d), act=1,
+                    drop_p=0.25, seed=77, c_bf16=H1)
+    monkeypatch.setenv("S2ST_GEMM_P4", "0")
+    H2 = torch.zeros(M, N, dtype=torch.bfloat16, device=d)
+    tile2 = backend.bd.gemm(Am.to(d), Bm.to(d), None, M, N, K, a_kmajor=True, b_kmajor=True, a_ld=a_ld, b_ld=b_ld, bias=bias.to(d),
+                            act=1, drop_p=0.25, seed=77, c_bf16=H2, return_tile=True)
+    C3 = torch.zeros(M, N, device=d)
+    backend.bd.gemm(Am.to(d), Bm.to(d), C3, M, N, K, a_kmajor=True, b_kmajor=True, a_ld=a_ld, b_ld=b_ld)
+    backend.sync()
+    assert tile2 != (256, 256)
+    assert torch.equal(H1, H2) and float((H1.float() == 0).float().mean()) > 0.3
+    assert torch.equal(C3, C)
+    monkeypatch.delenv("S2ST_GEMM_P4")
+    # a rows-contiguous B: not this form's
+    Bt = B.t().contiguous()
+    Btm, bt_ld = _pad_cols(Bt)
+    C4 = torch.zeros(M, N, device=d)
+    tile4 = backend.bd.gemm(Am.to(d), Btm.to(d), C4, M, N, K, a_kmajor=True, b_kmajor=False, a_ld=a_ld, b_ld=bt_ld, return_tile=True)
+    backend.sync()
+    assert tile4 != (256, 256) and torch.equal(C4, C)
+
+
 @pytest.mark.parametrize("tile", [128, 256, "oneshot", "w4"])
 def test_bf16_group_of_weight_gradients(backend, monkeypatch, tile):
     """s2st_gemm_group_f32: a layer's weight-gradient products dW_i += dY_i^T X_i (different shapes, K = tokens, one with
