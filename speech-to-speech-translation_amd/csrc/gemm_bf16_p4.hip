@@ -133,41 +133,55 @@ __device__ __forceinline__ void gemm_p4_tile(const GemmArgs& g, int id, const in
 #define P4_READ_A(S, R0) _Pragma("unroll") for (int i = 0; i < 4; ++i) a[S][i] = LA::frag(aimg, arow + (R0) + i * 16, S, lane);
 #define P4_READ_B(S, C0) _Pragma("unroll") for (int j = 0; j < 2; ++j) b[S][j] = LB::frag(bimg, bcol + (C0) + j * 16, S, lane);
 #define P4_FENCE() __builtin_amdgcn_sched_barrier(0)
+    // counted LDS waits (reads return in order): N = the reads issued AFTER the ones the next MFMA group consumes.  hipcc
+    // waits lgkmcnt(0) at these points -- i.e. also for the reads it has just issued for the group after next, whose latency
+    // the 8 MFMAs in between are there to cover
+#define P4_LGKM(N) __builtin_amdgcn_s_waitcnt(0xc07f | ((N) << 8))
     // ---- quadrant (m-half 0, n-half 0) + the A half of the next K-tile's DMA -----------------------------------------
     P4_READ_B(0, 0) P4_READ_A(0, 0) P4_READ_B(1, 0) P4_READ_A(1, 0)
     if (more) issue_a(nxt, kn);
     P4_FENCE();
+    P4_LGKM(6);
     P4_MFMA8(0, 0, 0)
     P4_FENCE();
     P4_READ_B(0, 32)  // (n-half 1, k-half 0) into the registers k-half 0 just released
     P4_FENCE();
+    P4_LGKM(2);
     P4_MFMA8(1, 0, 0)
     P4_FENCE();
     P4_READ_B(1, 32)
     // ---- quadrant (0, 1) + the B half of the next K-tile's DMA -----------------------------------------------------
     if (more) issue_b(nxt, kn);
     P4_FENCE();
+    P4_LGKM(2);
     P4_MFMA8(0, 0, 2)
     P4_FENCE();
     P4_READ_A(0, 64)  // (m-half 1, k-half 0)
     P4_FENCE();
+    P4_LGKM(4);
     P4_MFMA8(1, 0, 2)
     P4_FENCE();
     P4_READ_A(1, 64)
     P4_FENCE();
     // ---- quadrant (1, 1) ---------------------------------------------------------------------------------------------
+    P4_LGKM(4);
     P4_MFMA8(0, 4, 2)
     P4_FENCE();
     P4_READ_B(0, 0)  // back to n-half 0
     P4_FENCE();
+    P4_LGKM(2);
     P4_MFMA8(1, 4, 2)
     P4_FENCE();
     P4_READ_B(1, 0)
     P4_FENCE();
     // ---- quadrant (1, 0) ---------------------------------------------------------------------------------------------
+    P4_LGKM(2);
     P4_MFMA8(0, 4, 0)
+    P4_FENCE();
+    P4_LGKM(0);
     P4_MFMA8(1, 4, 0)
     P4_FENCE();
+#undef P4_LGKM
 #undef P4_MFMA8
 #undef P4_READ_A
 #undef P4_READ_B
