@@ -254,9 +254,9 @@ def infer_main(args):
     # batch's vocoder is waited for inside the timed region.
     DEFER = os.environ.get("S2ST_DEFER_VOCODER", "1") != "0"
 
-    # S2ST_DECODE_CHAINS=2 (default): consecutive batches are decoded two at a time (generate_two: the second on a twin
-    # engine and a second stream, the step loops alternated) -- one batch's decoding steps leave most of the chip idle, the
-    # next batch's do not depend on them.  Same hypotheses as one batch after the other (tests/test_inference.py).
+    # S2ST_DECODE_CHAINS=<n> (default 2): consecutive batches are decoded n at a time (generate_many: batch k > 0 on a twin
+    # engine and its own stream, the step loops alternated) -- one batch's decoding steps leave most of the chip idle, the
+    # next batches' do not depend on them.  Same hypotheses as one batch after the other (tests/test_inference.py).
     CHAINS = int(os.environ.get("S2ST_DECODE_CHAINS", "2"))
 
     def run(gen_list, n_steps, first=0):
@@ -273,10 +273,12 @@ def infer_main(args):
         i = first
         while i < first + n_steps:
             k = i % len(samples)
-            if CHAINS >= 2 and i + 1 < first + n_steps and gen_list[k] is gen_list[(i + 1) % len(samples)]:
-                k2 = (i + 1) % len(samples)
-                fins = list(gen_list[k].generate_two(model, samples[k], samples[k2], defer_vocoder=DEFER))
-                i += 2
+            nc = min(CHAINS, first + n_steps - i)
+            while nc >= 2 and not all(gen_list[(i + q) % len(samples)] is gen_list[k] for q in range(nc)):
+                nc -= 1
+            if nc >= 2:
+                fins = list(gen_list[k].generate_many(model, [samples[(i + q) % len(samples)] for q in range(nc)], defer_vocoder=DEFER))
+                i += nc
             else:
                 fins = [gen_list[k].generate(model, samples[k], defer_vocoder=DEFER)]
                 i += 1

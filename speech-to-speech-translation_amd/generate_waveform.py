@@ -214,8 +214,7 @@ def main(argv: Optional[List[str]] = None, device: Optional[torch.device] = None
     defer = device.type == "cuda" and os.environ.get("S2ST_DEFER_VOCODER", "1") != "0"
     # ... and two batches are DECODED at once (generate_two: the second on a twin engine and a second stream) where the
     # generator has that form: the decoding steps of one batch leave most of the chip idle (S2ST_DECODE_CHAINS=1: one by one)
-    chains = 2 if (defer and not mtl and hasattr(generator, "generate_two")
-                   and os.environ.get("S2ST_DECODE_CHAINS", "2") != "1") else 1
+    chains = max(1, int(os.environ.get("S2ST_DECODE_CHAINS", "2"))) if (defer and not mtl and hasattr(generator, "generate_many")) else 1
 
     def groups():
         buf, n = [], 0
@@ -237,8 +236,8 @@ def main(argv: Optional[List[str]] = None, device: Optional[torch.device] = None
     t_all = time.perf_counter()
     for group in groups():
         t0 = time.perf_counter()
-        if len(group) == 2:
-            hyps = list(generator.generate_two(model, group[0], group[1], has_targ=args.dump_target, defer_vocoder=defer))
+        if len(group) >= 2:
+            hyps = list(generator.generate_many(model, group, has_targ=args.dump_target, defer_vocoder=defer))
         elif mtl:  # generate_waveform_mtl.py:195
             hyps = [generator.generate(model, group[0], has_targ=args.dump_target and decode_mel,
                                        decode_source_text=decode_src, decode_target_mel=decode_mel, defer_vocoder=defer)]

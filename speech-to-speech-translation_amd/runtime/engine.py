@@ -231,10 +231,14 @@ class Engine:
 
     def inference_twin(self) -> "Engine":
         """A second engine over the same weights (created once, kept): for decoding two batches as two interleaved chains."""
-        tw = self.__dict__.get("_twin")
-        if tw is None:
-            tw = self._twin = Engine(self.args, self.device, precise=bool(self.cfg.precise), share_with=self)
-        return tw
+        return self.inference_twins(1)[0]
+
+    def inference_twins(self, n: int) -> List["Engine"]:
+        """``n`` further engines over the same weights (created once, kept): one per additional decode chain."""
+        tws = self.__dict__.setdefault("_twins", [])
+        while len(tws) < n:
+            tws.append(Engine(self.args, self.device, precise=bool(self.cfg.precise), share_with=self))
+        return tws[:n]
 
     def __del__(self):
         try:

@@ -130,28 +130,41 @@ class AutoRegressiveSpeechGenerator(SpeechGenerator):
 
     @torch.no_grad()
     def generate_two(self, model, sample_a, sample_b, has_targ: bool = False, **kwargs):
-        """Two batches decoded AT ONCE: the decoding steps of one batch are thousands of small dependent launches that leave
-        most of the chip idle, and the other batch's steps do not depend on them.  Batch b runs on a second engine object
-        over the same weights (``Engine.inference_twin``: own caches, workspace, bf16 copies) and a second stream; the host
-        alternates the two step loops.  Results and their order are those of ``generate(sample_a)`` followed by
-        ``generate(sample_b)``: numpy's phase stream is consumed in that order (batch b's run-ahead draws assume batch a
-        uses all of its upper bound and are discarded otherwise).  Returns the two hypothesis lists (``PendingHypos``)."""
+        """``generate_many`` for two batches (round 4's entry point)."""
+        return tuple(self.generate_many(model, [sample_a, sample_b], has_targ, **kwargs))
+
+    @torch.no_grad()
+    def generate_many(self, model, samples, has_targ: bool = False, **kwargs):
+        """Several batches decoded AT ONCE (round 4: two; round 5: any number of chains): the decoding steps of one batch are
+        thousands of small dependent launches that leave most of the chip idle, and the other batches' steps do not depend on
+        them.  Batch k > 0 runs on its own engine object over the same weights (``Engine.inference_twins``: own caches,
+        workspace, bf16 copies) and its own stream; the host alternates the step loops.  Results and their order are those
+        of ``generate`` called on the batches one after the other: a batch's post-processing -- its vocoder's draws from
+        numpy's phase stream -- is held until the batch before it has done its own, and its run-ahead phase stream starts
+        from the state the earlier batch's draws REALLY leave numpy in (vocoder._HostMTStream).  Returns the hypothesis lists
+        (``PendingHypos``) in batch order."""
         model.eval()
+        samples = list(samples)
+        n = len(samples)
         dev = model.engine.device
-        if dev.type != "cuda" or getattr(model, "hubert", None) is not None:
-            # (no second stream; or a frozen front end whose one workspace the two chains would share -- checked BEFORE the
-            # twin engine, with its own bf16 arena, is built: ADVICE r4)
-            return self.generate(model, sample_a, has_targ, **kwargs), self.generate(model, sample_b, has_targ, **kwargs)
-        engs = (model.engine, model.engine.inference_twin())
-        if self.__dict__.get("_chain_stream") is None:
-            self._chain_stream = torch.cuda.Stream(device=dev)
+        if n == 1 or dev.type != "cuda" or getattr(model, "hubert", None) is not None:
+            # (no second stream; or a frozen front end whose one workspace the chains would share -- checked BEFORE the
+            # twin engines, each with its own bf16 arena, are built: ADVICE r4)
+            return [self.generate(model, s, has_targ, **kwargs) for s in samples]
+        engs = [model.engine] + model.engine.inference_twins(n - 1)
+        cs = self.__dict__.setdefault("_chain_streams", [])
+        while len(cs) < n - 1:
+            cs.append(torch.cuda.Stream(device=dev))
         cur = torch.cuda.current_stream()
-        streams = (cur, self._chain_stream)
-        self._chain_stream.wait_stream(cur)
+        streams = [cur] + cs[:n - 1]
+        for st in streams[1:]:
+            st.wait_stream(cur)
         self.defer_vocoder = bool(kwargs.get("defer_vocoder", False))
+        if self.vocoder is not None and hasattr(self.vocoder, "set_inflight"):
+            self.vocoder.set_inflight(n)  # (that many run-ahead phase streams may be pending at once)
         runs = []
         try:
-            for eng, st, sample in zip(engs, streams, (sample_a, sample_b)):
+            for eng, st, sample in zip(engs, streams, samples):
                 with torch.cuda.stream(st):
                     ni = sample["net_input"]
                     if self.input_text != bool(eng.cfg.text_input):
@@ -164,32 +177,34 @@ class AutoRegressiveSpeechGenerator(SpeechGenerator):
                     bsz = src.shape[0]
                     eng.decode_begin(src, src_lens, self.max_iter, speaker=sample.get("speaker"))
                     fin = PendingHypos(dict() for _ in range(bsz))
-                    runs.append([self._decode_mel_steps(model, sample, bsz, fin, eng), st, fin, sample, bsz, True])
-            alive, held_b = 2, False
+                    # [generator, stream, hypotheses, sample, batch size, alive, held at "post"]
+                    runs.append([self._decode_mel_steps(model, sample, bsz, fin, eng), st, fin, sample, bsz, True, False])
+            alive = n
             while alive:
-                for r in runs:
+                for k, r in enumerate(runs):
                     if not r[5]:
                         continue
-                    if r is runs[1] and held_b:
-                        if runs[0][5]:
-                            continue  # batch b's post-processing (its phase draws) comes after batch a's
-                        held_b = False
+                    if r[6]:
+                        if runs[k - 1][5]:
+                            continue  # this batch's post-processing (its phase draws) comes after the previous batch's
+                        r[6] = False
                     with torch.cuda.stream(r[1]):
                         try:
-                            if next(r[0]) == "post" and r is runs[1]:
-                                held_b = True
+                            if next(r[0]) == "post" and k > 0:
+                                r[6] = True
                         except StopIteration:
                             r[5] = False
                             alive -= 1
                             if has_targ:
                                 self._add_targets(model, r[3], r[4], r[2])
-            # the caller's stream takes in what the second chain produced
-            ev = torch.cuda.Event()
-            ev.record(self._chain_stream)
-            runs[1][2]._events = tuple(runs[1][2]._events) + (ev,)
+            # the caller's stream takes in what the other chains produced
+            for r in runs[1:]:
+                ev = torch.cuda.Event()
+                ev.record(r[1])
+                r[2]._events = tuple(r[2]._events) + (ev,)
         finally:
             self.defer_vocoder = False
-        return runs[0][2], runs[1][2]
+        return [r[2] for r in runs]
 
     def _decode_mel(self, model, sample, bsz: int, finalized: List[Dict]) -> None:
         """The AR loop + post-processing of speech_generator_for_s2st.py:70-122 over the caches ``decode_begin`` filled."""

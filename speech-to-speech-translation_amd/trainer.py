@@ -40,18 +40,7 @@ class Trainer:
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self._sumsq_nparts = int(bd._bind("s2st_sumsq_parts_count")(self.engine.n_params))
-        # (+ 64 slots per backward segment: the per-segment form below rounds every range's count up on its own)
-        self.sumsq_parts = torch.zeros(max(self._sumsq_nparts, 1) + 64 * 64, dtype=torch.float32, device=dev)
-        # Gradient norm by backward segment (round 5, single GPU): the sum-of-squares partials of a segment's arena range
-        # are taken on the engine's second stream as soon as the segment's gradients are final, beside the rest of the
-        # backward, instead of as one 292 MB pass between the backward and the optimizer kernel (58 us on the critical
-        # path).  The optimizer kernel folds all partials in index order as before: the norm -- hence the clip coefficient
-        # and the update -- repeats bit for bit.  S2ST_NORM_BY_SEGMENT=0: the single pass (A/B switch).  With N > 1 the
-        # norm is that of the all-reduced gradients and stays one pass behind the exchange.
-        import os as _os
-        self._norm_by_segment = _os.environ.get("S2ST_NORM_BY_SEGMENT", "1") != "0"
-        self._side = self.engine.side_stream()
-        self._seg_parts = {}  # (lo, hi) -> partial count of that range
+        self.sumsq_parts = torch.zeros(max(self._sumsq_nparts, 1), dtype=torch.float32, device=dev)
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.gmul_dev = torch.ones(1, dtype=torch.float32, device=dev)
         self.skipped = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -103,10 +92,6 @@ class Trainer:
         sample_size = 0
         logs = []
         hooks = self.reducer.on_segment if self.reducer is not None else None
-        norm_state = None
-        if hooks is None and self._norm_by_segment and fast:
-            norm_state = {"off": 0, "next_hi": eng.n_params, "ok": True}
-            hooks = lambda i, lo, hi: self._norm_segment(norm_state, lo, hi)  # noqa: E731
         for i, sample in enumerate(samples):
             last = i == len(samples) - 1
             seg_hooks = hooks if last else None  # like no_sync(): reduce once, on the last micro-batch
@@ -147,13 +132,7 @@ class Trainer:
         # gradient norm: per-block partial sums folded in index order inside the Adam kernel (no zeroing pass, no atomics:
         # the clip coefficient, hence the whole update, repeats bit for bit)
         nparts = self._sumsq_nparts
-        if norm_state is not None and norm_state["ok"] and norm_state["next_hi"] == 0:
-            # every range of the arena was covered, back to front, by the last micro-batch's segments
-            nparts = norm_state["off"]
-            if self._side is not None:
-                torch.cuda.current_stream().wait_stream(self._side)
-        else:
-            bd.call("s2st_sumsq_parts_f32", eng.grads, eng.n_params, self.sumsq_parts)
+        bd.call("s2st_sumsq_parts_f32", eng.grads, eng.n_params, self.sumsq_parts)
         lr = self.get_lr()
         import os
         if overlap_optimizer:
@@ -170,28 +149,6 @@ class Trainer:
         self.num_updates += 1
         self.model.set_num_updates(self.num_updates)
         return {"logs": logs, "sample_size": sample_size, "lr": lr, "gnorm": self.gnorm}
-
-    def _norm_segment(self, st, lo: int, hi: int):
-        """Engine callback after backward segment i: gradients in [lo, hi) are final -- their sum-of-squares partials go
-        to the next free slots of ``sumsq_parts``, on the second stream behind everything enqueued so far."""
-        if not st["ok"] or hi != st["next_hi"] or lo % 4:
-            st["ok"] = False  # (ranges must tile the arena back to front; otherwise the single pass is taken)
-            return
-        cnt = self._seg_parts.get((lo, hi))
-        if cnt is None:
-            cnt = self._seg_parts[(lo, hi)] = int(bd._bind("s2st_sumsq_parts_count")(hi - lo))
-        if st["off"] + cnt > self.sumsq_parts.numel():
-            st["ok"] = False
-            return
-        view, out = self.engine.grads[lo:hi], self.sumsq_parts[st["off"]:st["off"] + cnt]
-        if self._side is not None:
-            self._side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self._side):
-                bd.call("s2st_sumsq_parts_f32", view, hi - lo, out)
-        else:
-            bd.call("s2st_sumsq_parts_f32", view, hi - lo, out)
-        st["off"] += cnt
-        st["next_hi"] = lo
 
     def check_overflow(self):
         """Raise FloatingPointError if any update since the last check met a non-finite gradient norm

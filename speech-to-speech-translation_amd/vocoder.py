@@ -331,6 +331,10 @@ class GriffinLim:
         fn = bd.lib().s2st_gl_fft_supported_i32
         self.use_fft = bool(fn(int(n_fft))) and os.environ.get("S2ST_GL_FFT", "1") != "0"
 
+    def set_inflight(self, n: int):
+        """How many batches may have a run-ahead phase stream pending at once (the generator's decode chains)."""
+        self._inflight = max(2, int(n))
+
     def prefetch_phases(self, n_frames_upper: int):
         """Called by the speech generator BEFORE it decodes (``n_frames_upper``: an upper bound of the frames the batch
         will vocode): with phase_rng="numpy" and the FFT path, numpy's generator is continued while the decoder runs -- by the
@@ -374,10 +378,11 @@ class GriffinLim:
         self._streams.append(obj)
         # at most two batches are in flight; an entry nobody took (its batch failed, or the vocoder was called with explicit
         # angles) is dropped -- after its generator thread has been joined: it may still be filling / uploading its slot
-        for old in self._streams[:-2]:
+        keep = max(2, int(self.__dict__.get("_inflight", 2)))
+        for old in self._streams[:-keep]:
             if isinstance(old, _HostMTStream):
                 old.abandon()
-        del self._streams[:-2]
+        del self._streams[:-keep]
 
     def _ring_buffer(self, n: int):
         """One of two persistent pinned staging buffers for the run-ahead draws, alternating, each guarded by the event of
@@ -385,8 +390,11 @@ class GriffinLim:
         k + 1's generator starts filling)."""
         if self.device.type != "cuda":
             return None
-        ring = self.__dict__.setdefault("_pin_ring", [[None, None, None], [None, None, None]])  # [buffer, upload event, owner]
-        self._ring_i = (self.__dict__.get("_ring_i", -1) + 1) % 2
+        nslots = max(2, int(self.__dict__.get("_inflight", 2)))
+        ring = self.__dict__.setdefault("_pin_ring", [])  # slots of [buffer, upload event, owner]
+        while len(ring) < nslots:
+            ring.append([None, None, None])
+        self._ring_i = (self.__dict__.get("_ring_i", -1) + 1) % nslots
         slot = ring[self._ring_i]
         if slot[2] is not None:  # the stream that last filled the slot: its thread is joined before anything is reused
             slot[2].abandon() if not slot[2].taken.is_set() else slot[2].thread.join()
@@ -645,6 +653,9 @@ class GriffinLimVocoder:
 
     def prefetch_phases(self, n_frames_upper: int):
         self.gl.prefetch_phases(n_frames_upper)
+
+    def set_inflight(self, n: int):
+        self.gl.set_inflight(n)
 
     def batch(self, xs, angles=None):
         """List of [T_u, n_mels] log-mels -> list of [1, N_u] waveforms, all utterances per launch."""

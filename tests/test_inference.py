@@ -884,3 +884,19 @@ def test_two_batches_decoded_at_once_give_the_sequential_results(backend, has_ta
                         assert torch.equal(hx[k], hy[k]), (thr, defer, k)
                     # (the alignment layer's head mean is summed by atomics: last-bit differences between any two runs)
                     assert float((hx["attn"] - hy["attn"]).abs().max()) < 1e-6
+        # round 5: three chains (batch 0 a second time as the third batch) == the three batches one after the other
+        np.random.seed(9)
+        plain3 = [gen.generate(model, s, has_targ=has_targ) for s in (batches[0], batches[1], batches[0])]
+        tail_p = np.random.rand(3)
+        backend.sync()
+        np.random.seed(9)
+        three = gen.generate_many(model, [batches[0], batches[1], batches[0]], has_targ=has_targ, defer_vocoder=True)
+        for h in three:
+            h.wait()
+        tail_t = np.random.rand(3)
+        backend.sync()
+        assert np.array_equal(tail_p, tail_t)
+        for x, y in zip(plain3, three):
+            for hx, hy in zip(x, y):
+                for k in ("feature", "eos_prob", "alignment", "waveform"):
+                    assert torch.equal(hx[k], hy[k]), (thr, "three chains", k)
