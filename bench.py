@@ -570,18 +570,6 @@ def main():
     tasks = importlib.import_module(PKG + ".tasks")
     trainer_mod = importlib.import_module(PKG + ".trainer")
     bd = importlib.import_module(PKG + ".runtime.binding")
-    if os.environ.get("S2ST_MAIN_CU_MASK"):
-        # tuning instrument (tools/cu_partition.sh): the data path on a CU-masked stream (S2ST_SIDE_CU_MASK masks the
-        # engine's second stream; S2ST_DATA_CUS tells the tile picker how many CUs the data path has)
-        import ctypes as _C
-        words = [int(w, 16) for w in os.environ["S2ST_MAIN_CU_MASK"].split(",")]
-        arr = (_C.c_uint32 * len(words))(*words)
-        sp = _C.c_void_p()
-        fn = bd.lib().s2st_stream_create_cu_mask
-        fn.argtypes = [_C.c_void_p, _C.c_int32, _C.POINTER(_C.c_void_p)]
-        bd.check(fn(arr, len(words), _C.byref(sp)), "s2st_stream_create_cu_mask")
-        torch.cuda.set_stream(torch.cuda.ExternalStream(sp.value, device=dev))
-        vlog("data path on a CU-masked stream", os.environ["S2ST_MAIN_CU_MASK"])
     prefetch = importlib.import_module(PKG + ".runtime.prefetch")
 
     a = C_.recipe_args(args.config)  # named configurations live in the package (configs.py)

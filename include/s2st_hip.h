@@ -475,15 +475,9 @@ int s2st_gl_polar_c_f32(const float* mag, const float* ang, const int32_t* tl, f
 /* initial phases (vocoder.py:101-102) from the uniform draws themselves: uniform = the doubles numpy's generator produced, utterance
  * u's [F][T_u] block at uniform + offsets[u]; X = mag * exp(i wrap(2 pi u)).  uniform == NULL: the draws come from the device's
  * counter-based generator (seed): same distribution, not numpy's stream. */
-/* numpy's legacy generator (MT19937, np.random.random_sample / rand: one double per two 32-bit outputs) on the device: n
- * doubles continuing from `state` -- S2ST_MT_STATE_WORDS (640) uint32: the 624 key words and the position of
- * np.random.get_state(), then have_carry / carry (0 for a state taken from numpy; set in snapshot records) -- and the state
- * numpy would be left in (same layout) -- what the reference's GriffinLim draws on the host (vocoder.py:101-102), draw
- * for draw.  out == NULL: only the successor state.  snaps (optional, max_snaps records of 640 words): a resumable record
- * after every snap_every regenerated 624-word blocks, for callers that generate ahead of knowing how many draws they need. */
-#define S2ST_MT_STATE_WORDS 640
-int s2st_mt19937_doubles_f64(const uint32_t* state, int64_t n, double* out, uint32_t* state_out, int32_t snap_every, uint32_t* snaps, int32_t max_snaps, void* stream);
-/* The same stream on the HOST, several threads (csrc/mt19937_host.cpp): `state` = 624 key words + position (625 uint32),
+/* numpy's legacy generator (MT19937, np.random.random_sample / rand: one double per two 32-bit outputs) -- what the
+ * reference's GriffinLim draws on the host (vocoder.py:101-102), draw for draw --
+ * on the HOST, several threads (csrc/mt19937_host.cpp): `state` = 624 key words + position (625 uint32),
  * out = n doubles in host memory (NULL: states only), bounds_out (optional) = (threads + 1) records of 625 words: the state
  * in front of double n * t / threads, t = 0 .. threads.  Thread t reaches its share by running the recurrence alone. No GPU
  * work: replaces the host-side np.random.rand of vocoder.py:101-102 (0.37 G draws/s on one core) draw for draw. */
@@ -592,13 +586,6 @@ int s2st_version(void);
 int s2st_experimental_build(void);
 /* number of HIP devices visible (0 = none: every compute entry point then fails) */
 int s2st_device_count(void);
-/* A stream restricted to the CUs named by `words` (bit i of word j = CU 32 j + i, hipExtStreamCreateWithCUMask); the
- * caller drives the engine on it to keep the data path and the engine's second stream (S2ST_SIDE_CU_MASK) on disjoint
- * parts of the chip.  A tuning instrument (tools/cu_partition.sh): the reference has no counterpart.  *out owns the
- * stream until s2st_stream_destroy. */
-int s2st_stream_create_cu_mask(const uint32_t* words, int32_t n_words, void** out);
-int s2st_stream_destroy(void* stream);
-
 #ifdef __cplusplus
 }
 #endif

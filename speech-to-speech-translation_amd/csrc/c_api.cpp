@@ -20,19 +20,6 @@ int s2st_device_count(void) {
   return n;
 }
 
-int s2st_stream_create_cu_mask(const uint32_t* words, int32_t n_words, void** out) {
-  if (!words || n_words <= 0 || !out) return S2ST_ERR_ARG;
-  hipStream_t st = nullptr;
-  if (hipExtStreamCreateWithCUMask(&st, (unsigned)n_words, words) != hipSuccess) return S2ST_ERR_LAUNCH;
-  *out = (void*)st;
-  return 0;
-}
-
-int s2st_stream_destroy(void* stream) {
-  if (!stream) return S2ST_ERR_ARG;
-  return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
-}
-
 int s2st_grad_pack_bf16_f32(const float* g, uint16_t* out, int64_t n, void* stream) {
   return s2st_grad_pack_bf16(g, out, (long)n, (hipStream_t)stream);
 }
@@ -222,9 +209,6 @@ int s2st_decode_stop_update_i32(const float* eos_prob, float thr, int32_t step, 
 int s2st_gl_fft_supported_i32(int32_t n_fft) { return s2st_gl_fft_supported(n_fft) ? 1 : 0; }
 int s2st_gl_polar_c_f32(const float* mag, const float* ang, const int32_t* tl, float* X, int32_t U, int32_t F, int32_t Tmax, void* stream) {
   return s2st_gl_polar_c(mag, ang, tl, X, U, F, Tmax, (hipStream_t)stream);
-}
-int s2st_mt19937_doubles_f64(const uint32_t* state, int64_t n, double* out, uint32_t* state_out, int32_t snap_every, uint32_t* snaps, int32_t max_snaps, void* stream) {
-  return s2st_mt19937_doubles(state, n, out, state_out, snap_every, snaps, max_snaps, (hipStream_t)stream);
 }
 int s2st_exp_inplace_f32(float* x, int64_t n, void* stream) { return s2st_exp_inplace(x, n, (hipStream_t)stream); }
 int s2st_gl_polar_u_f32(const float* mag, const double* uniform, const int64_t* offsets, const int32_t* tl, uint64_t seed, float* X, int32_t U, int32_t F, int32_t Tmax, void* stream) {

@@ -142,13 +142,10 @@ struct s2st_engine {
     return dec_st.base + (long)c.dec_layers * 2 * dec_st.B * dec_st.maxT * c.dec_dim + (long)l * dec_st.B * dec_st.E * 2 * c.dec_dim;
   }
   bool conv_tail_on_main = true;  // S2ST_CONV_TAIL_MAIN=0 (A/B switch): the first convolution's weight gradient on the second stream too
-  bool tail_share = false;   // set while the last tape closures run (see linear()'s weight-gradient GEMM)
-  unsigned tail_count = 0, wgrad_count = 0;
+  unsigned wgrad_count = 0;
   int wgrad_main_every = 0;  // S2ST_WGRAD_MAIN_EVERY=<n>: every n-th weight-gradient GEMM stays on the data-path stream
                              // (0 = none).  Balances the two streams; measured on the bench workload: n = 3 .. 16,
                              // best 7 (11.15 -> 10.89 ms/step together with the attention-backward bf16 gradients)
-  int tail_closures = 0;     // S2ST_TAIL_SHARE=<n>: how many closures from the end share weight gradients; measured
-                             // (n = 12 / 24 / 48) within run-to-run noise of the ~0.19 ms tail wait, so off
   bool use_ln_skinny = true; // S2ST_NO_LN_SKINNY=1 (A/B switch): separate layer-norm kernels in the AR decoding steps
   bool use_skinny = true;    // S2ST_NO_SKINNY=1 (A/B switch): tiled GEMMs for the AR decoding steps too
   bool skip_resid_h = true;  // S2ST_RESID_H=1 (A/B switch): also write bf16 copies of residual-stream outputs
@@ -563,27 +560,14 @@ struct s2st_engine {
   // ------------------------------------------------------------------------------------
   // weight-gradient GEMMs waiting for their group launch (S2ST_NO_WGRAD_GROUP=1: A/B switch, one launch each)
   bool group_wgrad = true;
-  int wgrad_kchunk = 0;    // S2ST_WGRAD_KCHUNK (see flush_wgrad)
   int group_flush_at = 6;  // S2ST_WGRAD_GROUP=<n>: problems per launch (<= S2ST_GROUP_MAX); measured 2 .. 8 on the bench
                            // workload: 12.25 / 10.99 / 10.56 / 10.44 / 10.46 ms per step for 2 / 3 / 4 / 6 / 8
   std::vector<GemmArgs> pending_wgrad;
-  // S2ST_WGRAD_TILES=<n> (tuning aid, default 0 = off): cut a group when its 128 x 128 tiles would exceed n.  The idea --
-  // six products of an encoder layer and a half are 288 tiles, a full round of the 256 CUs plus a 12 % one; cuts at 256
-  // make every launch one round -- measured SLOWER on the step (8.22 vs 8.11 ms, profiles/r03_c_ab_switches.txt): the
-  // group runs beside the data-path stream, which takes the CUs the short second round leaves free.
-  long pending_tiles = 0;
-  int group_tile_budget = 0;
-  static long wgrad_tiles(const GemmArgs& g) { return (long)((g.M + 127) / 128) * ((g.N + 127) / 128); }
   void push_wgrad(const GemmArgs& g) {
     for (const GemmArgs& p : pending_wgrad)
       if (p.C.p == g.C.p) { flush_wgrad(); break; }  // two sums into one matrix must not share a launch
-    const long t = wgrad_tiles(g);
-    if (group_tile_budget > 0 && !pending_wgrad.empty() && pending_tiles + t > group_tile_budget) flush_wgrad();
     pending_wgrad.push_back(g);
-    pending_tiles += t;
-    if ((int)pending_wgrad.size() >= (group_tile_budget > 0 ? S2ST_GROUP_MAX : group_flush_at) ||
-        (group_tile_budget > 0 && pending_tiles >= group_tile_budget))
-      flush_wgrad();
+    if ((int)pending_wgrad.size() >= group_flush_at) flush_wgrad();
   }
   void flush_wgrad() {
     if (pending_wgrad.empty()) return;
@@ -602,34 +586,9 @@ struct s2st_engine {
 #else
       constexpr bool skip = false;
 #endif
-      if (!skip && wgrad_kchunk > 0) {
-        // S2ST_WGRAD_KCHUNK=<tokens> (round 4): the group as SEVERAL launches over consecutive token ranges, each
-        // accumulating into the same gradient tiles (stream order keeps the sums in a fixed order).  A launch's
-        // workgroups then live K / chunks as long: the data path's kernels, which share the chip with them, find free
-        // CUs sooner -- at the price of one more read-modify-write of the gradient tiles per chunk on the second stream.
-        int kmax = 0;
-        for (const GemmArgs& g : pending_wgrad) kmax = g.K > kmax ? g.K : kmax;
-        const int nch = (kmax + wgrad_kchunk - 1) / wgrad_kchunk;
-        const int step = (((kmax + nch - 1) / nch) + 63) / 64 * 64;  // equal chunks, multiples of the K-step
-        std::vector<GemmArgs> part;
-        for (int k0 = 0; k0 < kmax; k0 += step) {
-          part.clear();
-          for (const GemmArgs& g : pending_wgrad) {
-            if (k0 >= g.K) continue;
-            GemmArgs q = g;
-            q.K = (g.K - k0 < step) ? g.K - k0 : step;
-            // both operands are stored [k][rows] (rows contiguous): K index k0 is k0 rows further down
-            q.A.p = reinterpret_cast<const bf16raw*>(g.A.p) + (long)k0 * g.A.sp.ld;
-            q.B.p = reinterpret_cast<const bf16raw*>(g.B.p) + (long)k0 * g.B.sp.ld;
-            part.push_back(q);
-          }
-          if (!part.empty()) chk(s2st_gemm_bf16_group(part.data(), (int)part.size(), s));
-        }
-      } else
       if (!skip) chk(s2st_gemm_bf16_group(pending_wgrad.data(), (int)pending_wgrad.size(), s));
     }
     pending_wgrad.clear();
-    pending_tiles = 0;
   }
 
   // layer-norm parameter gradients: the backward row kernels leave column-sum partials; one batched fold per backward
@@ -752,9 +711,8 @@ struct s2st_engine {
         g.C = gemm_out(G + w, K);
         g.ep = gemm_epi_default();
         g.ep.accumulate = 1;
-        // weight gradients go to the second stream -- except every other one at the very end of the backward
-        // sweep: nothing is left to overlap them with there, the data path would only wait for the backlog
-        const bool on_main = (tail_share && ((tail_count++) & 1)) || (wgrad_main_every > 0 && (wgrad_count++ % wgrad_main_every) == 0);
+        // weight gradients go to the second stream (S2ST_WGRAD_MAIN_EVERY: a share of them stays on the data path)
+        const bool on_main = wgrad_main_every > 0 && (wgrad_count++ % wgrad_main_every) == 0;
         g.M = N; g.N = K; g.K = M; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
         if (fm && !on_main && group_wgrad && s2st_gemm_group_ok(g)) {
           // a layer's weight-gradient products leave together, as ONE persistent launch with K = tokens unsplit
@@ -1666,7 +1624,6 @@ struct s2st_engine {
   bool use_streamk = getenv("S2ST_GEMM_STREAMK") && atoi(getenv("S2ST_GEMM_STREAMK")) > 0;
   void reset_call() {
     pending_wgrad.clear();
-    pending_tiles = 0;
     pending_lnfold = s2st_lnfold_table{};
     s2st_gemm_streamk_unbind_all();  // the scratch lives in the previous call's workspace
     for (Ten* t : tens) delete t;
@@ -2100,11 +2057,9 @@ struct s2st_engine {
         if (i + 1 == aux_lo_idx && st_ != main_st) { flush_wgrad(); flush_lnfold(); hipEventRecord(ev_auxb_, st_); st_ = main_st; }
         if (i + 1 == aux_wait_idx) wait_traced(main_st, ev_auxb_, "aux decoders' backward (tap gradients)");
       }
-      tail_share = tail_closures > 0 && seg == ns - 1 && i < lo + (size_t)tail_closures && side_ != nullptr;
       tape[i]();
       if (err) break;
     }
-    tail_share = false;
     flush_wgrad();  // the segment's gradients are final once its launches are enqueued
     flush_lnfold();
     if (st_ != main_st) { hipEventRecord(ev_auxb_, st_); st_ = main_st; }
@@ -2146,7 +2101,6 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->use_only_h = !(getenv("S2ST_NO_ONLY_H") && atoi(getenv("S2ST_NO_ONLY_H")) != 0);
   e->hoist_kv = !(getenv("S2ST_NO_KV_HOIST") && atoi(getenv("S2ST_NO_KV_HOIST")) != 0);
   e->stall_trace = getenv("S2ST_STALL_TRACE") && atoi(getenv("S2ST_STALL_TRACE")) != 0;
-  if (getenv("S2ST_TAIL_SHARE")) e->tail_closures = atoi(getenv("S2ST_TAIL_SHARE"));
   if (getenv("S2ST_WGRAD_MAIN_EVERY")) e->wgrad_main_every = atoi(getenv("S2ST_WGRAD_MAIN_EVERY"));
   e->use_ln_skinny = !(getenv("S2ST_NO_LN_SKINNY") && atoi(getenv("S2ST_NO_LN_SKINNY")) != 0);
   e->use_skinny = !(getenv("S2ST_NO_SKINNY") && atoi(getenv("S2ST_NO_SKINNY")) != 0);
@@ -2154,8 +2108,6 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->use_ln_fuse = !(getenv("S2ST_NO_LN_FUSE") && atoi(getenv("S2ST_NO_LN_FUSE")) != 0);
   e->attn_gfuse_mode = getenv("S2ST_ATTN_GFUSE") ? atoi(getenv("S2ST_ATTN_GFUSE")) : 1;
   e->use_attn_gfuse = e->attn_gfuse_mode != 0;
-  if (getenv("S2ST_WGRAD_TILES")) e->group_tile_budget = atoi(getenv("S2ST_WGRAD_TILES"));
-  if (getenv("S2ST_WGRAD_KCHUNK")) e->wgrad_kchunk = atoi(getenv("S2ST_WGRAD_KCHUNK"));
   e->ln_bwd_split = getenv("S2ST_LN_BWD_SPLIT") && atoi(getenv("S2ST_LN_BWD_SPLIT")) != 0;
   if (getenv("S2ST_CONV_TAIL_MAIN")) e->conv_tail_on_main = atoi(getenv("S2ST_CONV_TAIL_MAIN")) != 0;
   e->ordered_sums = !(getenv("S2ST_ORDERED_BIAS_SUMS") && atoi(getenv("S2ST_ORDERED_BIAS_SUMS")) == 0);
@@ -2164,27 +2116,9 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   if (!cfg->precise && !(getenv("S2ST_NO_SIDE_STREAM") && atoi(getenv("S2ST_NO_SIDE_STREAM")))) {
     // the side stream carries weight gradients nobody waits for until the segment ends: lowest queue priority, so that
     // when both queues have workgroups ready the data path (the critical chain of the backward) is dispatched first
-    // (S2ST_SIDE_PRIORITY=0: default priority, the A/B switch)
     int pr_least = 0, pr_greatest = 0;
-    const bool low = !(getenv("S2ST_SIDE_PRIORITY") && atoi(getenv("S2ST_SIDE_PRIORITY")) == 0);
-    if (!low || hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest) != hipSuccess) pr_least = 0;
-    // S2ST_SIDE_CU_MASK="w0,w1,...,w7" (hex words, bit i of word j = CU 32 j + i as hipExtStreamCreateWithCUMask counts
-    // them): the second stream only runs on those CUs -- an experiment of round 4 (keep the
-    // weight-gradient groups off part of the chip so that the data path's kernels do not share their CUs)
-    bool masked = false;
-    if (const char* mk = getenv("S2ST_SIDE_CU_MASK")) {
-      std::vector<unsigned> words;
-      for (const char* p = mk; *p;) {
-        char* end = nullptr;
-        const unsigned long v = strtoul(p, &end, 16);
-        if (end == p) break;
-        words.push_back((unsigned)v);
-        p = *end == ',' ? end + 1 : end;
-      }
-      if (!words.empty() && hipExtStreamCreateWithCUMask(&e->side_, (unsigned)words.size(), words.data()) == hipSuccess) masked = true;
-      else { e->side_ = nullptr; fprintf(stderr, "[s2st] S2ST_SIDE_CU_MASK: masked stream not created, falling back\n"); }
-    }
-    if (!masked && hipStreamCreateWithPriority(&e->side_, hipStreamNonBlocking, pr_least) != hipSuccess) e->side_ = nullptr;
+    if (hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest) != hipSuccess) pr_least = 0;
+    if (hipStreamCreateWithPriority(&e->side_, hipStreamNonBlocking, pr_least) != hipSuccess) e->side_ = nullptr;
     e->overlap_aux = !(getenv("S2ST_NO_AUX_OVERLAP") && atoi(getenv("S2ST_NO_AUX_OVERLAP")) != 0);
     if (e->side_ && hipEventCreateWithFlags(&e->ev_kv_, hipEventDisableTiming) != hipSuccess) e->ev_kv_ = nullptr;
     if (e->side_ && (hipEventCreateWithFlags(&e->ev_fork_, hipEventDisableTiming) != hipSuccess ||

@@ -983,15 +983,8 @@ void mark_fast_epilogue(GemmArgs& g) {
 // with more tiles than CUs the hardware dispatcher back-fills CUs as one-shot workgroups retire, which balances better
 // than a fixed walk of 2.25 tiles per workgroup -- 10.05 vs 10.58 ms per training step, profiles/r02_ab_switches.txt),
 // 2 = every 128-row launch persistent, 3 = grouped launches and single products with more tiles than CUs
-// CUs the data path's single products can count on: the whole chip, or -- S2ST_DATA_CUS=<n>, with the caller's stream
-// restricted by a CU mask (s2st_stream_create_cu_mask) -- that many; the tile choice prices rounds over this number
-int data_cus() {
-  static const int n = [] {
-    const char* ev = getenv("S2ST_DATA_CUS");
-    return ev && atoi(ev) > 0 ? atoi(ev) : 0;
-  }();
-  return n > 0 ? n : num_cus();
-}
+// CUs a single product's tiles are priced over (the tile pickers' round counts)
+int data_cus() { return num_cus(); }
 
 int persist_mode() {
   const char* ev = getenv("S2ST_GEMM_PERSIST");  // read per call: an A/B switch the tests flip

@@ -1163,111 +1163,10 @@ int s2st_gl_polar_c(const float* mag, const float* ang, const int* tl, float* X,
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
-// ------------------------------------------------------------------------------------------------
-// numpy's legacy generator ON THE DEVICE.  The reference draws its initial Griffin-Lim phases from numpy's GLOBAL generator
-// (np.random.rand, vocoder.py:101-102): MT19937 (Matsumoto & Nishimura 1998; numpy/random/mtrand: 624-word state, position),
-// a double per TWO 32-bit outputs: (a >> 5, b >> 6) -> (a * 2^26 + b) / 2^53.  45 M draws per 64 utterances cost the host
-// ~125 ms -- more than the whole decode after this round.  The recurrence is sequential between 624-word blocks but parallel
-// inside one (words 0 .. 226 depend on the old block only, 227 .. 453 on the new 0 .. 226, 454 .. 622 on the new 227 .. 395,
-// word 623 on the new 0 and 396): ONE workgroup regenerates block after block in LDS, tempers and converts, and writes the
-// doubles numpy would have produced, starting from numpy's own state (key + position uploaded by the host) and returning the
-// state numpy would be left in (set back with np.random.set_state): the global stream continues exactly as after the
-// reference's calls.  tests/test_inference.py compares with numpy draw for draw.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned mt_twist(unsigned hi, unsigned lo, unsigned far) {
-  const unsigned y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
-  return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-}
-__device__ __forceinline__ unsigned mt_temper(unsigned y) {
-  y ^= y >> 11;
-  y ^= (y << 7) & 0x9d2c5680u;
-  y ^= (y << 15) & 0xefc60000u;
-  y ^= y >> 18;
-  return y;
-}
-// state: 624 key words + position (0 .. 624) [+ have_carry, carry: a pending first half of a double, when resuming from a
-// snapshot] ; out: n doubles (nullptr: only the successor state is wanted) ; state_out: the state after exactly 2 n outputs.
-// snaps (optional): every snap_every regenerated blocks the run leaves a resumable record (S2ST_MT_SNAP_WORDS words: key,
-// position 0, have_carry, carry) -- a caller that generated AHEAD of knowing how many draws it needs gets the state after
-// any smaller count from the nearest record plus a short output-less run.
-__global__ __launch_bounds__(256) void mt19937_doubles_kernel(const unsigned* __restrict__ state, long n, double* __restrict__ out,
-                                                              unsigned* __restrict__ state_out, int snap_every,
-                                                              unsigned* __restrict__ snaps, int max_snaps) {
-  __shared__ unsigned A[624], B[624], T[624];
-  __shared__ unsigned carry;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 624; i += 256) A[i] = state[i];
-  int pos = (int)state[624];
-  bool have_carry = state[625] != 0;  // (uniform: every thread tracks it)
-  if (tid == 0) carry = state[626];
-  long produced = 0;   // doubles written so far
-  long blocks = 0;     // regenerated blocks so far
-  unsigned* cur = A;
-  unsigned* nxt = B;
-  __syncthreads();
-  while (produced < n) {
-    if (pos >= 624) {  // regenerate: cur -> nxt
-      if (tid < 227) nxt[tid] = mt_twist(cur[tid], cur[tid + 1], cur[tid + 397]);
-      __syncthreads();
-      if (tid < 227) nxt[227 + tid] = mt_twist(cur[227 + tid], cur[228 + tid], nxt[tid]);
-      __syncthreads();
-      if (tid < 169) nxt[454 + tid] = mt_twist(cur[454 + tid], cur[455 + tid], nxt[227 + tid]);
-      __syncthreads();
-      if (tid == 0) nxt[623] = mt_twist(cur[623], nxt[0], nxt[396]);
-      __syncthreads();
-      unsigned* t_ = cur; cur = nxt; nxt = t_;
-      pos = 0;
-      ++blocks;
-      if (snaps && snap_every > 0 && blocks % snap_every == 0 && blocks / snap_every <= max_snaps) {
-        unsigned* sp = snaps + (blocks / snap_every - 1) * S2ST_MT_SNAP_WORDS;
-        for (int i = tid; i < 624; i += 256) sp[i] = cur[i];
-        if (tid == 0) { sp[624] = 0u; sp[625] = have_carry ? 1u : 0u; sp[626] = carry; }
-      }
-    }
-    for (int i = tid; i < 624; i += 256) T[i] = mt_temper(cur[i]);
-    __syncthreads();
-    // words pos .. 623 of this block; a pending first half (carry) pairs with word pos
-    const int start = pos;
-    const long want_words = 2 * (n - produced) - (have_carry ? 1 : 0);  // words still needed from here on
-    const int avail = 624 - start;
-    const int take = (long)avail < want_words ? avail : (int)want_words;  // words consumed from this block
-    int w0 = start;
-    long o0 = produced;
-    if (have_carry && take > 0) {
-      if (tid == 0 && out) out[o0] = ((double)(carry >> 5) * 67108864.0 + (double)(T[w0] >> 6)) / 9007199254740992.0;
-      w0 += 1;
-      o0 += 1;
-    }
-    const int rem = start + take - w0;      // words left for whole pairs (+ maybe one trailing first half)
-    const int pairs = rem / 2;
-    if (out)
-      for (int i = tid; i < pairs; i += 256)
-        out[o0 + i] = ((double)(T[w0 + 2 * i] >> 5) * 67108864.0 + (double)(T[w0 + 2 * i + 1] >> 6)) / 9007199254740992.0;
-    const bool new_carry = (rem & 1) != 0;
-    __syncthreads();
-    if (new_carry && tid == 0) carry = T[w0 + 2 * pairs];
-    produced = o0 + pairs;
-    have_carry = new_carry;
-    pos = start + take;
-    __syncthreads();
-  }
-  // (2 n outputs from a carry-free start, or from a snapshot of such a run, always end on a whole pair)
-  for (int i = tid; i < 624; i += 256) state_out[i] = cur[i];
-  if (tid == 0) { state_out[624] = (unsigned)pos; state_out[625] = have_carry ? 1u : 0u; state_out[626] = carry; }
-}
-
 // x <- exp(x) in place (the vocoder's log-mel -> mel step, vocoder.py:139, for a whole padded batch at once)
 int s2st_exp_inplace(float* x, long n, hipStream_t st) {
   if (n <= 0) return 0;
   S2ST_LAUNCH(exp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n);
-  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
-}
-
-// n doubles of numpy's legacy stream from `state` (624 key words + position), the successor state into state_out
-int s2st_mt19937_doubles(const unsigned* state, long n, double* out, unsigned* state_out, int snap_every, unsigned* snaps,
-                         int max_snaps, hipStream_t st) {
-  if (!state || !state_out || n < 0) return S2ST_ERR_ARG;
-  S2ST_LAUNCH(mt19937_doubles_kernel, dim3(1), dim3(256), 0, st, state, n, out, state_out, snap_every, snaps, max_snaps);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 

@@ -303,9 +303,6 @@ int s2st_gl_polar_c(const float* mag, const float* ang, const int* tl, float* X,
 // initial phases from uniform draws (uni: utterance u's [F][T_u] block at uni + uoff[u], doubles as numpy drew them) or, uni ==
 // nullptr, from the device's counter-based generator
 int s2st_exp_inplace(float* x, long n, hipStream_t st);
-#define S2ST_MT_SNAP_WORDS 640  // 624 key words, position, have_carry, carry (+ padding)
-int s2st_mt19937_doubles(const unsigned* state, long n, double* out, unsigned* state_out, int snap_every, unsigned* snaps,
-                         int max_snaps, hipStream_t st);
 int s2st_gl_polar_u(const float* mag, const double* uni, const long* uoff, const int* tl, uint64_t seed, float* X, int U, int F,
                     int Tmax, hipStream_t st);
 int s2st_gl_stft_project(const float* wave, const int* tl, const float* win, const float* tw, const float* mag, float* X, int U,

@@ -330,7 +330,8 @@ class S2STTransformerModel(ModelBase):  # fairseq's BaseFairseqModel when fairse
                 or os.environ.get("S2ST_HUBERT_AHEAD", "1") == "0":
             return sample
         if self._fe_stream is None:
-            self._fe_stream = torch.cuda.Stream(device=self.engine.device)
+            from ..runtime import streams
+            self._fe_stream = streams.get("front-end", self.engine.device)
         fe = self._fe_stream
         fe.wait_stream(torch.cuda.current_stream())
         if after is not None:

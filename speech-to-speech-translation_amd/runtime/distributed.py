@@ -97,7 +97,8 @@ class GradReducer:
         self.extra_stream = extra_stream
         self.min_bucket = min_bucket_floats
         self.cuda = grads.is_cuda
-        self.stream = torch.cuda.Stream() if self.cuda else None
+        from . import streams
+        self.stream = streams.get("gradient-exchange", grads.device) if self.cuda else None
         self.pending: Optional[Tuple[int, int]] = None
         self.handles: List = []
         self.reduced: List[Tuple[int, int]] = []

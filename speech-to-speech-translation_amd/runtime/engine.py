@@ -237,7 +237,18 @@ class Engine:
         """``n`` further engines over the same weights (created once, kept): one per additional decode chain."""
         tws = self.__dict__.setdefault("_twins", [])
         while len(tws) < n:
-            tws.append(Engine(self.args, self.device, precise=bool(self.cfg.precise), share_with=self))
+            # (a decode chain never uses the engine's second stream: created all the same it would take a hardware queue
+            # slot and shift every later stream's mapping -- runtime/streams.py)
+            import os as _os
+            old = _os.environ.get("S2ST_NO_SIDE_STREAM")
+            _os.environ["S2ST_NO_SIDE_STREAM"] = "1"
+            try:
+                tws.append(Engine(self.args, self.device, precise=bool(self.cfg.precise), share_with=self))
+            finally:
+                if old is None:
+                    _os.environ.pop("S2ST_NO_SIDE_STREAM", None)
+                else:
+                    _os.environ["S2ST_NO_SIDE_STREAM"] = old
         return tws[:n]
 
     def __del__(self):

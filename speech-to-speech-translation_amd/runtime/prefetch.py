@@ -52,7 +52,8 @@ class DevicePrefetcher:
         self.engine, self.training, self.model = engine, training, model
         self.q: "queue.Queue" = queue.Queue(maxsize=max(depth, 1))
         self.cuda = engine.device.type == "cuda"
-        self.stream = torch.cuda.Stream(device=engine.device) if self.cuda else None
+        from . import streams
+        self.stream = streams.get("prefetch", engine.device) if self.cuda else None
         self._stop = False
         self._held = None  # (the look-ahead item of a --use-hubert run)
         self.thread = threading.Thread(target=self._run, args=(iter(batches),), daemon=True)

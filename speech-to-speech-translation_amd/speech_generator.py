@@ -69,7 +69,8 @@ class SpeechGenerator:
             return self.get_waveforms(feats), None
         vs = getattr(self.vocoder, "_defer_stream", None)  # (one per vocoder: generators that share it share the stream)
         if vs is None:
-            vs = torch.cuda.Stream(device=feats[0].device)
+            from .runtime import streams
+            vs = streams.get("vocoder", feats[0].device)  # (one per device: see runtime/streams.py)
             try:
                 self.vocoder._defer_stream = vs
             except AttributeError:
@@ -152,9 +153,8 @@ class AutoRegressiveSpeechGenerator(SpeechGenerator):
             # twin engines, each with its own bf16 arena, are built: ADVICE r4)
             return [self.generate(model, s, has_targ, **kwargs) for s in samples]
         engs = [model.engine] + model.engine.inference_twins(n - 1)
-        cs = self.__dict__.setdefault("_chain_streams", [])
-        while len(cs) < n - 1:
-            cs.append(torch.cuda.Stream(device=dev))
+        from .runtime import streams
+        cs = [streams.get(f"decode-chain-{k}", dev) for k in range(1, n)]  # (one per chain and device: runtime/streams.py)
         cur = torch.cuda.current_stream()
         streams = [cur] + cs[:n - 1]
         for st in streams[1:]:

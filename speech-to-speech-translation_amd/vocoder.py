@@ -229,77 +229,6 @@ def _mt_host(state: np.ndarray, n: int, out_ptr, bounds: np.ndarray, threads: in
                   ctypes.c_void_p(bounds.ctypes.data), int(threads)))
 
 
-class _DeviceMTStream:
-    """numpy's global generator continued ON THE DEVICE (``s2st_mt19937_doubles_f64``: MT19937 + numpy's two-words-per-double
-    conversion, draw for draw -- tests/test_inference.py::test_device_mt19937_is_numpys_stream).  Started by
-    ``prefetch_phases`` on a side stream while the decoder runs: an upper bound of draws goes straight into device memory
-    (no host generator run, no upload), with a resumable snapshot every ``SNAP`` blocks.  ``take(n)`` returns the first n,
-    and puts the GLOBAL numpy generator into the state n sequential draws would have left it in (nearest snapshot + a short
-    output-less run on the device, one 2.5 KB read-back) -- unless somebody used the global generator in between (None)."""
-    SNAP = 256          # blocks of 624 words between snapshots (80 k doubles)
-    CAP = 1 << 26       # doubles generated ahead at most (512 MB); a longer request draws the rest afterwards
-
-    def __init__(self, n_upper: int, device):
-        self.dev = device
-        self.state0 = np.random.get_state()
-        self.n = int(min(n_upper, self.CAP))
-        w = np.zeros(640, dtype=np.uint32)
-        w[:624] = self.state0[1]
-        w[624] = self.state0[2]
-        self.first_words = 624 - int(self.state0[2])
-        self.state_dev = torch.from_numpy(w.view(np.int32)).to(device)
-        self.buf = torch.empty(max(self.n, 1), dtype=torch.float64, device=device)
-        n_blocks = (2 * self.n) // 624 + 2
-        self.max_snaps = n_blocks // self.SNAP + 1
-        self.snaps = torch.zeros(self.max_snaps * 640, dtype=torch.int32, device=device)
-        self.end_state = torch.zeros(640, dtype=torch.int32, device=device)
-        self.stream = torch.cuda.Stream(device=device) if device.type == "cuda" else None
-        if self.stream is not None:
-            self.stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.stream):
-                self._launch(self.state_dev, self.n, self.buf, self.end_state, self.SNAP, self.snaps, self.max_snaps)
-        else:
-            self._launch(self.state_dev, self.n, self.buf, self.end_state, self.SNAP, self.snaps, self.max_snaps)
-
-    @staticmethod
-    def _launch(state, n, out, state_out, snap_every, snaps, max_snaps):
-        bd.call("s2st_mt19937_doubles_f64", state, int(n), out, state_out, int(snap_every), snaps, int(max_snaps))
-
-    def take(self, n: int):
-        cur = np.random.get_state()
-        same = cur[0] == self.state0[0] and cur[2] == self.state0[2] and np.array_equal(cur[1], self.state0[1]) \
-            and cur[3] == self.state0[3] and cur[4] == self.state0[4]
-        if not same or n > self.n:
-            if self.stream is not None:
-                self.stream.synchronize()
-            return None
-        ctx = torch.cuda.stream(self.stream) if self.stream is not None else None
-        if ctx is not None:
-            ctx.__enter__()
-        try:
-            if n == self.n:
-                final = self.end_state
-            else:
-                # snapshot k is taken in front of regenerated block (k + 1) * SNAP: 624 ((k + 1) SNAP - 1) + first_words
-                # words -- whole doubles plus perhaps half a one (the record's carry) -- were consumed before it
-                k = (2 * n - self.first_words) // (624 * self.SNAP) - 1 if 2 * n >= self.first_words else -1
-                k = min(k, self.max_snaps - 1)
-                final = torch.zeros(640, dtype=torch.int32, device=self.dev)
-                if k >= 0:
-                    words = self.first_words + 624 * ((k + 1) * self.SNAP - 1)
-                    self._launch(self.snaps[k * 640:(k + 1) * 640], n - words // 2, None, final, 0, None, 0)
-                else:
-                    self._launch(self.state_dev, n, None, final, 0, None, 0)
-            so = final.cpu().numpy().view(np.uint32)  # (waits for the side stream only)
-        finally:
-            if ctx is not None:
-                ctx.__exit__(None, None, None)
-        np.random.set_state((self.state0[0], so[:624].copy(), int(so[624]), self.state0[3], self.state0[4]))
-        if self.stream is not None:
-            torch.cuda.current_stream().wait_stream(self.stream)
-        return self.buf[:n]
-
-
 class GriffinLim:
     PHASE_CAP = 1 << 26  # doubles drawn ahead of the decode at most (512 MB of pinned memory per ring slot)
 
@@ -339,15 +268,15 @@ class GriffinLim:
         """Called by the speech generator BEFORE it decodes (``n_frames_upper``: an upper bound of the frames the batch
         will vocode): with phase_rng="numpy" and the FFT path, numpy's generator is continued while the decoder runs -- by the
         library's multi-threaded host generator into pinned memory (``_HostMTStream``, default), ``S2ST_GL_PHASE_STREAM=
-        numpy``: by numpy itself on one background thread (``_UniformStream``), ``=device``: by the one-workgroup device kernel
-        (``_DeviceMTStream``; 160 ms for 64 utterances: slower than either host form, kept for hosts without spare cores),
-        ``=off``: drawn after the decode, the ordinary way.  All four hand out the same doubles."""
+        numpy``: by numpy itself on one background thread (``_UniformStream``), ``=off``: drawn after the decode, the ordinary
+        way.  All three hand out the same doubles.  (Rounds 3 - 4 also carried a one-workgroup device kernel that continued
+        numpy's stream -- 160 ms for 64 utterances, slower than one host core -- removed in round 5.)"""
         obj = None
         pending = [x for x in self._streams if x is not None]
         if self.phase_rng == "numpy" and self.use_fft and n_frames_upper > 0:
             import os
             how = os.environ.get("S2ST_GL_PHASE_STREAM", "host")
-            # (the run-ahead is capped like the device generator's: the speech generator's upper bound is bsz x max_iter
+            # (the run-ahead is capped: the speech generator's upper bound is bsz x max_iter
             # frames, and max_iter defaults to 6000 -- 12 GB of doubles for a batch of 64 at n_fft 2048; a batch that
             # really vocodes more than the cap draws the ordinary way, after the decode: ADVICE r4)
             n = min(self.F * int(n_frames_upper), self.PHASE_CAP)
@@ -355,8 +284,6 @@ class GriffinLim:
                 how = "off"  # (a second batch in flight: only the host generator can be chained behind a pending one)
             if how == "numpy":
                 obj = _UniformStream(n, self.device.type == "cuda")
-            elif how == "device":
-                obj = _DeviceMTStream(n, self.device)
             elif how == "host":
                 up = None
                 try:
@@ -367,14 +294,15 @@ class GriffinLim:
                     if self.device.type == "cuda" and os.environ.get("S2ST_GL_EARLY_UPLOAD", "1") != "0":
                         # the draws go to the device as soon as the host has them, under the decode (a copy stream of their own)
                         if self.__dict__.get("_copy_stream") is None:
-                            self._copy_stream = torch.cuda.Stream(device=self.device)
+                            from .runtime import streams
+                            self._copy_stream = streams.get("phase-upload", self.device)
                         up = (self.device, self._copy_stream, None)
                     obj = _HostMTStream(n, self.device.type == "cuda", buf=buf, upload=up,
                                         start_after=pending[-1] if pending else None)
                     if self.device.type == "cuda":
                         self._pin_ring[self._ring_i][2] = obj  # the stream OWNS its slot until it has been joined
             elif how != "off":
-                raise ValueError("S2ST_GL_PHASE_STREAM must be host, numpy, device or off")
+                raise ValueError("S2ST_GL_PHASE_STREAM must be host, numpy or off")
         self._streams.append(obj)
         # at most two batches are in flight; an entry nobody took (its batch failed, or the vocoder was called with explicit
         # angles) is dropped -- after its generator thread has been joined: it may still be filling / uploading its slot

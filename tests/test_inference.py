@@ -584,8 +584,8 @@ def test_uniform_stream_runs_numpy_ahead_and_leaves_its_state_exact(backend):
     np.random.rand(1)  # someone else draws in between
     assert st2.take(10) is None
     # through the vocoder: prefetch + batch == plain batch, same seed -- with the library's threaded host generator (the
-    # default), numpy on a host thread, and numpy's generator continued on the device
-    for how in ("host", "numpy", "device", "off"):
+    # default) and numpy on a host thread
+    for how in ("host", "numpy", "off"):
         os.environ["S2ST_GL_PHASE_STREAM"] = how
         try:
             _prefetch_equals_plain(backend, V)
@@ -628,44 +628,6 @@ def _np_state_words(extra=(0, 0)):
     w[624] = st[2]
     w[625], w[626] = extra
     return st, w
-
-
-@pytest.mark.parametrize("warm,n", [(0, 1000), (1, 311), (3, 312 * 3 + 7), (624, 5), (5, 1)])
-def test_device_mt19937_is_numpys_stream(backend, warm, n):
-    """numpy's legacy generator on the device (s2st_mt19937_doubles_f64): from numpy's own state -- after `warm` single 32-bit
-    draws, so that odd positions and doubles straddling 624-word blocks occur -- the same doubles, draw for draw, and the
-    successor state numpy itself arrives at; snapshot records resume to the same state after any smaller count."""
-    np.random.seed(1234 + warm)
-    for _ in range(warm):
-        np.random.randint(0, 2 ** 31)  # (one 32-bit output each)
-    st, words = _np_state_words()
-    dev = backend.device
-    state = torch.from_numpy(words.view(np.int32)).to(dev)
-    out = torch.empty(n, dtype=torch.float64, device=dev)
-    state_out = torch.zeros(640, dtype=torch.int32, device=dev)
-    max_snaps = 8
-    snaps = torch.zeros(max_snaps * 640, dtype=torch.int32, device=dev)
-    backend.bd.call("s2st_mt19937_doubles_f64", state, n, out, state_out, 1, snaps, max_snaps)
-    backend.sync()
-    ref = np.random.random_sample(n)
-    assert np.array_equal(out.cpu().numpy(), ref)
-    after = np.random.get_state()
-    so = state_out.cpu().numpy().view(np.uint32)
-    assert np.array_equal(so[:624], after[1]) and int(so[624]) == after[2] and int(so[625]) == 0
-    # resume from every snapshot taken (one per regenerated block): the state after n draws again, without output
-    first_words = 624 - int(words[624])
-    for j in range(max_snaps):
-        w_j = first_words + 624 * j  # words consumed before the (j + 1)-th regenerated block
-        if w_j >= 2 * n:
-            break
-        produced = w_j // 2
-        rec = snaps[j * 640:(j + 1) * 640]
-        assert int(rec[625]) == (w_j & 1)
-        so2 = torch.zeros(640, dtype=torch.int32, device=dev)
-        backend.bd.call("s2st_mt19937_doubles_f64", rec, n - produced, None, so2, 0, None, 0)
-        backend.sync()
-        s2 = so2.cpu().numpy().view(np.uint32)
-        assert np.array_equal(s2[:624], after[1]) and int(s2[624]) == after[2], j
 
 
 def test_host_mt19937_is_numpys_stream():
