@@ -101,9 +101,13 @@ struct s2st_engine {
   bool join_every_segment = false;  // S2ST_JOIN_EVERY_SEGMENT=1 (A/B switch)
   float* skws_side = nullptr;
   hipStream_t fork_side() {  // everything issued on st_ so far happens-before what follows on the returned stream
-    if (!side_) return st_;
+    if (!side_) { sync_chains(); return st_; }
     hipEventRecord(ev_fork_, st_);
     hipStreamWaitEvent(side_, ev_fork_, 0);
+    if (forked_) {  // ... and everything issued on the second chain
+      hipEventRecord(ev_cside_, chain1_);
+      hipStreamWaitEvent(side_, ev_cside_, 0);
+    }
     side_used = true;
     return side_;
   }
@@ -123,10 +127,69 @@ struct s2st_engine {
     stalls.push_back(s);
   }
   void join_side() {
+    sync_chains();
     if (!side_ || !side_used) return;
     hipEventRecord(ev_join_, side_);
     wait_traced(st_, ev_join_, "join_side");
     side_used = false;
+  }
+
+  // ---- two utterance-half chains (round 5; S2ST_CHAINS=2) -----------------------------------------
+  // Between the conv front end and the post-net every op of the training step is independent across utterances: rows of
+  // the linear layers and layer norms, attention per (utterance, head).  In this mode those ops are launched TWICE -- rows
+  // of utterances [0, B/2) on the caller's stream, rows of [B/2, B) on a second chain stream -- over the SAME whole-batch
+  // tensors, so that one chain's per-kernel latency (launch boundary, prologue, a single round of tiles) runs under the
+  // other's.  Everything that spans the batch stays ONE launch behind both chains: the weight-gradient products (K = all
+  // tokens: fork_side waits for both), BatchNorm / convolutions / losses (sync_chains in front of them), the partial-sum
+  // folds (both chains' partial rows, chain 0's first).  Dropout masks are keyed by (seed, element index of the LAUNCH):
+  // chain 1 salts its seed, so its masks are independent of chain 0's (they differ from the one-chain schedule's masks for
+  // those rows -- same distribution; with dropout off the two schedules' forward outputs are bit-identical).
+  int nchains = 1;               // S2ST_CHAINS
+  bool chains_one_stream = false;  // S2ST_CHAINS_ONE_STREAM=1 (debugging aid): both halves on the caller's stream
+  hipStream_t chain1_ = nullptr;
+  hipEvent_t ev_cfork_ = nullptr, ev_cjoin_ = nullptr, ev_cside_ = nullptr;
+  bool forked_ = false;
+  bool in_region_ = false;       // forward: between chain_region(true) and chain_region(false); backward: per closure
+  hipStream_t main_ = nullptr;   // the caller's stream of this call (st_ points at side_ while the aux sections run)
+  float* skws_c1 = nullptr;      // split-K scratch of the second chain
+  std::vector<char> tape_aware;  // closure i launches per chain itself (everything else gets sync_chains() first)
+  static constexpr uint64_t CHAIN_SALT = 0xD6E8FEB86659FD93ULL;
+  struct Part { int r0, nr; hipStream_t st; uint64_t salt; };
+  // how many parts an op over `rows` rows (rows = B x positions) is launched in -- independent of live(), so that the dry
+  // run of the schedule allocates what the real one does
+  int chain_count(int rows) const {
+    return (nchains == 2 && chain1_ && in_region_ && st_ == main_ && bt.B >= 2 && rows > 0 && rows % bt.B == 0) ? 2 : 1;
+  }
+  int chain_parts(int rows, Part* p) {
+    if (chain_count(rows) == 1) {
+      if (live()) sync_chains();
+      p[0] = Part{0, rows, st_, 0};
+      return 1;
+    }
+    const int per = rows / bt.B, b0 = bt.B / 2;
+    if (live()) ensure_forked();
+    p[0] = Part{0, b0 * per, main_, 0};
+    p[1] = Part{b0 * per, rows - b0 * per, chains_one_stream ? main_ : chain1_, CHAIN_SALT};
+    return 2;
+  }
+  void ensure_forked() {
+    if (forked_) return;
+    hipEventRecord(ev_cfork_, main_);
+    hipStreamWaitEvent(chain1_, ev_cfork_, 0);
+    forked_ = true;
+  }
+  void sync_chains() {  // the caller's stream takes in what the second chain did
+    if (!forked_) return;
+    hipEventRecord(ev_cjoin_, chain1_);
+    hipStreamWaitEvent(main_, ev_cjoin_, 0);
+    forked_ = false;
+  }
+  void set_aware() {
+    tape_aware.resize(tape.size(), 0);
+    if (!tape.empty()) tape_aware.back() = in_region_ ? 1 : 0;
+  }
+  void chains_wait(hipEvent_t ev) {  // an event both chains have to honour (work handed over from the second stream)
+    if (forked_) hipStreamWaitEvent(chain1_, ev, 0);
   }
   // ---- AR decoding state (config 5): caller-owned cache buffer laid out by decode_begin --------
   bool stop_after_encoder = false;
@@ -179,7 +242,7 @@ struct s2st_engine {
   struct HubP {
     long conv_w[8]; long gn_g, gn_b; LNP ln; LinP proj; long pos_w, pos_b; std::vector<EncLayerP> L; LNP enc_ln;
   } hp;
-  float* ws_for(hipStream_t s) const { return (side_ && s == side_) ? skws_side : skws; }
+  float* ws_for(hipStream_t s) const { return (side_ && s == side_) ? skws_side : ((chain1_ && s == chain1_) ? skws_c1 : skws); }
   float* skws = nullptr;  // split-K partial-sum scratch of the weight-gradient GEMMs (per call)
   long skws_n = 0;
   bool ph_fresh = false;   // s2st_engine_bf16_is_fresh: PH already equals bf16(P) for the next forward
@@ -469,14 +532,14 @@ struct s2st_engine {
   bf16raw* half_of(Ten* t) {
     if (!t->h) {
       t->h = alloc_h((long)t->rows * t->hld());
-      if (live()) chk(s2st_cast_bf16_rows(t->d, t->cols, t->h, t->hld(), t->rows, t->cols, st_));
+      if (live()) { sync_chains(); chk(s2st_cast_bf16_rows(t->d, t->cols, t->h, t->hld(), t->rows, t->cols, st_)); }
     }
     return t->h;
   }
   bf16raw* ghalf_of(Ten* t) {
     if (!t->gh) {
       t->gh = alloc_h((long)t->rows * t->hld());
-      if (live()) chk(s2st_cast_bf16_rows(t->g, t->cols, t->gh, t->hld(), t->rows, t->cols, st_));
+      if (live()) { sync_chains(); chk(s2st_cast_bf16_rows(t->g, t->cols, t->gh, t->hld(), t->rows, t->cols, st_)); }
     }
     return t->gh;
   }
@@ -515,6 +578,7 @@ struct s2st_engine {
     if (!live()) return;
     while (adam_next < (int)adam_lo.size() && adam_lo[adam_next] < off_end) {
       hipStreamWaitEvent(st_, adam_ev[adam_next], 0);  // (st_ is the data-path stream here: touch() skips the second one)
+      chains_wait(adam_ev[adam_next]);  // (a second chain forked earlier reads the same parameters)
       ++adam_next;
     }
     if (adam_next >= (int)adam_lo.size()) adam_pending = false;
@@ -573,6 +637,7 @@ struct s2st_engine {
     if (pending_wgrad.empty()) return;
     if (live()) {
       // everything the products read was enqueued on st_ before this point
+      if (!side_) sync_chains();
       hipStream_t s = (side_ && st_ != side_) ? fork_side() : st_;
       // S2ST_TIMING_SKIP_WGRAD=1 (-DS2ST_EXPERIMENTAL builds only: it makes the gradients WRONG): a timing experiment --
       // how much of the step is the weight-gradient products' share of the chip
@@ -599,6 +664,7 @@ struct s2st_engine {
   void flush_lnfold() {
     if (pending_lnfold.n == 0) return;
     if (live()) {
+      if (!side_) sync_chains();
       hipStream_t s = (side_ && st_ != side_) ? fork_side() : st_;
       chk(s2st_layernorm_bwd_fold(pending_lnfold, s));
     }
@@ -644,27 +710,40 @@ struct s2st_engine {
     if (fm && act == 0 && drop_p > 0.f && N % 8 == 0 && use_ln_fuse) {
       y->drop2_ok = true; y->drop2_p = drop_p; y->drop2_seed = sd; y->drop2_bias = b;
     }
+    Part pt[2];
+    const int np = chain_parts(M, pt);  // (two utterance-half chains: rows [r0, r0 + nr) on each chain's stream)
     if (live()) {
-      GemmArgs g{};
-      g.A = fm ? gemm_rowmajor(xh, x->hld()) : gemm_rowmajor(x->d, x->cols);
-      g.B = fm ? gemm_rowmajor(PH + w, K) : gemm_rowmajor(P + w, K);
-      g.C = gemm_out(y->d, N);
-      g.C.h = y->h;
-      g.ep = gemm_epi_default();
-      g.ep.bias = b >= 0 ? P + b : nullptr;
-      g.ep.act = act;
-      g.ep.drop_p = drop_p;
-      g.ep.seed = sd;
-      g.ep.resid = resid ? resid->d : nullptr;
-      g.M = M; g.N = N; g.K = K; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
-      chk(s2st_gemm(g, st_));
+      for (int ci = 0; ci < np; ++ci) {
+        const long r0 = pt[ci].r0;
+        GemmArgs g{};
+        g.A = fm ? gemm_rowmajor(xh + r0 * x->hld(), x->hld()) : gemm_rowmajor(x->d + r0 * x->cols, x->cols);
+        g.B = fm ? gemm_rowmajor(PH + w, K) : gemm_rowmajor(P + w, K);
+        g.C = gemm_out(y->d ? y->d + r0 * N : nullptr, N);
+        g.C.h = y->h ? y->h + r0 * N : nullptr;
+        g.ep = gemm_epi_default();
+        g.ep.bias = b >= 0 ? P + b : nullptr;
+        g.ep.act = act;
+        g.ep.drop_p = drop_p;
+        g.ep.seed = sd ^ pt[ci].salt;
+        g.ep.resid = resid ? resid->d + r0 * N : nullptr;
+        g.M = pt[ci].nr; g.N = N; g.K = K; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
+        chk(s2st_gemm(g, pt[ci].st));
+      }
     }
+    const bool region = in_region_;
     tape.push_back([=]() {
+      const bool region_was = in_region_;
+      in_region_ = region;
+      struct Restore { bool& r; bool v; ~Restore() { r = v; } } restore_{in_region_, region_was};
+      Part bp[2];
+      const int nb = chain_parts(M, bp);
       if (!y->g && !y->gpre_h) return;  // nothing flowed back
       float* dy = y->g;
       if (resid && resid->needs_grad) {
         if (!resid->g) resid->g = dy;  // alias: every reader of dy runs before resid's producers
-        else if (live()) chk(s2st_axpy(dy, resid->g, y->n(), 1.f, st_));
+        else if (live())
+          for (int ci = 0; ci < nb; ++ci)
+            chk(s2st_axpy(dy + (long)bp[ci].r0 * N, resid->g + (long)bp[ci].r0 * N, (long)bp[ci].nr * N, 1.f, bp[ci].st));
       }
       float* dpre = dy;
       const int ldp = (N + 7) & ~7;
@@ -679,16 +758,23 @@ struct s2st_engine {
         const int mode = act == 1 ? 1 : (drop_p > 0.f ? 2 : 0);
         // (bias sums in a fixed order: a bias whose gradient is mathematically zero -- key projections -- gets pure rounding
         // noise, which must repeat from run to run)
-        float* part = (b >= 0 && ordered_sums) ? alloc(s2st_linear_bwd_prep_scratch_floats(M, N, ldp)) : nullptr;
+        float* part[2] = {nullptr, nullptr};
+        for (int ci = 0; ci < nb; ++ci)
+          part[ci] = (b >= 0 && ordered_sums) ? alloc(s2st_linear_bwd_prep_scratch_floats(M, N, ldp)) : nullptr;
         if (live()) {
-          int slabs = 0;
-          chk(s2st_linear_bwd_prep(dy, y->d, y->d ? nullptr : y->h, mode, drop_p, sd, t, ldp, nullptr,
-                                   b >= 0 ? G + b : nullptr, M, N, st_, part, part ? &slabs : nullptr));
-          if (part) add_fold(part, slabs, N, G + b);
+          for (int ci = 0; ci < nb; ++ci) {
+            const long r0 = bp[ci].r0;
+            int slabs = 0;
+            chk(s2st_linear_bwd_prep(dy + r0 * N, y->d ? y->d + r0 * N : nullptr, y->d ? nullptr : y->h + r0 * N, mode, drop_p,
+                                     sd ^ bp[ci].salt, t + r0 * ldp, ldp, nullptr, b >= 0 ? G + b : nullptr, bp[ci].nr, N, bp[ci].st,
+                                     part[ci], part[ci] ? &slabs : nullptr));
+            if (part[ci]) add_fold(part[ci], slabs, N, G + b);
+          }
         }
         dph = t;
         bias_done = true;
       } else {
+        if (live()) sync_chains();  // (whole-tensor passes of the precise / odd-width path)
         if (act == 1) {
           dpre = alloc(y->n());
           if (live()) chk(s2st_relu_drop_bwd(dy, y->d, dpre, y->n(), drop_p, st_));
@@ -719,6 +805,7 @@ struct s2st_engine {
           // (no slabs, no combine kernels): see flush_wgrad()
           push_wgrad(g);
         } else {
+          if (!(fm && !on_main)) sync_chains();  // (a whole-batch product on the data-path stream)
           hipStream_t ws_st = fm && !on_main ? fork_side() : st_;
           g.ws = ws_for(ws_st); g.ws_floats = skws_n;
           chk(s2st_gemm(g, ws_st));
@@ -735,37 +822,44 @@ struct s2st_engine {
         if (fm && !acc && x->want_gh && x->hld() == x->cols) x->gh = alloc_h(x->n());
         const bool fuse_act = fm && !acc && x->act_mode == 1 && x->h && x->hld() == x->cols && use_act_fuse;
         if (fuse_act) x->gpre_h = alloc_h(x->n());
-        float* cs_part = (fuse_act && ordered_sums && x->act_bias >= 0) ? alloc((long)2 * ((M + 63) / 64) * K) : nullptr;
+        float* cs_part[2] = {nullptr, nullptr};
+        for (int ci = 0; ci < nb; ++ci)
+          cs_part[ci] = (fuse_act && ordered_sums && x->act_bias >= 0) ? alloc((long)2 * ((M + 63) / 64) * K) : nullptr;
         if (live()) {
-          GemmArgs g{};  // dx[M][K] (+)= dpre W
-          g.A = fm ? gemm_rowmajor(dph, ldp) : gemm_rowmajor(dpre, N);
-          g.B = fm ? (has_wt(w, N, K) ? gemm_rowmajor(PHT + w, N) : gemm_colmajor(PH + w, K)) : gemm_colmajor(P + w, K);
-          g.C = gemm_out(dx, x->cols);
-          if (fm && !acc) g.C.h = x->gh;  // the consumer (attention backward) reads dO as a GEMM operand
-          g.ep = gemm_epi_default();
-          if (fuse_act) {  // dx is the gradient w.r.t. a ReLU+dropout output: emit its pre-activation gradient
-            g.C.p = nullptr;
-            g.C.h = x->gpre_h;
-            g.ep.mask_y = x->h;
-            g.ep.mask_scale = x->act_p > 0.f ? 1.f / (1.f - x->act_p) : 1.f;
-            g.ep.colsum = x->act_bias >= 0 ? G + x->act_bias : nullptr;
+          if (nb == 2) ensure_forked();  // (a whole-batch pass above may have joined the chains)
+          for (int ci = 0; ci < nb; ++ci) {
+            const long r0 = bp[ci].r0;
+            GemmArgs g{};  // dx[M][K] (+)= dpre W
+            g.A = fm ? gemm_rowmajor(dph + r0 * ldp, ldp) : gemm_rowmajor(dpre + r0 * N, N);
+            g.B = fm ? (has_wt(w, N, K) ? gemm_rowmajor(PHT + w, N) : gemm_colmajor(PH + w, K)) : gemm_colmajor(P + w, K);
+            g.C = gemm_out(dx + r0 * x->cols, x->cols);
+            if (fm && !acc && x->gh) g.C.h = x->gh + r0 * x->cols;  // the consumer (attention backward) reads dO as a GEMM operand
+            g.ep = gemm_epi_default();
+            if (fuse_act) {  // dx is the gradient w.r.t. a ReLU+dropout output: emit its pre-activation gradient
+              g.C.p = nullptr;
+              g.C.h = x->gpre_h + r0 * x->cols;
+              g.ep.mask_y = x->h + r0 * x->cols;
+              g.ep.mask_scale = x->act_p > 0.f ? 1.f / (1.f - x->act_p) : 1.f;
+              g.ep.colsum = x->act_bias >= 0 ? G + x->act_bias : nullptr;
+            }
+            g.ep.accumulate = acc ? 1 : 0;
+            g.ws = ws_for(bp[ci].st); g.ws_floats = skws_n;
+            g.M = bp[ci].nr; g.N = K; g.K = N; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
+            if (fuse_act && g.ep.colsum && ordered_sums) {
+              // the bias gradient of the masked layer as per-(row tile, wave row) partial rows (worst case: 64-row tiles)
+              g.ep.colsum_part = cs_part[ci];
+              int tile = 0;
+              chk(s2st_gemm(g, bp[ci].st, &tile));
+              const int bm = tile / 1000;
+              if (bm > 0) add_fold(cs_part[ci], 2 * ((bp[ci].nr + bm - 1) / bm), K, g.ep.colsum);
+              else if (!err) err = S2ST_ERR_LAUNCH;
+            } else
+            chk(s2st_gemm(g, bp[ci].st));
           }
-          g.ep.accumulate = acc ? 1 : 0;
-          g.ws = ws_for(st_); g.ws_floats = skws_n;
-          g.M = M; g.N = K; g.K = N; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
-          if (fuse_act && g.ep.colsum && ordered_sums) {
-            // the bias gradient of the masked layer as per-(row tile, wave row) partial rows (worst case: 64-row tiles)
-            g.ep.colsum_part = cs_part;
-            int tile = 0;
-            chk(s2st_gemm(g, st_, &tile));
-            const int bm = tile / 1000;
-            if (bm > 0) add_fold(cs_part, 2 * ((M + bm - 1) / bm), K, g.ep.colsum);
-            else if (!err) err = S2ST_ERR_LAUNCH;
-          } else
-          chk(s2st_gemm(g, st_));
         }
       }
     });
+    set_aware();
     return y;
   }
 
@@ -792,18 +886,32 @@ struct s2st_engine {
     float* rstd = alloc(x->rows);
     touch(p.b + p.C);
     if (fast() && x->cols % 8 == 0) y->h = alloc_h(y->n());
+    Part pt[2];
+    const int np = chain_parts(x->rows, pt);
     if (live())
-      chk(s2st_layernorm_fwd(x->d, P + p.g, P + p.b, y->d, mean, rstd, x->rows, x->cols, 1e-5f, st_, y->h));
+      for (int ci = 0; ci < np; ++ci) {
+        const long r0 = pt[ci].r0, o = r0 * x->cols;
+        chk(s2st_layernorm_fwd(x->d + o, P + p.g, P + p.b, y->d ? y->d + o : nullptr, mean + r0, rstd + r0, pt[ci].nr, x->cols, 1e-5f,
+                               pt[ci].st, y->h ? y->h + o : nullptr));
+      }
     LNP pp = p;
+    const bool region = in_region_;
     // first layer norm applied to x (forward order): its backward is the last contribution to x's gradient
     const bool fuse_cand = fast() && x->drop2_ok && !x->ln_seen && x->needs_grad;
     x->ln_seen = true;
     tape.push_back([=]() {
       if (!y->g) return;
+      const bool region_was = in_region_;
+      in_region_ = region;
+      struct Restore { bool& r; bool v; ~Restore() { r = v; } } restore_{in_region_, region_was};
+      Part bp[2];
+      const int nb = chain_parts(x->rows, bp);
+      if (dbg_dir_set() && live()) sync_chains();  // (the dump below reads whole tensors; debugging runs use one chain)
       bool acc;
       float* dx = gradbuf(x, acc);
       const bool fuse = fuse_cand && !x->gpre_h;
       float* scratch = alloc((long)s2st_layernorm_bwd_blocks(x->rows, x->cols) * (fuse ? 3 : 2) * x->cols);
+      float* scratch1 = nb == 2 ? alloc((long)s2st_layernorm_bwd_blocks(x->rows, x->cols) * (fuse ? 3 : 2) * x->cols) : nullptr;
       bf16raw* dph = nullptr;
       if (fuse) dph = x->gpre_h = alloc_h(x->n());
       float* dbias = fuse && x->drop2_bias >= 0 ? G + x->drop2_bias : nullptr;
@@ -830,24 +938,31 @@ struct s2st_engine {
         if (acc) dump("dx0", dx, sizeof(float) * x->n());
       }
       if (live()) {
+        if (nb == 2) ensure_forked();
         if (!ln_bwd_split) {
           // one row kernel on the data path (dx, the fused bf16 operand, and the column-sum partials of dgamma / dbeta /
           // dbias); the partials of the segment's layer norms are folded together (flush_lnfold)
-          chk(s2st_layernorm_bwd(y->g, x->d, P + pp.g, mean, rstd, dx, acc ? 1 : 0, G + pp.g, G + pp.b, scratch,
-                                 x->rows, x->cols, st_, 3, dph, x->drop2_p, x->drop2_seed, dbias));
-          if (pending_lnfold.n == S2ST_LNFOLD_MAX) flush_lnfold();
-          chk(s2st_lnfold_add(pending_lnfold, scratch, x->rows, x->cols, fuse ? 3 : 2, G + pp.g, G + pp.b, dbias));
-        } else if (side_) {  // dx on the data path; the dgamma / dbeta reduce next to it on the second stream
-          chk(s2st_layernorm_bwd(y->g, x->d, P + pp.g, mean, rstd, dx, acc ? 1 : 0, G + pp.g, G + pp.b, scratch,
-                                 x->rows, x->cols, st_, 1, dph, x->drop2_p, x->drop2_seed, dbias));
-          hipStream_t rs = fork_side();
-          chk(s2st_layernorm_bwd(y->g, x->d, P + pp.g, mean, rstd, dx, acc ? 1 : 0, G + pp.g, G + pp.b, scratch,
-                                 x->rows, x->cols, rs, 2, dph, x->drop2_p, x->drop2_seed, dbias));
+          for (int ci = 0; ci < nb; ++ci) {
+            const long r0 = bp[ci].r0, o = r0 * x->cols;
+            float* sc = ci == 0 ? scratch : scratch1;
+            chk(s2st_layernorm_bwd(y->g + o, x->d + o, P + pp.g, mean + r0, rstd + r0, dx + o, acc ? 1 : 0, G + pp.g, G + pp.b, sc,
+                                   bp[ci].nr, x->cols, bp[ci].st, 3, dph ? dph + o : nullptr, x->drop2_p, x->drop2_seed ^ bp[ci].salt,
+                                   dbias));
+            if (pending_lnfold.n == S2ST_LNFOLD_MAX) flush_lnfold();
+            chk(s2st_lnfold_add(pending_lnfold, sc, bp[ci].nr, x->cols, fuse ? 3 : 2, G + pp.g, G + pp.b, dbias));
+          }
         } else {
-          chk(s2st_layernorm_bwd(y->g, x->d, P + pp.g, mean, rstd, dx, acc ? 1 : 0, G + pp.g, G + pp.b, scratch,
-                                 x->rows, x->cols, st_, 1, dph, x->drop2_p, x->drop2_seed, dbias));
-          chk(s2st_layernorm_bwd(y->g, x->d, P + pp.g, mean, rstd, dx, acc ? 1 : 0, G + pp.g, G + pp.b, scratch,
-                                 x->rows, x->cols, st_, 2, dph, x->drop2_p, x->drop2_seed, dbias));
+          // S2ST_LN_BWD_SPLIT=1 (A/B switch): dx row kernel on the data path (per chain), then a second pass over dy and x
+          // for the parameter gradients + its fold on the second stream (or behind it without one)
+          auto pass = [&](int ci, int phase, hipStream_t st) {
+            const long r0 = bp[ci].r0, o = r0 * x->cols;
+            chk(s2st_layernorm_bwd(y->g + o, x->d + o, P + pp.g, mean + r0, rstd + r0, dx + o, acc ? 1 : 0, G + pp.g, G + pp.b,
+                                   ci == 0 ? scratch : scratch1, bp[ci].nr, x->cols, st, phase, dph ? dph + o : nullptr, x->drop2_p,
+                                   x->drop2_seed ^ bp[ci].salt, dbias));
+          };
+          for (int ci = 0; ci < nb; ++ci) pass(ci, 1, bp[ci].st);
+          hipStream_t rs = side_ ? fork_side() : (sync_chains(), st_);
+          for (int ci = 0; ci < nb; ++ci) pass(ci, 2, rs);
         }
       }
       if (dbg) {
@@ -855,7 +970,12 @@ struct s2st_engine {
         ++dbg_n;
       }
     });
+    set_aware();
     return y;
+  }
+  static bool dbg_dir_set() {
+    static const bool on = getenv("S2ST_DEBUG_LN_DUMP") != nullptr;
+    return on;
   }
 
   // attention core.  q: [B*T] rows at qp (+ h*dh), ld ldq ; k/v rows [B*S] ; out [B*T][C]
@@ -884,13 +1004,36 @@ struct s2st_engine {
       fa.o = o->d; fa.oh = o->h; fa.lse = lse; fa.klen = klen;
       fa.B = B; fa.H = H; fa.T = T; fa.S = S; fa.dh = dh; fa.causal = causal;
       fa.scale = 1.0f / sqrtf((float)dh); fa.drop_p = drop_p; fa.seed = sd; fa.ld_drop = ld;
-      if (live()) chk(s2st_flash_attn_fwd(&fa, st_));
+      // one chain's share of the batch: utterances [b0, b0 + nbat) of every per-utterance array
+      auto chain_args = [=](s2st_attn_args a, int b0, int nbat, uint64_t salt) {
+        a.q += (long)b0 * T * a.ldq; a.k += (long)b0 * S * a.ldk; a.v += (long)b0 * S * a.ldv;
+        a.o += (long)b0 * T * C; if (a.oh) a.oh += (long)b0 * T * C;
+        a.lse += (long)b0 * H * T; if (a.klen) a.klen += b0;
+        if (a.doh) a.doh += (long)b0 * T * C;
+        if (a.dq) a.dq += (long)b0 * T * a.ldq; if (a.dk) a.dk += (long)b0 * S * a.ldk; if (a.dv) a.dv += (long)b0 * S * a.ldv;
+        if (a.dqh) a.dqh += (long)b0 * T * a.ldq; if (a.dkh) a.dkh += (long)b0 * S * a.ldk; if (a.dvh) a.dvh += (long)b0 * S * a.ldv;
+        a.B = nbat; a.seed ^= salt;
+        return a;
+      };
+      Part pt[2];
+      const int np = chain_parts(B * T, pt);
+      if (live())
+        for (int ci = 0; ci < np; ++ci) {
+          const s2st_attn_args a = chain_args(fa, pt[ci].r0 / T, pt[ci].nr / T, pt[ci].salt);
+          chk(s2st_flash_attn_fwd(&a, pt[ci].st));
+        }
       AttnIO io3 = io;
+      const bool region = in_region_;
       tape.push_back([=]() {
         if (!o->g) return;
+        const bool region_was = in_region_;
+        in_region_ = region;
+        struct Restore { bool& r; bool v; ~Restore() { r = v; } } restore_{in_region_, region_was};
         float* dvec = alloc((long)B * H * T);
         s2st_attn_args fb = fa;
         fb.doh = ghalf_of(o);
+        Part bp[2];
+        const int nb = chain_parts(B * T, bp);
         // q / k / v are column blocks of plain projections: their gradients are only ever read as bf16
         // GEMM operands (+ bias column sums), so the kernels emit exactly that and no fp32 gradient
         const bool gf = use_attn_gfuse && io3.qt->lin_plain && io3.kt->lin_plain && io3.vt->lin_plain &&
@@ -915,23 +1058,28 @@ struct s2st_engine {
         // =2: the same sums as fp32 atomics per head column (contention: slow); =3: column sums of the rounded bf16
         // copies (round 1's form: a rounding residue of ~1e-5 instead of ~0)
         const bool gf_db = gf && attn_gfuse_mode != 3;
-        float* dbp = nullptr;
+        float* dbp[2] = {nullptr, nullptr};
         if (gf_db) {
           if (io3.qt->act_bias >= 0) fb.dbq = G + io3.qt->act_bias + io3.qoff;
           if (io3.kt->act_bias >= 0) fb.dbk = G + io3.kt->act_bias + io3.koff;
           if (io3.vt->act_bias >= 0) fb.dbv = G + io3.vt->act_bias + io3.voff;
-          if (attn_gfuse_mode != 2) dbp = alloc(s2st_flash_attn_db_scratch_floats(&fb));
+          if (attn_gfuse_mode != 2)
+            for (int ci = 0; ci < nb; ++ci) dbp[ci] = alloc(s2st_flash_attn_db_scratch_floats(&fb));  // (sized for the whole batch)
         }
-        if (live()) chk(s2st_flash_attn_bwd(&fb, o->g, dvec, st_, 0, dbp));
-        if (dbp && live()) {
-          // parameter gradients: the partials join the segment's batched fold (flush_lnfold, second stream)
-          int sq = 0, sk = 0;
-          s2st_flash_attn_db_layout(&fb, &sq, &sk);
-          const int Cm = fb.H * fb.dh;
-          if (pending_lnfold.n + 3 > S2ST_LNFOLD_MAX) flush_lnfold();
-          if (fb.dbq) chk(s2st_fold_add(pending_lnfold, dbp, sq, Cm, 1, fb.dbq, nullptr, nullptr));
-          if (fb.dbk) chk(s2st_fold_add(pending_lnfold, dbp + (long)sq * Cm, sk, Cm, 1, fb.dbk, nullptr, nullptr));
-          if (fb.dbv) chk(s2st_fold_add(pending_lnfold, dbp + (long)(sq + sk) * Cm, sk, Cm, 1, fb.dbv, nullptr, nullptr));
+        for (int ci = 0; ci < nb; ++ci) {
+          const int b0 = bp[ci].r0 / T, nbat = bp[ci].nr / T;
+          const s2st_attn_args a = chain_args(fb, b0, nbat, bp[ci].salt);
+          if (live()) chk(s2st_flash_attn_bwd(&a, o->g + (long)b0 * T * C, dvec + (long)b0 * H * T, bp[ci].st, 0, dbp[ci]));
+          if (dbp[ci] && live()) {
+            // parameter gradients: the partials join the segment's batched fold (flush_lnfold, second stream)
+            int sq = 0, sk = 0;
+            s2st_flash_attn_db_layout(&a, &sq, &sk);
+            const int Cm = a.H * a.dh;
+            if (pending_lnfold.n + 3 > S2ST_LNFOLD_MAX) flush_lnfold();
+            if (a.dbq) chk(s2st_fold_add(pending_lnfold, dbp[ci], sq, Cm, 1, a.dbq, nullptr, nullptr));
+            if (a.dbk) chk(s2st_fold_add(pending_lnfold, dbp[ci] + (long)sq * Cm, sk, Cm, 1, a.dbk, nullptr, nullptr));
+            if (a.dbv) chk(s2st_fold_add(pending_lnfold, dbp[ci] + (long)(sq + sk) * Cm, sk, Cm, 1, a.dbv, nullptr, nullptr));
+          }
         }
         if (gf && !gf_db) {
           // projection bias gradients = column sums of the bf16 gradients: parameter gradients only, so
@@ -950,8 +1098,10 @@ struct s2st_engine {
           }
         }
       });
+      set_aware();
       return o;
     }
+    if (live()) sync_chains();  // (the unfused path below works on whole-batch score tensors)
     float* p = alloc((long)B * H * T * ld);
     float* pd = drop_p > 0.f ? alloc((long)B * H * T * ld) : p;
     bf16raw* pdh = fm ? alloc_h((long)B * H * T * ld) : nullptr;  // bf16 dropout(p): the P*V / dV operand
@@ -1045,6 +1195,7 @@ struct s2st_engine {
     Ten* kv = kv_pre ? kv_pre : cross_kv(encx, a, C);
     if (kv_pre && kv_wait_) {  // first consumer of the projections issued on the second stream
       wait_traced(st_, ev_kv_, "cross-attention K|V projections");
+      chains_wait(ev_kv_);
       kv_wait_ = false;
     }
     AttnIO io{q, 0, C, kv, 0, 2 * C, kv, C, 2 * C};
@@ -1629,6 +1780,9 @@ struct s2st_engine {
     for (Ten* t : tens) delete t;
     tens.clear();
     tape.clear();
+    tape_aware.clear();
+    forked_ = false;
+    in_region_ = false;
     marks.clear();
     ws_top = 0;
     ws_peak = 0;
@@ -1650,6 +1804,10 @@ struct s2st_engine {
     const bool tr = bt.training != 0;
     const bool with_loss = bt.tgt != nullptr;
     seed = bt.seed;
+    main_ = st_;
+    forked_ = false;
+    in_region_ = false;
+    const bool two_chains = nchains == 2 && chain1_ && tr && fast();  // (training step only; see the note at chain_count)
 
     // sinusoidal tables come from the host side (cached per dim); conv weight layouts are
     // scratch at the bottom of the workspace
@@ -1679,6 +1837,7 @@ struct s2st_engine {
     skws_n = fm ? (long)16 << 20 : 0;
     skws = fm ? alloc(skws_n) : nullptr;
     skws_side = fm && side_ ? alloc(skws_n) : skws;
+    skws_c1 = fm && chain1_ && nchains == 2 ? alloc(skws_n) : skws;
     // stream-K scratch of the persistent GEMM kernel, one per stream (ticket counters zeroed here, before any fork)
     if (fm && tr && use_streamk) {
       float* sk0 = alloc(S2ST_STREAMK_SCRATCH_FLOATS);
@@ -1753,6 +1912,7 @@ struct s2st_engine {
     mark();
     // ---- encoder layers, taps -----------------------------------------------------------------
     Ten *tap_asr = nullptr, *tap_st = nullptr;
+    in_region_ = two_chains;  // ---- two utterance-half chains: the encoder layers + the final layer norm
     for (int i = 0; i < c.enc_layers; ++i) {
       x = enc_layer(x, enc[i], B, E);
       if (i == c.tap_asr) tap_asr = x;
@@ -1761,6 +1921,8 @@ struct s2st_engine {
     }
     const bool t2s_spk = c.text_input && enc_spk >= 0 && bt.speaker != nullptr;
     Ten* enc_out = has_enc_ln ? layernorm(x, enc_ln, t2s_spk ? nullptr : outs.enc_out) : x;
+    in_region_ = false;
+    if (live()) sync_chains();
     if (t2s_spk) {
       // t2s_transformer.py:107-111: x = spk_emb_proj(cat[x, emb.expand(T)]) on EVERY position (padded ones included),
       // after the final layer norm.  The concatenation is materialised so that forward, data gradient and weight
@@ -1853,6 +2015,7 @@ struct s2st_engine {
     h = linear(h, prenet.back().w, prenet.back().b, Cd, c.prenet_dim);
     Ten* y = add_pe(h, bt.dec_pos, pe_dec, 1.f, pos_alpha, tr ? c.dropout : 0.f);
     mark();
+    in_region_ = two_chains;  // ---- two chains again: decoder layers, final layer norm, the two output projections
     float* attn_out = nullptr;
     Ten* tap_dec_t = nullptr;
     for (int i = 0; i < c.dec_layers; ++i) {
@@ -1865,6 +2028,8 @@ struct s2st_engine {
     if (has_dec_ln) y = layernorm(y, dec_ln);
     Ten* feat = linear(y, feat_proj.w, feat_proj.b, c.out_dim, Cd, 0, 0.f, nullptr, outs.feat);
     Ten* eos = linear(y, eos_proj.w, eos_proj.b, 1, Cd, 0, 0.f, nullptr, outs.eos);
+    in_region_ = false;
+    if (live()) sync_chains();
     Ten* post = postnet(feat, B, D, tr, csp, outs.post_feat);
     // ---- mtl variant: CTC over the TARGET text on a decoder layer's output (s2st_loss_mtl.py:171-186: input lengths =
     //      decoder steps, targets = tgt_text incl. EOS) ------------------------------------------------------
@@ -2048,6 +2213,8 @@ struct s2st_engine {
     if (seg == 0) join_side();  // transposed weights (and anything else the forward left on the side stream)
     size_t hi = marks[ns - seg].tape_idx, lo = marks[ns - seg - 1].tape_idx;
     hipStream_t main_st = st_;
+    main_ = st_;
+    in_region_ = false;
     for (size_t i = hi; i-- > lo;) {
       if (aux_bwd_on_side && live()) {
         // the aux decoders' backward (CTC head + text decoders: many small kernels that only produce
@@ -2057,12 +2224,15 @@ struct s2st_engine {
         if (i + 1 == aux_lo_idx && st_ != main_st) { flush_wgrad(); flush_lnfold(); hipEventRecord(ev_auxb_, st_); st_ = main_st; }
         if (i + 1 == aux_wait_idx) wait_traced(main_st, ev_auxb_, "aux decoders' backward (tap gradients)");
       }
+      // (a closure that does not launch per chain itself sees everything the second chain did)
+      if (live() && !(i < tape_aware.size() && tape_aware[i])) sync_chains();
       tape[i]();
       if (err) break;
     }
     flush_wgrad();  // the segment's gradients are final once its launches are enqueued
     flush_lnfold();
     if (st_ != main_st) { hipEventRecord(ev_auxb_, st_); st_ = main_st; }
+    if (live()) sync_chains();  // (the caller's stream is the one the next segment / the optimizer continues on)
     // The segment's weight gradients live on the second stream.  A caller that overlaps the gradient
     // all-reduce waits on that stream itself (s2st_engine_side_stream); the data path only joins once,
     // after the last segment, so it never stalls behind the weight-gradient backlog.
@@ -2129,6 +2299,16 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
       e->side_ = nullptr;
     }
   }
+  // S2ST_CHAINS=2: the training step's layers as two utterance-half chains (see chain_count)
+  if (!cfg->precise && getenv("S2ST_CHAINS") && atoi(getenv("S2ST_CHAINS")) == 2) {
+    if (hipStreamCreateWithFlags(&e->chain1_, hipStreamNonBlocking) == hipSuccess &&
+        hipEventCreateWithFlags(&e->ev_cfork_, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&e->ev_cjoin_, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&e->ev_cside_, hipEventDisableTiming) == hipSuccess)
+      e->nchains = 2;
+    else { delete e; return S2ST_ERR_LAUNCH; }  // (asked for and not available: loud)
+  }
+  e->chains_one_stream = getenv("S2ST_CHAINS_ONE_STREAM") && atoi(getenv("S2ST_CHAINS_ONE_STREAM")) != 0;
   *out = e;
   return 0;
 }
@@ -2144,6 +2324,13 @@ void s2st_engine_destroy(s2st_engine* e) {
     if (e->ev_auxb_) hipEventDestroy(e->ev_auxb_);
     if (e->ev_kv_) hipEventDestroy(e->ev_kv_);
     for (hipEvent_t ev : e->adam_ev) hipEventDestroy(ev);
+  }
+  if (e->chain1_) {
+    hipStreamSynchronize(e->chain1_);
+    hipStreamDestroy(e->chain1_);
+    if (e->ev_cfork_) hipEventDestroy(e->ev_cfork_);
+    if (e->ev_cjoin_) hipEventDestroy(e->ev_cjoin_);
+    if (e->ev_cside_) hipEventDestroy(e->ev_cside_);
   }
   e->reset_call();
   delete e;

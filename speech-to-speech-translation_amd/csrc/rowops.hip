@@ -369,6 +369,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_fold_batched_kernel(s2st_ln
       a3 += f.part[(long)(b + 24) * ld + c];
     }
     for (; b < f.nblocks; b += 8) a0 += f.part[(long)b * ld + c];
+    if (f.part2) {  // the second chain's partial rows, behind the first chain's
+      float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+      b = ty;
+      for (; b + 24 < f.nblocks2; b += 32) {
+        e0 += f.part2[(long)b * ld + c];
+        e1 += f.part2[(long)(b + 8) * ld + c];
+        e2 += f.part2[(long)(b + 16) * ld + c];
+        e3 += f.part2[(long)(b + 24) * ld + c];
+      }
+      for (; b < f.nblocks2; b += 8) e0 += f.part2[(long)b * ld + c];
+      a0 += e0; a1 += e1; a2 += e2; a3 += e3;
+    }
   }
   red[ty][tx] = (a0 + a1) + (a2 + a3);
   __syncthreads();
@@ -587,10 +599,21 @@ int s2st_layernorm_bwd_fold(const s2st_lnfold_table& t, hipStream_t st) {
 }
 int s2st_fold_add(s2st_lnfold_table& t, const float* part, int nblocks, int cols, int nout, float* out0, float* out1,
                   float* out2) {
+  for (int j = 0; j < t.n; ++j) {
+    s2st_lnfold_item& e = t.item[j];
+    const bool shares = (out0 && (out0 == e.dgamma || out0 == e.dbeta || out0 == e.dbias)) ||
+                        (out1 && (out1 == e.dgamma || out1 == e.dbeta || out1 == e.dbias)) ||
+                        (out2 && (out2 == e.dgamma || out2 == e.dbeta || out2 == e.dbias));
+    if (!shares) continue;
+    // one output, two arrays of partial rows: the fold's "+=" is not atomic, so they become ONE entry
+    if (e.dgamma != out0 || e.dbeta != out1 || e.dbias != out2 || e.cols != cols || e.nout != nout || e.part2) return S2ST_ERR_ARG;
+    e.part2 = part; e.nblocks2 = nblocks;
+    return 0;
+  }
   if (t.n >= S2ST_LNFOLD_MAX) return S2ST_ERR_ARG;
   s2st_lnfold_item& f = t.item[t.n];
   f.part = part; f.dgamma = out0; f.dbeta = out1; f.dbias = out2;
-  f.nblocks = nblocks; f.cols = cols; f.nout = nout;
+  f.nblocks = nblocks; f.cols = cols; f.nout = nout; f.part2 = nullptr; f.nblocks2 = 0;
   t.blk0[t.n + 1] = t.blk0[t.n] + (nout * cols + 31) / 32;
   ++t.n;
   return 0;

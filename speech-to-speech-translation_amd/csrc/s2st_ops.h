@@ -105,7 +105,10 @@ int s2st_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
 int s2st_layernorm_bwd_blocks(int rows, int cols);  // scratch floats = blocks * (dph ? 3 : 2) * cols
 // column-sum partials of several layer-norm backward passes (phase 3 below), folded by ONE launch in a fixed order
 #define S2ST_LNFOLD_MAX 24
-struct s2st_lnfold_item { const float* part; float *dgamma, *dbeta, *dbias; int nblocks, cols, nout; };
+// (part2 / nblocks2: a second array of partial rows for the SAME outputs, summed behind the first -- the second
+//  utterance-half chain's partials, engine.cpp S2ST_CHAINS=2; s2st_fold_add attaches it by itself when the outputs of a
+//  new entry equal those of one already in the table, because two entries with one output would race in the fold)
+struct s2st_lnfold_item { const float* part; float *dgamma, *dbeta, *dbias; int nblocks, cols, nout; const float* part2; int nblocks2; };
 struct s2st_lnfold_table { int n; int blk0[S2ST_LNFOLD_MAX + 1]; s2st_lnfold_item item[S2ST_LNFOLD_MAX]; };
 int s2st_lnfold_add(s2st_lnfold_table& t, const float* part, int rows, int cols, int nout, float* dgamma, float* dbeta,
                     float* dbias);

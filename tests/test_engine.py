@@ -401,6 +401,52 @@ def test_grouped_weight_gradients_equal_single_launches(backend, switch, monkeyp
     test_fused_backward_paths_equal_the_unfused_ones(backend, cfg, switch, monkeypatch)
 
 
+@pytest.mark.parametrize("n_utts", [4, 3], ids=["even", "odd"])
+@pytest.mark.parametrize("postln", [False, True], ids=["preln_aux", "postln"])
+def test_two_utterance_half_chains_equal_one_chain(backend, postln, n_utts, monkeypatch):
+    """S2ST_CHAINS=2 (engine.cpp chain_count): the layers of the training step launched as two utterance-half chains over
+    the same whole-batch tensors.  With dropout off both schedules compute the same function row by row: same losses and
+    outputs, gradients equal up to the order of the partial-sum folds (and of the tile shapes the halves pick).  With
+    dropout on, chain 1's masks are salted: the step runs, repeats for a seed, and differs from the one-chain masks."""
+    D = importlib.import_module(DATA)
+    base = dict(MICRO_POSTLN if postln else MICRO, encoder_embed_dim=128, decoder_embed_dim=128, encoder_ffn_embed_dim=256,
+                decoder_ffn_embed_dim=256, encoder_attention_heads=2, decoder_attention_heads=2, prenet_dim=128, postnet_conv_dim=128)
+    c = D.SyntheticFisherCorpus(n_utts=n_utts, seed=3, max_src=64, median_src=50, min_src=30)
+    s = c.collate_batch(range(n_utts))
+
+    def run(chains, cfg, seed=9):
+        monkeypatch.setenv("S2ST_CHAINS", str(chains))
+        a, e = make_engine(backend, cfg, precise=False)
+        o = e.forward(s, training=True, seed=seed)
+        e.zero_grad()
+        e.backward(1.0)
+        backend.sync()
+        r = (o["stats"].clone(), o["feature_out"].clone(), o["post_feat_out"].clone(), e.grads.clone(),
+             {n: gv.clone() for n, pv, gv, isb in e.named_views() if not isb})
+        del e
+        return r
+
+    nodrop = dict(base, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, prenet_dropout=0.0, postnet_dropout=0.0)
+    s1, f1, p1, g1, v1 = run(1, nodrop)
+    s2, f2, p2, g2, v2 = run(2, nodrop)
+    assert torch.allclose(s1, s2, rtol=1e-5, atol=1e-6)
+    assert float((f1 - f2).abs().max()) <= 1e-5 * float(f1.abs().max())
+    assert float((p1 - p2).abs().max()) <= 1e-5 * float(p1.abs().max())
+    worst = sorted(((float((v1[n] - v2[n]).norm()), float(v1[n].norm()), n) for n in v1), reverse=True)[:8]
+    assert float((g1 - g2).norm()) <= 2e-5 * float(g1.norm()), worst
+    gmax = max(float(v.norm()) for v in v1.values())
+    for n in v1:
+        assert float((v1[n] - v2[n]).norm()) <= 1e-4 * (float(v1[n].norm()) + 1e-2 * gmax), n
+    if n_utts == 4 and not postln:
+        drop = dict(base, dropout=0.1, attention_dropout=0.1, activation_dropout=0.05, prenet_dropout=0.5, postnet_dropout=0.5)
+        a = run(2, drop)
+        b = run(2, drop)
+        one = run(1, drop)
+        assert abs(float(a[0][0]) - float(b[0][0])) < 1e-4 and float((a[3] - b[3]).norm()) <= 2e-5 * float(a[3].norm())
+        assert all(torch.isfinite(a[3])) if a[3].numel() < 1 else bool(torch.isfinite(a[3]).all())
+        assert float((a[3] - one[3]).norm()) > 1e-3 * float(one[3].norm())  # (chain 1's rows drew other masks)
+
+
 @pytest.mark.parametrize("cfg", [MICRO, MICRO_POSTLN], ids=["preln_aux", "postln"])
 def test_micro_engine_fast_mode_vs_oracle(backend, cfg):
     """Fast mode (bf16 copies of every GEMM operand, gemm_bf16.hip) against the fp32 oracle.

@@ -87,6 +87,45 @@ def test_step_is_a_function_of_the_seed(backend, workload):
     assert not _grad_close(g2, g0, 5e-2)
 
 
+def test_two_utterance_half_chains_at_full_size(backend, workload, monkeypatch):
+    """S2ST_CHAINS=2 on the benchmarked batch.  Dropout off: the same step as the one-chain schedule (forward outputs
+    row by row from the same arithmetic, gradients up to the order of the partial-sum folds).  Recipe dropouts: chain 1
+    draws its own masks, so the step is ANOTHER sample of the same random function -- it repeats bit for bit for a
+    seed, and its logged losses sit where other seeds of the one-chain schedule sit."""
+    _need_gpu(backend)
+    corpus, b = workload
+    s = corpus.collate_batch(b[0])
+
+    def run(chains, cfg, seeds):
+        monkeypatch.setenv("S2ST_CHAINS", str(chains))
+        a, e = _engine(backend, cfg)
+        out = []
+        for seed in seeds:
+            o = e.forward(s, training=True, seed=seed)
+            e.zero_grad()
+            e.backward(1.0)
+            backend.sync()
+            out.append((o["stats"].clone(), o["feature_out"].clone(), e.grads.clone()))
+        del e
+        return out
+
+    nd = dict(CONFIGS["base_recipe"], **NO_DROP)
+    (s1, f1, g1), = run(1, nd, [3])
+    (s2, f2, g2), = run(2, nd, [3])
+    assert torch.allclose(s1, s2, rtol=2e-6, atol=1e-6), (s1, s2)
+    assert float((f1 - f2).abs().max()) <= 1e-5 * float(f1.abs().max())
+    assert _rel(g2, g1) <= 2e-4, _rel(g2, g1)  # (bf16 operands of the backward emitted from differently ordered fp32 sums)
+    one = run(1, CONFIGS["base_recipe"], [11, 12, 13, 14])
+    two = run(2, CONFIGS["base_recipe"], [11, 11, 12])
+    assert torch.equal(two[0][0], two[1][0]) and torch.equal(two[0][2], two[1][2])
+    assert not torch.equal(two[0][2], one[0][2])
+    l1 = torch.stack([r[0][0] for r in one]).double()
+    l2 = torch.stack([two[0][0][0], two[2][0][0]]).double()
+    spread = float(l1.max() - l1.min())
+    assert float((l2 - l1.mean()).abs().max()) <= max(3.0 * spread, 2e-2 * float(l1.mean())), (l1, l2)
+    assert abs(_rel(two[0][2], one[0][2]) - _rel(one[1][2], one[0][2])) <= 0.5 * _rel(one[1][2], one[0][2])
+
+
 # normalisation of each logged loss (s2st_loss.py:179-292, reduction="mean"): masked frames for the
 # spectrogram / stop losses, utterances for CTC (nn.CTCLoss mean), text tokens for the aux decoders
 LOSS_WEIGHT = {"l1_loss": "ntokens", "mse_loss": "ntokens", "eos_loss": "ntokens", "ctc_loss": "nsentences",
