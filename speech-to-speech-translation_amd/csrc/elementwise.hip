@@ -484,16 +484,20 @@ __global__ __launch_bounds__(256) void conv_w_permute_tiled_kernel(const float* 
   }
 }
 
+// (slabs > 1: dwf is [slabs][O][Kw][I] -- partial sums over K ranges of the token axis, added in slab order)
 __global__ __launch_bounds__(256) void conv_w_unpermute_acc_kernel(const float* __restrict__ dwf,
                                                                    float* __restrict__ dw, int O,
-                                                                   int I, int Kw) {
+                                                                   int I, int Kw, int slabs) {
   long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x;
   long n = (long)O * I * Kw;
   if (i >= n) return;
   int j = (int)(i % Kw);
   int c = (int)((i / Kw) % I);
   int o = (int)(i / ((long)Kw * I));
-  dw[i] += dwf[((long)o * Kw + j) * I + c];
+  const long src = ((long)o * Kw + j) * I + c;
+  float v = dwf[src];
+  for (int sl = 1; sl < slabs; ++sl) v += dwf[sl * n + src];
+  dw[i] += v;
 }
 
 // ---- column reductions with a per-element functor returning two values ------------------
@@ -1033,10 +1037,10 @@ int s2st_conv_w_permute(const float* w, float* wf, float* wd, int O, int I, int 
   return LAUNCH_OK();
 }
 
-int s2st_conv_w_unpermute_acc(const float* dwf, float* dw, int O, int I, int Kw, hipStream_t st) {
+int s2st_conv_w_unpermute_acc(const float* dwf, float* dw, int O, int I, int Kw, hipStream_t st, int slabs) {
   long n = (long)O * I * Kw;
   if (n <= 0) return 0;
-  S2ST_LAUNCH(conv_w_unpermute_acc_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, dwf, dw, O, I, Kw);
+  S2ST_LAUNCH(conv_w_unpermute_acc_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, dwf, dw, O, I, Kw, slabs < 1 ? 1 : slabs);
   return LAUNCH_OK();
 }
 

@@ -624,6 +624,9 @@ struct s2st_engine {
   // ------------------------------------------------------------------------------------
   // weight-gradient GEMMs waiting for their group launch (S2ST_NO_WGRAD_GROUP=1: A/B switch, one launch each)
   bool group_wgrad = true;
+  int conv_wgrad_group = 0;  // (default 0: measured 7.30 - 7.33 / 7.30 - 7.35 / 7.38 - 7.40 ms per step, profiles/r05_conv_wgrad_ab.txt)
+                             // S2ST_CONV_WGRAD_GROUP=0/1/2: convolution weight gradients as split-row products / in the grouped
+                             // launch for stride-1 layers whose input takes a gradient (the image exists anyway) / for all
   int group_flush_at = 6;  // S2ST_WGRAD_GROUP=<n>: problems per launch (<= S2ST_GROUP_MAX); measured 2 .. 8 on the bench
                            // workload: 12.25 / 10.99 / 10.56 / 10.44 / 10.46 ms per step for 2 / 3 / 4 / 6 / 8
   std::vector<GemmArgs> pending_wgrad;
@@ -1264,47 +1267,100 @@ struct s2st_engine {
       const bf16raw* dzh = fm ? ghalf_of(z) : nullptr;
       // (fixed-order bias sums: a convolution bias in front of BatchNorm has a mathematically zero gradient)
       float* cpart = ordered_sums ? alloc(s2st_colsum_scratch_floats(M, pp.O)) : nullptr;
+      const bool no_dgrad = !(in2.src && in2.src->needs_grad);
+      // dz placed at rows pad + stride*t of a zeroed [B][Tin + 2 pad][O] image: the data gradient's operand (a stride-1
+      // correlation with flipped taps) and, round 5, the weight gradient's -- fast mode builds it directly in bf16 from
+      // dz's bf16 twin (no fp32 image, no cast pass)
+      const bool direct = fm && pp.O % 8 == 0;
+      // Weight gradient over WHOLE halo-image rows: with R the flat row index of the images,
+      //   dWf[o][(j, c)] = sum_R up[R][o] * xh[R - pad + j][c]
+      // -- the rows of `up` that hold no dz (halos, the odd rows of a stride-2 image) are zero, and a row that does hold one
+      // reads xh rows of its own utterance only -- is a plain [K = rows][O]^T x [K][Kw * I] product (second operand: rows
+      // of Kw * I elements at a pitch of I, overlapping): no per-utterance row splits, so it qualifies for the grouped
+      // LDS-DMA launch of the linear layers' weight gradients (K unsplit: no slabs, no combine kernel).  K runs over rows
+      // [pad, B * Th - pad): both operands stay inside their images.  S2ST_CONV_WGRAD_GROUP=0: the per-utterance
+      // split-row product of rounds 1 - 4 (A/B switch).
+      GemmArgs gw{};
+      bool grouped = false;
+      // (K = all image rows stays in ONE launch, but a product of few 128 x 128 output tiles is cut into K ranges -- one
+      //  problem of the group each, its own fp32 slab, plain stores -- until the launch has a tile per CU; the layout pass
+      //  that adds the result into the parameter's [O][I][Kw] gradient sums the slabs in order)
+      int kslabs = 1, kchunk = 0;
+      float* wslab = nullptr;
+      const long wn = (long)pp.O * pp.I * pp.Kw;
+      if (fm && direct && group_wgrad && in2.xhh && (long)B * Th > 2L * pad &&
+          (conv_wgrad_group >= 2 || (conv_wgrad_group == 1 && stride == 1 && !no_dgrad))) {
+        gw.A = gemm_colmajor((const bf16raw*)nullptr, pp.O);
+        gw.B = gemm_colmajor(in2.xhh, pp.I);
+        gw.C = gemm_out(dwf, (long)pp.Kw * pp.I);
+        gw.ep = gemm_epi_default();
+        gw.M = pp.O; gw.N = pp.Kw * pp.I; gw.K = B * Th - 2 * pad; gw.batch = 1; gw.zdiv = 1; gw.precise = c.precise;
+        GemmArgs probe = gw;
+        probe.A.p = in2.xhh;  // (any aligned pointer: the image is allocated below)
+        grouped = s2st_gemm_group_ok(probe);
+        if (grouped) {
+          const long tiles = (long)((gw.M + 127) / 128) * ((gw.N + 127) / 128);
+          long want = (256 + tiles - 1) / tiles, most = gw.K / 1024;
+          if (most < 1) most = 1;
+          if (want > most) want = most;
+          if (want > 16) want = 16;
+          kchunk = (int)(((gw.K + want - 1) / want + 63) / 64 * 64);
+          kslabs = (gw.K + kchunk - 1) / kchunk;
+          wslab = alloc(kslabs * wn);
+        }
+      }
+      const bool need_img = grouped || !no_dgrad;
+      float* up = (need_img && !direct) ? alloc((long)B * Th * pp.O, true) : nullptr;
+      bf16raw* upd = (need_img && direct) ? alloc_h((long)B * Th * pp.O) : nullptr;
+      if (need_img && live()) {
+        Split xs{(long)pp.O, 0, 0, 0};
+        Split ys{(long)stride * pp.O, (long)Th * pp.O, Tout, 0};
+        if (direct) {
+          chk(s2st_halo_image_bf16(dzh, z->hld(), upd, B, Tout, Th, pp.O, pad, stride, st_));
+        } else {
+          chk(s2st_copy_rows(z->g, xs, up + (long)pad * pp.O, ys, M, pp.O, st_));
+        }
+      }
       if (live()) {
-        GemmArgs g{};  // dWf[O][(j,c)] += sum_(b,t) dz[(b,t)][o] * xh[b][t*stride + j][c]
-        g.A = fm ? gemm_colmajor(dzh, z->hld()) : gemm_colmajor(z->g, pp.O);
-        g.B = fm ? gemm_colmajor(in2.xhh, (long)stride * pp.I) : gemm_colmajor(in2.xh, (long)stride * pp.I);
-        g.B.sp.per = Tout; g.B.sp.bs = (long)Th * pp.I;
-        g.C = gemm_out(dwf, (long)pp.Kw * pp.I);
-        g.ep = gemm_epi_default();
-        g.ep.accumulate = 1;
         // parameter gradients only: on the second stream, next to the data-gradient chain -- except for a convolution
         // whose input needs no gradient (the model's first one = the LAST closure of the backward): no data-gradient
         // chain is left, the data-path stream would only wait, so it takes the product and the second stream the bias sum
-        const bool no_dgrad = !(in2.src && in2.src->needs_grad);
         hipStream_t side_st = fm ? fork_side() : st_;
         hipStream_t ws_st = (fm && !(no_dgrad && conv_tail_on_main)) ? side_st : st_;
-        g.ws = ws_for(ws_st); g.ws_floats = skws_n;
-        g.M = pp.O; g.N = pp.Kw * pp.I; g.K = M; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
-        chk(s2st_gemm(g, ws_st));
+        if (grouped) {
+          for (int sl = 0; sl < kslabs; ++sl) {
+            GemmArgs gs = gw;
+            const long k0 = (long)sl * kchunk;
+            gs.A.p = upd + ((long)pad + k0) * pp.O;
+            gs.B.p = in2.xhh + k0 * pp.I;
+            gs.C.p = wslab + sl * wn;
+            gs.K = (int)(gw.K - k0 < kchunk ? gw.K - k0 : kchunk);
+            push_wgrad(gs);
+          }
+          flush_wgrad();  // (the layout pass below reads the slabs: the launch cannot wait for the segment's end)
+          ws_st = side_ ? side_ : st_;
+        } else {
+          GemmArgs g{};  // dWf[O][(j,c)] += sum_(b,t) dz[(b,t)][o] * xh[b][t*stride + j][c]
+          g.A = fm ? gemm_colmajor(dzh, z->hld()) : gemm_colmajor(z->g, pp.O);
+          g.B = fm ? gemm_colmajor(in2.xhh, (long)stride * pp.I) : gemm_colmajor(in2.xh, (long)stride * pp.I);
+          g.B.sp.per = Tout; g.B.sp.bs = (long)Th * pp.I;
+          g.C = gemm_out(dwf, (long)pp.Kw * pp.I);
+          g.ep = gemm_epi_default();
+          g.ep.accumulate = 1;
+          g.ws = ws_for(ws_st); g.ws_floats = skws_n;
+          g.M = pp.O; g.N = pp.Kw * pp.I; g.K = M; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
+          chk(s2st_gemm(g, ws_st));
+        }
         {
           int slabs = 0;
           chk(s2st_colsum(z->g, pp.O, M, pp.O, G + pp.b, 1, side_st, cpart, cpart ? &slabs : nullptr));
           if (cpart) add_fold(cpart, slabs, pp.O, G + pp.b);
         }
-        chk(s2st_conv_w_unpermute_acc(dwf, G + pp.w, pp.O, pp.I, pp.Kw, ws_st));
+        chk(s2st_conv_w_unpermute_acc(grouped ? wslab : dwf, G + pp.w, pp.O, pp.I, pp.Kw, ws_st, grouped ? kslabs : 1));
       }
-      if (in2.src && in2.src->needs_grad) {
-        // dz placed at rows pad + stride*t of a zeroed [B][Tin + 2 pad][O] image
-        // fast mode builds the image directly in bf16 from dz's bf16 twin (no fp32 image, no cast pass)
-        const bool direct = fm && pp.O % 8 == 0;
-        float* up = direct ? nullptr : alloc((long)B * Th * pp.O, true);
-        bf16raw* upd = direct ? alloc_h((long)B * Th * pp.O) : nullptr;
+      if (!no_dgrad) {
         bool acc;
         float* dx = gradbuf(in2.src, acc);
-        if (live()) {
-          Split xs{(long)pp.O, 0, 0, 0};
-          Split ys{(long)stride * pp.O, (long)Th * pp.O, Tout, 0};
-          if (direct) {
-            chk(s2st_halo_image_bf16(dzh, z->hld(), upd, B, Tout, Th, pp.O, pad, stride, st_));
-          } else {
-            chk(s2st_copy_rows(z->g, xs, up + (long)pad * pp.O, ys, M, pp.O, st_));
-          }
-        }
         const bf16raw* uph = direct ? upd : (fm ? cast_buf(up, (long)B * Th * pp.O) : nullptr);
         if (live()) {
           GemmArgs g{};  // dx[(b,u)][c] = sum_(j',o) up[b][u + j'][o] * Wd[c][j'][o]
@@ -2262,6 +2318,7 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   e->use_flash = !(getenv("S2ST_NO_FLASH") && atoi(getenv("S2ST_NO_FLASH")) != 0);
   e->transpose_each = getenv("S2ST_TRANSPOSE_EACH") && atoi(getenv("S2ST_TRANSPOSE_EACH")) != 0;
   e->group_wgrad = !(getenv("S2ST_NO_WGRAD_GROUP") && atoi(getenv("S2ST_NO_WGRAD_GROUP")) != 0);
+  if (getenv("S2ST_CONV_WGRAD_GROUP")) e->conv_wgrad_group = atoi(getenv("S2ST_CONV_WGRAD_GROUP"));
   if (getenv("S2ST_WGRAD_GROUP")) {
     e->group_flush_at = atoi(getenv("S2ST_WGRAD_GROUP"));
     if (e->group_flush_at < 1) e->group_flush_at = 1;

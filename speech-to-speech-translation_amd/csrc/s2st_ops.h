@@ -231,7 +231,7 @@ int s2st_scale(float* x, long n, float a, hipStream_t st);
 int s2st_conv_w_permute(const float* w, float* wf, float* wd, int O, int I, int Kw, hipStream_t st,
                         uint16_t* wfh = nullptr, uint16_t* wdh = nullptr /* optional bf16 twins */);
 // dW[O][I][Kw] += dWf[O][Kw][I]
-int s2st_conv_w_unpermute_acc(const float* dwf, float* dw, int O, int I, int Kw, hipStream_t st);
+int s2st_conv_w_unpermute_acc(const float* dwf, float* dw, int O, int I, int Kw, hipStream_t st, int slabs = 1);
 // BatchNorm1d in training mode over [rows][C] (rows = ALL B*T positions, padded included,
 // tacotron2.py:122-126): two-pass statistics + running-stat update; tmp = 2*C floats
 int s2st_bn_stats(const float* x, int rows, int C, float* mean, float* var, float* run_mean,

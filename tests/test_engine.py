@@ -352,7 +352,7 @@ def test_fused_backward_paths_equal_the_unfused_ones(backend, cfg, switch, monke
     # the GPU run, where every combination executes: the CPU suite stays within minutes)
     if backend.kind == "emu" and switch not in ("S2ST_NO_LN_FUSE", "S2ST_NO_ACT_FUSE", "S2ST_ATTN_GFUSE=0", "S2ST_ATTN_GFUSE=3",
                                                 "S2ST_LN_BWD_SPLIT", "S2ST_NO_WGRAD_GROUP", "S2ST_ORDERED_BIAS_SUMS=0",
-                                                "S2ST_ATTN_DVEC_KERNEL"):
+                                                "S2ST_ATTN_DVEC_KERNEL", "S2ST_CONV_WGRAD_GROUP=2"):
         pytest.skip("launch-structure switch: covered by the GPU run")
     if backend.kind == "emu" and cfg is MICRO_POSTLN and switch not in ("S2ST_NO_LN_FUSE", "S2ST_LN_BWD_SPLIT"):
         pytest.skip("post-LN layers differ from pre-LN ones in where the layer norms sit: their two switches run here, "
@@ -391,7 +391,8 @@ def test_fused_backward_paths_equal_the_unfused_ones(backend, cfg, switch, monke
         assert float((v0[n] - v1[n]).norm()) <= tol * 1e-4 * (float(v0[n].norm()) + 1e-2 * gmax), n
 
 
-@pytest.mark.parametrize("switch", ["S2ST_NO_WGRAD_GROUP", "S2ST_GEMM_PERSIST=0", "S2ST_GEMM_PERSIST=2", "S2ST_WGRAD_GROUP=8"])
+@pytest.mark.parametrize("switch", ["S2ST_NO_WGRAD_GROUP", "S2ST_GEMM_PERSIST=0", "S2ST_GEMM_PERSIST=2", "S2ST_WGRAD_GROUP=8",
+                                    "S2ST_CONV_WGRAD_GROUP=2"])
 def test_grouped_weight_gradients_equal_single_launches(backend, switch, monkeypatch):
     """128-wide layers, so that the weight-gradient products qualify for the grouped persistent launch (one launch
     per <= 4 products, K = tokens unsplit) and the larger forward products for the persistent kernel: same
