@@ -971,7 +971,7 @@ void mark_fast_epilogue(GemmArgs& g) {
   const bool h16 = !g.C.h || ((uintptr_t)g.C.h % 16 == 0 && g.C.sp.ld % 8 == 0 && g.C.sp.bs % 8 == 0 && g.C.zo % 8 == 0 &&
                               g.C.zi % 8 == 0 && g.N % 8 == 0);
   if (g.cvec && g.N >= 4 && g.N % 4 == 0 && g.M >= 1 && g.splitk == 1 && !g.slab && !g.ep.mask_y && !g.ep.colsum && !g.ep.colsum_part &&
-      g.ep.act != 2 && combo && h16 && (g.C.p || g.C.h) && (!accu || g.C.p))
+      (g.ep.act != 2 || (!drop && !accu)) && combo && h16 && (g.C.p || g.C.h) && (!accu || g.C.p))
     g.cvec |= 2;
   // bit 3: the masked data-gradient form (bf16 output only, nothing else in the epilogue but the column sums)
   if (g.cvec && g.ep.mask_y && g.C.h && !g.C.p && h16 && g.N >= 8 && g.M >= 1 && g.splitk == 1 && !g.slab && !g.ep.bias &&
@@ -1027,7 +1027,14 @@ int w4_pick(const GemmArgs& g, bool dma_ok) {
   if (mode < 0 && t128 < data_cus()) return 0;
   const long s128 = 2L * data_cus(), s64 = 3L * data_cus();
   const double e128 = (double)t128 / (double)(((t128 + s128 - 1) / s128) * s128);
-  const double e64 = (double)t64 / (double)(((t64 + s64 - 1) / s64) * s64);
+  double e64 = (double)t64 / (double)(((t64 + s64 - 1) / s64) * s64);
+  // (tuning aid, read per call: S2ST_W4_E64=<factor on the 128 x 64 form's fill>)
+  if (const char* ev = getenv("S2ST_W4_E64")) e64 *= atof(ev);
+  // Round 5: many rounds of long K-loops are priced by the steady state, not by the last round's fill -- per flop the
+  // 128 x 128 tile needs 2/3 of the LDS reads of the 128 x 64 one.  HuBERT's conv stack (307 k / 154 k rows x 512 x 1536):
+  // 632 vs 750 us and 342 vs 402 us, where the fill rule took 128 x 64 (25.0 full rounds against 18.75);
+  // tools/conv_forms_bench.py, profiles/r05_hubert_forms.txt.  (The training step's products have < 4 rounds: unchanged.)
+  else if (g.N > 64 && g.K >= 1024 && t128 >= 4 * s128) return 128;
   return (g.N > 64 && e128 >= e64) ? 128 : 64;
 }
 

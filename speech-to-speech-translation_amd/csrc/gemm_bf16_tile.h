@@ -166,7 +166,7 @@ struct Stage {
 // stores.  The general epilogue below tests ~12 kernel-argument conditions per block: measured with in-kernel clock
 // stamps (tools/gemm_stamp.sh) it took 5.3 k cycles per 128 x 128 tile with a bf16 output alone and 15.9 k with bias +
 // residual -- as long as the whole K-loop of a K = 512 product (7.6 k).
-template <int BM, int BN, int WGN, bool DROP, bool RESID, bool ACC, bool HASC, bool HASH, bool H16>
+template <int BM, int BN, int WGN, bool DROP, bool RESID, bool ACC, bool HASC, bool HASH, bool H16, bool GELU = false>
 __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, f32x4 (&acc)[BM / 32][BN / (16 * WGN)], int m0, int n0,
                                                    int wm, int wn, int lane, int zb, int zq, int zr,
                                                    const float4 (*pre)[BN / (16 * WGN)]) {
@@ -228,6 +228,10 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, f32x4 (&ac
     for (int j = 0; j < TN; ++j) {
       float v[4] = {fmaxf(alpha * acc[i][j][0] + b4[j].x, lo), fmaxf(alpha * acc[i][j][1] + b4[j].y, lo),
                     fmaxf(alpha * acc[i][j][2] + b4[j].z, lo), fmaxf(alpha * acc[i][j][3] + b4[j].w, lo)};
+      if (GELU) {  // (act == 2: lo is -inf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_fast(v[r]);
+      }
       if (DROP) {
         const uint64_t e0 = ((uint64_t)zb * M + mrow[i]) * (uint64_t)N + ncol[j];
 #pragma unroll
@@ -355,7 +359,7 @@ __device__ __forceinline__ void gemm_epilogue_fast_masky(const GemmArgs& g, f32x
 
 // output forms that exist: fp32 only; bf16 only / fp32 + bf16 with the 16-byte bf16 stores (the launcher marks a product
 // fast only if its bf16 copy qualifies for them); accumulate only into an fp32-only output (weight gradients)
-template <int BM, int BN, int WGN, bool DROP, bool RESID, bool ACC>
+template <int BM, int BN, int WGN, bool DROP, bool RESID, bool ACC, bool GELU = false>
 __device__ __forceinline__ void gemm_epilogue_fast_out(const GemmArgs& g, f32x4 (&acc)[BM / 32][BN / (16 * WGN)], int m0, int n0,
                                                        int wm, int wn, int lane, int zb, int zq, int zr,
                                                        const float4 (*pre)[BN / (16 * WGN)]) {
@@ -363,9 +367,9 @@ __device__ __forceinline__ void gemm_epilogue_fast_out(const GemmArgs& g, f32x4 
   if constexpr (ACC) {
     gemm_epilogue_fast<BM, BN, WGN, DROP, RESID, ACC, true, false, false>(g, acc, m0, n0, wm, wn, lane, zb, zq, zr, pre);
   } else {
-    if (g.C.p && g.C.h) gemm_epilogue_fast<BM, BN, WGN, DROP, RESID, ACC, true, true, PAIRS>(g, acc, m0, n0, wm, wn, lane, zb, zq, zr, pre);
-    else if (g.C.p) gemm_epilogue_fast<BM, BN, WGN, DROP, RESID, ACC, true, false, false>(g, acc, m0, n0, wm, wn, lane, zb, zq, zr, pre);
-    else gemm_epilogue_fast<BM, BN, WGN, DROP, RESID, ACC, false, true, PAIRS>(g, acc, m0, n0, wm, wn, lane, zb, zq, zr, pre);
+    if (g.C.p && g.C.h) gemm_epilogue_fast<BM, BN, WGN, DROP, RESID, ACC, true, true, PAIRS, GELU>(g, acc, m0, n0, wm, wn, lane, zb, zq, zr, pre);
+    else if (g.C.p) gemm_epilogue_fast<BM, BN, WGN, DROP, RESID, ACC, true, false, false, GELU>(g, acc, m0, n0, wm, wn, lane, zb, zq, zr, pre);
+    else gemm_epilogue_fast<BM, BN, WGN, DROP, RESID, ACC, false, true, PAIRS, GELU>(g, acc, m0, n0, wm, wn, lane, zb, zq, zr, pre);
   }
 }
 
@@ -392,6 +396,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
   }
   if (g.cvec & 2) {  // (launcher, mark_fast_epilogue: aligned, N % 4 == 0, no split-K / slab / output mask / column sums / GELU)
     const bool drop = g.ep.drop_p > 0.f, res = g.ep.resid != nullptr, accu = g.ep.accumulate != 0;
+    if (g.ep.act == 2) {  // (launcher: GELU only without dropout / accumulation -- the frozen HuBERT front end's products)
+      if (res) gemm_epilogue_fast_out<BM, BN, WGN, false, true, false, true>(g, acc, m0, n0, wm, wn, lane, zb, zq, zr, pre);
+      else gemm_epilogue_fast_out<BM, BN, WGN, false, false, false, true>(g, acc, m0, n0, wm, wn, lane, zb, zq, zr, pre);
+    } else
     if (!drop && !res && !accu) gemm_epilogue_fast_out<BM, BN, WGN, false, false, false>(g, acc, m0, n0, wm, wn, lane, zb, zq, zr, pre);
     else if (!drop && res && !accu) gemm_epilogue_fast_out<BM, BN, WGN, false, true, false>(g, acc, m0, n0, wm, wn, lane, zb, zq, zr, pre);
     else if (!drop && !res && accu) gemm_epilogue_fast_out<BM, BN, WGN, false, false, true>(g, acc, m0, n0, wm, wn, lane, zb, zq, zr, pre);
@@ -464,7 +472,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
       } else if (g.ep.act == 2) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_fast(v[r]);  // (as the fast forms: a result must not depend on the form)
       }
       if (g.ep.drop_p > 0.f) {
         const uint64_t e0 = ((uint64_t)zb * g.M + m) * (uint64_t)g.N + n;

@@ -59,6 +59,24 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // exact GELU (nn.GELU(), fairseq utils.gelu: 0.5 x (1 + erf(x / sqrt 2)))
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// The same function for the bf16-operand kernels' epilogues (HuBERT's conv stack and FFN: 670 M evaluations per 24 x 8 s
+// batch, where libm's branchy erff was ~0.6 ms of a 6.9 ms forward): erfc(|z|) = t (a1 + t (a2 + t (a3 + t (a4 + t a5))))
+// exp(-z^2), t = 1 / (1 + p |z|) (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 -- fp32's own epsilon; results are rounded
+// to bf16 or feed bf16 operands), composed so that the negative tail has no 1 - erf cancellation:
+// gelu(x) = x >= 0 ? x - 0.5 x erfc(z) : 0.5 x erfc(-z).  One v_rcp, one v_exp, eight multiply-adds, no branch.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+  const float az = fabsf(x) * 0.70710678118654752f;
+  const float t = __frcp_rn(1.f + 0.3275911f * az);
+  const float e = __expf(-az * az);
+  float q = 1.061405429f;
+  q = q * t - 1.453152027f;
+  q = q * t + 1.421413741f;
+  q = q * t - 0.284496736f;
+  q = q * t + 0.254829592f;
+  q = q * t * e;                 // erfc(|z|)
+  const float r = 0.5f * x * q;  // sign of x
+  return x >= 0.f ? x - r : r;
+}
 
 // Counter-based dropout RNG: keep(element) is a pure function of (seed, element index), so
 // the backward pass regenerates the forward mask without storing it.

@@ -238,6 +238,10 @@ class HubertFrontend:
         need = self._plan[key]
         if self.workspace is None or self.workspace.numel() < need:
             self.workspace = torch.empty(need, dtype=torch.float32, device=self.device)
+        # frozen weights: the engine's bf16 copy stays valid while nobody wrote the parameter tensor (or a view of it)
+        if self.params_bf16 is not None and getattr(self, "_ph_version", None) == self.params._version:
+            self.lib.s2st_engine_bf16_is_fresh(self.h)
+        self._ph_version = self.params._version
         bd.check(self.lib.s2st_hubert_forward(self.h, wave.data_ptr(), lens.data_ptr(), B, N, out.data_ptr(),
                                               self.workspace.data_ptr(), self.workspace.numel(),
                                               C.c_void_p(bd.stream_ptr())), "s2st_hubert_forward")

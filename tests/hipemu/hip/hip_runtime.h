@@ -112,6 +112,7 @@ static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); re
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __fdividef(float a, float b) { return a / b; }
 #define __expf(x) expf(x)
+#define __frcp_rn(x) (1.0f / (x))
 #define __logf(x) logf(x)
 
 // ---- MFMA: v_mfma_f32_16x16x32_bf16 ---------------------------------------------------------

@@ -1,0 +1,63 @@
+"""HuBERT's transformer products by GEMM form in isolation (bias, bf16 result only; fc1 with GELU; out / fc2 with an fp32
+residual and fp32 + bf16 results).   python tools/linear_forms_bench.py [M]"""
+import importlib, os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+bd = importlib.import_module("speech-to-speech-translation_amd.runtime.binding")
+bd.load_library(bd.DEFAULT_LIB, emulator=False)
+d = torch.device("cuda:0")
+_lib = bd.lib()
+_lib.s2st_profile_enable.argtypes = [C.c_int32]
+_lib.s2st_profile_report.argtypes = [C.c_char_p, C.c_int64]
+_lib.s2st_profile_report.restype = C.c_int64
+FORMS = [("auto", {}), ("W4 128x64", {"S2ST_GEMM_P4": "0", "S2ST_W4_E64": "100"}), ("W4 128x128", {"S2ST_GEMM_P4": "0", "S2ST_W4_E64": "0.01"}),
+         ("ring", {"S2ST_GEMM_P4": "0", "S2ST_GEMM_W4": "0"}), ("P4 forced", {"S2ST_GEMM_TILE": "256x256"})]
+KEYS = sorted({k for _, e in FORMS for k in e})
+
+
+def setenv(e):
+    for k in KEYS:
+        os.environ.pop(k, None)
+    os.environ.update(e)
+
+
+def run(M, N, K, act, resid, reps=8):
+    g = torch.Generator().manual_seed(1)
+    A = (torch.rand(M, K, generator=g) * 2 - 1).bfloat16().to(d)
+    W = ((torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5).bfloat16().to(d)
+    kw = dict(a_kmajor=True, b_kmajor=True, a_ld=K, b_ld=K, bias=torch.randn(N, device=d), act=act,
+              c_bf16=torch.zeros(M, N, dtype=torch.bfloat16, device=d))
+    Cc = None
+    if resid:
+        kw["resid"] = torch.randn(M, N, device=d)
+        Cc = torch.zeros(M, N, device=d)
+    out = []
+    for name, env in FORMS:
+        setenv(env)
+        tile = bd.gemm(A, W, Cc, M, N, K, return_tile=True, **kw)
+        for _ in range(2):
+            bd.gemm(A, W, Cc, M, N, K, **kw)
+        torch.cuda.synchronize()
+        _lib.s2st_profile_enable(1)
+        for _ in range(reps):
+            bd.gemm(A, W, Cc, M, N, K, **kw)
+        torch.cuda.synchronize()
+        _lib.s2st_profile_enable(0)
+        buf = C.create_string_buffer(1 << 16)
+        n = _lib.s2st_profile_report(buf, len(buf))
+        tot = cnt = 0
+        tag = ""
+        for line in buf.raw[:max(n, 0)].decode().splitlines():
+            f = line.split("\t"); cnt += int(f[1]); tot += float(f[2]); tag = f[0]
+        us = tot / max(cnt, 1)
+        out.append("%-11s %7.1f us %5.0f TF/s %s %s" % (name, us, 2.0 * M * N * K / us / 1e6, tile, tag.split("<")[0][-20:]))
+    setenv({})
+    return out
+
+
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 9576
+for (N, K, act, resid, label) in ((2304, 768, 0, False, "qkv"), (768, 768, 0, True, "out"), (3072, 768, 2, False, "fc1 (gelu)"),
+                                  (768, 3072, 0, True, "fc2"), (768, 512, 0, False, "proj"), (512, 1024, 2, False, "conv5-like")):
+    print("== %s  %d x %d x %d" % (label, M, N, K))
+    for r in run(M, N, K, act, resid):
+        print("   " + r)
