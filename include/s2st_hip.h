@@ -61,6 +61,8 @@ typedef struct {
    * to colsum_part[(2 * tile_m + wave_m) * N + n] -- 2 * ceil(M / tile rows) partial rows (the tile rows come back from
    * s2st_gemm_f32_tile), folded in index order by the caller: run-to-run identical sums */
   float* colsum_part;
+  /* batched products: the bias of batch z is bias + (z / zdiv) * bias_zo (0: one bias for all) */
+  int64_t bias_zo;
 } s2st_gemm_epilogue;
 
 typedef struct {

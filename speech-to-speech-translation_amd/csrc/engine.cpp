@@ -1800,7 +1800,11 @@ struct s2st_engine {
     Ten* x2 = newT(B * T, E);
     if (live()) {
       chk(s2st_posconv_prep(x->d, frame_lens, img, imgh, B, T, E, G, pad, Tp, st_));
-      for (int gi = 0; gi < G; ++gi) {
+      // the G groups as ONE batched product (round 5: 16 launches of 150 tiles each -- a third of the CUs -- took 515 us of
+      // the 5.8 ms forward): group z reads its image and its [Eg][kp * Eg] weights, writes columns [z Eg, (z + 1) Eg) of x2
+      // (bias and residual follow the columns); S2ST_POSCONV_EACH=1: one launch per group (A/B switch)
+      static const bool each = getenv("S2ST_POSCONV_EACH") && atoi(getenv("S2ST_POSCONV_EACH")) != 0;
+      for (int gi = 0; gi < (each ? G : 1); ++gi) {
         GemmArgs g{};
         const long io = (long)gi * B * Tp * Eg, wo = hp.pos_w + (long)gi * Eg * kp * Eg;
         g.A = fm ? gemm_rowmajor(imgh + io, Eg) : gemm_rowmajor(img + io, Eg);
@@ -1812,6 +1816,10 @@ struct s2st_engine {
         g.ep.act = 2;
         g.ep.resid = x->d + (long)gi * Eg;
         g.M = B * T; g.N = Eg; g.K = kp * Eg; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
+        if (!each) {
+          g.batch = G;
+          g.A.zo = (long)B * Tp * Eg; g.B.zo = (long)Eg * kp * Eg; g.C.zo = Eg; g.ep.bias_zo = Eg;
+        }
         chk(s2st_gemm(g, st_));
       }
     }

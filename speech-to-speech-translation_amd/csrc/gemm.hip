@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         int n = n0 + wn * WN + j * 16 + (lane & 15);
         if (n >= g.N) continue;
         float v = g.ep.alpha * acc[i][j][r];
-        if (g.ep.bias && lead) v += g.ep.bias[n];
+        if (g.ep.bias && lead) v += g.ep.bias[zq * g.ep.bias_zo + n];
         if (g.ep.act == 1) v = fmaxf(v, 0.f);
         else if (g.ep.act == 2) v = gelu_erf(v);
         if (g.ep.drop_p > 0.f)

@@ -954,7 +954,7 @@ bool prep_flags(GemmArgs& g) {
   g.avec = g.bvec = vec ? 1 : 0;
   g.cvec = ((!g.C.p || (uintptr_t)g.C.p % 16 == 0) && (!g.C.h || (uintptr_t)g.C.h % 8 == 0) &&
             g.C.sp.ld % 4 == 0 && g.C.sp.bs % 4 == 0 && g.C.zo % 4 == 0 && g.C.zi % 4 == 0 &&
-            (!g.ep.resid || (uintptr_t)g.ep.resid % 16 == 0) && (!g.ep.bias || (uintptr_t)g.ep.bias % 16 == 0))
+            (!g.ep.resid || (uintptr_t)g.ep.resid % 16 == 0) && (!g.ep.bias || ((uintptr_t)g.ep.bias % 16 == 0 && g.ep.bias_zo % 4 == 0)))
                ? 1 : 0;
   return vec;
 }

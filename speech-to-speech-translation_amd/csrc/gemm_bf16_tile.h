@@ -190,8 +190,9 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, f32x4 (&ac
     b4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (g.ep.bias) {
+    const float* bias = g.ep.bias + zq * g.ep.bias_zo;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) b4[j] = *reinterpret_cast<const float4*>(g.ep.bias + ncol[j]);
+    for (int j = 0; j < TN; ++j) b4[j] = *reinterpret_cast<const float4*>(bias + ncol[j]);
   }
   long roff[TM];
   int mrow[TM];
@@ -459,12 +460,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
         }
       }
       if (g.ep.bias && lead) {
+        const float* bias = g.ep.bias + zq * g.ep.bias_zo;
         if (full) {
-          const float4 b4 = *reinterpret_cast<const float4*>(g.ep.bias + n);
+          const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
           v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
         } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) if (n + r < g.N) v[r] += g.ep.bias[n + r];
+          for (int r = 0; r < 4; ++r) if (n + r < g.N) v[r] += bias[n + r];
         }
       }
       if (g.ep.act == 1) {

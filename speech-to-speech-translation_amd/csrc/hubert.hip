@@ -91,7 +91,9 @@ __global__ __launch_bounds__(256) void hubert_conv0_gn_kernel(const float* __res
           acq[e] = fmaf(d, d, acq[e]);
         }
       } else {
-        const float o0 = gelu_erf((a[0] - mu[0]) * sc[0] + sh[0]), o1 = gelu_erf((a[1] - mu[1]) * sc[1] + sh[1]);
+        // (MODE 3 = MODE 2 with the epilogues' branch-free erf, s2st_common.h: the bf16-only output of fast mode)
+        const float u0 = (a[0] - mu[0]) * sc[0] + sh[0], u1 = (a[1] - mu[1]) * sc[1] + sh[1];
+        const float o0 = MODE == 3 ? gelu_erf_fast(u0) : gelu_erf(u0), o1 = MODE == 3 ? gelu_erf_fast(u1) : gelu_erf(u1);
         const long o = ((long)b * T + t0 + t) * C + c0;
         if (y) *reinterpret_cast<float2*>(y + o) = make_float2(o0, o1);
         if (yh) *reinterpret_cast<unsigned*>(yh + o) = pack_bf16x4(o0, o1, 0.f, 0.f).x;
@@ -179,7 +181,10 @@ int s2st_hubert_conv0_gn_gelu(const float* x, const float* w, const float* gamma
     S2ST_LAUNCH((hubert_conv0_gn_kernel<0, CONV0_MAXK>), grid, dim3(256), 0, st, x, w, cm, cv, part, shift, gamma, beta, y, yh, B, N, T,
                 C, k, stride, eps);
   S2ST_LAUNCH(conv0_fold_kernel, fgrid, dim3(256), 0, st, (const float*)part, (const float*)shift, mean, var, B, nblk, C, T);
-  if (k == 10)
+  if (k == 10 && !y)
+    S2ST_LAUNCH((hubert_conv0_gn_kernel<3, 10>), grid, dim3(256), 0, st, x, w, cm, cv, part, shift, gamma, beta, y, yh, B, N, T, C, k,
+                stride, eps);
+  else if (k == 10)
     S2ST_LAUNCH((hubert_conv0_gn_kernel<2, 10>), grid, dim3(256), 0, st, x, w, cm, cv, part, shift, gamma, beta, y, yh, B, N, T, C, k,
                 stride, eps);
   else

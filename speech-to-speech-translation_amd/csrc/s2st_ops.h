@@ -47,7 +47,7 @@ inline GemmEpilogue gemm_epi_default() {
   GemmEpilogue e;
   e.alpha = 1.f; e.bias = nullptr; e.act = 0; e.drop_p = 0.f; e.seed = 0; e.resid = nullptr;
   e.accumulate = 0;
-  e.mask_y = nullptr; e.mask_scale = 1.f; e.colsum = nullptr; e.colsum_part = nullptr;
+  e.mask_y = nullptr; e.mask_scale = 1.f; e.colsum = nullptr; e.colsum_part = nullptr; e.bias_zo = 0;
   return e;
 }
 

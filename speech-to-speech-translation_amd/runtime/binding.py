@@ -38,7 +38,7 @@ class GemmEpilogue(C.Structure):
     _fields_ = [("alpha", C.c_float), ("act", C.c_int32), ("bias", C.c_void_p),
                 ("drop_p", C.c_float), ("accumulate", C.c_int32), ("seed", C.c_uint64),
                 ("resid", C.c_void_p), ("mask_y", C.c_void_p), ("mask_scale", C.c_float), ("colsum", C.c_void_p),
-                ("colsum_part", C.c_void_p)]
+                ("colsum_part", C.c_void_p), ("bias_zo", C.c_int64)]
 
 
 class GemmArgs(C.Structure):
