@@ -26,7 +26,9 @@ namespace {
 // and the waveform samples are read straight from global memory at wave-UNIFORM addresses (s_load_dwordx8 + x2 per frame
 // into SGPRs that the FMAs take as operands) instead of 10 LDS broadcast reads per frame and thread: the statistics
 // passes were bound by LDS-read issue, not by FMAs.  (Tried on the apply pass: a 12-instruction erf instead of libm's --
-// no change, 302 us: it is bound by its 4-byte-per-lane stores, 0.63 GB of bf16 at 2.1 TB/s.)
+// no change, 302 us; round 5 again with the epilogues' branch-free erf AND eight channels per lane = one 1 KB store per wave
+// and frame: 305 us -- neither the stores' width nor the erf; 0.63 GB of bf16 at 2.1 TB/s beside ~220 VALU instructions per
+// frame and wave.)
 // A workgroup owns C0_TT consecutive frames of one utterance and ALL channels; a thread keeps the taps of its two channels in
 // registers and writes coalesced rows.
 constexpr int C0_TT = 128, CONV0_MAXK = 16, CONV0_CPT = 2;  // frames per block, max taps, channels per thread
@@ -91,9 +93,7 @@ __global__ __launch_bounds__(256) void hubert_conv0_gn_kernel(const float* __res
           acq[e] = fmaf(d, d, acq[e]);
         }
       } else {
-        // (MODE 3 = MODE 2 with the epilogues' branch-free erf, s2st_common.h: the bf16-only output of fast mode)
-        const float u0 = (a[0] - mu[0]) * sc[0] + sh[0], u1 = (a[1] - mu[1]) * sc[1] + sh[1];
-        const float o0 = MODE == 3 ? gelu_erf_fast(u0) : gelu_erf(u0), o1 = MODE == 3 ? gelu_erf_fast(u1) : gelu_erf(u1);
+        const float o0 = gelu_erf((a[0] - mu[0]) * sc[0] + sh[0]), o1 = gelu_erf((a[1] - mu[1]) * sc[1] + sh[1]);
         const long o = ((long)b * T + t0 + t) * C + c0;
         if (y) *reinterpret_cast<float2*>(y + o) = make_float2(o0, o1);
         if (yh) *reinterpret_cast<unsigned*>(yh + o) = pack_bf16x4(o0, o1, 0.f, 0.f).x;
@@ -181,10 +181,7 @@ int s2st_hubert_conv0_gn_gelu(const float* x, const float* w, const float* gamma
     S2ST_LAUNCH((hubert_conv0_gn_kernel<0, CONV0_MAXK>), grid, dim3(256), 0, st, x, w, cm, cv, part, shift, gamma, beta, y, yh, B, N, T,
                 C, k, stride, eps);
   S2ST_LAUNCH(conv0_fold_kernel, fgrid, dim3(256), 0, st, (const float*)part, (const float*)shift, mean, var, B, nblk, C, T);
-  if (k == 10 && !y)
-    S2ST_LAUNCH((hubert_conv0_gn_kernel<3, 10>), grid, dim3(256), 0, st, x, w, cm, cv, part, shift, gamma, beta, y, yh, B, N, T, C, k,
-                stride, eps);
-  else if (k == 10)
+  if (k == 10)
     S2ST_LAUNCH((hubert_conv0_gn_kernel<2, 10>), grid, dim3(256), 0, st, x, w, cm, cv, part, shift, gamma, beta, y, yh, B, N, T, C, k,
                 stride, eps);
   else
