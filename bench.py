@@ -254,10 +254,10 @@ def infer_main(args):
     # batch's vocoder is waited for inside the timed region.
     DEFER = os.environ.get("S2ST_DEFER_VOCODER", "1") != "0"
 
-    # S2ST_DECODE_CHAINS=<n> (default 2): consecutive batches are decoded n at a time (generate_many: batch k > 0 on a twin
+    # S2ST_DECODE_CHAINS=<n> (default 3): consecutive batches are decoded n at a time (generate_many: batch k > 0 on a twin
     # engine and its own stream, the step loops alternated) -- one batch's decoding steps leave most of the chip idle, the
     # next batches' do not depend on them.  Same hypotheses as one batch after the other (tests/test_inference.py).
-    CHAINS = int(os.environ.get("S2ST_DECODE_CHAINS", "2"))
+    CHAINS = importlib.import_module(PKG + ".runtime.streams").default_decode_chains()
 
     def run(gen_list, n_steps, first=0):
         held, n_u, n_f = [], 0, 0
@@ -461,6 +461,9 @@ def infer_main(args):
                        "vocoder_overlap": ("batch k's Griffin-Lim on a second stream beside batch k + 1's decoding steps"
                                            if DEFER else "off"),
                        "decode_chains": CHAINS, "early_stop": early,
+                       # roles of the package's stream pool for which no free hardware queue was found (runtime/streams.py)
+                       "stream_collisions": importlib.import_module(PKG + ".runtime.streams").collisions(),
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "4 (runtime default)"),
                        "value_without_vocoder_overlap": round(value_serial, 2) if value_serial else None,
                        "decode_steps_per_batch": iters, "batch0_decode_ms": round(t_dec * 1e3, 2),
                        "batch0_vocoder_alone_ms": round(t_voc * 1e3, 2),

@@ -425,6 +425,35 @@ int s2st_engine_decode_step(s2st_engine* e, int32_t step, const float* prev, con
                             const int32_t* self_klen /* [B] or NULL: self-attention keys per utterance */,
                             uint64_t seed, float* feat_out, float* eos_prob, float* attn_out, float* workspace,
                             int64_t workspace_floats, void* stream);
+
+/* The same step in a form a HIP graph can replay (round 5: config 5 was bound by the host's ~15 k launches per batch).
+ * Everything that changes from step to step is read from DEVICE memory, so one captured step serves a whole run:
+ *   step      [1]  the step the next replay computes (self-attention: keys 0 .. step, cache row step);
+ *   seeds     [8]  the dropout seeds of the step's sites (prenet layers), in launch order;
+ *   cur_feat  [B][out_dim]  in: the previous step's features (the zero frame before step 0); out: this step's;
+ *   cur_eos   [B], cur_attn [B][E] (or NULL)  this step's stop probabilities / head-averaged alignment;
+ *   pe_cur    [dec_dim]  alpha * PE[step + 2], the row every utterance adds at this step.
+ * decode_replay_begin sets the state for step 0 (seed0 = the seed decode_step would get at step 0; step s gets seed0 + s).
+ * decode_step_replay enqueues one step (S2ST_ERR_SHAPE where the step is not made of the skinny / fused forms: the caller
+ * falls back to decode_step).  decode_replay_commit is the stop rule of s2st_decode_stop_update_i32 for the step, copies the
+ * step's outputs to row `step` of the run's buffers (feat_all [max_iter][B][out_dim], eos_all [max_iter][B], attn_all
+ * [max_iter][B][E] or NULL), prepares pe_cur / seeds for the next step and advances `step`.  Results are those of
+ * decode_step + s2st_decode_stop_update_i32 called step by step, bit for bit (tests/test_inference.py). */
+typedef struct {
+  int32_t* step;
+  uint64_t* seeds;
+  float* cur_feat;
+  float* cur_eos;
+  float* cur_attn;
+  float* pe_cur;
+} s2st_decode_replay;
+int32_t s2st_engine_decode_replay_supported(const s2st_engine* e); /* after decode_begin: 1 if the run's steps can take this form */
+int s2st_engine_decode_replay_begin(s2st_engine* e, const s2st_decode_replay* r, uint64_t seed0, void* stream);
+int s2st_engine_decode_step_replay(s2st_engine* e, const s2st_decode_replay* r, const int32_t* self_klen, float* workspace,
+                                   int64_t workspace_floats, void* stream);
+int s2st_engine_decode_replay_commit(s2st_engine* e, const s2st_decode_replay* r, uint64_t seed0, float thr, int32_t max_iter,
+                                     int32_t* finished, int32_t* out_lens, int32_t* klen_next, int32_t* n_done,
+                                     float* feat_all, float* eos_all, float* attn_all, void* stream);
 int s2st_engine_postnet_eval(s2st_engine* e, const float* feat, int32_t B, int32_t D, float* post_out,
                              float* workspace, int64_t workspace_floats, void* stream);
 

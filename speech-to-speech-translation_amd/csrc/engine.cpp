@@ -100,6 +100,25 @@ struct s2st_engine {
   bool side_used = false;
   bool join_every_segment = false;  // S2ST_JOIN_EVERY_SEGMENT=1 (A/B switch)
   float* skws_side = nullptr;
+  bool side_allowed = false;  // bf16-operand mode and no S2ST_NO_SIDE_STREAM=1
+  bool side_tried = false;
+  void ensure_side() {        // the second stream and its events, on first need (the first training forward; the overlapped update)
+    if (side_ || side_tried || !side_allowed) return;
+    side_tried = true;
+    // the side stream carries weight gradients nobody waits for until the segment ends: lowest queue priority, so that
+    // when both queues have workgroups ready the data path (the critical chain of the backward) is dispatched first
+    int pr_least = 0, pr_greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest) != hipSuccess) pr_least = 0;
+    if (hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, pr_least) != hipSuccess) side_ = nullptr;
+    if (side_ && hipEventCreateWithFlags(&ev_kv_, hipEventDisableTiming) != hipSuccess) ev_kv_ = nullptr;
+    if (side_ && (hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming) != hipSuccess ||
+                  hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming) != hipSuccess ||
+                  hipEventCreateWithFlags(&ev_taps_, hipEventDisableTiming) != hipSuccess ||
+                  hipEventCreateWithFlags(&ev_auxb_, hipEventDisableTiming) != hipSuccess)) {
+      hipStreamDestroy(side_);
+      side_ = nullptr;
+    }
+  }
   hipStream_t fork_side() {  // everything issued on st_ so far happens-before what follows on the returned stream
     if (!side_) { sync_chains(); return st_; }
     hipEventRecord(ev_fork_, st_);
@@ -192,6 +211,9 @@ struct s2st_engine {
     if (forked_) hipStreamWaitEvent(chain1_, ev, 0);
   }
   // ---- AR decoding state (config 5): caller-owned cache buffer laid out by decode_begin --------
+  // replay_ != null: decode_step in its graph-replayable form (s2st_engine_decode_step_replay): the step, the prenet's dropout
+  // seeds, the input frame, the position row and the output rows are read from / written to the fixed device buffers of *replay_
+  const s2st_decode_replay* replay_ = nullptr;
   bool stop_after_encoder = false;
   Ten* enc_out_keep = nullptr;
   struct Dec {
@@ -589,6 +611,7 @@ struct s2st_engine {
     if (!P || !G || n_params <= 0) return S2ST_ERR_ARG;
     if (nchunks < 1) nchunks = 1;
     if (nchunks > 64) nchunks = 64;
+    ensure_side();
     hipStream_t saved = st_;
     st_ = main;
     hipStream_t a = side_ ? fork_side() : main;  // behind the norm's partial sums (and everything else) on `main`
@@ -699,11 +722,17 @@ struct s2st_engine {
     if (b >= 0) touch(b + N);
     const uint64_t sd = drop_p > 0.f ? next_seed() : 0;
     if (skinny) {
+      const uint64_t* seed_ptr = nullptr;
+      if (replay_ && drop_p > 0.f) {
+        if (site < 1 || site > 8) { if (!err) err = S2ST_ERR_SHAPE; return y; }
+        seed_ptr = replay_->seeds + (site - 1);
+      }
       if (live())
         chk(s2st_gemm_skinny(x->d, K, PH + w, K, y->d, N, b >= 0 ? P + b : nullptr, act, drop_p, sd,
-                             resid ? resid->d : resid_row, resid ? N : 0, M, N, K, st_));
+                             resid ? resid->d : resid_row, resid ? N : 0, M, N, K, st_, nullptr, nullptr, 1e-5f, seed_ptr));
       return y;  // inference only: no tape entry
     }
+    if (replay_ && drop_p > 0.f && !err) err = S2ST_ERR_SHAPE;  // (a dropout site off the skinny path: not replayable)
     const bf16raw* xh = fm ? half_of(x) : nullptr;
     // (a residual-stream output is read in fp32 by the next layer norm / residual add: no bf16 copy; a consumer that
     // does want one gets it from half_of())
@@ -1460,12 +1489,13 @@ struct s2st_engine {
   // to row `pos_new` of the caches before it attends (the two copy launches per layer of rounds 1 - 3 are gone)
   Ten* dec_attn(Ten* qt, int qoff, float* K, float* V, long ldk, long kbs, const int* klen, int nkeys,
                 int H, float* attn_mean, int S, const float* k_new = nullptr, const float* v_new = nullptr, long ld_new = 0,
-                int pos_new = 0, int kv_bf16 = 0) {
+                int pos_new = 0, int kv_bf16 = 0, const int* step_ptr = nullptr) {
     const int Cd = c.dec_dim, B = dec_st.B;
     Ten* o = newT(B, Cd);
     if (live())
       chk(s2st_decode_attn(qt->d + qoff, qt->cols, K, V, ldk, kbs, klen, nkeys, B, H, Cd / H,
-                           1.0f / sqrtf((float)(Cd / H)), o->d, Cd, attn_mean, S, st_, k_new, v_new, ld_new, pos_new, kv_bf16));
+                           1.0f / sqrtf((float)(Cd / H)), o->d, Cd, attn_mean, S, st_, k_new, v_new, ld_new, pos_new, kv_bf16,
+                           step_ptr));
     return o;
   }
 
@@ -1495,8 +1525,9 @@ struct s2st_engine {
     // (every utterance is at position step + 2 in the incremental path: x + alpha * PE[pos] is ONE row for the whole
     // batch, taken from the alpha-scaled table decode_begin prepared -- added in the projection's epilogue on the skinny
     // path, by the position kernel otherwise)
-    const float* pe_row = dec_st.pe_alpha ? dec_st.pe_alpha + (long)(step + 2) * Cd : nullptr;
+    const float* pe_row = dec_st.pe_alpha ? (replay_ ? replay_->pe_cur : dec_st.pe_alpha + (long)(step + 2) * Cd) : nullptr;
     const bool pe_fused = pe_row && fast() && use_skinny && B <= 64 && c.prenet_dim % 32 == 0;
+    if (replay_ && !pe_fused) return S2ST_ERR_SHAPE;  // (the position kernel takes this step's rows: not replayable)
     x = linear(x, prenet.back().w, prenet.back().b, Cd, c.prenet_dim, 0, 0.f, nullptr, nullptr, false, pe_fused ? pe_row : nullptr);
     if (!pe_fused) x = add_pe(x, pos, dec_st.pe_dec, 1.f, pos_alpha, 0.f);
     for (int l = 0; l < c.dec_layers; ++l) {
@@ -1505,8 +1536,9 @@ struct s2st_engine {
       Ten* kvq = pre ? ln_linear(x, L.ln1, L.sa.kvq_w, L.sa.kvq_b, 3 * Cd, Cd) : linear(x, L.sa.kvq_w, L.sa.kvq_b, 3 * Cd, Cd);
       // keys >= self_klen[b] are masked: a finished utterance keeps its final length (the reference's
       // cached key padding mask, speech_generator_for_s2st.py:88-89 + multihead_attention.py:268-277)
-      Ten* o = dec_attn(kvq, 2 * Cd, dec_selfK(l), dec_selfV(l), Cd, (long)maxT * Cd, self_klen, step + 1, H, nullptr, 0,
-                        kvq->d, kvq->d + Cd, 3 * Cd, step);
+      // (replay form: the kernel takes keys 0 .. *step and cache row *step; the host-side bound is the whole cache)
+      Ten* o = dec_attn(kvq, 2 * Cd, dec_selfK(l), dec_selfV(l), Cd, (long)maxT * Cd, self_klen, replay_ ? maxT : step + 1, H, nullptr, 0,
+                        kvq->d, kvq->d + Cd, 3 * Cd, replay_ ? 0 : step, 0, replay_ ? replay_->step : nullptr);
       x = linear(o, L.sa.out_w, L.sa.out_b, Cd, Cd, 0, 0.f, x);
       if (!pre) x = layernorm(x, L.ln1);
       // encoder attention (static keys / values precomputed by decode_begin)
@@ -1530,6 +1562,7 @@ struct s2st_engine {
     }
     // the stop head's logistic rides in its projection's epilogue on the skinny path (act 3)
     const bool sig_fused = fast() && use_skinny && B <= 64 && Cd % 64 == 0 && (!has_dec_ln || use_ln_skinny);
+    if (replay_ && !sig_fused) return S2ST_ERR_SHAPE;
     Ten* eos;
     if (has_dec_ln) {  // both heads read the normalised state
       ln_linear(x, dec_ln, feat_proj.w, feat_proj.b, c.out_dim, Cd, 0, feat_out);
@@ -1868,6 +1901,7 @@ struct s2st_engine {
     const bool tr = bt.training != 0;
     const bool with_loss = bt.tgt != nullptr;
     seed = bt.seed;
+    if (tr) ensure_side();  // (also in the dry run that sizes the workspace: same stream set, same allocations)
     main_ = st_;
     forked_ = false;
     in_region_ = false;
@@ -1900,16 +1934,16 @@ struct s2st_engine {
     }
     skws_n = fm ? (long)16 << 20 : 0;
     skws = fm ? alloc(skws_n) : nullptr;
-    skws_side = fm && side_ ? alloc(skws_n) : skws;
+    skws_side = fm && side_allowed ? alloc(skws_n) : skws;  // (by permission, not by existence: the stream is made lazily)
     skws_c1 = fm && chain1_ && nchains == 2 ? alloc(skws_n) : skws;
     // stream-K scratch of the persistent GEMM kernel, one per stream (ticket counters zeroed here, before any fork)
     if (fm && tr && use_streamk) {
       float* sk0 = alloc(S2ST_STREAMK_SCRATCH_FLOATS);
-      float* sk1 = side_ ? alloc(S2ST_STREAMK_SCRATCH_FLOATS) : nullptr;
+      float* sk1 = side_allowed ? alloc(S2ST_STREAMK_SCRATCH_FLOATS) : nullptr;
       if (live()) {
         hipMemsetAsync(sk0, 0, 4096, st_);
         s2st_gemm_streamk_bind(st_, sk0, S2ST_STREAMK_SCRATCH_FLOATS);
-        if (sk1) {
+        if (sk1 && side_) {
           hipMemsetAsync(sk1, 0, 4096, st_);
           s2st_gemm_streamk_bind(side_, sk1, S2ST_STREAMK_SCRATCH_FLOATS);
         }
@@ -2347,23 +2381,15 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   if (getenv("S2ST_CONV_TAIL_MAIN")) e->conv_tail_on_main = atoi(getenv("S2ST_CONV_TAIL_MAIN")) != 0;
   e->ordered_sums = !(getenv("S2ST_ORDERED_BIAS_SUMS") && atoi(getenv("S2ST_ORDERED_BIAS_SUMS")) == 0);
   e->build_params();
+  // (a process that replays HIP graphs can carry a stale "last error" of the runtime's own capture-time queries: the preload's
+  //  launch checks must see their own errors only)
+  (void)hipGetLastError();
   if (!cfg->precise && (s2st_gemm_bf16_preload(nullptr) != 0 || s2st_flash_attn_preload(nullptr) != 0)) { delete e; return S2ST_ERR_LAUNCH; }
-  if (!cfg->precise && !(getenv("S2ST_NO_SIDE_STREAM") && atoi(getenv("S2ST_NO_SIDE_STREAM")))) {
-    // the side stream carries weight gradients nobody waits for until the segment ends: lowest queue priority, so that
-    // when both queues have workgroups ready the data path (the critical chain of the backward) is dispatched first
-    int pr_least = 0, pr_greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest) != hipSuccess) pr_least = 0;
-    if (hipStreamCreateWithPriority(&e->side_, hipStreamNonBlocking, pr_least) != hipSuccess) e->side_ = nullptr;
-    e->overlap_aux = !(getenv("S2ST_NO_AUX_OVERLAP") && atoi(getenv("S2ST_NO_AUX_OVERLAP")) != 0);
-    if (e->side_ && hipEventCreateWithFlags(&e->ev_kv_, hipEventDisableTiming) != hipSuccess) e->ev_kv_ = nullptr;
-    if (e->side_ && (hipEventCreateWithFlags(&e->ev_fork_, hipEventDisableTiming) != hipSuccess ||
-                     hipEventCreateWithFlags(&e->ev_join_, hipEventDisableTiming) != hipSuccess ||
-                     hipEventCreateWithFlags(&e->ev_taps_, hipEventDisableTiming) != hipSuccess ||
-                     hipEventCreateWithFlags(&e->ev_auxb_, hipEventDisableTiming) != hipSuccess)) {
-      hipStreamDestroy(e->side_);
-      e->side_ = nullptr;
-    }
-  }
+  // The second stream is made at the first TRAINING forward (ensure_side), not here: a process has four hardware queues
+  // (runtime/streams.py) and an engine that only ever decodes would hold one of them for nothing -- the caller's stream
+  // then shares a queue with one of the generator's chains (config 5, profiles/r05_queue_matrix.txt).
+  e->side_allowed = !cfg->precise && !(getenv("S2ST_NO_SIDE_STREAM") && atoi(getenv("S2ST_NO_SIDE_STREAM")));
+  e->overlap_aux = !(getenv("S2ST_NO_AUX_OVERLAP") && atoi(getenv("S2ST_NO_AUX_OVERLAP")) != 0);
   // S2ST_CHAINS=2: the training step's layers as two utterance-half chains (see chain_count)
   if (!cfg->precise && getenv("S2ST_CHAINS") && atoi(getenv("S2ST_CHAINS")) == 2) {
     if (hipStreamCreateWithFlags(&e->chain1_, hipStreamNonBlocking) == hipSuccess &&
@@ -2525,7 +2551,10 @@ int s2st_engine_wait_optimizer(s2st_engine* e, void* stream) {
 
 int32_t s2st_engine_num_segments(const s2st_engine* e) { return e->n_segments(); }
 
-void* s2st_engine_side_stream(const s2st_engine* e) { return (void*)e->side_; }
+void* s2st_engine_side_stream(const s2st_engine* e) {  // (a trainer asks before the first forward: made on demand)
+  const_cast<s2st_engine*>(e)->ensure_side();
+  return (void*)e->side_;
+}
 
 int s2st_engine_segment_range(const s2st_engine* e, int32_t i, int64_t* lo, int64_t* hi) {
   int ns = e->n_segments();
@@ -2617,6 +2646,54 @@ int s2st_engine_decode_step(s2st_engine* e, int32_t step, const float* prev, con
   int rc = e->decode_step(step, prev, pos, self_klen, seed, feat_out, eos_prob, attn_out);
   e->tape.clear();
   return rc;
+}
+
+// ---- the decode step in its graph-replayable form (include/s2st_hip.h: s2st_decode_replay) --------------------------------
+// 1 when the run decode_begin prepared is made of the forms decode_step_replay can take (bf16-operand mode, skinny products
+// for <= 64 utterances, the position row and the logistic fused): the conditions decode_step itself checks, asked up front
+int32_t s2st_engine_decode_replay_supported(const s2st_engine* e) {
+  if (!e || !e->dec_st.base || !e->dec_st.pe_alpha || !e->fast() || !e->PH || !e->use_skinny) return 0;
+  const int B = e->dec_st.B, Cd = e->c.dec_dim;
+  if (B < 1 || B > 64 || e->c.prenet_dim % 32 || e->c.out_dim % 32 || Cd % 64 || e->c.prenet_layers > 7) return 0;
+  if (e->has_dec_ln && !e->use_ln_skinny) return 0;
+  return 1;
+}
+
+int s2st_engine_decode_replay_begin(s2st_engine* e, const s2st_decode_replay* r, uint64_t seed0, void* stream) {
+  if (!e || !r || !e->dec_st.base || !e->dec_st.pe_alpha) return S2ST_ERR_ARG;
+  return s2st_decode_replay_init(r->step, r->seeds, r->cur_feat, (long)e->dec_st.B * e->c.out_dim, r->pe_cur, e->dec_st.pe_alpha,
+                                 e->c.dec_dim, seed0, (hipStream_t)stream);
+}
+
+int s2st_engine_decode_step_replay(s2st_engine* e, const s2st_decode_replay* r, const int32_t* self_klen, float* workspace,
+                                   int64_t workspace_floats, void* stream) {
+  if (!e || !e->P || !r || !r->step || !r->seeds || !r->cur_feat || !r->cur_eos || !r->pe_cur) return S2ST_ERR_ARG;
+  if (!e->fast() || !e->PH || !e->dec_st.pe_alpha) return S2ST_ERR_SHAPE;
+  s2st_engine::Dec keep = e->dec_st;
+  s2st_batch bt_keep = e->bt;
+  e->reset_call();
+  e->dec_st = keep;
+  e->bt = bt_keep;
+  e->dry = false;
+  e->ws = workspace;
+  e->ws_cap = workspace_floats;
+  e->st_ = (hipStream_t)stream;
+  e->skws = nullptr; e->skws_n = 0; e->skws_side = nullptr;
+  e->replay_ = r;
+  // (step 0 / seed 0 on the host side: every step-dependent value comes from *r inside the kernels)
+  int rc = e->decode_step(0, r->cur_feat, nullptr, self_klen, 0, r->cur_feat, r->cur_eos, r->cur_attn);
+  e->replay_ = nullptr;
+  e->tape.clear();
+  return rc;
+}
+
+int s2st_engine_decode_replay_commit(s2st_engine* e, const s2st_decode_replay* r, uint64_t seed0, float thr, int32_t max_iter,
+                                     int32_t* finished, int32_t* out_lens, int32_t* klen_next, int32_t* n_done,
+                                     float* feat_all, float* eos_all, float* attn_all, void* stream) {
+  if (!e || !r || !e->dec_st.base || !e->dec_st.pe_alpha) return S2ST_ERR_ARG;
+  return s2st_decode_replay_commit(r->step, r->seeds, r->cur_feat, r->cur_eos, r->cur_attn, r->pe_cur, e->dec_st.pe_alpha,
+                                   e->dec_st.maxT + 2, e->c.dec_dim, seed0, thr, max_iter, e->dec_st.B, e->c.out_dim, e->dec_st.E,
+                                   finished, out_lens, klen_next, n_done, feat_all, eos_all, attn_all, (hipStream_t)stream);
 }
 
 int s2st_engine_postnet_eval(s2st_engine* e, const float* feat, int32_t B, int32_t D, float* post_out,
@@ -2723,6 +2800,9 @@ int s2st_hubert_create(const s2st_hubert_config* cfg, s2st_engine** out) {
   e->f32_operands = getenv("S2ST_F32_OPERANDS") && atoi(getenv("S2ST_F32_OPERANDS")) != 0;
   e->use_flash = !(getenv("S2ST_NO_FLASH") && atoi(getenv("S2ST_NO_FLASH")) != 0);
   e->build_params_hubert();
+  // (a process that replays HIP graphs can carry a stale "last error" of the runtime's own capture-time queries: the preload's
+  //  launch checks must see their own errors only)
+  (void)hipGetLastError();
   if (!cfg->precise && (s2st_gemm_bf16_preload(nullptr) != 0 || s2st_flash_attn_preload(nullptr) != 0)) { delete e; return S2ST_ERR_LAUNCH; }
   *out = e;
   return 0;

@@ -1331,7 +1331,9 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
                                                           const float* __restrict__ bias, int act, float drop_p,
                                                           uint64_t seed, const float* __restrict__ resid, long ldr,
                                                           int M, int N, int K, const float* __restrict__ ln_g,
-                                                          const float* __restrict__ ln_b, float ln_eps) {
+                                                          const float* __restrict__ ln_b, float ln_eps,
+                                                          const uint64_t* __restrict__ seed_ptr) {
+  if (seed_ptr) seed = *seed_ptr;  // (replayable decode step: the step's seeds live in device memory)
   __shared__ __attribute__((aligned(16))) float part[3][MT * 64 * 4];
   __shared__ float ln_mean[16 * MT], ln_rstd[16 * MT];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1537,7 +1539,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
 // while they are converted (K % 64 == 0 then).  resid rows may all be the same one (ldr = 0: a positional row).
 int s2st_gemm_skinny(const float* A, long lda, const bf16raw* W, long ldw, float* C, long ldc, const float* bias, int act,
                      float drop_p, uint64_t seed, const float* resid, long ldr, int M, int N, int K, hipStream_t st,
-                     const float* ln_g, const float* ln_b, float ln_eps) {
+                     const float* ln_g, const float* ln_b, float ln_eps, const uint64_t* seed_ptr) {
   if (M <= 0 || N <= 0) return 0;
   if (M > 64 || K <= 0 || K % 32 || lda % 4 || ldw % 8 || ((uintptr_t)A % 16) || ((uintptr_t)W % 16)) return S2ST_ERR_SHAPE;
   if (ln_g && (!ln_b || K % 64 || ((uintptr_t)ln_g % 16) || ((uintptr_t)ln_b % 16))) return S2ST_ERR_SHAPE;
@@ -1547,6 +1549,6 @@ int s2st_gemm_skinny(const float* A, long lda, const bf16raw* W, long ldw, float
   const dim3 grid((N + 15) / 16, (M + 15) / 16), block(256);  // (16 columns) x (16 rows) per workgroup
   const bf16_t* Wp = reinterpret_cast<const bf16_t*>(W);
   s2st_launch("gemm_skinny_kernel", by, fl, gemm_skinny_kernel<1>, grid, block, 0, st, A, lda, Wp, ldw, C, ldc, bias, act, drop_p,
-              seed, resid, ldr, M, N, K, ln_g, ln_b, ln_eps);
+              seed, resid, ldr, M, N, K, ln_g, ln_b, ln_eps, seed_ptr);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }

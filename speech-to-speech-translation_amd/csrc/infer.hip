@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
                                                           int H, int dh, float scale, float* __restrict__ o, long ldo,
                                                           float* __restrict__ attn_mean, int S,
                                                           const float* __restrict__ k_new, const float* __restrict__ v_new,
-                                                          long ld_new, int pos_new) {
+                                                          long ld_new, int pos_new, const int* __restrict__ step_ptr) {
+  if (step_ptr) { pos_new = *step_ptr; nkeys = pos_new + 1; }  // (replayable step: the step lives in device memory)
   __shared__ float p[DA_MAXS];
   __shared__ __attribute__((aligned(16))) float qs[256];
   __shared__ float red[4];
@@ -360,7 +361,9 @@ __global__ __launch_bounds__(NT) void decode_attn_fast_kernel(const float* __res
                                                               const int* __restrict__ klen, int nkeys, int H, float scale,
                                                               float* __restrict__ o, long ldo, float* __restrict__ attn_mean,
                                                               int S, const float* __restrict__ k_new,
-                                                              const float* __restrict__ v_new, long ld_new, int pos_new) {
+                                                              const float* __restrict__ v_new, long ld_new, int pos_new,
+                                                              const int* __restrict__ step_ptr) {
+  if (step_ptr) { pos_new = *step_ptr; nkeys = pos_new + 1; }  // (replayable step: the step lives in device memory)
   constexpr int dh = 64 * ND, G = NT / 16;
   constexpr int KP = (sizeof(KT) == 2 ? 16 : 8) / (NT / 256 > 2 ? 2 : 1);
   typedef typename RawRow<KT>::T Raw;
@@ -960,10 +963,11 @@ __global__ __launch_bounds__(256) void gl_overlap_add_kernel(const float* __rest
 
 int s2st_decode_attn(const float* q, long ldq, float* kc, float* vc, long ldk, long kbs, const int* klen,
                      int nkeys, int B, int H, int dh, float scale, float* o, long ldo, float* attn_mean, int S,
-                     hipStream_t st, const float* k_new, const float* v_new, long ld_new, int pos_new, int kv_bf16) {
+                     hipStream_t st, const float* k_new, const float* v_new, long ld_new, int pos_new, int kv_bf16,
+                     const int* step_ptr) {
   if (B <= 0) return 0;
   if (nkeys > DA_MAXS || dh > 256 || dh % 4 || 256 % dh) return S2ST_ERR_SHAPE;
-  if ((k_new != nullptr) != (v_new != nullptr) || (k_new && (pos_new < 0 || pos_new >= nkeys))) return S2ST_ERR_ARG;
+  if ((k_new != nullptr) != (v_new != nullptr) || (k_new && !step_ptr && (pos_new < 0 || pos_new >= nkeys))) return S2ST_ERR_ARG;
   if (kv_bf16 && (k_new || (dh != 64 && dh != 128) || ldk % 4)) return S2ST_ERR_ARG;  // (bf16 caches: static rows only)
   if (nkeys < 1) return S2ST_ERR_ARG;
   if (attn_mean) hipMemsetAsync(attn_mean, 0, sizeof(float) * (size_t)B * S, st);
@@ -980,10 +984,10 @@ int s2st_decode_attn(const float* q, long ldq, float* kc, float* vc, long ldk, l
   const bool big = nt_env == 1024;  // (measured slower at B * H = 256: 9.3 us against 5.8 us for one key, 16.3 against 13.3 for the bench batch)
 #define S2ST_DA_LAUNCH(KT_, ND_, NT_, kp, vp)                                                                               \
   S2ST_LAUNCH((decode_attn_fast_kernel<KT_, ND_, NT_>), dim3(B * H), dim3(NT_), 0, st, q, ldq, kp, vp, ldk, kbs, klen, nkeys, H, \
-              scale, o, ldo, attn_mean, S, k_new, v_new, ld_new, pos_new)
+              scale, o, ldo, attn_mean, S, k_new, v_new, ld_new, pos_new, step_ptr)
   if (!fast_ok) {
     S2ST_LAUNCH(decode_attn_kernel, dim3(B * H), dim3(256), 0, st, q, ldq, kc, vc, ldk, kbs, klen, nkeys, H, dh,
-                scale, o, ldo, attn_mean, S, k_new, v_new, ld_new, pos_new);
+                scale, o, ldo, attn_mean, S, k_new, v_new, ld_new, pos_new, step_ptr);
   } else if (kv_bf16) {
     bf16raw* kh = reinterpret_cast<bf16raw*>(kc);
     bf16raw* vh = reinterpret_cast<bf16raw*>(vc);
@@ -1049,7 +1053,92 @@ __global__ __launch_bounds__(256) void decode_stop_update_kernel(const float* __
   __syncthreads();
   if (threadIdx.x == 0) n_done[step] = cnt[0] + cnt[1] + cnt[2] + cnt[3];
 }
+
+// ---- replayable decode step (engine.cpp, include/s2st_hip.h s2st_decode_replay) ---------------------------------------
+// Seeds as the host derives them: decode_step gets seed0 + step, its i-th dropout site next_seed() = seed * 0x100000001B3 +
+// (i + 1) * 0x9E3779B97F4A7C15 (engine.cpp next_seed; site counts from 1).
+__device__ __forceinline__ uint64_t replay_site_seed(uint64_t seed0, int step, int site) {
+  return (seed0 + (uint64_t)step) * 0x100000001B3ULL + (uint64_t)(site + 1) * 0x9E3779B97F4A7C15ULL;
+}
+__global__ __launch_bounds__(1024) void decode_replay_init_kernel(int* __restrict__ step, uint64_t* __restrict__ seeds,
+                                                                  float* __restrict__ cur_feat, long n_feat,
+                                                                  float* __restrict__ pe_cur, const float* __restrict__ pe_alpha,
+                                                                  int Cd, uint64_t seed0) {
+  const int tid = threadIdx.x;
+  for (long i = tid; i < n_feat; i += 1024) cur_feat[i] = 0.f;  // the zero frame (speech_generator_for_s2st.py:76-77)
+  for (int c = tid; c < Cd; c += 1024) pe_cur[c] = pe_alpha[2L * Cd + c];
+  if (tid < 8) seeds[tid] = replay_site_seed(seed0, 0, tid);
+  if (tid == 0) *step = 0;
+}
+// Commit of a replayed step.  Workgroup 0: the stop rule of decode_stop_update_kernel on the step's probabilities (+ the
+// step's row of eos_all), the next step's position row and seeds; the other workgroups: the step's features / alignment into
+// row `step` of the run's buffers.  Every workgroup only READS the step counter: decode_replay_advance_kernel, the next node
+// of the stream, increments it (one workgroup copying 37 k floats by itself cost 60 us per step).
+__global__ __launch_bounds__(256) void decode_replay_commit_kernel(const int* __restrict__ step_p, uint64_t* __restrict__ seeds,
+                                                                   const float* __restrict__ cur_feat,
+                                                                   const float* __restrict__ cur_eos,
+                                                                   const float* __restrict__ cur_attn, float* __restrict__ pe_cur,
+                                                                   const float* __restrict__ pe_alpha, int pe_rows, int Cd,
+                                                                   uint64_t seed0, float thr, int max_iter, int B, int out_dim, int E,
+                                                                   int* __restrict__ finished, int* __restrict__ out_lens,
+                                                                   int* __restrict__ klen_next, int* __restrict__ n_done,
+                                                                   float* __restrict__ feat_all, float* __restrict__ eos_all,
+                                                                   float* __restrict__ attn_all) {
+  const int tid = threadIdx.x, step = *step_p;
+  if (blockIdx.x == 0) {
+    __shared__ int cnt[4];
+    int c = 0;
+    for (int b = tid; b < B; b += 256) {
+      const float pr = cur_eos[b];
+      const int cur = pr > thr ? 1 : 0;
+      int f = finished[b], ol = out_lens[b];
+      if (!f && cur) ol = step + 1;
+      f |= cur;
+      finished[b] = f;
+      out_lens[b] = ol;
+      klen_next[b] = ol == max_iter ? step + 2 : ol;
+      c += f;
+      if (step < max_iter) eos_all[(long)step * B + b] = pr;
+    }
+    c = (int)wave_sum((float)c);
+    if ((tid & 63) == 0) cnt[tid >> 6] = c;
+    const int row = min(step + 3, pe_rows - 1);  // next step's position: (step + 1) + 2
+    for (int k = tid; k < Cd; k += 256) pe_cur[k] = pe_alpha[(long)row * Cd + k];
+    if (tid < 8) seeds[tid] = replay_site_seed(seed0, step + 1, tid);
+    __syncthreads();
+    if (tid == 0 && step < max_iter) n_done[step] = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    return;
+  }
+  if (step >= max_iter) return;
+  const long nf = (long)B * out_dim, na = (attn_all && cur_attn) ? (long)B * E : 0;
+  const long i = ((long)blockIdx.x - 1) * 256 + tid;
+  if (i < nf) feat_all[(long)step * nf + i] = cur_feat[i];
+  else if (i - nf < na) attn_all[(long)step * na + (i - nf)] = cur_attn[i - nf];
+}
+__global__ void decode_replay_advance_kernel(int* __restrict__ step_p) { *step_p += 1; }
 }  // namespace
+
+int s2st_decode_replay_init(int* step, uint64_t* seeds, float* cur_feat, long n_feat, float* pe_cur, const float* pe_alpha, int Cd,
+                            uint64_t seed0, hipStream_t st) {
+  if (!step || !seeds || !cur_feat || !pe_cur || !pe_alpha || n_feat <= 0 || Cd <= 0) return S2ST_ERR_ARG;
+  S2ST_LAUNCH(decode_replay_init_kernel, dim3(1), dim3(1024), 0, st, step, seeds, cur_feat, n_feat, pe_cur, pe_alpha, Cd, seed0);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+int s2st_decode_replay_commit(int* step, uint64_t* seeds, const float* cur_feat, const float* cur_eos, const float* cur_attn,
+                              float* pe_cur, const float* pe_alpha, int pe_rows, int Cd, uint64_t seed0, float thr, int max_iter,
+                              int B, int out_dim, int E, int* finished, int* out_lens, int* klen_next, int* n_done,
+                              float* feat_all, float* eos_all, float* attn_all, hipStream_t st) {
+  if (B <= 0) return 0;
+  if (!step || !seeds || !cur_feat || !cur_eos || !pe_cur || !pe_alpha || !finished || !out_lens || !klen_next || !n_done ||
+      !feat_all || !eos_all)
+    return S2ST_ERR_ARG;
+  const long n_copy = (long)B * out_dim + ((attn_all && cur_attn) ? (long)B * E : 0);
+  S2ST_LAUNCH(decode_replay_commit_kernel, dim3(1 + (unsigned)((n_copy + 255) / 256)), dim3(256), 0, st, (const int*)step, seeds,
+              cur_feat, cur_eos, cur_attn, pe_cur, pe_alpha, pe_rows, Cd, seed0, thr, max_iter, B, out_dim, E, finished, out_lens,
+              klen_next, n_done, feat_all, eos_all, attn_all);
+  S2ST_LAUNCH(decode_replay_advance_kernel, dim3(1), dim3(1), 0, st, step);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
 
 int s2st_decode_stop_update(const float* eos_prob, float thr, int step, int max_iter, int B, int* finished, int* out_lens,
                             int* klen_next, int* n_done, hipStream_t st) {

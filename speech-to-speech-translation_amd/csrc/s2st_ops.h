@@ -82,7 +82,8 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* tile_out);
 // skinny-M (<= 16 rows) y = f(x W^T + b) (+ resid) with fp32 x converted in registers (AR decoding)
 int s2st_gemm_skinny(const float* A, long lda, const bf16raw* W, long ldw, float* C, long ldc, const float* bias, int act,
                      float drop_p, uint64_t seed, const float* resid, long ldr, int M, int N, int K, hipStream_t st,
-                     const float* ln_g = nullptr, const float* ln_b = nullptr, float ln_eps = 1e-5f /* optional fused LayerNorm of x */);
+                     const float* ln_g = nullptr, const float* ln_b = nullptr, float ln_eps = 1e-5f /* optional fused LayerNorm of x */,
+                     const uint64_t* seed_ptr = nullptr /* replayable decode step: the seed is read from device memory */);
 // gemm_bf16_w4.hip: the 4-wave early-release ring form (2 - 3 workgroups per CU) for the short-K products of a step;
 // g / grp as prepared by s2st_gemm_bf16 / s2st_gemm_bf16_group for the tile (bm, bn)
 int s2st_gemm_bf16_w4(const GemmArgs& g, int bm, int bn, dim3 grid, hipStream_t st);
@@ -281,10 +282,18 @@ int s2st_posconv_prep(float* x, const int* lens, float* img, uint16_t* imgh, int
 int s2st_decode_attn(const float* q, long ldq, float* kc, float* vc, long ldk, long kbs, const int* klen,
                      int nkeys, int B, int H, int dh, float scale, float* o, long ldo, float* attn_mean, int S,
                      hipStream_t st, const float* k_new = nullptr, const float* v_new = nullptr, long ld_new = 0,
-                     int pos_new = 0, int kv_bf16 = 0);  // kv_bf16: kc / vc point at bf16 rows (ldk, kbs in elements)
+                     int pos_new = 0, int kv_bf16 = 0,  // kv_bf16: kc / vc point at bf16 rows (ldk, kbs in elements)
+                     const int* step_ptr = nullptr);  // replayable decode step: nkeys = *step_ptr + 1, pos_new = *step_ptr (nkeys: the bound)
 int s2st_scale_rows(const float* x, const float* a, float* y, long n, hipStream_t st);
 int s2st_decode_stop_update(const float* eos_prob, float thr, int step, int max_iter, int B, int* finished, int* out_lens,
                             int* klen_next, int* n_done, hipStream_t st);
+// replayable decode step (engine.cpp decode_step replay mode): state for step 0; stop rule + output rows + next step's state
+int s2st_decode_replay_init(int* step, uint64_t* seeds, float* cur_feat, long n_feat, float* pe_cur, const float* pe_alpha, int Cd,
+                            uint64_t seed0, hipStream_t st);
+int s2st_decode_replay_commit(int* step, uint64_t* seeds, const float* cur_feat, const float* cur_eos, const float* cur_attn,
+                              float* pe_cur, const float* pe_alpha, int pe_rows, int Cd, uint64_t seed0, float thr, int max_iter,
+                              int B, int out_dim, int E, int* finished, int* out_lens, int* klen_next, int* n_done,
+                              float* feat_all, float* eos_all, float* attn_all, hipStream_t st);
 int s2st_sigmoid(const float* x, float* y, long n, hipStream_t st);
 int s2st_argmax_dim1(const float* x, long* idx, int B, int E, int D, hipStream_t st);
 int s2st_affine_cols(const float* x, const float* scale, const float* shift, float* y, long rows, int C, hipStream_t st);

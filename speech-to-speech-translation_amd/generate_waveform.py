@@ -30,6 +30,7 @@ import torch
 
 from . import checkpoint_utils
 from .registry import TASKS
+from .runtime import streams as _streams
 
 
 def make_parser() -> argparse.ArgumentParser:
@@ -214,7 +215,7 @@ def main(argv: Optional[List[str]] = None, device: Optional[torch.device] = None
     defer = device.type == "cuda" and os.environ.get("S2ST_DEFER_VOCODER", "1") != "0"
     # ... and two batches are DECODED at once (generate_two: the second on a twin engine and a second stream) where the
     # generator has that form: the decoding steps of one batch leave most of the chip idle (S2ST_DECODE_CHAINS=1: one by one)
-    chains = max(1, int(os.environ.get("S2ST_DECODE_CHAINS", "2"))) if (defer and not mtl and hasattr(generator, "generate_many")) else 1
+    chains = _streams.default_decode_chains() if (defer and not mtl and hasattr(generator, "generate_many")) else 1
 
     def groups():
         buf, n = [], 0

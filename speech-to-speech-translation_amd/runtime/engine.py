@@ -58,6 +58,11 @@ class Outputs(C.Structure):
                                   "asr_logits", "st_logits", "ctc_lprobs", "stats")]
 
 
+class DecodeReplay(C.Structure):  # s2st_decode_replay (include/s2st_hip.h)
+    _fields_ = [(n, C.c_void_p) for n in ("step", "seeds", "cur_feat", "cur_eos", "cur_attn", "pe_cur")]
+
+
+
 STAT = dict(L1_SUM=0, MSE_SUM=1, BCE_SUM=2, ASR_NLL=3, ASR_SMOOTH=4, ASR_CORRECT=5, ASR_TOTAL=6,
             ST_NLL=7, ST_SMOOTH=8, ST_CORRECT=9, ST_TOTAL=10, LOSS=16, L1=17, MSE=18, EOS=19,
             CTC=20, ASR=21, ST=22, CTC_TGT=23, GNORM=24)
@@ -656,6 +661,66 @@ class Engine:
                    self.workspace.data_ptr(), self.workspace.numel(), bd.stream_ptr()), "s2st_engine_decode_step")
         bd.call("s2st_decode_stop_update_i32", b["eos"][step], float(thr), step, int(max_iter), d["B"], b["finished"],
                 b["out_lens"], b["klen"], b["n_done"])
+
+    # ---- the step in its graph-replayable form (include/s2st_hip.h s2st_decode_replay; round 5) ------------------------
+    def decode_replay_prepare(self, seed0: int, thr: float, max_iter: int, graph: bool = True) -> bool:
+        """After ``decode_buffers``: set up this run's steps in the form whose step-dependent values live in device memory
+        (step counter, prenet seeds, input frame, position row), so that ONE captured step is replayed for the whole run
+        -- a HIP graph launch per step instead of ~55 kernel launches (config 5 was bound by the host's enqueue rate).
+        ``graph=False``: the same calls enqueued directly every step (what the CPU tests run: the emulator has no graphs).
+        False where the run's steps do not qualify (the caller keeps ``decode_step_into``)."""
+        d, dev, c = self._dec, self.device, self.cfg
+        lib = self.lib
+        lib.s2st_engine_decode_replay_supported.argtypes = [C.c_void_p]
+        lib.s2st_engine_decode_replay_supported.restype = C.c_int32
+        if not int(lib.s2st_engine_decode_replay_supported(self.h)):
+            return False
+        B, E = d["B"], d["E"]
+        r = dict(step=torch.zeros(1, dtype=torch.int32, device=dev), seeds=torch.zeros(8, dtype=torch.int64, device=dev),
+                 cur_feat=torch.zeros(B, c.out_dim, device=dev), cur_eos=torch.zeros(B, device=dev),
+                 cur_attn=torch.zeros(B, E, device=dev), pe_cur=torch.zeros(c.dec_dim, device=dev))
+        st = DecodeReplay(*(r[k].data_ptr() for k in ("step", "seeds", "cur_feat", "cur_eos", "cur_attn", "pe_cur")))
+        seed0 &= (1 << 64) - 1
+        d["replay"] = dict(bufs=r, st=st, seed0=seed0, thr=float(thr), max_iter=int(max_iter), graph=None)
+        lib.s2st_engine_decode_replay_begin.argtypes = [C.c_void_p, C.POINTER(DecodeReplay), C.c_uint64, C.c_void_p]
+        lib.s2st_engine_decode_step_replay.argtypes = [C.c_void_p, C.POINTER(DecodeReplay), C.c_void_p, C.c_void_p, C.c_int64,
+                                                       C.c_void_p]
+        lib.s2st_engine_decode_replay_commit.argtypes = [C.c_void_p, C.POINTER(DecodeReplay), C.c_uint64, C.c_float, C.c_int32,
+                                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                         C.c_void_p, C.c_void_p, C.c_void_p]
+        if graph and dev.type == "cuda":
+            from . import streams
+            g = torch.cuda.CUDAGraph()
+            cap = streams.capture_stream(dev)
+            cap.wait_stream(torch.cuda.current_stream())
+            # (thread_local: the vocoder's phase-draw thread keeps uploading on its own stream while this thread captures)
+            with torch.cuda.graph(g, stream=cap, capture_error_mode="thread_local"):
+                self._decode_replay_enqueue()
+            torch.cuda.current_stream().wait_stream(cap)
+            d["replay"]["graph"] = g
+        bd.check(lib.s2st_engine_decode_replay_begin(self.h, C.byref(st), seed0, bd.stream_ptr()),
+                 "s2st_engine_decode_replay_begin")
+        return True
+
+    def _decode_replay_enqueue(self):
+        d = self._dec
+        rp, b = d["replay"], d["bufs"]
+        bd.check(self.lib.s2st_engine_decode_step_replay(self.h, C.byref(rp["st"]), b["klen"].data_ptr(),
+                                                         self.workspace.data_ptr(), self.workspace.numel(), bd.stream_ptr()),
+                 "s2st_engine_decode_step_replay")
+        bd.check(self.lib.s2st_engine_decode_replay_commit(self.h, C.byref(rp["st"]), rp["seed0"], rp["thr"], rp["max_iter"],
+                                                           b["finished"].data_ptr(), b["out_lens"].data_ptr(),
+                                                           b["klen"].data_ptr(), b["n_done"].data_ptr(), b["feat"].data_ptr(),
+                                                           b["eos"].data_ptr(), b["attn"].data_ptr(), bd.stream_ptr()),
+                 "s2st_engine_decode_replay_commit")
+
+    def decode_replay_step(self):
+        """The next step of a run ``decode_replay_prepare`` set up (same outputs as ``decode_step_into`` step by step)."""
+        g = self._dec["replay"]["graph"]
+        if g is not None:
+            g.replay()
+        else:
+            self._decode_replay_enqueue()
 
     def decode_step(self, step: int, prev: torch.Tensor, seed: int, want_attn: bool = True,
                     self_klen: Optional[torch.Tensor] = None):

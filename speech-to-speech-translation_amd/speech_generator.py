@@ -5,6 +5,8 @@ post-net, the alignment argmax, the global-CMVN de-normalisation and the vocoder
 libs2st_hip.so; this file is the reference's host loop (step counting, finished flags, slicing)."""
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional
 
 import torch
@@ -70,7 +72,7 @@ class SpeechGenerator:
         vs = getattr(self.vocoder, "_defer_stream", None)  # (one per vocoder: generators that share it share the stream)
         if vs is None:
             from .runtime import streams
-            vs = streams.get("vocoder", feats[0].device)  # (one per device: see runtime/streams.py)
+            vs = streams.get("vocoder", feats[0].device, may_share=("phase-upload",))  # (one per device: see runtime/streams.py)
             try:
                 self.vocoder._defer_stream = vs
             except AttributeError:
@@ -238,8 +240,22 @@ class AutoRegressiveSpeechGenerator(SpeechGenerator):
         pinned.zero_()
         events = []
         n_steps = self.max_iter
+        # Round 5, measured and left OFF (profiles/r05_infer_graph.txt): the step as ONE HIP-graph launch.  A run's ~55
+        # kernels per step are enqueued one by one (15 k launches per batch of 64 utterances); the engine's replay form keeps
+        # everything that changes from step to step in device memory, so a step captured once per run can be replayed
+        # (runtime/engine.py decode_replay_prepare).  The host's share of a step drops from 0.21 to 0.03 ms -- and the GPU's
+        # grows from 0.46 to 0.52 ms (the runtime's graph nodes cost more than stream launches between dependent kernels),
+        # which is what bounds config 5: 640 - 670 utterances/s against 725 - 780.  S2ST_DECODE_GRAPH=1: the graph; =direct:
+        # the replay form's calls without a graph (what runs on the CPU emulator); default 0: the step-by-step calls.  Same
+        # outputs in all three, bit for bit (tests/test_inference.py).
+        mode = os.environ.get("S2ST_DECODE_GRAPH", "0")
+        replay = mode != "0" and eng.decode_replay_prepare(self.seed * 1000003, self.eos_prob_threshold, self.max_iter,
+                                                            graph=(mode != "direct"))
         for step in range(self.max_iter):
-            eng.decode_step_into(step, self.seed * 1000003 + step, self.eos_prob_threshold, self.max_iter)
+            if replay:
+                eng.decode_replay_step()
+            else:
+                eng.decode_step_into(step, self.seed * 1000003 + step, self.eos_prob_threshold, self.max_iter)
             pinned[step:step + 1].copy_(bufs["n_done"][step:step + 1], non_blocking=True)
             if on_gpu:
                 ev = torch.cuda.Event()

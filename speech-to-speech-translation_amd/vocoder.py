@@ -295,7 +295,7 @@ class GriffinLim:
                         # the draws go to the device as soon as the host has them, under the decode (a copy stream of their own)
                         if self.__dict__.get("_copy_stream") is None:
                             from .runtime import streams
-                            self._copy_stream = streams.get("phase-upload", self.device)
+                            self._copy_stream = streams.get("phase-upload", self.device, may_share=("vocoder",))
                         up = (self.device, self._copy_stream, None)
                     obj = _HostMTStream(n, self.device.type == "cuda", buf=buf, upload=up,
                                         start_after=pending[-1] if pending else None)

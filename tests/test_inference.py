@@ -862,3 +862,51 @@ def test_two_batches_decoded_at_once_give_the_sequential_results(backend, has_ta
             for hx, hy in zip(x, y):
                 for k in ("feature", "eos_prob", "alignment", "waveform"):
                     assert torch.equal(hx[k], hy[k]), (thr, "three chains", k)
+
+
+@pytest.mark.parametrize("early", [True, False], ids=["early_stops", "to_max_iter"])
+def test_decode_step_replay_form_equals_step_by_step(backend, monkeypatch, early):
+    """Round 5 (include/s2st_hip.h s2st_decode_replay): the AR step in the form whose step counter, prenet seeds, input frame
+    and position row live in device memory -- one captured HIP graph replayed per step on the GPU, the same calls enqueued
+    directly on the emulator -- against decode_step + the stop rule called step by step: every output bit for bit (prenet
+    dropout ON: the seeds the kernels read from device memory are the ones the host derives), early stops included."""
+    gen_mod = importlib.import_module(PKG + ".speech_generator")
+    tasks = importlib.import_module(PKG + ".tasks")
+    a = O.make_args(**dict(CONFIGS["tiny"], prenet_dropout=0.5))
+    a.precise_gemm = False
+    task = tasks.S2ST_TranslationTask.setup_task(a, device=backend.device)
+    model = task.build_model(a)
+    load_synth(model, 0)
+    s = golden_sample("tiny", 0)
+    s["net_input"]["collated_audios_orig"] = None
+    s["net_input"]["padding_mask"] = None
+    thr = 2.0
+    if early:  # a threshold about half of the utterances cross somewhere before max_iter (from a run that never stops)
+        monkeypatch.setenv("S2ST_DECODE_GRAPH", "0")
+        gen = gen_mod.AutoRegressiveSpeechGenerator(model, None, None, max_iter=9, eos_prob_threshold=2.0)
+        gen.seed = 77
+        peaks = sorted(float(h["eos_prob"][:-4].max()) for h in gen.generate(model, s))
+        thr = 0.5 * (peaks[len(peaks) // 2 - 1] + peaks[len(peaks) // 2])
+    runs = {}
+    for mode in ("0", "direct") + (("1",) if backend.kind == "hip" else ()):
+        monkeypatch.setenv("S2ST_DECODE_GRAPH", mode)
+        gen = gen_mod.AutoRegressiveSpeechGenerator(model, None, None, max_iter=9, eos_prob_threshold=thr)
+        gen.seed = 77
+        for rep in range(2):  # (a second run over the same engine: fresh state, same results)
+            fin = gen.generate(model, s)
+            backend.sync()
+            used = model.engine._dec.get("replay") is not None
+            assert used == (mode != "0"), (mode, used)  # (the default, unset, is "0")
+            if mode == "1":
+                assert model.engine._dec["replay"]["graph"] is not None
+            runs[(mode, rep)] = [{k: h[k].clone() for k in ("feature", "eos_prob", "attn", "alignment")} for h in fin]
+    ref = runs[("0", 0)]
+    lens = {h["feature"].shape[0] for h in ref}
+    if early:
+        assert len(lens) > 1, (thr, lens)  # (the batch mixes early stops and max_iter)
+    for key, got in runs.items():
+        assert len(got) == len(ref)
+        for hx, hy in zip(ref, got):
+            for k in ("feature", "eos_prob", "alignment"):
+                assert torch.equal(hx[k], hy[k]), (key, k)
+            assert float((hx["attn"] - hy["attn"]).abs().max()) < 1e-6, key  # (head mean by atomics: last-bit noise)
