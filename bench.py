@@ -169,7 +169,7 @@ INFER_MAX_TOKENS = 100000  # the recipe's generate_waveform batches by --max-tok
                            # utterances x longest source of a length-ordered batch; the 64 utterances below are ONE batch
                            # (rounds 1 - 3 decoded them 16 at a time: four times the sequential decoding steps)
 INFER_N_UTTS = 64     # 64 utterances of the synthetic Fisher-shaped distribution
-INFER_GL_ITERS = 64   # --spec-bwd-max-iter 64
+INFER_GL_ITERS = int(os.environ.get("S2ST_BENCH_GL_ITERS", "64"))   # --spec-bwd-max-iter 64 (the env override: a diagnosis aid, never the reported workload)
 
 
 def infer_cpu_leg(args):
