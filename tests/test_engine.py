@@ -409,6 +409,8 @@ def test_two_utterance_half_chains_equal_one_chain(backend, postln, n_utts, monk
     the same whole-batch tensors.  With dropout off both schedules compute the same function row by row: same losses and
     outputs, gradients equal up to the order of the partial-sum folds (and of the tile shapes the halves pick).  With
     dropout on, chain 1's masks are salted: the step runs, repeats for a seed, and differs from the one-chain masks."""
+    if backend.kind == "emu" and (postln, n_utts) in ((False, 3), (True, 4)):
+        pytest.skip("the emulator runs pre-LN / even and post-LN / odd; all four on the GPU (the CPU suite's time budget)")
     D = importlib.import_module(DATA)
     base = dict(MICRO_POSTLN if postln else MICRO, encoder_embed_dim=128, decoder_embed_dim=128, encoder_ffn_embed_dim=256,
                 decoder_ffn_embed_dim=256, encoder_attention_heads=2, decoder_attention_heads=2, prenet_dim=128, postnet_conv_dim=128)

@@ -25,16 +25,27 @@ SOURCES = ("gemm_bf16.hip", "gemm_bf16_w4.hip", "losses.hip")
 @pytest.fixture(scope="module")
 def asm(tmp_path_factory):
     """The three sources compiled to gfx950 assembly, side by side (one hipcc process each)."""
-    d = str(tmp_path_factory.mktemp("isa"))
-    procs = {}
+    # (cached beside the build's objects, keyed by the sources' modification times: the three compilations take ~2 minutes
+    #  of the CPU suite, the kernels change a few times a round)
+    d = os.path.join(CSRC, "build", "isa")
+    os.makedirs(d, exist_ok=True)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include")) if f.endswith(".h")]
+    procs, res = {}, {}
     for src in SOURCES:
         out = os.path.join(d, src + ".s")
+        newest = max(os.path.getmtime(p) for p in deps + [os.path.join(CSRC, src)])
+        if os.path.exists(out) and os.path.getsize(out) > 0 and os.path.getmtime(out) > newest:
+            res[src] = out
+            continue
         procs[src] = (out, subprocess.Popen(
             [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-Wno-unused-value",
              "-Wno-unused-command-line-argument", "-S", "--cuda-device-only", "-x", "hip", os.path.join(CSRC, src), "-o", out]))
-    res = {}
     for src, (out, pr) in procs.items():
-        assert pr.wait() == 0, "hipcc failed on " + src
+        if pr.wait() != 0:
+            if os.path.exists(out):
+                os.remove(out)
+            raise AssertionError("hipcc failed on " + src)
         res[src] = out
     return res
 
