@@ -98,7 +98,10 @@ class GradReducer:
         self.min_bucket = min_bucket_floats
         self.cuda = grads.is_cuda
         from . import streams
-        self.stream = streams.get("gradient-exchange", grads.device) if self.cuda else None
+        # (its own hardware queue: not the engine's weight-gradient stream's, whose ranges it ships while that stream works on
+        #  the next ones; the batch prefetcher's rare copies may sit behind it)
+        self.stream = (streams.get("gradient-exchange", grads.device, avoid=[extra_stream] if extra_stream is not None else None,
+                                   may_share=("prefetch",)) if self.cuda else None)
         self.pending: Optional[Tuple[int, int]] = None
         self.handles: List = []
         self.reduced: List[Tuple[int, int]] = []

@@ -53,7 +53,7 @@ class DevicePrefetcher:
         self.q: "queue.Queue" = queue.Queue(maxsize=max(depth, 1))
         self.cuda = engine.device.type == "cuda"
         from . import streams
-        self.stream = streams.get("prefetch", engine.device) if self.cuda else None
+        self.stream = streams.get("prefetch", engine.device, may_share=("gradient-exchange",)) if self.cuda else None
         self._stop = False
         self._held = None  # (the look-ahead item of a --use-hubert run)
         self.thread = threading.Thread(target=self._run, args=(iter(batches),), daemon=True)
