@@ -1,7 +1,13 @@
 // Fiber scheduler of the wave64 emulator (test infrastructure, see hip/hip_runtime.h).
 #include "hip/hip_runtime.h"
+#include <setjmp.h>
 #include <ucontext.h>
+#include <deque>
+#include <pthread.h>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -12,9 +18,14 @@ thread_local dim3 blockDim, gridDim;
 namespace {
 constexpr size_t kStack = 96 * 1024;
 
+// Fibers live as long as their worker thread and are switched with _setjmp / _longjmp (round 5): getcontext / swapcontext
+// save and restore the signal mask -- a system call per switch, several per fiber and block; only a fiber's FIRST entry onto
+// its stack still goes through swapcontext.  A fiber runs the kernel of every block its worker executes, one after the other.
 struct Fiber {
   ucontext_t ctx;
+  jmp_buf jb;
   char* stack = nullptr;
+  bool started = false;
   bool done = true;
   const volatile unsigned* wait_ptr = nullptr;  // runnable when *wait_ptr != wait_val
   unsigned wait_val = 0;
@@ -30,9 +41,10 @@ struct Wave {
 };
 
 struct Worker {
-  std::vector<Fiber> fibers;
+  std::deque<Fiber> fibers;  // (stable addresses: a ucontext_t must not move once made)
   std::vector<Wave> waves;
   ucontext_t sched;
+  jmp_buf sched_jb;
   int cur = -1;
   int nthreads = 0;
   int active = 0;
@@ -48,14 +60,16 @@ struct Worker {
 thread_local Worker* W = nullptr;
 
 void fiber_main() {
-  Worker* w = W;
-  w->tramp(w->args);
-  Fiber& f = w->fibers[w->cur];
-  f.done = true;
-  w->active--;
-  // a thread that exits counts as arrived for any pending workgroup barrier
-  if (w->bar_arrived > 0 && w->bar_arrived >= w->active) { w->bar_arrived = 0; w->bar_gen++; }
-  swapcontext(&f.ctx, &w->sched);
+  Worker* w = W;  // (a fiber stays with the thread that made it)
+  for (;;) {      // one kernel invocation per block this fiber takes part in
+    w->tramp(w->args);
+    Fiber& f = w->fibers[w->cur];
+    f.done = true;
+    w->active--;
+    // a thread that exits counts as arrived for any pending workgroup barrier
+    if (w->bar_arrived > 0 && w->bar_arrived >= w->active) { w->bar_arrived = 0; w->bar_gen++; }
+    if (!_setjmp(f.jb)) _longjmp(w->sched_jb, 1);
+  }
 }
 
 void yield_wait(const volatile unsigned* p, unsigned v) {
@@ -63,15 +77,20 @@ void yield_wait(const volatile unsigned* p, unsigned v) {
   Fiber& f = w->fibers[w->cur];
   f.wait_ptr = p;
   f.wait_val = v;
-  swapcontext(&f.ctx, &w->sched);
+  if (!_setjmp(f.jb)) _longjmp(w->sched_jb, 1);
 }
 
 void run_block(Worker* w, dim3 block) {
   int n = block.x * block.y * block.z;
-  if ((int)w->fibers.size() < n) {
-    size_t old = w->fibers.size();
-    w->fibers.resize(n);
-    for (size_t i = old; i < (size_t)n; ++i) w->fibers[i].stack = (char*)malloc(kStack);
+  while ((int)w->fibers.size() < n) {
+    w->fibers.emplace_back();
+    Fiber& f = w->fibers.back();
+    f.stack = (char*)malloc(kStack);
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack;
+    f.ctx.uc_stack.ss_size = kStack;
+    f.ctx.uc_link = nullptr;
+    makecontext(&f.ctx, fiber_main, 0);
   }
   int nw = (n + 63) / 64;
   w->waves.assign(nw, Wave());
@@ -87,11 +106,6 @@ void run_block(Worker* w, dim3 block) {
     f.tid.x = i % block.x;
     f.tid.y = (i / block.x) % block.y;
     f.tid.z = i / (block.x * block.y);
-    getcontext(&f.ctx);
-    f.ctx.uc_stack.ss_sp = f.stack;
-    f.ctx.uc_stack.ss_size = kStack;
-    f.ctx.uc_link = nullptr;
-    makecontext(&f.ctx, fiber_main, 0);
   }
   int remaining = n;
   while (remaining > 0) {
@@ -105,7 +119,14 @@ void run_block(Worker* w, dim3 block) {
       f.wait_ptr = nullptr;
       w->cur = i;
       threadIdx = f.tid;
-      swapcontext(&w->sched, &f.ctx);
+      if (!_setjmp(w->sched_jb)) {
+        if (!f.started) {
+          f.started = true;
+          swapcontext(&w->sched, &f.ctx);  // (first entry onto the fiber's stack; it comes back through sched_jb)
+        } else {
+          _longjmp(f.jb, 1);
+        }
+      }
       progressed = true;
     }
     if (!progressed && remaining > 0) {
@@ -154,6 +175,56 @@ void emu_wave_exchange(const void* in, void* all_out, int bytes) {
   for (int i = 0; i < 64; ++i) memcpy(o + (size_t)i * bytes, wv.buf[b][i], bytes);
 }
 
+// Worker threads that live as long as the process (round 5): a launch used to START up to 8 threads, each of which
+// allocated -- and at its exit freed -- the fiber stacks of its thread_local Worker; with thousands of launches per test the
+// CPU suite spent a quarter of its time in the kernel (13 of 57 CPU-minutes).  The pool's threads keep their Workers; one
+// launch runs at a time (launches are synchronous anyway; a second host thread waits its turn); after a fork() the child
+// builds a pool of its own.
+namespace {
+struct Pool {
+  std::mutex launch_mu;
+  std::mutex mu;
+  std::condition_variable cv_work, cv_done;
+  std::function<void()> job;
+  unsigned size = 0, want = 0, finished = 0;
+  unsigned long gen = 0;
+};
+Pool* g_pool = nullptr;
+std::once_flag g_atfork;
+
+void pool_thread(Pool* p, unsigned idx) {
+  unsigned long seen = 0;
+  for (;;) {
+    std::function<void()> job;
+    {
+      std::unique_lock<std::mutex> lk(p->mu);
+      p->cv_work.wait(lk, [&] { return p->gen != seen; });
+      seen = p->gen;
+      if (idx >= p->want) continue;
+      job = p->job;
+    }
+    job();
+    {
+      std::lock_guard<std::mutex> lk(p->mu);
+      if (++p->finished == p->want) p->cv_done.notify_all();
+    }
+  }
+}
+
+Pool* get_pool() {
+  std::call_once(g_atfork, [] { pthread_atfork(nullptr, nullptr, [] { g_pool = nullptr; }); });
+  if (!g_pool) {
+    Pool* p = new Pool();  // (never destroyed: its threads are detached and end with the process)
+    unsigned hw = std::thread::hardware_concurrency();
+    p->size = hw ? hw : 4;
+    if (p->size < 8) p->size = 8;  // (HIPEMU_THREADS may ask for up to this many)
+    for (unsigned i = 0; i < p->size; ++i) std::thread(pool_thread, p, i).detach();
+    g_pool = p;
+  }
+  return g_pool;
+}
+}  // namespace
+
 void emu_launch_impl(void (*tramp)(void*), void* args, dim3 grid, dim3 block) {
   size_t nblocks = (size_t)grid.x * grid.y * grid.z;
   if (nblocks == 0) return;
@@ -179,7 +250,17 @@ void emu_launch_impl(void (*tramp)(void*), void* args, dim3 grid, dim3 block) {
     }
   };
   if (nthr <= 1) { work(); return; }
-  std::vector<std::thread> ts;
-  for (unsigned i = 0; i < nthr; ++i) ts.emplace_back(work);
-  for (auto& t : ts) t.join();
+  Pool* p = get_pool();
+  if (nthr > p->size) nthr = p->size;
+  std::lock_guard<std::mutex> one(p->launch_mu);
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->job = work;
+    p->want = nthr;
+    p->finished = 0;
+    ++p->gen;
+  }
+  p->cv_work.notify_all();
+  std::unique_lock<std::mutex> lk(p->mu);
+  p->cv_done.wait(lk, [&] { return p->finished == p->want; });
 }
