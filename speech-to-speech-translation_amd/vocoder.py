@@ -361,6 +361,8 @@ class GriffinLim:
         return self._dense
 
     def _fft_tables(self):
+        # (made lazily on whichever stream asks first and read on others later: `.to(device)` of a pageable host tensor is a
+        #  blocking copy -- the bytes are in place when it returns -- so no event is needed; the same holds for _window_sum_square)
         if self._ft is None:
             j = np.arange(self.n_fft, dtype=np.float64)
             tw = np.stack([np.cos(2 * np.pi * j / self.n_fft), -np.sin(2 * np.pi * j / self.n_fft)], axis=1).astype(np.float32)
