@@ -376,6 +376,34 @@ int s2st_engine_bf16_is_fresh(s2st_engine* e);
 /* instrumentation (S2ST_STALL_TRACE=1): time the data-path stream spent in cross-stream waits since the last
  * report, in microseconds (per-wait lines on stderr when verbose); call after synchronising the device */
 int64_t s2st_engine_stall_report(s2st_engine* e, int32_t verbose);
+/* Dropout sites of a forward (test instrumentation: parity with the recipe's dropouts ON).  The reference draws its masks
+ * from torch's generator at every F.dropout (fairseq/modules/fairseq_dropout.py:16-27; sites: transformer_layer.py:150-162,
+ * 384-431; multihead_attention.py:360-366; s2st_transformer.py:197-208, 385-388; tacotron2.py:95-98, 122-126;
+ * transformer_decoder.py:281-370); this library keeps no masks -- keep(element) = hash(site seed, element index) -- so the
+ * only way to compare a dropout-on step with the CPU oracle is to give the oracle THIS step's masks.  With the log on, every
+ * forward records one entry per site; the mask of an entry is s2st_dropout_f32(ones, y, n, 1, p, seed, 0) over its element
+ * geometry:
+ *   S2ST_SITE_LINEAR  y = dropout(act(x W^T + b))            dims = {rows, N}: element (row, n) -> row * N + n, rows in [B][T] order
+ *   S2ST_SITE_ATTN    dropout on the attention probabilities  dims = {B, H, T, S, ld}: ((b * H + h) * T + t) * ld + s
+ *   S2ST_SITE_ROWS    dropout after the position add          dims = {rows, C}
+ *   S2ST_SITE_NORM    dropout after BatchNorm (+ tanh / ReLU) dims = {rows = B * T, C}
+ * ctx names the place ("enc.pe", "enc.L3", "dec.prenet", "dec.pe", "dec.L0", "post", "asr.pe", "asr.L0", "st...", "s2t...",
+ * "enc.prenet"); ordinal counts the sites of the same kind inside that place in forward order. */
+#define S2ST_SITE_LINEAR 1
+#define S2ST_SITE_ATTN 2
+#define S2ST_SITE_ROWS 3
+#define S2ST_SITE_NORM 4
+typedef struct s2st_dropout_site {
+  uint64_t seed;
+  int32_t kind;
+  int32_t ordinal;
+  float p;
+  int32_t reserved;
+  int64_t dims[5];
+  char ctx[24];
+} s2st_dropout_site;
+int s2st_engine_site_log(s2st_engine* e, int32_t on);
+int32_t s2st_engine_site_log_get(const s2st_engine* e, s2st_dropout_site* out, int32_t cap);
 /* optional second bf16 arena (param_floats elements): every training forward stores W^T of each 2-D
  * weight there (on the engine's second stream) so the data-gradient GEMMs read K-contiguous operands */
 int s2st_engine_bind_bf16_transposed(s2st_engine* e, uint16_t* params_bf16_t);

@@ -99,6 +99,64 @@ def make_args(**kw) -> argparse.Namespace:
 
 
 # ----------------------------------------------------------------------------------------
+# dropout sites
+# ----------------------------------------------------------------------------------------
+# Every dropout of the path goes through drop().  By default it IS F.dropout (torch's generator, as in the reference:
+# fairseq/modules/fairseq_dropout.py:16-27).  Inside ``with injected_masks(provider):`` the keep decision comes from
+# ``provider(site, layout, x, p)`` instead -- a 0/1 tensor of x's shape -- and the kept elements are scaled by 1 / (1 - p)
+# exactly as F.dropout scales them: the way tests/test_dropout_parity.py hands the oracle the masks the HIP engine used
+# (it keeps none; a mask is a function of (site seed, element index)), so that a misplaced site, a missing 1 / (1 - p) or
+# a forward / backward mask mismatch in the fused kernels shows against the reference's placement below.
+# A site's name = where it sits + kind + ordinal there (the engine's log uses the same scheme, include/s2st_hip.h):
+#   "<ctx>/attn<k>" probabilities [B*H, T, S]       (multihead_attention.py:360-366)
+#   "<ctx>/lin<k>"  outputs of linear layers        (transformer_layer.py:150-162, 384-431; tacotron2.py:95-98)
+#   "<ctx>/rows0"   after the position add          (s2st_transformer.py:197-208, 385-388; transformer_decoder.py:281-326)
+#   "<ctx>/norm<k>" after conv -> BatchNorm (-> tanh) (tacotron2.py:122-126; t2s_transformer.py:55-66)
+# layout says how x's axes relate to the engine's [B][T][C] rows: "tbc", "btc", "bct", or "attn".
+_MASK_PROVIDER = None
+
+
+class injected_masks:
+    def __init__(self, provider):
+        self.provider = provider
+
+    def __enter__(self):
+        global _MASK_PROVIDER
+        self.prev, _MASK_PROVIDER = _MASK_PROVIDER, self.provider
+        return self
+
+    def __exit__(self, *exc):
+        global _MASK_PROVIDER
+        _MASK_PROVIDER = self.prev
+
+
+def drop(x, p, training, site, layout):
+    if _MASK_PROVIDER is None or not training or p <= 0.0:
+        return F.dropout(x, p=p, training=training)
+    keep = _MASK_PROVIDER(site, layout, x, p)
+    assert keep.shape == x.shape, (site, tuple(keep.shape), tuple(x.shape))
+    return x * keep.to(x.dtype) * (1.0 / (1.0 - p))
+
+
+def name_sites(model):
+    """Give every module that owns a dropout site its place name (ctx): encoder / decoder / aux-decoder layers by index."""
+    def layers(mods, pre):
+        for i, l in enumerate(mods):
+            l.site = f"{pre}.L{i}"
+            l.self_attn.site, l.self_attn.site_k = l.site, 0
+            if hasattr(l, "encoder_attn"):
+                l.encoder_attn.site, l.encoder_attn.site_k = l.site, 1
+    layers(model.encoder.transformer_layers, "enc")
+    if hasattr(model, "decoder") and hasattr(model.decoder, "transformer_layers"):
+        layers(model.decoder.transformer_layers, "dec")
+    for who, dec in (("asr", getattr(model, "aux_asr_decoder", None)), ("st", getattr(model, "aux_st_decoder", None))):
+        if dec is not None:
+            dec.site = who
+            layers(dec.layers, who)
+    return model
+
+
+# ----------------------------------------------------------------------------------------
 # building blocks
 # ----------------------------------------------------------------------------------------
 def lengths_to_padding_mask(lens: torch.Tensor, max_len: Optional[int] = None) -> torch.Tensor:
@@ -160,6 +218,7 @@ class MultiheadAttention(nn.Module):
         self.head_dim = embed_dim // num_heads
         self.scaling = self.head_dim ** -0.5
         self.dropout = dropout
+        self.site, self.site_k = "", 0  # (name_sites)
         self.k_proj = nn.Linear(kdim, embed_dim)
         self.v_proj = nn.Linear(vdim, embed_dim)
         self.q_proj = nn.Linear(embed_dim, embed_dim)
@@ -185,7 +244,7 @@ class MultiheadAttention(nn.Module):
                 key_padding_mask.unsqueeze(1).unsqueeze(2).to(torch.bool), float("-inf")
             ).view(B * H, T, S)
         p = F.softmax(w.float(), dim=-1).type_as(w)
-        pd = F.dropout(p, p=self.dropout, training=self.training)
+        pd = drop(p, self.dropout, self.training, f"{self.site}/attn{self.site_k}", "attn")
         o = torch.bmm(pd, v)  # [B*H, T, Dh]
         o = o.transpose(0, 1).contiguous().view(T, B, C)
         o = self.out_proj(o)
@@ -205,20 +264,21 @@ class TransformerEncoderLayer(nn.Module):
         self.final_layer_norm = nn.LayerNorm(dim)
         self.normalize_before = normalize_before
         self.p, self.pa = dropout, act_dropout
+        self.site = ""
 
     def forward(self, x, pad_mask):
         r = x
         if self.normalize_before:
             x = self.self_attn_layer_norm(x)
         x, _ = self.self_attn(x, x, x, key_padding_mask=pad_mask)
-        x = r + F.dropout(x, self.p, self.training)
+        x = r + drop(x, self.p, self.training, f"{self.site}/lin0", "tbc")
         if not self.normalize_before:
             x = self.self_attn_layer_norm(x)
         r = x
         if self.normalize_before:
             x = self.final_layer_norm(x)
-        x = F.dropout(F.relu(self.fc1(x)), self.pa, self.training)
-        x = r + F.dropout(self.fc2(x), self.p, self.training)
+        x = drop(F.relu(self.fc1(x)), self.pa, self.training, f"{self.site}/lin1", "tbc")
+        x = r + drop(self.fc2(x), self.p, self.training, f"{self.site}/lin2", "tbc")
         if not self.normalize_before:
             x = self.final_layer_norm(x)
         return x
@@ -240,13 +300,14 @@ class TransformerDecoderLayer(nn.Module):
         self.final_layer_norm = nn.LayerNorm(dim)
         self.normalize_before = normalize_before
         self.p, self.pa = dropout, act_dropout
+        self.site = ""
 
     def forward(self, x, enc, enc_pad_mask, self_attn_mask, self_pad_mask, need_attn=False):
         r = x
         if self.normalize_before:
             x = self.self_attn_layer_norm(x)
         x, _ = self.self_attn(x, x, x, key_padding_mask=self_pad_mask, attn_mask=self_attn_mask)
-        x = r + F.dropout(x, self.p, self.training)
+        x = r + drop(x, self.p, self.training, f"{self.site}/lin0", "tbc")
         if not self.normalize_before:
             x = self.self_attn_layer_norm(x)
         r = x
@@ -254,14 +315,14 @@ class TransformerDecoderLayer(nn.Module):
             x = self.encoder_attn_layer_norm(x)
         x, attn = self.encoder_attn(x, enc, enc, key_padding_mask=enc_pad_mask,
                                     need_head_weights=need_attn)
-        x = r + F.dropout(x, self.p, self.training)
+        x = r + drop(x, self.p, self.training, f"{self.site}/lin1", "tbc")
         if not self.normalize_before:
             x = self.encoder_attn_layer_norm(x)
         r = x
         if self.normalize_before:
             x = self.final_layer_norm(x)
-        x = F.dropout(F.relu(self.fc1(x)), self.pa, self.training)
-        x = r + F.dropout(self.fc2(x), self.p, self.training)
+        x = drop(F.relu(self.fc1(x)), self.pa, self.training, f"{self.site}/lin2", "tbc")
+        x = r + drop(self.fc2(x), self.p, self.training, f"{self.site}/lin3", "tbc")
         if not self.normalize_before:
             x = self.final_layer_norm(x)
         return x, attn
@@ -311,8 +372,8 @@ class _PrenetLayers(nn.Module):
         self.dropout = dropout
 
     def forward(self, x):
-        for layer in self.layers:
-            x = F.dropout(layer(x), p=self.dropout)
+        for i, layer in enumerate(self.layers):
+            x = drop(layer(x), self.dropout, True, f"dec.prenet/lin{i}", "btc")
         return x
 
 
@@ -333,8 +394,9 @@ class Postnet(nn.Module):
 
     def forward(self, x):
         x = x.transpose(1, 2)
-        for c in self.convolutions:
-            x = c(x)
+        for i, c in enumerate(self.convolutions):
+            for m in c:  # (the Dropout module stays in the Sequential: state_dict indices as in the reference)
+                x = drop(x, m.p, self.training, f"post/norm{i}", "bct") if isinstance(m, nn.Dropout) else m(x)
         return x.transpose(1, 2)
 
 
@@ -374,7 +436,7 @@ class S2STEncoder(nn.Module):
         x = x + positional_embedding(pad, x.shape[-1]).transpose(0, 1)
         if speaker is not None:  # s2st_transformer.py:203-206: every position, padded ones included
             x = x + self.embed_speaker(speaker).transpose(0, 1)
-        x = F.dropout(x, self.a.dropout, self.training)
+        x = drop(x, self.a.dropout, self.training, "enc.pe/rows0", "tbc")
         taps = []
         for i, layer in enumerate(self.transformer_layers):
             x = layer(x, pad)
@@ -419,12 +481,13 @@ class T2SEncoder(nn.Module):
 
     def forward(self, src_tokens, src_lens, speaker=None):
         x = self.embed_tokens(src_tokens).transpose(1, 2).contiguous()
-        for conv in self.prenet:
-            x = conv(x)
+        for i, conv in enumerate(self.prenet):
+            for m in conv:
+                x = drop(x, m.p, self.training, f"enc.prenet/norm{i}", "bct") if isinstance(m, nn.Dropout) else m(x)
         x = self.prenet_proj(x.transpose(1, 2).contiguous())
         pad = src_tokens.eq(PAD)
         x = x + self.pos_emb_alpha * positional_embedding(pad, x.shape[-1])
-        x = F.dropout(x, self.a.dropout, self.training).transpose(0, 1)
+        x = drop(x, self.a.dropout, self.training, "enc.pe/rows0", "btc").transpose(0, 1)
         for layer in self.transformer_layers:
             x = layer(x, pad)
         if self.layer_norm is not None:
@@ -478,7 +541,7 @@ class S2STDecoder(nn.Module):
         pos = positional_embedding(pad, self.a.decoder_embed_dim)
         x = self.prenet(prev)
         x = x + self.pos_emb_alpha * pos
-        x = F.dropout(x, self.a.dropout, self.training)
+        x = drop(x, self.a.dropout, self.training, "dec.pe/rows0", "btc")
         x = x.transpose(0, 1)
         self_pad = pad if bool(pad.any()) else None
         enc_pad = enc["encoder_padding_mask"] if bool(enc["encoder_padding_mask"].any()) else None
@@ -533,13 +596,14 @@ class AuxTextDecoder(nn.Module):
         self.output_projection = nn.Linear(out_dim, vocab, bias=False)
         self.register_buffer("version", torch.Tensor([3]))
         self.embed_positions = _PositionalEmbeddingState()
+        self.site = ""
 
     def forward(self, tokens, enc):
         x = self.embed_scale * self.embed_tokens(tokens)
         if self.project_in_dim is not None:
             x = self.project_in_dim(x)
         x = x + positional_embedding(tokens, self.d)
-        x = F.dropout(x, self.a.dropout, self.training)
+        x = drop(x, self.a.dropout, self.training, f"{self.site}.pe/rows0", "btc")
         x = x.transpose(0, 1)
         pad = tokens.eq(PAD)
         self_pad = pad if bool(pad.any()) else None

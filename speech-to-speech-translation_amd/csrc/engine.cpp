@@ -579,7 +579,28 @@ struct s2st_engine {
     return y;
   }
   void chk(int rc) { if (rc && !err) err = rc; }
-  uint64_t next_seed() { return seed * 0x100000001B3ULL + (++site) * 0x9E3779B97F4A7C15ULL; }
+  // Dropout sites: the seed of the n-th site of a forward is a function of (batch seed, n).  s2st_engine_site_log(e, 1)
+  // makes the forward also RECORD every site -- seed, kind, p, the element geometry its mask is indexed by and where in
+  // the model it sits -- so that a test can regenerate the keep masks (s2st_dropout_f32 over ones) and hand them to the CPU
+  // oracle: parity with the recipe's dropouts ON (tests/test_dropout_parity.py).  Nothing on the data path reads the log.
+  bool site_log_on = false;
+  std::vector<s2st_dropout_site> site_log;
+  char site_ctx[24] = "";
+  void set_ctx(const char* fmt, int i = 0) { snprintf(site_ctx, sizeof site_ctx, fmt, i); }
+  uint64_t next_seed(int kind, float p, long d0, long d1 = 0, long d2 = 0, long d3 = 0, long d4 = 0) {
+    const uint64_t s = seed * 0x100000001B3ULL + (++site) * 0x9E3779B97F4A7C15ULL;
+    if (site_log_on) {
+      s2st_dropout_site r{};
+      r.seed = s; r.kind = kind; r.p = p;
+      r.dims[0] = d0; r.dims[1] = d1; r.dims[2] = d2; r.dims[3] = d3; r.dims[4] = d4;
+      snprintf(r.ctx, sizeof r.ctx, "%s", site_ctx);
+      int ord = 0;
+      for (const s2st_dropout_site& q : site_log) ord += (q.kind == kind && !strcmp(q.ctx, r.ctx)) ? 1 : 0;
+      r.ordinal = ord;
+      site_log.push_back(r);
+    }
+    return s;
+  }
   void mark() { marks.push_back(Mark{tape.size(), param_watermark}); }
   void touch(long off_end) {
     if (off_end > param_watermark) param_watermark = off_end;
@@ -720,7 +741,7 @@ struct s2st_engine {
     Ten* y = newT(M, N, ext_out, !only_h);
     touch(w + (long)N * K);
     if (b >= 0) touch(b + N);
-    const uint64_t sd = drop_p > 0.f ? next_seed() : 0;
+    const uint64_t sd = drop_p > 0.f ? next_seed(S2ST_SITE_LINEAR, drop_p, M, N) : 0;
     if (skinny) {
       const uint64_t* seed_ptr = nullptr;
       if (replay_ && drop_p > 0.f) {
@@ -1028,7 +1049,7 @@ struct s2st_engine {
     // the last decoder layer still needs the probabilities, so that one call stays unfused.
     if (fm && use_flash && s2st_flash_attn_supported(dh) && !attn_mean_out && o->h && io.ldq % 8 == 0 &&
         io.ldk % 8 == 0 && io.ldv % 8 == 0) {
-      const uint64_t sd = drop_p > 0.f ? next_seed() : 0;
+      const uint64_t sd = drop_p > 0.f ? next_seed(S2ST_SITE_ATTN, drop_p, B, H, T, S, ld) : 0;
       float* lse = alloc((long)B * H * T);
       s2st_attn_args fa{};
       fa.q = half_of(io.qt) + io.qoff; fa.k = half_of(io.kt) + io.koff; fa.v = half_of(io.vt) + io.voff;
@@ -1137,7 +1158,7 @@ struct s2st_engine {
     float* p = alloc((long)B * H * T * ld);
     float* pd = drop_p > 0.f ? alloc((long)B * H * T * ld) : p;
     bf16raw* pdh = fm ? alloc_h((long)B * H * T * ld) : nullptr;  // bf16 dropout(p): the P*V / dV operand
-    const uint64_t sd = drop_p > 0.f ? next_seed() : 0;
+    const uint64_t sd = drop_p > 0.f ? next_seed(S2ST_SITE_ATTN, drop_p, B, H, T, S, ld) : 0;
     const float scaling = 1.0f / sqrtf((float)dh);
     const int prec = c.precise;
     // operand views: (fp32 base, bf16 base) + element offset; strides are the same in both
@@ -1429,7 +1450,7 @@ struct s2st_engine {
   Ten* add_pe(Ten* x, const int* pos, const float* table, float scale, long alpha_off, float drop_p, long spk_off = -1,
               int T = 0) {
     Ten* y = newT(x->rows, x->cols);
-    const uint64_t sd = drop_p > 0.f ? next_seed() : 0;
+    const uint64_t sd = drop_p > 0.f ? next_seed(S2ST_SITE_ROWS, drop_p, x->rows, x->cols) : 0;
     if (alpha_off >= 0) touch(alpha_off + 1);
     const bool spk = spk_off >= 0 && bt.speaker != nullptr;
     if (spk) touch_spk(spk_off + (long)c.n_speakers * x->cols);
@@ -1473,9 +1494,14 @@ struct s2st_engine {
     });
     Ten* x = emb;
     if (a.proj_in >= 0) x = linear(x, a.proj_in, -1, a.d, a.in_dim);
+    const char* who = &a == &asr ? "asr" : (&a == &st ? "st" : "s2t");
+    snprintf(site_ctx, sizeof site_ctx, "%s.pe", who);
     x = add_pe(x, pos, pe, 1.f, -1, bt.training ? c.dropout : 0.f);
-    for (int i = 0; i < a.layers; ++i)
+    for (int i = 0; i < a.layers; ++i) {
+      snprintf(site_ctx, sizeof site_ctx, "%s.L%d", who, i);
       x = dec_layer(x, tap, a.L[i], B, L, E, c.dec_heads, c.dec_pre_ln != 0, lens, nullptr);
+    }
+    site_ctx[0] = 0;
     if (a.has_ln) x = layernorm(x, a.ln);
     if (a.proj_out >= 0) x = linear(x, a.proj_out, -1, a.out_dim, a.d);
     return linear(x, a.out_proj, -1, a.V, a.out_dim, 0, 0.f, nullptr, logits_out);
@@ -1618,7 +1644,7 @@ struct s2st_engine {
       float* var = alloc(bn.C);
       touch(bn.b + bn.C);
       const float pdrop = tr ? c.postnet_dropout : 0.f;
-      const uint64_t sd = pdrop > 0.f ? next_seed() : 0;
+      const uint64_t sd = pdrop > 0.f ? next_seed(S2ST_SITE_NORM, pdrop, (long)B * D, bn.C) : 0;
       float* nexth = nullptr;
       bf16raw* nexthh = nullptr;
       Ten* out;
@@ -1697,7 +1723,7 @@ struct s2st_engine {
       float* var = alloc(C);
       touch(bn.b + C);
       const float pdrop = tr ? c.enc_dropout : 0.f;
-      const uint64_t sd = pdrop > 0.f ? next_seed() : 0;
+      const uint64_t sd = pdrop > 0.f ? next_seed(S2ST_SITE_NORM, pdrop, (long)B * T, C) : 0;
       float* nexth = nullptr;
       bf16raw* nexthh = nullptr;
       Ten* out;
@@ -1886,6 +1912,8 @@ struct s2st_engine {
     oom = false;
     err = 0;
     site = 0;
+    site_log.clear();
+    site_ctx[0] = 0;
     param_watermark = 0;
     next_segment = 0;
   }
@@ -1984,8 +2012,10 @@ struct s2st_engine {
         if (!emb->g) return;
         if (live()) chk(s2st_embed_bwd((const long*)bt.src_txt, emb->g, G + eoff, B * E, C, 1.f, 1, st_, ordered_sums ? c.src_vocab : 0));
       });
+      set_ctx("enc.prenet");
       Ten* pn = text_prenet(emb, B, E, tr, cst);
       Ten* pj = linear(pn, enc_prenet_proj.w, enc_prenet_proj.b, C, C);
+      set_ctx("enc.pe");
       x = add_pe(pj, bt.enc_pos, pe_enc, 1.f, enc_pos_alpha, tr ? c.dropout : 0.f);
     } else {
     // ---- encoder front: 2 x (conv k s2 -> GLU), sqrt(C) scale + positions + dropout -------------
@@ -2004,6 +2034,7 @@ struct s2st_engine {
     Ten* z2 = conv(ConvIn{g1h, g1, T1, g1hh}, sub[1], B, 2, cs1);
     float* x0d = alloc((long)B * E * C);
     Ten* x0 = glu_to(z2, x0d, Split{(long)C, 0, 0, 0}, C);
+    set_ctx("enc.pe");
     x = add_pe(x0, bt.enc_pos, pe_enc, c.no_scale_embedding ? 1.f : sqrtf((float)C), -1,
                     tr ? c.dropout : 0.f, enc_spk, E);
     }
@@ -2012,6 +2043,7 @@ struct s2st_engine {
     Ten *tap_asr = nullptr, *tap_st = nullptr;
     in_region_ = two_chains;  // ---- two utterance-half chains: the encoder layers + the final layer norm
     for (int i = 0; i < c.enc_layers; ++i) {
+      set_ctx("enc.L%d", i);
       x = enc_layer(x, enc[i], B, E);
       if (i == c.tap_asr) tap_asr = x;
       if (i == c.tap_st) tap_st = x;
@@ -2108,9 +2140,11 @@ struct s2st_engine {
       prev = pv;
     }
     Ten* h = prev;
+    set_ctx("dec.prenet");
     for (int i = 0; i < c.prenet_layers; ++i)
       h = linear(h, prenet[i].w, prenet[i].b, prenet[i].N, prenet[i].K, 1, c.prenet_dropout);
     h = linear(h, prenet.back().w, prenet.back().b, Cd, c.prenet_dim);
+    set_ctx("dec.pe");
     Ten* y = add_pe(h, bt.dec_pos, pe_dec, 1.f, pos_alpha, tr ? c.dropout : 0.f);
     mark();
     in_region_ = two_chains;  // ---- two chains again: decoder layers, final layer norm, the two output projections
@@ -2118,6 +2152,7 @@ struct s2st_engine {
     Ten* tap_dec_t = nullptr;
     for (int i = 0; i < c.dec_layers; ++i) {
       float* am = (i == c.dec_layers - 1 && bt.want_attn) ? outs.attn : nullptr;
+      set_ctx("dec.L%d", i);
       y = dec_layer(y, enc_out, dec[i], B, D, E, c.dec_heads, c.dec_pre_ln != 0, bt.tgt_lens, am, xkv[i]);
       if (c.has_ctc_tgt && i == c.tap_dec) tap_dec_t = y;  // raw layer output (s2st_transformer_mtl.py:325-327)
       if (i % 2 == 1) mark();
@@ -2128,7 +2163,9 @@ struct s2st_engine {
     Ten* eos = linear(y, eos_proj.w, eos_proj.b, 1, Cd, 0, 0.f, nullptr, outs.eos);
     in_region_ = false;
     if (live()) sync_chains();
+    set_ctx("post");
     Ten* post = postnet(feat, B, D, tr, csp, outs.post_feat);
+    set_ctx("");
     // ---- mtl variant: CTC over the TARGET text on a decoder layer's output (s2st_loss_mtl.py:171-186: input lengths =
     //      decoder steps, targets = tgt_text incl. EOS) ------------------------------------------------------
     Ten* ctc_tgt_logits = nullptr;
@@ -2455,6 +2492,21 @@ int s2st_engine_bind(s2st_engine* e, float* params, float* grads, float* buffers
 int s2st_engine_bind_bf16(s2st_engine* e, uint16_t* params_bf16) {
   e->PH = params_bf16;
   return 0;
+}
+
+// Dropout-site log (test instrumentation, see Engine::next_seed): on = 1 makes every later forward record its sites;
+// s2st_engine_site_log_get copies the records of the LAST forward (at most cap) and returns their number.
+int s2st_engine_site_log(s2st_engine* e, int32_t on) {
+  if (!e) return S2ST_ERR_ARG;
+  e->site_log_on = on != 0;
+  if (!on) e->site_log.clear();
+  return S2ST_OK;
+}
+int32_t s2st_engine_site_log_get(const s2st_engine* e, s2st_dropout_site* out, int32_t cap) {
+  if (!e) return -1;
+  const int32_t n = (int32_t)e->site_log.size();
+  for (int32_t i = 0; i < n && i < cap && out; ++i) out[i] = e->site_log[i];
+  return n;
 }
 
 // S2ST_STALL_TRACE=1: prints (stderr) and clears the cross-stream waits recorded since the last report; the caller

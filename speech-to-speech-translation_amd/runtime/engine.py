@@ -58,6 +58,14 @@ class Outputs(C.Structure):
                                   "asr_logits", "st_logits", "ctc_lprobs", "stats")]
 
 
+class DropoutSite(C.Structure):  # s2st_dropout_site (include/s2st_hip.h)
+    _fields_ = [("seed", C.c_uint64), ("kind", C.c_int32), ("ordinal", C.c_int32), ("p", C.c_float), ("reserved", C.c_int32),
+                ("dims", C.c_int64 * 5), ("ctx", C.c_char * 24)]
+
+
+SITE_KIND = {1: "lin", 2: "attn", 3: "rows", 4: "norm"}
+
+
 class DecodeReplay(C.Structure):  # s2st_decode_replay (include/s2st_hip.h)
     _fields_ = [(n, C.c_void_p) for n in ("step", "seeds", "cur_feat", "cur_eos", "cur_attn", "pe_cur")]
 
@@ -798,6 +806,43 @@ class Engine:
         tensor's version so the next forward can skip its refresh pass -- unless something else (a state-dict
         load, a manual copy_) touches ``params`` in between, which bumps the version."""
         self._ph_version = self.params._version
+
+    # ---- dropout-site log (test instrumentation: include/s2st_hip.h, s2st_engine_site_log) ----------------------------
+    def site_log(self, on: bool = True):
+        """Make every later forward record its dropout sites (seed, kind, p, element geometry, place)."""
+        f = self.lib.s2st_engine_site_log
+        f.argtypes = [C.c_void_p, C.c_int32]
+        bd.check(f(self.h, 1 if on else 0), "s2st_engine_site_log")
+
+    def dropout_sites(self) -> Dict[str, "DropoutSite"]:
+        """The last forward's sites by name ``<ctx>/<kind><ordinal>`` (e.g. ``enc.L3/lin1``, ``dec.L0/attn1``, ``post/norm2``)."""
+        f = self.lib.s2st_engine_site_log_get
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        f.restype = C.c_int32
+        n = int(f(self.h, None, 0))
+        recs = (DropoutSite * max(n, 1))()
+        f(self.h, C.cast(recs, C.c_void_p), n)
+        out = {}
+        for r in recs[:n]:
+            name = f"{r.ctx.decode()}/{SITE_KIND[r.kind]}{r.ordinal}"
+            assert name not in out, name
+            out[name] = r
+        return out
+
+    def dropout_keep_mask(self, site: "DropoutSite") -> torch.Tensor:
+        """The site's keep decisions as a 0/1 float tensor in the ENGINE's element geometry (dims of the record: rows x N,
+        or B x H x T x ld for attention probabilities), regenerated by ``s2st_dropout_f32`` over ones -- the same
+        (seed, element index) hash every fused epilogue evaluates."""
+        d = [int(v) for v in site.dims]
+        shape = (d[0], d[1], d[2], d[4]) if site.kind == 2 else (d[0], d[1])
+        n = 1
+        for v in shape:
+            n *= v
+        ones = torch.ones(n, dtype=torch.float32, device=self.device)
+        y = torch.empty_like(ones)
+        bd.call("s2st_dropout_f32", ones, y, n, 1.0, float(site.p), int(site.seed), 0)
+        keep = (y != 0).float()
+        return keep.view(*shape)
 
     def side_stream(self):
         """torch view of the engine's second stream (None on the emulator / when disabled)."""
