@@ -108,3 +108,58 @@ def test_flash_attention_dropout_matches_unfused_mask(backend):
     backend.sync()
     ref = pd[0, 0, :, :S].cpu().double() @ v[0].double()
     assert rel(o[0], ref) < 1e-2
+
+
+# the BENCH's head geometry (dh 128 x H 4) at the lengths its batches really have -- one partial
+# tile (31), exact tile edges (32, 64, 128), one past them (33, 129), several key blocks (213 = the 16 x 850 batch's encoder
+# length, 349 = the longest timed batch), the corpus maximum (750 encoder positions, s2st_transformer.py max-source-positions
+# 3000 / 4) -- self-attention with and without the causal mask (causal tile skipping needs T > 128) and cross-attention
+# rectangles (decoder steps x encoder length of the timed batches); key lengths exactly ON the 32 / 64 / 128 boundaries and
+# klen = 1; 16 (batch, head) pairs so that the XCD re-deal of the blocks engages at dh 128.
+# Reference semantics: multihead_attention.py:332-367, s2st_transformer.py:465-477 (future mask).
+BENCH_GEOMS = [(31, 31), (32, 32), (33, 33), (64, 64), (127, 127), (128, 128), (129, 129), (213, 213), (349, 349),
+               (750, 750), (72, 108), (140, 213), (219, 349)]
+
+
+def _boundary_klens(S):
+    edges = [e for e in (128, 64, 32) if e < S]
+    ks = [S] + edges[:2]
+    while len(ks) < 3:
+        ks.append(max(S - 1, 1))
+    return ks + [1]
+
+
+@pytest.mark.parametrize("causal", [False, True], ids=["full", "causal"])
+@pytest.mark.parametrize("T,S", BENCH_GEOMS, ids=[f"{t}x{s}" for t, s in BENCH_GEOMS])
+def test_flash_attention_bench_head_geometry(backend, T, S, causal):
+    if causal and T != S:
+        pytest.skip("the causal mask belongs to self-attention (T == S)")
+    if backend.kind == "emu" and (T, S) not in ((31, 31), (33, 33), (129, 129)):
+        pytest.skip("the emulator runs three small geometries; the sweep runs on the GPU (the CPU suite's time budget)")
+    H, dh = 4, 128
+    klen = torch.tensor(_boundary_klens(S), dtype=torch.int32)
+    B = klen.numel()
+    if backend.kind == "emu":
+        B, klen = 2, klen[[1, 3]] if S > 32 else klen[[0, 3]]
+    Cm = H * dh
+    g = torch.Generator().manual_seed(1000 * T + S + causal)
+    q = torch.randn(B, T, Cm, generator=g).to(torch.bfloat16)
+    k = torch.randn(B, S, Cm, generator=g).to(torch.bfloat16)
+    v = torch.randn(B, S, Cm, generator=g).to(torch.bfloat16)
+    dO = torch.randn(B, T, Cm, generator=g)
+    d = backend.device
+    o, lse, dq, dk, dv, (dqh, dkh, dvh, dbq, dbk, dbv) = backend.bd.flash_attention(
+        q.to(d), k.to(d), v.to(d), H, klen=klen.to(d), causal=causal, dO=dO.to(d), bf16_grads=True, bf16_o=True)
+    backend.sync()
+    ro, rl, rq, rk, rv = reference(q.float(), k.float(), v.float(), H, klen.long(), causal, dO.to(torch.bfloat16).float())
+    assert rel(o, ro) < 1e-2, rel(o, ro)
+    assert rel(lse, rl) < 1e-4
+    assert rel(dq, rq) < 2e-2 and rel(dk, rk) < 2e-2 and rel(dv, rv) < 2e-2, (rel(dq, rq), rel(dk, rk), rel(dv, rv))
+    for b in range(B):  # keys beyond klen get no gradient, and nothing leaks into them
+        kl = int(klen[b])
+        if kl < S:
+            assert float(dk[b, kl:].abs().max()) == 0.0 and float(dv[b, kl:].abs().max()) == 0.0, b
+    for full, half, db in ((dq, dqh, dbq), (dk, dkh, dbk), (dv, dvh, dbv)):
+        assert torch.equal(half.cpu(), full.cpu().to(torch.bfloat16))
+        ref_db = full.cpu().double().sum(dim=(0, 1))
+        assert float((db.cpu().double() - ref_db).abs().max()) < 1e-4 * float(ref_db.abs().max() + 1e-6)

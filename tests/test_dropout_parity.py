@@ -150,7 +150,7 @@ def test_micro_recipe_dropouts_against_oracle_fast(backend, cfg):
     a, e = make_engine(backend, cfg, precise=False)
     _, m = make_oracle(cfg)
     check_with_injected_masks(backend, e, m, micro_batch(), out_tol=3e-2, loss_tol=2e-3, grad_tol=0.5, whole_tol=0.12,
-                              stat_tol=1e-2)
+                              stat_tol=4e-2)
 
 
 def test_masks_are_what_the_comparison_rests_on(backend):
@@ -185,7 +185,7 @@ def test_tiny_recipe_dropouts_against_oracle(backend, name, precise):
     a, e = make_engine(backend, cfg, precise=precise)
     _, m = make_oracle(cfg)
     tol = dict(out_tol=5e-4, loss_tol=5e-5, grad_tol=1.5e-2, whole_tol=5e-3) if precise else \
-        dict(out_tol=3e-2, loss_tol=1e-3, grad_tol=0.35, whole_tol=0.1, stat_tol=1e-2)
+        dict(out_tol=3e-2, loss_tol=1e-3, grad_tol=0.35, whole_tol=0.1, stat_tol=4e-2)
     check_with_injected_masks(backend, e, m, golden_sample(name, 0), **tol)
 
 
@@ -201,6 +201,6 @@ def test_base_recipe_dropouts_against_oracle(backend, precise):
     a, e = make_engine(backend, cfg, precise=precise)
     _, m = make_oracle(cfg)
     tol = dict(out_tol=5e-4, loss_tol=5e-5, grad_tol=1e-2, whole_tol=3e-3) if precise else \
-        dict(out_tol=3e-2, loss_tol=1e-3, grad_tol=0.15, whole_tol=3e-2, stat_tol=1e-2)
+        dict(out_tol=3e-2, loss_tol=1e-3, grad_tol=0.15, whole_tol=3e-2, stat_tol=4e-2)
     o, log = check_with_injected_masks(backend, e, m, golden_sample("base", 0), **tol)
     print(f"[base recipe dropouts {'bf16x3' if precise else 'bf16'}] loss {float(o['stats'][16]):.6f} vs oracle {float(log['loss']):.6f}")
