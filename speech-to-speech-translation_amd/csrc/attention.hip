@@ -614,12 +614,385 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_bwd_kernel(AttnArgs a, int n
   else flash_bwd_q_body<DH, NW>(a, smem, bx - nkx, bh);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Short-sequence backward (round 6): T, S <= 128 -- 50 % / 80 % of the bench's encoder / decoder
+// batches.  The two-pass kernels above cost ~30 us per launch whatever the length (profiles/r05_attn_by_geometry.txt):
+// 1.2 - 2.9 rounds of workgroups whose life is their fixed part -- two dependent round trips before the first tile is
+// in LDS, two barriers + a global -> LDS commit per 32-row tile -- and the scores are computed twice (7 products).
+// Here ONE workgroup of 8 waves owns a (batch, head) pair:
+//   phase 0  Q, dO, K go to LDS once (<= 128 rows each, 96 KB at DH 128); the wave's 16 keys' K / V fragments to registers;
+//            D[q] = rowsum(dO * O) and lse[q] to LDS;                                                  ONE barrier
+//   phase A  wave w owns keys 16 w ..: per 32-query tile  X = Q K^T, dP = dO V^T, P, dS (the element work, ONCE),
+//            dV += dO^T Pd, dK += Q^T dS, and dS^T goes to LDS as bf16 [key][query] (8-byte stores)    no barriers
+//   phase B  (ONE barrier) wave w owns queries 16 w ..: dQ^T += K^T dS^T over the key tiles, the dS^T fragments read
+//            back with ds_read_b64_tr_b16 -- 5 products instead of 7, every operand fetched from HBM once.
+// LDS images are "dual": one copy of a tile serves BOTH the row-fragment reads (ds_read_b128, rows on lanes) and the
+// transposed reads -- the 32-byte pair is XORed with the row's low bits as in Img<>, and the 16-byte half inside the pair
+// with bit 3 of the row, so that the 16 rows of a b128 phase hit 16 different 16-byte slots and the 8 rows of a
+// transposed-read phase 8 different pairs.
+// Masks, dropout decisions (same (seed, element) hash and index space), bias-gradient partial slots and scaling are the
+// two-pass kernels'; results differ from theirs only by summation order and by dS passing through bf16 once (it already
+// does: it is the MFMA operand of dK and dQ there too).
+// ------------------------------------------------------------------------------------------------
+template <int DH>
+struct Img2 {
+  static constexpr int PITCH = DH * 2;  // bytes per row
+  static constexpr int CH = DH / 8;     // 16-byte chunks per row
+  __device__ static __forceinline__ int key(int row) { return DH >= 128 ? (row & 7) : ((row >> 1) & 3); }
+  __device__ static __forceinline__ int flip(int row) { return (row >> 3) & 1; }
+  __device__ static __forceinline__ int off(int row, int ch) {
+    return row * PITCH + (((((ch >> 1) ^ key(row)) << 1) | ((ch & 1) ^ flip(row))) << 4);
+  }
+  // A-style fragment: rows rt .. rt + 15 on the lanes, k = 32 ks + 8 (l >> 4) + j
+  __device__ static __forceinline__ bf16x8 row_frag(const unsigned char* img, int rt, int ks, int lane) {
+    return *reinterpret_cast<const bf16x8*>(img + off(rt + (lane & 15), 4 * ks + (lane >> 4)));
+  }
+  // transposed fragment: lane -> column 16 dt + (l & 15); k-slot (g, j) = row rb + 4g + j (j < 4) / rb + 16 + 4g + (j - 4)
+  __device__ static __forceinline__ bf16x8 tr_frag(const unsigned char* img, int rb, int dt, int lane) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int r0 = rb + 4 * g + q, r1 = r0 + 16;
+    s16x4 lo = lds_read_tr16(img + off(r0, 2 * dt + (p >> 1)) + 8 * (p & 1));
+    s16x4 hi = lds_read_tr16(img + off(r1, 2 * dt + (p >> 1)) + 8 * (p & 1));
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+  }
+};
+
+constexpr int SHORT_MAX = 128;  // longest sequence of the short forms (8 waves x 16 columns)
+// NW = 8 waves: T, S <= 128, one workgroup per CU; NW = 4: T, S <= 64 in half the LDS, two workgroups per CU (batches of many
+// short utterances have more (batch, head) pairs than the chip has CUs).  Images are sized by the tile-rounded lengths.
+inline int short_lds_bytes(int dh, int T, int S) {
+  const int Tt = (T + 31) & ~31, St = (S + 31) & ~31;
+  return (2 * Tt + St) * dh * 2 + St * 256 + 2 * SHORT_MAX * 4;
+}
+
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void flash_bwd_short_kernel(AttnArgs a) {
+  constexpr int KS = DH / 32, DT = DH / 16, NT = 64 * NW, CH = DH / 8;
+  constexpr int RMAX = 16 * NW;            // rows per image at most
+  constexpr int NI = RMAX * CH / NT;       // 16-byte chunks per thread and image (4 at DH 128, 2 at DH 64)
+  constexpr int RPI = NT / CH;             // rows per load iteration (32 / 64 at 8 waves)
+  if (a.T <= 0 || a.S <= 0) return;        // empty problem (kernel preload)
+  using I = Img2<DH>;
+  using IS = Img2<128>;                    // the dS^T image: rows = keys, 128 query columns
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+  const int Tt = (a.T + 31) & ~31, St = (a.S + 31) & ~31;
+  unsigned char* qimg = smem;
+  unsigned char* doimg = qimg + Tt * I::PITCH;
+  unsigned char* kimg = doimg + Tt * I::PITCH;
+  unsigned char* dst = kimg + St * I::PITCH;
+  float* dsh = reinterpret_cast<float*>(dst + St * 256);
+  float* lsh = dsh + SHORT_MAX;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const int bh = blockIdx.x;
+  const int b = bh / a.H, h = bh - b * a.H;
+  const long ldo = (long)a.H * DH;
+  const bf16_t* qb = a.q + (long)b * a.T * a.ldq + h * DH;
+  const bf16_t* kb = a.k + (long)b * a.S * a.ldk + h * DH;
+  const bf16_t* vb = a.v + (long)b * a.S * a.ldv + h * DH;
+  const bf16_t* dob = a.doh + (long)b * a.T * ldo + h * DH;
+  const int klim = a.klen ? min((int)a.klen[b], a.S) : a.S;
+  const bool own_d = a.dvec == nullptr;
+  const bf16_t* ob = own_d ? a.oh + (long)b * a.T * ldo + h * DH : nullptr;
+
+  // ---- phase 0: every global load of the workgroup is issued before anything waits ------------------------------
+  ATTN_STAMP(0);
+  uint4 rq[NI], rd[NI], ro[NI], rk[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int f = tid + NT * i, row = f / CH, ch = f - row * CH;
+    rq[i] = rd[i] = ro[i] = rk[i] = make_uint4(0, 0, 0, 0);
+    if (RPI * i < Tt) {  // (wave-uniform: an iteration covers whole 32-row tiles)
+      const long r = min(row, a.T - 1);
+      const uint4 vq = *reinterpret_cast<const uint4*>(qb + r * a.ldq + ch * 8);
+      const uint4 vd = *reinterpret_cast<const uint4*>(dob + r * ldo + ch * 8);
+      if (row < a.T) { rq[i] = vq; rd[i] = vd; }
+      if (own_d) {
+        const uint4 vo = *reinterpret_cast<const uint4*>(ob + r * ldo + ch * 8);
+        if (row < a.T) ro[i] = vo;
+      }
+    }
+    if (RPI * i < St) {
+      const uint4 vk = *reinterpret_cast<const uint4*>(kb + (long)min(row, a.S - 1) * a.ldk + ch * 8);
+      if (row < a.S) rk[i] = vk;
+    }
+  }
+  const int k0 = wave * 16, ki = k0 + (lane & 15);  // phase A: this lane's key (column)
+  const bool key_ok = ki < klim;
+  const bool run_a = k0 < St;
+  bf16x8 kf[KS], vf[KS];
+  if (run_a) {
+    load_frags<DH>(kb, a.ldk, k0, a.S, lane, kf);
+    load_frags<DH>(vb, a.ldv, k0, a.S, lane, vf);
+  }
+  float lse_v = 0.f, d_v = 0.f;
+  if (tid < RMAX && tid < a.T) {
+    lse_v = a.lse[(long)bh * a.T + tid];
+    if (!own_d) d_v = a.dvec[(long)bh * a.T + tid];
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int f = tid + NT * i, row = f / CH, ch = f - row * CH;
+    if (row < Tt) {  // (images hold Tt / St rows; an iteration may reach past them)
+      *reinterpret_cast<uint4*>(qimg + I::off(row, ch)) = rq[i];
+      *reinterpret_cast<uint4*>(doimg + I::off(row, ch)) = rd[i];
+      if (own_d) {
+        float s = dot_bf16x8(rd[i], ro[i]);
+        if (CH == 16) s = row16_sum(s);
+        else {
+#pragma unroll
+          for (int m = CH / 2; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+        }
+        if (ch == 0) dsh[row] = s;
+      }
+    }
+    if (row < St) *reinterpret_cast<uint4*>(kimg + I::off(row, ch)) = rk[i];
+  }
+  if (tid < RMAX) {
+    lsh[tid] = lse_v;
+    if (!own_d) dsh[tid] = d_v;
+  }
+  ATTN_STAMP(1);  // loads landed, images written
+  __syncthreads();
+  ATTN_STAMP(2);
+
+  // ---- phase A: keys on the columns; dK, dV; dS^T to LDS ----------------------------------------------------------
+  const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+  f32x4 dk[DT], dv[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) dk[d] = dv[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (run_a) {
+    const int qbeg = a.causal ? (k0 & ~31) : 0;  // queries in front of the block's first key see none of it
+    for (int qt = qbeg; qt < a.T; qt += 32) {
+      f32x4 x[2], dp[2];
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        x[t2] = dp[t2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          x[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::row_frag(qimg, qt + 16 * t2, ks, lane), kf[ks], x[t2], 0, 0, 0);
+          dp[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::row_frag(doimg, qt + 16 * t2, ks, lane), vf[ks], dp[t2], 0, 0, 0);
+        }
+      }
+      float pd[8], ds[8], keep[8];
+      const uint64_t d0 = ((uint64_t)bh * a.T + qt + 4 * g) * (uint64_t)a.ld_drop + ki;  // dropout index of element 0
+      if (a.drop_p > 0.f) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          keep[e] = drop_scale(a.seed, d0 + (uint64_t)((16 * (e >> 2) + (e & 3)) * a.ld_drop), a.drop_p, inv_keep);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) keep[e] = 1.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int qq = qt + 16 * (e >> 2) + 4 * g + (e & 3);
+        const bool ok = key_ok && qq < a.T && (!a.causal || ki <= qq);
+        const float p = ok ? __expf(x[e >> 2][e & 3] * a.scale - lsh[qq]) : 0.f;
+        pd[e] = p * keep[e];
+        ds[e] = p * (keep[e] * dp[e >> 2][e & 3] - dsh[qq]);
+      }
+      const bf16x8 pf = pack_frag(pd), sf = pack_frag(ds);
+      {  // dS^T[key][queries qt + 4g .. + 3] and [.. + 16 ..]: two 8-byte stores
+        union { bf16x8 f; uint4 u; } cv;
+        cv.f = sf;
+        const int c0 = qt + 4 * g;
+        *reinterpret_cast<uint2*>(dst + IS::off(ki, c0 >> 3) + ((g & 1) << 3)) = make_uint2(cv.u.x, cv.u.y);
+        *reinterpret_cast<uint2*>(dst + IS::off(ki, (c0 + 16) >> 3) + ((g & 1) << 3)) = make_uint2(cv.u.z, cv.u.w);
+      }
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::tr_frag(doimg, qt, d, lane), pf, dv[d], 0, 0, 0);
+        dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::tr_frag(qimg, qt, d, lane), sf, dk[d], 0, 0, 0);
+      }
+    }
+  }
+  ATTN_STAMP(3);  // phase A loop done (wave 0)
+  // (bias-gradient partial slots: the two-pass kernels' numbering -- blocks of 64 columns, 4 waves each)
+  if (wave < 4 * ((a.S + 63) / 64)) {
+    const bool on = ki < a.S;
+    const long ko = ((long)b * a.S + min(ki, a.S - 1)) * a.ldk + h * DH;
+    const long vo = ((long)b * a.S + min(ki, a.S - 1)) * a.ldv + h * DH;
+    const long slot = a.db_part ? ((long)b * ((a.S + 63) / 64) * 4 + wave) * ((long)a.H * DH) : 0;
+    store_grad<DT>(dk, a.scale, on, a.dk ? a.dk + ko : nullptr, a.dkh ? a.dkh + ko : nullptr,
+                   a.dbk ? a.dbk + slot + h * DH : nullptr, lane, a.db_part != 0);
+    store_grad<DT>(dv, 1.f, on, a.dv ? a.dv + vo : nullptr, a.dvh ? a.dvh + vo : nullptr,
+                   a.dbv ? a.dbv + slot + h * DH : nullptr, lane, a.db_part != 0);
+  }
+  ATTN_STAMP(4);  // dK, dV stored
+  __syncthreads();
+  ATTN_STAMP(5);
+
+  // ---- phase B: queries on the columns; dQ ------------------------------------------------------------------------
+  if (wave < 4 * ((a.T + 63) / 64)) {
+    const int q0 = wave * 16, qi = q0 + (lane & 15);
+    f32x4 dq[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kmax = q0 < a.T ? (a.causal ? min(klim, q0 + 16) : klim) : 0;
+    for (int kt = 0; kt < kmax; kt += 32) {
+      const bf16x8 sf = IS::tr_frag(dst, kt, wave, lane);
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+        dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::tr_frag(kimg, kt, d, lane), sf, dq[d], 0, 0, 0);
+    }
+    ATTN_STAMP(6);  // dQ products done
+    const bool q_ok = qi < a.T;
+    const long qo = ((long)b * a.T + min(qi, a.T - 1)) * a.ldq + h * DH;
+    const long slot = a.db_part ? ((long)b * ((a.T + 63) / 64) * 4 + wave) * ((long)a.H * DH) : 0;
+    store_grad<DT>(dq, a.scale, q_ok, a.dq ? a.dq + qo : nullptr, a.dqh ? a.dqh + qo : nullptr,
+                   a.dbq ? a.dbq + slot + h * DH : nullptr, lane, a.db_part != 0);
+    ATTN_STAMP(7);
+  }
+}
+
+// Short-sequence forward (S <= 128, T <= 128): one workgroup of 8 waves per (batch, head) pair; K and V go to LDS ONCE
+// (dual images, 64 KB at DH 128), every wave then walks the key tiles for its 16 queries without a barrier -- the
+// streaming kernel above re-stages every 32-key tile per 64-query block behind two barriers.  Same arithmetic per tile.
+inline int short_fwd_lds_bytes(int dh, int S) { return 2 * ((S + 31) & ~31) * dh * 2; }
+
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void flash_fwd_short_kernel(AttnArgs a) {
+  constexpr int KS = DH / 32, DT = DH / 16, NT = 64 * NW, CH = DH / 8;
+  constexpr int NI = 16 * NW * CH / NT, RPI = NT / CH;
+  if (a.T <= 0 || a.S <= 0) return;
+  using I = Img2<DH>;
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+  unsigned char* kimg = smem;
+  unsigned char* vimg = smem + ((a.S + 31) & ~31) * I::PITCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const int bh = blockIdx.x;
+  const int b = bh / a.H, h = bh - b * a.H;
+  const bf16_t* qb = a.q + (long)b * a.T * a.ldq + h * DH;
+  const bf16_t* kb = a.k + (long)b * a.S * a.ldk + h * DH;
+  const bf16_t* vb = a.v + (long)b * a.S * a.ldv + h * DH;
+  const int klim = a.klen ? min((int)a.klen[b], a.S) : a.S;
+  const int St = (klim + 31) & ~31;  // (keys past the longest valid one are never read)
+  uint4 rk[NI], rv[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int f = tid + NT * i, row = f / CH, ch = f - row * CH;
+    rk[i] = rv[i] = make_uint4(0, 0, 0, 0);
+    if (RPI * i < St) {
+      const long r = min(row, a.S - 1);
+      const uint4 vk = *reinterpret_cast<const uint4*>(kb + r * a.ldk + ch * 8);
+      const uint4 vv = *reinterpret_cast<const uint4*>(vb + r * a.ldv + ch * 8);
+      if (row < a.S) { rk[i] = vk; rv[i] = vv; }
+    }
+  }
+  const int q0 = wave * 16, qi = q0 + (lane & 15);
+  const bool run = q0 < a.T;
+  bf16x8 qf[KS];
+  if (run) load_frags<DH>(qb, a.ldq, q0, a.T, lane, qf);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int f = tid + NT * i, row = f / CH, ch = f - row * CH;
+    if (row < St) {
+      *reinterpret_cast<uint4*>(kimg + I::off(row, ch)) = rk[i];
+      *reinterpret_cast<uint4*>(vimg + I::off(row, ch)) = rv[i];
+    }
+  }
+  __syncthreads();
+  if (!run) return;
+  const int kmax = a.causal ? min(klim, q0 + 16) : klim;
+  f32x4 o[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f;
+  const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+  const uint64_t drow = ((uint64_t)bh * a.T + qi) * (uint64_t)a.ld_drop;
+  for (int kt = 0; kt < kmax; kt += 32) {
+    f32x4 x[2];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      x[t2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        x[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::row_frag(kimg, kt + 16 * t2, ks, lane), qf[ks], x[t2], 0, 0, 0);
+    }
+    float sc[8];
+    float mt = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int key = kt + 16 * (e >> 2) + 4 * g + (e & 3);
+      const bool ok = key < klim && (!a.causal || key <= qi);
+      sc[e] = ok ? x[e >> 2][e & 3] * a.scale : -INFINITY;
+      mt = fmaxf(mt, sc[e]);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 16));
+    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    const float mn = fmaxf(m, mt);
+    const float mu = mn == -INFINITY ? 0.f : mn;
+    const float alpha = __expf(m - mu);  // m = -inf -> 0
+    float p[8], ps = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      p[e] = __expf(sc[e] - mu);
+      ps += p[e];
+    }
+    if (a.drop_p > 0.f) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        p[e] *= drop_scale(a.seed, drow + (uint64_t)(kt + 16 * (e >> 2) + 4 * g + (e & 3)), a.drop_p, inv_keep);
+    }
+    l = l * alpha + ps;
+    m = mn;
+    const bf16x8 pf = pack_frag(p);
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      o[d] *= alpha;
+      o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::tr_frag(vimg, kt, d, lane), pf, o[d], 0, 0, 0);
+    }
+  }
+  l += __shfl_xor(l, 16);
+  l += __shfl_xor(l, 32);
+  const float inv_l = l > 0.f ? 1.f / l : 0.f;
+  if (qi < a.T) {
+    const long ro = ((long)b * a.T + qi) * ((long)a.H * DH) + h * DH;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      const float4 v = make_float4(o[d][0] * inv_l, o[d][1] * inv_l, o[d][2] * inv_l, o[d][3] * inv_l);
+      *reinterpret_cast<float4*>(a.o + ro + 16 * d + 4 * g) = v;
+      if (a.oh) *reinterpret_cast<uint2*>(a.oh + ro + 16 * d + 4 * g) = pack_bf16x4(v.x, v.y, v.z, v.w);
+    }
+    if (g == 0 && a.lse) a.lse[(long)bh * a.T + qi] = l > 0.f ? m + __logf(l) : -INFINITY;
+  }
+}
+
 // waves per workgroup (16 columns each): 2 -> T/32 x B*H workgroups, several resident per CU, so the
 // barrier / global-load latency of one overlaps the MFMAs of another (sequences here are 100-750 long)
 constexpr int ANW = 4;  // default (measured: 4 > 2 > 1 on the bench step)
 int attn_nw() {
   static const int v = getenv("S2ST_ATTN_NW") ? atoi(getenv("S2ST_ATTN_NW")) : ANW;
   return v == 1 || v == 2 || v == 4 ? v : ANW;
+}
+
+// the short-sequence kernels use more than 64 KB of dynamic LDS: set the attribute once per instantiation
+bool short_configure() {
+  static int ok = -1;
+  if (ok < 0) {
+    auto set = [](auto kern, int bytes) {
+      return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+    };
+    ok = set(flash_fwd_short_kernel<128, 8>, short_fwd_lds_bytes(128, 128)) && set(flash_fwd_short_kernel<64, 8>, short_fwd_lds_bytes(64, 128)) &&
+         set(flash_fwd_short_kernel<128, 4>, short_fwd_lds_bytes(128, 64)) && set(flash_fwd_short_kernel<64, 4>, short_fwd_lds_bytes(64, 64)) &&
+         set(flash_bwd_short_kernel<128, 8>, short_lds_bytes(128, 128, 128)) && set(flash_bwd_short_kernel<64, 8>, short_lds_bytes(64, 128, 128)) &&
+         set(flash_bwd_short_kernel<128, 4>, short_lds_bytes(128, 64, 64)) && set(flash_bwd_short_kernel<64, 4>, short_lds_bytes(64, 64, 64)) ? 1 : 0;
+  }
+  return ok == 1;
+}
+// S2ST_ATTN_SHORT=0 (read per call: the A/B tests flip it): the two-pass kernels at every length
+bool short_enabled() {
+  const char* e = getenv("S2ST_ATTN_SHORT");
+  return !(e && atoi(e) == 0);
+}
+
+// S2ST_ATTN_SHORT_FWD=0: the streaming forward at every length (S2ST_ATTN_SHORT=0 switches both off)
+bool short_fwd_enabled() {
+  const char* e = getenv("S2ST_ATTN_SHORT_FWD");
+  return short_enabled() && !(e && atoi(e) == 0);
 }
 
 bool attn_args_ok(const s2st_attn_args& p) {
@@ -664,12 +1037,32 @@ int s2st_flash_attn_preload(hipStream_t st) {
   if (nw == 1) go(std::integral_constant<int, 1>{});
   else if (nw == 2) go(std::integral_constant<int, 2>{});
   else go(std::integral_constant<int, 4>{});
+  if (!short_configure()) return S2ST_ERR_LAUNCH;
+  S2ST_LAUNCH((flash_fwd_short_kernel<128, 8>), dim3(1), dim3(512), 0, st, a);
+  S2ST_LAUNCH((flash_fwd_short_kernel<64, 8>), dim3(1), dim3(512), 0, st, a);
+  S2ST_LAUNCH((flash_fwd_short_kernel<128, 4>), dim3(1), dim3(256), 0, st, a);
+  S2ST_LAUNCH((flash_fwd_short_kernel<64, 4>), dim3(1), dim3(256), 0, st, a);
+  S2ST_LAUNCH((flash_bwd_short_kernel<128, 8>), dim3(1), dim3(512), 0, st, a);
+  S2ST_LAUNCH((flash_bwd_short_kernel<64, 8>), dim3(1), dim3(512), 0, st, a);
+  S2ST_LAUNCH((flash_bwd_short_kernel<128, 4>), dim3(1), dim3(256), 0, st, a);
+  S2ST_LAUNCH((flash_bwd_short_kernel<64, 4>), dim3(1), dim3(256), 0, st, a);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
 int s2st_flash_attn_fwd(const s2st_attn_args* p, hipStream_t st) {
   if (!p || !attn_args_ok(*p) || !p->o || !p->lse) return S2ST_ERR_ARG;
   AttnArgs a = to_args(*p);
+  if (p->T <= SHORT_MAX && p->S <= SHORT_MAX && short_fwd_enabled() && short_configure()) {
+    const double fl = 4.0 * p->B * p->H * (double)p->T * p->S * p->dh * (p->causal ? 0.5 : 1.0);
+    const dim3 grid(p->B * p->H);
+    const int lds = short_fwd_lds_bytes(p->dh, p->S);
+    const bool w4 = p->T <= 64 && p->S <= 64;
+    if (p->dh == 128 && w4) s2st_launch("flash_fwd_short_kernel<128, 4>", fl, 0.0, flash_fwd_short_kernel<128, 4>, grid, dim3(256), lds, st, a);
+    else if (p->dh == 128) s2st_launch("flash_fwd_short_kernel<128, 8>", fl, 0.0, flash_fwd_short_kernel<128, 8>, grid, dim3(512), lds, st, a);
+    else if (w4) s2st_launch("flash_fwd_short_kernel<64, 4>", fl, 0.0, flash_fwd_short_kernel<64, 4>, grid, dim3(256), lds, st, a);
+    else s2st_launch("flash_fwd_short_kernel<64, 8>", fl, 0.0, flash_fwd_short_kernel<64, 8>, grid, dim3(512), lds, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+  }
   auto go = [&](auto nwc) {
     constexpr int NW = decltype(nwc)::value;
     dim3 grid((p->T + 16 * NW - 1) / (16 * NW), p->B * p->H);
@@ -726,6 +1119,29 @@ int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_sc
     a.dbq = p->dbq ? db_part : nullptr;
     a.dbk = p->dbk ? db_part + slots_q * Cp : nullptr;
     a.dbv = p->dbv ? db_part + (slots_q + slots_k) * Cp : nullptr;
+  }
+  // T, S <= 128: one workgroup per (batch, head) pair, every operand loaded once, the scores computed once
+  const bool split_env = getenv("S2ST_ATTN_BWD_SPLIT") && atoi(getenv("S2ST_ATTN_BWD_SPLIT")) != 0;
+  if (phase == 0 && p->T <= SHORT_MAX && p->S <= SHORT_MAX && nwp == 4 && !split_env && short_enabled() && short_configure()) {
+    if (!own_d) {  // (D from the fp32 row kernel: the S2ST_ATTN_DVEC_KERNEL=1 / no-bf16-O form)
+      const long rows_ = (long)p->B * p->T * p->H;
+      if (p->dh == 128)
+        S2ST_LAUNCH(attn_dvec_kernel<128>, dim3((unsigned)((rows_ * 32 + 255) / 256)), dim3(256), 0, st, dO, (const float*)p->o,
+                    dvec_scratch, p->B, p->H, p->T);
+      else
+        S2ST_LAUNCH(attn_dvec_kernel<64>, dim3((unsigned)((rows_ * 16 + 255) / 256)), dim3(256), 0, st, dO, (const float*)p->o,
+                    dvec_scratch, p->B, p->H, p->T);
+    }
+    // as-launched FLOPs: S, dP, dV, dK, dQ over the padded T x S rectangle (the causal form skips whole tiles only)
+    const double fl = 5.0 * 2.0 * p->B * p->H * (double)p->T * p->S * p->dh * (p->causal ? 0.5 : 1.0);
+    const dim3 grid(p->B * p->H);
+    const int lds = short_lds_bytes(p->dh, p->T, p->S);
+    const bool w4 = p->T <= 64 && p->S <= 64;
+    if (p->dh == 128 && w4) s2st_launch("flash_bwd_short_kernel<128, 4>", fl, 0.0, flash_bwd_short_kernel<128, 4>, grid, dim3(256), lds, st, a);
+    else if (p->dh == 128) s2st_launch("flash_bwd_short_kernel<128, 8>", fl, 0.0, flash_bwd_short_kernel<128, 8>, grid, dim3(512), lds, st, a);
+    else if (w4) s2st_launch("flash_bwd_short_kernel<64, 4>", fl, 0.0, flash_bwd_short_kernel<64, 4>, grid, dim3(256), lds, st, a);
+    else s2st_launch("flash_bwd_short_kernel<64, 8>", fl, 0.0, flash_bwd_short_kernel<64, 8>, grid, dim3(512), lds, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
   }
   const long rows = (long)p->B * p->T * p->H;
   if (phase > 1 || own_d) {

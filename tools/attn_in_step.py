@@ -40,9 +40,12 @@ for i, p in zip(pick, prepared):
     buf = C.create_string_buffer(1 << 17)
     n = lib.s2st_profile_report(buf, len(buf))
     tot, fw, bw = 0.0, (0.0, 0), (0.0, 0)
+    tags = {}
     for line in buf.raw[:max(n, 0)].decode().splitlines():
         f = line.split("\t")
         tot += float(f[2])
+        if f[0].startswith("flash_"):
+            tags[f[0]] = (float(f[2]) / max(int(f[1]), 1), int(f[1]))
         if f[0].startswith("flash_fwd"):
             fw = (fw[0] + float(f[2]), fw[1] + int(f[1]))
         if f[0].startswith("flash_bwd"):
@@ -51,4 +54,5 @@ for i, p in zip(pick, prepared):
     E = int(p.batch.E) if hasattr(p, "batch") else -1
     D = int(p.batch.D) if hasattr(p, "batch") else -1
     print("%4d %4d %4d   %8.1f (%2d)      %8.1f (%2d)      %8.3f      %8.3f" % (B, E, D, fw[0] / max(fw[1], 1), fw[1], bw[0] / max(bw[1], 1), bw[1],
-                                                                          (fw[0] + bw[0]) / 1e3, tot / 1e3))
+                                                                          (fw[0] + bw[0]) / 1e3, tot / 1e3),
+          "  ".join("%s %.1f us x %d" % (k, v[0], v[1]) for k, v in sorted(tags.items())))

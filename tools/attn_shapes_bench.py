@@ -44,4 +44,7 @@ for (B, E, D) in ((16, 213, 140), (24, 191, 131), (32, 134, 92), (40, 108, 73), 
         r = run(B, T, S, c)
         fl = 14.0 * B * H * T * S * dh * (0.5 if c else 1.0) / 1e9
         wg = B * H * ((S + 63) // 64 + (T + 63) // 64)
-        print("%3d x %3d x %3d %-9s %8.1f %8.1f %14.2f %10d" % (B, T, S, label, r.get("flash_fwd_kernel", 0), r.get("flash_bwd_kernel", 0), fl, wg))
+        bw = r.get("flash_bwd_short_kernel", r.get("flash_bwd_kernel", 0))
+        form = "short" if "flash_bwd_short_kernel" in r else "two-pass"
+        fw = r.get("flash_fwd_short_kernel", r.get("flash_fwd_kernel", 0))
+        print("%3d x %3d x %3d %-9s %8.1f %8.1f %14.2f %10d  %s" % (B, T, S, label, fw, bw, fl, wg, form))
