@@ -666,16 +666,18 @@ def main():
     step_ev = []
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
-        if os.environ.get('S2ST_BENCH_VERBOSE'):  # per-step GPU time (event per step end; not part of the metric)
-            e_ = torch.cuda.Event(enable_timing=True)
-            e_.record()
-            step_ev.append(e_)
+        # per-step GPU time (one event record per step end: no synchronisation, not part of the metric) -- the straggler
+        # statistic below is simulated from these
+        e_ = torch.cuda.Event(enable_timing=True)
+        e_.record()
+        step_ev.append(e_)
     t_issue = time.perf_counter() - t0  # host time to enqueue the steps (GPU-bound if << dt)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    my_dt_local = dt
     vlog('timed region', dt, 'host issue time', t_issue)
     last_loss = float(trainer.criterion.last_outputs["stats"][16])  # (of the last TIMED step: the legs below run more)
     # N > 1: what the gradient exchange cost beyond what the backward hid (the compute stream's wait in
@@ -748,8 +750,9 @@ def main():
             model.prepare_sample(smp, training=True) if hub else eng.prepare(smp, training=True, seed=0)
         torch.cuda.synchronize()
         vlog('batch preparation alone: %.3f ms per batch' % ((time.perf_counter() - tp0) / n_h * 1e3))
-    if step_ev:
-        vlog('per-step GPU ms (mel frames):', ' '.join('%.2f(%d)' % (step_ev[j - 1].elapsed_time(step_ev[j]), frames[args.warmup + j])
+    step_ms = [step_ev[j - 1].elapsed_time(step_ev[j]) for j in range(1, len(step_ev))]
+    if step_ms:
+        vlog('per-step GPU ms (mel frames):', ' '.join('%.2f(%d)' % (step_ms[j - 1], frames[args.warmup + j])
                                                      for j in range(1, len(step_ev))))
     # how many ranks the communicator really joined (a SUM of ones over it), reported next to n_gpus
     n_ranks_seen = 1
@@ -807,51 +810,96 @@ def main():
         alg = 3.0 * 2.0 * sum(macs[args.warmup:args.warmup + n_replay])  # valid (un-padded) tokens, fwd + bwd
         launched = sum(r["work"] for r in mfma.values())                  # as launched: padded rows / rectangles included
         useful = alg / launched                                           # algorithmic share of the launched FLOPs
-        dom_tag, dom = max(gemm.items(), key=lambda kv: kv[1]["us"])
-        avg_us = dom["us"] / dom["n"]
-        alg_per_launch = useful * dom["work"] / dom["n"]
-        achieved = alg_per_launch / (avg_us * 1e-6) / 1e12
-        # HBM traffic per launch of the dominant kernel: rocprofv3 PMC passes of this command (cannot run inside this
-        # process); the committed measurement is reported, with its source
-        traffic, traffic_src = None, None
+        # HBM traffic per launch and kernel: rocprofv3 PMC passes of this command (they cannot run inside this process); the
+        # committed measurement is used when -- and only when -- it was taken on the sources the loaded library was built from
+        tj, traffic_src = None, None
         try:
             import glob
             hb = C.create_string_buffer(32)
             lib.s2st_source_hash.argtypes = [C.c_char_p, C.c_int32]
             lib.s2st_source_hash(hb, 32)
-            # the newest committed measurement taken on the sources the loaded library was built from
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True)
             for fn in cands:
                 with open(fn) as f:
-                    tj = json.load(f)
-                if tj.get("source_hash") == hb.value.decode() and tj.get("config", "base_recipe") == args.config:
-                    traffic, traffic_src = round(tj["kernels"][dom_tag]["hbm_bytes_per_launch"]), tj["source"]
+                    tj_ = json.load(f)
+                if tj_.get("source_hash") == hb.value.decode() and tj_.get("config", "base_recipe") == args.config:
+                    tj, traffic_src = tj_, "profiles/" + os.path.basename(fn)
                     break
             else:
-                # measured on other sources than the loaded library was built from: not this kernel's figure any more
                 traffic_src = ("stale: no profiles/r*_pmc_traffic.json was measured on the sources the loaded library was built "
                                "from (%s; newest file: %s) -- tools/profile_round.sh re-measures" % (
                                    hb.value.decode(), os.path.basename(cands[0]) if cands else "none"))
         except Exception:
             pass
+
+        def counted_bytes(tag):
+            if tj is None or tag not in tj["kernels"]:
+                return None
+            return float(tj["kernels"][tag]["hbm_bytes_per_launch"])
+
+        ridge = MFMA_BF16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBPS * 1e9)  # FLOP per byte at which the two roofs meet (312.5)
+
+        def kernel_entry(tag, r):
+            """One GEMM instantiation against BOTH roofs.  The binding roof follows from its arithmetic intensity --
+            algorithmic FLOP per launch / HBM bytes per launch (the PMC-counted ones when a matching measurement exists, the
+            bytes the launch has to move at least otherwise) -- against the ridge, not from a constant."""
+            us = r["us"] / r["n"]
+            alg_fl = useful * r["work"] / r["n"]
+            minb = r["work2"] / r["n"]
+            cb = counted_bytes(tag)
+            inten = alg_fl / (cb if cb else max(minb, 1.0))
+            tf = alg_fl / (us * 1e-6) / 1e12
+            gb_alg = minb / (us * 1e-6) / 1e9
+            return {"kernel": tag, "launches_per_step": round(r["n"] / n_replay, 1), "avg_launch_us": round(us, 2),
+                    "ms_per_step": round(r["us"] / n_replay * 1e-3, 3),
+                    "algorithmic_gflop_per_launch": round(alg_fl / 1e9, 3),
+                    "as_launched_gflop_per_launch": round(r["work"] / r["n"] / 1e9, 3),
+                    "algorithmic_bytes_per_launch": round(minb), "counted_hbm_bytes_per_launch": round(cb) if cb else None,
+                    "intensity_flop_per_byte": round(inten, 1), "bound": "hbm" if inten < ridge else "mfma",
+                    "achieved_tflops": round(tf, 2), "frac_mfma": round(tf / MFMA_BF16_PEAK_TFLOPS, 5),
+                    "achieved_gbps_algorithmic": round(gb_alg, 1), "frac_hbm": round(gb_alg / HBM_PEAK_GBPS, 5),
+                    "frac_hbm_counted": round(cb / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5) if cb else None}
+
+        by_time = sorted(gemm.items(), key=lambda kv: -kv[1]["us"])
+        top = [kernel_entry(t, r) for t, r in by_time[:3]]
+        dom = top[0]
         gemm_us = sum(r["us"] for r in gemm.values())
+        all_tf = useful * sum(r["work"] for r in gemm.values()) / (gemm_us * 1e-6) / 1e12
+        # the whole step against its HBM traffic (every kernel of the matching PMC measurement x its launches per step)
+        hbm_step = None
+        if tj is not None:
+            nsteps_pass = float(tj.get("steps_in_pass", 5))
+            hbm_step = sum(v["hbm_bytes_per_launch"] * v["launches_fetch_pass"] / nsteps_pass for v in tj["kernels"].values())
         roofline = {
-            "bound": "mfma", "kernel": dom_tag + " (the GEMM instantiation with the largest share of the step)",
-            "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 5), "traffic": traffic, "traffic_unit": "B/launch",
-            "traffic_source": traffic_src,
-            "launches_per_step": round(dom["n"] / n_replay, 1), "avg_launch_us": round(avg_us, 2),
-            "ms_per_step": round(dom["us"] / n_replay * 1e-3, 3),
-            "algorithmic_gflop_per_launch": round(alg_per_launch / 1e9, 3),
-            "as_launched_gflop_per_launch": round(dom["work"] / dom["n"] / 1e9, 3),
-            "min_bytes_per_launch": round(dom["work2"] / dom["n"]),
+            "bound": dom["bound"],
+            "kernel": dom["kernel"] + " (the GEMM instantiation with the largest share of the step in this run)",
+            # `achieved` / `peak` / `frac` are the figures of the BINDING roof of that kernel; both fractions are listed
+            "achieved": dom["achieved_gbps_algorithmic"] if dom["bound"] == "hbm" else dom["achieved_tflops"],
+            "peak": HBM_PEAK_GBPS if dom["bound"] == "hbm" else MFMA_BF16_PEAK_TFLOPS,
+            "unit": "GB/s" if dom["bound"] == "hbm" else "TFLOP/s",
+            "frac": dom["frac_hbm"] if dom["bound"] == "hbm" else dom["frac_mfma"],
+            "frac_mfma": dom["frac_mfma"], "frac_hbm": dom["frac_hbm"],
+            "traffic": dom["counted_hbm_bytes_per_launch"], "traffic_unit": "B/launch", "traffic_source": traffic_src,
+            "ridge_flop_per_byte": round(ridge, 1),
+            "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_launch_us"], "ms_per_step": dom["ms_per_step"],
+            "algorithmic_gflop_per_launch": dom["algorithmic_gflop_per_launch"],
+            "as_launched_gflop_per_launch": dom["as_launched_gflop_per_launch"],
+            "min_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
             "algorithmic_share_of_launched_flops": round(useful, 4),
             "timing": "start/stop events attached to each dispatch (hipExtLaunchKernelGGL), %d replayed steps" % n_replay,
+            # the three GEMM instantiations with the largest shares (the ring forms of the data path and the grouped
+            # weight-gradient launch trade places from box to box): each with its own figures against both roofs
+            "top_kernels": top,
             "all_gemm": {"launches_per_step": round(sum(r["n"] for r in gemm.values()) / n_replay, 1),
-                         "ms_per_step": round(gemm_us / n_replay * 1e-3, 3),
-                         "achieved": round(useful * sum(r["work"] for r in gemm.values()) / (gemm_us * 1e-6) / 1e12, 2),
-                         "frac": round(useful * sum(r["work"] for r in gemm.values()) / (gemm_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 5)},
+                         "ms_per_step": round(gemm_us / n_replay * 1e-3, 3), "achieved": round(all_tf, 2),
+                         "frac": round(all_tf / MFMA_BF16_PEAK_TFLOPS, 5)},
             "algorithmic_gflop_per_step": round(alg / n_replay / 1e9, 1),
+            "hbm_gb_per_step": round(hbm_step / 1e9, 2) if hbm_step else None,
+            "step_intensity_flop_per_byte": round(alg / n_replay / hbm_step, 1) if hbm_step else None,
+            "step_hbm_frac": round(hbm_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS, 4) if hbm_step else None,
+            "recompute_from": {"durations": "this run's per-dispatch events; the rocprofv3 kernel trace of the same command is "
+                                            "profiles/<round tag>_kernel_stats_replayed_steps.txt",
+                               "traffic": traffic_src},
             # the HBM-bound kernels of the step: bytes they have to move / their own dispatch time
             "hbm_kernels": {t: {"gbps": round(r["work"] / (r["us"] * 1e-6) / 1e9, 1),
                                 "frac": round(r["work"] / (r["us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
@@ -904,7 +952,12 @@ def main():
     #      configs[4] carry a figure in the driver's own run.  Fresh child processes of this script (started while this
     #      process sits idle; never an exec), each printing its own line; summarised under config.other_configs ----------
     others = None
-    if rank == 0 and world == 1 and args.config == "base_recipe" and not args.no_other_configs:
+    # (under rocprofv3 the children would inherit the profiler's preload and its -d / -o target: three processes writing one
+    #  run_results.db, the other-config legs inside the per-kernel accounting -- ADVICE r5; skipped there)
+    profiled = any(("rocprof" in os.environ.get(k, "").lower()) for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB",
+                                                                          "ROCPROFILER_LIBRARY_PATH")) or \
+        any(k.startswith(("ROCPROF_", "ROCPROFILER_")) for k in os.environ)
+    if rank == 0 and world == 1 and args.config == "base_recipe" and not args.no_other_configs and not profiled:
         import subprocess
         others = {}
         legs = {"infer_base": ["--config", "infer_base", "--steps", "8", "--warmup", "2", "--cpu-seconds", "0", "--no-roofline"],
@@ -929,6 +982,33 @@ def main():
                             others[name][k] = got["config"][k]
             except subprocess.TimeoutExpired:
                 others[name] = {"error": "timed out"}
+
+    # ---- 8-GPU pricing, term (a): straggler loss.  Batches are dealt round-robin (fairseq/data/iterators.py:518-548) and
+    #      every update waits for the slowest rank: max / mean - 1 of the ranks' step times.  N > 1: measured per rank;
+    #      N = 1: SIMULATED from this run's per-batch GPU times for W = 2, 4, 8 (update u of rank r takes batch u W + r) ----
+    straggler = None
+    if world > 1:
+        mine_t = torch.tensor([my_dt_local / args.steps * 1e3], dtype=torch.float64, device="cpu" if share else dev)
+        allt = [torch.zeros_like(mine_t) for _ in range(world)]
+        torch.distributed.all_gather(allt, mine_t)
+        ts = [float(t[0]) for t in allt]
+        straggler = {"per_rank_ms_per_step": {"min": round(min(ts), 3), "mean": round(sum(ts) / len(ts), 3), "max": round(max(ts), 3)},
+                     "straggler_loss": round(max(ts) / (sum(ts) / len(ts)) - 1.0, 4),
+                     "note": "host time of each rank's own timed loop (it contains the waits for the other ranks' gradients)"}
+    elif len(step_ms) >= 8:
+        sim = {}
+        for W in (2, 4, 8):
+            nu = len(step_ms) // W
+            if nu < 1:
+                continue
+            mx = [max(step_ms[u * W:(u + 1) * W]) for u in range(nu)]
+            mean = sum(step_ms[:nu * W]) / (nu * W)
+            sim["dp%d" % W] = round(sum(mx) / nu / mean - 1.0, 4)
+        straggler = {"simulated_straggler_loss": sim,
+                     "per_batch_gpu_ms": {"min": round(min(step_ms), 3), "mean": round(sum(step_ms) / len(step_ms), 3),
+                                          "max": round(max(step_ms), 3)},
+                     "note": "max over W consecutive batches / their mean - 1, averaged over the updates the timed batches give: what "
+                             "round-robin dealing costs before any communication"}
 
     if rank == 0:
         value = total_frames / dt
@@ -961,6 +1041,8 @@ def main():
             line["config"]["x_over_cpu"] = round(value / cpu["value"], 1)
         if exchange:
             line["gradient_exchange"] = exchange  # rank 0's view
+        if straggler:
+            line["straggler"] = straggler
         if others:
             line["config"]["other_configs"] = others
         print(json.dumps(line))

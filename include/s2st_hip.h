@@ -402,6 +402,8 @@ typedef struct s2st_dropout_site {
   int64_t dims[5];
   char ctx[24];
 } s2st_dropout_site;
+/* allow = 0: the engine never creates its second stream (inference twins that only decode); before the first forward */
+int s2st_engine_allow_side_stream(s2st_engine* e, int32_t allow);
 int s2st_engine_site_log(s2st_engine* e, int32_t on);
 int32_t s2st_engine_site_log_get(const s2st_engine* e, s2st_dropout_site* out, int32_t cap);
 /* optional second bf16 arena (param_floats elements): every training forward stores W^T of each 2-D

@@ -2494,6 +2494,15 @@ int s2st_engine_bind_bf16(s2st_engine* e, uint16_t* params_bf16) {
   return 0;
 }
 
+// allow = 0: this engine never makes (or sizes scratch for) a second stream -- inference twins, which only ever decode
+// (a stream created all the same would take a hardware-queue slot: runtime/streams.py).  Call before the first forward.
+int s2st_engine_allow_side_stream(s2st_engine* e, int32_t allow) {
+  if (!e) return S2ST_ERR_ARG;
+  if (e->side_) return allow ? S2ST_OK : S2ST_ERR_ARG;  // (already made: cannot be taken back)
+  e->side_allowed = allow != 0 && !e->c.precise;
+  return S2ST_OK;
+}
+
 // Dropout-site log (test instrumentation, see Engine::next_seed): on = 1 makes every later forward record its sites;
 // s2st_engine_site_log_get copies the records of the LAST forward (at most cap) and returns their number.
 int s2st_engine_site_log(s2st_engine* e, int32_t on) {

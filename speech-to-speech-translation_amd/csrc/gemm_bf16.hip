@@ -1238,6 +1238,10 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* bm_out) {
     if (forced_p4 && !p4) { bm = 128; bn = 128; }
     if (p4) { bm = 256; bn = 256; w4bn = 0; }
   }
+  // (a forced 256 x 256 form on a product that then splits K -- fewer than 256 tiles of 256 x 256 -- used to fall
+  //  through to the 64 x 64 launch with a grid built for 256 x 256 tiles: most of C never written.  The four-phase kernel has
+  //  no split-K form, so such a product goes back to 128 x 128 tiles BEFORE the grid is derived.)
+  if (p4 && can_split_ && (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * g.batch < 256) { p4 = false; bm = 128; bn = 128; }
   const int tm = (g.M + bm - 1) / bm, tn = (g.N + bn - 1) / bn;
   const long nt = (long)tm * tn * g.batch;
   // split-K only for accumulating fp32 outputs with a linear epilogue (weight gradients): K is

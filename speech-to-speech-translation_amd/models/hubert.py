@@ -134,6 +134,7 @@ class HubertFrontend:
         for k, v in sd.items():
             if k not in need:
                 self._extra[k] = v.detach().clone()
+        self.invalidate_bf16()  # (explicit: the copies above also bump torch's version counter)
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
         out: Dict[str, torch.Tensor] = {}
@@ -238,15 +239,33 @@ class HubertFrontend:
         need = self._plan[key]
         if self.workspace is None or self.workspace.numel() < need:
             self.workspace = torch.empty(need, dtype=torch.float32, device=self.device)
-        # frozen weights: the engine's bf16 copy stays valid while nobody wrote the parameter tensor (or a view of it)
+        # frozen weights: the engine's bf16 copy stays valid while nobody wrote the parameter tensor (or a view of it).
+        # torch's version counter sees in-place ops on the tensor and its views; writers that bypass it (``.data``, raw
+        # pointers: a C-side load, broadcast_ on a .data view) call invalidate_bf16().  The cast of the last refresh ran on
+        # ONE stream: a forward on another stream waits for that cast's event before it reads the copy.
+        cur = torch.cuda.current_stream() if self.device.type == "cuda" else None
         if self.params_bf16 is not None and getattr(self, "_ph_version", None) == self.params._version:
+            ev = getattr(self, "_ph_event", None)
+            if ev is not None and cur is not None and getattr(self, "_ph_stream", None) != cur.cuda_stream:
+                cur.wait_event(ev)
             self.lib.s2st_engine_bf16_is_fresh(self.h)
+            refreshed = False
+        else:
+            refreshed = True
         self._ph_version = self.params._version
         bd.check(self.lib.s2st_hubert_forward(self.h, wave.data_ptr(), lens.data_ptr(), B, N, out.data_ptr(),
                                               self.workspace.data_ptr(), self.workspace.numel(),
                                               C.c_void_p(bd.stream_ptr())), "s2st_hubert_forward")
+        if refreshed and cur is not None:  # the refresh cast was enqueued by this forward, on this stream
+            self._ph_event = torch.cuda.Event()
+            self._ph_event.record(cur)
+            self._ph_stream = cur.cuda_stream
         self._keep = (wave, lens)
         return out
+
+    def invalidate_bf16(self):
+        """The parameters were written behind torch's version counter: the next forward refreshes the bf16 copy."""
+        self._ph_version = None
 
     def reserve(self, B: int, N: int):
         """Size the workspace for a [B, N] waveform batch up front (no allocation inside a training loop)."""

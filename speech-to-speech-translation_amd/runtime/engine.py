@@ -252,16 +252,13 @@ class Engine:
         while len(tws) < n:
             # (a decode chain never uses the engine's second stream: created all the same it would take a hardware queue
             # slot and shift every later stream's mapping -- runtime/streams.py)
-            import os as _os
-            old = _os.environ.get("S2ST_NO_SIDE_STREAM")
-            _os.environ["S2ST_NO_SIDE_STREAM"] = "1"
-            try:
-                tws.append(Engine(self.args, self.device, precise=bool(self.cfg.precise), share_with=self))
-            finally:
-                if old is None:
-                    _os.environ.pop("S2ST_NO_SIDE_STREAM", None)
-                else:
-                    _os.environ["S2ST_NO_SIDE_STREAM"] = old
+            # (said to the engine itself -- s2st_engine_allow_side_stream -- not through the process environment: setenv
+            #  races with the getenv calls other threads' launches make inside the library)
+            tw = Engine(self.args, self.device, precise=bool(self.cfg.precise), share_with=self)
+            f = tw.lib.s2st_engine_allow_side_stream
+            f.argtypes = [C.c_void_p, C.c_int32]
+            bd.check(f(tw.h, 0), "s2st_engine_allow_side_stream")
+            tws.append(tw)
         return tws[:n]
 
     def __del__(self):

@@ -58,11 +58,35 @@ def shares_queue(a: "torch.cuda.Stream", b: "torch.cuda.Stream") -> bool:
     return both > 1.6 * one
 
 
-def _probe_on() -> bool:
-    return os.environ.get("S2ST_STREAM_PROBE", "1") != "0" and hasattr(torch.cuda, "_sleep")
+# Roles of the TRAINING loop: a queue collision there costs speed, never results, and their streams are first asked for
+# inside a training step (the gradient reducer of every DDP rank, the prefetcher's thread) -- a wall-clock probe with a
+# device-wide synchronise does not belong there: creation order decides unless warm() is called for them.
+_UNPROBED_ROLES = ("gradient-exchange", "prefetch", "front-end")
 
 
-def get(role: str, device=None, avoid: Optional[list] = None, may_share=()) -> "torch.cuda.Stream":
+def _probe_on(role: str = "", explicit: bool = False) -> bool:
+    if os.environ.get("S2ST_STREAM_PROBE", "1") == "0" or not hasattr(torch.cuda, "_sleep"):
+        return False
+    if not explicit and role in _UNPROBED_ROLES:
+        return False
+    # a probe synchronises the device: illegal while a stream of this thread is capturing a graph
+    try:
+        if torch.cuda.is_current_stream_capturing():
+            return False
+    except Exception:
+        pass
+    return True
+
+
+def warm(roles, device=None, may_share=None) -> Dict[str, "torch.cuda.Stream"]:
+    """Create (and probe) the streams of ``roles`` NOW -- at a defined point of a program's start-up (a generator's or
+    trainer's construction), outside any timed region or graph capture -- instead of at their first use.  ``may_share``:
+    {role: tuple of roles whose queue it may share}.  Results are cached per device like those of ``get``."""
+    may_share = may_share or {}
+    return {r: get(r, device, may_share=may_share.get(r, ()), _explicit=True) for r in roles}
+
+
+def get(role: str, device=None, avoid: Optional[list] = None, may_share=(), _explicit: bool = False) -> "torch.cuda.Stream":
     """The device's stream for ``role`` (created on first use, then kept for the life of the process).  ``avoid``: further
     streams the role must not share a queue with (an engine's own second stream, say); ``may_share``: pool roles whose
     queue it may share (work that is rare or that runs after the other role's anyway)."""
@@ -73,7 +97,7 @@ def get(role: str, device=None, avoid: Optional[list] = None, may_share=()) -> "
     if st is not None:
         return st
     d = torch.device("cuda", idx)
-    if not _probe_on():
+    if not _probe_on(role, _explicit):
         st = _POOL[key] = torch.cuda.Stream(device=d)
         return st
     with torch.cuda.device(d):
@@ -90,7 +114,8 @@ def get(role: str, device=None, avoid: Optional[list] = None, may_share=()) -> "
                       flush=True)
             if hit is None:
                 break
-            _REJECTED.append(st)
+            if len(_REJECTED) < 2 * _TRIES:  # (bounded: beyond that a rejected candidate is simply dropped)
+                _REJECTED.append(st)
         if hit is not None:
             _COLLISIONS[key] = hit
     _POOL[key] = st

@@ -486,6 +486,33 @@ def test_bf16_p4_four_phase_kernel(backend, monkeypatch, K):
     assert tile4 != (256, 256) and torch.equal(C4, C)
 
 
+def test_bf16_p4_forced_on_a_split_k_product_falls_back(backend, monkeypatch):
+    """with the four-phase form FORCED (S2ST_GEMM_P4=1 / S2ST_GEMM_TILE=256x256) an accumulating K-major x
+    K-major product with fewer than 256 tiles splits K -- the 256 x 256 kernel has no split-K form, and the launcher used to
+    fall through to a 64 x 64 launch on a grid built for 256 x 256 tiles (most of C never written).  It now goes back to
+    128 x 128 tiles before the grid is derived: the accumulated result is the exact one, every element written."""
+    M, N, K = (520, 300, 1100) if backend.kind == "emu" else (2560, 2560, 4608)
+    g = torch.Generator().manual_seed(5)
+    A, B = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g))
+    Am, a_ld = _pad_cols(A)
+    Bm, b_ld = _pad_cols(B)
+    d = backend.device
+    old = torch.randn(M, N, generator=g)
+    ws = torch.zeros(16 << 20, device=d)
+    ref = old.double() + A.double() @ B.double().t()
+    for env in ({"S2ST_GEMM_TILE": "256x256"}, {"S2ST_GEMM_P4": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        C = old.clone().to(d)
+        tile = backend.bd.gemm(Am.to(d), Bm.to(d), C, M, N, K, a_kmajor=True, b_kmajor=True, a_ld=a_ld, b_ld=b_ld, accumulate=True,
+                               ws=ws, return_tile=True)
+        backend.sync()
+        assert tile != (256, 256), (env, tile)
+        assert _relerr(C, ref) < 2e-6, env
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 @pytest.mark.parametrize("tile", [128, 256, "oneshot", "w4"])
 def test_bf16_group_of_weight_gradients(backend, monkeypatch, tile):
     """s2st_gemm_group_f32: a layer's weight-gradient products dW_i += dY_i^T X_i (different shapes, K = tokens, one with

@@ -22,10 +22,11 @@ def per_kernel(db_path, counter):
 
 def main():
     fdb, wdb, cfg, out = sys.argv[1:5]
+    steps_in_pass = int(sys.argv[5]) if len(sys.argv) > 5 else 5  # (tools/profile_round.sh: --steps 3 --warmup 2, no replay)
     f, w = per_kernel(fdb, "FETCH_SIZE"), per_kernel(wdb, "WRITE_SIZE")
     import importlib, os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    res = {"config": cfg, "source_hash": importlib.import_module("__graft_entry__").source_hash(), "source": f"profiles/{out.split('/')[-1].replace('_traffic.json', '')}_fetch_size.txt, ..._write_size.txt "
+    res = {"config": cfg, "steps_in_pass": steps_in_pass, "source_hash": importlib.import_module("__graft_entry__").source_hash(), "source": f"profiles/{out.split('/')[-1].replace('_traffic.json', '')}_fetch_size.txt, ..._write_size.txt "
            "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py; KiB per dispatch; FETCH_SIZE x2 on gfx950)",
            "kernels": {}}
     for k in sorted(set(f) | set(w)):
