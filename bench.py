@@ -531,6 +531,11 @@ def main():
                          "base_recipe_hubert = configs[3] on one GPU) into config.other_configs of the default line")
     ap.add_argument("--grad-exchange-dtype", default="fp32", choices=["fp32", "bf16"],
                     help="N > 1: type the gradient ranges are all-reduced in (runtime/distributed.py; fp32 = the reference's)")
+    ap.add_argument("--exchange-proxy", default=None, metavar="WGS,RANKS,GBPS",
+                    help="ONE GPU only: per gradient bucket, launch the library's stand-in for the all-reduce's kernels on the "
+                         "gradient-exchange stream (that many workgroups moving the bucket's 2 (N - 1) / N share at that pace): "
+                         "what RCCL's kernels beside the backward would cost the step.  Reported under `exchange_proxy`, and "
+                         "the line's `value` is then NOT the headline (config.name gets a suffix)")
     ap.add_argument("--timeline", default=None, help="write the per-dispatch timeline (stream, start, duration on the GPU "
                     "clock) of ONE replayed step to this file; tools/timeline.py summarises it")
     ap.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)
@@ -542,6 +547,11 @@ def main():
             args.steps = 4  # (default: four passes over the corpus' batch(es))
         return infer_main(args)
 
+    if args.exchange_proxy:
+        if args.gpus != 1 or "WORLD_SIZE" in os.environ:
+            raise SystemExit("--exchange-proxy is a ONE-GPU experiment (the stand-in for a collective that cannot run here)")
+        os.environ["S2ST_EXCHANGE_PROXY"] = args.exchange_proxy  # read by runtime/distributed.GradReducer
+        args.no_other_configs = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks here, as fresh child processes BEFORE this
         # process touches the GPU (the reference spawns its ranks itself too: fairseq/distributed/utils.py:334-369
@@ -658,9 +668,9 @@ def main():
             ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3])))
     if world > 1:
         torch.distributed.barrier()
-        if trainer.reducer is not None and trainer.reducer.cuda:
-            trainer.reducer.exposed_ms()  # (drop what the warm-up recorded)
-            trainer.reducer.measure_exposed = True
+    if (world > 1 or args.exchange_proxy) and trainer.reducer is not None and trainer.reducer.cuda:
+        trainer.reducer.exposed_ms()  # (drop what the warm-up recorded)
+        trainer.reducer.measure_exposed = True
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     step_ev = []
@@ -683,6 +693,18 @@ def main():
     # N > 1: what the gradient exchange cost beyond what the backward hid (the compute stream's wait in
     # GradReducer.finish(), GPU clock), and the ranges it was issued in
     exchange = None
+    proxy = None
+    if args.exchange_proxy and trainer.reducer is not None and trainer.reducer.cuda:
+        trainer.reducer.measure_exposed = False
+        ex = trainer.reducer.exposed_ms()
+        bk = trainer.reducer.last_buckets
+        w_, n_, g_ = trainer.reducer.proxy
+        proxy = {"workgroups": w_, "ranks_modelled": n_, "pace_gbps": g_,
+                 "buckets_mib": [round((hi - lo) * 4 / 2 ** 20, 1) for lo, hi in bk],
+                 "bytes_moved_per_update": int(sum(hi - lo for lo, hi in bk) * 4 * 2 * (n_ - 1) / n_),
+                 "exposed_ms": round(sum(ex) / max(len(ex), 1), 4), "exposed_ms_max": round(max(ex) if ex else 0.0, 4),
+                 "note": "no collective ran: per bucket, a stand-in kernel (s2st_exchange_proxy_f32) on the gradient-exchange "
+                         "stream read + wrote the bucket's 2 (N - 1) / N share on that many workgroups at that pace"}
     if world > 1 and trainer.reducer is not None and trainer.reducer.cuda:
         trainer.reducer.measure_exposed = False
         ex = trainer.reducer.exposed_ms()
@@ -1043,6 +1065,9 @@ def main():
             line["gradient_exchange"] = exchange  # rank 0's view
         if straggler:
             line["straggler"] = straggler
+        if proxy:
+            line["exchange_proxy"] = proxy
+            line["config"]["name"] = args.config + "+exchange_proxy"
         if others:
             line["config"]["other_configs"] = others
         print(json.dumps(line))

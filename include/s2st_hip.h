@@ -236,6 +236,11 @@ int s2st_adam_f32(float* p, float* g, float* m, float* v, int64_t n, const float
  * fairseq/models/distributed_fairseq_model.py:58-67): a finished range of the gradient arena rounded to bf16 (RNE) for
  * the collective, and the reduced values widened back into the fp32 arena.  g 16-byte aligned, the bf16 buffer 8-byte. */
 int s2st_grad_pack_bf16_f32(const float* g, uint16_t* out, int64_t n, void* stream);
+/* One-GPU stand-in for the kernels of the gradient all-reduce (fairseq/models/distributed_fairseq_model.py:58-67 wraps the
+ * model in torch DDP, whose reducer all-reduces 25 MB buckets over NCCL beside the backward): `wgs` workgroups read move_bytes
+ * from bucket [n floats] (cyclically) and write them to scratch [n floats], paced to gbps GB/s.  Changes no gradient; lets a
+ * single GPU measure what a bandwidth-moving neighbour on a few CUs costs the training step (bench.py --exchange-proxy). */
+int s2st_exchange_proxy_f32(const float* bucket, float* scratch, int64_t n, int64_t move_bytes, int32_t wgs, float gbps, void* stream);
 int s2st_grad_unpack_bf16_f32(const uint16_t* in, float* g, int64_t n, void* stream);
 
 /* floats of workspace s2st_ctc_f32 needs */
@@ -587,6 +592,23 @@ int s2st_engine_aux_decode(s2st_engine* e, int32_t which, const float* tap, cons
                            const int64_t* prev_tokens, const int32_t* positions, const int32_t* lens, const float* pe,
                            int32_t Bb, int32_t L, int32_t E, float* logits_out, float* workspace,
                            int64_t workspace_floats, void* stream);
+
+/* The same decoder STEP BY STEP with key / value caches -- what fairseq's SequenceGenerator does through incremental_state
+ * (fairseq/sequence_generator.py:189-571: decoder.forward(tokens, incremental_state) on the last token only, and
+ * reorder_incremental_state(new_order) after every step's beam selection; fairseq/modules/multihead_attention.py:261-299, 387-403;
+ * fairseq/models/transformer/transformer_decoder.py:281-326 takes the LAST position when an incremental state is given).
+ * state: caller-owned, s2st_engine_aux_inc_state_floats(which, Bb, E, max_len) floats -- two copies of the self-attention caches
+ * (a reorder gathers from one into the other) and the layers' static encoder K | V projections.  begin: tap [Bb][E][enc_dim] (one
+ * copy per hypothesis), enc_lens [Bb].  step s: tokens [Bb] = the hypotheses' last tokens (int64), reorder [Bb] (int32, or NULL)
+ * = hypothesis b continues old hypothesis reorder[b], positions [Bb] = s + 2 (prefixes hold no padding), pe as above;
+ * logits_out [Bb][V] = the last position's logits.  A hypothesis costs O(L) per step (the prefix form above: O(L^2)). */
+int64_t s2st_engine_aux_inc_state_floats(const s2st_engine* e, int32_t which, int32_t Bb, int32_t E, int32_t max_len);
+int64_t s2st_engine_aux_inc_workspace(const s2st_engine* e, int32_t which, int32_t Bb, int32_t E);
+int s2st_engine_aux_inc_begin(s2st_engine* e, int32_t which, const float* tap, const int32_t* enc_lens, int32_t Bb, int32_t E,
+                              int32_t max_len, float* state, float* workspace, int64_t workspace_floats, void* stream);
+int s2st_engine_aux_inc_step(s2st_engine* e, int32_t which, int32_t step, const int64_t* tokens, const int32_t* reorder,
+                             const int32_t* positions, const float* pe, float* logits_out, float* workspace,
+                             int64_t workspace_floats, void* stream);
 
 /* ---- frozen HuBERT front end of config 4 (--use-hubert): fairseq/models/hubert/hubert.py:412-461,
  * 518-534 (extract_features, eval, mask=False) with wav2vec2.py:736-905.  The handle is an

@@ -139,7 +139,7 @@ __device__ __forceinline__ bf16x8 pack_frag(const float (&v)[8]) {
 // (batch, head) pair -- which all read the same Q / K / V / dO tiles -- used to land on 8 different L2s (PMC: the backward
 // fetched 68 MB per launch for 17 MB of operands).  The linear id is re-read as (XCD = id % 8, slot = id / 8): XCD x
 // owns pair 8 s + x of every group s of 8 pairs, for all of that pair's blocks.  Pairs beyond the last full group keep
-// the plain order.  (S2ST_ATTN_XCD=0 at launch: `plain` = 1, the A/B switch.)
+// the plain order.  (`plain` = 1 restores launch order: round 3's A/B form, no longer switchable.)
 __device__ __forceinline__ void attn_block(int plain, int& bx, int& bh) {
   const int nbx = gridDim.x, nbh = gridDim.y;
   bx = blockIdx.x;
@@ -810,18 +810,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void flash_bwd_short_kern
     }
   }
   ATTN_STAMP(3);  // phase A loop done (wave 0)
-  // (bias-gradient partial slots: the two-pass kernels' numbering -- blocks of 64 columns, 4 waves each)
-  if (wave < 4 * ((a.S + 63) / 64)) {
-    const bool on = ki < a.S;
-    const long ko = ((long)b * a.S + min(ki, a.S - 1)) * a.ldk + h * DH;
-    const long vo = ((long)b * a.S + min(ki, a.S - 1)) * a.ldv + h * DH;
-    const long slot = a.db_part ? ((long)b * ((a.S + 63) / 64) * 4 + wave) * ((long)a.H * DH) : 0;
-    store_grad<DT>(dk, a.scale, on, a.dk ? a.dk + ko : nullptr, a.dkh ? a.dkh + ko : nullptr,
-                   a.dbk ? a.dbk + slot + h * DH : nullptr, lane, a.db_part != 0);
-    store_grad<DT>(dv, 1.f, on, a.dv ? a.dv + vo : nullptr, a.dvh ? a.dvh + vo : nullptr,
-                   a.dbv ? a.dbv + slot + h * DH : nullptr, lane, a.db_part != 0);
-  }
-  ATTN_STAMP(4);  // dK, dV stored
   __syncthreads();
   ATTN_STAMP(5);
 
@@ -844,8 +832,23 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void flash_bwd_short_kern
     const long slot = a.db_part ? ((long)b * ((a.T + 63) / 64) * 4 + wave) * ((long)a.H * DH) : 0;
     store_grad<DT>(dq, a.scale, q_ok, a.dq ? a.dq + qo : nullptr, a.dqh ? a.dqh + qo : nullptr,
                    a.dbq ? a.dbq + slot + h * DH : nullptr, lane, a.db_part != 0);
-    ATTN_STAMP(7);
+    ATTN_STAMP(4);  // dQ stored
   }
+  // dK, dV leave AFTER phase B: the barrier in front of it is then reached as soon as a wave's dS^T rows are in LDS, and the
+  // gradient stores of the fast waves no longer sit in front of everybody's phase B (stamps: 3.9 k cycles of stores + 3 k of
+  // waiting at the barrier per workgroup in the first form)
+  // (bias-gradient partial slots: the two-pass kernels' numbering -- blocks of 64 columns, 4 waves each)
+  if (wave < 4 * ((a.S + 63) / 64)) {
+    const bool on = ki < a.S;
+    const long ko = ((long)b * a.S + min(ki, a.S - 1)) * a.ldk + h * DH;
+    const long vo = ((long)b * a.S + min(ki, a.S - 1)) * a.ldv + h * DH;
+    const long slot = a.db_part ? ((long)b * ((a.S + 63) / 64) * 4 + wave) * ((long)a.H * DH) : 0;
+    store_grad<DT>(dk, a.scale, on, a.dk ? a.dk + ko : nullptr, a.dkh ? a.dkh + ko : nullptr,
+                   a.dbk ? a.dbk + slot + h * DH : nullptr, lane, a.db_part != 0);
+    store_grad<DT>(dv, 1.f, on, a.dv ? a.dv + vo : nullptr, a.dvh ? a.dvh + vo : nullptr,
+                   a.dbv ? a.dbv + slot + h * DH : nullptr, lane, a.db_part != 0);
+  }
+  ATTN_STAMP(7);
 }
 
 // Short-sequence forward (S <= 128, T <= 128): one workgroup of 8 waves per (batch, head) pair; K and V go to LDS ONCE
@@ -963,11 +966,8 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_short_kernel(AttnArgs a)
 
 // waves per workgroup (16 columns each): 2 -> T/32 x B*H workgroups, several resident per CU, so the
 // barrier / global-load latency of one overlaps the MFMAs of another (sequences here are 100-750 long)
-constexpr int ANW = 4;  // default (measured: 4 > 2 > 1 on the bench step)
-int attn_nw() {
-  static const int v = getenv("S2ST_ATTN_NW") ? atoi(getenv("S2ST_ATTN_NW")) : ANW;
-  return v == 1 || v == 2 || v == 4 ? v : ANW;
-}
+constexpr int ANW = 4;  // (measured in round 2: 4 > 2 > 1 on the bench step; the switch and the other instantiations are gone)
+constexpr int attn_nw() { return ANW; }
 
 // the short-sequence kernels use more than 64 KB of dynamic LDS: set the attribute once per instantiation
 bool short_configure() {
@@ -983,17 +983,12 @@ bool short_configure() {
   }
   return ok == 1;
 }
-// S2ST_ATTN_SHORT=0 (read per call: the A/B tests flip it): the two-pass kernels at every length
+// S2ST_ATTN_SHORT=0 (read per call: the A/B test flips it): the streaming / two-pass kernels at every length
 bool short_enabled() {
-  const char* e = getenv("S2ST_ATTN_SHORT");
+  const char* e = s2st_env_str("S2ST_ATTN_SHORT");
   return !(e && atoi(e) == 0);
 }
-
-// S2ST_ATTN_SHORT_FWD=0: the streaming forward at every length (S2ST_ATTN_SHORT=0 switches both off)
-bool short_fwd_enabled() {
-  const char* e = getenv("S2ST_ATTN_SHORT_FWD");
-  return short_enabled() && !(e && atoi(e) == 0);
-}
+bool short_fwd_enabled() { return short_enabled(); }
 
 bool attn_args_ok(const s2st_attn_args& p) {
   auto al = [](const void* x, int n) { return ((uintptr_t)x % n) == 0; };
@@ -1010,8 +1005,7 @@ AttnArgs to_args(const s2st_attn_args& p) {
   a.scale = p.scale; a.drop_p = p.drop_p; a.seed = p.seed; a.ld_drop = p.ld_drop;
   a.doh = p.doh; a.dq = p.dq; a.dk = p.dk; a.dv = p.dv;
   a.dqh = p.dqh; a.dkh = p.dkh; a.dvh = p.dvh; a.dbq = p.dbq; a.dbk = p.dbk; a.dbv = p.dbv;
-  static const int plain = (getenv("S2ST_ATTN_XCD") && atoi(getenv("S2ST_ATTN_XCD")) == 0) ? 1 : 0;
-  a.plain_order = plain;
+  a.plain_order = 0;  // (XCD-aware block order: round 3's A/B -- 68 -> 18 MB fetched per backward launch -- is closed)
   return a;
 }
 
@@ -1033,10 +1027,7 @@ int s2st_flash_attn_preload(hipStream_t st) {
     S2ST_LAUNCH((flash_bwd_kernel<128, NW>), dim3(1, 1), dim3(64 * NW), 0, st, a, 1);
     S2ST_LAUNCH((flash_bwd_kernel<64, NW>), dim3(1, 1), dim3(64 * NW), 0, st, a, 1);
   };
-  const int nw = attn_nw();
-  if (nw == 1) go(std::integral_constant<int, 1>{});
-  else if (nw == 2) go(std::integral_constant<int, 2>{});
-  else go(std::integral_constant<int, 4>{});
+  go(std::integral_constant<int, ANW>{});
   if (!short_configure()) return S2ST_ERR_LAUNCH;
   S2ST_LAUNCH((flash_fwd_short_kernel<128, 8>), dim3(1), dim3(512), 0, st, a);
   S2ST_LAUNCH((flash_fwd_short_kernel<64, 8>), dim3(1), dim3(512), 0, st, a);
@@ -1071,10 +1062,7 @@ int s2st_flash_attn_fwd(const s2st_attn_args* p, hipStream_t st) {
     if (p->dh == 128) s2st_launch("flash_fwd_kernel<128>", fl, 0.0, flash_fwd_kernel<128, NW>, grid, dim3(64 * NW), 0, st, a);
     else s2st_launch("flash_fwd_kernel<64>", fl, 0.0, flash_fwd_kernel<64, NW>, grid, dim3(64 * NW), 0, st, a);
   };
-  const int nw = attn_nw();
-  if (nw == 1) go(std::integral_constant<int, 1>{});
-  else if (nw == 2) go(std::integral_constant<int, 2>{});
-  else go(std::integral_constant<int, 4>{});
+  go(std::integral_constant<int, ANW>{});
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
@@ -1100,9 +1088,8 @@ int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_sc
   if (!p || !attn_args_ok(*p) || !p->doh || (!p->dq && !p->dqh) || (!p->dk && !p->dkh) || (!p->dv && !p->dvh) || !p->lse)
     return S2ST_ERR_ARG;
   // D = rowsum(dO * O): inside the backward kernels from the bf16 copies when the forward left one of O (no separate
-  // launch; S2ST_ATTN_DVEC_KERNEL=1, the A/B switch (read per call: tests flip it), or no bf16 O: the fp32 row kernel first)
-  const bool dvec_kernel = getenv("S2ST_ATTN_DVEC_KERNEL") && atoi(getenv("S2ST_ATTN_DVEC_KERNEL")) != 0;
-  const bool own_d = p->oh && !dvec_kernel && phase == 0;
+  // launch; without a bf16 copy of O: the fp32 row kernel first)
+  const bool own_d = p->oh && phase == 0;
   if (!own_d && (!dO || !dvec_scratch || !p->o)) return S2ST_ERR_ARG;
   AttnArgs a = to_args(*p);
   a.dvec = own_d ? nullptr : dvec_scratch;
@@ -1121,9 +1108,8 @@ int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_sc
     a.dbv = p->dbv ? db_part + (slots_q + slots_k) * Cp : nullptr;
   }
   // T, S <= 128: one workgroup per (batch, head) pair, every operand loaded once, the scores computed once
-  const bool split_env = getenv("S2ST_ATTN_BWD_SPLIT") && atoi(getenv("S2ST_ATTN_BWD_SPLIT")) != 0;
-  if (phase == 0 && p->T <= SHORT_MAX && p->S <= SHORT_MAX && nwp == 4 && !split_env && short_enabled() && short_configure()) {
-    if (!own_d) {  // (D from the fp32 row kernel: the S2ST_ATTN_DVEC_KERNEL=1 / no-bf16-O form)
+  if (phase == 0 && p->T <= SHORT_MAX && p->S <= SHORT_MAX && short_enabled() && short_configure()) {
+    if (!own_d) {  // (D from the fp32 row kernel: the no-bf16-O form)
       const long rows_ = (long)p->B * p->T * p->H;
       if (p->dh == 128)
         S2ST_LAUNCH(attn_dvec_kernel<128>, dim3((unsigned)((rows_ * 32 + 255) / 256)), dim3(256), 0, st, dO, (const float*)p->o,
@@ -1157,8 +1143,7 @@ int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_sc
     const bool kv = phase == 0 || phase == 2, qq = phase == 0 || phase == 3;
     // as-launched FLOPs: dK,dV pass = S^T recompute + dP + dV + dK (4 products), dQ pass = S + dP + dQ (3 products)
     const double f1 = 2.0 * p->B * p->H * (double)p->T * p->S * p->dh * (p->causal ? 0.5 : 1.0);
-    const bool split = getenv("S2ST_ATTN_BWD_SPLIT") && atoi(getenv("S2ST_ATTN_BWD_SPLIT")) != 0;  // A/B switch (per call: tests flip it)
-    if (kv && qq && !split) {
+    if (kv && qq) {
       dim3 g2(gk.x + gq.x, gk.y);
       if (p->dh == 128) s2st_launch("flash_bwd_kernel<128>", 7 * f1, 0.0, flash_bwd_kernel<128, NW>, g2, dim3(64 * NW), 0, st, a, (int)gk.x);
       else s2st_launch("flash_bwd_kernel<64>", 7 * f1, 0.0, flash_bwd_kernel<64, NW>, g2, dim3(64 * NW), 0, st, a, (int)gk.x);
@@ -1170,10 +1155,7 @@ int s2st_flash_attn_bwd(const s2st_attn_args* p, const float* dO, float* dvec_sc
       if (qq) s2st_launch("flash_bwd_q_kernel<64>", 3 * f1, 0.0, flash_bwd_q_kernel<64, NW>, gq, dim3(64 * NW), 0, st, a);
     }
   };
-  const int nw = attn_nw();
-  if (nw == 1) go(std::integral_constant<int, 1>{});
-  else if (nw == 2) go(std::integral_constant<int, 2>{});
-  else go(std::integral_constant<int, 4>{});
+  go(std::integral_constant<int, ANW>{});
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 

@@ -20,6 +20,9 @@ int s2st_device_count(void) {
   return n;
 }
 
+int s2st_exchange_proxy_f32(const float* bucket, float* scratch, int64_t n, int64_t move_bytes, int32_t wgs, float gbps, void* stream) {
+  return s2st_exchange_proxy(bucket, scratch, (long)n, (long)move_bytes, wgs, gbps, (hipStream_t)stream);
+}
 int s2st_grad_pack_bf16_f32(const float* g, uint16_t* out, int64_t n, void* stream) {
   return s2st_grad_pack_bf16(g, out, (long)n, (hipStream_t)stream);
 }

@@ -42,7 +42,7 @@ bool load_api() {
   const char* names[] = {"librccl.so.1", "librccl.so"};
   for (const char* n : names)
     if (!g_api.lib) g_api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
-  if (!g_api.lib && getenv("S2ST_RCCL_LIB")) g_api.lib = dlopen(getenv("S2ST_RCCL_LIB"), RTLD_NOW | RTLD_GLOBAL);
+  if (!g_api.lib && s2st_env_str("S2ST_RCCL_LIB")) g_api.lib = dlopen(s2st_env_str("S2ST_RCCL_LIB"), RTLD_NOW | RTLD_GLOBAL);
   for (const char* n : names)
     if (!g_api.lib) g_api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
   if (!g_api.lib) return false;

@@ -578,18 +578,6 @@ int colreduce2(F f, int rows, int cols, float* out0, float* out1, float* scratch
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }
 
-struct SumF {
-  const float* x; int C;
-  __device__ float2 operator()(int r, int c) const { return make_float2(x[(long)r * C + c], 0.f); }
-};
-struct SqDevF {
-  const float* x; const float* sum; int C; float inv_rows;
-  __device__ float2 operator()(int r, int c) const {
-    float d = x[(long)r * C + c] - sum[c] * inv_rows;
-    return make_float2(d * d, 0.f);
-  }
-};
-
 // One pass over x: d = x - x[row 0] (a data sample of the column: |mean - shift| is a few standard deviations at most, so
 // var = E[d^2] - E[d]^2 loses ~10 ulp where the unshifted form can lose everything), returns {d, d^2}
 struct ShiftSqF {
@@ -632,35 +620,6 @@ __global__ __launch_bounds__(256) void bn_finalize_shift_kernel(const float* __r
   }
 }
 
-// sq_part: the squared-deviation slab partials [slabs][2][C] (folded here, in slab order)
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sum,
-                                                          const float* __restrict__ sq_part, int slabs,
-                                                          float* __restrict__ mean,
-                                                          float* __restrict__ var,
-                                                          float* __restrict__ run_mean,
-                                                          float* __restrict__ run_var, int C,
-                                                          int rows, float momentum) {
-  int c = blockIdx.x * EW_BLOCK + threadIdx.x;
-  if (c >= C) return;
-  float m = sum[c] / rows;
-  float sq = 0.f;
-  for (int sb = 0; sb < slabs; sb += 16) {
-    float v[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = sq_part[(long)min(sb + j, slabs - 1) * 2 * C + c];
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-      if (sb + j < slabs) sq += v[j];
-  }
-  float v = sq / rows;
-  mean[c] = m;
-  var[c] = v;
-  if (run_mean) {
-    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * m;
-    float unb = rows > 1 ? v * ((float)rows / (float)(rows - 1)) : v;
-    run_var[c] = (1.f - momentum) * run_var[c] + momentum * unb;
-  }
-}
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(
     const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ var,
@@ -1048,23 +1007,13 @@ int s2st_conv_w_unpermute_acc(const float* dwf, float* dw, int O, int I, int Kw,
 int s2st_bn_stats(const float* x, int rows, int C, float* mean, float* var, float* run_mean,
                   float* run_var, float momentum, float* tmp, hipStream_t st) {
   if (rows <= 0 || C <= 0) return 0;
-  // one pass (shifted sums; 2 launches) unless S2ST_BN_TWO_PASS=1 (round 1-2 form: mean, then squared deviations; 4)
-  static const bool two_pass = getenv("S2ST_BN_TWO_PASS") && atoi(getenv("S2ST_BN_TWO_PASS")) != 0;
+  // one pass: shifted sums (d = x - x[row 0]; var = E[d^2] - E[d]^2), partials folded in slab order; 2 launches.  (Round 1 - 2's
+  // mean pass + squared-deviation pass, 4 launches, was the A/B form of round 3: 7.82 vs 7.79 ms per step; gone.)
   int slabs = 0;
-  if (!two_pass) {
-    int rc = colreduce2(ShiftSqF{x, C}, rows, C, nullptr, nullptr, tmp + 2 * (long)C, st, nullptr, nullptr, &slabs);
-    if (rc) return rc;
-    S2ST_LAUNCH(bn_finalize_shift_kernel, dim3((C + EW_BLOCK - 1) / EW_BLOCK), dim3(EW_BLOCK), 0, st, x,
-                (const float*)(tmp + 2 * (long)C), slabs, mean, var, run_mean, run_var, C, rows, momentum);
-    return LAUNCH_OK();
-  }
-  int rc = colreduce2(SumF{x, C}, rows, C, tmp, nullptr, tmp + 2 * (long)C, st);
+  int rc = colreduce2(ShiftSqF{x, C}, rows, C, nullptr, nullptr, tmp + 2 * (long)C, st, nullptr, nullptr, &slabs);
   if (rc) return rc;
-  rc = colreduce2(SqDevF{x, tmp, C, 1.f / rows}, rows, C, nullptr, nullptr, tmp + 2 * (long)C, st, nullptr, nullptr, &slabs);
-  if (rc) return rc;
-  S2ST_LAUNCH(bn_finalize_kernel, dim3((C + EW_BLOCK - 1) / EW_BLOCK), dim3(EW_BLOCK), 0, st,
-                     (const float*)tmp, (const float*)(tmp + 2 * (long)C), slabs, mean, var, run_mean, run_var, C, rows,
-                     momentum);
+  S2ST_LAUNCH(bn_finalize_shift_kernel, dim3((C + EW_BLOCK - 1) / EW_BLOCK), dim3(EW_BLOCK), 0, st, x,
+              (const float*)(tmp + 2 * (long)C), slabs, mean, var, run_mean, run_var, C, rows, momentum);
   return LAUNCH_OK();
 }
 

@@ -98,7 +98,6 @@ struct s2st_engine {
   size_t aux_wait_idx = 0, aux_lo_idx = 0, aux_hi_idx = 0;  // tape indices: tap-LN end; aux section [lo, hi)
   bool aux_bwd_on_side = false;
   bool side_used = false;
-  bool join_every_segment = false;  // S2ST_JOIN_EVERY_SEGMENT=1 (A/B switch)
   float* skws_side = nullptr;
   bool side_allowed = false;  // bf16-operand mode and no S2ST_NO_SIDE_STREAM=1
   bool side_tried = false;
@@ -164,7 +163,6 @@ struct s2st_engine {
   // chain 1 salts its seed, so its masks are independent of chain 0's (they differ from the one-chain schedule's masks for
   // those rows -- same distribution; with dropout off the two schedules' forward outputs are bit-identical).
   int nchains = 1;               // S2ST_CHAINS
-  bool chains_one_stream = false;  // S2ST_CHAINS_ONE_STREAM=1 (debugging aid): both halves on the caller's stream
   hipStream_t chain1_ = nullptr;
   hipEvent_t ev_cfork_ = nullptr, ev_cjoin_ = nullptr, ev_cside_ = nullptr;
   bool forked_ = false;
@@ -188,7 +186,7 @@ struct s2st_engine {
     const int per = rows / bt.B, b0 = bt.B / 2;
     if (live()) ensure_forked();
     p[0] = Part{0, b0 * per, main_, 0};
-    p[1] = Part{b0 * per, rows - b0 * per, chains_one_stream ? main_ : chain1_, CHAIN_SALT};
+    p[1] = Part{b0 * per, rows - b0 * per, chain1_, CHAIN_SALT};
     return 2;
   }
   void ensure_forked() {
@@ -219,21 +217,16 @@ struct s2st_engine {
   struct Dec {
     float* base = nullptr; int B = 0, E = 0, maxT = 0; const int* enc_lens = nullptr; const float* pe_dec = nullptr;
     float* pe_alpha = nullptr;  // [maxT + 2][dec_dim]: pos_emb_alpha * PE rows (tail of the caller's state buffer)
-    bf16raw* cross_h = nullptr; // fast mode: bf16 copies of the static cross-attention keys | values, [L][B * E][2 dec_dim]
   } dec_st;
   float* dec_selfK(int l) const { return dec_st.base + (long)l * 2 * dec_st.B * dec_st.maxT * c.dec_dim; }
   float* dec_selfV(int l) const { return dec_selfK(l) + (long)dec_st.B * dec_st.maxT * c.dec_dim; }
   float* dec_crossKV(int l) const {
     return dec_st.base + (long)c.dec_layers * 2 * dec_st.B * dec_st.maxT * c.dec_dim + (long)l * dec_st.B * dec_st.E * 2 * c.dec_dim;
   }
-  bool conv_tail_on_main = true;  // S2ST_CONV_TAIL_MAIN=0 (A/B switch): the first convolution's weight gradient on the second stream too
-  unsigned wgrad_count = 0;
-  int wgrad_main_every = 0;  // S2ST_WGRAD_MAIN_EVERY=<n>: every n-th weight-gradient GEMM stays on the data-path stream
                              // (0 = none).  Balances the two streams; measured on the bench workload: n = 3 .. 16,
                              // best 7 (11.15 -> 10.89 ms/step together with the attention-backward bf16 gradients)
   bool use_ln_skinny = true; // S2ST_NO_LN_SKINNY=1 (A/B switch): separate layer-norm kernels in the AR decoding steps
   bool use_skinny = true;    // S2ST_NO_SKINNY=1 (A/B switch): tiled GEMMs for the AR decoding steps too
-  bool skip_resid_h = true;  // S2ST_RESID_H=1 (A/B switch): also write bf16 copies of residual-stream outputs
   bool use_ln_fuse = true;  // S2ST_NO_LN_FUSE=1 (A/B switch): separate dropout-backward prologue pass
   bool use_only_h = true;  // S2ST_NO_ONLY_H=1: always keep the fp32 copy of GEMM-only tensors (A/B switch)
   // S2ST_ATTN_GFUSE (default 1): the attention backward emits the bf16 projection gradients itself (no fp32 gradient, no
@@ -279,7 +272,6 @@ struct s2st_engine {
     for (const WT& t : wt_list) if (t.off == off && t.N == N && t.K == K) return true;
     return false;
   }
-  bool transpose_each = false;
   std::vector<s2st_transpose_table> wt_tables;
   void build_wt_tables() {
     s2st_transpose_table cur{};
@@ -668,9 +660,6 @@ struct s2st_engine {
   // ------------------------------------------------------------------------------------
   // weight-gradient GEMMs waiting for their group launch (S2ST_NO_WGRAD_GROUP=1: A/B switch, one launch each)
   bool group_wgrad = true;
-  int conv_wgrad_group = 0;  // (default 0: measured 7.30 - 7.33 / 7.30 - 7.35 / 7.38 - 7.40 ms per step, profiles/r05_conv_wgrad_ab.txt)
-                             // S2ST_CONV_WGRAD_GROUP=0/1/2: convolution weight gradients as split-row products / in the grouped
-                             // launch for stride-1 layers whose input takes a gradient (the image exists anyway) / for all
   int group_flush_at = 6;  // S2ST_WGRAD_GROUP=<n>: problems per launch (<= S2ST_GROUP_MAX); measured 2 .. 8 on the bench
                            // workload: 12.25 / 10.99 / 10.56 / 10.44 / 10.46 ms per step for 2 / 3 / 4 / 6 / 8
   std::vector<GemmArgs> pending_wgrad;
@@ -690,7 +679,7 @@ struct s2st_engine {
       // how much of the step is the weight-gradient products' share of the chip
 #ifdef S2ST_EXPERIMENTAL
       static const bool skip = [] {
-        const bool on = getenv("S2ST_TIMING_SKIP_WGRAD") && atoi(getenv("S2ST_TIMING_SKIP_WGRAD")) != 0;
+        const bool on = s2st_env_on("S2ST_TIMING_SKIP_WGRAD");
         if (on) fprintf(stderr, "[s2st] S2ST_TIMING_SKIP_WGRAD=1: weight-gradient products are SKIPPED -- gradients are WRONG, "
                                 "timing experiments only\n");
         return on;
@@ -757,7 +746,7 @@ struct s2st_engine {
     const bf16raw* xh = fm ? half_of(x) : nullptr;
     // (a residual-stream output is read in fp32 by the next layer norm / residual add: no bf16 copy; a consumer that
     // does want one gets it from half_of())
-    if (fm && N % 8 == 0 && !(resid && skip_resid_h)) y->h = alloc_h(y->n());
+    if (fm && N % 8 == 0 && !resid) y->h = alloc_h(y->n());  // (residual-stream outputs are only ever read as fp32)
     if (fm && act == 1 && y->h && !resid) { y->act_mode = 1; y->act_p = drop_p; y->act_bias = b; }
     if (fm && act == 0 && drop_p == 0.f && !resid && y->h) { y->lin_plain = true; y->act_bias = b; }
     if (fm && act == 0 && drop_p > 0.f && N % 8 == 0 && use_ln_fuse) {
@@ -850,8 +839,8 @@ struct s2st_engine {
         g.C = gemm_out(G + w, K);
         g.ep = gemm_epi_default();
         g.ep.accumulate = 1;
-        // weight gradients go to the second stream (S2ST_WGRAD_MAIN_EVERY: a share of them stays on the data path)
-        const bool on_main = wgrad_main_every > 0 && (wgrad_count++ % wgrad_main_every) == 0;
+        // weight gradients go to the second stream
+        constexpr bool on_main = false;
         g.M = N; g.N = K; g.K = M; g.batch = 1; g.zdiv = 1; g.precise = c.precise;
         if (fm && !on_main && group_wgrad && s2st_gemm_group_ok(g)) {
           // a layer's weight-gradient products leave together, as ONE persistent launch with K = tokens unsplit
@@ -959,7 +948,6 @@ struct s2st_engine {
       struct Restore { bool& r; bool v; ~Restore() { r = v; } } restore_{in_region_, region_was};
       Part bp[2];
       const int nb = chain_parts(x->rows, bp);
-      if (dbg_dir_set() && live()) sync_chains();  // (the dump below reads whole tensors; debugging runs use one chain)
       bool acc;
       float* dx = gradbuf(x, acc);
       const bool fuse = fuse_cand && !x->gpre_h;
@@ -968,28 +956,6 @@ struct s2st_engine {
       bf16raw* dph = nullptr;
       if (fuse) dph = x->gpre_h = alloc_h(x->n());
       float* dbias = fuse && x->drop2_bias >= 0 ? G + x->drop2_bias : nullptr;
-      // debugging aid (tools/debug_lnsplit3.py): S2ST_DEBUG_LN_DUMP=<dir> writes the inputs / outputs of every call
-      static const char* const dbg_dir = getenv("S2ST_DEBUG_LN_DUMP");
-      const char* dbg = live() ? dbg_dir : nullptr;
-      static int dbg_n = 0;
-      auto dump = [&](const char* what, const void* dptr, size_t bytes) {
-        std::vector<char> h(bytes);
-        hipStreamSynchronize(st_);
-        if (side_) hipStreamSynchronize(side_);
-        hipMemcpyAsync(h.data(), dptr, bytes, hipMemcpyDeviceToHost, st_);
-        hipStreamSynchronize(st_);
-        char path[512];
-        snprintf(path, sizeof path, "%s/ln%03d_%s.bin", dbg, dbg_n, what);
-        if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 1, bytes, f); fclose(f); }
-      };
-      if (dbg) {
-        fprintf(stderr, "[ln dump %d] rows %d cols %d acc %d fuse %d\n", dbg_n, x->rows, x->cols, (int)acc, (int)fuse);
-        dump("dy", y->g, sizeof(float) * x->n());
-        dump("x", x->d, sizeof(float) * x->n());
-        dump("mean", mean, sizeof(float) * x->rows);
-        dump("rstd", rstd, sizeof(float) * x->rows);
-        if (acc) dump("dx0", dx, sizeof(float) * x->n());
-      }
       if (live()) {
         if (nb == 2) ensure_forked();
         if (!ln_bwd_split) {
@@ -1018,17 +984,9 @@ struct s2st_engine {
           for (int ci = 0; ci < nb; ++ci) pass(ci, 2, rs);
         }
       }
-      if (dbg) {
-        dump("dx1", dx, sizeof(float) * x->n());
-        ++dbg_n;
-      }
     });
     set_aware();
     return y;
-  }
-  static bool dbg_dir_set() {
-    static const bool on = getenv("S2ST_DEBUG_LN_DUMP") != nullptr;
-    return on;
   }
 
   // attention core.  q: [B*T] rows at qp (+ h*dh), ld ldq ; k/v rows [B*S] ; out [B*T][C]
@@ -1319,47 +1277,13 @@ struct s2st_engine {
       float* cpart = ordered_sums ? alloc(s2st_colsum_scratch_floats(M, pp.O)) : nullptr;
       const bool no_dgrad = !(in2.src && in2.src->needs_grad);
       // dz placed at rows pad + stride*t of a zeroed [B][Tin + 2 pad][O] image: the data gradient's operand (a stride-1
-      // correlation with flipped taps) and, round 5, the weight gradient's -- fast mode builds it directly in bf16 from
-      // dz's bf16 twin (no fp32 image, no cast pass)
+      // correlation with flipped taps) -- fast mode builds it directly in bf16 from dz's bf16 twin (no fp32 image, no cast pass).
+      // (Round 5 also expressed the WEIGHT gradient over whole halo-image rows so that it could join the grouped LDS-DMA
+      //  launch: built, tested, the second stream did 0.11 ms less and the step got 0.07 ms SLOWER -- a grouped workgroup holds
+      //  128 KB of LDS where the split-row kernel leaves room for the data path's workgroups; profiles/r05_conv_wgrad_ab.txt.
+      //  Removed in round 6.)
       const bool direct = fm && pp.O % 8 == 0;
-      // Weight gradient over WHOLE halo-image rows: with R the flat row index of the images,
-      //   dWf[o][(j, c)] = sum_R up[R][o] * xh[R - pad + j][c]
-      // -- the rows of `up` that hold no dz (halos, the odd rows of a stride-2 image) are zero, and a row that does hold one
-      // reads xh rows of its own utterance only -- is a plain [K = rows][O]^T x [K][Kw * I] product (second operand: rows
-      // of Kw * I elements at a pitch of I, overlapping): no per-utterance row splits, so it qualifies for the grouped
-      // LDS-DMA launch of the linear layers' weight gradients (K unsplit: no slabs, no combine kernel).  K runs over rows
-      // [pad, B * Th - pad): both operands stay inside their images.  S2ST_CONV_WGRAD_GROUP=0: the per-utterance
-      // split-row product of rounds 1 - 4 (A/B switch).
-      GemmArgs gw{};
-      bool grouped = false;
-      // (K = all image rows stays in ONE launch, but a product of few 128 x 128 output tiles is cut into K ranges -- one
-      //  problem of the group each, its own fp32 slab, plain stores -- until the launch has a tile per CU; the layout pass
-      //  that adds the result into the parameter's [O][I][Kw] gradient sums the slabs in order)
-      int kslabs = 1, kchunk = 0;
-      float* wslab = nullptr;
-      const long wn = (long)pp.O * pp.I * pp.Kw;
-      if (fm && direct && group_wgrad && in2.xhh && (long)B * Th > 2L * pad &&
-          (conv_wgrad_group >= 2 || (conv_wgrad_group == 1 && stride == 1 && !no_dgrad))) {
-        gw.A = gemm_colmajor((const bf16raw*)nullptr, pp.O);
-        gw.B = gemm_colmajor(in2.xhh, pp.I);
-        gw.C = gemm_out(dwf, (long)pp.Kw * pp.I);
-        gw.ep = gemm_epi_default();
-        gw.M = pp.O; gw.N = pp.Kw * pp.I; gw.K = B * Th - 2 * pad; gw.batch = 1; gw.zdiv = 1; gw.precise = c.precise;
-        GemmArgs probe = gw;
-        probe.A.p = in2.xhh;  // (any aligned pointer: the image is allocated below)
-        grouped = s2st_gemm_group_ok(probe);
-        if (grouped) {
-          const long tiles = (long)((gw.M + 127) / 128) * ((gw.N + 127) / 128);
-          long want = (256 + tiles - 1) / tiles, most = gw.K / 1024;
-          if (most < 1) most = 1;
-          if (want > most) want = most;
-          if (want > 16) want = 16;
-          kchunk = (int)(((gw.K + want - 1) / want + 63) / 64 * 64);
-          kslabs = (gw.K + kchunk - 1) / kchunk;
-          wslab = alloc(kslabs * wn);
-        }
-      }
-      const bool need_img = grouped || !no_dgrad;
+      const bool need_img = !no_dgrad;
       float* up = (need_img && !direct) ? alloc((long)B * Th * pp.O, true) : nullptr;
       bf16raw* upd = (need_img && direct) ? alloc_h((long)B * Th * pp.O) : nullptr;
       if (need_img && live()) {
@@ -1376,20 +1300,8 @@ struct s2st_engine {
         // whose input needs no gradient (the model's first one = the LAST closure of the backward): no data-gradient
         // chain is left, the data-path stream would only wait, so it takes the product and the second stream the bias sum
         hipStream_t side_st = fm ? fork_side() : st_;
-        hipStream_t ws_st = (fm && !(no_dgrad && conv_tail_on_main)) ? side_st : st_;
-        if (grouped) {
-          for (int sl = 0; sl < kslabs; ++sl) {
-            GemmArgs gs = gw;
-            const long k0 = (long)sl * kchunk;
-            gs.A.p = upd + ((long)pad + k0) * pp.O;
-            gs.B.p = in2.xhh + k0 * pp.I;
-            gs.C.p = wslab + sl * wn;
-            gs.K = (int)(gw.K - k0 < kchunk ? gw.K - k0 : kchunk);
-            push_wgrad(gs);
-          }
-          flush_wgrad();  // (the layout pass below reads the slabs: the launch cannot wait for the segment's end)
-          ws_st = side_ ? side_ : st_;
-        } else {
+        hipStream_t ws_st = (fm && !no_dgrad) ? side_st : st_;
+        {
           GemmArgs g{};  // dWf[O][(j,c)] += sum_(b,t) dz[(b,t)][o] * xh[b][t*stride + j][c]
           g.A = fm ? gemm_colmajor(dzh, z->hld()) : gemm_colmajor(z->g, pp.O);
           g.B = fm ? gemm_colmajor(in2.xhh, (long)stride * pp.I) : gemm_colmajor(in2.xh, (long)stride * pp.I);
@@ -1406,7 +1318,7 @@ struct s2st_engine {
           chk(s2st_colsum(z->g, pp.O, M, pp.O, G + pp.b, 1, side_st, cpart, cpart ? &slabs : nullptr));
           if (cpart) add_fold(cpart, slabs, pp.O, G + pp.b);
         }
-        chk(s2st_conv_w_unpermute_acc(grouped ? wslab : dwf, G + pp.w, pp.O, pp.I, pp.Kw, ws_st, grouped ? kslabs : 1));
+        chk(s2st_conv_w_unpermute_acc(dwf, G + pp.w, pp.O, pp.I, pp.Kw, ws_st, 1));
       }
       if (!no_dgrad) {
         bool acc;
@@ -1515,14 +1427,89 @@ struct s2st_engine {
   // to row `pos_new` of the caches before it attends (the two copy launches per layer of rounds 1 - 3 are gone)
   Ten* dec_attn(Ten* qt, int qoff, float* K, float* V, long ldk, long kbs, const int* klen, int nkeys,
                 int H, float* attn_mean, int S, const float* k_new = nullptr, const float* v_new = nullptr, long ld_new = 0,
-                int pos_new = 0, int kv_bf16 = 0, const int* step_ptr = nullptr) {
-    const int Cd = c.dec_dim, B = dec_st.B;
+                int pos_new = 0, int kv_bf16 = 0, const int* step_ptr = nullptr, int dim = 0, int rows = 0) {
+    const int Cd = dim > 0 ? dim : c.dec_dim, B = rows > 0 ? rows : dec_st.B;  // (dim / rows: an aux text decoder's, below)
     Ten* o = newT(B, Cd);
     if (live())
       chk(s2st_decode_attn(qt->d + qoff, qt->cols, K, V, ldk, kbs, klen, nkeys, B, H, Cd / H,
                            1.0f / sqrtf((float)(Cd / H)), o->d, Cd, attn_mean, S, st_, k_new, v_new, ld_new, pos_new, kv_bf16,
                            step_ptr));
     return o;
+  }
+
+  // ---- incremental decoding of an aux ASR / ST text decoder (beam search: fairseq/sequence_generator.py:189-571 carries an
+  //      incremental_state and calls reorder_incremental_state with the surviving beams' indices every step;
+  //      fairseq/modules/multihead_attention.py:261-299 appends the step's key / value rows to the cached ones and keeps the
+  //      static encoder keys / values).  State = a caller-owned buffer: TWO copies of the self-attention caches
+  //      [layer][K | V][Bb][maxT][d] (a step that reorders gathers the valid rows of every hypothesis from one copy into the
+  //      other) and the per-layer encoder K | V projections [layer][Bb * E][2 d] of the head's encoder tap.  A hypothesis then
+  //      costs O(L) per step instead of a re-run of the decoder on its whole prefix. -----------------------------------------
+  struct AuxInc {
+    float* base = nullptr; int Bb = 0, E = 0, maxT = 0, cur = 0; const int* enc_lens = nullptr;
+  } aux_inc[2];
+  static long aux_inc_half(const AuxP& a, int Bb, int maxT) { return (long)a.layers * 2 * Bb * maxT * a.d; }
+  float* aux_selfK(const AuxP& a, const AuxInc& S, int l, int buf) const {
+    return S.base + (long)buf * aux_inc_half(a, S.Bb, S.maxT) + (long)l * 2 * S.Bb * S.maxT * a.d;
+  }
+  float* aux_crossKV(const AuxP& a, const AuxInc& S, int l) const {
+    return S.base + 2 * aux_inc_half(a, S.Bb, S.maxT) + (long)l * S.Bb * S.E * 2 * a.d;
+  }
+  int aux_inc_begin(const AuxP& a, AuxInc& S, Ten* tap) {
+    bt.training = 0;
+    for (int l = 0; l < a.layers; ++l) {
+      const XAttnP& xa = a.L[l].xa;
+      linear(tap, xa.kv_w, xa.kv_b, 2 * a.d, tap->cols, 0, 0.f, nullptr, aux_crossKV(a, S, l));
+    }
+    S.cur = 0;
+    return err;
+  }
+  // tokens [Bb]: the hypotheses' LAST tokens; reorder [Bb] (or null): hypothesis b continues old hypothesis reorder[b]
+  // (fairseq's reorder_incremental_state); pos [Bb]: the tokens' positions (step + 2: prefixes hold no padding)
+  int aux_inc_step(const AuxP& a, AuxInc& S, int step, const long* tokens, const int* reorder, const int* pos, const float* pe,
+                   float* logits_out) {
+    const int Bb = S.Bb, d = a.d, H = c.dec_heads, maxT = S.maxT, E = S.E;
+    if (!S.base || step < 0 || step >= maxT) return S2ST_ERR_ARG;
+    bt.training = 0;
+    const bool pre = c.dec_pre_ln != 0;
+    if (reorder && step > 0) {
+      if (live())
+        chk(s2st_cache_reorder(S.base + (long)S.cur * aux_inc_half(a, Bb, maxT), S.base + (long)(1 - S.cur) * aux_inc_half(a, Bb, maxT),
+                               reorder, 2 * a.layers, Bb, (long)maxT * d, (long)step * d, st_));
+      S.cur ^= 1;
+    }
+    Ten* emb = newT(Bb, a.in_dim);
+    emb->needs_grad = false;
+    const float scale = c.no_scale_embedding ? 1.f : sqrtf((float)a.d);
+    touch(a.embed + (long)a.V * a.in_dim);
+    if (live()) chk(s2st_embed_fwd(tokens, P + a.embed, emb->d, Bb, a.in_dim, scale, st_));
+    Ten* x = emb;
+    if (a.proj_in >= 0) x = linear(x, a.proj_in, -1, d, a.in_dim);
+    x = add_pe(x, pos, pe, 1.f, -1, 0.f);
+    for (int l = 0; l < a.layers; ++l) {
+      const DecLayerP& L = a.L[l];
+      float* Kc = aux_selfK(a, S, l, S.cur);
+      float* Vc = Kc + (long)Bb * maxT * d;
+      Ten* kvq = pre ? ln_linear(x, L.ln1, L.sa.kvq_w, L.sa.kvq_b, 3 * d, d) : linear(x, L.sa.kvq_w, L.sa.kvq_b, 3 * d, d);
+      Ten* o = dec_attn(kvq, 2 * d, Kc, Vc, d, (long)maxT * d, nullptr, step + 1, H, nullptr, 0, kvq->d, kvq->d + d, 3 * d, step, 0,
+                        nullptr, d, Bb);
+      x = linear(o, L.sa.out_w, L.sa.out_b, d, d, 0, 0.f, x);
+      if (!pre) x = layernorm(x, L.ln1);
+      Ten* q = pre ? ln_linear(x, L.ln2, L.xa.q_w, L.xa.q_b, d, d) : linear(x, L.xa.q_w, L.xa.q_b, d, d);
+      o = dec_attn(q, 0, aux_crossKV(a, S, l), aux_crossKV(a, S, l) + d, 2 * d, (long)E * 2 * d, S.enc_lens, E, H, nullptr, E, nullptr,
+                   nullptr, 0, 0, 0, nullptr, d, Bb);
+      x = linear(o, L.xa.out_w, L.xa.out_b, d, d, 0, 0.f, x);
+      if (!pre) x = layernorm(x, L.ln2);
+      if (pre) {
+        Ten* hdn = ln_linear(x, L.ln3, L.fc1.w, L.fc1.b, L.fc1.N, L.fc1.K, ffn_act);
+        x = linear(hdn, L.fc2.w, L.fc2.b, L.fc2.N, L.fc2.K, 0, 0.f, x);
+      } else {
+        x = layernorm(ffn_block(x, L.fc1, L.fc2, x), L.ln3);
+      }
+    }
+    if (a.has_ln) x = layernorm(x, a.ln);
+    if (a.proj_out >= 0) x = linear(x, a.proj_out, -1, a.out_dim, d);
+    linear(x, a.out_proj, -1, a.V, a.out_dim, 0, 0.f, nullptr, logits_out);
+    return err;
   }
 
   int decode_step(int step, const float* prev, const int* pos, const int* self_klen, uint64_t sd, float* feat_out,
@@ -1570,11 +1557,6 @@ struct s2st_engine {
       // encoder attention (static keys / values precomputed by decode_begin)
       Ten* q = pre ? ln_linear(x, L.ln2, L.xa.q_w, L.xa.q_b, Cd, Cd) : linear(x, L.xa.q_w, L.xa.q_b, Cd, Cd);
       const bool align = l == c.dec_layers - 1;
-      if (dec_st.cross_h) {  // fast mode: the static rows as bf16 (what the training path's attention kernels read too)
-        bf16raw* kvh = dec_st.cross_h + (long)l * B * E * 2 * Cd;
-        o = dec_attn(q, 0, reinterpret_cast<float*>(kvh), reinterpret_cast<float*>(kvh + Cd), 2 * Cd, (long)E * 2 * Cd,
-                     dec_st.enc_lens, E, H, align ? attn_out : nullptr, E, nullptr, nullptr, 0, 0, 1);
-      } else
       o = dec_attn(q, 0, dec_crossKV(l), dec_crossKV(l) + Cd, 2 * Cd, (long)E * 2 * Cd, dec_st.enc_lens, E, H,
                    align ? attn_out : nullptr, E);
       x = linear(o, L.xa.out_w, L.xa.out_b, Cd, Cd, 0, 0.f, x);
@@ -1861,9 +1843,9 @@ struct s2st_engine {
       chk(s2st_posconv_prep(x->d, frame_lens, img, imgh, B, T, E, G, pad, Tp, st_));
       // the G groups as ONE batched product (round 5: 16 launches of 150 tiles each -- a third of the CUs -- took 515 us of
       // the 5.8 ms forward): group z reads its image and its [Eg][kp * Eg] weights, writes columns [z Eg, (z + 1) Eg) of x2
-      // (bias and residual follow the columns); S2ST_POSCONV_EACH=1: one launch per group (A/B switch)
-      static const bool each = getenv("S2ST_POSCONV_EACH") && atoi(getenv("S2ST_POSCONV_EACH")) != 0;
-      for (int gi = 0; gi < (each ? G : 1); ++gi) {
+      // (bias and residual follow the columns)
+      constexpr bool each = false;
+      for (int gi = 0; gi < 1; ++gi) {
         GemmArgs g{};
         const long io = (long)gi * B * Tp * Eg, wo = hp.pos_w + (long)gi * Eg * kp * Eg;
         g.A = fm ? gemm_rowmajor(imgh + io, Eg) : gemm_rowmajor(img + io, Eg);
@@ -1895,7 +1877,7 @@ struct s2st_engine {
   // ------------------------------------------------------------------------------------
   // S2ST_GEMM_STREAMK=1: bind stream-K scratch buffers to the two streams (opt-in: on the products of this step the
   // hand-off costs more than the idle tail it removes -- gemm_bf16.hip streamk_mode())
-  bool use_streamk = getenv("S2ST_GEMM_STREAMK") && atoi(getenv("S2ST_GEMM_STREAMK")) > 0;
+  bool use_streamk = s2st_env_on("S2ST_GEMM_STREAMK");
   void reset_call() {
     pending_wgrad.clear();
     pending_lnfold = s2st_lnfold_table{};
@@ -1950,14 +1932,9 @@ struct s2st_engine {
     pht_valid = false;
     if (fm && tr && PHT && live()) {
       hipStream_t ts = side_ ? fork_side() : st_;
-      // one launch per <= 200 matrices (the table rides in the kernel arguments); S2ST_TRANSPOSE_EACH=1: one
-      // launch per matrix (A/B switch)
-      if (transpose_each) {
-        for (const WT& t : wt_list) chk(s2st_transpose_bf16(PH + t.off, PHT + t.off, t.N, t.K, ts));
-      } else {
-        if (wt_tables.empty()) build_wt_tables();
-        for (const s2st_transpose_table& tb : wt_tables) chk(s2st_transpose_bf16_batched(PH, PHT, tb, ts));
-      }
+      // one launch per <= 200 matrices (the table rides in the kernel arguments)
+      if (wt_tables.empty()) build_wt_tables();
+      for (const s2st_transpose_table& tb : wt_tables) chk(s2st_transpose_bf16_batched(PH, PHT, tb, ts));
       pht_valid = true;
     }
     skws_n = fm ? (long)16 << 20 : 0;
@@ -2371,7 +2348,7 @@ struct s2st_engine {
     // The segment's weight gradients live on the second stream.  A caller that overlaps the gradient
     // all-reduce waits on that stream itself (s2st_engine_side_stream); the data path only joins once,
     // after the last segment, so it never stalls behind the weight-gradient backlog.
-    if (seg == ns - 1 || join_every_segment) join_side();
+    if (seg == ns - 1) join_side();
     return err;
   }
 };
@@ -2392,31 +2369,25 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
     return S2ST_ERR_SHAPE;
   s2st_engine* e = new s2st_engine();
   e->c = *cfg;
-  e->f32_operands = getenv("S2ST_F32_OPERANDS") && atoi(getenv("S2ST_F32_OPERANDS")) != 0;
-  e->join_every_segment = getenv("S2ST_JOIN_EVERY_SEGMENT") && atoi(getenv("S2ST_JOIN_EVERY_SEGMENT")) != 0;
-  e->use_flash = !(getenv("S2ST_NO_FLASH") && atoi(getenv("S2ST_NO_FLASH")) != 0);
-  e->transpose_each = getenv("S2ST_TRANSPOSE_EACH") && atoi(getenv("S2ST_TRANSPOSE_EACH")) != 0;
-  e->group_wgrad = !(getenv("S2ST_NO_WGRAD_GROUP") && atoi(getenv("S2ST_NO_WGRAD_GROUP")) != 0);
-  if (getenv("S2ST_CONV_WGRAD_GROUP")) e->conv_wgrad_group = atoi(getenv("S2ST_CONV_WGRAD_GROUP"));
-  if (getenv("S2ST_WGRAD_GROUP")) {
-    e->group_flush_at = atoi(getenv("S2ST_WGRAD_GROUP"));
+  e->f32_operands = s2st_env_on("S2ST_F32_OPERANDS");
+  e->use_flash = !(s2st_env_on("S2ST_NO_FLASH"));
+  e->group_wgrad = !(s2st_env_on("S2ST_NO_WGRAD_GROUP"));
+  if (s2st_env_str("S2ST_WGRAD_GROUP")) {
+    e->group_flush_at = atoi(s2st_env_str("S2ST_WGRAD_GROUP"));
     if (e->group_flush_at < 1) e->group_flush_at = 1;
     if (e->group_flush_at > S2ST_GROUP_MAX) e->group_flush_at = S2ST_GROUP_MAX;
   }
-  e->use_act_fuse = !(getenv("S2ST_NO_ACT_FUSE") && atoi(getenv("S2ST_NO_ACT_FUSE")) != 0);
-  e->use_only_h = !(getenv("S2ST_NO_ONLY_H") && atoi(getenv("S2ST_NO_ONLY_H")) != 0);
-  e->hoist_kv = !(getenv("S2ST_NO_KV_HOIST") && atoi(getenv("S2ST_NO_KV_HOIST")) != 0);
-  e->stall_trace = getenv("S2ST_STALL_TRACE") && atoi(getenv("S2ST_STALL_TRACE")) != 0;
-  if (getenv("S2ST_WGRAD_MAIN_EVERY")) e->wgrad_main_every = atoi(getenv("S2ST_WGRAD_MAIN_EVERY"));
-  e->use_ln_skinny = !(getenv("S2ST_NO_LN_SKINNY") && atoi(getenv("S2ST_NO_LN_SKINNY")) != 0);
-  e->use_skinny = !(getenv("S2ST_NO_SKINNY") && atoi(getenv("S2ST_NO_SKINNY")) != 0);
-  e->skip_resid_h = !(getenv("S2ST_RESID_H") && atoi(getenv("S2ST_RESID_H")) != 0);
-  e->use_ln_fuse = !(getenv("S2ST_NO_LN_FUSE") && atoi(getenv("S2ST_NO_LN_FUSE")) != 0);
-  e->attn_gfuse_mode = getenv("S2ST_ATTN_GFUSE") ? atoi(getenv("S2ST_ATTN_GFUSE")) : 1;
+  e->use_act_fuse = !(s2st_env_on("S2ST_NO_ACT_FUSE"));
+  e->use_only_h = !(s2st_env_on("S2ST_NO_ONLY_H"));
+  e->hoist_kv = !(s2st_env_on("S2ST_NO_KV_HOIST"));
+  e->stall_trace = s2st_env_on("S2ST_STALL_TRACE");
+  e->use_ln_skinny = !(s2st_env_on("S2ST_NO_LN_SKINNY"));
+  e->use_skinny = !(s2st_env_on("S2ST_NO_SKINNY"));
+  e->use_ln_fuse = !(s2st_env_on("S2ST_NO_LN_FUSE"));
+  e->attn_gfuse_mode = s2st_env_int("S2ST_ATTN_GFUSE", 1);
   e->use_attn_gfuse = e->attn_gfuse_mode != 0;
-  e->ln_bwd_split = getenv("S2ST_LN_BWD_SPLIT") && atoi(getenv("S2ST_LN_BWD_SPLIT")) != 0;
-  if (getenv("S2ST_CONV_TAIL_MAIN")) e->conv_tail_on_main = atoi(getenv("S2ST_CONV_TAIL_MAIN")) != 0;
-  e->ordered_sums = !(getenv("S2ST_ORDERED_BIAS_SUMS") && atoi(getenv("S2ST_ORDERED_BIAS_SUMS")) == 0);
+  e->ln_bwd_split = s2st_env_on("S2ST_LN_BWD_SPLIT");
+  e->ordered_sums = !(s2st_env_int("S2ST_ORDERED_BIAS_SUMS", 1) == 0);
   e->build_params();
   // (a process that replays HIP graphs can carry a stale "last error" of the runtime's own capture-time queries: the preload's
   //  launch checks must see their own errors only)
@@ -2425,10 +2396,10 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
   // The second stream is made at the first TRAINING forward (ensure_side), not here: a process has four hardware queues
   // (runtime/streams.py) and an engine that only ever decodes would hold one of them for nothing -- the caller's stream
   // then shares a queue with one of the generator's chains (config 5, profiles/r05_queue_matrix.txt).
-  e->side_allowed = !cfg->precise && !(getenv("S2ST_NO_SIDE_STREAM") && atoi(getenv("S2ST_NO_SIDE_STREAM")));
-  e->overlap_aux = !(getenv("S2ST_NO_AUX_OVERLAP") && atoi(getenv("S2ST_NO_AUX_OVERLAP")) != 0);
+  e->side_allowed = !cfg->precise && !(s2st_env_on("S2ST_NO_SIDE_STREAM"));
+  e->overlap_aux = !(s2st_env_on("S2ST_NO_AUX_OVERLAP"));
   // S2ST_CHAINS=2: the training step's layers as two utterance-half chains (see chain_count)
-  if (!cfg->precise && getenv("S2ST_CHAINS") && atoi(getenv("S2ST_CHAINS")) == 2) {
+  if (!cfg->precise && s2st_env_int("S2ST_CHAINS", 1) == 2) {
     if (hipStreamCreateWithFlags(&e->chain1_, hipStreamNonBlocking) == hipSuccess &&
         hipEventCreateWithFlags(&e->ev_cfork_, hipEventDisableTiming) == hipSuccess &&
         hipEventCreateWithFlags(&e->ev_cjoin_, hipEventDisableTiming) == hipSuccess &&
@@ -2436,7 +2407,6 @@ int s2st_engine_create(const s2st_model_config* cfg, s2st_engine** out) {
       e->nchains = 2;
     else { delete e; return S2ST_ERR_LAUNCH; }  // (asked for and not available: loud)
   }
-  e->chains_one_stream = getenv("S2ST_CHAINS_ONE_STREAM") && atoi(getenv("S2ST_CHAINS_ONE_STREAM")) != 0;
   *out = e;
   return 0;
 }
@@ -2664,24 +2634,12 @@ int s2st_engine_decode_begin(s2st_engine* e, const s2st_batch* b, const s2st_out
       e->chk(s2st_scale_rows(b->pe_dec, e->P + e->pos_alpha, e->dec_st.pe_alpha, ((long)max_steps + 2) * Cd, e->st_));
   }
   // static cross-attention keys / values of every decoder layer (static_kv=True)
-  // S2ST_DECODE_KV_BF16=1 (fast mode, head width 64 / 128): the decode steps' cross-attention reads bf16 copies of the static
-  // rows.  Built for the bandwidth (a step's six launches read every row of the batch), measured slower than the fp32 rows
-  // on the bench batch (csrc/infer.hip: decode_attn_fast_kernel), so off by default.
-  const char* kv_env = getenv("S2ST_DECODE_KV_BF16");  // (per call: the tests run both forms in one process)
-  const bool kv_bf16 = kv_env && kv_env[0] == '1';
-  const int dhd = e->c.dec_dim / e->c.dec_heads;
-  e->dec_st.cross_h = nullptr;
-  if (e->fast() && kv_bf16 && (dhd == 64 || dhd == 128)) {
-    float* tail = e->dec_st.pe_alpha + ((long)max_steps + 2) * e->c.dec_dim;
-    tail += (8 - ((tail - state) & 7)) & 7;  // (16-byte rows for the 8-byte loads)
-    e->dec_st.cross_h = reinterpret_cast<bf16raw*>(tail);
-  }
+  // (bf16 copies of the static rows for the decode steps' cross-attention were built in round 4 and measured SLOWER than the
+  //  fp32 rows -- 15.0 against 13.3 us per launch, profiles/r04_t_decode_attn_bench.txt; the kernel form stays in the C ABI
+  //  (s2st_decode_attn, kv_bf16), the engine switch is gone)
   for (int l = 0; l < e->c.dec_layers; ++l) {
     const XAttnP& xa = e->dec[l].xa;
     e->linear(e->enc_out_keep, xa.kv_w, xa.kv_b, 2 * e->c.dec_dim, e->c.enc_dim, 0, 0.f, nullptr, e->dec_crossKV(l));
-    if (e->dec_st.cross_h && e->live())
-      e->chk(s2st_cast_bf16_rows(e->dec_crossKV(l), 2 * e->c.dec_dim, e->dec_st.cross_h + (long)l * b->B * b->E * 2 * e->c.dec_dim,
-                                 2 * e->c.dec_dim, (long)b->B * b->E, 2 * e->c.dec_dim, e->st_));
   }
   e->tape.clear();
   return e->err;
@@ -2816,6 +2774,85 @@ int s2st_engine_aux_decode(s2st_engine* e, int32_t which, const float* tap, cons
   return e->err;
 }
 
+// ---- the same decoder step by step with key / value caches (include/s2st_hip.h) --------------------------------------------
+namespace {
+bool aux_inc_args_ok(const s2st_engine* e, int which) {
+  return e && which >= 0 && which <= 1 && !((which == 0 && !e->c.has_asr) || (which == 1 && !e->c.has_st));
+}
+void aux_inc_enter(s2st_engine* e, float* workspace, int64_t workspace_floats, void* stream, int Bb, int E) {
+  e->reset_call();
+  e->dry = false;
+  e->ws = workspace;
+  e->ws_cap = workspace_floats;
+  e->st_ = (hipStream_t)stream;
+  e->bt = s2st_batch{};
+  e->bt.B = Bb; e->bt.E = E; e->bt.training = 0;
+  e->skws = nullptr; e->skws_n = 0; e->skws_side = nullptr;
+}
+}  // namespace
+
+int64_t s2st_engine_aux_inc_state_floats(const s2st_engine* e, int32_t which, int32_t Bb, int32_t E, int32_t max_len) {
+  if (!aux_inc_args_ok(e, which) || Bb <= 0 || E <= 0 || max_len <= 0) return S2ST_ERR_ARG;
+  const AuxP& a = which == 0 ? e->asr : e->st;
+  return 2 * s2st_engine::aux_inc_half(a, Bb, max_len) + (long)a.layers * Bb * E * 2 * a.d + 64;
+}
+
+int64_t s2st_engine_aux_inc_workspace(const s2st_engine* e, int32_t which, int32_t Bb, int32_t E) {
+  if (!aux_inc_args_ok(e, which) || Bb <= 0 || E <= 0) return S2ST_ERR_ARG;
+  const AuxP& a = which == 0 ? e->asr : e->st;
+  // begin: bf16 copies of the tap and of every layer's K | V projection; a step: a few dozen [Bb][width] tensors
+  long w = a.in_dim;
+  for (long v : {(long)3 * a.d, (long)e->c.dec_ffn, (long)a.V, (long)a.out_dim, (long)e->c.enc_dim}) w = v > w ? v : w;
+  return (long)Bb * E * (e->c.enc_dim + 2L * a.layers * a.d) + 96L * Bb * w + (1L << 20);
+}
+
+int s2st_engine_aux_inc_begin(s2st_engine* e, int32_t which, const float* tap, const int32_t* enc_lens, int32_t Bb, int32_t E,
+                              int32_t max_len, float* state, float* workspace, int64_t workspace_floats, void* stream) {
+  if (!aux_inc_args_ok(e, which) || !e->P || !tap || !enc_lens || !state) return S2ST_ERR_ARG;
+  if (Bb <= 0 || E <= 0 || max_len <= 0) return S2ST_ERR_SHAPE;
+  if (!workspace) return S2ST_ERR_WORKSPACE;
+  aux_inc_enter(e, workspace, workspace_floats, stream, Bb, E);
+  e->bt.enc_lens = enc_lens;
+  if (e->fast()) {
+    if (!e->PH) return S2ST_ERR_ARG;
+    int rc = s2st_cast_bf16_rows(e->P, e->n_params, e->PH, e->n_params, 1, (int)e->n_params, e->st_);
+    if (rc) return rc;
+  }
+  hipStream_t keep_side = e->side_;
+  e->side_ = nullptr;  // forward only, one stream
+  s2st_engine::AuxInc& S = e->aux_inc[which];
+  S = s2st_engine::AuxInc{};
+  S.base = state; S.Bb = Bb; S.E = E; S.maxT = max_len; S.enc_lens = enc_lens;
+  Ten* t = e->newT(Bb * E, e->c.enc_dim, const_cast<float*>(tap));
+  t->needs_grad = false;
+  const int rc = e->aux_inc_begin(which == 0 ? e->asr : e->st, S, t);
+  e->side_ = keep_side;
+  e->tape.clear();
+  return rc;
+}
+
+int s2st_engine_aux_inc_step(s2st_engine* e, int32_t which, int32_t step, const int64_t* tokens, const int32_t* reorder,
+                             const int32_t* positions, const float* pe, float* logits_out, float* workspace,
+                             int64_t workspace_floats, void* stream) {
+  if (!aux_inc_args_ok(e, which) || !e->P || !tokens || !positions || !pe || !logits_out) return S2ST_ERR_ARG;
+  if (!workspace) return S2ST_ERR_WORKSPACE;
+  s2st_engine::AuxInc keep = e->aux_inc[which];
+  if (!keep.base) return S2ST_ERR_ARG;
+  s2st_engine::AuxInc keep_other = e->aux_inc[1 - which];
+  aux_inc_enter(e, workspace, workspace_floats, stream, keep.Bb, keep.E);
+  e->aux_inc[which] = keep;
+  e->aux_inc[1 - which] = keep_other;
+  e->bt.enc_lens = keep.enc_lens;
+  if (e->fast() && !e->PH) return S2ST_ERR_ARG;  // (PH was refreshed by aux_inc_begin)
+  hipStream_t keep_side = e->side_;
+  e->side_ = nullptr;
+  const int rc = e->aux_inc_step(which == 0 ? e->asr : e->st, e->aux_inc[which], step, (const long*)tokens, reorder, positions, pe,
+                                 logits_out);
+  e->side_ = keep_side;
+  e->tape.clear();
+  return rc;
+}
+
 int64_t s2st_engine_aux_decode_workspace(s2st_engine* e, int32_t which, int32_t Bb, int32_t L, int32_t E) {
   if (!e || which < 0 || which > 1 || (which == 0 && !e->c.has_asr) || (which == 1 && !e->c.has_st)) return S2ST_ERR_ARG;
   e->reset_call();
@@ -2858,8 +2895,8 @@ int s2st_hubert_create(const s2st_hubert_config* cfg, s2st_engine** out) {
   e->c.enc_heads = cfg->heads;
   e->c.enc_dim = cfg->embed;
   e->ffn_act = 2;
-  e->f32_operands = getenv("S2ST_F32_OPERANDS") && atoi(getenv("S2ST_F32_OPERANDS")) != 0;
-  e->use_flash = !(getenv("S2ST_NO_FLASH") && atoi(getenv("S2ST_NO_FLASH")) != 0);
+  e->f32_operands = s2st_env_on("S2ST_F32_OPERANDS");
+  e->use_flash = !(s2st_env_on("S2ST_NO_FLASH"));
   e->build_params_hubert();
   // (a process that replays HIP graphs can carry a stale "last error" of the runtime's own capture-time queries: the preload's
   //  launch checks must see their own errors only)

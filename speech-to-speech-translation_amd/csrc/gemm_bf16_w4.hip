@@ -192,10 +192,8 @@ int s2st_gemm_bf16_w4(const GemmArgs& g, int bm, int bn, dim3 grid, hipStream_t 
   const double fl = w4_flops(g), by = w4_min_bytes(g);
   if (bm == 128 && bn == 128) return launch_w4<128, 128, 2, false>(g, akm, bkm, grid, fl, by, st);
   if (bm == 128 && bn == 64) {
-    // S2ST_W4_NS64 (tuning aid, read per call): ring slots of the 128 x 64 form -- 2 (default): 48 KB, three workgroups
-    // per CU (what w4_pick's slot count assumes; 4584 x 2048 x 512: 18.3 us); 3: 72 KB, two per CU (22.0 us)
-    const char* ev = getenv("S2ST_W4_NS64");
-    if (ev && atoi(ev) == 3) return launch_w4<128, 64, 3, false>(g, akm, bkm, grid, fl, by, st);
+    // two ring slots: 48 KB, three workgroups per CU (what w4_pick's slot count assumes; 4584 x 2048 x 512: 18.3 us against
+    // 22.0 us with three slots = two workgroups per CU, measured in round 3)
     return launch_w4<128, 64, 2, false>(g, akm, bkm, grid, fl, by, st);
   }
   return S2ST_ERR_ARG;
@@ -217,7 +215,6 @@ int s2st_gemm_bf16_w4_preload(hipStream_t st) {
     g.A.kmajor = lay & 1; g.B.kmajor = (lay >> 1) & 1;
     rc |= s2st_gemm_bf16_w4(g, 128, 128, dim3(1), st);
     rc |= launch_w4<128, 64, 2, false>(g, g.A.kmajor != 0, g.B.kmajor != 0, dim3(1), 0.0, 0.0, st);
-    rc |= launch_w4<128, 64, 3, false>(g, g.A.kmajor != 0, g.B.kmajor != 0, dim3(1), 0.0, 0.0, st);
     GemmGroup grp{};
     grp.n = 1; grp.g[0] = g; grp.total = 0;
     rc |= s2st_gemm_bf16_w4_group(grp, st);

@@ -961,6 +961,26 @@ __global__ __launch_bounds__(256) void gl_overlap_add_kernel(const float* __rest
 
 }  // namespace
 
+// fairseq's reorder_incremental_state for the cached keys / values of a beam search (sequence_generator.py:393-400,
+// multihead_attention.py:387-403): dst[n][b][0 : valid) = src[n][idx[b]][0 : valid) for the nb (layer, K | V) arrays.
+namespace {
+__global__ __launch_bounds__(256) void cache_reorder_kernel(const float4* __restrict__ src, float4* __restrict__ dst,
+                                                            const int* __restrict__ idx, int Bb, long row4, long valid4) {
+  const int b = blockIdx.x, n = blockIdx.y;
+  const float4* s = src + ((long)n * Bb + idx[b]) * row4;
+  float4* d = dst + ((long)n * Bb + b) * row4;
+  for (long i = threadIdx.x; i < valid4; i += 256) d[i] = s[i];
+}
+}  // namespace
+int s2st_cache_reorder(const float* src, float* dst, const int* idx, int nb, int Bb, long row_floats, long valid_floats,
+                       hipStream_t st) {
+  if (nb <= 0 || Bb <= 0 || valid_floats <= 0) return 0;
+  if (row_floats % 4 || valid_floats % 4 || ((uintptr_t)src % 16) || ((uintptr_t)dst % 16) || !idx) return S2ST_ERR_ARG;
+  S2ST_LAUNCH(cache_reorder_kernel, dim3(Bb, nb), dim3(256), 0, st, reinterpret_cast<const float4*>(src),
+              reinterpret_cast<float4*>(dst), idx, Bb, row_floats / 4, valid_floats / 4);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+
 int s2st_decode_attn(const float* q, long ldq, float* kc, float* vc, long ldk, long kbs, const int* klen,
                      int nkeys, int B, int H, int dh, float scale, float* o, long ldo, float* attn_mean, int S,
                      hipStream_t st, const float* k_new, const float* v_new, long ld_new, int pos_new, int kv_bf16,
@@ -971,17 +991,10 @@ int s2st_decode_attn(const float* q, long ldq, float* kc, float* vc, long ldk, l
   if (kv_bf16 && (k_new || (dh != 64 && dh != 128) || ldk % 4)) return S2ST_ERR_ARG;  // (bf16 caches: static rows only)
   if (nkeys < 1) return S2ST_ERR_ARG;
   if (attn_mean) hipMemsetAsync(attn_mean, 0, sizeof(float) * (size_t)B * S, st);
-  static const bool old_form = [] {
-    const char* e = getenv("S2ST_DECODE_ATTN_V1");  // A/B switch: the first form of the kernel
-    return e && e[0] == '1';
-  }();
-  const bool fast_ok = (dh == 64 || dh == 128) && ldk % 4 == 0 && ldq % 4 == 0 && (!k_new || ld_new % 4 == 0) &&
-                       (!old_form || kv_bf16);
+  // (round 4's A/B forms are closed and gone: the two-pass first kernel stays only as the fallback for head widths other
+  //  than 64 / 128; 64 key groups per workgroup measured 16.3 against 13.3 us on the bench batch, profiles/r04_t_decode_attn_bench.txt)
+  const bool fast_ok = (dh == 64 || dh == 128) && ldk % 4 == 0 && ldq % 4 == 0 && (!k_new || ld_new % 4 == 0);
   if (kv_bf16 && !fast_ok) return S2ST_ERR_ARG;
-  // S2ST_DECODE_ATTN_NT=1024: 64 key groups per workgroup (an experiment kept for small batches)
-  const char* nt_e = getenv("S2ST_DECODE_ATTN_NT");  // (read per call: the tests run both forms in one process)
-  const int nt_env = nt_e ? atoi(nt_e) : 0;
-  const bool big = nt_env == 1024;  // (measured slower at B * H = 256: 9.3 us against 5.8 us for one key, 16.3 against 13.3 for the bench batch)
 #define S2ST_DA_LAUNCH(KT_, ND_, NT_, kp, vp)                                                                               \
   S2ST_LAUNCH((decode_attn_fast_kernel<KT_, ND_, NT_>), dim3(B * H), dim3(NT_), 0, st, q, ldq, kp, vp, ldk, kbs, klen, nkeys, H, \
               scale, o, ldo, attn_mean, S, k_new, v_new, ld_new, pos_new, step_ptr)
@@ -991,21 +1004,11 @@ int s2st_decode_attn(const float* q, long ldq, float* kc, float* vc, long ldk, l
   } else if (kv_bf16) {
     bf16raw* kh = reinterpret_cast<bf16raw*>(kc);
     bf16raw* vh = reinterpret_cast<bf16raw*>(vc);
-    if (dh == 64) {
-      if (big) S2ST_DA_LAUNCH(bf16raw, 1, 1024, kh, vh);
-      else S2ST_DA_LAUNCH(bf16raw, 1, 256, kh, vh);
-    } else {
-      if (big) S2ST_DA_LAUNCH(bf16raw, 2, 1024, kh, vh);
-      else S2ST_DA_LAUNCH(bf16raw, 2, 256, kh, vh);
-    }
+    if (dh == 64) S2ST_DA_LAUNCH(bf16raw, 1, 256, kh, vh);
+    else S2ST_DA_LAUNCH(bf16raw, 2, 256, kh, vh);
   } else {
-    if (dh == 64) {
-      if (big) S2ST_DA_LAUNCH(float, 1, 1024, kc, vc);
-      else S2ST_DA_LAUNCH(float, 1, 256, kc, vc);
-    } else {
-      if (big) S2ST_DA_LAUNCH(float, 2, 1024, kc, vc);
-      else S2ST_DA_LAUNCH(float, 2, 256, kc, vc);
-    }
+    if (dh == 64) S2ST_DA_LAUNCH(float, 1, 256, kc, vc);
+    else S2ST_DA_LAUNCH(float, 2, 256, kc, vc);
   }
 #undef S2ST_DA_LAUNCH
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
@@ -1307,7 +1310,7 @@ int gl_istft_ola_launch(const float* X, const int* tl, const float* win, const f
   // R frames per workgroup: about three workgroups per CU over the batch (S2ST_GL_OLA_FRAMES overrides), at least 16 so that
   // the ceil(N / hop) frames recomputed in front of each block stay a small share
   static const int r_env = [] {
-    const char* e = getenv("S2ST_GL_OLA_FRAMES");
+    const char* e = s2st_env_str("S2ST_GL_OLA_FRAMES");
     return e ? atoi(e) : 0;
   }();
   int R = r_env > 0 ? r_env : (int)(((long)U * Tmax + 3 * 256 - 1) / (3 * 256));  // (256 CUs)

@@ -153,6 +153,47 @@ __global__ __launch_bounds__(256) void grad_unpack_bf16_kernel(const uint16_t* _
 }
 }  // namespace
 
+// ---- 8-GPU pricing on ONE GPU: a stand-in for the collective's kernels --------------------------------
+// A ring all-reduce over N ranks moves 2 (N - 1) / N of a bucket's bytes in and out of every GPU, through a handful of
+// workgroups (RCCL's channels) that sit on CUs beside the backward and read / write HBM at the links' pace.  This kernel is
+// that neighbour and nothing else: `wgs` workgroups read `move_bytes` from the bucket (cyclically) and write them to a
+// scratch range, paced to `gbps` by the constant-frequency wall clock (each workgroup may move its share of the bytes no
+// faster than gbps / wgs).  It changes no gradient.  bench.py --exchange-proxy launches it per bucket on the
+// gradient-exchange stream behind both engine streams, where the real collective would go.
+namespace {
+__global__ __launch_bounds__(256) void exchange_proxy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long n4,
+                                                             long move4, double ticks_per_chunk) {
+  // this workgroup's chunks: chunk c = 1024 float4 (16 KB); chunks are dealt round-robin to the workgroups
+  const long nchunks = (move4 + 1023) / 1024;
+  const unsigned long long t0 = wall_clock64();
+  long done = 0;
+  for (long c = blockIdx.x; c < nchunks; c += gridDim.x, ++done) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long i = c * 1024 + q * 256 + threadIdx.x;
+      if (i < move4) {
+        const long j = i % n4;
+        dst[j] = src[j];
+      }
+    }
+    // pace: chunk number `done + 1` of this workgroup must not finish before its share of the wire time has passed
+    const unsigned long long due = t0 + (unsigned long long)((double)(done + 1) * ticks_per_chunk);
+    while (wall_clock64() < due) __builtin_amdgcn_s_sleep(8);
+  }
+}
+}  // namespace
+
+int s2st_exchange_proxy(const float* bucket, float* scratch, long n, long move_bytes, int wgs, float gbps, hipStream_t st) {
+  if (n < 4 || move_bytes <= 0 || wgs <= 0) return 0;
+  if (((uintptr_t)bucket % 16) || ((uintptr_t)scratch % 16) || gbps <= 0.f) return S2ST_ERR_ARG;
+  const long n4 = n / 4, move4 = move_bytes / 16;
+  // wall_clock64 ticks at 100 MHz on gfx9: a workgroup's 16 KB chunk is due every 16384 * wgs / (gbps * 1e9) s
+  const double ticks_per_chunk = 16384.0 * wgs / ((double)gbps * 1e9) * 100e6;
+  S2ST_LAUNCH(exchange_proxy_kernel, dim3((unsigned)wgs), dim3(256), 0, st, reinterpret_cast<const float4*>(bucket),
+              reinterpret_cast<float4*>(scratch), n4, move4, ticks_per_chunk);
+  return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
+}
+
 int s2st_grad_pack_bf16(const float* g, uint16_t* out, long n, hipStream_t st) {
   if (n <= 0) return 0;
   if (((uintptr_t)g % 16) || ((uintptr_t)out % 8)) return S2ST_ERR_ARG;

@@ -573,12 +573,8 @@ static int ln_split_blocks(int rows) {
   return b < 1 ? 1 : b;
 }
 // fused form: 4 waves x RPW rows per block; RPW = 4 while a lane holds <= 2 float4 per row (cols <= 512), else 2
-// (S2ST_LN_RPW=2, tuning aid: 2 rows per wave also for narrow rows -- twice the blocks and partial rows)
-static int ln_rpw(int cols) {
-  static const int ev = getenv("S2ST_LN_RPW") ? atoi(getenv("S2ST_LN_RPW")) : 4;
-  if (ev == 1) return 1;
-  return (cols <= 512 && ev != 2) ? 4 : 2;
-}
+// (1 / 2 / 4 rows per wave measured within noise in round 3: the tuning switch is gone)
+static int ln_rpw(int cols) { return cols <= 512 ? 4 : 2; }
 static int ln_fused_rows_per_block(int cols) { return 4 * ln_rpw(cols); }
 static int ln_fused_blocks(int rows, int cols) {
   const int rpb = ln_fused_rows_per_block(cols);

@@ -2,6 +2,13 @@
 // include/s2st_hip.h wraps these).  All launchers are stateless, stream-ordered, take
 // caller-owned device buffers and return 0 or a negative error code (no exceptions).
 #pragma once
+#include <cstdlib>
+// The library's ONE reader of the process environment: every switch of DESIGN.md section 4's table goes through these three
+// (so that `grep getenv csrc/` finds this place and nothing else, and a switch cannot be read in two spellings).
+static inline const char* s2st_env_str(const char* name) { return getenv(name); }
+static inline int s2st_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static inline bool s2st_env_on(const char* name) { return s2st_env_int(name, 0) != 0; }
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "s2st_common.h"
@@ -157,6 +164,7 @@ int s2st_attn_headmean(const float* p, float* out, int B, int H, int T, int S, i
 int s2st_cast_bf16_rows(const float* x, long ldx, uint16_t* y, long ldy, long rows, int cols, hipStream_t st);
 // bf16 gradient exchange (optim.hip): round a range of the gradient arena to bf16 / widen the reduced values back
 int s2st_grad_pack_bf16(const float* g, uint16_t* out, long n, hipStream_t st);
+int s2st_exchange_proxy(const float* bucket, float* scratch, long n, long move_bytes, int wgs, float gbps, hipStream_t st);
 int s2st_grad_unpack_bf16(const uint16_t* in, float* g, long n, hipStream_t st);
 int s2st_transpose_bf16(const uint16_t* x, uint16_t* y, int R, int C, hipStream_t st);  // [R][C] -> [C][R]
 // every registered matrix [rows][cols] at element offset off of x_base -> its transpose at the same offset of y_base,
@@ -285,6 +293,7 @@ int s2st_decode_attn(const float* q, long ldq, float* kc, float* vc, long ldk, l
                      int pos_new = 0, int kv_bf16 = 0,  // kv_bf16: kc / vc point at bf16 rows (ldk, kbs in elements)
                      const int* step_ptr = nullptr);  // replayable decode step: nkeys = *step_ptr + 1, pos_new = *step_ptr (nkeys: the bound)
 int s2st_scale_rows(const float* x, const float* a, float* y, long n, hipStream_t st);
+int s2st_cache_reorder(const float* src, float* dst, const int* idx, int nb, int Bb, long row_floats, long valid_floats, hipStream_t st);
 int s2st_decode_stop_update(const float* eos_prob, float thr, int step, int max_iter, int B, int* finished, int* out_lens,
                             int* klen_next, int* n_done, hipStream_t st);
 // replayable decode step (engine.cpp decode_step replay mode): state for step 0; stop rule + output rows + next step's state

@@ -110,6 +110,16 @@ class GradReducer:
         self.measure_exposed = False
         self._exposed_events: List = []
         self.last_buckets: List[Tuple[int, int]] = []
+        # S2ST_EXCHANGE_PROXY="<workgroups>,<ranks>,<GB/s>" on ONE GPU (bench.py --exchange-proxy): no collective, but every
+        # bucket launches the library's stand-in for the collective's kernels where the all-reduce would go -- that many
+        # workgroups reading + writing the 2 (N - 1) / N share of the bucket at the given pace (s2st_exchange_proxy_f32) --
+        # so that a single GPU can price what RCCL's kernels beside the backward cost the step
+        self.proxy = None
+        spec = os.environ.get("S2ST_EXCHANGE_PROXY")
+        if spec and self.cuda and not dist.is_initialized():
+            w, n, g = spec.split(",")
+            self.proxy = (int(w), int(n), float(g))
+            self._proxy_scratch = None
 
     def _launch(self, lo: int, hi: int):
         if hi <= lo:
@@ -123,7 +133,15 @@ class GradReducer:
             if self.extra_stream is not None:
                 self.stream.wait_stream(self.extra_stream)
             with torch.cuda.stream(self.stream):
-                if self.exchange_dtype == "bf16":
+                if self.proxy is not None:
+                    from . import binding as bd
+                    wgs, nranks, gbps = self.proxy
+                    if self._proxy_scratch is None or self._proxy_scratch.numel() < view.numel():
+                        self._proxy_scratch = torch.empty(max(view.numel(), self.min_bucket), dtype=torch.float32, device=view.device)
+                    esz = 2 if self.exchange_dtype == "bf16" else 4
+                    move = int(2 * (nranks - 1) / nranks * view.numel() * esz)
+                    bd.call("s2st_exchange_proxy_f32", view, self._proxy_scratch, view.numel(), move, wgs, gbps)
+                elif self.exchange_dtype == "bf16":
                     self._exchange_bf16(view)
                 elif self.staged:
                     if self._pin is None or self._pin.numel() < view.numel():
@@ -179,7 +197,7 @@ class GradReducer:
     def on_segment(self, i: int, lo: int, hi: int):
         """Engine callback: gradients in [lo, hi) are final.  Ranges arrive back-to-front and
         are coalesced until they reach ``min_bucket``."""
-        if not is_dist():
+        if not is_dist() and self.proxy is None:
             return
         if self.pending is None:
             self.pending = (lo, hi)
@@ -193,7 +211,7 @@ class GradReducer:
 
     def finish(self):
         """Flush the tail bucket and make the reduced gradients visible to the compute stream."""
-        if not is_dist():
+        if not is_dist() and self.proxy is None:
             return
         if self.pending is not None:
             self._launch(*self.pending)

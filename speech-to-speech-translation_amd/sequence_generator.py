@@ -7,7 +7,11 @@ Counterpart of what ``fairseq_cli/generate_for_s2st.py:107-111, 178-219`` runs: 
 attention over the head's encoder tap, output projection) and the log-softmax run in libs2st_hip.so
 (``s2st_engine_aux_decode``, ``s2st_log_softmax_rows_f32``); the search itself -- top-2k candidates, EOS bookkeeping,
 finalisation, length normalisation -- is host-side integer / index work on small arrays, as in the reference, here in
-numpy.  The decoder is re-run on the whole prefix each step (prefixes are tens of tokens; no incremental state).
+numpy.  Round 6: the decoder runs INCREMENTALLY like the reference's (``incremental_state`` + ``reorder_incremental_state``,
+fairseq/sequence_generator.py:330-400): ``s2st_engine_aux_inc_begin`` projects the encoder tap to every layer's static keys /
+values once, ``s2st_engine_aux_inc_step`` embeds the hypotheses' last tokens, appends their key / value rows to the caches and
+attends over them, and the surviving beams' indices reorder the caches on the device -- a hypothesis costs O(L) per step.
+``incremental=False`` keeps rounds 2 - 5's form (the decoder re-run on the whole prefix each step): the reference result either way.
 """
 from __future__ import annotations
 
@@ -25,12 +29,13 @@ from .runtime.engine import PAD
 class AuxSequenceGenerator:
     def __init__(self, model, tgt_dict, which: str = "st", beam_size: int = 5, max_len_a: float = 0.0, max_len_b: int = 200,
                  max_len: int = 0, min_len: int = 1, normalize_scores: bool = True, len_penalty: float = 1.0,
-                 unk_penalty: float = 0.0, temperature: float = 1.0, **unused):
+                 unk_penalty: float = 0.0, temperature: float = 1.0, incremental: bool = True, **unused):
         if which not in ("asr", "st"):
             raise ValueError("which must be 'asr' or 'st'")
         if temperature != 1.0:
             raise NotImplementedError("temperature != 1")
         self.model, self.which, self.tgt_dict = model, which, tgt_dict
+        self.incremental = bool(incremental)
         self.pad, self.unk, self.eos = tgt_dict.pad(), tgt_dict.unk(), tgt_dict.eos()
         self.vocab_size = len(tgt_dict)
         self.beam_size = min(beam_size, self.vocab_size - 1)
@@ -73,6 +78,46 @@ class AuxSequenceGenerator:
         bd.call("s2st_log_softmax_rows_f32", last, V, lp, V, Bb, V, 1)  # get_normalized_probs(log_probs=True)
         return lp.cpu().numpy()
 
+    # -- the incremental form: caches live in a device buffer owned here for the length of one generate() ----------------
+    def _inc_begin(self, tap, enc_lens_dev, E: int, max_len: int):
+        eng, dev = self.model.engine, self.model.engine.device
+        lib = eng.lib
+        w = 0 if self.which == "asr" else 1
+        Bb = tap.shape[0]
+        lib.s2st_engine_aux_inc_state_floats.argtypes = [C.c_void_p] + [C.c_int32] * 4
+        lib.s2st_engine_aux_inc_state_floats.restype = C.c_int64
+        lib.s2st_engine_aux_inc_workspace.argtypes = [C.c_void_p] + [C.c_int32] * 3
+        lib.s2st_engine_aux_inc_workspace.restype = C.c_int64
+        lib.s2st_engine_aux_inc_begin.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 3 + \
+            [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        lib.s2st_engine_aux_inc_step.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 6 + [C.c_int64, C.c_void_p]
+        n = int(lib.s2st_engine_aux_inc_state_floats(eng.h, w, Bb, E, max_len + 2))
+        need = int(lib.s2st_engine_aux_inc_workspace(eng.h, w, Bb, E))
+        if n < 0 or need < 0:
+            raise bd.S2STHipError(f"s2st_engine_aux_inc_state_floats / _workspace failed ({n}, {need})")
+        if eng.workspace is None or eng.workspace.numel() < need:
+            eng.workspace = torch.empty(int(need * 1.25) + 4096, dtype=torch.float32, device=dev)
+        state = torch.zeros(n, dtype=torch.float32, device=dev)
+        bd.check(lib.s2st_engine_aux_inc_begin(eng.h, w, tap.data_ptr(), enc_lens_dev.data_ptr(), Bb, E, max_len + 2,
+                                               state.data_ptr(), eng.workspace.data_ptr(), eng.workspace.numel(), bd.stream_ptr()),
+                 "s2st_engine_aux_inc_begin")
+        d = eng.cfg.asr_dim if self.which == "asr" else eng.cfg.st_dim
+        return {"state": state, "Bb": Bb, "pe": eng.pe(d, max_len + 4), "w": w,
+                "logits": torch.empty(Bb, self.vocab_size, dtype=torch.float32, device=dev),
+                "lp": torch.empty(Bb, self.vocab_size, dtype=torch.float32, device=dev)}
+
+    def _inc_step_lprobs(self, inc, step: int, last_tokens: np.ndarray, reorder) -> np.ndarray:
+        eng, dev = self.model.engine, self.model.engine.device
+        Bb, V = inc["Bb"], self.vocab_size
+        tok = torch.from_numpy(np.ascontiguousarray(last_tokens, dtype=np.int64)).to(dev)
+        pos = torch.full((Bb,), step + PAD + 1, dtype=torch.int32, device=dev)  # make_positions: no padding inside a prefix
+        ro = None if reorder is None else torch.from_numpy(np.ascontiguousarray(reorder, dtype=np.int32)).to(dev)
+        bd.check(eng.lib.s2st_engine_aux_inc_step(eng.h, inc["w"], step, tok.data_ptr(), bd.ptr(ro), pos.data_ptr(),
+                                                  inc["pe"].data_ptr(), inc["logits"].data_ptr(), eng.workspace.data_ptr(),
+                                                  eng.workspace.numel(), bd.stream_ptr()), "s2st_engine_aux_inc_step")
+        bd.call("s2st_log_softmax_rows_f32", inc["logits"], V, inc["lp"], V, Bb, V, 1)  # get_normalized_probs(log_probs=True)
+        return inc["lp"].cpu().numpy()
+
     @torch.no_grad()
     def generate(self, models, sample: Dict, **kwargs) -> List[List[Dict]]:
         model = models[0] if isinstance(models, (list, tuple)) else models
@@ -111,8 +156,13 @@ class AuxSequenceGenerator:
         bbsz_offsets = (np.arange(bsz) * beam)[:, None]
         cand_offsets = np.arange(cand_size)
         V = self.vocab_size
+        inc = self._inc_begin(tap_b, lens_b, E, max_len) if self.incremental else None
+        reorder = None  # (the beams step s + 1 continues: fairseq's reorder_state, sequence_generator.py:393-400)
         for step in range(max_len + 1):
-            lprobs = self._step_lprobs(tap_b, lens_b, tokens[:, :step + 1], E)
+            if inc is not None:
+                lprobs = self._inc_step_lprobs(inc, step, tokens[:, step], reorder)
+            else:
+                lprobs = self._step_lprobs(tap_b, lens_b, tokens[:, :step + 1], E)
             if step < self.min_len:
                 lprobs[:, self.eos] = ninf
             lprobs[lprobs != lprobs] = ninf
@@ -158,6 +208,7 @@ class AuxSequenceGenerator:
             new_ignore = np.take_along_axis(active_mask, active_hypos, axis=1)
             cands_to_ignore = new_ignore >= cand_size
             active_bbsz_idx = np.take_along_axis(cand_bbsz_idx, active_hypos, axis=1).reshape(-1)
+            reorder = active_bbsz_idx
             tokens[:, :step + 1] = tokens[active_bbsz_idx, :step + 1]
             tokens.reshape(bsz, beam, -1)[:, :, step + 1] = np.take_along_axis(cand_indices, active_hypos, axis=1)
             if step > 0:

@@ -14,6 +14,7 @@ host sync per step.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -56,7 +57,8 @@ class Trainer:
         self.seed = getattr(args, "seed", 1)
         self._dummy_batch = None
         self.reducer = GradReducer(self.engine.grads, extra_stream=self.engine.side_stream(),
-                                   exchange_dtype=str(getattr(args, "grad_exchange_dtype", "fp32") or "fp32")) if is_dist() else None
+                                   exchange_dtype=str(getattr(args, "grad_exchange_dtype", "fp32") or "fp32")) \
+            if (is_dist() or (os.environ.get("S2ST_EXCHANGE_PROXY") and dev.type == "cuda")) else None
         if is_dist():
             # DDP's constructor broadcast of parameters and buffers from rank 0
             broadcast_(self.engine.params, 0)

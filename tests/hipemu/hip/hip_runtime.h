@@ -172,6 +172,7 @@ static inline void emu_global_load_lds(const void* g, void* l, unsigned size, in
 }
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_global_load_lds((const void*)(g), (void*)(l), size, off, aux)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+static inline unsigned long long wall_clock64() { static thread_local unsigned long long t = 0; return t += 1ull << 40; }  // (every call is "much later": pacing loops end at once on the emulator)
 #define __builtin_amdgcn_s_sleep(x) emu_sleep_us(20)  // (a workgroup waiting for another one: emulated blocks are ~1000x slower)
 #include <unistd.h>
 static inline void emu_sleep_us(int us) { usleep(us); }
@@ -224,6 +225,7 @@ static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; 
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 enum { hipDeviceAttributeMultiprocessorCount = 63 };
 static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 8; return hipSuccess; }  // 8 'CUs': persistent kernels walk several tiles, stream-K has one workgroup per 'XCD'
 using std::min;

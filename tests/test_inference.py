@@ -667,17 +667,12 @@ def _bf16_round(x: np.ndarray) -> np.ndarray:
     return u.astype(np.uint32).view(np.float32)
 
 
-@pytest.mark.parametrize("nt", [1024, 256])
 @pytest.mark.parametrize("dh,H,kv_bf16", [(64, 2, 0), (128, 2, 0), (64, 3, 1), (128, 1, 1), (32, 4, 0)])
-def test_decode_attention_kernels(backend, monkeypatch, dh, H, kv_bf16, nt):
+def test_decode_attention_kernels(backend, monkeypatch, dh, H, kv_bf16):
     """One decoding step's attention (multihead_attention.py:194-385, incremental path) through the C ABI against its plain
     float64 restatement: ragged key lengths (one key, a length inside a pass, several passes), the step's own key / value row
     appended by the kernel, the head-averaged weights of the alignment layer; head widths 64 / 128 take the running-softmax
-    kernel (fp32 rows, and bf16 rows as the fast mode's static cross-attention uses them; 64 or 16 key groups per workgroup),
-    other widths the first form."""
-    if dh == 32 and nt == 256:
-        pytest.skip("one form only")
-    monkeypatch.setenv("S2ST_DECODE_ATTN_NT", str(nt))
+    kernel (fp32 rows, and bf16 rows -- a form of the C ABI the engine no longer selects), other widths the first form."""
     rs = np.random.RandomState(dh + H + kv_bf16)
     B, S = 5, 300
     C = H * dh

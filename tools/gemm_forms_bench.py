@@ -17,8 +17,7 @@ FORMS = [  # name, environment
     ("r8 128x64", {"S2ST_GEMM_TILE": "128x64"}),
     ("r8 64x64", {"S2ST_GEMM_TILE": "64x64"}),
     ("w4 128x128", {"S2ST_GEMM_W4": "1", "S2ST_GEMM_TILE": "128x128"}),
-    ("w4 128x64/3", {"S2ST_GEMM_W4": "1", "S2ST_GEMM_TILE": "128x64", "S2ST_W4_NS64": "3"}),
-    ("w4 128x64/2", {"S2ST_GEMM_W4": "1", "S2ST_GEMM_TILE": "128x64", "S2ST_W4_NS64": "2"}),
+    ("w4 128x64", {"S2ST_GEMM_W4": "1", "S2ST_GEMM_TILE": "128x64"}),
 ]
 KEYS = sorted({k for _, e in FORMS for k in e})
 NSETS = 8

@@ -10,7 +10,7 @@ _lib = bd.lib()
 _lib.s2st_profile_enable.argtypes = [C.c_int32]
 _lib.s2st_profile_report.argtypes = [C.c_char_p, C.c_int64]
 _lib.s2st_profile_report.restype = C.c_int64
-FORMS = [("auto", {}), ("W4 128x64", {"S2ST_GEMM_P4": "0", "S2ST_W4_E64": "100"}), ("W4 128x128", {"S2ST_GEMM_P4": "0", "S2ST_W4_E64": "0.01"}),
+FORMS = [("auto", {}), ("W4 128x64", {"S2ST_GEMM_P4": "0", "S2ST_GEMM_W4": "1", "S2ST_GEMM_TILE": "128x64"}), ("W4 128x128", {"S2ST_GEMM_P4": "0", "S2ST_GEMM_W4": "1", "S2ST_GEMM_TILE": "128x128"}),
          ("ring", {"S2ST_GEMM_P4": "0", "S2ST_GEMM_W4": "0"}), ("P4 forced", {"S2ST_GEMM_TILE": "256x256"})]
 KEYS = sorted({k for _, e in FORMS for k in e})
 

@@ -1,5 +1,5 @@
 """Isolated timing of the layer-norm backward row kernel (per-dispatch events) for the rows-per-wave variants, against a
-plain device copy of the same bytes.   usage: python tools/ln_bwd_bench.py   (spawns one child per S2ST_LN_RPW value)"""
+plain device copy of the same bytes.   usage: python tools/ln_bwd_bench.py   (round 3 compared 1 / 2 / 4 rows per wave through S2ST_LN_RPW: within noise, the switch is gone)"""
 import ctypes as C, importlib, os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
@@ -40,7 +40,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         for _ in range(50):
             b.add_(a[: rows * cols]).add_(a[rows * cols: 2 * rows * cols])
         e1.record(); torch.cuda.synchronize()
-        print("rows %d RPW %s: %s | two torch add_ passes %.2f us" % (rows, os.environ.get("S2ST_LN_RPW", "default"), "; ".join(out), e0.elapsed_time(e1) * 1000 / 50))
+        print("rows %d RPW %s: %s | two torch add_ passes %.2f us" % (rows, "by width", "; ".join(out), e0.elapsed_time(e1) * 1000 / 50))
     sys.exit(0)
-for rpw in ("1", "2", "4"):
-    subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, S2ST_LN_RPW=rpw))
+subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ))  # (rows per wave: fixed by width since round 6)
