@@ -456,6 +456,11 @@ int64_t s2st_engine_decode_state_floats(const s2st_engine* e, int32_t B, int32_t
 int s2st_engine_decode_begin(s2st_engine* e, const s2st_batch* b, const s2st_outputs* out, float* state,
                              int64_t state_floats, int32_t max_steps, float* workspace,
                              int64_t workspace_floats, void* stream);
+/* several batches decoded as ONE merged batch (round 6): row_map [B] (device int32) = for every row of the merged batch the
+ * row of its OWN batch -- the always-on Prenet dropout (tacotron2.py:95-98) keys its mask by (seed, row, column), so the merged
+ * run draws for every utterance the mask its own batch would have drawn (speech_generator_for_s2st.py:83-103 run batch after
+ * batch).  Call after decode_begin (which clears it); NULL: rows count from 0. */
+int s2st_engine_decode_row_map(s2st_engine* e, const int32_t* row_map);
 int s2st_engine_decode_step(s2st_engine* e, int32_t step, const float* prev, const int32_t* pos,
                             const int32_t* self_klen /* [B] or NULL: self-attention keys per utterance */,
                             uint64_t seed, float* feat_out, float* eos_prob, float* attn_out, float* workspace,

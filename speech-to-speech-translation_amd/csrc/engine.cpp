@@ -212,6 +212,8 @@ struct s2st_engine {
   // replay_ != null: decode_step in its graph-replayable form (s2st_engine_decode_step_replay): the step, the prenet's dropout
   // seeds, the input frame, the position row and the output rows are read from / written to the fixed device buffers of *replay_
   const s2st_decode_replay* replay_ = nullptr;
+  // merged decode batches (s2st_engine_decode_row_map): device [B] -- the row of its OWN batch whose Prenet dropout mask row b draws
+  const int* dec_row_map = nullptr;
   bool stop_after_encoder = false;
   Ten* enc_out_keep = nullptr;
   struct Dec {
@@ -724,7 +726,7 @@ struct s2st_engine {
     const bool fm = fast();
     // AR decoding: a handful of rows (one per utterance) -- the skinny kernel converts x in registers, so neither
     // a bf16 copy of the input nor one of the output is made (fp32 in, fp32 out)
-    const bool skinny = fm && !bt.training && use_skinny && M <= 64 && K % 32 == 0 && x->d && x->cols == K &&
+    const bool skinny = fm && !bt.training && use_skinny && M <= S2ST_SKINNY_MAX_ROWS && K % 32 == 0 && x->d && x->cols == K &&
                         (act == 0 || act == 1 || act == 3);
     only_h = only_h && fast() && use_only_h && N % 8 == 0 && !ext_out && !resid && !skinny;
     Ten* y = newT(M, N, ext_out, !only_h);
@@ -739,7 +741,8 @@ struct s2st_engine {
       }
       if (live())
         chk(s2st_gemm_skinny(x->d, K, PH + w, K, y->d, N, b >= 0 ? P + b : nullptr, act, drop_p, sd,
-                             resid ? resid->d : resid_row, resid ? N : 0, M, N, K, st_, nullptr, nullptr, 1e-5f, seed_ptr));
+                             resid ? resid->d : resid_row, resid ? N : 0, M, N, K, st_, nullptr, nullptr, 1e-5f, seed_ptr,
+                             drop_p > 0.f ? dec_row_map : nullptr));
       return y;  // inference only: no tape entry
     }
     if (replay_ && drop_p > 0.f && !err) err = S2ST_ERR_SHAPE;  // (a dropout site off the skinny path: not replayable)
@@ -908,7 +911,7 @@ struct s2st_engine {
   // inference with a handful of rows (AR decoding): y = act(LayerNorm(x) W^T + b) in ONE skinny launch (the
   // normalisation is applied while the rows are converted to bf16); otherwise layernorm() + linear()
   Ten* ln_linear(Ten* x, const LNP& ln, long w, long b, int N, int K, int act = 0, float* ext_out = nullptr) {
-    const bool fused = fast() && !bt.training && use_skinny && use_ln_skinny && x->rows <= 64 && K % 64 == 0 &&
+    const bool fused = fast() && !bt.training && use_skinny && use_ln_skinny && x->rows <= S2ST_SKINNY_MAX_ROWS && K % 64 == 0 &&
                        x->d && x->cols == K && (act == 0 || act == 1 || act == 3);
     if (!fused) return linear(layernorm(x, ln), w, b, N, K, act, 0.f, nullptr, ext_out);
     Ten* y = newT(x->rows, N, ext_out);
@@ -1539,7 +1542,7 @@ struct s2st_engine {
     // batch, taken from the alpha-scaled table decode_begin prepared -- added in the projection's epilogue on the skinny
     // path, by the position kernel otherwise)
     const float* pe_row = dec_st.pe_alpha ? (replay_ ? replay_->pe_cur : dec_st.pe_alpha + (long)(step + 2) * Cd) : nullptr;
-    const bool pe_fused = pe_row && fast() && use_skinny && B <= 64 && c.prenet_dim % 32 == 0;
+    const bool pe_fused = pe_row && fast() && use_skinny && B <= S2ST_SKINNY_MAX_ROWS && c.prenet_dim % 32 == 0;
     if (replay_ && !pe_fused) return S2ST_ERR_SHAPE;  // (the position kernel takes this step's rows: not replayable)
     x = linear(x, prenet.back().w, prenet.back().b, Cd, c.prenet_dim, 0, 0.f, nullptr, nullptr, false, pe_fused ? pe_row : nullptr);
     if (!pe_fused) x = add_pe(x, pos, dec_st.pe_dec, 1.f, pos_alpha, 0.f);
@@ -1569,7 +1572,7 @@ struct s2st_engine {
       }
     }
     // the stop head's logistic rides in its projection's epilogue on the skinny path (act 3)
-    const bool sig_fused = fast() && use_skinny && B <= 64 && Cd % 64 == 0 && (!has_dec_ln || use_ln_skinny);
+    const bool sig_fused = fast() && use_skinny && B <= S2ST_SKINNY_MAX_ROWS && Cd % 64 == 0 && (!has_dec_ln || use_ln_skinny);
     if (replay_ && !sig_fused) return S2ST_ERR_SHAPE;
     Ten* eos;
     if (has_dec_ln) {  // both heads read the normalised state
@@ -2608,6 +2611,7 @@ int s2st_engine_decode_begin(s2st_engine* e, const s2st_batch* b, const s2st_out
                              void* stream) {
   if (!e->P || !e->BUF || !state || !b || !out) return S2ST_ERR_ARG;
   if (state_floats < s2st_engine_decode_state_floats(e, b->B, b->E, max_steps)) return S2ST_ERR_WORKSPACE;
+  e->dec_row_map = nullptr;
   e->reset_call();
   e->bt = *b;
   e->bt.training = 0;
@@ -2643,6 +2647,15 @@ int s2st_engine_decode_begin(s2st_engine* e, const s2st_batch* b, const s2st_out
   }
   e->tape.clear();
   return e->err;
+}
+
+// Several batches decoded as ONE (round 6): the always-on Prenet dropout (tacotron2.py:95-98) keys its mask by the row of the
+// batch, so the rows of the 2nd, 3rd ... batch say which row of their own batch they are.  NULL: rows count from 0.
+// Set after decode_begin (which clears it), holds for the run's steps; the non-skinny paths (more than 256 rows) ignore it.
+int s2st_engine_decode_row_map(s2st_engine* e, const int32_t* row_map) {
+  if (!e) return S2ST_ERR_ARG;
+  e->dec_row_map = row_map;
+  return S2ST_OK;
 }
 
 int s2st_engine_decode_step(s2st_engine* e, int32_t step, const float* prev, const int32_t* pos,

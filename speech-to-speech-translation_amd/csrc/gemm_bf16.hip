@@ -1334,7 +1334,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
                                                           uint64_t seed, const float* __restrict__ resid, long ldr,
                                                           int M, int N, int K, const float* __restrict__ ln_g,
                                                           const float* __restrict__ ln_b, float ln_eps,
-                                                          const uint64_t* __restrict__ seed_ptr) {
+                                                          const uint64_t* __restrict__ seed_ptr,
+                                                          const int* __restrict__ row_map) {
   if (seed_ptr) seed = *seed_ptr;  // (replayable decode step: the step's seeds live in device memory)
   __shared__ __attribute__((aligned(16))) float part[3][MT * 64 * 4];
   __shared__ float ln_mean[16 * MT], ln_rstd[16 * MT];
@@ -1353,6 +1354,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
     M -= mb;
   }
   const int m_glob0 = blockIdx.y * 16 * MT;
+  // row_map (round 6: several batches decoded as ONE merged batch): the dropout mask of row m is the one row row_map[m] of its
+  // OWN batch would draw -- the merged decode returns the hypotheses of one batch after the other, bit for bit
+  const int m_last = m_glob0 + M - 1;
+  auto drow = [&](int m) -> uint64_t { return (uint64_t)(row_map ? row_map[min(m_glob0 + m, m_last)] : m_glob0 + m); };
   if (ln_g) {
     // fused LayerNorm of the activation rows (the decoder's pre-LN in front of a projection): every workgroup
     // recomputes the row statistics (L2-resident input) instead of a separate kernel + round trip.
@@ -1504,7 +1509,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
         if (act == 1) x = fmaxf(x, 0.f);
         else if (act == 2) x = gelu_erf(x);
         else if (act == 3) x = 1.f / (1.f + __expf(-x));
-        if (drop_p > 0.f) x *= drop_scale(seed, (uint64_t)(m_glob0 + m) * (uint64_t)N + n + r, drop_p, inv_keep);
+        if (drop_p > 0.f) x *= drop_scale(seed, drow(m) * (uint64_t)N + n + r, drop_p, inv_keep);
         v[r] = x + rr[r];
       }
       *reinterpret_cast<float4*>(C + (long)m * ldc + n) = float4{v[0], v[1], v[2], v[3]};
@@ -1529,7 +1534,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
       if (act == 1) x = fmaxf(x, 0.f);
       else if (act == 2) x = gelu_erf(x);
       else if (act == 3) x = 1.f / (1.f + __expf(-x));
-      if (drop_p > 0.f) x *= drop_scale(seed, (uint64_t)(m_glob0 + m) * (uint64_t)N + n + r, drop_p, inv_keep);
+      if (drop_p > 0.f) x *= drop_scale(seed, drow(m) * (uint64_t)N + n + r, drop_p, inv_keep);
       if (resid) x += resid[(long)m * ldr + n + r];
       C[(long)m * ldc + n + r] = x;
     }
@@ -1541,9 +1546,9 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
 // while they are converted (K % 64 == 0 then).  resid rows may all be the same one (ldr = 0: a positional row).
 int s2st_gemm_skinny(const float* A, long lda, const bf16raw* W, long ldw, float* C, long ldc, const float* bias, int act,
                      float drop_p, uint64_t seed, const float* resid, long ldr, int M, int N, int K, hipStream_t st,
-                     const float* ln_g, const float* ln_b, float ln_eps, const uint64_t* seed_ptr) {
+                     const float* ln_g, const float* ln_b, float ln_eps, const uint64_t* seed_ptr, const int* row_map) {
   if (M <= 0 || N <= 0) return 0;
-  if (M > 64 || K <= 0 || K % 32 || lda % 4 || ldw % 8 || ((uintptr_t)A % 16) || ((uintptr_t)W % 16)) return S2ST_ERR_SHAPE;
+  if (M > S2ST_SKINNY_MAX_ROWS || K <= 0 || K % 32 || lda % 4 || ldw % 8 || ((uintptr_t)A % 16) || ((uintptr_t)W % 16)) return S2ST_ERR_SHAPE;
   if (ln_g && (!ln_b || K % 64 || ((uintptr_t)ln_g % 16) || ((uintptr_t)ln_b % 16))) return S2ST_ERR_SHAPE;
   // bytes the launch has to move: the bf16 weight rows once, the fp32 activation rows, the result (+ residual)
   const double by = 2.0 * N * K + 4.0 * M * K + 4.0 * M * N * (resid ? 2 : 1);
@@ -1551,6 +1556,6 @@ int s2st_gemm_skinny(const float* A, long lda, const bf16raw* W, long ldw, float
   const dim3 grid((N + 15) / 16, (M + 15) / 16), block(256);  // (16 columns) x (16 rows) per workgroup
   const bf16_t* Wp = reinterpret_cast<const bf16_t*>(W);
   s2st_launch("gemm_skinny_kernel", by, fl, gemm_skinny_kernel<1>, grid, block, 0, st, A, lda, Wp, ldw, C, ldc, bias, act, drop_p,
-              seed, resid, ldr, M, N, K, ln_g, ln_b, ln_eps, seed_ptr);
+              seed, resid, ldr, M, N, K, ln_g, ln_b, ln_eps, seed_ptr, row_map);
   return hipGetLastError() == hipSuccess ? 0 : S2ST_ERR_LAUNCH;
 }

@@ -90,7 +90,10 @@ int s2st_gemm_bf16(GemmArgs g, hipStream_t st, int* tile_out);
 int s2st_gemm_skinny(const float* A, long lda, const bf16raw* W, long ldw, float* C, long ldc, const float* bias, int act,
                      float drop_p, uint64_t seed, const float* resid, long ldr, int M, int N, int K, hipStream_t st,
                      const float* ln_g = nullptr, const float* ln_b = nullptr, float ln_eps = 1e-5f /* optional fused LayerNorm of x */,
-                     const uint64_t* seed_ptr = nullptr /* replayable decode step: the seed is read from device memory */);
+                     const uint64_t* seed_ptr = nullptr /* replayable decode step: the seed is read from device memory */,
+                     const int* row_map = nullptr /* [M]: the row whose dropout mask row m draws (merged decode batches) */);
+// rows a skinny launch takes (row blocks of 16 on grid.y): up to four batches of 64 utterances decoded as one merged batch
+#define S2ST_SKINNY_MAX_ROWS 256
 // gemm_bf16_w4.hip: the 4-wave early-release ring form (2 - 3 workgroups per CU) for the short-K products of a step;
 // g / grp as prepared by s2st_gemm_bf16 / s2st_gemm_bf16_group for the tile (bm, bn)
 int s2st_gemm_bf16_w4(const GemmArgs& g, int bm, int bn, dim3 grid, hipStream_t st);

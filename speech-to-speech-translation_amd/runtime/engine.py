@@ -634,6 +634,13 @@ class Engine:
         o["encoder_lens"] = keep["enc_lens"]
         return o
 
+    def decode_row_map(self, row_map: Optional[torch.Tensor]):
+        """After ``decode_begin`` of a MERGED batch: ``row_map`` [B] int32 (device) = every row's index inside its own batch."""
+        f = self.lib.s2st_engine_decode_row_map
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        self._dec["row_map"] = row_map  # (kept alive for the run)
+        bd.check(f(self.h, bd.ptr(row_map)), "s2st_engine_decode_row_map")
+
     def decode_buffers(self, max_steps: int):
         """Whole-run buffers of an AR decode (round 4: nothing is allocated, filled or uploaded per step): outputs
         ``feat`` [steps, B, out_dim] / ``eos`` [steps, B] / ``attn`` [steps, B, E], the positions of every step, and the stop

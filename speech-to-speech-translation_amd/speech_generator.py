@@ -150,9 +150,19 @@ class AutoRegressiveSpeechGenerator(SpeechGenerator):
         samples = list(samples)
         n = len(samples)
         dev = model.engine.device
-        if n == 1 or dev.type != "cuda" or getattr(model, "hubert", None) is not None:
-            # (no second stream; or a frozen front end whose one workspace the chains would share -- checked BEFORE the
-            # twin engines, each with its own bf16 arena, are built: ADVICE r4)
+        if n == 1 or getattr(model, "hubert", None) is not None:
+            # (a frozen front end whose one workspace the chains would share -- checked BEFORE the twin engines, each with its
+            # own bf16 arena, are built: ADVICE r4)
+            return [self.generate(model, s, has_targ, **kwargs) for s in samples]
+        # round 6, S2ST_DECODE_MERGE=1: the batches as ONE merged batch on one chain (built, bit-equal to sequential decoding,
+        # measured NEUTRAL on the GPU: 759 utterances/s against 768 - 862 for three chains -- a step's cost follows its rows, the
+        # attention launches read every row's caches; profiles/r06_infer_merged_ab.txt -- and the only multi-batch form a CPU
+        # (emulator) run can take).  Default: round 5's chains.
+        if os.environ.get("S2ST_DECODE_MERGE", "0" if dev.type == "cuda" else "1") != "0" and not self.input_text and (
+                not model.engine.cfg.precise or model.engine.cfg.prenet_dropout == 0.0) and all(
+                s.get("speaker") is None for s in samples) and sum(int(s["net_input"]["src_speech"].shape[0]) for s in samples) <= 256:
+            return self._generate_merged(model, samples, has_targ, **kwargs)
+        if dev.type != "cuda":  # (no second stream)
             return [self.generate(model, s, has_targ, **kwargs) for s in samples]
         engs = [model.engine] + model.engine.inference_twins(n - 1)
         from .runtime import streams
@@ -208,12 +218,51 @@ class AutoRegressiveSpeechGenerator(SpeechGenerator):
             self.defer_vocoder = False
         return [r[2] for r in runs]
 
+    def _generate_merged(self, model, samples, has_targ: bool = False, **kwargs):
+        """Round 6: the batches of ``generate_many`` as ONE merged batch on ONE chain (<= 256 utterances: the skinny
+        projections' row limit).  A decoding step costs ~55 launches whether it carries 64 rows or 192, and the launches of
+        several chains mostly wait for each other's CUs (profiles/r05_infer_graph.txt: three chains overlap 1.2 x), so the rows
+        ride together instead.  The hypotheses are those of one batch after the other, bit for bit: every kernel of the decode
+        treats rows independently; the always-on Prenet dropout draws, for a row of batch k, the mask its own batch would
+        have drawn (``Engine.decode_row_map``); a batch's post-net / vocoder see the steps up to ITS last stop; the phase draws
+        follow batch order.  Sources are padded to the longest batch (padded encoder frames are masked keys, as always)."""
+        eng = model.engine
+        dev = eng.device
+        srcs, lens, sizes = [], [], []
+        for s in samples:
+            ni = s["net_input"]
+            src, sl = model._front_end(ni.get("src_speech"), ni.get("src_speech_lens"), ni.get("collated_audios_orig"),
+                                       ni.get("padding_mask"))
+            srcs.append(src.to(dev, torch.float32))
+            lens.append(sl.to(dev))
+            sizes.append(int(src.shape[0]))
+        smax = max(int(x.shape[1]) for x in srcs)
+        srcs = [x if x.shape[1] == smax else torch.nn.functional.pad(x, (0, 0, 0, smax - x.shape[1])) for x in srcs]
+        src_all, lens_all = torch.cat(srcs, 0).contiguous(), torch.cat(lens, 0)
+        eng.decode_begin(src_all, lens_all, self.max_iter)
+        eng.decode_row_map(torch.cat([torch.arange(nb, dtype=torch.int32) for nb in sizes]).to(dev))
+        self.defer_vocoder = bool(kwargs.get("defer_vocoder", False))
+        if self.vocoder is not None and hasattr(self.vocoder, "set_inflight"):
+            self.vocoder.set_inflight(len(samples))
+        fins, groups, r0 = [], [], 0
+        for s, nb in zip(samples, sizes):
+            fin = PendingHypos(dict() for _ in range(nb))
+            fins.append(fin)
+            groups.append((slice(r0, r0 + nb), nb, fin, s if has_targ else None))
+            r0 += nb
+        try:
+            for _ in self._decode_mel_steps(model, None, r0, None, eng, groups=groups):
+                pass
+        finally:
+            self.defer_vocoder = False
+        return fins
+
     def _decode_mel(self, model, sample, bsz: int, finalized: List[Dict]) -> None:
         """The AR loop + post-processing of speech_generator_for_s2st.py:70-122 over the caches ``decode_begin`` filled."""
         for _ in self._decode_mel_steps(model, sample, bsz, finalized, model.engine):
             pass
 
-    def _decode_mel_steps(self, model, sample, bsz: int, finalized: List[Dict], eng):
+    def _decode_mel_steps(self, model, sample, bsz: int, finalized: List[Dict], eng, groups=None):
         """``_decode_mel`` as a generator that yields after every enqueued decoding step: ``generate_two`` alternates two of
         them (two batches on two engines / streams), ``_decode_mel`` just runs one to its end."""
         c = eng.cfg
@@ -223,7 +272,10 @@ class AutoRegressiveSpeechGenerator(SpeechGenerator):
         dev = eng.device
         if self.vocoder is not None and hasattr(self.vocoder, "prefetch_phases"):
             # the vocoder's random initial phases: numpy's generator starts running ahead while the GPU decodes
-            self.vocoder.prefetch_phases(bsz * self.max_iter * n_frames_per_step)
+            # (groups: the batches of a merged decode, each with its own run-ahead stream, in batch order)
+            # (with targets a batch's draws are followed by its targets' before the next batch's: no run-ahead past the first)
+            for nb in ([bsz] if groups is None else [g[1] for g in groups[:1 if groups[0][3] is not None else len(groups)]]):
+                self.vocoder.prefetch_phases(nb * self.max_iter * n_frames_per_step)
         # The loop of speech_generator_for_s2st.py:83-103 without a host round trip per step (round 4): the stop rule --
         # finished flags, out_lens, the next step's key lengths -- is a one-workgroup kernel behind every step
         # (s2st_decode_stop_update_i32), outputs land in whole-run buffers, and the host learns the number of finished
@@ -276,13 +328,33 @@ class AutoRegressiveSpeechGenerator(SpeechGenerator):
             if done.numel():
                 n_steps = int(done[0]) + 1
         yield "post"  # (generate_two holds the second batch here until the first one's post-processing is done)
+        if groups is None:
+            self._post(model, eng, bufs, n_steps, None, bsz, finalized)
+        else:
+            # a merged decode: batch k's own loop would have ended at the step its LAST utterance stopped (the merged loop ran on
+            # for the other batches; those extra rows are the dropped run-ahead of batch k)
+            ol = bufs["out_lens"].cpu()
+            for gi, (rows, nb, fin, targ_sample) in enumerate(groups):
+                if gi > 0 and targ_sample is not None and self.vocoder is not None and hasattr(self.vocoder, "prefetch_phases"):
+                    self.vocoder.prefetch_phases(nb * self.max_iter * n_frames_per_step)
+                self._post(model, eng, bufs, min(n_steps, int(ol[rows].max())), rows, nb, fin)
+                if targ_sample is not None:  # (phase draws in the order of one batch after the other: prediction, then target)
+                    self._add_targets(model, targ_sample, nb, fin)
+
+    def _post(self, model, eng, bufs, n_steps: int, rows, bsz: int, finalized: List[Dict]) -> None:
+        """speech_generator_for_s2st.py:104-122 over the whole-run buffers of a decode: ``rows`` = the batch's rows of the
+        buffers (None: all of them; a slice when several batches were decoded as ONE merged batch, ``_generate_merged``)."""
+        n_frames_per_step = model.args.n_frames_per_step
+        raw_dim = eng.cfg.out_dim // n_frames_per_step
+        dev = eng.device
+        sel = (lambda t, dim: t) if rows is None else (lambda t, dim: t.narrow(dim, rows.start, rows.stop - rows.start))
         # (the reference's out_lens after its loop: steps at which the utterances stopped, max_iter for those still running;
         # an utterance that would have stopped only in a dropped run-ahead step is still running at the real stop)
-        out_lens = bufs["out_lens"].cpu().long()
+        out_lens = sel(bufs["out_lens"], 0).cpu().long()
         out_lens = torch.where(out_lens > n_steps, torch.full_like(out_lens, self.max_iter), out_lens)
-        feat = bufs["feat"][:n_steps].transpose(0, 1).contiguous()          # [B, steps, out_dim]
-        eos_prob = bufs["eos"][:n_steps].transpose(0, 1).contiguous()        # [B, steps]
-        attn = bufs["attn"][:n_steps].permute(1, 2, 0).contiguous()          # [B, E, steps]
+        feat = sel(bufs["feat"][:n_steps], 1).transpose(0, 1).contiguous()          # [B, steps, out_dim]
+        eos_prob = sel(bufs["eos"][:n_steps], 1).transpose(0, 1).contiguous()        # [B, steps]
+        attn = sel(bufs["attn"][:n_steps], 1).permute(1, 2, 0).contiguous()          # [B, E, steps]
         feat = eng.postnet_eval(feat)  # postnet(feat) + feat, BatchNorm in eval mode
         alignment = torch.empty(bsz, attn.shape[2], dtype=torch.long, device=dev)
         bd.call("s2st_argmax_dim1_f32", attn, alignment, bsz, attn.shape[1], attn.shape[2])

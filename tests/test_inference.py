@@ -801,17 +801,34 @@ def test_fft_griffin_lim_edge_geometries(backend, monkeypatch, n_fft, win, hop):
             assert float(np.abs(w.cpu().numpy() - ref).max()) < 2e-4 * float(np.abs(ref).max())
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16_prenet_dropout"])
+@pytest.mark.parametrize("form", ["merged", "chains"])
 @pytest.mark.parametrize("has_targ", [False, True])
-def test_two_batches_decoded_at_once_give_the_sequential_results(backend, has_targ):
+def test_two_batches_decoded_at_once_give_the_sequential_results(backend, has_targ, form, mode, monkeypatch):
     """generate_two(a, b): batch b on a second engine over the same weights and a second stream, the two step loops alternated
     by the host == generate(a) then generate(b): every field of every hypothesis, incl. the waveforms (numpy's phase draws
     are consumed in batch order; batch b's run-ahead stream is a guess that is checked) -- with early stops in batch a (its
     upper bound of draws is then NOT used up: b's guess fails and it draws the ordinary way) and without."""
-    if backend.kind == "emu":
-        pytest.skip("no second stream on the emulator: generate_two is two generate() calls")
+    # round 6, form "merged" (the default): the batches ride as ONE merged batch on one chain -- rows padded to the longest
+    # source, every row's Prenet dropout mask drawn as its own batch would draw it (Engine.decode_row_map), each batch's
+    # post-net / vocoder over the steps up to its own last stop; "chains" (S2ST_DECODE_MERGE=0): round 5's form
+    if backend.kind == "emu" and form == "chains":
+        pytest.skip("no second stream on the emulator: the chained form runs on the GPU, the merged form here")
+    monkeypatch.setenv("S2ST_DECODE_MERGE", "1" if form == "merged" else "0")
     gen_mod = importlib.import_module(PKG + ".speech_generator")
     V = importlib.import_module(PKG + ".vocoder")
-    a, model = _build_model(backend, AR_CFG)
+    if mode == "bf16x3":
+        a, model = _build_model(backend, AR_CFG)
+    else:
+        # the benchmarked mode with the recipe's always-on Prenet dropout (tacotron2.py:95-98): the mask of a row is keyed by
+        # its row IN ITS OWN BATCH -- sequential, chained and merged decoding must draw the same masks
+        if has_targ:
+            pytest.skip("targets are covered in bf16x3 mode")
+        tasks = importlib.import_module(PKG + ".tasks")
+        a = O.make_args(**dict(CONFIGS["tiny"], prenet_dropout=0.5))
+        task = tasks.S2ST_TranslationTask.setup_task(a, device=backend.device)
+        model = task.build_model(a)
+        load_synth(model, 0)
     voc = V.GriffinLimVocoder(spec_bwd_max_iter=2, device=backend.device, sample_rate=16000, win_size=200, hop_size=64, n_fft=256,
                               n_mels=80, f_min=20, f_max=8000)
     batches = []
