@@ -511,3 +511,22 @@ def test_dropout_mask_independence(backend):
                 q = (p if va == 0 else 1 - p) * (p if vb == 0 else 1 - p) * (p if vc == 0 else 1 - p)
                 got = float(((a == va) & (b == vb) & (c == vc)).double().mean())
                 assert abs(got - q) < 4.5 * (q * (1 - q) / n) ** 0.5, (va, vb, vc, got, q)
+
+
+def test_exchange_proxy_moves_bytes_and_changes_nothing(backend):
+    """s2st_exchange_proxy_f32 (bench.py --exchange-proxy: the one-GPU stand-in for the gradient all-reduce's kernels): it
+    copies the requested share of the bucket into the scratch range -- cyclically when the share exceeds the bucket -- and
+    leaves the bucket (the gradients) untouched; workgroup count and pace only change how long it takes."""
+    d = backend.device
+    n = 40000
+    g = torch.Generator().manual_seed(3)
+    bucket = torch.randn(n, generator=g).to(d)
+    ref = bucket.clone()
+    for move_bytes, wgs, gbps in ((n * 4, 4, 1000.0), (int(1.75 * n * 4), 16, 50.0), (4096 * 16, 2, 300.0)):
+        scratch = torch.zeros(n, device=d)
+        backend.bd.call("s2st_exchange_proxy_f32", bucket, scratch, n, move_bytes, wgs, gbps)
+        backend.sync()
+        assert torch.equal(bucket, ref)
+        moved = min(move_bytes // 16 * 4, n)  # floats of the bucket the share reaches (cyclic beyond the bucket's end)
+        assert torch.equal(scratch[:moved], ref[:moved])
+        assert float(scratch[moved:].abs().max()) == 0.0 if moved < n else True
