@@ -153,6 +153,18 @@ def test_micro_recipe_dropouts_against_oracle_fast(backend, cfg):
                               stat_tol=4e-2)
 
 
+def test_micro_text_input_variant_recipe_dropouts_against_oracle(backend):
+    """t2s_transformer (text encoder: conv -> BatchNorm -> ReLU -> dropout prenet, t2s_transformer.py:55-66, 86-100; post-LN
+    encoder layers): the BatchNorm + ReLU + dropout sites of the encoder prenet (``enc.prenet/norm<i>``), the dropout behind
+    the alpha-scaled positions and every layer site, bf16x3 mode -- the same mask-injection comparison."""
+    cfg = dict(MICRO, asr_ce_weight=0.0, st_ce_weight=0.0, ctc_weight=0.0, text_encoder=True, encoder_conv_layers=2,
+               encoder_conv_kernel_size=5, encoder_dropout=0.3, encoder_normalize_before=False, **STRONG)
+    a, e = make_engine(backend, cfg, precise=True)
+    _, m = make_oracle(cfg)
+    o, log = check_with_injected_masks(backend, e, m, micro_batch(), out_tol=3e-4, loss_tol=3e-5, grad_tol=1e-2, whole_tol=2e-3)
+    assert any(k.startswith("enc.prenet/norm") for k in e.dropout_sites())
+
+
 def test_masks_are_what_the_comparison_rests_on(backend):
     """Control: the SAME comparison with the masks of a different seed must fail loudly (losses move by >> the tolerance):
     the test above is not passing because dropout is too weak to matter."""
