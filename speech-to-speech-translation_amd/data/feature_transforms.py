@@ -79,6 +79,30 @@ class TGTGlobalCMVN(_GlobalCMVN):
     pass
 
 
+def resize_rows_linear(src: np.ndarray, new_rows: int) -> np.ndarray:
+    """``cv2.resize(src, dsize=(src.shape[1], new_rows), interpolation=cv2.INTER_LINEAR)`` for a 2-D float array whose
+    width stays (what the time warp of specaugment.py:100-109 asks OpenCV for).  OpenCV's bilinear resize, restated: output
+    row y samples the source at fy = (y + 0.5) * (rows / new_rows) - 0.5 (pixel centres aligned, the scale in double, fy in
+    float), sy = floor(fy), weights (1 - (fy - sy), fy - sy) in float32 on rows sy and sy + 1, each index clamped into the
+    image; the horizontal pass has scale 1 and weights (1, 0), i.e. it is the identity; equal sizes are a plain copy.
+    OpenCV is not part of this image: checked against a float64 restatement and the operator's invariants
+    (``tests/test_data_audio.py``), not against cv2 itself."""
+    rows = src.shape[0]
+    if new_rows == rows:
+        return src.copy()
+    scale = 1.0 / (new_rows / float(rows))
+    fy = ((np.arange(new_rows, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+    sy = np.floor(fy).astype(np.int64)
+    fy = (fy - sy.astype(np.float32)).astype(np.float32)
+    i0 = np.clip(sy, 0, rows - 1)
+    i1 = np.clip(sy + 1, 0, rows - 1)
+    if src.dtype == np.float64:
+        b0, b1 = (1.0 - fy.astype(np.float64))[:, None], fy.astype(np.float64)[:, None]
+    else:
+        b0, b1 = (np.float32(1.0) - fy)[:, None], fy[:, None]
+    return (src[i0] * b0 + src[i1] * b1).astype(src.dtype)
+
+
 @register_audio_feature_transform("specaugment")
 class SpecAugmentTransform:
     @classmethod
@@ -94,8 +118,7 @@ class SpecAugmentTransform:
             assert freq_mask_f > 0
         if time_mask_n > 0:
             assert time_mask_t > 0
-        if time_warp_w > 0:
-            raise NotImplementedError("time warping needs OpenCV (cv2.resize) in the reference; not available here")
+        self.time_warp_w = time_warp_w
         self.freq_mask_n, self.freq_mask_f = freq_mask_n, freq_mask_f
         self.time_mask_n, self.time_mask_t, self.time_mask_p = time_mask_n, time_mask_t, time_mask_p
         self.mask_value = mask_value
@@ -109,6 +132,13 @@ class SpecAugmentTransform:
             mask_value = spectrogram.mean()
         if num_frames == 0 or num_freqs < self.freq_mask_f:
             return spectrogram
+        if self.time_warp_w > 0 and 2 * self.time_warp_w < num_frames:
+            # specaugment.py:95-110: a random frame w0 moves by w; the parts before / after it are stretched to fit
+            # (two draws, in this order, before the masks' draws)
+            w0 = np.random.randint(self.time_warp_w, num_frames - self.time_warp_w)
+            w = np.random.randint(-self.time_warp_w + 1, self.time_warp_w)
+            distorted = np.concatenate((resize_rows_linear(distorted[:w0, :], w0 + w),
+                                        resize_rows_linear(distorted[w0:, :], num_frames - w0 - w)), axis=0)
         for _ in range(self.freq_mask_n):  # two draws per mask, in this order (specaugment.py:110-114)
             f = np.random.randint(0, self.freq_mask_f)
             f0 = np.random.randint(0, num_freqs - f)
