@@ -3,6 +3,9 @@
 ``batch_by_size``: behavioural restatement of ``batch_by_size_vec`` (fairseq/data/data_utils_fast.pyx:20-100).
 Pinned against the reference's own Cython extension built into oracle/_ref by oracle/build_ref.sh (when the
 reference is present) and against tests/golden/batcher.npz generated from that build (oracle/gen_golden_data.py).
+
+``kaldi_fbank_f64`` / ``resize_rows_linear_f64`` (end of the file): PARITY UNPINNED -- they restate torchaudio's Kaldi
+filter bank and OpenCV's bilinear resize, neither of which is installed here or vendored by the reference.
 """
 from typing import List
 
