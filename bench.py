@@ -440,7 +440,9 @@ def infer_main(args):
                            "utterances": len(ids), "max_abs_feature_diff": round(ferr, 5),
                            "note": "MFCC distance along the DTW path between the GPU path's waveform (bf16 operands) and the "
                                    "CPU oracle's (fp32) for the same weights, inputs, Prenet dropout 0 and initial phases; "
-                                   "0 = identical"}
+                                   "0 = identical.  Both sides use this repository's restatements of two third-party tables "
+                                   "that are absent from the image (librosa's Slaney mel filters, torchaudio's MFCC): the "
+                                   "figure compares the two paths with each other, its absolute scale is unpinned"}
             except subprocess.TimeoutExpired:
                 vlog("cpu leg timed out")
 
