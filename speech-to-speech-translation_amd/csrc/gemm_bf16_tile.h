@@ -533,6 +533,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// (the nt cache policy on these loads was measured: +0.45 ... +1.3 ms per step, profiles/r06_dma_nontemporal_ab.txt -- every panel
+//  is re-read by the tiles beside it)
 template <bool KM, int ROWS, int NW>
 struct Dma {
   static constexpr int NI = ROWS / (8 * NW);  // wave-instructions per wave per stage (1 KiB each)

@@ -56,8 +56,13 @@ __device__ __forceinline__ float adam_one(float& g, float& m, float& v, float p,
   if (wd_lr != 0.f) p -= wd_lr * p;
   return p - step_size * m / (sqrtf(v) + eps);
 }
-// One element per thread and iteration, 1024 blocks: ~5.2 TB/s over the 32 (+2) bytes per parameter -- the kernel is
-// HBM-bound; a float4 form and other grid sizes measured the same or slower (tools/adam_bench.py).
+// One element per thread and iteration, 1024 blocks: ~5.9 TB/s over the 32 (+2) bytes per parameter -- the kernel is
+// HBM-bound; a float4 form, two / four elements in flight per thread and other grid sizes measured the same or slower
+// (tools/adam_bench.py).  The four fp32 streams (every byte touched exactly once per update, 1.2 GB each way) are read and
+// written with the NONTEMPORAL cache policy: the kernel alone gains 2 - 8 % and the step 0.03 - 0.06 ms on two boxes
+// (profiles/r06_adam_nontemporal_ab.txt); the bf16 parameter copy, which the next forward reads, keeps the default policy.
+// (The same policy on the GEMMs' operand loads, the weight transpose, the norm pass and the weight-gradient epilogues
+// measured neutral to strongly negative: profiles/r06_dma_nontemporal_ab.txt, r06_nontemporal_other_streams_ab.txt.)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                           float* __restrict__ m, float* __restrict__ v,
                                                           long n, const float* __restrict__ sumsq,
@@ -79,9 +84,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
   if (max_norm > 0.f) coef *= fminf(1.f, max_norm / (gn + 1e-6f));
   const float wd_lr = wd * lr;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    float gi = g[i], mi = m[i], vi = v[i];
-    const float pi = adam_one(gi, mi, vi, p[i], coef, b1, b2, eps, wd_lr, step_size);
-    g[i] = zero_grad ? 0.f : gi; m[i] = mi; v[i] = vi; p[i] = pi;
+    float gi = __builtin_nontemporal_load(g + i), mi = __builtin_nontemporal_load(m + i), vi = __builtin_nontemporal_load(v + i);
+    const float pi = adam_one(gi, mi, vi, __builtin_nontemporal_load(p + i), coef, b1, b2, eps, wd_lr, step_size);
+    __builtin_nontemporal_store(zero_grad ? 0.f : gi, g + i);
+    __builtin_nontemporal_store(mi, m + i);
+    __builtin_nontemporal_store(vi, v + i);
+    __builtin_nontemporal_store(pi, p + i);
     if (ph) ph[i] = (uint16_t)(pack_bf16x4(pi, 0.f, 0.f, 0.f).x & 0xffffu);
   }
 }
