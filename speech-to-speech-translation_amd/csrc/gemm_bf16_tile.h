@@ -269,12 +269,6 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, f32x4 (&ac
         const int n = n0 + wn * WN + j * 16 + ((lane >> 4) & 2) * 4;  // first of the 8 columns
         const bool ok = (odd ? mok[i + 1] : mok[i]) && n < N;
         const long ro = odd ? roff[i + 1] : roff[i];
-#ifdef S2ST_GEMM_NT_OUT  // (experiment: a bf16 result larger than half the memory-side cache is stored nontemporally)
-        if (ok && (long)M * N * 2 > ((long)S2ST_GEMM_NT_OUT << 20)) {
-          typedef unsigned __attribute__((ext_vector_type(4))) u4;
-          __builtin_nontemporal_store(u4{ax, ay, bx, by}, reinterpret_cast<u4*>(hbase + ro + n));
-        } else
-#endif
         if (ok) *reinterpret_cast<uint4*>(hbase + ro + n) = make_uint4(ax, ay, bx, by);
       }
     }

@@ -35,7 +35,7 @@ constexpr int C0_TT = 128, CONV0_MAXK = 16, CONV0_CPT = 2;  // frames per block,
 // KT: the number of taps the loops run over (k <= KT; with KT = CONV0_MAXK taps >= k carry zero weights and read clamped
 // addresses): 10 for HuBERT / wav2vec 2.0's first block (k == 10 exactly), CONV0_MAXK otherwise -- compile-time so that a
 // frame's sample loads are issued together, without a branch per tap
-template <int MODE, int KT, bool NTS = false>
+template <int MODE, int KT>
 __global__ __launch_bounds__(256) void hubert_conv0_gn_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ mean_, const float* __restrict__ var_,
                                                               float* __restrict__ part, float* __restrict__ shift,
@@ -96,10 +96,9 @@ __global__ __launch_bounds__(256) void hubert_conv0_gn_kernel(const float* __res
         const float o0 = gelu_erf((a[0] - mu[0]) * sc[0] + sh[0]), o1 = gelu_erf((a[1] - mu[1]) * sc[1] + sh[1]);
         const long o = ((long)b * T + t0 + t) * C + c0;
         if (y) *reinterpret_cast<float2*>(y + o) = make_float2(o0, o1);
-        if (yh) {
-          if (NTS) __builtin_nontemporal_store(pack_bf16x4(o0, o1, 0.f, 0.f).x, reinterpret_cast<unsigned*>(yh + o));
-          else *reinterpret_cast<unsigned*>(yh + o) = pack_bf16x4(o0, o1, 0.f, 0.f).x;
-        }
+        // (nontemporal: 629 MB per 24 x 8 s of audio, read once by the next convolution -- more than the memory-side cache holds;
+        //  300 -> 290 us and the next product 726 -> 714, config 3 -0.08 ms per step, profiles/r06_hubert_nontemporal_ab.txt)
+        if (yh) __builtin_nontemporal_store(pack_bf16x4(o0, o1, 0.f, 0.f).x, reinterpret_cast<unsigned*>(yh + o));
       }
     }
     if (MODE == 0) {  // this block's share of the time sums: plain stores, folded in block order by conv0_fold_kernel
@@ -184,11 +183,7 @@ int s2st_hubert_conv0_gn_gelu(const float* x, const float* w, const float* gamma
     S2ST_LAUNCH((hubert_conv0_gn_kernel<0, CONV0_MAXK>), grid, dim3(256), 0, st, x, w, cm, cv, part, shift, gamma, beta, y, yh, B, N, T,
                 C, k, stride, eps);
   S2ST_LAUNCH(conv0_fold_kernel, fgrid, dim3(256), 0, st, (const float*)part, (const float*)shift, mean, var, B, nblk, C, T);
-  static const int nts = s2st_env_int("S2ST_HUBERT_C0_NT", 0);  // (experiment)
-  if (k == 10 && nts)
-    S2ST_LAUNCH((hubert_conv0_gn_kernel<2, 10, true>), grid, dim3(256), 0, st, x, w, cm, cv, part, shift, gamma, beta, y, yh, B, N, T, C, k,
-                stride, eps);
-  else if (k == 10)
+  if (k == 10)
     S2ST_LAUNCH((hubert_conv0_gn_kernel<2, 10>), grid, dim3(256), 0, st, x, w, cm, cv, part, shift, gamma, beta, y, yh, B, N, T, C, k,
                 stride, eps);
   else

@@ -1,7 +1,7 @@
 # HuBERT front end (config 3): nontemporal stores of the conv stack's big once-read outputs
 #   C0 = the first convolution's apply pass (629 MB of bf16 per 24 x 8 s; switch S2ST_HUBERT_C0_NT of the experiment)
 #   G  = GEMM epilogues store a bf16 result > 128 MB nontemporally (variant library, tools/experiments/build_gemm_nt_out_variant.sh)
-C=speech-to-speech-translation_amd/csrc
+C=speech-to-speech-translation_amd/csrc   # (C0 was a switch, G a variant library of the experiment: C0 became the default, G was removed -- profiles/r06_hubert_nontemporal_ab.txt)
 B="python bench.py --config base_recipe_hubert --steps 20 --warmup 5 --cpu-seconds 0 --no-roofline --no-host-fed --no-other-configs"
 line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('ms_per_step', d['ms_per_step'])"; }
 echo "==== front end alone, every dispatch (tools/hubert_timeline.py): default"
