@@ -631,7 +631,7 @@ struct PairInfo {
   }
 };
 
-template <int N, bool XNT = false>
+template <int N>
 __global__ __launch_bounds__(256) void gl_stft_project_kernel(const float* __restrict__ wave, const int* __restrict__ tl,
                                                               const float* __restrict__ win, const cplx* __restrict__ twg,
                                                               const float* __restrict__ mag, cplx* __restrict__ X, int U,
@@ -707,10 +707,6 @@ __global__ __launch_bounds__(256) void gl_stft_project_kernel(const float* __res
             o = cplx{mg[i][h], 0.f};
           }
         }
-        if (XNT) {
-          typedef float __attribute__((ext_vector_type(2))) v2f;
-          __builtin_nontemporal_store(v2f{o.x, o.y}, reinterpret_cast<v2f*>(X + m * F + k));
-        } else
         X[m * F + k] = o;
       }
     }
@@ -1284,11 +1280,7 @@ int gl_fft_launch(int inverse, const float* wave_or_frames, const int* tl, const
   if (npairs <= 0) return 0;
   // (4 k workgroups at most: a workgroup keeps its twiddle table over the pairs it walks)
   const unsigned grid = (unsigned)(npairs < 4096 ? npairs : 4096);
-  static const int xnt = s2st_env_int("S2ST_GL_X_NT", 0);  // (experiment)
-  if (!inverse && xnt)
-    S2ST_LAUNCH((gl_stft_project_kernel<N, true>), dim3(grid), dim3(256), 0, st, wave_or_frames, tl, win, reinterpret_cast<const cplx*>(tw),
-                mag, reinterpret_cast<cplx*>(X), U, Tmax, hop, Lw, npairs);
-  else if (!inverse)
+  if (!inverse)
     S2ST_LAUNCH(gl_stft_project_kernel<N>, dim3(grid), dim3(256), 0, st, wave_or_frames, tl, win, reinterpret_cast<const cplx*>(tw),
                 mag, reinterpret_cast<cplx*>(X), U, Tmax, hop, Lw, npairs);
   else

@@ -1,4 +1,5 @@
 # Griffin-Lim (64 iterations, 64 utterances batched): the projected spectra (236 MB per iteration, written by gl_stft_project_kernel,
+# (S2ST_GL_X_NT was a switch of the experiment; removed after it: profiles/r06_nontemporal_other_streams_ab.txt)
 # read once by gl_istft_ola_kernel) stored nontemporally (switch S2ST_GL_X_NT of the experiment), alternating
 for rep in 1 2 3; do
   for x in 0 1; do echo "== x_nt $x: $(S2ST_GL_X_NT=$x python tools/infer_bench.py 64 60 2>/dev/null | grep 'batched over')"; done
