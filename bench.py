@@ -481,7 +481,11 @@ def infer_main(args):
     print(json.dumps(line))
 
 
-ADAM_OVERLAP = os.environ.get("S2ST_ADAM_OVERLAP", "0") == "1"
+# The optimizer update runs in chunks on the engine's second stream and the next forward waits chunk by chunk (the same
+# parameter trajectory, bit for bit: tests/test_full_size.py::test_overlapped_optimizer_update_gives_the_same_trajectory).
+# Round 3 measured it neutral; with the nontemporal optimizer kernel of round 6 it is worth 0.02 - 0.11 ms per step on two
+# boxes (profiles/r06_adam_overlap_ab.txt) and is the default of bench.py and train.py; S2ST_ADAM_OVERLAP=0 switches it off.
+ADAM_OVERLAP = os.environ.get("S2ST_ADAM_OVERLAP", "1") != "0"
 
 
 def spawn_ranks(args) -> None:
@@ -633,8 +637,8 @@ def main():
         vlog('largest waveform batch', tuple(wb))
 
     def step(i):
-        # (S2ST_ADAM_OVERLAP=1: the update overlapped with the next forward -- measured 7.40 vs 7.43 ms/step, within
-        # noise: the HBM-bound update slows the forward's first layers by what it saves, so it stays off)
+        # (the update overlaps the next step's forward, see ADAM_OVERLAP above; the last timed step's update is inside the
+        #  timed region: the closing synchronize waits for every stream)
         if hub and i + 1 < len(prepared):
             # frozen HuBERT of the NEXT batch beside this step (it does not depend on the update): every timed step launches
             # exactly one front-end forward, as before -- for the batch after it instead of its own

@@ -140,7 +140,7 @@ class Trainer:
         if overlap_optimizer:
             eng.adam_overlapped(self.exp_avg, self.exp_avg_sq, self.sumsq_parts, nparts, gmul, gmul_dev, float(self.clip_norm),
                                 lr, self.betas[0], self.betas[1], self.eps, self.wd, self.num_updates + 1, self.gnorm,
-                                self.skipped, self._ph() is not None, int(os.environ.get("S2ST_ADAM_CHUNKS", "8")))
+                                self.skipped, self._ph() is not None, int(os.environ.get("S2ST_ADAM_CHUNKS", "16")))
         else:
             bd.call("s2st_adam_f32", eng.params, eng.grads, self.exp_avg, self.exp_avg_sq, eng.n_params,
                     self.sumsq_parts, gmul, gmul_dev, float(self.clip_norm), lr, self.betas[0], self.betas[1],
@@ -185,4 +185,7 @@ class Trainer:
                 b += n
 
     def valid_step(self, sample):
+        # (validation reads the parameters through more than the training engine's own forward -- inference twins of the
+        #  --eval-inference decode, torch-side copies: an overlapped update still in flight is waited for first)
+        self.engine.wait_optimizer()
         return self.task.valid_step(sample, self.model, self.criterion)
