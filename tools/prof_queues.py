@@ -5,14 +5,16 @@ import sqlite3, sys
 from collections import defaultdict
 db = sqlite3.connect(sys.argv[1])
 rows = list(db.execute("select name, start, end, queue_id from kernels order by start"))
-ad = [i for i, r in enumerate(rows) if 'adam_kernel' in r[0]]
+# (steps are delimited by the gradient-norm pass, one launch per update on the data-path stream: since round 6 the Adam kernel
+#  runs in chunks on the second stream beside the NEXT step's forward -- those chunks belong to the window they run in)
+ad = [i for i, r in enumerate(rows) if 'sumsq_kernel' in r[0]]
 a, b = ad[-3], ad[-2]
 seg = rows[a + 1:b + 1]
 print("step wall ms %.3f  kernels %d" % ((seg[-1][2] - seg[0][1]) / 1e6, len(seg)))
 byq = defaultdict(list)
 for r in seg:
     byq[r[3]].append(r)
-main = rows[ad[-2]][3]  # the queue the optimizer runs on is the data-path stream
+main = rows[ad[-2]][3]  # the queue the norm pass runs on is the data-path stream
 for q, rs in byq.items():
     busy = sum(r[2] - r[1] for r in rs)
     gaps = [rs[i + 1][1] - rs[i][2] for i in range(len(rs) - 1)]
@@ -27,7 +29,7 @@ for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
     print("%-72s %5d %8.3f ms %7.1f us" % (k, n, t / 1e6, t / n / 1e3))
 # tail: who finishes last before the optimizer, and a coarse occupancy timeline of both queues
 t0 = seg[0][1]
-opt = [r for r in seg if 'sumsq_kernel' in r[0] or 'adam_kernel' in r[0]]
+opt = [r for r in seg if 'sumsq_kernel' in r[0]]
 t_opt = opt[0][1] if opt else seg[-1][1]
 for q, rs in byq.items():
     pre = [r for r in rs if r[2] <= t_opt]

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-kernel summary (calls, total, average, share) of a rocprofv3 --kernel-trace run_results.db.
 usage: prof_summary.py <db> <steps> [last N]   -- with "last N": only the kernels of the last N optimizer steps of the
-trace (steps are delimited by adam_kernel): bench.py replays its timed steps at the end with per-dispatch events, so
+trace (steps are delimited by sumsq_kernel, the one launch per update on the data-path stream -- the Adam kernel runs in
+chunks beside the next forward since round 6): bench.py replays its timed steps at the end with per-dispatch events, so
 "last <steps>" is exactly the set of launches behind the bench line's roofline figures."""
 import sqlite3, sys
 from collections import defaultdict
@@ -10,7 +11,7 @@ steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 last = int(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[3] == "last" else 0
 rows = list(db.execute("select name, start, end from kernels order by start"))
 if last:
-    ad = [i for i, r in enumerate(rows) if "adam_kernel" in r[0]]
+    ad = [i for i, r in enumerate(rows) if "sumsq_kernel" in r[0]]
     lo = ad[-last - 1] + 1 if len(ad) > last else 0
     rows = rows[lo:ad[-1] + 1]
     steps = float(last)
