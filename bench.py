@@ -1057,6 +1057,10 @@ def main():
                        "parallelism": f"dp{world}", "gemm": "bf16 MFMA operands (bf16 copies of fp32 tensors), fp32 accumulate, fp32 master weights / residual stream / softmax / losses",
                        "final_loss": round(last_loss, 4),
                        "model_tflops": round(total_flops / dt / 1e12, 2),
+                       "optimizer_update": ("scale + clip + Adam of every timed step inside the timed region; step k's update runs in "
+                                            "16 chunks on the engine's second stream beside step k + 1's forward, which waits chunk by "
+                                            "chunk (same trajectory bit for bit; S2ST_ADAM_OVERLAP=0: in line)" if ADAM_OVERLAP else
+                                            "scale + clip + Adam of every timed step inside the timed region, in line"),
                        **({"host_fed_ms_per_step": round(host_fed, 3),
                            "host_fed_note": "the same steps fed from host batches through DevicePrefetcher (feature upload + "
                                             "Engine.prepare per batch inside the timed region, steady state); never `value`"}
